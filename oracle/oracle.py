@@ -1,0 +1,126 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes wrapper of oracle/libsmj_oracle.so (fp64 CPU restatement).
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only.
+PARITY UNPINNED: see smj_oracle.h.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build() -> str:
+    path = os.path.join(_HERE, "libsmj_oracle.so")
+    src = os.path.join(_HERE, "smj_oracle.c")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return path
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = ctypes.CDLL(build())
+        L.smjo_load.restype = ctypes.c_void_p
+        L.smjo_load.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+        L.smjo_make_data.restype = ctypes.c_void_p
+        L.smjo_make_data.argtypes = [ctypes.c_void_p]
+        for f in ("smjo_reset", "smjo_forward", "smjo_step"):
+            getattr(L, f).argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+            getattr(L, f).restype = None
+        L.smjo_step_n.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.smjo_step_n.restype = None
+        L.smjo_sensors.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.smjo_sensors.restype = None
+        L.smjo_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double]
+        L.smjo_get.restype = ctypes.POINTER(ctypes.c_double)
+        L.smjo_get.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+        L.smjo_get_int.restype = ctypes.POINTER(ctypes.c_int)
+        L.smjo_get_int.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+        L.smjo_dim.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+        _LIB = L
+    return _LIB
+
+
+_SIZES = {"qpos": "nq", "ctrl": "nu", "xpos": ("nbody", 3), "xquat": ("nbody", 4), "xmat": ("nbody", 9),
+          "xipos": ("nbody", 3), "ximat": ("nbody", 9), "xanchor": ("njnt", 3), "xaxis": ("njnt", 3),
+          "geom_xpos": ("ngeom", 3), "geom_xmat": ("ngeom", 9), "site_xpos": ("nsite", 3), "site_xmat": ("nsite", 9),
+          "cam_xpos": ("ncam", 3), "cam_xmat": ("ncam", 9),
+          "subtree_com": ("nbody", 3), "cinert": ("nbody", 10), "crb": ("nbody", 10), "cvel": ("nbody", 6),
+          "cacc": ("nbody", 6), "ten_length": 1, "actuator_length": "nu", "actuator_velocity": "nu",
+          "actuator_force": "nu", "actuator_moment": ("nu", "nv"), "lidar": "nlidar"}
+
+CONTACT_FIELDS = 29  # doubles per contact_t (27 doubles + 4 ints)
+
+
+class Oracle:
+    """One environment, fp64.  Arrays are numpy views into the C data (no copies)."""
+
+    def __init__(self, blob: bytes):
+        self.L = lib()
+        self._blob = blob
+        self.m = self.L.smjo_load(blob, len(blob))
+        if not self.m:
+            raise ValueError("bad model blob")
+        self.d = self.L.smjo_make_data(self.m)
+
+    def dim(self, name: str) -> int:
+        return self.L.smjo_dim(self.m, name.encode())
+
+    def set_option(self, name: str, value: float):
+        if self.L.smjo_set_option(self.m, name.encode(), float(value)) != 0:
+            raise KeyError(name)
+
+    def arr(self, name: str) -> np.ndarray:
+        n = ctypes.c_int(0)
+        p = self.L.smjo_get(self.d, name.encode(), ctypes.byref(n))
+        if not p:
+            raise KeyError(name)
+        cnt = n.value
+        shape = None
+        if cnt < 0:
+            s = _SIZES[name]
+            if isinstance(s, tuple):
+                shape = tuple(self.dim(x) if isinstance(x, str) else x for x in s)
+                cnt = int(np.prod(shape))
+            else:
+                cnt = self.dim(s) if isinstance(s, str) else s
+        a = np.ctypeslib.as_array(p, shape=(cnt,))
+        return a.reshape(shape) if shape else a
+
+    def iarr(self, name: str) -> np.ndarray:
+        n = ctypes.c_int(0)
+        p = self.L.smjo_get_int(self.d, name.encode(), ctypes.byref(n))
+        if not p:
+            raise KeyError(name)
+        return np.ctypeslib.as_array(p, shape=(n.value,))
+
+    @property
+    def time(self) -> float:
+        return float(self.arr("time")[0])
+
+    @property
+    def nefc(self) -> int:
+        return int(self.iarr("nefc")[0])
+
+    @property
+    def ncon(self) -> int:
+        return int(self.iarr("ncon")[0])
+
+    def reset(self):
+        self.L.smjo_reset(self.m, self.d)
+
+    def forward(self):
+        self.L.smjo_forward(self.m, self.d)
+
+    def step(self, n: int = 1):
+        self.L.smjo_step_n(self.m, self.d, n)
+
+    def sensors(self, with_lidar: bool = True):
+        self.L.smjo_sensors(self.m, self.d, int(with_lidar))

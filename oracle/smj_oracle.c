@@ -1,0 +1,1349 @@
+/* TEST INFRASTRUCTURE ONLY -- see smj_oracle.h.  PARITY UNPINNED (no MuJoCo in this image).
+ *
+ * fp64, single environment, body-for-body, stage-by-stage restatement of what
+ * `mj_step` (reference call site stretch_mujoco/mujoco_server.py:378) computes for the
+ * Stretch model (stretch_mujoco/models/stretch.xml) under its options
+ * (stretch.xml:7: integrator=implicitfast, cone=elliptic, impratio=20) with the PGS solver
+ * named by BASELINE.json north_star.  Stage names are MuJoCo's.
+ */
+#include "smj_oracle.h"
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MINVAL 1e-15
+#define MINIMP 0.0001
+#define MAXIMP 0.9999
+#define MAXCON 256
+#define MAXEFC 1024
+enum { JNT_FREE = 0, JNT_BALL = 1, JNT_SLIDE = 2, JNT_HINGE = 3 };
+enum { G_PLANE = 0, G_HFIELD, G_SPHERE, G_CAPSULE, G_ELLIPSOID, G_CYLINDER, G_BOX, G_MESH };
+enum { C_EQUALITY = 0, C_FRICTION_DOF = 1, C_LIMIT_JOINT = 3, C_CONTACT_FRICTIONLESS = 5, C_CONTACT_ELLIPTIC = 7 };
+
+/* ------------------------------------------------------------------ blob */
+typedef struct {
+  char name[48];
+  uint32_t dtype, ndim, shape[4];
+  uint64_t offset, nbytes;
+} blob_entry;
+
+static const blob_entry* blob_find(const uint8_t* b, const char* name) {
+  uint32_t n;
+  memcpy(&n, b + 8, 4);
+  const blob_entry* e = (const blob_entry*)(b + 16);
+  for (uint32_t i = 0; i < n; i++)
+    if (strncmp(e[i].name, name, 48) == 0) return &e[i];
+  return NULL;
+}
+static double* blob_f64(const uint8_t* b, const char* name, int* count) {
+  const blob_entry* e = blob_find(b, name);
+  if (!e || e->dtype != 0) { fprintf(stderr, "smj_oracle: missing f64 array %s\n", name); abort(); }
+  double* p = (double*)malloc(e->nbytes ? e->nbytes : 8);
+  memcpy(p, b + e->offset, e->nbytes);
+  if (count) *count = (int)(e->nbytes / 8);
+  return p;
+}
+static int* blob_i32(const uint8_t* b, const char* name, int* count) {
+  const blob_entry* e = blob_find(b, name);
+  if (!e || e->dtype != 1) { fprintf(stderr, "smj_oracle: missing i32 array %s\n", name); abort(); }
+  int* p = (int*)malloc(e->nbytes ? e->nbytes : 4);
+  memcpy(p, b + e->offset, e->nbytes);
+  if (count) *count = (int)(e->nbytes / 4);
+  return p;
+}
+
+/* ------------------------------------------------------------------ model / data */
+struct smjo_model {
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, ncam, neq, ntendon, nwrap, nkey, npair, nhullvert, nlidar;
+  double timestep, gravity[3], impratio, tolerance, meaninertia, lidar_cutoff;
+  int iterations, cone, warmstart, pgs_fixed_iter, max_con_pair;
+  int *body_parentid, *body_weldid, *body_rootid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum;
+  double *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_gravcomp, *body_invweight0,
+      *body_subtreemass;
+  int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;
+  double *jnt_pos, *jnt_axis, *jnt_stiffness, *jnt_range, *jnt_margin, *jnt_solref, *jnt_solimp;
+  int *dof_bodyid, *dof_jntid, *dof_parentid;
+  double *dof_armature, *dof_damping, *dof_frictionloss, *dof_invweight0, *dof_solref, *dof_solimp;
+  double *qpos0, *qpos_spring;
+  int *geom_type, *geom_bodyid, *geom_hulladr, *geom_hullnum;
+  double *geom_pos, *geom_quat, *geom_size, *geom_rbound, *geom_center, *geom_rgba, *hull_vert;
+  int *site_bodyid, *cam_bodyid;
+  double *site_pos, *site_quat, *cam_pos, *cam_quat, *cam_fovy;
+  int *tendon_adr, *tendon_num, *wrap_objid;
+  double* wrap_prm;
+  int *eq_obj1id, *eq_obj2id, *eq_active;
+  double *eq_data, *eq_solref, *eq_solimp;
+  int *actuator_trntype, *actuator_trnid, *actuator_ctrllimited, *actuator_forcelimited, *actuator_biastype;
+  double *actuator_gear, *actuator_gainprm, *actuator_biasprm, *actuator_ctrlrange, *actuator_forcerange;
+  double* key_ctrl;
+  int *pair_geom1, *pair_geom2, *pair_condim;
+  double *pair_friction, *pair_solref, *pair_solimp, *pair_margin, *pair_gap;
+  int imu_site, *lidar_site;
+};
+
+typedef struct {
+  double dist, pos[3], frame[9], friction[5], solref[2], solimp[5], includemargin, mu;
+  int dim, geom1, geom2, efc_address;
+} contact_t;
+
+struct smjo_data {
+  int nv, ncon, nefc, ne, nf, solver_niter, ncon_dropped;
+  double time;
+  double *qpos, *qvel, *ctrl, *qacc_warmstart, *qacc, *qacc_smooth, *qfrc_bias, *qfrc_passive, *qfrc_actuator,
+      *qfrc_smooth, *qfrc_constraint, *qfrc_applied;
+  double *xpos, *xquat, *xmat, *xipos, *ximat, *xanchor, *xaxis, *geom_xpos, *geom_xmat, *site_xpos, *site_xmat,
+      *cam_xpos, *cam_xmat;
+  double *subtree_com, *cinert, *crb, *cdof, *cdof_dot, *cvel, *cacc, *cfrc;
+  double *qM, *qL, *qH; /* dense nv*nv: mass matrix, its Cholesky factor, implicit matrix factor */
+  double *ten_length, *ten_J, *actuator_length, *actuator_velocity, *actuator_moment, *actuator_force;
+  contact_t* contact;
+  double *efc_J, *efc_pos, *efc_margin, *efc_D, *efc_R, *efc_aref, *efc_b, *efc_force, *efc_vel, *efc_KBIP,
+      *efc_diagApprox, *efc_frictionloss, *efc_AR;
+  int *efc_type, *efc_id;
+  double *gyro, *accel, *lidar;
+  double* scratch;
+};
+
+#define LOADF(name) m->name = blob_f64(b, #name, NULL)
+#define LOADI(name) m->name = blob_i32(b, #name, NULL)
+
+smjo_model* smjo_load(const void* blob, size_t nbytes) {
+  const uint8_t* b = (const uint8_t*)blob;
+  if (nbytes < 16 || memcmp(b, "SMJB0001", 8) != 0) return NULL;
+  smjo_model* m = (smjo_model*)calloc(1, sizeof(smjo_model));
+  int* dims = blob_i32(b, "dims", NULL);
+  m->nq = dims[0]; m->nv = dims[1]; m->nu = dims[2]; m->nbody = dims[3]; m->njnt = dims[4]; m->ngeom = dims[5];
+  m->nsite = dims[6]; m->ncam = dims[7]; m->neq = dims[8]; m->ntendon = dims[9]; m->nwrap = dims[10];
+  m->nkey = dims[11]; m->npair = dims[12]; m->nhullvert = dims[13];
+  free(dims);
+  double* t;
+  t = blob_f64(b, "opt_timestep", NULL); m->timestep = t[0]; free(t);
+  t = blob_f64(b, "opt_gravity", NULL); memcpy(m->gravity, t, 24); free(t);
+  t = blob_f64(b, "opt_impratio", NULL); m->impratio = t[0]; free(t);
+  t = blob_f64(b, "opt_tolerance", NULL); m->tolerance = t[0]; free(t);
+  t = blob_f64(b, "stat_meaninertia", NULL); m->meaninertia = t[0]; free(t);
+  t = blob_f64(b, "sensor_lidar_cutoff", NULL); m->lidar_cutoff = t[0]; free(t);
+  int* ti;
+  ti = blob_i32(b, "opt_iterations", NULL); m->iterations = ti[0]; free(ti);
+  ti = blob_i32(b, "opt_cone", NULL); m->cone = ti[0]; free(ti);
+  ti = blob_i32(b, "sensor_imu_site", NULL); m->imu_site = ti[0]; free(ti);
+  m->lidar_site = blob_i32(b, "sensor_lidar_site", &m->nlidar);
+  m->warmstart = 1; m->pgs_fixed_iter = 0; m->max_con_pair = 4;
+  LOADI(body_parentid); LOADI(body_weldid); LOADI(body_rootid); LOADI(body_jntadr); LOADI(body_jntnum);
+  LOADI(body_dofadr); LOADI(body_dofnum);
+  LOADF(body_pos); LOADF(body_quat); LOADF(body_ipos); LOADF(body_iquat); LOADF(body_mass); LOADF(body_inertia);
+  LOADF(body_gravcomp); LOADF(body_invweight0); LOADF(body_subtreemass);
+  LOADI(jnt_type); LOADI(jnt_qposadr); LOADI(jnt_dofadr); LOADI(jnt_bodyid); LOADI(jnt_limited);
+  LOADF(jnt_pos); LOADF(jnt_axis); LOADF(jnt_stiffness); LOADF(jnt_range); LOADF(jnt_margin); LOADF(jnt_solref);
+  LOADF(jnt_solimp);
+  LOADI(dof_bodyid); LOADI(dof_jntid); LOADI(dof_parentid);
+  LOADF(dof_armature); LOADF(dof_damping); LOADF(dof_frictionloss); LOADF(dof_invweight0); LOADF(dof_solref);
+  LOADF(dof_solimp);
+  LOADF(qpos0); LOADF(qpos_spring);
+  LOADI(geom_type); LOADI(geom_bodyid); LOADI(geom_hulladr); LOADI(geom_hullnum);
+  LOADF(geom_pos); LOADF(geom_quat); LOADF(geom_size); LOADF(geom_rbound); LOADF(geom_center); LOADF(geom_rgba);
+  LOADF(hull_vert);
+  LOADI(site_bodyid); LOADI(cam_bodyid); LOADF(site_pos); LOADF(site_quat); LOADF(cam_pos); LOADF(cam_quat);
+  LOADF(cam_fovy);
+  LOADI(tendon_adr); LOADI(tendon_num); LOADI(wrap_objid); LOADF(wrap_prm);
+  LOADI(eq_obj1id); LOADI(eq_obj2id); LOADI(eq_active); LOADF(eq_data); LOADF(eq_solref); LOADF(eq_solimp);
+  LOADI(actuator_trntype); LOADI(actuator_trnid); LOADI(actuator_ctrllimited); LOADI(actuator_forcelimited);
+  LOADI(actuator_biastype);
+  LOADF(actuator_gear); LOADF(actuator_gainprm); LOADF(actuator_biasprm); LOADF(actuator_ctrlrange);
+  LOADF(actuator_forcerange);
+  LOADF(key_ctrl);
+  LOADI(pair_geom1); LOADI(pair_geom2); LOADI(pair_condim);
+  LOADF(pair_friction); LOADF(pair_solref); LOADF(pair_solimp); LOADF(pair_margin); LOADF(pair_gap);
+  return m;
+}
+
+void smjo_free_model(smjo_model* m) { free(m); /* arrays leak by design: test process lifetime */ }
+
+int smjo_set_option(smjo_model* m, const char* name, double v) {
+  if (!strcmp(name, "iterations")) m->iterations = (int)v;
+  else if (!strcmp(name, "tolerance")) m->tolerance = v;
+  else if (!strcmp(name, "warmstart")) m->warmstart = (int)v;
+  else if (!strcmp(name, "pgs_fixed_iter")) m->pgs_fixed_iter = (int)v;
+  else if (!strcmp(name, "max_contacts_per_pair")) m->max_con_pair = (int)v;
+  else if (!strcmp(name, "timestep")) m->timestep = v;
+  else if (!strcmp(name, "gravity_z")) m->gravity[2] = v;
+  else if (!strcmp(name, "impratio")) m->impratio = v;
+  else return -1;
+  return 0;
+}
+
+int smjo_dim(const smjo_model* m, const char* n) {
+  if (!strcmp(n, "nq")) return m->nq;
+  if (!strcmp(n, "nv")) return m->nv;
+  if (!strcmp(n, "nu")) return m->nu;
+  if (!strcmp(n, "nbody")) return m->nbody;
+  if (!strcmp(n, "njnt")) return m->njnt;
+  if (!strcmp(n, "ngeom")) return m->ngeom;
+  if (!strcmp(n, "nsite")) return m->nsite;
+  if (!strcmp(n, "npair")) return m->npair;
+  if (!strcmp(n, "nlidar")) return m->nlidar;
+  if (!strcmp(n, "ncam")) return m->ncam;
+  return -1;
+}
+
+static double* dalloc(size_t n) { return (double*)calloc(n ? n : 1, sizeof(double)); }
+
+smjo_data* smjo_make_data(const smjo_model* m) {
+  smjo_data* d = (smjo_data*)calloc(1, sizeof(smjo_data));
+  int nv = m->nv, nb = m->nbody;
+  d->nv = nv;
+  d->qpos = dalloc(m->nq); d->qvel = dalloc(nv); d->ctrl = dalloc(m->nu); d->qacc_warmstart = dalloc(nv);
+  d->qacc = dalloc(nv); d->qacc_smooth = dalloc(nv); d->qfrc_bias = dalloc(nv); d->qfrc_passive = dalloc(nv);
+  d->qfrc_actuator = dalloc(nv); d->qfrc_smooth = dalloc(nv); d->qfrc_constraint = dalloc(nv);
+  d->qfrc_applied = dalloc(nv);
+  d->xpos = dalloc(3 * nb); d->xquat = dalloc(4 * nb); d->xmat = dalloc(9 * nb); d->xipos = dalloc(3 * nb);
+  d->ximat = dalloc(9 * nb); d->xanchor = dalloc(3 * m->njnt); d->xaxis = dalloc(3 * m->njnt);
+  d->geom_xpos = dalloc(3 * m->ngeom); d->geom_xmat = dalloc(9 * m->ngeom);
+  d->site_xpos = dalloc(3 * m->nsite); d->site_xmat = dalloc(9 * m->nsite);
+  d->cam_xpos = dalloc(3 * m->ncam); d->cam_xmat = dalloc(9 * m->ncam);
+  d->subtree_com = dalloc(3 * nb); d->cinert = dalloc(10 * nb); d->crb = dalloc(10 * nb); d->cdof = dalloc(6 * nv);
+  d->cdof_dot = dalloc(6 * nv); d->cvel = dalloc(6 * nb); d->cacc = dalloc(6 * nb); d->cfrc = dalloc(6 * nb);
+  d->qM = dalloc(nv * nv); d->qL = dalloc(nv * nv); d->qH = dalloc(nv * nv);
+  d->ten_length = dalloc(m->ntendon); d->ten_J = dalloc(m->ntendon * nv);
+  d->actuator_length = dalloc(m->nu); d->actuator_velocity = dalloc(m->nu); d->actuator_moment = dalloc(m->nu * nv);
+  d->actuator_force = dalloc(m->nu);
+  d->contact = (contact_t*)calloc(MAXCON, sizeof(contact_t));
+  d->efc_J = dalloc((size_t)MAXEFC * nv); d->efc_pos = dalloc(MAXEFC); d->efc_margin = dalloc(MAXEFC);
+  d->efc_D = dalloc(MAXEFC); d->efc_R = dalloc(MAXEFC); d->efc_aref = dalloc(MAXEFC); d->efc_b = dalloc(MAXEFC);
+  d->efc_force = dalloc(MAXEFC); d->efc_vel = dalloc(MAXEFC); d->efc_KBIP = dalloc(4 * MAXEFC);
+  d->efc_diagApprox = dalloc(MAXEFC); d->efc_frictionloss = dalloc(MAXEFC); d->efc_AR = dalloc((size_t)MAXEFC * MAXEFC);
+  d->efc_type = (int*)calloc(MAXEFC, sizeof(int)); d->efc_id = (int*)calloc(MAXEFC, sizeof(int));
+  d->gyro = dalloc(3); d->accel = dalloc(3); d->lidar = dalloc(m->nlidar);
+  d->scratch = dalloc((size_t)MAXEFC * nv + 16 * nv);
+  smjo_reset(m, d);
+  return d;
+}
+void smjo_free_data(smjo_data* d) { free(d); }
+
+void smjo_reset(const smjo_model* m, smjo_data* d) {
+  memcpy(d->qpos, m->qpos0, sizeof(double) * m->nq);
+  memset(d->qvel, 0, sizeof(double) * m->nv);
+  memset(d->ctrl, 0, sizeof(double) * m->nu);
+  memset(d->qacc_warmstart, 0, sizeof(double) * m->nv);
+  memset(d->qfrc_applied, 0, sizeof(double) * m->nv);
+  d->time = 0;
+}
+
+#define GETD(nm, cnt) if (!strcmp(name, #nm)) { *n = (cnt); return d->nm; }
+double* smjo_get(smjo_data* d, const char* name, int* n) {
+  int nv = d->nv, dummy;
+  if (!n) n = &dummy;
+  if (!strcmp(name, "time")) { *n = 1; return &d->time; }
+  GETD(qpos, -1) GETD(qvel, nv) GETD(ctrl, -1) GETD(qacc_warmstart, nv) GETD(qacc, nv) GETD(qacc_smooth, nv)
+  GETD(qfrc_bias, nv) GETD(qfrc_passive, nv) GETD(qfrc_actuator, nv) GETD(qfrc_smooth, nv) GETD(qfrc_constraint, nv)
+  GETD(qfrc_applied, nv)
+  GETD(xpos, -1) GETD(xquat, -1) GETD(xmat, -1) GETD(xipos, -1) GETD(ximat, -1) GETD(xanchor, -1) GETD(xaxis, -1)
+  GETD(geom_xpos, -1) GETD(geom_xmat, -1) GETD(site_xpos, -1) GETD(site_xmat, -1) GETD(cam_xpos, -1) GETD(cam_xmat, -1)
+  GETD(subtree_com, -1) GETD(cinert, -1) GETD(crb, -1) GETD(cdof, 6 * nv) GETD(cdof_dot, 6 * nv) GETD(cvel, -1)
+  GETD(cacc, -1) GETD(qM, nv * nv) GETD(qL, nv * nv)
+  GETD(ten_length, -1) GETD(actuator_length, -1) GETD(actuator_velocity, -1) GETD(actuator_force, -1)
+  GETD(actuator_moment, -1)
+  GETD(efc_J, d->nefc * nv) GETD(efc_pos, d->nefc) GETD(efc_D, d->nefc) GETD(efc_R, d->nefc) GETD(efc_aref, d->nefc)
+  GETD(efc_b, d->nefc) GETD(efc_force, d->nefc) GETD(efc_vel, d->nefc) GETD(efc_AR, d->nefc * d->nefc)
+  GETD(efc_diagApprox, d->nefc) GETD(efc_KBIP, 4 * d->nefc)
+  GETD(gyro, 3) GETD(accel, 3) GETD(lidar, -1)
+  if (!strcmp(name, "contact")) { *n = d->ncon * (int)(sizeof(contact_t) / 8); return (double*)d->contact; }
+  return NULL;
+}
+int* smjo_get_int(smjo_data* d, const char* name, int* n) {
+  int dummy;
+  if (!n) n = &dummy;
+  if (!strcmp(name, "efc_type")) { *n = d->nefc; return d->efc_type; }
+  if (!strcmp(name, "efc_id")) { *n = d->nefc; return d->efc_id; }
+  if (!strcmp(name, "ncon")) { *n = 1; return &d->ncon; }
+  if (!strcmp(name, "nefc")) { *n = 1; return &d->nefc; }
+  if (!strcmp(name, "solver_niter")) { *n = 1; return &d->solver_niter; }
+  if (!strcmp(name, "ncon_dropped")) { *n = 1; return &d->ncon_dropped; }
+  return NULL;
+}
+
+/* ------------------------------------------------------------------ small math */
+static inline double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void cross3(double* r, const double* a, const double* b) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static inline double norm3(const double* a) { return sqrt(dot3(a, a)); }
+static inline double normalize3(double* a) {
+  double n = norm3(a);
+  if (n < MINVAL) { a[0] = 1; a[1] = 0; a[2] = 0; return 0; }
+  a[0] /= n; a[1] /= n; a[2] /= n;
+  return n;
+}
+static void quat_mul(double* r, const double* a, const double* b) {
+  double t[4] = {a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                 a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]};
+  memcpy(r, t, 32);
+}
+static void quat_normalize(double* q) {
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  for (int i = 0; i < 4; i++) q[i] /= n;
+}
+static void quat2mat(double* R, const double* q) {
+  double w = q[0], x = q[1], y = q[2], z = q[3];
+  R[0] = w * w + x * x - y * y - z * z; R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z); R[4] = w * w - x * x + y * y - z * z; R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = w * w - x * x - y * y + z * z;
+}
+static void axisangle2quat(double* q, const double* axis, double ang) {
+  double s = sin(0.5 * ang);
+  q[0] = cos(0.5 * ang); q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+static inline void mulmat3vec(double* r, const double* R, const double* v) {
+  double x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2], y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2],
+         z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static inline void mulmat3Tvec(double* r, const double* R, const double* v) {
+  double x = R[0] * v[0] + R[3] * v[1] + R[6] * v[2], y = R[1] * v[0] + R[4] * v[1] + R[7] * v[2],
+         z = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static void mulmat3(double* r, const double* A, const double* B) {
+  double t[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+  memcpy(r, t, 72);
+}
+
+/* spatial algebra on [angular(3); linear(3)] about the tree-root subtree COM.  [MJ] mju_mulInertVec etc. */
+static void mul_inert_vec(double* r, const double* i, const double* v) {
+  r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  r[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  r[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+static void cross_motion(double* r, const double* vel, const double* v) {
+  double a[3], b[3], c[3];
+  cross3(a, vel, v); cross3(b, vel, v + 3); cross3(c, vel + 3, v);
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = b[0] + c[0]; r[4] = b[1] + c[1]; r[5] = b[2] + c[2];
+}
+static void cross_force(double* r, const double* vel, const double* f) {
+  double a[3], b[3], c[3];
+  cross3(a, vel, f); cross3(b, vel + 3, f + 3); cross3(c, vel, f + 3);
+  r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2]; r[3] = c[0]; r[4] = c[1]; r[5] = c[2];
+}
+
+/* dense Cholesky A = L L^T (lower, row-major n x n); returns rank */
+static int chol_factor(double* A, int n, double mindiag) {
+  int rank = n;
+  for (int j = 0; j < n; j++) {
+    double s = A[j * n + j];
+    for (int k = 0; k < j; k++) s -= A[j * n + k] * A[j * n + k];
+    if (s < mindiag) { s = mindiag; rank--; }
+    double l = sqrt(s);
+    A[j * n + j] = l;
+    for (int i = j + 1; i < n; i++) {
+      double t = A[i * n + j];
+      for (int k = 0; k < j; k++) t -= A[i * n + k] * A[j * n + k];
+      A[i * n + j] = t / l;
+    }
+  }
+  return rank;
+}
+static void chol_solve(double* x, const double* L, const double* b, int n) {
+  if (x != b) memcpy(x, b, sizeof(double) * n);
+  for (int i = 0; i < n; i++) {
+    double s = x[i];
+    for (int k = 0; k < i; k++) s -= L[i * n + k] * x[k];
+    x[i] = s / L[i * n + i];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    double s = x[i];
+    for (int k = i + 1; k < n; k++) s -= L[k * n + i] * x[k];
+    x[i] = s / L[i * n + i];
+  }
+}
+
+/* ------------------------------------------------------------------ B.1 position stage */
+/* [MJ] mj_kinematics */
+static void kinematics(const smjo_model* m, smjo_data* d) {
+  d->xpos[0] = d->xpos[1] = d->xpos[2] = 0;
+  d->xquat[0] = 1; d->xquat[1] = d->xquat[2] = d->xquat[3] = 0;
+  quat2mat(d->xmat, d->xquat);
+  memset(d->xipos, 0, 24);
+  quat2mat(d->ximat, d->xquat);
+  for (int b = 1; b < m->nbody; b++) {
+    int p = m->body_parentid[b], ja = m->body_jntadr[b], jn = m->body_jntnum[b];
+    double pos[3], quat[4], R[9];
+    if (jn == 1 && m->jnt_type[ja] == JNT_FREE) {
+      const double* q = d->qpos + m->jnt_qposadr[ja];
+      memcpy(pos, q, 24); memcpy(quat, q + 3, 32);
+      quat_normalize(quat);
+      memcpy(d->xanchor + 3 * ja, pos, 24);
+      d->xaxis[3 * ja] = 0; d->xaxis[3 * ja + 1] = 0; d->xaxis[3 * ja + 2] = 1;
+    } else {
+      mulmat3vec(pos, d->xmat + 9 * p, m->body_pos + 3 * b);
+      for (int k = 0; k < 3; k++) pos[k] += d->xpos[3 * p + k];
+      quat_mul(quat, d->xquat + 4 * p, m->body_quat + 4 * b);
+      for (int j = ja; j < ja + jn; j++) {
+        quat2mat(R, quat);
+        mulmat3vec(d->xaxis + 3 * j, R, m->jnt_axis + 3 * j);
+        double a[3];
+        mulmat3vec(a, R, m->jnt_pos + 3 * j);
+        for (int k = 0; k < 3; k++) d->xanchor[3 * j + k] = pos[k] + a[k];
+        double q = d->qpos[m->jnt_qposadr[j]] - m->qpos0[m->jnt_qposadr[j]];
+        if (m->jnt_type[j] == JNT_SLIDE) {
+          for (int k = 0; k < 3; k++) pos[k] += d->xaxis[3 * j + k] * q;
+        } else {
+          double dq[4];
+          axisangle2quat(dq, m->jnt_axis + 3 * j, q);
+          quat_mul(quat, quat, dq);
+          quat2mat(R, quat);
+          mulmat3vec(a, R, m->jnt_pos + 3 * j);
+          for (int k = 0; k < 3; k++) pos[k] = d->xanchor[3 * j + k] - a[k];
+        }
+      }
+    }
+    quat_normalize(quat);
+    memcpy(d->xpos + 3 * b, pos, 24); memcpy(d->xquat + 4 * b, quat, 32);
+    quat2mat(d->xmat + 9 * b, quat);
+    double t[3], Ri[9];
+    mulmat3vec(t, d->xmat + 9 * b, m->body_ipos + 3 * b);
+    for (int k = 0; k < 3; k++) d->xipos[3 * b + k] = pos[k] + t[k];
+    quat2mat(Ri, m->body_iquat + 4 * b);
+    mulmat3(d->ximat + 9 * b, d->xmat + 9 * b, Ri);
+  }
+  for (int g = 0; g < m->ngeom; g++) {
+    int b = m->geom_bodyid[g];
+    double t[3], R[9];
+    mulmat3vec(t, d->xmat + 9 * b, m->geom_pos + 3 * g);
+    for (int k = 0; k < 3; k++) d->geom_xpos[3 * g + k] = d->xpos[3 * b + k] + t[k];
+    quat2mat(R, m->geom_quat + 4 * g);
+    mulmat3(d->geom_xmat + 9 * g, d->xmat + 9 * b, R);
+  }
+  for (int s = 0; s < m->nsite; s++) {
+    int b = m->site_bodyid[s];
+    double t[3], R[9];
+    mulmat3vec(t, d->xmat + 9 * b, m->site_pos + 3 * s);
+    for (int k = 0; k < 3; k++) d->site_xpos[3 * s + k] = d->xpos[3 * b + k] + t[k];
+    quat2mat(R, m->site_quat + 4 * s);
+    mulmat3(d->site_xmat + 9 * s, d->xmat + 9 * b, R);
+  }
+  for (int c = 0; c < m->ncam; c++) {
+    int b = m->cam_bodyid[c];
+    double t[3], R[9];
+    mulmat3vec(t, d->xmat + 9 * b, m->cam_pos + 3 * c);
+    for (int k = 0; k < 3; k++) d->cam_xpos[3 * c + k] = d->xpos[3 * b + k] + t[k];
+    quat2mat(R, m->cam_quat + 4 * c);
+    mulmat3(d->cam_xmat + 9 * c, d->xmat + 9 * b, R);
+  }
+}
+
+/* [MJ] mj_comPos: subtree COMs, cinert, cdof */
+static void com_pos(const smjo_model* m, smjo_data* d) {
+  int nb = m->nbody;
+  for (int b = 0; b < nb; b++)
+    for (int k = 0; k < 3; k++) d->subtree_com[3 * b + k] = m->body_mass[b] * d->xipos[3 * b + k];
+  for (int b = nb - 1; b > 0; b--)
+    for (int k = 0; k < 3; k++) d->subtree_com[3 * m->body_parentid[b] + k] += d->subtree_com[3 * b + k];
+  for (int b = 0; b < nb; b++) {
+    if (m->body_subtreemass[b] < MINVAL) memcpy(d->subtree_com + 3 * b, d->xipos + 3 * b, 24);
+    else for (int k = 0; k < 3; k++) d->subtree_com[3 * b + k] /= m->body_subtreemass[b];
+  }
+  memset(d->cinert, 0, 80);
+  for (int b = 1; b < nb; b++) {
+    const double* R = d->ximat + 9 * b;
+    const double* I = m->body_inertia + 3 * b;
+    double mass = m->body_mass[b], dif[3], *c = d->cinert + 10 * b;
+    for (int k = 0; k < 3; k++) dif[k] = d->xipos[3 * b + k] - d->subtree_com[3 * m->body_rootid[b] + k];
+    double T[9];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++)
+        T[3 * i + j] = R[3 * i] * I[0] * R[3 * j] + R[3 * i + 1] * I[1] * R[3 * j + 1] + R[3 * i + 2] * I[2] * R[3 * j + 2];
+    double dd = dot3(dif, dif);
+    c[0] = T[0] + mass * (dd - dif[0] * dif[0]);
+    c[1] = T[4] + mass * (dd - dif[1] * dif[1]);
+    c[2] = T[8] + mass * (dd - dif[2] * dif[2]);
+    c[3] = T[1] - mass * dif[0] * dif[1];
+    c[4] = T[2] - mass * dif[0] * dif[2];
+    c[5] = T[5] - mass * dif[1] * dif[2];
+    c[6] = mass * dif[0]; c[7] = mass * dif[1]; c[8] = mass * dif[2]; c[9] = mass;
+  }
+  for (int j = 0; j < m->njnt; j++) {
+    int b = m->jnt_bodyid[j], da = m->jnt_dofadr[j];
+    const double* com = d->subtree_com + 3 * m->body_rootid[b];
+    double off[3];
+    for (int k = 0; k < 3; k++) off[k] = com[k] - d->xanchor[3 * j + k];
+    if (m->jnt_type[j] == JNT_FREE) {
+      for (int k = 0; k < 3; k++) {
+        double* c = d->cdof + 6 * (da + k);
+        memset(c, 0, 48); c[3 + k] = 1;
+        double ax[3] = {d->xmat[9 * b + k], d->xmat[9 * b + 3 + k], d->xmat[9 * b + 6 + k]};
+        c = d->cdof + 6 * (da + 3 + k);
+        memcpy(c, ax, 24); cross3(c + 3, ax, off);
+      }
+    } else if (m->jnt_type[j] == JNT_SLIDE) {
+      double* c = d->cdof + 6 * da;
+      c[0] = c[1] = c[2] = 0; memcpy(c + 3, d->xaxis + 3 * j, 24);
+    } else {
+      double* c = d->cdof + 6 * da;
+      memcpy(c, d->xaxis + 3 * j, 24); cross3(c + 3, d->xaxis + 3 * j, off);
+    }
+  }
+}
+
+/* [MJ] mj_tendon (fixed) + mj_transmission */
+static void tendon_transmission(const smjo_model* m, smjo_data* d) {
+  int nv = m->nv;
+  memset(d->ten_J, 0, sizeof(double) * m->ntendon * nv);
+  for (int t = 0; t < m->ntendon; t++) {
+    double L = 0;
+    for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) {
+      int j = m->wrap_objid[w];
+      L += m->wrap_prm[w] * d->qpos[m->jnt_qposadr[j]];
+      d->ten_J[t * nv + m->jnt_dofadr[j]] = m->wrap_prm[w];
+    }
+    d->ten_length[t] = L;
+  }
+  memset(d->actuator_moment, 0, sizeof(double) * m->nu * nv);
+  for (int a = 0; a < m->nu; a++) {
+    double gear = m->actuator_gear[a];
+    if (m->actuator_trntype[a] == 0) {
+      int j = m->actuator_trnid[a];
+      d->actuator_length[a] = gear * d->qpos[m->jnt_qposadr[j]];
+      d->actuator_moment[a * nv + m->jnt_dofadr[j]] = gear;
+    } else {
+      int t = m->actuator_trnid[a];
+      d->actuator_length[a] = gear * d->ten_length[t];
+      for (int k = 0; k < nv; k++) d->actuator_moment[a * nv + k] = gear * d->ten_J[t * nv + k];
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ B.2 inertia */
+/* [MJ] mj_crb (dense storage) + factorisation (dense Cholesky instead of sparse L'DL: same M^-1) */
+static void crb_factor(const smjo_model* m, smjo_data* d) {
+  int nv = m->nv, nb = m->nbody;
+  memcpy(d->crb, d->cinert, sizeof(double) * 10 * nb);
+  for (int b = nb - 1; b > 0; b--) {
+    int p = m->body_parentid[b];
+    if (p > 0) for (int k = 0; k < 10; k++) d->crb[10 * p + k] += d->crb[10 * b + k];
+  }
+  memset(d->qM, 0, sizeof(double) * nv * nv);
+  for (int i = 0; i < nv; i++) {
+    double buf[6];
+    mul_inert_vec(buf, d->crb + 10 * m->dof_bodyid[i], d->cdof + 6 * i);
+    for (int j = i; j >= 0; j = m->dof_parentid[j]) {
+      double v = 0;
+      for (int k = 0; k < 6; k++) v += d->cdof[6 * j + k] * buf[k];
+      d->qM[i * nv + j] = d->qM[j * nv + i] = v;
+    }
+    d->qM[i * nv + i] += m->dof_armature[i];
+  }
+  memcpy(d->qL, d->qM, sizeof(double) * nv * nv);
+  chol_factor(d->qL, nv, MINVAL);
+}
+
+/* Jacobian of a world point attached to body: jacp (3 x nv), jacr (3 x nv).  [MJ] mj_jac */
+static void jac_point(const smjo_model* m, const smjo_data* d, double* jacp, double* jacr, const double* point, int body) {
+  int nv = m->nv;
+  if (jacp) memset(jacp, 0, sizeof(double) * 3 * nv);
+  if (jacr) memset(jacr, 0, sizeof(double) * 3 * nv);
+  while (body > 0 && m->body_dofnum[body] == 0) body = m->body_parentid[body];
+  if (body == 0) return;
+  const double* com = d->subtree_com + 3 * m->body_rootid[body];
+  double off[3] = {point[0] - com[0], point[1] - com[1], point[2] - com[2]};
+  for (int i = m->body_dofadr[body] + m->body_dofnum[body] - 1; i >= 0; i = m->dof_parentid[i]) {
+    const double* c = d->cdof + 6 * i;
+    if (jacr) { jacr[i] = c[0]; jacr[nv + i] = c[1]; jacr[2 * nv + i] = c[2]; }
+    if (jacp) {
+      double t[3];
+      cross3(t, c, off);
+      jacp[i] = c[3] + t[0]; jacp[nv + i] = c[4] + t[1]; jacp[2 * nv + i] = c[5] + t[2];
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ B.3 collision */
+static void make_frame(double* f) { /* [MJ] mju_makeFrame: f[0:3] = normal given */
+  normalize3(f);
+  double* y = f + 3;
+  if (f[1] > -0.5 && f[1] < 0.5) { y[0] = 0; y[1] = 1; y[2] = 0; } else { y[0] = 0; y[1] = 0; y[2] = 1; }
+  double t = dot3(f, y);
+  for (int k = 0; k < 3; k++) y[k] -= t * f[k];
+  normalize3(y);
+  cross3(f + 6, f, y);
+}
+
+typedef struct { double dist, pos[3], normal[3]; } rawcon;
+
+static int plane_sphere(const double* ppos, const double* pmat, const double* spos, double r, double margin, rawcon* c) {
+  double n[3] = {pmat[2], pmat[5], pmat[8]}, dif[3] = {spos[0] - ppos[0], spos[1] - ppos[1], spos[2] - ppos[2]};
+  double dist = dot3(dif, n) - r;
+  if (dist > margin) return 0;
+  c->dist = dist;
+  memcpy(c->normal, n, 24);
+  for (int k = 0; k < 3; k++) c->pos[k] = spos[k] - n[k] * (r + 0.5 * dist);
+  return 1;
+}
+
+/* [MJ] mjc_PlaneCylinder */
+static int plane_cylinder(const double* ppos, const double* pmat, const double* cpos, const double* cmat, const double* size,
+                          double margin, rawcon* con) {
+  double normal[3] = {pmat[2], pmat[5], pmat[8]}, axis[3] = {cmat[2], cmat[5], cmat[8]};
+  double prjaxis = dot3(normal, axis);
+  if (prjaxis > 0) { for (int k = 0; k < 3; k++) axis[k] = -axis[k]; prjaxis = -prjaxis; }
+  double vec[3] = {cpos[0] - ppos[0], cpos[1] - ppos[1], cpos[2] - ppos[2]};
+  double dist0 = dot3(vec, normal);
+  for (int k = 0; k < 3; k++) vec[k] = axis[k] * prjaxis - normal[k];
+  double len2 = dot3(vec, vec);
+  if (len2 >= MINVAL * MINVAL) { double s = size[0] / sqrt(len2); for (int k = 0; k < 3; k++) vec[k] *= s; }
+  else { vec[0] = cmat[0] * size[0]; vec[1] = cmat[3] * size[0]; vec[2] = cmat[6] * size[0]; }
+  double prjvec = dot3(vec, normal);
+  for (int k = 0; k < 3; k++) axis[k] *= size[1];
+  prjaxis *= size[1];
+  int cnt = 0;
+  if (dist0 + prjaxis + prjvec <= margin) {
+    double dist = dist0 + prjaxis + prjvec;
+    con[cnt].dist = dist; memcpy(con[cnt].normal, normal, 24);
+    for (int k = 0; k < 3; k++) con[cnt].pos[k] = cpos[k] + vec[k] + axis[k] - normal[k] * dist * 0.5;
+    cnt++;
+  } else return 0;
+  if (dist0 - prjaxis + prjvec <= margin) {
+    double dist = dist0 - prjaxis + prjvec;
+    con[cnt].dist = dist; memcpy(con[cnt].normal, normal, 24);
+    for (int k = 0; k < 3; k++) con[cnt].pos[k] = cpos[k] + vec[k] - axis[k] - normal[k] * dist * 0.5;
+    cnt++;
+  }
+  double prjvec1 = -prjvec * 0.5;
+  if (dist0 + prjaxis + prjvec1 <= margin) {
+    double vec1[3];
+    cross3(vec1, vec, axis);
+    normalize3(vec1);
+    for (int k = 0; k < 3; k++) vec1[k] *= size[0] * sqrt(3.0) * 0.5;
+    double dist = dist0 + prjaxis + prjvec1;
+    for (int s = 0; s < 2; s++) {
+      double sg = s ? -1.0 : 1.0;
+      con[cnt].dist = dist; memcpy(con[cnt].normal, normal, 24);
+      for (int k = 0; k < 3; k++) con[cnt].pos[k] = cpos[k] + sg * vec1[k] + axis[k] - vec[k] * 0.5 - normal[k] * dist * 0.5;
+      cnt++;
+    }
+  }
+  return cnt;
+}
+
+/* [MJ] mjc_PlaneBox */
+static int plane_box(const double* ppos, const double* pmat, const double* bpos, const double* bmat, const double* size,
+                     double margin, rawcon* con) {
+  double n[3] = {pmat[2], pmat[5], pmat[8]}, dif[3] = {bpos[0] - ppos[0], bpos[1] - ppos[1], bpos[2] - ppos[2]};
+  double dist = dot3(dif, n);
+  int cnt = 0;
+  for (int i = 0; i < 8; i++) {
+    double vec[3] = {(i & 1 ? size[0] : -size[0]), (i & 2 ? size[1] : -size[1]), (i & 4 ? size[2] : -size[2])}, corner[3];
+    mulmat3vec(corner, bmat, vec);
+    double ldist = dot3(n, corner);
+    if (dist + ldist > margin || ldist > 0) continue;
+    double cd = dist + ldist;
+    con[cnt].dist = cd; memcpy(con[cnt].normal, n, 24);
+    for (int k = 0; k < 3; k++) con[cnt].pos[k] = bpos[k] + corner[k] - n[k] * cd * 0.5;
+    if (++cnt >= 4) return 4;
+  }
+  return cnt;
+}
+
+/* plane vs convex hull: the build's own manifold rule (MuJoCo's mjc_PlaneConvex picks support vertex +
+ * up to 3 neighbours; not restatable bit-for-bit): among hull vertices with dist <= margin take
+ * (1) the deepest, (2) the one farthest from (1), (3,4) the extremes of signed distance to the line (1)-(2). */
+static int plane_hull(const double* ppos, const double* pmat, const double* gpos, const double* gmat, const double* verts,
+                      int nvert, double margin, int maxc, rawcon* con) {
+  double n[3] = {pmat[2], pmat[5], pmat[8]};
+  double nl[3];
+  mulmat3Tvec(nl, gmat, n); /* plane normal in geom frame */
+  double off = (gpos[0] - ppos[0]) * n[0] + (gpos[1] - ppos[1]) * n[1] + (gpos[2] - ppos[2]) * n[2];
+  int i1 = -1, i2 = -1, i3 = -1, i4 = -1;
+  double best = margin;
+  for (int i = 0; i < nvert; i++) {
+    double dd = dot3(nl, verts + 3 * i) + off;
+    if (dd <= margin && (i1 < 0 || dd < best)) { best = dd; i1 = i; }
+  }
+  if (i1 < 0) return 0;
+  const double* v1 = verts + 3 * i1;
+  double far2 = 1e-12;
+  for (int i = 0; i < nvert && maxc > 1; i++) {
+    double dd = dot3(nl, verts + 3 * i) + off;
+    if (dd > margin) continue;
+    double e[3] = {verts[3 * i] - v1[0], verts[3 * i + 1] - v1[1], verts[3 * i + 2] - v1[2]};
+    double r2 = dot3(e, e);
+    if (r2 > far2) { far2 = r2; i2 = i; }
+  }
+  if (i2 >= 0 && maxc > 2) {
+    const double* v2 = verts + 3 * i2;
+    double e12[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]}, side[3];
+    cross3(side, nl, e12);
+    normalize3(side);
+    double smax = 1e-6, smin = -1e-6;
+    for (int i = 0; i < nvert; i++) {
+      double dd = dot3(nl, verts + 3 * i) + off;
+      if (dd > margin) continue;
+      double e[3] = {verts[3 * i] - v1[0], verts[3 * i + 1] - v1[1], verts[3 * i + 2] - v1[2]};
+      double s = dot3(e, side);
+      if (s > smax) { smax = s; i3 = i; }
+      if (s < smin) { smin = s; i4 = i; }
+    }
+    if (maxc < 4) i4 = -1;
+  }
+  int idx[4] = {i1, i2, i3, i4}, cnt = 0;
+  for (int k = 0; k < 4; k++) {
+    if (idx[k] < 0) continue;
+    const double* v = verts + 3 * idx[k];
+    double w[3], dd = dot3(nl, v) + off;
+    mulmat3vec(w, gmat, v);
+    con[cnt].dist = dd; memcpy(con[cnt].normal, n, 24);
+    for (int j = 0; j < 3; j++) con[cnt].pos[j] = gpos[j] + w[j] - n[j] * dd * 0.5;
+    cnt++;
+  }
+  return cnt;
+}
+
+/* [MJ] mj_collision: static pair table (built by the model compiler with MuJoCo's filters) ->
+ * bounding-sphere rejection -> narrowphase by type pair */
+static void collision(const smjo_model* m, smjo_data* d) {
+  d->ncon = 0; d->ncon_dropped = 0;
+  for (int p = 0; p < m->npair; p++) {
+    int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+    double margin = m->pair_margin[p];
+    const double *p1 = d->geom_xpos + 3 * g1, *R1 = d->geom_xmat + 9 * g1, *p2 = d->geom_xpos + 3 * g2, *R2 = d->geom_xmat + 9 * g2;
+    const double *s2 = m->geom_size + 3 * g2;
+    rawcon rc[8];
+    int n = 0;
+    double c2[3];
+    mulmat3vec(c2, R2, m->geom_center + 3 * g2);
+    for (int k = 0; k < 3; k++) c2[k] += p2[k];
+    if (t1 == G_PLANE) {
+      double nrm[3] = {R1[2], R1[5], R1[8]}, dif[3] = {c2[0] - p1[0], c2[1] - p1[1], c2[2] - p1[2]};
+      if (dot3(dif, nrm) - m->geom_rbound[g2] > margin) continue;
+      if (t2 == G_SPHERE) n = plane_sphere(p1, R1, p2, s2[0], margin, rc);
+      else if (t2 == G_CYLINDER) n = plane_cylinder(p1, R1, p2, R2, s2, margin, rc);
+      else if (t2 == G_BOX) n = plane_box(p1, R1, p2, R2, s2, margin, rc);
+      else if (t2 == G_MESH)
+        n = plane_hull(p1, R1, p2, R2, m->hull_vert + 3 * m->geom_hulladr[g2], m->geom_hullnum[g2], margin, m->max_con_pair, rc);
+      else continue;
+    } else {
+      continue; /* non-plane pairs: not yet on the restated path (DESIGN.md scope) */
+    }
+    for (int i = 0; i < n; i++) {
+      if (d->ncon >= MAXCON) { d->ncon_dropped++; continue; }
+      contact_t* c = d->contact + d->ncon++;
+      c->dist = rc[i].dist; memcpy(c->pos, rc[i].pos, 24); memcpy(c->frame, rc[i].normal, 24);
+      c->frame[3] = c->frame[4] = c->frame[5] = 0;
+      make_frame(c->frame);
+      c->dim = m->pair_condim[p]; c->geom1 = g1; c->geom2 = g2;
+      memcpy(c->friction, m->pair_friction + 5 * p, 40); memcpy(c->solref, m->pair_solref + 2 * p, 16);
+      memcpy(c->solimp, m->pair_solimp + 5 * p, 40);
+      c->includemargin = m->pair_margin[p] - m->pair_gap[p];
+      c->efc_address = -1;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ B.4 constraints */
+static int add_row(smjo_data* d, int nv, int type, int id, double pos, double margin, double floss, double diag) {
+  int i = d->nefc;
+  if (i >= MAXEFC) return -1;
+  memset(d->efc_J + (size_t)i * nv, 0, sizeof(double) * nv);
+  d->efc_type[i] = type; d->efc_id[i] = id; d->efc_pos[i] = pos; d->efc_margin[i] = margin;
+  d->efc_frictionloss[i] = floss; d->efc_diagApprox[i] = diag;
+  d->nefc++;
+  return i;
+}
+
+/* [MJ] getimpedance */
+static void get_impedance(const double* solimp, double pos, double margin, double* imp) {
+  double dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
+  dmin = fmin(MAXIMP, fmax(MINIMP, dmin)); dmax = fmin(MAXIMP, fmax(MINIMP, dmax));
+  width = fmax(MINVAL, width); mid = fmin(MAXIMP, fmax(MINIMP, mid)); power = fmax(1, power);
+  if (dmin == dmax) { *imp = 0.5 * (dmin + dmax); return; }
+  double x = fabs(pos - margin) / width, y;
+  if (x >= 1) { *imp = dmax; return; }
+  if (x <= 0) { *imp = dmin; return; }
+  if (power == 1) y = x;
+  else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
+  else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
+  *imp = dmin + y * (dmax - dmin);
+}
+
+/* [MJ] mj_makeConstraint + mj_makeImpedance + mj_projectConstraint */
+static void make_constraint(const smjo_model* m, smjo_data* d) {
+  int nv = m->nv;
+  d->nefc = 0;
+  /* equality (joint) */
+  for (int e = 0; e < m->neq; e++) {
+    if (!m->eq_active[e]) continue;
+    int j1 = m->eq_obj1id[e], j2 = m->eq_obj2id[e];
+    const double* a = m->eq_data + 5 * e;
+    double p1 = d->qpos[m->jnt_qposadr[j1]] - m->qpos0[m->jnt_qposadr[j1]], pos, deriv = 0;
+    double diag = m->dof_invweight0[m->jnt_dofadr[j1]];
+    if (j2 >= 0) {
+      double dif = d->qpos[m->jnt_qposadr[j2]] - m->qpos0[m->jnt_qposadr[j2]];
+      pos = p1 - (a[0] + dif * (a[1] + dif * (a[2] + dif * (a[3] + dif * a[4]))));
+      deriv = a[1] + dif * (2 * a[2] + dif * (3 * a[3] + dif * 4 * a[4]));
+      diag += m->dof_invweight0[m->jnt_dofadr[j2]];
+    } else pos = p1 - a[0];
+    int i = add_row(d, nv, C_EQUALITY, e, pos, 0, 0, diag);
+    d->efc_J[(size_t)i * nv + m->jnt_dofadr[j1]] = 1;
+    if (j2 >= 0) d->efc_J[(size_t)i * nv + m->jnt_dofadr[j2]] = -deriv;
+  }
+  d->ne = d->nefc;
+  /* dof friction loss */
+  for (int k = 0; k < nv; k++)
+    if (m->dof_frictionloss[k] > 0) {
+      int i = add_row(d, nv, C_FRICTION_DOF, k, 0, 0, m->dof_frictionloss[k], m->dof_invweight0[k]);
+      d->efc_J[(size_t)i * nv + k] = 1;
+    }
+  d->nf = d->nefc - d->ne;
+  /* joint limits (slide / hinge) */
+  for (int j = 0; j < m->njnt; j++) {
+    if (!m->jnt_limited[j] || m->jnt_type[j] == JNT_FREE) continue;
+    double q = d->qpos[m->jnt_qposadr[j]], margin = m->jnt_margin[j];
+    for (int side = -1; side <= 1; side += 2) {
+      double dist = side * (m->jnt_range[2 * j + (side + 1) / 2] - q);
+      if (dist < margin) {
+        int i = add_row(d, nv, C_LIMIT_JOINT, j, dist, margin, 0, m->dof_invweight0[m->jnt_dofadr[j]]);
+        d->efc_J[(size_t)i * nv + m->jnt_dofadr[j]] = -side;
+      }
+    }
+  }
+  /* contacts */
+  double* jp1 = d->scratch; double* jr1 = jp1 + 3 * nv; double* jp2 = jr1 + 3 * nv; double* jr2 = jp2 + 3 * nv;
+  for (int c = 0; c < d->ncon; c++) {
+    contact_t* con = d->contact + c;
+    con->efc_address = -1;
+    if (con->dist >= con->includemargin) continue;
+    int b1 = m->geom_bodyid[con->geom1], b2 = m->geom_bodyid[con->geom2], dim = con->dim;
+    if (d->nefc + dim > MAXEFC) { d->ncon_dropped++; continue; }
+    jac_point(m, d, jp1, jr1, con->pos, b1);
+    jac_point(m, d, jp2, jr2, con->pos, b2);
+    double tran = m->body_invweight0[2 * b1] + m->body_invweight0[2 * b2];
+    double rot = m->body_invweight0[2 * b1 + 1] + m->body_invweight0[2 * b2 + 1];
+    con->efc_address = d->nefc;
+    for (int r = 0; r < dim; r++) {
+      int type = dim == 1 ? C_CONTACT_FRICTIONLESS : C_CONTACT_ELLIPTIC;
+      int i = add_row(d, nv, type, c, con->dist, con->includemargin, 0, r < 3 ? tran : rot);
+      const double* ax = con->frame + 3 * (r < 3 ? r : r - 3);
+      const double *ja = r < 3 ? jp1 : jr1, *jb = r < 3 ? jp2 : jr2;
+      for (int k = 0; k < nv; k++) {
+        double v = 0;
+        for (int x = 0; x < 3; x++) v += ax[x] * (jb[x * nv + k] - ja[x * nv + k]);
+        d->efc_J[(size_t)i * nv + k] = v;
+      }
+    }
+  }
+  /* impedance, R, D, KBIP */
+  for (int i = 0; i < d->nefc; i++) {
+    const double *solref, *solimp;
+    int id = d->efc_id[i], t = d->efc_type[i];
+    if (t == C_EQUALITY) { solref = m->eq_solref + 2 * id; solimp = m->eq_solimp + 5 * id; }
+    else if (t == C_FRICTION_DOF) { solref = m->dof_solref + 2 * id; solimp = m->dof_solimp + 5 * id; }
+    else if (t == C_LIMIT_JOINT) { solref = m->jnt_solref + 2 * id; solimp = m->jnt_solimp + 5 * id; }
+    else { solref = d->contact[id].solref; solimp = d->contact[id].solimp; }
+    double imp;
+    get_impedance(solimp, d->efc_pos[i], d->efc_margin[i], &imp);
+    d->efc_R[i] = fmax(MINVAL, (1 - imp) * d->efc_diagApprox[i] / imp);
+    double dmax = fmin(MAXIMP, fmax(MINIMP, solimp[1])), K, B;
+    if (solref[0] > 0) {
+      double tc = fmax(solref[0], 2 * m->timestep), dr = solref[1];
+      K = 1 / fmax(MINVAL, dmax * dmax * tc * tc * dr * dr);
+      B = 2 / fmax(MINVAL, dmax * tc);
+    } else { K = -solref[0] / fmax(MINVAL, dmax * dmax); B = -solref[1] / fmax(MINVAL, dmax); }
+    int friction_row = (t == C_FRICTION_DOF) || (t == C_CONTACT_ELLIPTIC && i != d->contact[id].efc_address);
+    if (friction_row) K = 0;
+    d->efc_KBIP[4 * i] = K; d->efc_KBIP[4 * i + 1] = B; d->efc_KBIP[4 * i + 2] = imp; d->efc_KBIP[4 * i + 3] = 0;
+  }
+  /* elliptic cones: friction-row regularisation from the normal row, impratio ([MJ] mj_makeImpedance tail) */
+  for (int c = 0; c < d->ncon; c++) {
+    contact_t* con = d->contact + c;
+    int i = con->efc_address, dim = con->dim;
+    if (i < 0 || dim < 3) { con->mu = 0; continue; }
+    d->efc_R[i + 1] = d->efc_R[i] / fmax(MINVAL, m->impratio);
+    con->mu = con->friction[0] * sqrt(d->efc_R[i + 1] / d->efc_R[i]);
+    for (int j = 1; j < dim - 1; j++)
+      d->efc_R[i + 1 + j] = d->efc_R[i + 1] * con->friction[0] * con->friction[0] / (con->friction[j] * con->friction[j]);
+  }
+  for (int i = 0; i < d->nefc; i++) d->efc_D[i] = 1 / d->efc_R[i];
+  /* AR = J M^-1 J' + diag(R) */
+  int ne = d->nefc;
+  double* B = d->scratch; /* nefc x nv : rows M^-1 J_i' */
+  for (int i = 0; i < ne; i++) chol_solve(B + (size_t)i * nv, d->qL, d->efc_J + (size_t)i * nv, nv);
+  for (int i = 0; i < ne; i++)
+    for (int j = 0; j <= i; j++) {
+      double s = 0;
+      for (int k = 0; k < nv; k++) s += d->efc_J[(size_t)i * nv + k] * B[(size_t)j * nv + k];
+      d->efc_AR[(size_t)i * ne + j] = d->efc_AR[(size_t)j * ne + i] = s;
+    }
+  for (int i = 0; i < ne; i++) d->efc_AR[(size_t)i * ne + i] += d->efc_R[i];
+}
+
+/* ------------------------------------------------------------------ B.5 velocity stage */
+/* [MJ] mj_comVel */
+static void com_vel(const smjo_model* m, smjo_data* d) {
+  memset(d->cvel, 0, 48);
+  for (int b = 1; b < m->nbody; b++) {
+    double cv[6];
+    memcpy(cv, d->cvel + 6 * m->body_parentid[b], 48);
+    int da = m->body_dofadr[b];
+    for (int j = m->body_jntadr[b]; j < m->body_jntadr[b] + m->body_jntnum[b]; j++) {
+      int a = m->jnt_dofadr[j];
+      if (m->jnt_type[j] == JNT_FREE) {
+        memset(d->cdof_dot + 6 * a, 0, sizeof(double) * 18);
+        for (int k = 0; k < 3; k++)
+          for (int x = 0; x < 6; x++) cv[x] += d->cdof[6 * (a + k) + x] * d->qvel[a + k];
+        for (int k = 3; k < 6; k++) cross_motion(d->cdof_dot + 6 * (a + k), cv, d->cdof + 6 * (a + k));
+        for (int k = 3; k < 6; k++)
+          for (int x = 0; x < 6; x++) cv[x] += d->cdof[6 * (a + k) + x] * d->qvel[a + k];
+      } else {
+        cross_motion(d->cdof_dot + 6 * a, cv, d->cdof + 6 * a);
+        for (int x = 0; x < 6; x++) cv[x] += d->cdof[6 * a + x] * d->qvel[a];
+      }
+    }
+    (void)da;
+    memcpy(d->cvel + 6 * b, cv, 48);
+  }
+}
+
+/* [MJ] mj_passive: springs, dampers, gravity compensation */
+static void passive(const smjo_model* m, smjo_data* d) {
+  int nv = m->nv;
+  for (int k = 0; k < nv; k++) d->qfrc_passive[k] = -m->dof_damping[k] * d->qvel[k];
+  for (int j = 0; j < m->njnt; j++) {
+    if (m->jnt_type[j] == JNT_FREE || m->jnt_stiffness[j] == 0) continue;
+    int qa = m->jnt_qposadr[j];
+    d->qfrc_passive[m->jnt_dofadr[j]] -= m->jnt_stiffness[j] * (d->qpos[qa] - m->qpos_spring[qa]);
+  }
+  double* jp = d->scratch;
+  for (int b = 1; b < m->nbody; b++) {
+    if (m->body_gravcomp[b] == 0 || m->body_mass[b] == 0) continue;
+    double f[3];
+    for (int k = 0; k < 3; k++) f[k] = -m->gravity[k] * m->body_mass[b] * m->body_gravcomp[b];
+    jac_point(m, d, jp, NULL, d->xipos + 3 * b, b);
+    for (int k = 0; k < nv; k++) d->qfrc_passive[k] += jp[k] * f[0] + jp[nv + k] * f[1] + jp[2 * nv + k] * f[2];
+  }
+}
+
+/* [MJ] mj_rne(flg_acc=0): Coriolis, centrifugal, gravity */
+static void rne_bias(const smjo_model* m, smjo_data* d) {
+  int nb = m->nbody, nv = m->nv;
+  double* cacc = d->cacc; double* cfrc = d->cfrc;
+  memset(cacc, 0, 48);
+  for (int k = 0; k < 3; k++) cacc[3 + k] = -m->gravity[k];
+  for (int b = 1; b < nb; b++) {
+    double a[6], t[6], t2[6];
+    memcpy(a, cacc + 6 * m->body_parentid[b], 48);
+    for (int k = m->body_dofadr[b]; k < m->body_dofadr[b] + m->body_dofnum[b]; k++)
+      for (int x = 0; x < 6; x++) a[x] += d->cdof_dot[6 * k + x] * d->qvel[k];
+    memcpy(cacc + 6 * b, a, 48);
+    mul_inert_vec(t, d->cinert + 10 * b, a);
+    mul_inert_vec(t2, d->cinert + 10 * b, d->cvel + 6 * b);
+    double cf[6];
+    cross_force(cf, d->cvel + 6 * b, t2);
+    for (int x = 0; x < 6; x++) cfrc[6 * b + x] = t[x] + cf[x];
+  }
+  memset(cfrc, 0, 48);
+  for (int b = nb - 1; b > 0; b--) {
+    int p = m->body_parentid[b];
+    if (p > 0) for (int x = 0; x < 6; x++) cfrc[6 * p + x] += cfrc[6 * b + x];
+  }
+  for (int k = 0; k < nv; k++) {
+    double s = 0;
+    for (int x = 0; x < 6; x++) s += d->cdof[6 * k + x] * cfrc[6 * m->dof_bodyid[k] + x];
+    d->qfrc_bias[k] = s;
+  }
+}
+
+/* ------------------------------------------------------------------ B.6 actuation */
+static void fwd_actuation(const smjo_model* m, smjo_data* d) {
+  int nv = m->nv;
+  memset(d->qfrc_actuator, 0, sizeof(double) * nv);
+  for (int a = 0; a < m->nu; a++) {
+    double vel = 0, ctrl = d->ctrl[a];
+    for (int k = 0; k < nv; k++) vel += d->actuator_moment[a * nv + k] * d->qvel[k];
+    d->actuator_velocity[a] = vel;
+    if (m->actuator_ctrllimited[a]) ctrl = fmin(m->actuator_ctrlrange[2 * a + 1], fmax(m->actuator_ctrlrange[2 * a], ctrl));
+    const double *g = m->actuator_gainprm + 3 * a, *bp = m->actuator_biasprm + 3 * a;
+    double f = g[0] * ctrl;
+    if (m->actuator_biastype[a] == 1) f += bp[0] + bp[1] * d->actuator_length[a] + bp[2] * vel;
+    if (m->actuator_forcelimited[a]) f = fmin(m->actuator_forcerange[2 * a + 1], fmax(m->actuator_forcerange[2 * a], f));
+    d->actuator_force[a] = f;
+    for (int k = 0; k < nv; k++) d->qfrc_actuator[k] += d->actuator_moment[a * nv + k] * f;
+  }
+}
+
+/* ------------------------------------------------------------------ B.7 solver (PGS, dual) */
+static int qcqp(double* res, const double* Ain, const double* bin, const double* dd, double r, int n) {
+  double A[25], b[5], Ala[25], tmp[5], la = 0;
+  for (int i = 0; i < n; i++) {
+    b[i] = bin[i] * dd[i];
+    for (int j = 0; j < n; j++) A[i * n + j] = Ain[i * n + j] * dd[i] * dd[j];
+  }
+  for (int it = 0; it < 20; it++) {
+    memcpy(Ala, A, sizeof(double) * n * n);
+    for (int i = 0; i < n; i++) Ala[i * n + i] += la;
+    if (n == 2) { /* [MJ] mju_QCQP2: determinant test */
+      double det = Ala[0] * Ala[3] - Ala[1] * Ala[1];
+      if (det < 1e-10) { memset(res, 0, sizeof(double) * n); return 0; }
+      res[0] = -(Ala[3] * b[0] - Ala[1] * b[1]) / det; res[1] = -(-Ala[1] * b[0] + Ala[0] * b[1]) / det;
+      double P[4] = {Ala[3] / det, -Ala[1] / det, -Ala[1] / det, Ala[0] / det};
+      tmp[0] = P[0] * res[0] + P[1] * res[1]; tmp[1] = P[2] * res[0] + P[3] * res[1];
+    } else {
+      if (chol_factor(Ala, n, 1e-10) < n) { memset(res, 0, sizeof(double) * n); return 0; }
+      chol_solve(res, Ala, b, n);
+      for (int i = 0; i < n; i++) res[i] = -res[i];
+      chol_solve(tmp, Ala, res, n);
+    }
+    double val = -r * r, deriv = 0;
+    for (int i = 0; i < n; i++) { val += res[i] * res[i]; deriv -= 2 * res[i] * tmp[i]; }
+    if (val < 1e-10) break;
+    double delta = -val / deriv;
+    if (delta < 1e-10) break;
+    la += delta;
+  }
+  for (int i = 0; i < n; i++) res[i] *= dd[i];
+  return la != 0;
+}
+
+/* [MJ] mj_constraintUpdate (forces from primal residual jar), used only for the warm start */
+static void constraint_update_force(const smjo_model* m, smjo_data* d, const double* jar, double* force) {
+  for (int i = 0; i < d->nefc; i++) {
+    int t = d->efc_type[i];
+    double D = d->efc_D[i], R = d->efc_R[i];
+    if (t == C_EQUALITY) force[i] = -D * jar[i];
+    else if (t == C_FRICTION_DOF) {
+      double fl = d->efc_frictionloss[i];
+      if (jar[i] <= -R * fl) force[i] = fl;
+      else if (jar[i] >= R * fl) force[i] = -fl;
+      else force[i] = -D * jar[i];
+    } else if (t == C_LIMIT_JOINT || t == C_CONTACT_FRICTIONLESS) force[i] = jar[i] < 0 ? -D * jar[i] : 0;
+    else {
+      contact_t* con = d->contact + d->efc_id[i];
+      int dim = con->dim;
+      double mu = con->mu, U[6], N, T = 0;
+      U[0] = jar[i] * mu;
+      for (int j = 1; j < dim; j++) { U[j] = jar[i + j] * con->friction[j - 1]; T += U[j] * U[j]; }
+      N = U[0]; T = sqrt(T);
+      if ((T <= 0 && N >= 0) || (T > 0 && N >= mu * T)) { for (int j = 0; j < dim; j++) force[i + j] = 0; }
+      else if ((T <= 0 && N < 0) || (T > 0 && mu * N + T <= 0)) { for (int j = 0; j < dim; j++) force[i + j] = -d->efc_D[i + j] * jar[i + j]; }
+      else {
+        double Dm = d->efc_D[i] / fmax(mu * mu * (1 + mu * mu), MINVAL), NmT = N - mu * T;
+        force[i] = -Dm * NmT * mu;
+        for (int j = 1; j < dim; j++) force[i + j] = -force[i] / T * U[j] * con->friction[j - 1];
+      }
+      i += dim - 1;
+    }
+  }
+}
+
+/* [MJ] mj_fwdConstraint: warm start + mj_solPGS + dual->primal */
+static void fwd_constraint(const smjo_model* m, smjo_data* d) {
+  int nv = m->nv, ne = d->nefc;
+  if (ne == 0) {
+    memcpy(d->qacc, d->qacc_smooth, sizeof(double) * nv);
+    memcpy(d->qacc_warmstart, d->qacc_smooth, sizeof(double) * nv);
+    memset(d->qfrc_constraint, 0, sizeof(double) * nv);
+    d->solver_niter = 0;
+    return;
+  }
+  double* f = d->efc_force;
+  const double* AR = d->efc_AR;
+  /* b = J qacc_smooth - aref */
+  for (int i = 0; i < ne; i++) {
+    double s = 0;
+    for (int k = 0; k < nv; k++) s += d->efc_J[(size_t)i * nv + k] * d->qacc_smooth[k];
+    d->efc_b[i] = s - d->efc_aref[i];
+  }
+  /* warm start ([MJ] mj_warmstart, PGS branch) */
+  memset(f, 0, sizeof(double) * ne);
+  if (m->warmstart) {
+    double* jar = d->scratch;
+    for (int i = 0; i < ne; i++) {
+      double s = 0;
+      for (int k = 0; k < nv; k++) s += d->efc_J[(size_t)i * nv + k] * d->qacc_warmstart[k];
+      jar[i] = s - d->efc_aref[i];
+    }
+    constraint_update_force(m, d, jar, f);
+    double cost = 0;
+    for (int i = 0; i < ne; i++) {
+      double s = 0;
+      for (int j = 0; j < ne; j++) s += AR[(size_t)i * ne + j] * f[j];
+      cost += f[i] * (0.5 * s + d->efc_b[i]);
+    }
+    if (cost > 0) memset(f, 0, sizeof(double) * ne);
+  }
+  double scale = 1.0 / (m->meaninertia * (nv > 1 ? nv : 1));
+  int iter = 0;
+  for (; iter < m->iterations; iter++) {
+    double improvement = 0;
+    for (int i = 0; i < ne;) {
+      int t = d->efc_type[i], dim = 1;
+      contact_t* con = NULL;
+      if (t == C_CONTACT_ELLIPTIC) { con = d->contact + d->efc_id[i]; dim = con->dim; }
+      double res[6], old[6], Athis[36];
+      for (int r = 0; r < dim; r++) {
+        double s = d->efc_b[i + r];
+        for (int j = 0; j < ne; j++) s += AR[(size_t)(i + r) * ne + j] * f[j];
+        res[r] = s; old[r] = f[i + r];
+        for (int c = 0; c < dim; c++) Athis[r * dim + c] = AR[(size_t)(i + r) * ne + i + c];
+      }
+      if (dim == 1) {
+        f[i] -= res[0] / AR[(size_t)i * ne + i];
+        if (t == C_FRICTION_DOF) {
+          double fl = d->efc_frictionloss[i];
+          f[i] = fmin(fl, fmax(-fl, f[i]));
+        } else if (t != C_EQUALITY) f[i] = fmax(0, f[i]);
+      } else {
+        const double* mu = con->friction;
+        if (f[i] < MINVAL) { /* normal update */
+          f[i] -= res[0] / Athis[0];
+          if (f[i] < 0) f[i] = 0;
+          for (int j = 1; j < dim; j++) f[i + j] = 0;
+        } else { /* ray update */
+          double v[6], v1[6], denom = 0, num = 0;
+          for (int r = 0; r < dim; r++) v[r] = f[i + r];
+          for (int r = 0; r < dim; r++) {
+            v1[r] = 0;
+            for (int c = 0; c < dim; c++) v1[r] += Athis[r * dim + c] * v[c];
+            denom += v[r] * v1[r]; num += v[r] * res[r];
+          }
+          if (denom >= MINVAL) {
+            double x = -num / denom;
+            if (f[i] + x * v[0] < 0) x = -f[i] / v[0];
+            for (int r = 0; r < dim; r++) f[i + r] += x * v[r];
+          }
+        }
+        /* friction update with the normal fixed */
+        double Ac[25], bc[5], v[5];
+        int n = dim - 1;
+        for (int j = 0; j < n; j++) {
+          for (int c = 0; c < n; c++) Ac[j * n + c] = Athis[(j + 1) * dim + c + 1];
+          bc[j] = res[j + 1];
+          for (int c = 0; c < dim; c++) bc[j] -= Athis[(j + 1) * dim + c] * old[c];
+          bc[j] += Athis[(j + 1) * dim] * f[i];
+        }
+        if (f[i] < MINVAL) { for (int j = 1; j < dim; j++) f[i + j] = 0; }
+        else {
+          int active = qcqp(v, Ac, bc, mu, f[i], n);
+          if (active) {
+            double s = 0;
+            for (int j = 0; j < n; j++) s += v[j] * v[j] / (mu[j] * mu[j]);
+            s = sqrt(f[i] * f[i] / fmax(MINVAL, s));
+            for (int j = 0; j < n; j++) v[j] *= s;
+          }
+          for (int j = 0; j < n; j++) f[i + 1 + j] = v[j];
+        }
+      }
+      /* cost change ([MJ] costChange) */
+      double change = 0;
+      for (int r = 0; r < dim; r++) {
+        double dr = f[i + r] - old[r], s = 0;
+        for (int c = 0; c < dim; c++) s += Athis[r * dim + c] * (f[i + c] - old[c]);
+        change += dr * (0.5 * s + res[r]);
+      }
+      if (change > 1e-10) { for (int r = 0; r < dim; r++) f[i + r] = old[r]; change = 0; }
+      improvement -= change;
+      i += dim;
+    }
+    improvement *= scale;
+    if (!m->pgs_fixed_iter && improvement < m->tolerance) { iter++; break; }
+  }
+  d->solver_niter = iter;
+  for (int k = 0; k < nv; k++) {
+    double s = 0;
+    for (int i = 0; i < ne; i++) s += d->efc_J[(size_t)i * nv + k] * f[i];
+    d->qfrc_constraint[k] = s;
+  }
+  chol_solve(d->qacc, d->qL, d->qfrc_constraint, nv);
+  for (int k = 0; k < nv; k++) d->qacc[k] += d->qacc_smooth[k];
+  memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
+}
+
+/* ------------------------------------------------------------------ forward */
+void smjo_forward(const smjo_model* m, smjo_data* d) {
+  int nv = m->nv;
+  kinematics(m, d);
+  com_pos(m, d);
+  tendon_transmission(m, d);
+  crb_factor(m, d);
+  collision(m, d);
+  make_constraint(m, d);
+  com_vel(m, d);
+  passive(m, d);
+  /* [MJ] mj_referenceConstraint */
+  for (int i = 0; i < d->nefc; i++) {
+    double s = 0;
+    for (int k = 0; k < nv; k++) s += d->efc_J[(size_t)i * nv + k] * d->qvel[k];
+    d->efc_vel[i] = s;
+    d->efc_aref[i] = -d->efc_KBIP[4 * i + 1] * s - d->efc_KBIP[4 * i] * d->efc_KBIP[4 * i + 2] * (d->efc_pos[i] - d->efc_margin[i]);
+  }
+  rne_bias(m, d);
+  fwd_actuation(m, d);
+  for (int k = 0; k < nv; k++)
+    d->qfrc_smooth[k] = d->qfrc_passive[k] - d->qfrc_bias[k] + d->qfrc_applied[k] + d->qfrc_actuator[k];
+  chol_solve(d->qacc_smooth, d->qL, d->qfrc_smooth, nv);
+  fwd_constraint(m, d);
+}
+
+/* ------------------------------------------------------------------ B.8 integrate (implicitfast) */
+static void integrate_pos(const smjo_model* m, double* qpos, const double* qvel, double h) {
+  for (int j = 0; j < m->njnt; j++) {
+    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    if (m->jnt_type[j] == JNT_FREE) {
+      for (int k = 0; k < 3; k++) qpos[qa + k] += h * qvel[da + k];
+      double w[3] = {qvel[da + 3], qvel[da + 4], qvel[da + 5]}, ang = norm3(w) * h;
+      if (ang > 0) { /* [MJ] mju_quatIntegrate */
+        double ax[3] = {w[0], w[1], w[2]}, dq[4];
+        normalize3(ax);
+        axisangle2quat(dq, ax, ang);
+        quat_mul(qpos + qa + 3, qpos + qa + 3, dq);
+      }
+      quat_normalize(qpos + qa + 3);
+    } else qpos[qa] += h * qvel[da];
+  }
+}
+
+void smjo_step(const smjo_model* m, smjo_data* d) {
+  int nv = m->nv;
+  double h = m->timestep;
+  smjo_forward(m, d);
+  /* qH = M - h*D, D = d(qfrc_passive + qfrc_actuator)/d(qvel), symmetric part ([MJ] mjd_smooth_vel, flg_bias=0) */
+  memcpy(d->qH, d->qM, sizeof(double) * nv * nv);
+  for (int k = 0; k < nv; k++) d->qH[k * nv + k] += h * m->dof_damping[k];
+  for (int a = 0; a < m->nu; a++) {
+    if (m->actuator_biastype[a] != 1) continue;
+    double bv = m->actuator_biasprm[3 * a + 2];
+    if (bv == 0) continue;
+    if (m->actuator_forcelimited[a] &&
+        (d->actuator_force[a] <= m->actuator_forcerange[2 * a] || d->actuator_force[a] >= m->actuator_forcerange[2 * a + 1]))
+      continue;
+    const double* mo = d->actuator_moment + a * nv;
+    for (int i = 0; i < nv; i++)
+      if (mo[i] != 0)
+        for (int j = 0; j < nv; j++) d->qH[i * nv + j] -= h * bv * mo[i] * mo[j];
+  }
+  chol_factor(d->qH, nv, MINVAL);
+  double* rhs = d->scratch;
+  for (int k = 0; k < nv; k++) rhs[k] = d->qfrc_smooth[k] + d->qfrc_constraint[k];
+  chol_solve(rhs, d->qH, rhs, nv);
+  for (int k = 0; k < nv; k++) d->qvel[k] += h * rhs[k];
+  integrate_pos(m, d->qpos, d->qvel, h);
+  d->time += h;
+}
+
+void smjo_step_n(const smjo_model* m, smjo_data* d, int n) {
+  for (int i = 0; i < n; i++) smjo_step(m, d);
+}
+
+/* ------------------------------------------------------------------ B.9 sensors */
+static double ray_geom(const smjo_model* m, const smjo_data* d, int g, const double* pnt, const double* vec);
+
+void smjo_sensors(const smjo_model* m, smjo_data* d, int with_lidar) {
+  /* expects smjo_forward() state; [MJ] mj_rnePostConstraint for cacc, then mj_objectAcceleration/Velocity */
+  int nv = m->nv;
+  (void)nv;
+  double* cacc = d->cacc;
+  memset(cacc, 0, 48);
+  for (int k = 0; k < 3; k++) cacc[3 + k] = -m->gravity[k];
+  for (int b = 1; b < m->nbody; b++) {
+    double a[6];
+    memcpy(a, cacc + 6 * m->body_parentid[b], 48);
+    for (int k = m->body_dofadr[b]; k < m->body_dofadr[b] + m->body_dofnum[b]; k++)
+      for (int x = 0; x < 6; x++) a[x] += d->cdof_dot[6 * k + x] * d->qvel[k] + d->cdof[6 * k + x] * d->qacc[k];
+    memcpy(cacc + 6 * b, a, 48);
+  }
+  if (m->imu_site >= 0) {
+    int s = m->imu_site, b = m->site_bodyid[s];
+    const double* R = d->site_xmat + 9 * s;
+    const double* com = d->subtree_com + 3 * m->body_rootid[b];
+    double off[3] = {d->site_xpos[3 * s] - com[0], d->site_xpos[3 * s + 1] - com[1], d->site_xpos[3 * s + 2] - com[2]};
+    const double *cv = d->cvel + 6 * b, *ca = cacc + 6 * b;
+    double t[3], vlin[3], alin[3], c2[3];
+    cross3(t, cv, off);
+    for (int k = 0; k < 3; k++) vlin[k] = cv[3 + k] + t[k];
+    cross3(t, ca, off);
+    for (int k = 0; k < 3; k++) alin[k] = ca[3 + k] + t[k];
+    cross3(c2, cv, vlin);
+    for (int k = 0; k < 3; k++) alin[k] += c2[k];
+    mulmat3Tvec(d->gyro, R, cv);
+    mulmat3Tvec(d->accel, R, alin);
+  }
+  if (with_lidar)
+    for (int i = 0; i < m->nlidar; i++) {
+      int s = m->lidar_site[i], sb = m->site_bodyid[s];
+      const double* R = d->site_xmat + 9 * s;
+      double vec[3] = {R[2], R[5], R[8]}, best = -1;
+      for (int g = 0; g < m->ngeom; g++) {
+        if (m->geom_bodyid[g] == sb || m->geom_rgba[4 * g + 3] == 0) continue;
+        double x = ray_geom(m, d, g, d->site_xpos + 3 * s, vec);
+        if (x >= 0 && (best < 0 || x < best)) best = x;
+      }
+      if (best > m->lidar_cutoff && m->lidar_cutoff > 0) best = m->lidar_cutoff;
+      d->lidar[i] = best;
+    }
+}
+
+/* [MJ] mj_rayGeom for plane / sphere / cylinder / box; mesh geoms are tested against their convex hull's
+ * bounding box only when they collide (visual triangle meshes are outside the oracle's scope for now). */
+static double ray_quad(double a, double b, double c) {
+  double det = b * b - a * c;
+  if (det < MINVAL) return -1;
+  det = sqrt(det);
+  double x0 = (-b - det) / a, x1 = (-b + det) / a;
+  if (x0 >= 0) return x0;
+  if (x1 >= 0) return x1;
+  return -1;
+}
+static double ray_geom(const smjo_model* m, const smjo_data* d, int g, const double* pnt, const double* vec) {
+  const double *pos = d->geom_xpos + 3 * g, *R = d->geom_xmat + 9 * g, *size = m->geom_size + 3 * g;
+  double dif[3] = {pnt[0] - pos[0], pnt[1] - pos[1], pnt[2] - pos[2]}, lp[3], lv[3];
+  mulmat3Tvec(lp, R, dif);
+  mulmat3Tvec(lv, R, vec);
+  int t = m->geom_type[g];
+  if (t == G_PLANE) {
+    if (lv[2] > -MINVAL) return -1;
+    double x = -lp[2] / lv[2];
+    if (x < 0) return -1;
+    double px = lp[0] + x * lv[0], py = lp[1] + x * lv[1];
+    if ((size[0] <= 0 || fabs(px) <= size[0]) && (size[1] <= 0 || fabs(py) <= size[1])) return x;
+    return -1;
+  }
+  if (t == G_SPHERE) return ray_quad(dot3(lv, lv), dot3(lv, lp), dot3(lp, lp) - size[0] * size[0]);
+  if (t == G_CYLINDER) {
+    double best = -1;
+    double a = lv[0] * lv[0] + lv[1] * lv[1], b = lv[0] * lp[0] + lv[1] * lp[1], c = lp[0] * lp[0] + lp[1] * lp[1] - size[0] * size[0];
+    if (a > MINVAL) {
+      double x = ray_quad(a, b, c);
+      if (x >= 0 && fabs(lp[2] + x * lv[2]) <= size[1]) best = x;
+    }
+    if (fabs(lv[2]) > MINVAL)
+      for (int s = -1; s <= 1; s += 2) {
+        double x = (s * size[1] - lp[2]) / lv[2];
+        if (x >= 0) {
+          double px = lp[0] + x * lv[0], py = lp[1] + x * lv[1];
+          if (px * px + py * py <= size[0] * size[0] && (best < 0 || x < best)) best = x;
+        }
+      }
+    return best;
+  }
+  if (t == G_BOX) {
+    double best = -1;
+    for (int ax = 0; ax < 3; ax++) {
+      if (fabs(lv[ax]) < MINVAL) continue;
+      for (int s = -1; s <= 1; s += 2) {
+        double x = (s * size[ax] - lp[ax]) / lv[ax];
+        if (x < 0) continue;
+        int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+        if (fabs(lp[a1] + x * lv[a1]) <= size[a1] && fabs(lp[a2] + x * lv[a2]) <= size[a2] && (best < 0 || x < best)) best = x;
+      }
+    }
+    return best;
+  }
+  return -1;
+}

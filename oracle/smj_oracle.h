@@ -1,0 +1,45 @@
+/* TEST INFRASTRUCTURE ONLY -- fp64 CPU restatement of the physics step ("oracle").
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ * The product path (stretch_mujoco_amd/) never links, imports or calls it.
+ *
+ * PARITY UNPINNED: the arithmetic restated here lives in third-party mujoco==3.2.6
+ * (reference pyproject.toml:12), which is absent from /root/reference and from this
+ * image.  The one reference call site is stretch_mujoco/mujoco_server.py:378
+ * (`mj_step(self.mjmodel, self.mjdata)`).  Each function below names the MuJoCo stage
+ * it restates; none of it could be checked against MuJoCo here.
+ */
+#ifndef SMJ_ORACLE_H
+#define SMJ_ORACLE_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smjo_model smjo_model;
+typedef struct smjo_data smjo_data;
+
+smjo_model* smjo_load(const void* blob, size_t nbytes);
+void smjo_free_model(smjo_model* m);
+smjo_data* smjo_make_data(const smjo_model* m);
+void smjo_free_data(smjo_data* d);
+
+void smjo_reset(const smjo_model* m, smjo_data* d);          /* qpos=qpos0, qvel=0, ctrl=0, time=0 */
+void smjo_forward(const smjo_model* m, smjo_data* d);        /* mj_forward */
+void smjo_step(const smjo_model* m, smjo_data* d);           /* mj_step (implicitfast + PGS) */
+void smjo_step_n(const smjo_model* m, smjo_data* d, int n);
+void smjo_sensors(const smjo_model* m, smjo_data* d, int with_lidar); /* gyro, accel, lidar into d */
+
+/* options: name in {"iterations","tolerance","warmstart","pgs_fixed_iter","max_contacts_per_pair"} */
+int smjo_set_option(smjo_model* m, const char* name, double value);
+
+/* array access for tests: returns pointer (double*) or NULL; *n receives element count.
+ * int-typed arrays are exposed through smjo_get_int. */
+double* smjo_get(smjo_data* d, const char* name, int* n);
+int* smjo_get_int(smjo_data* d, const char* name, int* n);
+int smjo_dim(const smjo_model* m, const char* name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1054 @@
+"""MJCF -> compiled model arrays for the batched Stretch simulator.
+
+Stands in for `MjModel.from_xml_path(scene_xml_path)` in the reference
+(`stretch_mujoco/mujoco_server.py:252`): it resolves default classes,
+`<include>`, `<replicate>`, orientation forms, mesh mass properties and convex
+hulls, and produces the flat arrays consumed by the HIP kernels (through the
+C-ABI blob, see model_blob.py) and by the fp64 CPU oracle.
+
+Only the MJCF subset used by `stretch_mujoco/models/{stretch,scene,docking_station}.xml`
+and by simple primitive scenes is supported.  Semantics follow MuJoCo 3.2.6's
+documented compiler behaviour ([MJ] in SURVEY.md); MuJoCo itself is not
+available to cross-check, so every derived constant here is "parity unpinned".
+
+Host-side, offline, numpy only.  Nothing in here runs on the hot path.
+"""
+from __future__ import annotations
+
+import copy
+import json
+import math
+import os
+import struct
+import xml.etree.ElementTree as ET
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+# MuJoCo enum values kept so that dumps can be diffed against a real MjModel.
+JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = 0, 1, 2, 3
+GEOM_PLANE, GEOM_HFIELD, GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH = range(8)
+GEOM_TYPES = {"plane": 0, "hfield": 1, "sphere": 2, "capsule": 3, "ellipsoid": 4, "cylinder": 5, "box": 6, "mesh": 7}
+MINVAL = 1e-15
+
+
+# ----------------------------------------------------------------------------- math
+def quat_mul(a, b):
+    a = np.asarray(a, float)
+    b = np.asarray(b, float)
+    return np.array([
+        a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3],
+        a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+        a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1],
+        a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0],
+    ])
+
+
+def quat_norm(q):
+    q = np.asarray(q, float)
+    n = np.linalg.norm(q)
+    return np.array([1.0, 0, 0, 0]) if n < MINVAL else q / n
+
+
+def quat_conj(q):
+    return np.array([q[0], -q[1], -q[2], -q[3]])
+
+
+def quat2mat(q):
+    w, x, y, z = q
+    return np.array([
+        [w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)],
+        [2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)],
+        [2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z],
+    ])
+
+
+def mat2quat(R):
+    # robust (Shepperd)
+    R = np.asarray(R, float)
+    t = np.trace(R)
+    if t > 0:
+        s = math.sqrt(t + 1.0) * 2
+        q = [0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s]
+    elif R[0, 0] > R[1, 1] and R[0, 0] > R[2, 2]:
+        s = math.sqrt(1.0 + R[0, 0] - R[1, 1] - R[2, 2]) * 2
+        q = [(R[2, 1] - R[1, 2]) / s, 0.25 * s, (R[0, 1] + R[1, 0]) / s, (R[0, 2] + R[2, 0]) / s]
+    elif R[1, 1] > R[2, 2]:
+        s = math.sqrt(1.0 + R[1, 1] - R[0, 0] - R[2, 2]) * 2
+        q = [(R[0, 2] - R[2, 0]) / s, (R[0, 1] + R[1, 0]) / s, 0.25 * s, (R[1, 2] + R[2, 1]) / s]
+    else:
+        s = math.sqrt(1.0 + R[2, 2] - R[0, 0] - R[1, 1]) * 2
+        q = [(R[1, 0] - R[0, 1]) / s, (R[0, 2] + R[2, 0]) / s, (R[1, 2] + R[2, 1]) / s, 0.25 * s]
+    return quat_norm(np.array(q))
+
+
+def axisangle2quat(axis, angle):
+    axis = np.asarray(axis, float)
+    n = np.linalg.norm(axis)
+    if n < MINVAL:
+        return np.array([1.0, 0, 0, 0])
+    s = math.sin(angle / 2)
+    return np.concatenate([[math.cos(angle / 2)], axis / n * s])
+
+
+def euler2quat(e, seq="xyz"):
+    """MuJoCo `euler` attribute: lowercase = intrinsic (rotating axes), applied left to right."""
+    q = np.array([1.0, 0, 0, 0])
+    for ang, ax in zip(e, seq):
+        axis = {"x": [1, 0, 0], "y": [0, 1, 0], "z": [0, 0, 1]}[ax.lower()]
+        r = axisangle2quat(axis, ang)
+        q = quat_mul(q, r) if ax.islower() else quat_mul(r, q)
+    return quat_norm(q)
+
+
+def zaxis2quat(z):
+    """Minimal rotation that takes (0,0,1) to z (MuJoCo `zaxis` attribute)."""
+    z = np.asarray(z, float)
+    z = z / np.linalg.norm(z)
+    c = np.cross([0, 0, 1.0], z)
+    s = np.linalg.norm(c)
+    ang = math.atan2(s, z[2])
+    if s < MINVAL:
+        return np.array([1.0, 0, 0, 0]) if z[2] > 0 else np.array([0.0, 1, 0, 0])
+    return axisangle2quat(c / s, ang)
+
+
+def _floats(s, n=None):
+    v = [float(x) for x in s.split()]
+    if n is not None and len(v) < n:
+        v = v + [0.0] * (n - len(v))
+    return v
+
+
+# ----------------------------------------------------------------------------- meshes
+def load_obj(path) -> Tuple[np.ndarray, np.ndarray]:
+    verts, faces = [], []
+    with open(path, "r", errors="ignore") as f:
+        for line in f:
+            if line.startswith("v "):
+                p = line.split()
+                verts.append((float(p[1]), float(p[2]), float(p[3])))
+            elif line.startswith("f "):
+                idx = [int(tok.split("/")[0]) for tok in line.split()[1:]]
+                idx = [i - 1 if i > 0 else len(verts) + i for i in idx]
+                for k in range(1, len(idx) - 1):
+                    faces.append((idx[0], idx[k], idx[k + 1]))
+    return np.array(verts, float).reshape(-1, 3), np.array(faces, np.int64).reshape(-1, 3)
+
+
+def load_stl(path) -> Tuple[np.ndarray, np.ndarray]:
+    with open(path, "rb") as f:
+        data = f.read()
+    n = struct.unpack_from("<I", data, 80)[0]
+    if 84 + 50 * n != len(data):
+        raise ValueError(f"{path}: only binary STL is supported")
+    rec = np.frombuffer(data, dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]), count=n, offset=84)
+    tri = rec["v"].astype(np.float64).reshape(-1, 3)
+    # merge repeated vertices (MuJoCo does the same for STL)
+    uniq, inv = np.unique(np.round(tri, 9), axis=0, return_inverse=True)
+    return uniq, inv.reshape(-1, 3).astype(np.int64)
+
+
+def load_mesh(path):
+    ext = os.path.splitext(path)[1].lower()
+    if ext == ".obj":
+        return load_obj(path)
+    if ext == ".stl":
+        return load_stl(path)
+    raise ValueError(f"unsupported mesh format: {path}")
+
+
+def _tet_cov(a, b, c, d):
+    """Covariance integral  int (x-0)(x-0)^T dV  of tetrahedra (a,b,c,d) stacked on axis 0, and their volumes."""
+    M = np.stack([b - a, c - a, d - a], axis=-1)  # columns
+    det = np.linalg.det(M)
+    vol = det / 6.0
+    s = a + b + c + d
+    # int x x^T dV = vol/20 * (sum_i p_i p_i^T + s s^T)
+    P = sum(np.einsum("ni,nj->nij", p, p) for p in (a, b, c, d)) + np.einsum("ni,nj->nij", s, s)
+    return P * (vol / 20.0)[:, None, None], vol, s / 4.0
+
+
+def mesh_volume_props(verts, faces, legacy=True):
+    """(volume, com, inertia tensor about com) of a unit-density solid mesh.
+
+    `legacy=True` reproduces MuJoCo <= 3.2 default (exactmeshinertia="false"): tetrahedra
+    are built from the area-weighted surface centroid and their volumes are taken in
+    absolute value.  `legacy=False` is the exact signed-volume integration.
+    """
+    a, b, c = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
+    area2 = np.linalg.norm(np.cross(b - a, c - a), axis=1)
+    keep = area2 > 1e-18
+    a, b, c, area2 = a[keep], b[keep], c[keep], area2[keep]
+    cen0 = ((a + b + c) / 3.0 * area2[:, None]).sum(0) / area2.sum()
+    o = np.broadcast_to(cen0, a.shape)
+    cov, vol, tc = _tet_cov(o, a, b, c)
+    if legacy:
+        sgn = np.sign(vol)
+        sgn[sgn == 0] = 1.0
+        cov = cov * sgn[:, None, None]
+        vol = np.abs(vol)
+    V = vol.sum()
+    if abs(V) < 1e-18:
+        raise ValueError("mesh volume is zero")
+    com = (tc * vol[:, None]).sum(0) / V
+    C = cov.sum(0)  # second moment about origin
+    C = C - V * np.outer(com, com)
+    inertia = np.trace(C) * np.eye(3) - C
+    return float(V), com, inertia
+
+
+def mesh_shell_props(verts, faces):
+    """(area, com, inertia about com) of a unit-surface-density shell."""
+    a, b, c = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
+    area = 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
+    A = area.sum()
+    com = ((a + b + c) / 3.0 * area[:, None]).sum(0) / A
+    s = a + b + c
+    P = sum(np.einsum("ni,nj->nij", p, p) for p in (a, b, c)) + np.einsum("ni,nj->nij", s, s)
+    C = (P * (area / 12.0)[:, None, None]).sum(0) - A * np.outer(com, com)
+    inertia = np.trace(C) * np.eye(3) - C
+    return float(A), com, inertia
+
+
+def convex_hull_vertices(verts):
+    from scipy.spatial import ConvexHull, QhullError
+
+    v = np.unique(np.round(verts, 9), axis=0)
+    try:
+        hull = ConvexHull(v)
+        return v[np.sort(hull.vertices)]
+    except QhullError:
+        hull = ConvexHull(v, qhull_options="QJ")
+        return v[np.sort(hull.vertices)]
+
+
+# ----------------------------------------------------------------------------- defaults
+_GEOM_DEF = dict(type="sphere", size="0 0 0", pos="0 0 0", contype="1", conaffinity="1", condim="3", group="0",
+                 priority="0", friction="1 0.005 0.0001", solmix="1", solref="0.02 1",
+                 solimp="0.9 0.95 0.001 0.5 2", margin="0", gap="0", density="1000", rgba="0.5 0.5 0.5 1")
+_JOINT_DEF = dict(type="hinge", pos="0 0 0", axis="0 0 1", stiffness="0", damping="0", armature="0",
+                  frictionloss="0", springref="0", ref="0", margin="0", solreflimit="0.02 1",
+                  solimplimit="0.9 0.95 0.001 0.5 2", solreffriction="0.02 1",
+                  solimpfriction="0.9 0.95 0.001 0.5 2")
+_SITE_DEF = dict(pos="0 0 0", size="0.005")
+_CAM_DEF = dict(pos="0 0 0", fovy="45")
+_EQ_DEF = dict(solref="0.02 1", solimp="0.9 0.95 0.001 0.5 2", active="true")
+_ACT_DEF = dict(gainprm=[1.0, 0, 0], biasprm=[0.0, 0, 0], gear=[1.0, 0, 0, 0, 0, 0], ctrlrange=None, forcerange=None,
+                ctrllimited="auto", forcelimited="auto", gaintype="fixed", biastype="none")
+_ACT_TAGS = ("general", "motor", "position", "velocity")
+
+
+def _apply_actuator(tag: str, attrib: Dict[str, str], st: dict) -> dict:
+    """Fold one <general|motor|position|velocity> element (or default) into actuator state `st`.
+
+    Shortcut semantics [MJ]: <position> sets gain=kp and ALWAYS biasprm[1]=-gainprm[0] (also when
+    kp is inherited), biasprm[2]=-kv only when kv is given; <velocity> sets gain=kv,
+    bias=(0,0,-kv).
+    """
+    st = copy.deepcopy(st)
+    if "gainprm" in attrib:
+        v = _floats(attrib["gainprm"])
+        st["gainprm"][: len(v)] = v[:3]
+    if "biasprm" in attrib:
+        v = _floats(attrib["biasprm"])
+        st["biasprm"][: len(v)] = v[:3]
+    if "gear" in attrib:
+        v = _floats(attrib["gear"])
+        st["gear"][: len(v)] = v
+    for k in ("ctrlrange", "forcerange"):
+        if k in attrib:
+            st[k] = _floats(attrib[k], 2)
+    for k in ("ctrllimited", "forcelimited", "gaintype", "biastype"):
+        if k in attrib:
+            st[k] = attrib[k]
+    if tag == "motor":
+        st["gainprm"] = [1.0, 0, 0]
+        st["biasprm"] = [0.0, 0, 0]
+        st["gaintype"], st["biastype"] = "fixed", "none"
+    elif tag == "position":
+        if "kp" in attrib:
+            st["gainprm"][0] = float(attrib["kp"])
+        st["biasprm"][1] = -st["gainprm"][0]
+        if "kv" in attrib:
+            st["biasprm"][2] = -float(attrib["kv"])
+        st["gaintype"], st["biastype"] = "fixed", "affine"
+    elif tag == "velocity":
+        if "kv" in attrib:
+            st["gainprm"][0] = float(attrib["kv"])
+        st["biasprm"] = [0.0, 0.0, -st["gainprm"][0]]
+        st["gaintype"], st["biastype"] = "fixed", "affine"
+    return st
+
+
+class _Defaults:
+    def __init__(self):
+        self.cls: Dict[str, dict] = {"main": dict(geom={}, joint={}, site={}, camera={}, equality={}, mesh={},
+                                                  actuator=copy.deepcopy(_ACT_DEF))}
+
+    def parse(self, elem: ET.Element, parent: str = "main", top=True):
+        name = elem.get("class", "main" if top else None)
+        if name is None:
+            raise ValueError("nested <default> needs a class")
+        if name not in self.cls:
+            self.cls[name] = copy.deepcopy(self.cls[parent])
+        cur = self.cls[name]
+        for ch in elem:
+            if ch.tag == "default":
+                continue
+            if ch.tag in _ACT_TAGS:
+                cur["actuator"] = _apply_actuator(ch.tag, ch.attrib, cur["actuator"])
+            elif ch.tag in cur:
+                cur[ch.tag].update(ch.attrib)
+        for ch in elem:
+            if ch.tag == "default":
+                self.parse(ch, name, top=False)
+
+    def get(self, cls: Optional[str], tag: str) -> dict:
+        return self.cls[cls or "main"][tag]
+
+
+# ----------------------------------------------------------------------------- spec tree
+class _Body:
+    def __init__(self, name, parent, pos, quat, gravcomp=0.0):
+        self.name, self.parent, self.pos, self.quat, self.gravcomp = name, parent, np.asarray(pos, float), quat, gravcomp
+        self.joints: List[dict] = []
+        self.geoms: List[dict] = []
+        self.sites: List[dict] = []
+        self.cams: List[dict] = []
+        self.id = -1
+
+
+def _orient(attrib: Dict[str, str]) -> np.ndarray:
+    if "quat" in attrib:
+        return quat_norm(_floats(attrib["quat"]))
+    if "euler" in attrib:
+        return euler2quat(_floats(attrib["euler"]))
+    if "zaxis" in attrib:
+        return zaxis2quat(_floats(attrib["zaxis"]))
+    if "axisangle" in attrib:
+        v = _floats(attrib["axisangle"])
+        return axisangle2quat(v[:3], v[3])
+    return np.array([1.0, 0, 0, 0])
+
+
+def _expand_includes(root: ET.Element, base_dir: str) -> List[Tuple[ET.Element, str]]:
+    """Return [(mujoco-root, directory)] in document order with includes expanded depth-first."""
+    out = []
+    own = ET.Element("mujoco", root.attrib)
+    pending = []
+    for ch in root:
+        if ch.tag == "include":
+            if len(own):
+                pending.append((own, base_dir))
+                own = ET.Element("mujoco", root.attrib)
+            p = ch.get("file")
+            p = p if os.path.isabs(p) else os.path.join(base_dir, p)
+            sub = ET.parse(p).getroot()
+            pending.extend(_expand_includes(sub, os.path.dirname(os.path.abspath(p))))
+        else:
+            own.append(ch)
+    if len(own):
+        pending.append((own, base_dir))
+    out.extend(pending)
+    return out
+
+
+class MjcfCompiler:
+    def __init__(self):
+        self.defaults = _Defaults()
+        self.meshes: Dict[str, dict] = {}
+        self.materials: Dict[str, np.ndarray] = {}
+        self.bodies: List[_Body] = [_Body("world", None, [0, 0, 0], np.array([1.0, 0, 0, 0]))]
+        self.excludes: List[Tuple[str, str]] = []
+        self.tendons: List[dict] = []
+        self.equalities: List[dict] = []
+        self.actuators: List[dict] = []
+        self.sensors: List[dict] = []
+        self.keys: List[dict] = []
+        self.option = dict(timestep=0.002, gravity=[0, 0, -9.81], integrator="Euler", impratio=1.0, cone="pyramidal",
+                           solver="Newton", iterations=100, tolerance=1e-8, multiccd=False)
+        self.stat_extent: Optional[float] = None
+        self.znear, self.zfar = 0.01, 50.0
+        self.meshes_missing: List[str] = []
+
+    # ---- parsing
+    def parse_file(self, path: str):
+        root = ET.parse(path).getroot()
+        self.parse_root(root, os.path.dirname(os.path.abspath(path)))
+
+    def parse_string(self, xml: str, base_dir: str):
+        self.parse_root(ET.fromstring(xml), base_dir)
+
+    def parse_root(self, root: ET.Element, base_dir: str):
+        parts = _expand_includes(root, base_dir)
+        # pass 1: compiler/defaults/assets of every part (MuJoCo parses defaults before bodies of the same file;
+        # class names are global so doing all of them first is equivalent for non-conflicting files)
+        for part, d in parts:
+            assetdir = d
+            for ch in part:
+                if ch.tag == "compiler":
+                    if ch.get("angle", "degree") != "radian":
+                        raise ValueError("only angle=radian is supported")
+                    assetdir = os.path.join(d, ch.get("assetdir", ch.get("meshdir", "")))
+            part.set("_assetdir", assetdir)
+            for ch in part:
+                if ch.tag == "default":
+                    self.defaults.parse(ch)
+        for part, d in parts:
+            for ch in part:
+                if ch.tag == "asset":
+                    self._parse_assets(ch, part.get("_assetdir"))
+                elif ch.tag == "option":
+                    for k in ("timestep", "impratio", "tolerance"):
+                        if k in ch.attrib:
+                            self.option[k] = float(ch.get(k))
+                    if "iterations" in ch.attrib:
+                        self.option["iterations"] = int(ch.get("iterations"))
+                    for k in ("integrator", "cone", "solver"):
+                        if k in ch.attrib:
+                            self.option[k] = ch.get(k)
+                    if "gravity" in ch.attrib:
+                        self.option["gravity"] = _floats(ch.get("gravity"))
+                    for fl in ch.findall("flag"):
+                        if fl.get("multiccd") == "enable":
+                            self.option["multiccd"] = True
+                elif ch.tag == "statistic":
+                    if "extent" in ch.attrib:
+                        self.stat_extent = float(ch.get("extent"))
+                elif ch.tag == "visual":
+                    for mp in ch.findall("map"):
+                        self.znear = float(mp.get("znear", self.znear))
+                        self.zfar = float(mp.get("zfar", self.zfar))
+        for part, d in parts:
+            for ch in part:
+                if ch.tag == "worldbody":
+                    self._parse_body_children(ch, self.bodies[0], None)
+                elif ch.tag == "contact":
+                    for ex in ch.findall("exclude"):
+                        self.excludes.append((ex.get("body1"), ex.get("body2")))
+                elif ch.tag == "tendon":
+                    for t in ch.findall("fixed"):
+                        self.tendons.append(dict(name=t.get("name"), joints=[(j.get("joint"), float(j.get("coef", "1")))
+                                                                             for j in t.findall("joint")]))
+                elif ch.tag == "equality":
+                    for e in ch:
+                        if e.tag != "joint":
+                            raise ValueError(f"unsupported equality type {e.tag}")
+                        a = dict(_EQ_DEF)
+                        a.update(self.defaults.get(e.get("class"), "equality"))
+                        a.update(e.attrib)
+                        self.equalities.append(a)
+                elif ch.tag == "actuator":
+                    for a in ch:
+                        if a.tag not in _ACT_TAGS:
+                            raise ValueError(f"unsupported actuator {a.tag}")
+                        st = _apply_actuator(a.tag, a.attrib, self.defaults.get(a.get("class"), "actuator"))
+                        st.update(name=a.get("name"), joint=a.get("joint"), tendon=a.get("tendon"))
+                        self.actuators.append(st)
+                elif ch.tag == "sensor":
+                    for s in ch:
+                        self.sensors.append(dict(type=s.tag, **s.attrib))
+                elif ch.tag == "keyframe":
+                    for k in ch.findall("key"):
+                        self.keys.append(dict(k.attrib))
+
+    def _parse_assets(self, elem, assetdir):
+        for ch in elem:
+            if ch.tag == "mesh":
+                f = ch.get("file")
+                name = ch.get("name") or os.path.splitext(os.path.basename(f))[0]
+                self.meshes[name] = dict(path=os.path.join(assetdir, f), scale=_floats(ch.get("scale", "1 1 1")))
+            elif ch.tag == "material":
+                self.materials[ch.get("name")] = np.array(_floats(ch.get("rgba", "1 1 1 1")))
+
+    def _parse_body_children(self, elem, body: _Body, childclass, frame=None):
+        """frame = (pos, quat) of an enclosing <replicate>/<frame>, applied to direct children."""
+        fpos, fquat = frame if frame is not None else (np.zeros(3), np.array([1.0, 0, 0, 0]))
+
+        def place(attrib):
+            p = np.array(_floats(attrib.get("pos", "0 0 0")))
+            q = _orient(attrib)
+            return fpos + quat2mat(fquat) @ p, quat_norm(quat_mul(fquat, q))
+
+        for ch in elem:
+            cls = ch.get("class", childclass)
+            if ch.tag == "body":
+                p, q = place(ch.attrib)
+                b = _Body(ch.get("name"), body, p, q, float(ch.get("gravcomp", "0")))
+                self.bodies.append(b)
+                self._parse_body_children(ch, b, ch.get("childclass", childclass))
+            elif ch.tag in ("joint", "freejoint"):
+                a = dict(_JOINT_DEF)
+                if ch.tag == "freejoint":
+                    a["type"] = "free"
+                else:
+                    a.update(self.defaults.get(cls, "joint"))
+                a.update(ch.attrib)
+                body.joints.append(a)
+            elif ch.tag == "geom":
+                a = dict(_GEOM_DEF)
+                a.update(self.defaults.get(cls, "geom"))
+                a.update(ch.attrib)
+                a["_pos"], a["_quat"] = place({k: a[k] for k in ("pos", "quat", "euler", "zaxis", "axisangle") if k in a})
+                body.geoms.append(a)
+            elif ch.tag == "site":
+                a = dict(_SITE_DEF)
+                a.update(self.defaults.get(cls, "site"))
+                a.update(ch.attrib)
+                a["_pos"], a["_quat"] = place(a)
+                if frame is not None and "_suffix" in elem.attrib and "name" in a:
+                    a["name"] = a["name"] + elem.get("_suffix")
+                body.sites.append(a)
+            elif ch.tag == "camera":
+                a = dict(_CAM_DEF)
+                a.update(self.defaults.get(cls, "camera"))
+                a.update(ch.attrib)
+                a["_pos"], a["_quat"] = place(a)
+                body.cams.append(a)
+            elif ch.tag == "replicate":
+                count = int(ch.get("count"))
+                dq = _orient(ch.attrib)
+                dp = np.array(_floats(ch.get("offset", "0 0 0")))
+                width = len(str(count - 1))
+                p, q = fpos.copy(), fquat.copy()
+                for i in range(count):
+                    ch.set("_suffix", str(i).zfill(width))
+                    self._parse_body_children(ch, body, childclass, frame=(p.copy(), q.copy()))
+                    p = p + quat2mat(q) @ dp
+                    q = quat_norm(quat_mul(q, dq))
+            elif ch.tag in ("light", "inertial"):
+                if ch.tag == "inertial":
+                    raise ValueError("<inertial> not supported")
+            else:
+                raise ValueError(f"unsupported element <{ch.tag}> in body")
+
+    # ---- compile
+    def compile(self) -> Dict[str, np.ndarray]:
+        bodies = self.bodies  # already depth-first document order, parents before children
+        for i, b in enumerate(bodies):
+            b.id = i
+        nbody = len(bodies)
+        bid = {b.name: b.id for b in bodies if b.name}
+
+        mesh_cache: Dict[str, dict] = {}
+
+        def mesh_data(name):
+            if name in mesh_cache:
+                return mesh_cache[name]
+            m = self.meshes[name]
+            if not os.path.exists(m["path"]):
+                mesh_cache[name] = None
+                self.meshes_missing.append(name)
+                return None
+            v, f = load_mesh(m["path"])
+            v = v * np.array(m["scale"])
+            if np.prod(m["scale"]) < 0:
+                f = f[:, ::-1]
+            mesh_cache[name] = dict(v=v, f=f)
+            return mesh_cache[name]
+
+        # ---------------- joints / dofs
+        jnt_type, jnt_qposadr, jnt_dofadr, jnt_bodyid, jnt_pos, jnt_axis = [], [], [], [], [], []
+        jnt_stiffness, jnt_range, jnt_limited, jnt_margin, jnt_solref, jnt_solimp, jnt_names = [], [], [], [], [], [], []
+        dof_bodyid, dof_jntid, dof_parentid, dof_armature, dof_damping, dof_frictionloss = [], [], [], [], [], []
+        dof_solref, dof_solimp = [], []
+        qpos0, qpos_spring = [], []
+        body_jntadr, body_jntnum, body_dofadr, body_dofnum = [], [], [], []
+        body_lastdof = [-1] * nbody
+        for b in bodies:
+            body_jntadr.append(len(jnt_type) if b.joints else -1)
+            body_jntnum.append(len(b.joints))
+            body_dofadr.append(len(dof_bodyid) if b.joints else -1)
+            last = body_lastdof[b.parent.id] if b.parent is not None else -1
+            nd0 = len(dof_bodyid)
+            for j in b.joints:
+                t = {"free": JNT_FREE, "ball": JNT_BALL, "slide": JNT_SLIDE, "hinge": JNT_HINGE}[j["type"]]
+                if t == JNT_BALL:
+                    raise ValueError("ball joints not supported")
+                jid = len(jnt_type)
+                jnt_names.append(j.get("name", f"joint{jid}"))
+                jnt_type.append(t)
+                jnt_qposadr.append(len(qpos0))
+                jnt_dofadr.append(len(dof_bodyid))
+                jnt_bodyid.append(b.id)
+                jnt_pos.append(_floats(j["pos"], 3))
+                ax = np.array(_floats(j["axis"], 3))
+                jnt_axis.append(ax / max(np.linalg.norm(ax), MINVAL))
+                jnt_stiffness.append(float(j["stiffness"]))
+                rng = _floats(j["range"], 2) if "range" in j else [0.0, 0.0]
+                lim = j.get("limited", "auto")
+                jnt_limited.append(int((lim == "true") or (lim == "auto" and "range" in j)))
+                jnt_range.append(rng)
+                jnt_margin.append(float(j["margin"]))
+                jnt_solref.append(_floats(j["solreflimit"], 2))
+                jnt_solimp.append(_floats(j["solimplimit"], 5))
+                nd = 6 if t == JNT_FREE else 1
+                for k in range(nd):
+                    dof_bodyid.append(b.id)
+                    dof_jntid.append(jid)
+                    dof_parentid.append(last)
+                    last = len(dof_bodyid) - 1
+                    dof_armature.append(float(j["armature"]))
+                    dof_damping.append(float(j["damping"]))
+                    dof_frictionloss.append(float(j["frictionloss"]))
+                    dof_solref.append(_floats(j["solreffriction"], 2))
+                    dof_solimp.append(_floats(j["solimpfriction"], 5))
+                if t == JNT_FREE:
+                    qpos0.extend(list(b.pos) + list(b.quat))
+                    qpos_spring.extend(list(b.pos) + list(b.quat))
+                else:
+                    qpos0.append(float(j["ref"]))
+                    qpos_spring.append(float(j["springref"]))
+            body_dofnum.append(len(dof_bodyid) - nd0)
+            body_lastdof[b.id] = last
+        nq, nv, njnt = len(qpos0), len(dof_bodyid), len(jnt_type)
+        jid_by_name = {n: i for i, n in enumerate(jnt_names)}
+
+        body_parentid = [0 if b.parent is None else b.parent.id for b in bodies]
+        body_weldid = [0] * nbody
+        body_rootid = [0] * nbody
+        for b in bodies[1:]:
+            body_weldid[b.id] = b.id if b.joints else body_weldid[b.parent.id]
+            body_rootid[b.id] = b.id if b.parent.id == 0 else body_rootid[b.parent.id]
+
+        # ---------------- geoms + inertia
+        G = dict(type=[], bodyid=[], pos=[], quat=[], size=[], contype=[], conaffinity=[], condim=[], group=[],
+                 priority=[], friction=[], solmix=[], solref=[], solimp=[], margin=[], gap=[], rgba=[], rbound=[],
+                 center=[], aabb=[], hulladr=[], hullnum=[], meshid=[], name=[])
+        hull_verts: List[np.ndarray] = []
+        hull_cache: Dict[str, Tuple[int, int]] = {}
+        mesh_names: List[str] = []
+        body_mass = np.zeros(nbody)
+        body_ipos = np.zeros((nbody, 3))
+        body_iquat = np.tile([1.0, 0, 0, 0], (nbody, 1))
+        body_inertia = np.zeros((nbody, 3))
+        nhv = 0
+        for b in bodies:
+            parts = []  # (mass, com_in_body, inertia_about_com_in_body_axes)
+            for g in b.geoms:
+                t = GEOM_TYPES[g["type"]]
+                size = _floats(g["size"], 3)
+                gpos, gquat = g["_pos"], g["_quat"]
+                R = quat2mat(gquat)
+                md = None
+                if t == GEOM_MESH:
+                    md = mesh_data(g["mesh"])
+                    if md is None:
+                        # missing visual-only asset (.MISSING_LARGE_BLOBS); must not carry mass or collide
+                        if float(g.get("mass", "-1")) > 0 or int(g["contype"]) or int(g["conaffinity"]):
+                            raise FileNotFoundError(self.meshes[g["mesh"]]["path"])
+                        continue
+                # mass properties
+                mass_attr = float(g["mass"]) if "mass" in g else None
+                dens = float(g["density"])
+                shell = g.get("shellinertia", "false") == "true"
+                vol, com, I = 0.0, np.zeros(3), np.zeros((3, 3))
+                if t == GEOM_MESH:
+                    if (mass_attr is None and dens > 0) or (mass_attr is not None and mass_attr > 0):
+                        vol, com, I = mesh_shell_props(md["v"], md["f"]) if shell else mesh_volume_props(md["v"], md["f"])
+                elif t == GEOM_SPHERE:
+                    r = size[0]
+                    vol = 4.0 / 3 * math.pi * r ** 3
+                    I = np.eye(3) * (0.4 * vol * r * r)
+                elif t == GEOM_BOX:
+                    vol = 8 * size[0] * size[1] * size[2]
+                    I = np.diag([vol / 3 * (size[1] ** 2 + size[2] ** 2), vol / 3 * (size[0] ** 2 + size[2] ** 2),
+                                 vol / 3 * (size[0] ** 2 + size[1] ** 2)])
+                elif t == GEOM_CYLINDER:
+                    r, h = size[0], size[1]
+                    vol = math.pi * r * r * 2 * h
+                    ixx = vol * (3 * r * r + (2 * h) ** 2) / 12
+                    I = np.diag([ixx, ixx, vol * r * r / 2])
+                elif t == GEOM_CAPSULE:
+                    r, h = size[0], size[1]
+                    vc, vs = math.pi * r * r * 2 * h, 4.0 / 3 * math.pi * r ** 3
+                    vol = vc + vs
+                    izz = vc * r * r / 2 + vs * 0.4 * r * r
+                    ixx = vc * (3 * r * r + (2 * h) ** 2) / 12 + vs * (0.4 * r * r + h * h + 0.75 * h * r)
+                    I = np.diag([ixx, ixx, izz])
+                elif t == GEOM_ELLIPSOID:
+                    vol = 4.0 / 3 * math.pi * size[0] * size[1] * size[2]
+                    I = np.diag([vol / 5 * (size[1] ** 2 + size[2] ** 2), vol / 5 * (size[0] ** 2 + size[2] ** 2),
+                                 vol / 5 * (size[0] ** 2 + size[1] ** 2)])
+                if t != GEOM_PLANE and vol > 0:
+                    m = mass_attr if mass_attr is not None else dens * vol
+                    if m > 0:
+                        sc = m / vol
+                        parts.append((m, gpos + R @ com, R @ (I * sc) @ R.T))
+                # collision / ray shape data
+                collides = bool(int(g["contype"]) or int(g["conaffinity"]))
+                if t == GEOM_MESH and not collides:
+                    adr, num, meshid = -1, 0, -1
+                    lo, hi = md["v"].min(0), md["v"].max(0)
+                    cen = 0.5 * (lo + hi)
+                    rb = float(np.linalg.norm(md["v"] - cen, axis=1).max())
+                    aabb = np.concatenate([cen, 0.5 * (hi - lo)])
+                elif t == GEOM_MESH:
+                    key = g["mesh"]
+                    if key not in hull_cache:
+                        hv = convex_hull_vertices(md["v"])
+                        hull_cache[key] = (nhv, len(hv))
+                        hull_verts.append(hv)
+                        nhv += len(hv)
+                        mesh_names.append(key)
+                    adr, num = hull_cache[key]
+                    hv = hull_verts[mesh_names.index(key)]
+                    lo, hi = md["v"].min(0), md["v"].max(0)
+                    cen = 0.5 * (lo + hi)
+                    rb = float(np.linalg.norm(md["v"] - cen, axis=1).max())
+                    aabb = np.concatenate([cen, 0.5 * (hi - lo)])
+                    meshid = mesh_names.index(key)
+                else:
+                    adr, num, cen, meshid = -1, 0, np.zeros(3), -1
+                    if t == GEOM_PLANE:
+                        rb, aabb = 0.0, np.zeros(6)
+                    elif t == GEOM_SPHERE:
+                        rb, aabb = size[0], np.array([0, 0, 0, size[0], size[0], size[0]])
+                    elif t == GEOM_BOX:
+                        rb, aabb = float(np.linalg.norm(size)), np.array([0, 0, 0] + size)
+                    elif t == GEOM_CYLINDER:
+                        rb, aabb = math.hypot(size[0], size[1]), np.array([0, 0, 0, size[0], size[0], size[1]])
+                    elif t == GEOM_CAPSULE:
+                        rb, aabb = size[0] + size[1], np.array([0, 0, 0, size[0], size[0], size[0] + size[1]])
+                    elif t == GEOM_ELLIPSOID:
+                        rb, aabb = max(size), np.array([0, 0, 0] + size)
+                    else:
+                        raise ValueError("unsupported geom type")
+                rgba = np.array(_floats(g["rgba"], 4))
+                if "material" in g and g["rgba"] == _GEOM_DEF["rgba"]:
+                    rgba = self.materials.get(g["material"], rgba)
+                fr = _floats(g["friction"], 3)
+                G["type"].append(t); G["bodyid"].append(b.id); G["pos"].append(gpos); G["quat"].append(gquat)
+                G["size"].append(size); G["contype"].append(int(g["contype"])); G["conaffinity"].append(int(g["conaffinity"]))
+                G["condim"].append(int(g["condim"])); G["group"].append(int(g["group"])); G["priority"].append(int(g["priority"]))
+                G["friction"].append(fr); G["solmix"].append(float(g["solmix"])); G["solref"].append(_floats(g["solref"], 2))
+                G["solimp"].append(_floats(g["solimp"], 5)); G["margin"].append(float(g["margin"])); G["gap"].append(float(g["gap"]))
+                G["rgba"].append(rgba); G["rbound"].append(rb); G["center"].append(cen); G["aabb"].append(aabb)
+                G["hulladr"].append(adr); G["hullnum"].append(num); G["meshid"].append(meshid)
+                G["name"].append(g.get("name", ""))
+            if parts:
+                M = sum(p[0] for p in parts)
+                c = sum(p[0] * p[1] for p in parts) / M
+                I = np.zeros((3, 3))
+                for m, pc, Ic in parts:
+                    d = pc - c
+                    I += Ic + m * (np.dot(d, d) * np.eye(3) - np.outer(d, d))
+                w, V = np.linalg.eigh(I)
+                order = np.argsort(-w)
+                w, V = w[order], V[:, order]
+                if np.linalg.det(V) < 0:
+                    V[:, 2] = -V[:, 2]
+                body_mass[b.id], body_ipos[b.id], body_iquat[b.id], body_inertia[b.id] = M, c, mat2quat(V), w
+            elif b.joints:
+                raise ValueError(f"moving body {b.name} has no mass")
+        ngeom = len(G["type"])
+
+        # ---------------- sites, cameras
+        site_bodyid, site_pos, site_quat, site_names = [], [], [], []
+        cam_bodyid, cam_pos, cam_quat, cam_fovy, cam_names = [], [], [], [], []
+        for b in bodies:
+            for s in b.sites:
+                site_bodyid.append(b.id); site_pos.append(s["_pos"]); site_quat.append(s["_quat"]); site_names.append(s.get("name", ""))
+            for c in b.cams:
+                cam_bodyid.append(b.id); cam_pos.append(c["_pos"]); cam_quat.append(c["_quat"])
+                cam_fovy.append(float(c["fovy"])); cam_names.append(c.get("name", ""))
+
+        # ---------------- tendons (fixed), equalities, actuators, keys
+        ten_names = [t["name"] for t in self.tendons]
+        tendon_adr, tendon_num, wrap_objid, wrap_prm = [], [], [], []
+        for t in self.tendons:
+            tendon_adr.append(len(wrap_objid)); tendon_num.append(len(t["joints"]))
+            for jn, coef in t["joints"]:
+                wrap_objid.append(jid_by_name[jn]); wrap_prm.append(coef)
+        eq_obj1, eq_obj2, eq_data, eq_solref, eq_solimp, eq_active = [], [], [], [], [], []
+        for e in self.equalities:
+            eq_obj1.append(jid_by_name[e["joint1"]])
+            eq_obj2.append(jid_by_name[e["joint2"]] if "joint2" in e else -1)
+            eq_data.append(_floats(e.get("polycoef", "0 1 0 0 0"), 5))
+            eq_solref.append(_floats(e["solref"], 2)); eq_solimp.append(_floats(e["solimp"], 5))
+            eq_active.append(int(e.get("active", "true") == "true"))
+        nu = len(self.actuators)
+        A = dict(trntype=[], trnid=[], gear=[], gainprm=[], biasprm=[], ctrllimited=[], ctrlrange=[], forcelimited=[],
+                 forcerange=[], biastype=[], name=[])
+        for a in self.actuators:
+            if a["joint"] is not None:
+                A["trntype"].append(0); A["trnid"].append(jid_by_name[a["joint"]])
+                if jnt_type[jid_by_name[a["joint"]]] not in (JNT_SLIDE, JNT_HINGE):
+                    raise ValueError("actuators on free/ball joints are not supported")
+            elif a["tendon"] is not None:
+                A["trntype"].append(1); A["trnid"].append(ten_names.index(a["tendon"]))
+            else:
+                raise ValueError("actuator needs joint or tendon transmission")
+            A["gear"].append(a["gear"][0]); A["gainprm"].append(a["gainprm"]); A["biasprm"].append(a["biasprm"])
+            cl = a["ctrllimited"]; fl = a["forcelimited"]
+            A["ctrllimited"].append(int(cl == "true" or (cl == "auto" and a["ctrlrange"] is not None)))
+            A["forcelimited"].append(int(fl == "true" or (fl == "auto" and a["forcerange"] is not None)))
+            A["ctrlrange"].append(a["ctrlrange"] or [0.0, 0.0]); A["forcerange"].append(a["forcerange"] or [0.0, 0.0])
+            A["biastype"].append({"none": 0, "affine": 1}[a["biastype"]]); A["name"].append(a["name"])
+        key_ctrl = np.zeros((len(self.keys), max(nu, 1)))
+        for i, k in enumerate(self.keys):
+            if "ctrl" in k:
+                key_ctrl[i, :nu] = _floats(k["ctrl"], nu)[:nu]
+            if "qpos" in k:
+                raise ValueError("keyframe qpos not supported")
+
+        # ---------------- static collision pair table (body-pair major, then geom order; MuJoCo filters [MJ] B.3)
+        excl = set()
+        for b1, b2 in self.excludes:
+            excl.add((min(bid[b1], bid[b2]), max(bid[b1], bid[b2])))
+        pairs = []
+        gb = G["bodyid"]
+        for g1 in range(ngeom):
+            for g2 in range(g1 + 1, ngeom):
+                b1, b2 = gb[g1], gb[g2]
+                if b1 == b2:
+                    continue
+                if not ((G["contype"][g1] & G["conaffinity"][g2]) or (G["contype"][g2] & G["conaffinity"][g1])):
+                    continue
+                w1, w2 = body_weldid[b1], body_weldid[b2]
+                if w1 == w2:
+                    continue
+                p1, p2 = body_weldid[body_parentid[w1]], body_weldid[body_parentid[w2]]
+                if w1 and w2 and (w1 == p2 or w2 == p1):
+                    continue
+                if (min(b1, b2), max(b1, b2)) in excl:
+                    continue
+                if G["type"][g1] == GEOM_PLANE and G["type"][g2] == GEOM_PLANE:
+                    continue
+                a, b_ = (g1, g2) if G["type"][g1] <= G["type"][g2] else (g2, g1)
+                pairs.append((min(b1, b2), max(b1, b2), g1, g2, a, b_))
+        pairs.sort(key=lambda p: (p[0], p[1], p[2], p[3]))
+        P = dict(geom1=[], geom2=[], condim=[], friction=[], solref=[], solimp=[], margin=[], gap=[])
+        for _, _, _, _, a, b_ in pairs:
+            pa, pb = G["priority"][a], G["priority"][b_]
+            if pa != pb:
+                w = a if pa > pb else b_
+                condim, fr, sr, si = G["condim"][w], G["friction"][w], G["solref"][w], G["solimp"][w]
+            else:
+                condim = max(G["condim"][a], G["condim"][b_])
+                fr = [max(x, y) for x, y in zip(G["friction"][a], G["friction"][b_])]
+                ma, mb = G["solmix"][a], G["solmix"][b_]
+                mix = 0.5 if (ma < MINVAL and mb < MINVAL) else ma / (ma + mb)
+                sra, srb = G["solref"][a], G["solref"][b_]
+                if sra[0] > 0 and srb[0] > 0:
+                    sr = [mix * x + (1 - mix) * y for x, y in zip(sra, srb)]
+                else:
+                    sr = [min(x, y) for x, y in zip(sra, srb)]
+                si = [mix * x + (1 - mix) * y for x, y in zip(G["solimp"][a], G["solimp"][b_])]
+            P["geom1"].append(a); P["geom2"].append(b_); P["condim"].append(condim)
+            P["friction"].append([fr[0], fr[0], fr[1], fr[2], fr[2]]); P["solref"].append(sr); P["solimp"].append(si)
+            P["margin"].append(max(G["margin"][a], G["margin"][b_])); P["gap"].append(max(G["gap"][a], G["gap"][b_]))
+
+        # ---------------- sensors (the three the reference reads: sensor_manager.py:65-89)
+        site_id = {n: i for i, n in enumerate(site_names) if n}
+        imu_site, lidar_sites, lidar_cutoff = -1, [], 0.0
+        for s in self.sensors:
+            if s["type"] in ("gyro", "accelerometer"):
+                imu_site = site_id[s["site"]]
+            elif s["type"] == "rangefinder":
+                base = s["site"]
+                lidar_sites = [i for i, n in enumerate(site_names) if n.startswith(base) and n[len(base):].isdigit()]
+                lidar_cutoff = float(s.get("cutoff", "0"))
+
+        o = self.option
+        m: Dict[str, np.ndarray] = {}
+        m["dims"] = np.array([nq, nv, nu, nbody, njnt, ngeom, len(site_bodyid), len(cam_bodyid), len(eq_obj1),
+                              len(tendon_adr), len(wrap_objid), len(self.keys), len(P["geom1"]), nhv], np.int32)
+        m["opt_timestep"] = np.array([o["timestep"]]); m["opt_gravity"] = np.array(o["gravity"], float)
+        m["opt_impratio"] = np.array([o["impratio"]]); m["opt_tolerance"] = np.array([o["tolerance"]])
+        m["opt_iterations"] = np.array([o["iterations"]], np.int32)
+        m["opt_cone"] = np.array([{"pyramidal": 0, "elliptic": 1}[o["cone"]]], np.int32)
+        m["opt_integrator"] = np.array([{"Euler": 0, "RK4": 1, "implicit": 2, "implicitfast": 3}[o["integrator"]]], np.int32)
+        m["opt_solver"] = np.array([{"PGS": 0, "CG": 1, "Newton": 2}[o["solver"]]], np.int32)
+        m["body_parentid"] = np.array(body_parentid, np.int32); m["body_weldid"] = np.array(body_weldid, np.int32)
+        m["body_rootid"] = np.array(body_rootid, np.int32)
+        m["body_pos"] = np.array([b.pos for b in bodies]); m["body_quat"] = np.array([b.quat for b in bodies])
+        m["body_ipos"], m["body_iquat"], m["body_mass"], m["body_inertia"] = body_ipos, body_iquat, body_mass, body_inertia
+        m["body_gravcomp"] = np.array([b.gravcomp for b in bodies])
+        m["body_jntadr"] = np.array(body_jntadr, np.int32); m["body_jntnum"] = np.array(body_jntnum, np.int32)
+        m["body_dofadr"] = np.array(body_dofadr, np.int32); m["body_dofnum"] = np.array(body_dofnum, np.int32)
+        m["jnt_type"] = np.array(jnt_type, np.int32); m["jnt_qposadr"] = np.array(jnt_qposadr, np.int32)
+        m["jnt_dofadr"] = np.array(jnt_dofadr, np.int32); m["jnt_bodyid"] = np.array(jnt_bodyid, np.int32)
+        m["jnt_pos"] = np.array(jnt_pos, float).reshape(-1, 3); m["jnt_axis"] = np.array(jnt_axis, float).reshape(-1, 3)
+        m["jnt_stiffness"] = np.array(jnt_stiffness); m["jnt_range"] = np.array(jnt_range, float).reshape(-1, 2)
+        m["jnt_limited"] = np.array(jnt_limited, np.int32); m["jnt_margin"] = np.array(jnt_margin)
+        m["jnt_solref"] = np.array(jnt_solref, float).reshape(-1, 2); m["jnt_solimp"] = np.array(jnt_solimp, float).reshape(-1, 5)
+        m["dof_bodyid"] = np.array(dof_bodyid, np.int32); m["dof_jntid"] = np.array(dof_jntid, np.int32)
+        m["dof_parentid"] = np.array(dof_parentid, np.int32); m["dof_armature"] = np.array(dof_armature)
+        m["dof_damping"] = np.array(dof_damping); m["dof_frictionloss"] = np.array(dof_frictionloss)
+        m["dof_solref"] = np.array(dof_solref, float).reshape(-1, 2); m["dof_solimp"] = np.array(dof_solimp, float).reshape(-1, 5)
+        m["qpos0"] = np.array(qpos0); m["qpos_spring"] = np.array(qpos_spring)
+        for k in ("type", "bodyid", "contype", "conaffinity", "condim", "group", "priority", "hulladr", "hullnum", "meshid"):
+            m["geom_" + k] = np.array(G[k], np.int32)
+        m["geom_pos"] = np.array(G["pos"], float).reshape(-1, 3); m["geom_quat"] = np.array(G["quat"], float).reshape(-1, 4)
+        m["geom_size"] = np.array(G["size"], float).reshape(-1, 3); m["geom_rgba"] = np.array(G["rgba"], float).reshape(-1, 4)
+        m["geom_rbound"] = np.array(G["rbound"]); m["geom_center"] = np.array(G["center"], float).reshape(-1, 3)
+        m["geom_aabb"] = np.array(G["aabb"], float).reshape(-1, 6)
+        m["geom_friction"] = np.array(G["friction"], float).reshape(-1, 3)
+        m["hull_vert"] = np.concatenate(hull_verts, 0) if hull_verts else np.zeros((0, 3))
+        m["site_bodyid"] = np.array(site_bodyid, np.int32); m["site_pos"] = np.array(site_pos, float).reshape(-1, 3)
+        m["site_quat"] = np.array(site_quat, float).reshape(-1, 4)
+        m["cam_bodyid"] = np.array(cam_bodyid, np.int32); m["cam_pos"] = np.array(cam_pos, float).reshape(-1, 3)
+        m["cam_quat"] = np.array(cam_quat, float).reshape(-1, 4); m["cam_fovy"] = np.array(cam_fovy, float)
+        m["tendon_adr"] = np.array(tendon_adr, np.int32); m["tendon_num"] = np.array(tendon_num, np.int32)
+        m["wrap_objid"] = np.array(wrap_objid, np.int32); m["wrap_prm"] = np.array(wrap_prm, float)
+        m["eq_obj1id"] = np.array(eq_obj1, np.int32); m["eq_obj2id"] = np.array(eq_obj2, np.int32)
+        m["eq_data"] = np.array(eq_data, float).reshape(-1, 5); m["eq_solref"] = np.array(eq_solref, float).reshape(-1, 2)
+        m["eq_solimp"] = np.array(eq_solimp, float).reshape(-1, 5); m["eq_active"] = np.array(eq_active, np.int32)
+        m["actuator_trntype"] = np.array(A["trntype"], np.int32); m["actuator_trnid"] = np.array(A["trnid"], np.int32)
+        m["actuator_gear"] = np.array(A["gear"], float); m["actuator_gainprm"] = np.array(A["gainprm"], float).reshape(-1, 3)
+        m["actuator_biasprm"] = np.array(A["biasprm"], float).reshape(-1, 3)
+        m["actuator_ctrllimited"] = np.array(A["ctrllimited"], np.int32); m["actuator_forcelimited"] = np.array(A["forcelimited"], np.int32)
+        m["actuator_ctrlrange"] = np.array(A["ctrlrange"], float).reshape(-1, 2)
+        m["actuator_forcerange"] = np.array(A["forcerange"], float).reshape(-1, 2)
+        m["actuator_biastype"] = np.array(A["biastype"], np.int32)
+        m["key_ctrl"] = key_ctrl
+        m["pair_geom1"] = np.array(P["geom1"], np.int32); m["pair_geom2"] = np.array(P["geom2"], np.int32)
+        m["pair_condim"] = np.array(P["condim"], np.int32); m["pair_friction"] = np.array(P["friction"], float).reshape(-1, 5)
+        m["pair_solref"] = np.array(P["solref"], float).reshape(-1, 2); m["pair_solimp"] = np.array(P["solimp"], float).reshape(-1, 5)
+        m["pair_margin"] = np.array(P["margin"], float); m["pair_gap"] = np.array(P["gap"], float)
+        m["sensor_imu_site"] = np.array([imu_site], np.int32); m["sensor_lidar_site"] = np.array(lidar_sites, np.int32)
+        m["sensor_lidar_cutoff"] = np.array([lidar_cutoff])
+        extent = self.stat_extent
+        m["vis_znear_zfar_extent"] = np.array([self.znear, self.zfar, extent if extent is not None else -1.0])
+        names = dict(body=[b.name or "" for b in bodies], joint=jnt_names, geom=G["name"], site=site_names, camera=cam_names,
+                     actuator=A["name"], tendon=ten_names, key=[k.get("name", "") for k in self.keys], mesh=mesh_names,
+                     missing_meshes=self.meshes_missing)
+        m["names_json"] = np.frombuffer(json.dumps(names).encode(), np.uint8)
+        _set_const(m)
+        return m
+
+
+# ----------------------------------------------------------------------------- constants at qpos0
+def _fk(m, qpos):
+    nbody = len(m["body_parentid"])
+    xpos = np.zeros((nbody, 3)); xquat = np.tile([1.0, 0, 0, 0], (nbody, 1))
+    xanchor = np.zeros((len(m["jnt_type"]), 3)); xaxis = np.zeros((len(m["jnt_type"]), 3))
+    for b in range(1, nbody):
+        p = m["body_parentid"][b]
+        if m["body_jntnum"][b] == 1 and m["jnt_type"][m["body_jntadr"][b]] == JNT_FREE:
+            a = m["jnt_qposadr"][m["body_jntadr"][b]]
+            pos, quat = qpos[a:a + 3].copy(), quat_norm(qpos[a + 3:a + 7])
+            xanchor[m["body_jntadr"][b]] = pos; xaxis[m["body_jntadr"][b]] = [0, 0, 1]
+        else:
+            pos = xpos[p] + quat2mat(xquat[p]) @ m["body_pos"][b]
+            quat = quat_mul(xquat[p], m["body_quat"][b])
+            for j in range(m["body_jntadr"][b], m["body_jntadr"][b] + m["body_jntnum"][b]):
+                R = quat2mat(quat)
+                xaxis[j] = R @ m["jnt_axis"][j]
+                xanchor[j] = pos + R @ m["jnt_pos"][j]
+                q = qpos[m["jnt_qposadr"][j]] - m["qpos0"][m["jnt_qposadr"][j]]
+                if m["jnt_type"][j] == JNT_SLIDE:
+                    pos = pos + xaxis[j] * q
+                else:
+                    quat = quat_mul(quat, axisangle2quat(m["jnt_axis"][j], q))
+                    pos = xanchor[j] - quat2mat(quat) @ m["jnt_pos"][j]
+        xpos[b], xquat[b] = pos, quat_norm(quat)
+    return xpos, xquat, xanchor, xaxis
+
+
+def _body_jac(m, xanchor, xaxis, point, body):
+    """6 x nv Jacobian (rows 0-2 translational at `point`, 3-5 rotational) of `body`.  [MJ] mj_jac."""
+    nv = len(m["dof_bodyid"])
+    J = np.zeros((6, nv))
+    b = body
+    while b > 0 and m["body_dofnum"][b] == 0:
+        b = m["body_parentid"][b]
+    if b == 0:
+        return J
+    d = m["body_dofadr"][b] + m["body_dofnum"][b] - 1
+    while d >= 0:
+        j = m["dof_jntid"][d]
+        t = m["jnt_type"][j]
+        if t == JNT_FREE:
+            k = d - m["jnt_dofadr"][j]
+            if k < 3:
+                J[k, d] = 1.0
+            else:
+                ax = m["_free_R"][j][:, k - 3]
+                J[3:, d] = ax
+                J[:3, d] = np.cross(ax, point - xanchor[j])
+        elif t == JNT_SLIDE:
+            J[:3, d] = xaxis[j]
+        else:
+            J[3:, d] = xaxis[j]
+            J[:3, d] = np.cross(xaxis[j], point - xanchor[j])
+        d = m["dof_parentid"][d]
+    return J
+
+
+def mass_matrix(m, qpos):
+    """Dense joint-space inertia at qpos via body Jacobians (compile-time helper, not the hot path)."""
+    xpos, xquat, xanchor, xaxis = _fk(m, qpos)
+    m["_free_R"] = {j: quat2mat(xquat[m["jnt_bodyid"][j]]) for j in range(len(m["jnt_type"])) if m["jnt_type"][j] == JNT_FREE}
+    nv = len(m["dof_bodyid"])
+    M = np.diag(m["dof_armature"].astype(float))
+    jacs = {}
+    for b in range(1, len(m["body_parentid"])):
+        R = quat2mat(xquat[b])
+        xipos = xpos[b] + R @ m["body_ipos"][b]
+        J = _body_jac(m, xanchor, xaxis, xipos, b)
+        jacs[b] = J
+        if m["body_mass"][b] > 0:
+            Ri = R @ quat2mat(m["body_iquat"][b])
+            Iw = Ri @ np.diag(m["body_inertia"][b]) @ Ri.T
+            M += m["body_mass"][b] * J[:3].T @ J[:3] + J[3:].T @ Iw @ J[3:]
+    del m["_free_R"]
+    return M, jacs
+
+
+def _set_const(m):
+    """dof_invweight0, body_invweight0, tendon_invweight0, stat_meaninertia at qpos0.  [MJ] mj_setConst/set0."""
+    nv = len(m["dof_bodyid"])
+    nbody = len(m["body_parentid"])
+    M, jacs = mass_matrix(m, m["qpos0"])
+    Minv = np.linalg.inv(M) if nv else np.zeros((0, 0))
+    m["stat_meaninertia"] = np.array([float(np.mean(np.diag(M))) if nv else 1.0])
+    dinv = np.zeros(nv)
+    for j in range(len(m["jnt_type"])):
+        a = m["jnt_dofadr"][j]
+        if m["jnt_type"][j] == JNT_FREE:
+            dinv[a:a + 3] = np.mean(np.diag(Minv)[a:a + 3])
+            dinv[a + 3:a + 6] = np.mean(np.diag(Minv)[a + 3:a + 6])
+        else:
+            dinv[a] = Minv[a, a]
+    m["dof_invweight0"] = dinv
+    binv = np.zeros((nbody, 2))
+    for b in range(1, nbody):
+        if m["body_weldid"][b] == 0:
+            continue
+        A = jacs[b] @ Minv @ jacs[b].T
+        binv[b, 0] = max(MINVAL, np.trace(A[:3, :3]) / 3)
+        binv[b, 1] = max(MINVAL, np.trace(A[3:, 3:]) / 3)
+    m["body_invweight0"] = binv
+    tinv = np.zeros(len(m["tendon_adr"]))
+    for t in range(len(m["tendon_adr"])):
+        J = np.zeros(nv)
+        for w in range(m["tendon_adr"][t], m["tendon_adr"][t] + m["tendon_num"][t]):
+            J[m["jnt_dofadr"][m["wrap_objid"][w]]] = m["wrap_prm"][w]
+        tinv[t] = J @ Minv @ J
+    m["tendon_invweight0"] = tinv
+    sub = m["body_mass"].copy()
+    for b in range(nbody - 1, 0, -1):
+        sub[m["body_parentid"][b]] += sub[b]
+    m["body_subtreemass"] = sub
+
+
+# ----------------------------------------------------------------------------- public helpers
+def compile_file(path: str) -> Dict[str, np.ndarray]:
+    c = MjcfCompiler()
+    c.parse_file(path)
+    return c.compile()
+
+
+def compile_string(xml: str, base_dir: str = ".") -> Dict[str, np.ndarray]:
+    c = MjcfCompiler()
+    c.parse_string(xml, base_dir)
+    return c.compile()
+
+
+def empty_scene_xml(stretch_xml_path: str) -> str:
+    """The build's definition of the "empty scene" (SURVEY.md §0 finding 6): stretch.xml + one ground plane."""
+    return (f'<mujoco model="stretch_empty"><include file="{stretch_xml_path}"/>'
+            '<worldbody><geom name="floor" type="plane" size="0 0 0.05"/></worldbody></mujoco>')

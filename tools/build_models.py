@@ -1,0 +1,28 @@
+"""Compile the committed model blobs from the reference's MJCF (runs only where /root/reference is mounted).
+
+    python tools/build_models.py [/root/reference]
+
+Outputs stretch_mujoco_amd/models/*.smjb -- compiled numeric model data (the problem definition the
+kernels consume); the GPU box never parses XML.
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from stretch_mujoco_amd import mjcf_compiler as C, model_blob as B  # noqa: E402
+
+
+def main():
+    ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+    stretch = os.path.join(ref, "stretch_mujoco", "models", "stretch.xml")
+    out = os.path.join(os.path.dirname(HERE), "stretch_mujoco_amd", "models")
+    os.makedirs(out, exist_ok=True)
+    m = C.compile_string(C.empty_scene_xml(stretch))
+    B.save(os.path.join(out, "stretch_empty.smjb"), m)
+    print("stretch_empty:", dict(zip("nq nv nu nbody njnt ngeom nsite ncam neq ntendon nwrap nkey npair nhullvert".split(),
+                                     [int(x) for x in m["dims"]])))
+
+
+if __name__ == "__main__":
+    main()
