@@ -1,0 +1,79 @@
+/* smj.h -- C-ABI of the batched Stretch physics path (libsmj.so, HIP / gfx950).
+ *
+ * This is the drop-in boundary ("lower seam").  In the reference the seam is the set of
+ * pybind11 calls into the `mujoco` package made by stretch_mujoco/mujoco_server.py; each entry point below
+ * cites the reference call it replaces.  All buffers are plain device pointers owned by the CALLER (PyTorch
+ * tensors on the ROCm device); the library never allocates or frees memory it is handed.  Every call returns
+ * 0 on success and a negative code on error (see smj_last_error); nothing throws or aborts across the ABI.
+ * Launches are asynchronous on the stream passed by the caller.  One context per device; a context is not
+ * thread-safe, distinct contexts are independent.
+ */
+#ifndef SMJ_H
+#define SMJ_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smj_ctx smj_ctx;
+
+/* Buffer slots for smj_bind.  Arrays are fp32 (int32 where noted), batch-major [dim][ld], ld >= num_envs. */
+enum smj_slot {
+  SMJ_SLOT_QPOS = 0,      /* [nq][B]   MjData.qpos                                                        */
+  SMJ_SLOT_QVEL = 1,      /* [nv][B]   MjData.qvel                                                        */
+  SMJ_SLOT_CTRL = 2,      /* [nu][B]   MjData.ctrl   (written by push_command, mujoco_server.py:527-578)   */
+  SMJ_SLOT_WARMSTART = 3, /* [nv][B]   MjData.qacc_warmstart                                               */
+  SMJ_SLOT_NSTEP = 4,     /* int32 [B] steps since reset; MjData.time = nstep * opt.timestep               */
+  SMJ_SLOT_ACT_LENGTH = 5,/* [nu][B]   MjData.actuator_length   (pull_status, mujoco_server.py:475-504)    */
+  SMJ_SLOT_ACT_VELOCITY = 6, /* [nu][B] MjData.actuator_velocity                                           */
+  SMJ_SLOT_BASE_POSE = 7, /* [3][B]    x, y, theta of base_link (BaseController.get_base_pose, :124-129)   */
+  SMJ_SLOT_GYRO = 8,      /* [3][B]    sensor base_gyro   (mujoco_server_sensor_manager.py:85)             */
+  SMJ_SLOT_ACCEL = 9,     /* [3][B]    sensor base_accel                                                   */
+  SMJ_SLOT_LIDAR = 10,    /* [nlidar][B] sensors base_lidar000.. (mujoco_server_sensor_manager.py:77-83)   */
+  SMJ_SLOT_INFO = 11,     /* int32 [4][B] nefc, ncon, solver iterations, flags                             */
+  SMJ_SLOT_DEBUG = 12,    /* [SMJ_DEBUG_FLOATS][B] optional stage dumps for parity tests (may stay unbound) */
+  SMJ_SLOT_COUNT = 13
+};
+
+enum smj_dim {
+  SMJ_DIM_NQ = 0, SMJ_DIM_NV = 1, SMJ_DIM_NU = 2, SMJ_DIM_NBODY = 3, SMJ_DIM_NLIDAR = 4, SMJ_DIM_NKEY = 5,
+  SMJ_DIM_NUM_ENVS = 6, SMJ_DIM_DEBUG_FLOATS = 7, SMJ_DIM_NEFC_MAX = 8, SMJ_DIM_NCON_MAX = 9, SMJ_DIM_COUNT = 10
+};
+
+/* readout flags for smj_step */
+enum { SMJ_READ_IMU = 1, SMJ_READ_LIDAR = 2 };
+
+/* Replaces MjModel.from_xml_path + MjData(model) (mujoco_server.py:252,258): `blob` is the compiled model
+ * produced by stretch_mujoco_amd.mjcf_compiler / model_fuse (SMJB format, model_blob.py). */
+int smj_create(const void* blob, size_t nbytes, int num_envs, int device, smj_ctx** out);
+int smj_destroy(smj_ctx* ctx);
+
+/* Attach a caller-owned device buffer to a slot (the MjData field views the reference reads/writes). */
+int smj_bind(smj_ctx* ctx, int slot, void* dev_ptr, long ld);
+
+/* Copy of model constants the host glue needs: qpos0[nq], key_ctrl[nkey][nu], jnt ranges are read from the blob
+ * on the Python side; this returns dimensions only (model.nq etc.). */
+int smj_dims(const smj_ctx* ctx, int* out /* SMJ_DIM_COUNT ints */);
+
+/* mj_resetData for the envs whose mask byte is non-zero (mask_dev == NULL: all).  qpos <- qpos0 (per-env start
+ * pose applied by the caller afterwards, cf. change_start_pose, mujoco_server.py:206-229), qvel, ctrl,
+ * warmstart, nstep <- 0. */
+int smj_reset(smj_ctx* ctx, const uint8_t* mask_dev, void* stream);
+
+/* `nsteps` x mj_step (mujoco_server.py:378) for every env with ctrl held constant, one wavefront per env.
+ * On return (stream order) the bound ACT_LENGTH / ACT_VELOCITY / BASE_POSE hold the post-step readout and,
+ * if requested in read_flags, GYRO/ACCEL (+ LIDAR) hold the sensor values of the last step. */
+int smj_step(smj_ctx* ctx, int nsteps, unsigned read_flags, void* stream);
+
+/* Solver / collision options (mjOption fields): "iterations", "tolerance", "warmstart", "pgs_fixed_iter",
+ * "max_contacts_per_pair". */
+int smj_set_option(smj_ctx* ctx, const char* name, double value);
+
+const char* smj_last_error(const smj_ctx* ctx);
+const char* smj_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

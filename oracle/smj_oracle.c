@@ -61,7 +61,7 @@ struct smjo_model {
   int iterations, cone, warmstart, pgs_fixed_iter, max_con_pair;
   int *body_parentid, *body_weldid, *body_rootid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum;
   double *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_gravcomp, *body_invweight0,
-      *body_subtreemass;
+      *body_subtreemass, *body_gcmass, *body_gcipos, *geom_invweight0;
   int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;
   double *jnt_pos, *jnt_axis, *jnt_stiffness, *jnt_range, *jnt_margin, *jnt_solref, *jnt_solimp;
   int *dof_bodyid, *dof_jntid, *dof_parentid;
@@ -134,7 +134,8 @@ smjo_model* smjo_load(const void* blob, size_t nbytes) {
   LOADI(body_parentid); LOADI(body_weldid); LOADI(body_rootid); LOADI(body_jntadr); LOADI(body_jntnum);
   LOADI(body_dofadr); LOADI(body_dofnum);
   LOADF(body_pos); LOADF(body_quat); LOADF(body_ipos); LOADF(body_iquat); LOADF(body_mass); LOADF(body_inertia);
-  LOADF(body_gravcomp); LOADF(body_invweight0); LOADF(body_subtreemass);
+  LOADF(body_gravcomp); LOADF(body_invweight0); LOADF(body_subtreemass); LOADF(body_gcmass); LOADF(body_gcipos);
+  LOADF(geom_invweight0);
   LOADI(jnt_type); LOADI(jnt_qposadr); LOADI(jnt_dofadr); LOADI(jnt_bodyid); LOADI(jnt_limited);
   LOADF(jnt_pos); LOADF(jnt_axis); LOADF(jnt_stiffness); LOADF(jnt_range); LOADF(jnt_margin); LOADF(jnt_solref);
   LOADF(jnt_solimp);
@@ -824,8 +825,8 @@ static void make_constraint(const smjo_model* m, smjo_data* d) {
     if (d->nefc + dim > MAXEFC) { d->ncon_dropped++; continue; }
     jac_point(m, d, jp1, jr1, con->pos, b1);
     jac_point(m, d, jp2, jr2, con->pos, b2);
-    double tran = m->body_invweight0[2 * b1] + m->body_invweight0[2 * b2];
-    double rot = m->body_invweight0[2 * b1 + 1] + m->body_invweight0[2 * b2 + 1];
+    double tran = m->geom_invweight0[2 * con->geom1] + m->geom_invweight0[2 * con->geom2];
+    double rot = m->geom_invweight0[2 * con->geom1 + 1] + m->geom_invweight0[2 * con->geom2 + 1];
     con->efc_address = d->nefc;
     for (int r = 0; r < dim; r++) {
       int type = dim == 1 ? C_CONTACT_FRICTIONLESS : C_CONTACT_ELLIPTIC;
@@ -922,10 +923,12 @@ static void passive(const smjo_model* m, smjo_data* d) {
   }
   double* jp = d->scratch;
   for (int b = 1; b < m->nbody; b++) {
-    if (m->body_gravcomp[b] == 0 || m->body_mass[b] == 0) continue;
-    double f[3];
-    for (int k = 0; k < 3; k++) f[k] = -m->gravity[k] * m->body_mass[b] * m->body_gravcomp[b];
-    jac_point(m, d, jp, NULL, d->xipos + 3 * b, b);
+    if (m->body_gcmass[b] == 0) continue;
+    double f[3], pt[3];
+    for (int k = 0; k < 3; k++) f[k] = -m->gravity[k] * m->body_gcmass[b];
+    mulmat3vec(pt, d->xmat + 9 * b, m->body_gcipos + 3 * b);
+    for (int k = 0; k < 3; k++) pt[k] += d->xpos[3 * b + k];
+    jac_point(m, d, jp, NULL, pt, b);
     for (int k = 0; k < nv; k++) d->qfrc_passive[k] += jp[k] * f[0] + jp[nv + k] * f[1] + jp[2 * nv + k] * f[2];
   }
 }

@@ -1,0 +1,89 @@
+// Device-side view of the compiled (fused) model: plain pointers to fp32 / int32 arrays, named exactly as in
+// the SMJB blob (model_blob.py, model_fuse.py).  Filled by smj_create() (smj_capi.hip) on the GPU and by the
+// test-only lane emulator on the CPU.
+#pragma once
+#include <stdint.h>
+
+#define NVP 32   // dof capacity (model nv <= NVP)
+#define NBP 32   // fused-body capacity
+#define NEFC 64  // constraint-row capacity (= lanes of one wavefront)
+#define NCON 16  // contact capacity
+
+#define SMJ_MODEL_I32(X)                                                                                          \
+  X(body_parentid) X(body_rootid) X(body_jntadr) X(body_jntnum) X(body_dofadr) X(body_dofnum) X(k_body_level)     \
+  X(k_body_subtreesize) X(k_body_dofmask_lo) X(k_body_dofmask_hi) X(k_root_list) X(k_gc_body)                     \
+  X(jnt_type) X(jnt_qposadr) X(jnt_dofadr) X(jnt_bodyid) X(jnt_limited)                                           \
+  X(dof_bodyid) X(dof_jntid) X(dof_parentid) X(k_dof_anc_adr) X(k_dof_anc_num) X(k_dof_anc) X(k_dof_velmask_lo)   \
+  X(k_dof_velmask_hi) X(k_dof_qposadr) X(k_ldl_i) X(k_ldl_j) X(k_fric_dof) X(k_limit_jnt)                         \
+  X(geom_type) X(geom_bodyid) X(geom_hulladr) X(geom_hullnum)                                                     \
+  X(site_bodyid) X(sensor_lidar_site) X(k_ray_geom) X(k_ray_geom_origbody) X(k_site_origbody)                                                                           \
+  X(eq_obj1id) X(eq_obj2id) X(eq_active)                                                                          \
+  X(actuator_trntype) X(actuator_trnid) X(actuator_ctrllimited) X(actuator_forcelimited) X(actuator_biastype)     \
+  X(pair_geom1) X(pair_geom2) X(pair_condim) X(k_planepair)
+
+#define SMJ_MODEL_F32(X)                                                                                          \
+  X(body_pos) X(body_quat) X(k_body_inertia_local) X(body_gcmass) X(body_gcipos) X(body_subtreemass)              \
+  X(jnt_pos) X(jnt_axis) X(jnt_stiffness) X(jnt_range) X(jnt_margin) X(jnt_solref) X(jnt_solimp) X(qpos0)         \
+  X(qpos_spring)                                                                                                  \
+  X(dof_armature) X(dof_damping) X(dof_frictionloss) X(dof_invweight0) X(dof_solref) X(dof_solimp)                \
+  X(geom_pos) X(k_geom_mat) X(geom_size) X(geom_rbound) X(k_geom_bcenter) X(geom_rgba) X(geom_invweight0)         \
+  X(hull_vert)                                                                                                    \
+  X(site_pos) X(k_site_mat)                                                                                       \
+  X(eq_data) X(eq_solref) X(eq_solimp)                                                                            \
+  X(actuator_gear) X(actuator_gainprm) X(actuator_biasprm) X(actuator_ctrlrange) X(actuator_forcerange)           \
+  X(k_act_moment) X(key_ctrl)                                                                                     \
+  X(pair_friction) X(pair_solref) X(pair_solimp) X(pair_margin) X(pair_gap)
+
+struct DevModel {
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, neq, npair, nlevel, nfric, nlimit, nplanepair, nldl, nlidar, imu_site,
+      ngc, nroot, nkey, nraygeom;
+  int iterations, warmstart, pgs_fixed_iter, max_con_pair;
+  float timestep, gravity[3], impratio, tolerance, meaninertia, lidar_cutoff;
+#define X(n) const int* n;
+  SMJ_MODEL_I32(X)
+#undef X
+#define X(n) const float* n;
+  SMJ_MODEL_F32(X)
+#undef X
+};
+
+// Batch-major simulator state bound through smj_bind() (include/smj.h).  ld = row stride in elements (>= B).
+struct DevState {
+  int B;           // environments in this context
+  long ld;         // leading dimension of every [dim][B] array
+  float* qpos;     // [nq][B]
+  float* qvel;     // [nv][B]
+  float* ctrl;     // [nu][B]
+  float* warm;     // [nv][B]  qacc_warmstart
+  int* nstep;      // [B]      steps taken since reset (time = nstep * timestep)
+  float* act_len;  // [nu][B]  actuator_length   (readout, pull_status)
+  float* act_vel;  // [nu][B]  actuator_velocity
+  float* base;     // [3][B]   x, y, theta of base_link
+  float* gyro;     // [3][B]
+  float* accel;    // [3][B]
+  float* lidar;    // [nlidar][B]
+  int* info;       // [4][B]   nefc, ncon, solver iterations, flags (bit0: efc overflow, bit1: contact overflow, bit2: nan reset)
+  float* debug;    // [SMJ_DEBUG_FLOATS][B] or null: stage dumps for parity tests
+};
+
+enum { SMJ_INFO_NEFC = 0, SMJ_INFO_NCON = 1, SMJ_INFO_NITER = 2, SMJ_INFO_FLAGS = 3 };
+enum { SMJ_FLAG_EFC_OVERFLOW = 1, SMJ_FLAG_CON_OVERFLOW = 2, SMJ_FLAG_BAD_STATE = 4 };
+
+// layout of the optional debug dump (floats), one column per env
+enum {
+  SMJ_DBG_QM = 0,             // 32*32 dense mass matrix (row-major, stride 32)
+  SMJ_DBG_G = 1024,           // 32 qfrc_smooth
+  SMJ_DBG_QACC = 1056,        // 32 qacc (forward dynamics)
+  SMJ_DBG_EFC_FORCE = 1088,   // 64
+  SMJ_DBG_EFC_B = 1152,       // 64
+  SMJ_DBG_EFC_R = 1216,       // 64
+  SMJ_DBG_EFC_AREF = 1280,    // 64
+  SMJ_DBG_AR_DIAG = 1344,     // 64
+  SMJ_DBG_XPOS = 1408,        // 32*3
+  SMJ_DBG_QFRC_BIAS = 1504,   // 32
+  SMJ_DBG_QFRC_PASSIVE = 1536,// 32
+  SMJ_DBG_QFRC_ACT = 1568,    // 32
+  SMJ_DBG_CON = 1600,         // 16 contacts x (dist, pos3, normal3, dim) = 8 floats
+  SMJ_DBG_AR = 1728,          // 64*64 AR
+  SMJ_DEBUG_FLOATS = 1728 + 4096
+};

@@ -1,0 +1,1495 @@
+// One environment per wavefront: the whole mj_step pipeline (reference call site
+// stretch_mujoco/mujoco_server.py:378; stages per SURVEY.md Appendix B) for `nsteps` steps, state resident in
+// LDS/registers between steps.  Lane mappings: lane = body (tree stages), lane = dof (joint-space stages),
+// lane = constraint row (solver).  Written in the lane-region style of smj_wave.h.
+//
+// Stage map (MuJoCo names):  kinematics -> comPos -> comVel -> crb/factorM (sparse L'DL in LDS) ->
+// passive/rne/actuation -> collision (plane pairs) -> makeConstraint/makeImpedance ->
+// projectConstraint (Y = J L^-1, A = Y D^-1 Y' + R on MFMA) -> PGS (dual, elliptic cones, QCQP blocks) ->
+// implicitfast integrate.
+#pragma once
+#include "smj_model.h"
+#include "smj_wave.h"
+
+#define JS (NVP + 1)
+#define MS (NVP + 1)
+#define SMJ_MINVAL 1e-15f
+#define SMJ_MINIMP 0.0001f
+#define SMJ_MAXIMP 0.9999f
+
+enum { JT_FREE = 0, JT_BALL = 1, JT_SLIDE = 2, JT_HINGE = 3 };
+enum { GT_PLANE = 0, GT_SPHERE = 2, GT_CYLINDER = 5, GT_BOX = 6, GT_MESH = 7 };
+enum { CT_EQUALITY = 0, CT_FRICTION = 1, CT_LIMIT = 3, CT_CONTACT_FRICTIONLESS = 5, CT_CONTACT_ELLIPTIC = 7, CT_NONE = -1 };
+
+struct TreeTmp {  // lives in the A region until A is built
+  float cinert[NBP][10], crb[NBP][10], cvel[NBP][6], cfrc[NBP][6], buf[NVP][6], cdof[NVP][6], cdof_dot[NVP][6];
+};
+
+struct Smem {
+  union {
+    float A[NEFC * NEFC];
+    TreeTmp t;
+  } u;
+  float J[NEFC][JS];    // constraint Jacobian, transformed in place to Y = J L^-1
+  float MM[NVP][MS];    // strict upper: M; lower + diag: working copy -> L (unit, strictly lower), D on diag
+  float Mdiag[NVP], Dinv[NVP];
+  float xpos[NBP][3], xquat[NBP][4], xmat[NBP][9], com[NBP][3];
+  float xaxis[NVP][3], xanchor[NVP][3];
+  float qpos[NVP + 8], qvel[NVP], ctrl[16], g[NVP], uu[NVP], w[NVP], qacc[NVP], warm[NVP], tmp[NVP];
+  float act_force[16], act_len[16], act_vel[16];
+  int etype[NEFC], eid[NEFC];
+  float epos[NEFC], emargin[NEFC], ediag[NEFC], efloss[NEFC], eR[NEFC], eK[NEFC], eBv[NEFC], eimp[NEFC], earef[NEFC],
+      eb[NEFC], ef[NEFC];
+  float cpos[NCON][3], cframe[NCON][9], cdist[NCON], cfric[NCON][5], csolref[NCON][2], csolimp[NCON][5], cmargin[NCON];
+  int cdim[NCON], cgeom1[NCON], cgeom2[NCON], cefc[NCON];
+  int cand[64];
+};
+
+// ---------------------------------------------------------------------------------------------- MFMA tile
+// D(16x16) += A(16x4) * B(4x16), f32.  Lane l supplies A[l&15][l>>4] and B[l>>4][l&15]; holds D[(l>>4)*4+r][l&15].
+struct F4v { float r[4]; };
+#ifdef SMJ_EMUL
+static inline void mfma16x16x4(PL<F4v>& acc, const PL<float>& a, const PL<float>& b) {
+  for (int l = 0; l < 64; l++)
+    for (int r = 0; r < 4; r++) {
+      int row = (l >> 4) * 4 + r, col = l & 15;
+      float s = acc.v[l].r[r];
+      for (int k = 0; k < 4; k++) s = fmaf(a.v[row + 16 * k], b.v[col + 16 * k], s);
+      acc.v[l].r[r] = s;
+    }
+}
+#else
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mfma16x16x4(PL<F4v>& acc, const PL<float>& a, const PL<float>& b) {
+  f32x4 c = {acc.v.r[0], acc.v.r[1], acc.v.r[2], acc.v.r[3]};
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v, b.v, c, 0, 0, 0);
+  acc.v.r[0] = c[0]; acc.v.r[1] = c[1]; acc.v.r[2] = c[2]; acc.v.r[3] = c[3];
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------- QCQP (uniform)
+// min 0.5 x'Ax + x'b  s.t. sum (x_i/d_i)^2 <= r^2   [MJ] mju_QCQP2 / mju_QCQP3 / mju_QCQP.  Returns 1 if active.
+template <int N>
+SMJ_DEV int qcqp(float* res, const float* Ain, const float* bin, const float* dd, float r) {
+  float A[N * N], b[N], L[N * N], tmp[N], la = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    b[i] = bin[i] * dd[i];
+#pragma unroll
+    for (int j = 0; j < N; j++) A[i * N + j] = Ain[i * N + j] * dd[i] * dd[j];
+  }
+  for (int it = 0; it < 20; it++) {
+    if (N == 2) {
+      float a00 = A[0] + la, a11 = A[3] + la, a01 = A[1];
+      float det = a00 * a11 - a01 * a01;
+      if (det < 1e-10f) {
+        res[0] = 0; res[1] = 0;
+        return 0;
+      }
+      float di = 1.0f / det, P00 = a11 * di, P11 = a00 * di, P01 = -a01 * di;
+      res[0] = -(P00 * b[0] + P01 * b[1]); res[1] = -(P01 * b[0] + P11 * b[1]);
+      tmp[0] = P00 * res[0] + P01 * res[1]; tmp[1] = P01 * res[0] + P11 * res[1];
+    } else {
+      // Cholesky of A + la*I, rank test 1e-10
+      bool bad = false;
+#pragma unroll
+      for (int j = 0; j < N; j++) {
+        float s = A[j * N + j] + la;
+#pragma unroll
+        for (int k = 0; k < j; k++) s -= L[j * N + k] * L[j * N + k];
+        if (s < 1e-10f) { bad = true; s = 1e-10f; }
+        float l = sqrtf(s), li = 1.0f / l;
+        L[j * N + j] = l;
+#pragma unroll
+        for (int i = j + 1; i < N; i++) {
+          float t = A[i * N + j];
+#pragma unroll
+          for (int k = 0; k < j; k++) t -= L[i * N + k] * L[j * N + k];
+          L[i * N + j] = t * li;
+        }
+      }
+      if (bad) {
+#pragma unroll
+        for (int i = 0; i < N; i++) res[i] = 0;
+        return 0;
+      }
+      // res = -(A+la)^-1 b ; tmp = (A+la)^-1 res
+#pragma unroll
+      for (int pass = 0; pass < 2; pass++) {
+        float x[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] = pass == 0 ? b[i] : res[i];
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+          float s = x[i];
+#pragma unroll
+          for (int k = 0; k < i; k++) s -= L[i * N + k] * x[k];
+          x[i] = s / L[i * N + i];
+        }
+#pragma unroll
+        for (int i = N - 1; i >= 0; i--) {
+          float s = x[i];
+#pragma unroll
+          for (int k = i + 1; k < N; k++) s -= L[k * N + i] * x[k];
+          x[i] = s / L[i * N + i];
+        }
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+          if (pass == 0) res[i] = -x[i];
+          else tmp[i] = x[i];
+        }
+      }
+    }
+    float val = -r * r, deriv = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) { val += res[i] * res[i]; deriv -= 2 * res[i] * tmp[i]; }
+    if (val < 1e-10f) break;
+    float delta = -val / deriv;
+    if (delta < 1e-10f) break;
+    la += delta;
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) res[i] *= dd[i];
+  return la != 0;
+}
+
+SMJ_DEV float impedance(const float* solimp, float pos, float margin) {
+  float dmin = fminf(SMJ_MAXIMP, fmaxf(SMJ_MINIMP, solimp[0])), dmax = fminf(SMJ_MAXIMP, fmaxf(SMJ_MINIMP, solimp[1]));
+  float width = fmaxf(SMJ_MINVAL, solimp[2]), mid = fminf(SMJ_MAXIMP, fmaxf(SMJ_MINIMP, solimp[3])), power = fmaxf(1.0f, solimp[4]);
+  if (dmin == dmax) return 0.5f * (dmin + dmax);
+  float x = fabsf(pos - margin) / width, y;
+  if (x >= 1) return dmax;
+  if (x <= 0) return dmin;
+  if (power == 1.0f) y = x;
+  else if (power == 2.0f) y = (x <= mid) ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);
+  else if (x <= mid) y = powf(x, power) / powf(mid, power - 1);
+  else y = 1 - powf(1 - x, power) / powf(1 - mid, power - 1);
+  return dmin + y * (dmax - dmin);
+}
+
+// ---------------------------------------------------------------------------------------------- the step
+struct StepKernel {
+  const DevModel& M;
+  const DevState& S;
+  Smem& s;
+  const int env;
+
+  // lane = body
+  PL<int> b_parent, b_level, b_jadr, b_jnum, b_root, b_subsize;
+  PL<uint64_t> b_dofmask;
+  PL<float[3]> b_pos;
+  PL<float[4]> b_quat;
+  PL<float[10]> b_inl;  // local inertia 10-vector
+  PL<float> b_mass;
+  // lane = dof
+  PL<int> d_body, d_jnt, d_jtype, d_qadr, d_first;  // d_first: dofadr of the joint
+  PL<uint64_t> d_velmask, d_bodymask;
+  PL<float> d_arm, d_damp, d_stiff, d_spring;
+  PL<float[6]> cdof, cdof_dot;
+  PL<float> qvel_r, g_r, qacc_r;
+  // lane = ldl entry slots
+  PL<int[5]> e_i, e_j;
+  // lane = row
+  PL<float> f_r, r_r, ARinv_r;
+  int nefc, ncon, niter, flags;
+
+  SMJ_DEV StepKernel(const DevModel& M_, const DevState& S_, Smem& s_, int env_) : M(M_), S(S_), s(s_), env(env_) {}
+
+  SMJ_DEV static uint64_t mk64(int lo, int hi) { return (uint64_t)(uint32_t)lo | ((uint64_t)(uint32_t)hi << 32); }
+
+  // ------------------------------------------------------------------ setup (once per launch)
+  SMJ_DEV void setup() {
+    const int nb = M.nbody, nv = M.nv;
+    LANES {
+      int b = lane < nb ? lane : 0;
+      b_parent[lane] = M.body_parentid[b]; b_level[lane] = lane < nb ? M.k_body_level[b] : -1;
+      b_jadr[lane] = M.body_jntadr[b]; b_jnum[lane] = lane < nb ? M.body_jntnum[b] : 0;
+      b_root[lane] = M.body_rootid[b]; b_subsize[lane] = M.k_body_subtreesize[b];
+      b_dofmask[lane] = mk64(M.k_body_dofmask_lo[b], M.k_body_dofmask_hi[b]);
+      for (int k = 0; k < 3; k++) b_pos[lane][k] = M.body_pos[3 * b + k];
+      for (int k = 0; k < 4; k++) b_quat[lane][k] = M.body_quat[4 * b + k];
+      for (int k = 0; k < 10; k++) b_inl[lane][k] = M.k_body_inertia_local[10 * b + k];
+      int d = lane < nv ? lane : 0;
+      d_body[lane] = M.dof_bodyid[d]; d_jnt[lane] = M.dof_jntid[d]; d_jtype[lane] = M.jnt_type[M.dof_jntid[d]];
+      d_qadr[lane] = M.k_dof_qposadr[d]; d_first[lane] = M.jnt_dofadr[M.dof_jntid[d]];
+      d_velmask[lane] = mk64(M.k_dof_velmask_lo[d], M.k_dof_velmask_hi[d]);
+      int db = M.dof_bodyid[d];
+      d_bodymask[lane] = mk64(M.k_body_dofmask_lo[db], M.k_body_dofmask_hi[db]);
+      d_arm[lane] = M.dof_armature[d]; d_damp[lane] = M.dof_damping[d];
+      int j = M.dof_jntid[d];
+      d_stiff[lane] = (M.jnt_type[j] == JT_FREE) ? 0.f : M.jnt_stiffness[j];
+      d_spring[lane] = (M.jnt_type[j] == JT_FREE) ? 0.f : M.qpos_spring[M.jnt_qposadr[j]];
+      for (int t = 0; t < 5; t++) {
+        int e = lane + 64 * t;
+        e_i[lane][t] = e < M.nldl ? M.k_ldl_i[e] : -1;
+        e_j[lane][t] = e < M.nldl ? M.k_ldl_j[e] : 0;
+      }
+      // zero the factor storage once: the sparsity pattern is static, non-pattern entries stay zero
+      for (int k = lane; k < NVP * MS; k += 64) (&s.MM[0][0])[k] = 0.f;
+      // world body
+      if (lane == 0) {
+        s.xpos[0][0] = s.xpos[0][1] = s.xpos[0][2] = 0;
+        s.xquat[0][0] = 1; s.xquat[0][1] = s.xquat[0][2] = s.xquat[0][3] = 0;
+        for (int k = 0; k < 9; k++) s.xmat[0][k] = (k % 4 == 0) ? 1.f : 0.f;
+      }
+    }
+    SYNC();
+  }
+
+  SMJ_DEV void load_state() {
+    const long ld = S.ld;
+    LANES {
+      if (lane < M.nq) s.qpos[lane] = S.qpos[lane * ld + env];
+      if (lane < M.nv) { s.qvel[lane] = S.qvel[lane * ld + env]; s.warm[lane] = S.warm[lane * ld + env]; }
+      if (lane < M.nu) s.ctrl[lane] = S.ctrl[lane * ld + env];
+    }
+    SYNC();
+  }
+  SMJ_DEV void store_state(int nsteps) {
+    const long ld = S.ld;
+    LANES {
+      if (lane < M.nq) S.qpos[lane * ld + env] = s.qpos[lane];
+      if (lane < M.nv) { S.qvel[lane * ld + env] = s.qvel[lane]; S.warm[lane * ld + env] = s.warm[lane]; }
+      if (lane == 0) {
+        S.nstep[env] += nsteps;
+        S.info[SMJ_INFO_NEFC * ld + env] = nefc; S.info[SMJ_INFO_NCON * ld + env] = ncon;
+        S.info[SMJ_INFO_NITER * ld + env] = niter; S.info[SMJ_INFO_FLAGS * ld + env] |= flags;
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ B.1 kinematics  [MJ] mj_kinematics
+  SMJ_DEV void kinematics() {
+    const int nb = M.nbody;
+    for (int lev = 1; lev < M.nlevel; lev++) {
+      LANES {
+        if (lane < nb && b_level[lane] == lev) {
+          const int b = lane, p = b_parent[lane], ja = b_jadr[lane], jn = b_jnum[lane];
+          float pos[3], quat[4], R[9];
+          if (jn == 1 && M.jnt_type[ja] == JT_FREE) {
+            const int qa = M.jnt_qposadr[ja], da = M.jnt_dofadr[ja];
+            for (int k = 0; k < 3; k++) pos[k] = s.qpos[qa + k];
+            for (int k = 0; k < 4; k++) quat[k] = s.qpos[qa + 3 + k];
+            quat_normalize(quat);
+            for (int d = 0; d < 6; d++)
+              for (int k = 0; k < 3; k++) s.xanchor[da + d][k] = pos[k];
+          } else {
+            mulmat3vec(pos, s.xmat[p], b_pos[lane]);
+            for (int k = 0; k < 3; k++) pos[k] += s.xpos[p][k];
+            quat_mul(quat, s.xquat[p], b_quat[lane]);
+            for (int j = ja; j < ja + jn; j++) {
+              const int da = M.jnt_dofadr[j];
+              float ax[3] = {M.jnt_axis[3 * j], M.jnt_axis[3 * j + 1], M.jnt_axis[3 * j + 2]};
+              float jp[3] = {M.jnt_pos[3 * j], M.jnt_pos[3 * j + 1], M.jnt_pos[3 * j + 2]};
+              float xa[3], a[3], anchor[3];
+              quat2mat(R, quat);
+              mulmat3vec(xa, R, ax);
+              mulmat3vec(a, R, jp);
+              for (int k = 0; k < 3; k++) { anchor[k] = pos[k] + a[k]; s.xaxis[da][k] = xa[k]; s.xanchor[da][k] = anchor[k]; }
+              const int qa = M.jnt_qposadr[j];
+              float q = s.qpos[qa] - M.qpos0[qa];
+              if (M.jnt_type[j] == JT_SLIDE) {
+                for (int k = 0; k < 3; k++) pos[k] += xa[k] * q;
+              } else {
+                float sn = sinf(0.5f * q), dq[4] = {cosf(0.5f * q), ax[0] * sn, ax[1] * sn, ax[2] * sn};
+                quat_mul(quat, quat, dq);
+                quat2mat(R, quat);
+                mulmat3vec(a, R, jp);
+                for (int k = 0; k < 3; k++) pos[k] = anchor[k] - a[k];
+              }
+            }
+          }
+          quat_normalize(quat);
+          quat2mat(R, quat);
+          for (int k = 0; k < 3; k++) s.xpos[b][k] = pos[k];
+          for (int k = 0; k < 4; k++) s.xquat[b][k] = quat[k];
+          for (int k = 0; k < 9; k++) s.xmat[b][k] = R[k];
+          if (jn == 1 && M.jnt_type[ja] == JT_FREE) {
+            const int da = M.jnt_dofadr[ja];
+            for (int d = 0; d < 3; d++)
+              for (int k = 0; k < 3; k++) {
+                s.xaxis[da + d][k] = (d == k) ? 1.f : 0.f;
+                s.xaxis[da + 3 + d][k] = R[3 * k + d];
+              }
+          }
+        }
+      }
+      SYNC();
+    }
+  }
+
+  // ------------------------------------------------------------------ comPos + comVel + crb + M
+  SMJ_DEV void com_crb() {
+    const int nb = M.nbody, nv = M.nv;
+    // subtree com of each tree root: masked wave reductions
+    PL<float> mx, my, mz;
+    PL<float[3]> xip;
+    LANES {
+      const int b = lane;
+      float t[3] = {0, 0, 0};
+      if (b > 0 && b < nb) {
+        mulmat3vec(t, s.xmat[b], &b_inl[lane][6]);
+        for (int k = 0; k < 3; k++) t[k] += s.xpos[b][k];
+      }
+      for (int k = 0; k < 3; k++) xip[lane][k] = t[k];
+    }
+    for (int r = 0; r < M.nroot; r++) {
+      const int root = M.k_root_list[r];
+      LANES {
+        const bool in = lane > 0 && lane < nb && b_root[lane] == root;
+        const float m = in ? b_inl[lane][9] : 0.f;
+        mx[lane] = m * xip[lane][0]; my[lane] = m * xip[lane][1]; mz[lane] = m * xip[lane][2];
+      }
+      const float inv = 1.0f / M.body_subtreemass[root];
+      const float cx = wave_sum(mx) * inv, cy = wave_sum(my) * inv, cz = wave_sum(mz) * inv;
+      LANES {
+        if (lane < nb && b_root[lane] == root) { s.com[lane][0] = cx; s.com[lane][1] = cy; s.com[lane][2] = cz; }
+      }
+    }
+    SYNC();
+    // cinert (body lanes) and cdof (dof lanes)
+    LANES {
+      const int b = lane;
+      if (b > 0 && b < nb) {
+        const float* R = s.xmat[b];
+        const float* I = b_inl[lane];
+        // T = R * Iloc * R'   (Iloc symmetric: xx yy zz xy xz yz)
+        float Il[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]}, RI[9], T[9], Rt[9];
+        mulmat3(RI, R, Il);
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++) Rt[3 * i + j] = R[3 * j + i];
+        mulmat3(T, RI, Rt);
+        float dif[3] = {xip[lane][0] - s.com[b][0], xip[lane][1] - s.com[b][1], xip[lane][2] - s.com[b][2]};
+        const float mass = I[9], dd = dot3(dif, dif);
+        float* c = s.u.t.cinert[b];
+        c[0] = T[0] + mass * (dd - dif[0] * dif[0]); c[1] = T[4] + mass * (dd - dif[1] * dif[1]);
+        c[2] = T[8] + mass * (dd - dif[2] * dif[2]); c[3] = T[1] - mass * dif[0] * dif[1];
+        c[4] = T[2] - mass * dif[0] * dif[2]; c[5] = T[5] - mass * dif[1] * dif[2];
+        c[6] = mass * dif[0]; c[7] = mass * dif[1]; c[8] = mass * dif[2]; c[9] = mass;
+      }
+      if (lane < nv) {
+        const int d = lane, b = d_body[lane];
+        float off[3] = {s.com[b][0] - s.xanchor[d][0], s.com[b][1] - s.xanchor[d][1], s.com[b][2] - s.xanchor[d][2]};
+        float* c = cdof[lane];
+        const int jt = d_jtype[lane], k = d - d_first[lane];
+        if (jt == JT_SLIDE || (jt == JT_FREE && k < 3)) {
+          c[0] = c[1] = c[2] = 0;
+          for (int x = 0; x < 3; x++) c[3 + x] = s.xaxis[d][x];
+        } else {
+          for (int x = 0; x < 3; x++) c[x] = s.xaxis[d][x];
+          cross3(c + 3, s.xaxis[d], off);
+        }
+        for (int x = 0; x < 6; x++) s.u.t.cdof[d][x] = c[x];
+        qvel_r[lane] = s.qvel[d];
+      } else {
+        for (int x = 0; x < 6; x++) cdof[lane][x] = 0;
+        qvel_r[lane] = 0;
+      }
+    }
+    SYNC();
+    // comVel: cdof_dot (dof lanes), cvel (body lanes); crb = sum of cinert over the (contiguous) subtree
+    LANES {
+      if (lane < nv) {
+        float cv[6] = {0, 0, 0, 0, 0, 0};
+        uint64_t mk = d_velmask[lane];
+        while (mk) {
+          const int a = ffs64(mk);
+          mk &= mk - 1;
+          const float qv = s.qvel[a];
+          for (int x = 0; x < 6; x++) cv[x] += s.u.t.cdof[a][x] * qv;
+        }
+        const int jt = d_jtype[lane], k = lane - d_first[lane];
+        if (jt == JT_FREE && k < 3) { for (int x = 0; x < 6; x++) cdof_dot[lane][x] = 0; }
+        else cross_motion(cdof_dot[lane], cv, cdof[lane]);
+        for (int x = 0; x < 6; x++) s.u.t.cdof_dot[lane][x] = cdof_dot[lane][x];
+      } else {
+        for (int x = 0; x < 6; x++) cdof_dot[lane][x] = 0;
+      }
+      if (lane < nb) {
+        const int b = lane;
+        float cv[6] = {0, 0, 0, 0, 0, 0};
+        uint64_t mk = b_dofmask[lane];
+        while (mk) {
+          const int a = ffs64(mk);
+          mk &= mk - 1;
+          const float qv = s.qvel[a];
+          for (int x = 0; x < 6; x++) cv[x] += s.u.t.cdof[a][x] * qv;
+        }
+        for (int x = 0; x < 6; x++) s.u.t.cvel[b][x] = cv[x];
+        float c[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (b > 0)
+          for (int x = b; x < b + b_subsize[lane]; x++)
+            for (int k = 0; k < 10; k++) c[k] += s.u.t.cinert[x][k];
+        for (int k = 0; k < 10; k++) s.u.t.crb[b][k] = c[k];
+      }
+    }
+    SYNC();
+    LANES {
+      if (lane < nv) {
+        float bf[6];
+        mul_inert_vec(bf, s.u.t.crb[d_body[lane]], cdof[lane]);
+        for (int x = 0; x < 6; x++) s.u.t.buf[lane][x] = bf[x];
+      }
+    }
+    SYNC();
+    // M entries on the static sparsity pattern: lower (working copy), upper (kept), Mdiag
+    LANES {
+      for (int t = 0; t < 5; t++) {
+        const int i = e_i[lane][t], j = e_j[lane][t];
+        if (i < 0) continue;
+        float v = 0;
+        for (int x = 0; x < 6; x++) v += s.u.t.cdof[j][x] * s.u.t.buf[i][x];
+        if (i == j) { v += M.dof_armature[i]; s.Mdiag[i] = v; }
+        s.MM[i][j] = v;
+        if (i != j) s.MM[j][i] = v;
+      }
+    }
+    SYNC();
+  }
+
+  // ------------------------------------------------------------------ sparse L'DL in place (lower part of MM)
+  // [MJ] mj_factorM: for k = nv-1..0, eliminate row k from its ancestors' block.  Entry (i,j), j<=i<k, both
+  // ancestors of k:  M[i][j] -= M[k][i]*M[k][j]/M[k][k].  Non-ancestors hold zeros (static pattern, no fill-in).
+  SMJ_DEV void factor() {
+    const int nv = M.nv;
+    for (int k = nv - 1; k >= 0; k--) {
+      const float dkk = s.MM[k][k], dinv = 1.0f / dkk;
+      LANES {
+        for (int t = 0; t < 5; t++) {
+          const int i = e_i[lane][t], j = e_j[lane][t];
+          if (i < 0 || i >= k) continue;
+          const float a = s.MM[k][i];
+          if (a != 0.f) s.MM[i][j] -= a * s.MM[k][j] * dinv;
+        }
+      }
+      SYNC();
+      LANES {
+        if (lane < k) s.MM[k][lane] *= dinv;
+        if (lane == k) s.Dinv[k] = dinv;
+      }
+      SYNC();
+    }
+  }
+  // x <- L^-T-phase: for i = nv-1..0: x[j] -= L[i][j]*x[i] for j<i   (x lane-resident, lane = dof)
+  SMJ_DEV void solve_LT(PL<float>& x) {
+    for (int i = M.nv - 1; i > 0; i--) {
+      const float xi = wave_read(x, i);
+      LANES { if (lane < i) x[lane] -= s.MM[i][lane] * xi; }
+    }
+  }
+  // x <- L^-1-phase: for j = 0..nv-1: x[i] -= L[i][j]*x[j] for i>j
+  SMJ_DEV void solve_L(PL<float>& x) {
+    for (int j = 0; j < M.nv - 1; j++) {
+      const float xj = wave_read(x, j);
+      LANES { if (lane > j && lane < M.nv) x[lane] -= s.MM[lane][j] * xj; }
+    }
+  }
+
+  // ------------------------------------------------------------------ B.5/B.6 smooth forces -> g
+  SMJ_DEV void smooth_forces(bool dbg) {
+    const int nb = M.nbody, nv = M.nv, nu = M.nu;
+    PL<float> frc_passive, frc_bias, frc_act;
+    // passive: damper + spring
+    LANES {
+      float f = 0;
+      if (lane < nv) {
+        f = -d_damp[lane] * s.qvel[lane];
+        if (d_stiff[lane] != 0.f) f -= d_stiff[lane] * (s.qpos[d_qadr[lane]] - d_spring[lane]);
+      }
+      frc_passive[lane] = f;
+    }
+    // gravity compensation  [MJ] mj_passive gravcomp: F = -g*m*gravcomp at the body's gravcomp point
+    for (int t = 0; t < M.ngc; t++) {
+      const int b = M.k_gc_body[t];
+      const float gm = M.body_gcmass[b];
+      float pt[3], lp[3] = {M.body_gcipos[3 * b], M.body_gcipos[3 * b + 1], M.body_gcipos[3 * b + 2]};
+      mulmat3vec(pt, s.xmat[b], lp);
+      float off[3] = {pt[0] + s.xpos[b][0] - s.com[b][0], pt[1] + s.xpos[b][1] - s.com[b][1], pt[2] + s.xpos[b][2] - s.com[b][2]};
+      const float F[3] = {-M.gravity[0] * gm, -M.gravity[1] * gm, -M.gravity[2] * gm};
+      const uint64_t mk = mk64(M.k_body_dofmask_lo[b], M.k_body_dofmask_hi[b]);
+      LANES {
+        if ((mk >> lane) & 1) {
+          float tv[3];
+          cross3(tv, cdof[lane], off);
+          frc_passive[lane] += (cdof[lane][3] + tv[0]) * F[0] + (cdof[lane][4] + tv[1]) * F[1] + (cdof[lane][5] + tv[2]) * F[2];
+        }
+      }
+    }
+    // RNE bias: cacc (no qacc) per body, body force, subtree sum projected on cdof  [MJ] mj_rne(flg_acc=0)
+    LANES {
+      if (lane > 0 && lane < nb) {
+        const int b = lane;
+        float a[6] = {0, 0, 0, -M.gravity[0], -M.gravity[1], -M.gravity[2]};
+        uint64_t mk = b_dofmask[lane];
+        while (mk) {
+          const int d = ffs64(mk);
+          mk &= mk - 1;
+          const float qv = s.qvel[d];
+          for (int x = 0; x < 6; x++) a[x] += s.u.t.cdof_dot[d][x] * qv;
+        }
+        float t1[6], t2[6], cf[6];
+        mul_inert_vec(t1, s.u.t.cinert[b], a);
+        mul_inert_vec(t2, s.u.t.cinert[b], s.u.t.cvel[b]);
+        cross_force(cf, s.u.t.cvel[b], t2);
+        for (int x = 0; x < 6; x++) s.u.t.cfrc[b][x] = t1[x] + cf[x];
+      }
+    }
+    SYNC();
+    LANES {
+      float v = 0;
+      if (lane < nv) {
+        const int b = d_body[lane];
+        float cf[6] = {0, 0, 0, 0, 0, 0};
+        const int n = M.k_body_subtreesize[b];
+        for (int x = b; x < b + n; x++)
+          for (int k = 0; k < 6; k++) cf[k] += s.u.t.cfrc[x][k];
+        for (int k = 0; k < 6; k++) v += cdof[lane][k] * cf[k];
+      }
+      frc_bias[lane] = v;
+    }
+    // actuation  [MJ] mj_fwdActuation (static moments: joint / fixed-tendon transmissions)
+    LANES {
+      if (lane < nu) {
+        const int a = lane;
+        float len = 0, vel = 0;
+        for (int k = 0; k < nv; k++) {
+          const float mo = M.k_act_moment[a * nv + k];
+          if (mo != 0.f) {
+            vel += mo * s.qvel[k];
+            len += mo * s.qpos[M.k_dof_qposadr[k]];
+          }
+        }
+        float ctrl = s.ctrl[a];
+        if (M.actuator_ctrllimited[a]) ctrl = fminf(M.actuator_ctrlrange[2 * a + 1], fmaxf(M.actuator_ctrlrange[2 * a], ctrl));
+        float f = M.actuator_gainprm[3 * a] * ctrl;
+        if (M.actuator_biastype[a] == 1)
+          f += M.actuator_biasprm[3 * a] + M.actuator_biasprm[3 * a + 1] * len + M.actuator_biasprm[3 * a + 2] * vel;
+        if (M.actuator_forcelimited[a]) f = fminf(M.actuator_forcerange[2 * a + 1], fmaxf(M.actuator_forcerange[2 * a], f));
+        s.act_force[a] = f; s.act_len[a] = len; s.act_vel[a] = vel;
+      }
+    }
+    SYNC();
+    LANES {
+      float v = 0;
+      if (lane < nv)
+        for (int a = 0; a < nu; a++) v += M.k_act_moment[a * nv + lane] * s.act_force[a];
+      frc_act[lane] = v;
+      g_r[lane] = frc_passive[lane] - frc_bias[lane] + frc_act[lane];
+      if (lane < nv) s.g[lane] = g_r[lane];
+      if (dbg && S.debug && lane < nv) {
+        S.debug[(SMJ_DBG_QFRC_BIAS + lane) * S.ld + env] = frc_bias[lane];
+        S.debug[(SMJ_DBG_QFRC_PASSIVE + lane) * S.ld + env] = frc_passive[lane];
+        S.debug[(SMJ_DBG_QFRC_ACT + lane) * S.ld + env] = frc_act[lane];
+        S.debug[(SMJ_DBG_G + lane) * S.ld + env] = g_r[lane];
+      }
+    }
+    SYNC();
+  }
+
+  // ------------------------------------------------------------------ B.3 collision (plane pairs)
+  SMJ_DEV void geom_pose(int g, float* pos, float* mat) const {
+    const int b = M.geom_bodyid[g];
+    float lp[3] = {M.geom_pos[3 * g], M.geom_pos[3 * g + 1], M.geom_pos[3 * g + 2]};
+    mulmat3vec(pos, s.xmat[b], lp);
+    for (int k = 0; k < 3; k++) pos[k] += s.xpos[b][k];
+    float lm[9];
+    for (int k = 0; k < 9; k++) lm[k] = M.k_geom_mat[9 * g + k];
+    mulmat3(mat, s.xmat[b], lm);
+  }
+  SMJ_DEV void add_contact(int pair, int g1, int g2, float dist, const float* pos, const float* n) {
+    // uniform: every lane calls with identical arguments; lane 0 writes
+    if (ncon >= NCON) { flags |= SMJ_FLAG_CON_OVERFLOW; return; }
+    const int c = ncon++;
+    LANES {
+      if (lane == 0) {
+        s.cdist[c] = dist;
+        float fr[9] = {n[0], n[1], n[2], 0, 0, 0, 0, 0, 0};
+        normalize3(fr);
+        if (fr[1] > -0.5f && fr[1] < 0.5f) { fr[3] = 0; fr[4] = 1; fr[5] = 0; } else { fr[3] = 0; fr[4] = 0; fr[5] = 1; }
+        const float t = dot3(fr, fr + 3);
+        for (int k = 0; k < 3; k++) fr[3 + k] -= t * fr[k];
+        normalize3(fr + 3);
+        cross3(fr + 6, fr, fr + 3);
+        for (int k = 0; k < 9; k++) s.cframe[c][k] = fr[k];
+        for (int k = 0; k < 3; k++) s.cpos[c][k] = pos[k];
+        for (int k = 0; k < 5; k++) { s.cfric[c][k] = M.pair_friction[5 * pair + k]; s.csolimp[c][k] = M.pair_solimp[5 * pair + k]; }
+        s.csolref[c][0] = M.pair_solref[2 * pair]; s.csolref[c][1] = M.pair_solref[2 * pair + 1];
+        s.cmargin[c] = M.pair_margin[pair] - M.pair_gap[pair];
+        s.cdim[c] = M.pair_condim[pair]; s.cgeom1[c] = g1; s.cgeom2[c] = g2; s.cefc[c] = -1;
+      }
+    }
+  }
+
+  SMJ_DEV void collision() {
+    ncon = 0;
+    // broadphase over plane pairs: lane = pair (chunks of 64), bounding sphere vs plane
+    for (int base = 0; base < M.nplanepair; base += 64) {
+      PL<int> hit;
+      LANES {
+        int h = 0;
+        const int t = base + lane;
+        if (t < M.nplanepair) {
+          const int p = M.k_planepair[t], g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
+          const int b1 = M.geom_bodyid[g1], b2 = M.geom_bodyid[g2];
+          // plane: normal = z axis of plane geom frame
+          float pp[3], pm[9];
+          geom_pose(g1, pp, pm);
+          float c2[3], lc[3] = {M.k_geom_bcenter[3 * g2], M.k_geom_bcenter[3 * g2 + 1], M.k_geom_bcenter[3 * g2 + 2]};
+          mulmat3vec(c2, s.xmat[b2], lc);
+          const float n[3] = {pm[2], pm[5], pm[8]};
+          const float dif[3] = {c2[0] + s.xpos[b2][0] - pp[0], c2[1] + s.xpos[b2][1] - pp[1], c2[2] + s.xpos[b2][2] - pp[2]};
+          (void)b1;
+          h = (dot3(dif, n) - M.geom_rbound[g2] <= M.pair_margin[p]) ? 1 : 0;
+        }
+        hit[lane] = h;
+      }
+      uint64_t mask = wave_ballot(hit);
+      while (mask) {
+        const int l = ffs64(mask);
+        mask &= mask - 1;
+        narrow_plane(M.k_planepair[base + l]);
+      }
+    }
+    SYNC();
+  }
+
+  // narrowphase for one plane pair; uniform control flow, vertex loops are lane-parallel
+  SMJ_DEV void narrow_plane(int p) {
+    const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p], t2 = M.geom_type[g2];
+    const float margin = M.pair_margin[p];
+    float pp[3], pm[9], gp[3], gm[9];
+    geom_pose(g1, pp, pm);
+    geom_pose(g2, gp, gm);
+    const float n[3] = {pm[2], pm[5], pm[8]};
+    const float size[3] = {M.geom_size[3 * g2], M.geom_size[3 * g2 + 1], M.geom_size[3 * g2 + 2]};
+    if (t2 == GT_SPHERE) {
+      const float dif[3] = {gp[0] - pp[0], gp[1] - pp[1], gp[2] - pp[2]};
+      const float dist = dot3(dif, n) - size[0];
+      if (dist > margin) return;
+      float pos[3];
+      for (int k = 0; k < 3; k++) pos[k] = gp[k] - n[k] * (size[0] + 0.5f * dist);
+      add_contact(p, g1, g2, dist, pos, n);
+    } else if (t2 == GT_CYLINDER) {  // [MJ] mjc_PlaneCylinder
+      float axis[3] = {gm[2], gm[5], gm[8]};
+      float prjaxis = dot3(n, axis);
+      if (prjaxis > 0) { for (int k = 0; k < 3; k++) axis[k] = -axis[k]; prjaxis = -prjaxis; }
+      float vec[3] = {gp[0] - pp[0], gp[1] - pp[1], gp[2] - pp[2]};
+      const float dist0 = dot3(vec, n);
+      for (int k = 0; k < 3; k++) vec[k] = axis[k] * prjaxis - n[k];
+      const float len2 = dot3(vec, vec);
+      if (len2 >= 1e-30f) { const float sc = size[0] / sqrtf(len2); for (int k = 0; k < 3; k++) vec[k] *= sc; }
+      else { vec[0] = gm[0] * size[0]; vec[1] = gm[3] * size[0]; vec[2] = gm[6] * size[0]; }
+      const float prjvec = dot3(vec, n);
+      for (int k = 0; k < 3; k++) axis[k] *= size[1];
+      prjaxis *= size[1];
+      if (dist0 + prjaxis + prjvec > margin) return;
+      float pos[3], dist = dist0 + prjaxis + prjvec;
+      for (int k = 0; k < 3; k++) pos[k] = gp[k] + vec[k] + axis[k] - n[k] * dist * 0.5f;
+      add_contact(p, g1, g2, dist, pos, n);
+      if (dist0 - prjaxis + prjvec <= margin) {
+        dist = dist0 - prjaxis + prjvec;
+        for (int k = 0; k < 3; k++) pos[k] = gp[k] + vec[k] - axis[k] - n[k] * dist * 0.5f;
+        add_contact(p, g1, g2, dist, pos, n);
+      }
+      const float prjvec1 = -prjvec * 0.5f;
+      if (dist0 + prjaxis + prjvec1 <= margin) {
+        float vec1[3];
+        cross3(vec1, vec, axis);
+        normalize3(vec1);
+        for (int k = 0; k < 3; k++) vec1[k] *= size[0] * 0.8660254037844386f;
+        dist = dist0 + prjaxis + prjvec1;
+        for (int sg = 0; sg < 2; sg++) {
+          const float sgn = sg ? -1.f : 1.f;
+          for (int k = 0; k < 3; k++) pos[k] = gp[k] + sgn * vec1[k] + axis[k] - vec[k] * 0.5f - n[k] * dist * 0.5f;
+          add_contact(p, g1, g2, dist, pos, n);
+        }
+      }
+    } else if (t2 == GT_BOX) {  // [MJ] mjc_PlaneBox
+      const float dif[3] = {gp[0] - pp[0], gp[1] - pp[1], gp[2] - pp[2]};
+      const float dist = dot3(dif, n);
+      int cnt = 0;
+      for (int i = 0; i < 8 && cnt < 4; i++) {
+        const float v[3] = {(i & 1) ? size[0] : -size[0], (i & 2) ? size[1] : -size[1], (i & 4) ? size[2] : -size[2]};
+        float corner[3];
+        mulmat3vec(corner, gm, v);
+        const float ldist = dot3(n, corner);
+        if (dist + ldist > margin || ldist > 0) continue;
+        const float cd = dist + ldist;
+        float pos[3];
+        for (int k = 0; k < 3; k++) pos[k] = gp[k] + corner[k] - n[k] * cd * 0.5f;
+        add_contact(p, g1, g2, cd, pos, n);
+        cnt++;
+      }
+    } else if (t2 == GT_MESH) {
+      plane_hull(p, g1, g2, pp, n, gp, gm, margin);
+    }
+  }
+
+  // plane vs convex hull, vertices strided over lanes; same selection rule as oracle plane_hull()
+  SMJ_DEV void plane_hull(int p, int g1, int g2, const float* pp, const float* n, const float* gp, const float* gm, float margin) {
+    const float* verts = M.hull_vert + 3 * M.geom_hulladr[g2];
+    const int nvert = M.geom_hullnum[g2];
+    float nl[3];
+    mulmat3Tvec(nl, gm, n);
+    const float off = (gp[0] - pp[0]) * n[0] + (gp[1] - pp[1]) * n[1] + (gp[2] - pp[2]) * n[2];
+    // pass 1: deepest vertex (ties -> lowest index)
+    PL<float> best;
+    PL<int> bidx;
+    LANES {
+      float bd = 3.0e38f;
+      int bi = -1;
+      for (int i = lane; i < nvert; i += 64) {
+        const float dd = nl[0] * verts[3 * i] + nl[1] * verts[3 * i + 1] + nl[2] * verts[3 * i + 2] + off;
+        if (dd <= margin && dd < bd) { bd = dd; bi = i; }
+      }
+      best[lane] = bd; bidx[lane] = bi;
+    }
+    const float dmin = wave_min(best);
+    if (dmin > margin) return;
+    int i1 = pick_index(best, bidx, dmin);
+    int idx[4] = {i1, -1, -1, -1};
+    const float v1[3] = {verts[3 * i1], verts[3 * i1 + 1], verts[3 * i1 + 2]};
+    if (M.max_con_pair > 1) {
+      LANES {
+        float bd = 1e-12f;
+        int bi = -1;
+        for (int i = lane; i < nvert; i += 64) {
+          const float dd = nl[0] * verts[3 * i] + nl[1] * verts[3 * i + 1] + nl[2] * verts[3 * i + 2] + off;
+          if (dd > margin) continue;
+          const float e[3] = {verts[3 * i] - v1[0], verts[3 * i + 1] - v1[1], verts[3 * i + 2] - v1[2]};
+          const float r2 = dot3(e, e);
+          if (r2 > bd) { bd = r2; bi = i; }
+        }
+        best[lane] = bi >= 0 ? -bd : 3.0e38f; bidx[lane] = bi;
+      }
+      const float m2 = wave_min(best);
+      if (m2 < 1.0e38f) idx[1] = pick_index(best, bidx, m2);
+    }
+    if (idx[1] >= 0 && M.max_con_pair > 2) {
+      const int i2 = idx[1];
+      float e12[3] = {verts[3 * i2] - v1[0], verts[3 * i2 + 1] - v1[1], verts[3 * i2 + 2] - v1[2]}, side[3];
+      cross3(side, nl, e12);
+      normalize3(side);
+      PL<float> bmin;
+      PL<int> imin;
+      LANES {
+        float smax = 1e-6f, smin = -1e-6f;
+        int i3 = -1, i4 = -1;
+        for (int i = lane; i < nvert; i += 64) {
+          const float dd = nl[0] * verts[3 * i] + nl[1] * verts[3 * i + 1] + nl[2] * verts[3 * i + 2] + off;
+          if (dd > margin) continue;
+          const float e[3] = {verts[3 * i] - v1[0], verts[3 * i + 1] - v1[1], verts[3 * i + 2] - v1[2]};
+          const float sv = dot3(e, side);
+          if (sv > smax) { smax = sv; i3 = i; }
+          if (sv < smin) { smin = sv; i4 = i; }
+        }
+        best[lane] = i3 >= 0 ? -smax : 3.0e38f; bidx[lane] = i3;
+        bmin[lane] = i4 >= 0 ? smin : 3.0e38f; imin[lane] = i4;
+      }
+      const float m3 = wave_min(best);
+      if (m3 < 1.0e38f) idx[2] = pick_index(best, bidx, m3);
+      if (M.max_con_pair > 3) {
+        const float m4 = wave_min(bmin);
+        if (m4 < 1.0e38f) idx[3] = pick_index(bmin, imin, m4);
+      }
+    }
+    for (int k = 0; k < 4; k++) {
+      if (idx[k] < 0) continue;
+      const float v[3] = {verts[3 * idx[k]], verts[3 * idx[k] + 1], verts[3 * idx[k] + 2]};
+      float wv[3], pos[3];
+      const float dd = dot3(nl, v) + off;
+      mulmat3vec(wv, gm, v);
+      for (int j = 0; j < 3; j++) pos[j] = gp[j] + wv[j] - n[j] * dd * 0.5f;
+      add_contact(p, g1, g2, dd, pos, n);
+    }
+  }
+  // among lanes whose key equals `val`, the lowest stored index (deterministic tie-break)
+  SMJ_DEV int pick_index(const PL<float>& key, const PL<int>& idx, float val) {
+    PL<float> cand;
+    LANES { cand[lane] = (key[lane] == val && idx[lane] >= 0) ? (float)idx[lane] : 3.0e38f; }
+    return (int)wave_min(cand);
+  }
+
+  // ------------------------------------------------------------------ B.4 constraint rows
+  SMJ_DEV void make_constraint() {
+    const int nv = M.nv, neq = M.neq, nfric = M.nfric, nlimit = M.nlimit;
+    LANES {
+      for (int k = 0; k < JS; k++) s.J[lane][k] = 0.f;
+      s.etype[lane] = CT_NONE; s.efloss[lane] = 0; s.eid[lane] = 0; s.epos[lane] = 0; s.emargin[lane] = 0; s.ediag[lane] = 0;
+    }
+    SYNC();
+    // equality rows (all equalities active; inactive ones get an empty row with R large -> force 0)
+    PL<int> act;
+    LANES {
+      if (lane < neq) {
+        const int e = lane, j1 = M.eq_obj1id[e], j2 = M.eq_obj2id[e];
+        const float* a = M.eq_data + 5 * e;
+        const int q1 = M.jnt_qposadr[j1], d1 = M.jnt_dofadr[j1];
+        float pos = s.qpos[q1] - M.qpos0[q1], deriv = 0, diag = M.dof_invweight0[d1];
+        if (j2 >= 0) {
+          const int q2 = M.jnt_qposadr[j2], d2 = M.jnt_dofadr[j2];
+          const float dif = s.qpos[q2] - M.qpos0[q2];
+          pos -= a[0] + dif * (a[1] + dif * (a[2] + dif * (a[3] + dif * a[4])));
+          deriv = a[1] + dif * (2 * a[2] + dif * (3 * a[3] + dif * 4 * a[4]));
+          diag += M.dof_invweight0[d2];
+          s.J[e][d2] = -deriv;
+        } else pos -= a[0];
+        s.J[e][d1] = 1.f;
+        s.etype[e] = CT_EQUALITY; s.eid[e] = e; s.epos[e] = pos; s.emargin[e] = 0; s.ediag[e] = diag;
+      }
+      if (lane < nfric) {
+        const int r = neq + lane, k = M.k_fric_dof[lane];
+        s.J[r][k] = 1.f;
+        s.etype[r] = CT_FRICTION; s.eid[r] = k; s.efloss[r] = M.dof_frictionloss[k]; s.ediag[r] = M.dof_invweight0[k];
+      }
+      // limits: lane -> (joint, side), lower side first
+      int a = 0;
+      if (lane < 2 * nlimit) {
+        const int j = M.k_limit_jnt[lane >> 1], side = (lane & 1) ? 1 : -1;
+        const float q = s.qpos[M.jnt_qposadr[j]];
+        const float dist = side * (M.jnt_range[2 * j + (lane & 1)] - q);
+        a = dist < M.jnt_margin[j];
+      }
+      act[lane] = a;
+    }
+    const uint64_t lm = wave_ballot(act);
+    int row0 = neq + nfric;
+    LANES {
+      if (act[lane]) {
+        const int r = row0 + popc64(lm & ((1ull << lane) - 1));
+        if (r < NEFC) {
+          const int j = M.k_limit_jnt[lane >> 1], side = (lane & 1) ? 1 : -1, d = M.jnt_dofadr[j];
+          const float q = s.qpos[M.jnt_qposadr[j]];
+          s.J[r][d] = (float)(-side);
+          s.etype[r] = CT_LIMIT; s.eid[r] = j; s.epos[r] = side * (M.jnt_range[2 * j + (lane & 1)] - q);
+          s.emargin[r] = M.jnt_margin[j]; s.ediag[r] = M.dof_invweight0[d];
+        }
+      }
+    }
+    row0 += popc64(lm);
+    if (row0 > NEFC) { row0 = NEFC; flags |= SMJ_FLAG_EFC_OVERFLOW; }
+    SYNC();
+    // contact rows: lanes = dofs fill the Jacobian columns
+    for (int c = 0; c < ncon; c++) {
+      const int dim = s.cdim[c];
+      if (!(s.cdist[c] < s.cmargin[c])) continue;
+      if (row0 + dim > NEFC) { flags |= SMJ_FLAG_EFC_OVERFLOW; continue; }
+      const int g1 = s.cgeom1[c], g2 = s.cgeom2[c], b1 = M.geom_bodyid[g1], b2 = M.geom_bodyid[g2];
+      const uint64_t m1 = mk64(M.k_body_dofmask_lo[b1], M.k_body_dofmask_hi[b1]), m2 = mk64(M.k_body_dofmask_lo[b2], M.k_body_dofmask_hi[b2]);
+      const float tran = M.geom_invweight0[2 * g1] + M.geom_invweight0[2 * g2], rot = M.geom_invweight0[2 * g1 + 1] + M.geom_invweight0[2 * g2 + 1];
+      LANES {
+        if (lane < nv) {
+          const float sg = (float)((int)((m2 >> lane) & 1) - (int)((m1 >> lane) & 1));
+          if (sg != 0.f) {
+            // both bodies hang off the same tree root here (or one is the world): offsets relative to that root's com
+            const int bb = ((m2 >> lane) & 1) ? b2 : b1;
+            const float off[3] = {s.cpos[c][0] - s.com[bb][0], s.cpos[c][1] - s.com[bb][1], s.cpos[c][2] - s.com[bb][2]};
+            float tv[3];
+            cross3(tv, cdof[lane], off);
+            const float jp[3] = {cdof[lane][3] + tv[0], cdof[lane][4] + tv[1], cdof[lane][5] + tv[2]};
+            for (int r = 0; r < dim; r++) {
+              const float* ax = s.cframe[c] + 3 * (r < 3 ? r : r - 3);
+              s.J[row0 + r][lane] = sg * (r < 3 ? dot3(ax, jp) : dot3(ax, cdof[lane]));
+            }
+          }
+        }
+        if (lane < dim) {
+          const int r = row0 + lane;
+          s.etype[r] = dim == 1 ? CT_CONTACT_FRICTIONLESS : CT_CONTACT_ELLIPTIC;
+          s.eid[r] = c; s.epos[r] = s.cdist[c]; s.emargin[r] = s.cmargin[c]; s.ediag[r] = lane < 3 ? tran : rot;
+        }
+        if (lane == 0) s.cefc[c] = row0;
+      }
+      row0 += dim;
+    }
+    nefc = row0;
+    SYNC();
+    // impedance, R, K, B  [MJ] mj_makeImpedance
+    LANES {
+      const int i = lane;
+      if (i < nefc) {
+        const int t = s.etype[i], id = s.eid[i];
+        float solref[2], solimp[5];
+        const float *sr, *si;
+        if (t == CT_EQUALITY) { sr = M.eq_solref + 2 * id; si = M.eq_solimp + 5 * id; }
+        else if (t == CT_FRICTION) { sr = M.dof_solref + 2 * id; si = M.dof_solimp + 5 * id; }
+        else if (t == CT_LIMIT) { sr = M.jnt_solref + 2 * id; si = M.jnt_solimp + 5 * id; }
+        else { sr = s.csolref[id]; si = s.csolimp[id]; }
+        solref[0] = sr[0]; solref[1] = sr[1];
+        for (int k = 0; k < 5; k++) solimp[k] = si[k];
+        const float imp = impedance(solimp, s.epos[i], s.emargin[i]);
+        s.eR[i] = fmaxf(SMJ_MINVAL, (1 - imp) * s.ediag[i] / imp);
+        const float dmax = fminf(SMJ_MAXIMP, fmaxf(SMJ_MINIMP, solimp[1]));
+        float K, B;
+        if (solref[0] > 0) {
+          const float tc = fmaxf(solref[0], 2 * M.timestep), dr = solref[1];
+          K = 1.0f / fmaxf(SMJ_MINVAL, dmax * dmax * tc * tc * dr * dr);
+          B = 2.0f / fmaxf(SMJ_MINVAL, dmax * tc);
+        } else { K = -solref[0] / fmaxf(SMJ_MINVAL, dmax * dmax); B = -solref[1] / fmaxf(SMJ_MINVAL, dmax); }
+        const bool fr = (t == CT_FRICTION) || (t == CT_CONTACT_ELLIPTIC && i != s.cefc[id]);
+        if (fr) K = 0;
+        s.eK[i] = K; s.eBv[i] = B; s.eimp[i] = imp;
+      }
+    }
+    SYNC();
+    LANES {
+      if (lane < ncon) {
+        const int c = lane, i = s.cefc[c], dim = s.cdim[c];
+        if (i >= 0 && dim >= 3) {
+          const float r1 = s.eR[i] / fmaxf(SMJ_MINVAL, M.impratio);
+          s.eR[i + 1] = r1;
+          const float f0 = s.cfric[c][0];
+          for (int j = 1; j < dim - 1; j++) s.eR[i + 1 + j] = r1 * f0 * f0 / (s.cfric[c][j] * s.cfric[c][j]);
+        }
+      }
+    }
+    SYNC();
+  }
+
+  // contact regularised-cone mu  [MJ] con->mu = friction[0]*sqrt(R[1]/R[0])
+  SMJ_DEV float contact_mu(int c) const {
+    const int i = s.cefc[c];
+    return s.cfric[c][0] * sqrtf(s.eR[i + 1] / s.eR[i]);
+  }
+
+  // ------------------------------------------------------------------ projectConstraint + PGS
+  SMJ_DEV void solve(bool dbg) {
+    const int nv = M.nv, ne = nefc;
+    // efc_vel, aref, warm-start residual jar (rows = lanes), all from J before it is transformed
+    PL<float> aref, jar, Rr, bb;
+    LANES {
+      float vel = 0, jw = 0;
+      if (lane < ne)
+        for (int k = 0; k < nv; k++) { const float jv = s.J[lane][k]; vel += jv * s.qvel[k]; jw += jv * s.warm[k]; }
+      const float ar = lane < ne ? -s.eBv[lane] * vel - s.eK[lane] * s.eimp[lane] * (s.epos[lane] - s.emargin[lane]) : 0.f;
+      aref[lane] = ar; jar[lane] = jw - ar; Rr[lane] = lane < ne ? s.eR[lane] : 1.f;
+      s.earef[lane] = ar;
+    }
+    // u = L^-T phase of g (dof lanes)
+    PL<float> u;
+    LANES { u[lane] = lane < nv ? g_r[lane] : 0.f; }
+    solve_LT(u);
+    LANES { if (lane < NVP) s.uu[lane] = lane < nv ? u[lane] : 0.f; }
+    // Y = J L^-1 : every lane runs the L^-T phase on its own row (private LDS row)
+    for (int i = nv - 1; i > 0; i--) {
+      const int na = M.k_dof_anc_num[i], adr = M.k_dof_anc_adr[i];
+      if (na == 0) continue;
+      LANES {
+        const float xi = s.J[lane][i];
+        if (xi != 0.f)
+          for (int a = 0; a < na; a++) {
+            const int j = M.k_dof_anc[adr + a];
+            s.J[lane][j] -= s.MM[i][j] * xi;
+          }
+      }
+    }
+    SYNC();
+    // b = Y Dinv u - aref
+    LANES {
+      float v = 0;
+      if (lane < ne)
+        for (int k = 0; k < nv; k++) v += s.J[lane][k] * s.Dinv[k] * s.uu[k];
+      bb[lane] = v - aref[lane];
+      s.eb[lane] = bb[lane];
+    }
+    SYNC();  // all reads of the tree temporaries that alias A are done (cdof etc. live in registers from here on)
+    // A = Y Dinv Y' (+R on the diagonal) on the matrix cores, 16x16 tiles, K = nv padded to 4
+    {
+      const int ntile = (ne + 15) >> 4, ksteps = (nv + 3) >> 2;
+      for (int tr = 0; tr < ntile; tr++)
+        for (int tc = 0; tc <= tr; tc++) {
+          PL<F4v> acc;
+          LANES { for (int r = 0; r < 4; r++) acc[lane].r[r] = 0.f; }
+          for (int ks = 0; ks < ksteps; ks++) {
+            PL<float> a, b;
+            LANES {
+              const int k = 4 * ks + (lane >> 4);
+              const float dk = k < nv ? s.Dinv[k] : 0.f;
+              a[lane] = k < nv ? s.J[16 * tr + (lane & 15)][k] * dk : 0.f;
+              b[lane] = k < nv ? s.J[16 * tc + (lane & 15)][k] : 0.f;
+            }
+            mfma16x16x4(acc, a, b);
+          }
+          LANES {
+            for (int r = 0; r < 4; r++) {
+              const int row = 16 * tr + (lane >> 4) * 4 + r, col = 16 * tc + (lane & 15);
+              float v = acc[lane].r[r];
+              if (row == col) v += row < ne ? s.eR[row] : 1.f;
+              s.u.A[row * NEFC + col] = v;
+              if (tr != tc) s.u.A[col * NEFC + row] = v;
+            }
+          }
+        }
+    }
+    SYNC();
+    // warm start  [MJ] mj_warmstart (PGS branch): forces from the primal residual at qacc_warmstart
+    LANES { s.earef[lane] = jar[lane]; }  // stash jar in LDS so a contact's first row can see its block
+    SYNC();
+    LANES {
+      float f = 0;
+      const int i = lane;
+      if (i < ne && M.warmstart) {
+        const int t = s.etype[i];
+        const float D = 1.0f / Rr[lane], jr = jar[lane];
+        if (t == CT_EQUALITY) f = -D * jr;
+        else if (t == CT_FRICTION) {
+          const float fl = s.efloss[i];
+          f = (jr <= -Rr[lane] * fl) ? fl : (jr >= Rr[lane] * fl) ? -fl : -D * jr;
+        } else if (t == CT_LIMIT || t == CT_CONTACT_FRICTIONLESS) f = jr < 0 ? -D * jr : 0.f;
+      }
+      s.ef[lane] = f;  // elliptic rows: overwritten below by the contact's lane
+    }
+    SYNC();
+    LANES {
+      if (lane < ncon && M.warmstart) {
+        const int c = lane, i = s.cefc[c], dim = s.cdim[c];
+        if (i >= 0 && dim >= 3) {
+          const float mu = contact_mu(c);
+          float U[6], T = 0;
+          U[0] = s.earef[i] * mu;
+          for (int j = 1; j < dim; j++) { U[j] = s.earef[i + j] * s.cfric[c][j - 1]; T += U[j] * U[j]; }
+          const float N = U[0];
+          T = sqrtf(T);
+          if ((T <= 0 && N >= 0) || (T > 0 && N >= mu * T)) { for (int j = 0; j < dim; j++) s.ef[i + j] = 0; }
+          else if ((T <= 0 && N < 0) || (T > 0 && mu * N + T <= 0)) { for (int j = 0; j < dim; j++) s.ef[i + j] = -s.earef[i + j] / s.eR[i + j]; }
+          else {
+            const float Dm = (1.0f / s.eR[i]) / fmaxf(mu * mu * (1 + mu * mu), SMJ_MINVAL), NmT = N - mu * T;
+            const float fn = -Dm * NmT * mu;
+            s.ef[i] = fn;
+            for (int j = 1; j < dim; j++) s.ef[i + j] = -fn / T * U[j] * s.cfric[c][j - 1];
+          }
+        }
+      }
+    }
+    SYNC();
+    // residual r = A f + b (lanes = rows; column reads via symmetry), dual cost of the warm start
+    PL<float> cost;
+    LANES {
+      f_r[lane] = lane < ne ? s.ef[lane] : 0.f;
+      s.earef[lane] = aref[lane];
+    }
+    residual_refresh(bb);
+    LANES { cost[lane] = lane < ne ? f_r[lane] * 0.5f * (r_r[lane] + bb[lane]) : 0.f; }
+    const float wcost = wave_sum(cost);
+    if (wcost > 0) { LANES { f_r[lane] = 0.f; r_r[lane] = bb[lane]; } }
+    LANES { ARinv_r[lane] = 1.0f / s.u.A[lane * NEFC + lane]; }
+
+    // ---- PGS sweeps  [MJ] mj_solPGS
+    const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
+    int iter = 0;
+    for (; iter < M.iterations; iter++) {
+      float improvement = 0;
+      if (iter > 0 && (iter & 7) == 0) residual_refresh(bb);
+      for (int i = 0; i < ne;) {
+        const int t = s.etype[i];
+        if (t != CT_CONTACT_ELLIPTIC) {
+          const float res = wave_read(r_r, i), old = wave_read(f_r, i), aii = s.u.A[i * NEFC + i];
+          float fn = old - res / aii;
+          if (t == CT_FRICTION) { const float fl = s.efloss[i]; fn = fminf(fl, fmaxf(-fl, fn)); }
+          else if (t != CT_EQUALITY) fn = fmaxf(0.f, fn);
+          float delta = fn - old;
+          float change = delta * (0.5f * aii * delta + res);
+          if (change > 1e-10f) { delta = 0; change = 0; }
+          improvement -= change;
+          if (delta != 0.f) {
+            LANES {
+              r_r[lane] += s.u.A[i * NEFC + lane] * delta;
+              if (lane == i) f_r[lane] += delta;
+            }
+          }
+          i += 1;
+        } else {
+          const int c = s.eid[i], dim = s.cdim[c];
+          if (dim == 3) improvement += pgs_block<3>(i, c);
+          else if (dim == 4) improvement += pgs_block<4>(i, c);
+          else improvement += pgs_block<6>(i, c);
+          i += dim;
+        }
+      }
+      improvement *= scale;
+      if (!M.pgs_fixed_iter && improvement < M.tolerance) { iter++; break; }
+    }
+    niter = iter;
+    LANES { s.ef[lane] = lane < ne ? f_r[lane] : 0.f; }
+    SYNC();
+    // w = Y' f (dof lanes); qfrc_constraint = L' w ; qacc = L^-1 ( Dinv (u + w) )
+    PL<float> w, qc;
+    LANES {
+      float v = 0;
+      if (lane < nv)
+        for (int r = 0; r < ne; r++) v += s.J[r][lane] * s.ef[r];
+      w[lane] = v;
+      if (lane < NVP) s.w[lane] = v;
+    }
+    SYNC();
+    LANES {
+      float v = w[lane];
+      if (lane < nv)
+        for (int i = lane + 1; i < nv; i++) v += s.MM[i][lane] * s.w[i];
+      qc[lane] = v;  // J' f
+      qacc_r[lane] = lane < nv ? s.Dinv[lane] * (u[lane] + w[lane]) : 0.f;
+    }
+    solve_L(qacc_r);
+    LANES {
+      if (lane < nv) { s.qacc[lane] = qacc_r[lane]; s.warm[lane] = qacc_r[lane]; s.tmp[lane] = g_r[lane] + qc[lane]; }
+    }
+    SYNC();
+    if (dbg && S.debug) {
+      LANES {
+        if (lane < nv) S.debug[(SMJ_DBG_QACC + lane) * S.ld + env] = qacc_r[lane];
+        S.debug[(SMJ_DBG_EFC_FORCE + lane) * S.ld + env] = lane < ne ? f_r[lane] : 0.f;
+        S.debug[(SMJ_DBG_EFC_B + lane) * S.ld + env] = lane < ne ? bb[lane] : 0.f;
+        S.debug[(SMJ_DBG_EFC_R + lane) * S.ld + env] = lane < ne ? s.eR[lane] : 0.f;
+        S.debug[(SMJ_DBG_EFC_AREF + lane) * S.ld + env] = lane < ne ? aref[lane] : 0.f;
+        S.debug[(SMJ_DBG_AR_DIAG + lane) * S.ld + env] = lane < ne ? s.u.A[lane * NEFC + lane] : 0.f;
+        for (int k = 0; k < NEFC; k++) S.debug[(SMJ_DBG_AR + k * NEFC + lane) * S.ld + env] = (k < ne && lane < ne) ? s.u.A[k * NEFC + lane] : 0.f;
+      }
+    }
+  }
+
+  SMJ_DEV void residual_refresh(const PL<float>& bb) {
+    LANES { s.ef[lane] = f_r[lane]; }
+    SYNC();
+    LANES {
+      float v = bb[lane];
+      if (lane < nefc)
+        for (int k = 0; k < nefc; k++) v += s.u.A[k * NEFC + lane] * s.ef[k];
+      r_r[lane] = v;
+    }
+    SYNC();
+  }
+
+  // one elliptic contact block of the PGS sweep  [MJ] mj_solPGS elliptic branch (ray update + QCQP); uniform math
+  template <int DIM>
+  SMJ_DEV float pgs_block(int i, int c) {
+    float res[DIM], old[DIM], f[DIM], At[DIM * DIM], mu[DIM - 1];
+#pragma unroll
+    for (int r = 0; r < DIM; r++) {
+      res[r] = wave_read(r_r, i + r); old[r] = wave_read(f_r, i + r); f[r] = old[r];
+#pragma unroll
+      for (int q = 0; q < DIM; q++) At[r * DIM + q] = s.u.A[(i + r) * NEFC + i + q];
+    }
+#pragma unroll
+    for (int j = 0; j < DIM - 1; j++) mu[j] = s.cfric[c][j];
+    if (f[0] < SMJ_MINVAL) {
+      f[0] -= res[0] / At[0];
+      if (f[0] < 0) f[0] = 0;
+#pragma unroll
+      for (int j = 1; j < DIM; j++) f[j] = 0;
+    } else {
+      float denom = 0, num = 0;
+#pragma unroll
+      for (int r = 0; r < DIM; r++) {
+        float v1 = 0;
+#pragma unroll
+        for (int q = 0; q < DIM; q++) v1 += At[r * DIM + q] * old[q];
+        denom += old[r] * v1; num += old[r] * res[r];
+      }
+      if (denom >= SMJ_MINVAL) {
+        float x = -num / denom;
+        if (f[0] + x * old[0] < 0) x = -f[0] / old[0];
+#pragma unroll
+        for (int r = 0; r < DIM; r++) f[r] += x * old[r];
+      }
+    }
+    float Ac[(DIM - 1) * (DIM - 1)], bc[DIM - 1], v[DIM - 1];
+#pragma unroll
+    for (int j = 0; j < DIM - 1; j++) {
+#pragma unroll
+      for (int q = 0; q < DIM - 1; q++) Ac[j * (DIM - 1) + q] = At[(j + 1) * DIM + q + 1];
+      float bj = res[j + 1];
+#pragma unroll
+      for (int q = 0; q < DIM; q++) bj -= At[(j + 1) * DIM + q] * old[q];
+      bc[j] = bj + At[(j + 1) * DIM] * f[0];
+    }
+    if (f[0] < SMJ_MINVAL) {
+#pragma unroll
+      for (int j = 1; j < DIM; j++) f[j] = 0;
+    } else {
+      const int active = qcqp<DIM - 1>(v, Ac, bc, mu, f[0]);
+      if (active) {
+        float sc = 0;
+#pragma unroll
+        for (int j = 0; j < DIM - 1; j++) sc += v[j] * v[j] / (mu[j] * mu[j]);
+        sc = sqrtf(f[0] * f[0] / fmaxf(SMJ_MINVAL, sc));
+#pragma unroll
+        for (int j = 0; j < DIM - 1; j++) v[j] *= sc;
+      }
+#pragma unroll
+      for (int j = 0; j < DIM - 1; j++) f[j + 1] = v[j];
+    }
+    float change = 0, delta[DIM];
+#pragma unroll
+    for (int r = 0; r < DIM; r++) delta[r] = f[r] - old[r];
+#pragma unroll
+    for (int r = 0; r < DIM; r++) {
+      float sv = 0;
+#pragma unroll
+      for (int q = 0; q < DIM; q++) sv += At[r * DIM + q] * delta[q];
+      change += delta[r] * (0.5f * sv + res[r]);
+    }
+    if (change > 1e-10f) return 0.f;
+    LANES {
+      float acc = r_r[lane];
+#pragma unroll
+      for (int r = 0; r < DIM; r++) {
+        acc += s.u.A[(i + r) * NEFC + lane] * delta[r];
+        if (lane == i + r) f_r[lane] += delta[r];
+      }
+      r_r[lane] = acc;
+    }
+    return -change;
+  }
+
+  // ------------------------------------------------------------------ B.8 implicitfast integrate
+  SMJ_DEV void integrate() {
+    const int nv = M.nv, nu = M.nu;
+    const float h = M.timestep;
+    // qH = M - h*D on the sparse pattern, written over the (dead) L storage; D: dof damping + actuator velocity bias
+    LANES {
+      for (int t = 0; t < 5; t++) {
+        const int i = e_i[lane][t], j = e_j[lane][t];
+        if (i < 0) continue;
+        float v = (i == j) ? s.Mdiag[i] + h * M.dof_damping[i] : s.MM[j][i];
+        for (int a = 0; a < nu; a++) {
+          if (M.actuator_biastype[a] != 1) continue;
+          const float bv = M.actuator_biasprm[3 * a + 2];
+          if (bv == 0.f) continue;
+          const float mi = M.k_act_moment[a * nv + i], mj = M.k_act_moment[a * nv + j];
+          if (mi == 0.f || mj == 0.f) continue;
+          if (M.actuator_forcelimited[a] &&
+              (s.act_force[a] <= M.actuator_forcerange[2 * a] || s.act_force[a] >= M.actuator_forcerange[2 * a + 1]))
+            continue;
+          v -= h * bv * mi * mj;
+        }
+        s.MM[i][j] = v;
+      }
+    }
+    SYNC();
+    factor();
+    PL<float> x;
+    LANES { x[lane] = lane < nv ? s.tmp[lane] : 0.f; }
+    solve_LT(x);
+    LANES { if (lane < nv) x[lane] *= s.Dinv[lane]; }
+    solve_L(x);
+    LANES {
+      if (lane < nv) s.qvel[lane] += h * x[lane];
+    }
+    SYNC();
+    LANES {
+      if (lane < M.njnt) {
+        const int j = lane, qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
+        if (M.jnt_type[j] == JT_FREE) {
+          for (int k = 0; k < 3; k++) s.qpos[qa + k] += h * s.qvel[da + k];
+          float wv[3] = {s.qvel[da + 3], s.qvel[da + 4], s.qvel[da + 5]};
+          const float nrm = sqrtf(dot3(wv, wv)), ang = nrm * h;
+          float q[4] = {s.qpos[qa + 3], s.qpos[qa + 4], s.qpos[qa + 5], s.qpos[qa + 6]};
+          if (ang > 0) {
+            const float sn = sinf(0.5f * ang) / nrm, dq[4] = {cosf(0.5f * ang), wv[0] * sn, wv[1] * sn, wv[2] * sn};
+            quat_mul(q, q, dq);
+          }
+          quat_normalize(q);
+          for (int k = 0; k < 4; k++) s.qpos[qa + 3 + k] = q[k];
+        } else s.qpos[qa] += h * s.qvel[da];
+      }
+    }
+    SYNC();
+  }
+
+  // ------------------------------------------------------------------ readouts at the end of a launch
+  SMJ_DEV void readout() {
+    const long ld = S.ld;
+    // actuator_length / velocity of the post-step state and base pose (pull_status, mujoco_server.py:465-515, :124-129)
+    kinematics();
+    LANES {
+      if (lane < M.nu) {
+        float len = 0, vel = 0;
+        for (int k = 0; k < M.nv; k++) {
+          const float mo = M.k_act_moment[lane * M.nv + k];
+          if (mo != 0.f) { vel += mo * s.qvel[k]; len += mo * s.qpos[M.k_dof_qposadr[k]]; }
+        }
+        S.act_len[lane * ld + env] = len; S.act_vel[lane * ld + env] = vel;
+      }
+      if (lane == 0) {
+        const int b = 1;  // base_link is the first body after the world
+        S.base[0 * ld + env] = s.xpos[b][0]; S.base[1 * ld + env] = s.xpos[b][1];
+        S.base[2 * ld + env] = atan2f(s.xmat[b][3], s.xmat[b][0]);
+      }
+    }
+  }
+
+  // IMU: gyro + accelerometer at the IMU site from the last forward pass  [MJ] mj_sensorVel / mj_sensorAcc
+  SMJ_DEV void imu() {
+    if (M.imu_site < 0 || !S.gyro) return;
+    const int sid = M.imu_site, b = M.site_bodyid[sid];
+    const uint64_t mk = mk64(M.k_body_dofmask_lo[b], M.k_body_dofmask_hi[b]);
+    float cv[6], ca[6];
+    for (int x = 0; x < 6; x++) {
+      PL<float> tv, ta;
+      LANES {
+        const bool in = (mk >> lane) & 1;
+        tv[lane] = in ? cdof[lane][x] * qvel_r[lane] : 0.f;
+        ta[lane] = in ? cdof_dot[lane][x] * qvel_r[lane] + cdof[lane][x] * qacc_r[lane] : 0.f;
+      }
+      cv[x] = wave_sum(tv); ca[x] = wave_sum(ta);
+    }
+    for (int k = 0; k < 3; k++) ca[3 + k] -= M.gravity[k];
+    float lp[3] = {M.site_pos[3 * sid], M.site_pos[3 * sid + 1], M.site_pos[3 * sid + 2]}, sp[3], lm[9], R[9];
+    mulmat3vec(sp, s.xmat[b], lp);
+    for (int k = 0; k < 9; k++) lm[k] = M.k_site_mat[9 * sid + k];
+    mulmat3(R, s.xmat[b], lm);
+    const float off[3] = {sp[0] + s.xpos[b][0] - s.com[b][0], sp[1] + s.xpos[b][1] - s.com[b][1], sp[2] + s.xpos[b][2] - s.com[b][2]};
+    float t[3], vlin[3], alin[3], c2[3], gy[3], ac[3];
+    cross3(t, cv, off);
+    for (int k = 0; k < 3; k++) vlin[k] = cv[3 + k] + t[k];
+    cross3(t, ca, off);
+    for (int k = 0; k < 3; k++) alin[k] = ca[3 + k] + t[k];
+    cross3(c2, cv, vlin);
+    for (int k = 0; k < 3; k++) alin[k] += c2[k];
+    mulmat3Tvec(gy, R, cv);
+    mulmat3Tvec(ac, R, alin);
+    LANES {
+      if (lane < 3) { S.gyro[lane * S.ld + env] = gy[lane]; S.accel[lane * S.ld + env] = ac[lane]; }
+    }
+  }
+
+  // 2-D lidar: 360 rangefinder rays from the laser sites along site +Z  [MJ] mj_sensorPos rangefinder -> mj_ray.
+  // Scope of this round: plane and primitive geoms (k_ray_geom); mesh geoms are not ray-cast yet.
+  SMJ_DEV float ray_geom(int g, const float* pnt, const float* vec) const {
+    float pos[3], R[9];
+    geom_pose(g, pos, R);
+    const float size[3] = {M.geom_size[3 * g], M.geom_size[3 * g + 1], M.geom_size[3 * g + 2]};
+    const float dif[3] = {pnt[0] - pos[0], pnt[1] - pos[1], pnt[2] - pos[2]};
+    float lp[3], lv[3];
+    mulmat3Tvec(lp, R, dif);
+    mulmat3Tvec(lv, R, vec);
+    const int t = M.geom_type[g];
+    if (t == GT_PLANE) {
+      if (lv[2] > -SMJ_MINVAL) return -1.f;
+      const float x = -lp[2] / lv[2];
+      if (x < 0) return -1.f;
+      const float px = lp[0] + x * lv[0], py = lp[1] + x * lv[1];
+      if ((size[0] <= 0 || fabsf(px) <= size[0]) && (size[1] <= 0 || fabsf(py) <= size[1])) return x;
+      return -1.f;
+    }
+    if (t == GT_SPHERE) return ray_quad(dot3(lv, lv), dot3(lv, lp), dot3(lp, lp) - size[0] * size[0]);
+    if (t == GT_CYLINDER) {
+      float best = -1.f;
+      const float a = lv[0] * lv[0] + lv[1] * lv[1], b = lv[0] * lp[0] + lv[1] * lp[1], c = lp[0] * lp[0] + lp[1] * lp[1] - size[0] * size[0];
+      if (a > SMJ_MINVAL) {
+        const float x = ray_quad(a, b, c);
+        if (x >= 0 && fabsf(lp[2] + x * lv[2]) <= size[1]) best = x;
+      }
+      if (fabsf(lv[2]) > SMJ_MINVAL)
+        for (int sg = -1; sg <= 1; sg += 2) {
+          const float x = (sg * size[1] - lp[2]) / lv[2];
+          if (x >= 0) {
+            const float px = lp[0] + x * lv[0], py = lp[1] + x * lv[1];
+            if (px * px + py * py <= size[0] * size[0] && (best < 0 || x < best)) best = x;
+          }
+        }
+      return best;
+    }
+    if (t == GT_BOX) {
+      float best = -1.f;
+      for (int ax = 0; ax < 3; ax++) {
+        if (fabsf(lv[ax]) < SMJ_MINVAL) continue;
+        for (int sg = -1; sg <= 1; sg += 2) {
+          const float x = (sg * size[ax] - lp[ax]) / lv[ax];
+          if (x < 0) continue;
+          const int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+          if (fabsf(lp[a1] + x * lv[a1]) <= size[a1] && fabsf(lp[a2] + x * lv[a2]) <= size[a2] && (best < 0 || x < best)) best = x;
+        }
+      }
+      return best;
+    }
+    return -1.f;
+  }
+  SMJ_DEV static float ray_quad(float a, float b, float c) {
+    float det = b * b - a * c;
+    if (det < SMJ_MINVAL) return -1.f;
+    det = sqrtf(det);
+    const float x0 = (-b - det) / a, x1 = (-b + det) / a;
+    if (x0 >= 0) return x0;
+    if (x1 >= 0) return x1;
+    return -1.f;
+  }
+  SMJ_DEV void lidar() {
+    if (!S.lidar) return;
+    for (int base = 0; base < M.nlidar; base += 64) {
+      LANES {
+        const int i = base + lane;
+        if (i < M.nlidar) {
+          const int sid = M.sensor_lidar_site[i], b = M.site_bodyid[sid];
+          float lp[3] = {M.site_pos[3 * sid], M.site_pos[3 * sid + 1], M.site_pos[3 * sid + 2]}, pnt[3], vec[3];
+          mulmat3vec(pnt, s.xmat[b], lp);
+          for (int k = 0; k < 3; k++) pnt[k] += s.xpos[b][k];
+          const float lz[3] = {M.k_site_mat[9 * sid + 2], M.k_site_mat[9 * sid + 5], M.k_site_mat[9 * sid + 8]};
+          mulmat3vec(vec, s.xmat[b], lz);
+          float best = -1.f;
+          for (int t = 0; t < M.nraygeom; t++) {
+            const int g = M.k_ray_geom[t];
+            if (M.k_ray_geom_origbody[t] == M.k_site_origbody[sid]) continue;  // bodyexclude = the site's own body
+            const float x = ray_geom(g, pnt, vec);
+            if (x >= 0 && (best < 0 || x < best)) best = x;
+          }
+          if (M.lidar_cutoff > 0 && best > M.lidar_cutoff) best = M.lidar_cutoff;
+          S.lidar[(long)i * S.ld + env] = best;
+        }
+      }
+    }
+  }
+
+  SMJ_DEV void dump_debug() {
+    if (!S.debug) return;
+    LANES {
+      for (int i = 0; i < NVP; i++)
+        if (lane < NVP) {
+          float v = 0;
+          if (i < M.nv && lane < M.nv) v = (i == lane) ? s.Mdiag[i] : (i < lane ? s.MM[i][lane] : s.MM[lane][i]);
+          S.debug[(SMJ_DBG_QM + i * NVP + lane) * S.ld + env] = v;
+        }
+      if (lane < NBP)
+        for (int k = 0; k < 3; k++) S.debug[(SMJ_DBG_XPOS + 3 * lane + k) * S.ld + env] = lane < M.nbody ? s.xpos[lane][k] : 0.f;
+    }
+  }
+  SMJ_DEV void dump_contacts() {
+    if (!S.debug) return;
+    LANES {
+      if (lane < NCON) {
+        const int c = lane;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (c < ncon) {
+          v[0] = s.cdist[c]; v[1] = s.cpos[c][0]; v[2] = s.cpos[c][1]; v[3] = s.cpos[c][2];
+          v[4] = s.cframe[c][0]; v[5] = s.cframe[c][1]; v[6] = s.cframe[c][2]; v[7] = (float)s.cdim[c];
+        }
+        for (int k = 0; k < 8; k++) S.debug[(SMJ_DBG_CON + 8 * c + k) * S.ld + env] = v[k];
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ driver
+  SMJ_DEV void run(int nsteps, unsigned read_flags) {
+    const int want_imu = read_flags & 1, want_lidar = read_flags & 2;
+    flags = 0; nefc = 0; ncon = 0; niter = 0;
+    setup();
+    load_state();
+    for (int st = 0; st < nsteps; st++) {
+      const bool last = st == nsteps - 1;
+      kinematics();
+      if (last && want_lidar) lidar();
+      com_crb();
+      if (last) dump_debug();
+      smooth_forces(last);
+      factor();
+      collision();
+      if (last) dump_contacts();
+      make_constraint();
+      solve(last);
+      if (last && want_imu) imu();
+      integrate();
+    }
+    store_state(nsteps);
+    readout();
+  }
+};

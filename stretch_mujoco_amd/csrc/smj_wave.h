@@ -1,0 +1,172 @@
+// Wave-level programming model used by the physics kernels.
+//
+// Kernels are written as a sequence of *lane regions* (code every lane of the 64-wide wavefront runs on its
+// own lane-private data) separated by wave-uniform code and LDS synchronisation points:
+//
+//     LANES { x[lane] = ...; }        // per-lane work, no lane may read LDS another lane wrote in this region
+//     SYNC();                         // LDS writes of the region become visible to all lanes
+//     float s = wave_sum(x);          // cross-lane ops live OUTSIDE regions, in uniform control flow
+//
+// On gfx950 a region is plain straight-line code (`lane` = threadIdx.x, PL<T> is a register), SYNC() is the
+// single-wave workgroup barrier (a compiler/LDS fence; one wave per workgroup, see __launch_bounds__(64)),
+// and the cross-lane ops lower to DPP/readlane/ballot.  With SMJ_EMUL defined the same source compiles with
+// g++: a region is a loop over 64 lanes, PL<T> is an array.  The emulator is TEST INFRASTRUCTURE (tests/emul):
+// it lets the kernel logic be checked against the fp64 oracle on a box without a GPU.  It is never built into
+// the product library.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#ifdef SMJ_EMUL
+#define SMJ_DEV
+#define LANES for (int lane = 0; lane < 64; ++lane)
+#define SYNC() ((void)0)
+template <class T>
+struct PL {
+  T v[64];
+  T& operator[](int l) { return v[l]; }
+  const T& operator[](int l) const { return v[l]; }
+};
+static inline float wave_sum(const PL<float>& x) {
+  // same association as the butterfly used on the GPU so that fp32 results match bit for bit
+  float t[64];
+  for (int i = 0; i < 64; i++) t[i] = x.v[i];
+  for (int off = 32; off >= 1; off >>= 1) {
+    float u[64];
+    for (int i = 0; i < 64; i++) u[i] = t[i] + t[i ^ off];
+    for (int i = 0; i < 64; i++) t[i] = u[i];
+  }
+  return t[0];
+}
+static inline float wave_min(const PL<float>& x) {
+  float m = x.v[0];
+  for (int i = 1; i < 64; i++) m = fminf(m, x.v[i]);
+  return m;
+}
+static inline float wave_max(const PL<float>& x) {
+  float m = x.v[0];
+  for (int i = 1; i < 64; i++) m = fmaxf(m, x.v[i]);
+  return m;
+}
+static inline uint64_t wave_ballot(const PL<int>& p) {
+  uint64_t b = 0;
+  for (int i = 0; i < 64; i++)
+    if (p.v[i]) b |= 1ull << i;
+  return b;
+}
+template <class T>
+static inline T wave_read(const PL<T>& x, int l) { return x.v[l]; }
+static inline int popc64(uint64_t x) { return __builtin_popcountll(x); }
+static inline int ffs64(uint64_t x) { return __builtin_ffsll((long long)x) - 1; }
+#else
+#include <hip/hip_runtime.h>
+#define SMJ_DEV __device__ __forceinline__
+// a region is a one-trip scope that names the lane id
+#define LANES for (int lane = (int)threadIdx.x, _k = 0; _k < 1; ++_k)
+#define SYNC() __syncthreads()
+template <class T>
+struct PL {
+  T v;
+  __device__ __forceinline__ T& operator[](int) { return v; }
+  __device__ __forceinline__ const T& operator[](int) const { return v; }
+};
+__device__ __forceinline__ float wave_sum(const PL<float>& x) {
+  float t = x.v;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+  return t;
+}
+__device__ __forceinline__ float wave_min(const PL<float>& x) {
+  float t = x.v;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) t = fminf(t, __shfl_xor(t, off, 64));
+  return t;
+}
+__device__ __forceinline__ float wave_max(const PL<float>& x) {
+  float t = x.v;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) t = fmaxf(t, __shfl_xor(t, off, 64));
+  return t;
+}
+__device__ __forceinline__ uint64_t wave_ballot(const PL<int>& p) { return __ballot(p.v != 0); }
+__device__ __forceinline__ float wave_read(const PL<float>& x, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x.v), l));
+}
+__device__ __forceinline__ int wave_read(const PL<int>& x, int l) { return __builtin_amdgcn_readlane(x.v, l); }
+__device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
+__device__ __forceinline__ int ffs64(uint64_t x) { return __ffsll((long long)x) - 1; }
+#endif
+
+// ---------------------------------------------------------------------------------------------- small math
+struct F3 { float x, y, z; };
+struct F4 { float w, x, y, z; };
+struct F6 { float a[6]; };
+struct M3 { float m[9]; };
+
+SMJ_DEV float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+SMJ_DEV void cross3(float* r, const float* a, const float* b) {
+  float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+SMJ_DEV float normalize3(float* a) {
+  float n = sqrtf(dot3(a, a));
+  if (n < 1e-15f) { a[0] = 1; a[1] = 0; a[2] = 0; return 0; }
+  float i = 1.0f / n;
+  a[0] *= i; a[1] *= i; a[2] *= i;
+  return n;
+}
+SMJ_DEV void quat_mul(float* r, const float* a, const float* b) {
+  float w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+        y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+SMJ_DEV void quat_normalize(float* q) {
+  float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < 1e-15f) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  float i = 1.0f / n;
+  q[0] *= i; q[1] *= i; q[2] *= i; q[3] *= i;
+}
+SMJ_DEV void quat2mat(float* R, const float* q) {
+  float w = q[0], x = q[1], y = q[2], z = q[3];
+  R[0] = w * w + x * x - y * y - z * z; R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z); R[4] = w * w - x * x + y * y - z * z; R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = w * w - x * x - y * y + z * z;
+}
+SMJ_DEV void mulmat3vec(float* r, const float* R, const float* v) {
+  float x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2], y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2],
+        z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+SMJ_DEV void mulmat3Tvec(float* r, const float* R, const float* v) {
+  float x = R[0] * v[0] + R[3] * v[1] + R[6] * v[2], y = R[1] * v[0] + R[4] * v[1] + R[7] * v[2],
+        z = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+SMJ_DEV void mulmat3(float* r, const float* A, const float* B) {
+  float t[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+#pragma unroll
+  for (int i = 0; i < 9; i++) r[i] = t[i];
+}
+// spatial algebra on [angular; linear] vectors (same conventions as oracle/smj_oracle.c)
+SMJ_DEV void mul_inert_vec(float* r, const float* i, const float* v) {
+  r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  r[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  r[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+SMJ_DEV void cross_motion(float* r, const float* vel, const float* v) {
+  float a[3], b[3], c[3];
+  cross3(a, vel, v); cross3(b, vel, v + 3); cross3(c, vel + 3, v);
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = b[0] + c[0]; r[4] = b[1] + c[1]; r[5] = b[2] + c[2];
+}
+SMJ_DEV void cross_force(float* r, const float* vel, const float* f) {
+  float a[3], b[3], c[3];
+  cross3(a, vel, f); cross3(b, vel + 3, f + 3); cross3(c, vel, f + 3);
+  r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2]; r[3] = c[0]; r[4] = c[1]; r[5] = c[2];
+}

@@ -1,0 +1,53 @@
+"""ctypes loader of libsmj.so -- the thin C-ABI binding north_star asks for (include/smj.h).
+
+There is no CPU fallback: if the HIP library is missing this raises, loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsmj.so")
+
+SLOT = dict(QPOS=0, QVEL=1, CTRL=2, WARMSTART=3, NSTEP=4, ACT_LENGTH=5, ACT_VELOCITY=6, BASE_POSE=7, GYRO=8, ACCEL=9,
+            LIDAR=10, INFO=11, DEBUG=12)
+DIM = dict(NQ=0, NV=1, NU=2, NBODY=3, NLIDAR=4, NKEY=5, NUM_ENVS=6, DEBUG_FLOATS=7, NEFC_MAX=8, NCON_MAX=9)
+READ_IMU, READ_LIDAR = 1, 2
+EXPORTS = ("smj_create", "smj_destroy", "smj_bind", "smj_dims", "smj_reset", "smj_step", "smj_set_option",
+           "smj_last_error", "smj_version")
+
+_lib = None
+
+
+class SmjError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SmjError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950). There is no CPU fallback for the physics path.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci, cl, cu = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_uint
+    L.smj_create.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ci, ci, ctypes.POINTER(vp)]
+    L.smj_destroy.argtypes = [vp]
+    L.smj_bind.argtypes = [vp, ci, vp, cl]
+    L.smj_dims.argtypes = [vp, ctypes.POINTER(ci)]
+    L.smj_reset.argtypes = [vp, vp, vp]
+    L.smj_step.argtypes = [vp, ci, cu, vp]
+    L.smj_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_double]
+    L.smj_last_error.argtypes = [vp]
+    L.smj_last_error.restype = ctypes.c_char_p
+    L.smj_version.restype = ctypes.c_char_p
+    _lib = L
+    return L
+
+
+def check(L, ctx, rc: int, what: str):
+    if rc != 0:
+        msg = L.smj_last_error(ctx).decode() if ctx else "no context"
+        raise SmjError(f"{what} failed ({rc}): {msg}")

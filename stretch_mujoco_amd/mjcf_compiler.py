@@ -917,6 +917,11 @@ class MjcfCompiler:
                      missing_meshes=self.meshes_missing)
         m["names_json"] = np.frombuffer(json.dumps(names).encode(), np.uint8)
         _set_const(m)
+        # per-body gravity-compensation mass/point and per-geom invweight0 are carried explicitly so that
+        # static-body fusion (model_fuse.py) preserves them exactly
+        m["body_gcmass"] = m["body_mass"] * m["body_gravcomp"]
+        m["body_gcipos"] = m["body_ipos"].copy()
+        m["geom_invweight0"] = m["body_invweight0"][m["geom_bodyid"]] if ngeom else np.zeros((0, 2))
         return m
 
 

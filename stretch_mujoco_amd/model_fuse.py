@@ -1,0 +1,247 @@
+"""Static-body fusion and kernel scheduling tables for the HIP path.
+
+MuJoCo keeps welded (joint-less) bodies as separate tree nodes; the rigid-body dynamics are unchanged if
+each weld group is merged into one body with the composite inertia.  The HIP kernels walk the tree level
+by level with one lane per body, so fewer / shallower bodies is a direct latency win (Stretch: 38 -> 20
+bodies).  Quantities MuJoCo attaches to the *original* bodies are carried over explicitly:
+gravity-compensation mass + application point (`body_gcmass`, `body_gcipos`) and the per-geom
+`geom_invweight0` used by contact regularisation.  tests/test_model.py checks with the fp64 oracle that the
+fused model reproduces the unfused trajectories.
+
+Also emits the `k_*` tables (levels, children, dof ancestor lists, L'DL entry schedule, dof masks, row
+lists) that the kernels in csrc/ index with lane ids.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+
+from .mjcf_compiler import JNT_FREE, GEOM_PLANE, quat2mat, quat_mul, quat_norm, mat2quat, _set_const
+
+
+def fuse_static_bodies(m: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    nb = len(m["body_parentid"])
+    par = m["body_parentid"]
+    keep = [0] + [b for b in range(1, nb) if m["body_jntnum"][b] > 0]
+    newid = {b: i for i, b in enumerate(keep)}
+    anchor = np.zeros(nb, int)
+    rpos = np.zeros((nb, 3))
+    rquat = np.tile([1.0, 0, 0, 0], (nb, 1))
+    for b in range(1, nb):
+        if b in newid:
+            anchor[b] = b
+        else:
+            p = par[b]
+            anchor[b] = anchor[p]
+            rpos[b] = rpos[p] + quat2mat(rquat[p]) @ m["body_pos"][b]
+            rquat[b] = quat_norm(quat_mul(rquat[p], m["body_quat"][b]))
+    f = {k: v.copy() for k, v in m.items()}
+    nk = len(keep)
+    bp = np.zeros(nk, np.int32)
+    bpos = np.zeros((nk, 3)); bquat = np.tile([1.0, 0, 0, 0], (nk, 1))
+    mass = np.zeros(nk); ipos = np.zeros((nk, 3)); iquat = np.tile([1.0, 0, 0, 0], (nk, 1)); inertia = np.zeros((nk, 3))
+    gcm = np.zeros(nk); gcp = np.zeros((nk, 3)); gravcomp = np.zeros(nk)
+    for i, b in enumerate(keep):
+        if b == 0:
+            continue
+        p = par[b]
+        bp[i] = newid[anchor[p]]
+        bpos[i] = rpos[p] + quat2mat(rquat[p]) @ m["body_pos"][b]
+        bquat[i] = quat_norm(quat_mul(rquat[p], m["body_quat"][b]))
+        members = [x for x in range(1, nb) if anchor[x] == b]
+        M = sum(m["body_mass"][x] for x in members)
+        com = sum(m["body_mass"][x] * (rpos[x] + quat2mat(rquat[x]) @ m["body_ipos"][x]) for x in members) / M
+        I = np.zeros((3, 3))
+        for x in members:
+            if m["body_mass"][x] == 0:
+                continue
+            R = quat2mat(rquat[x]) @ quat2mat(m["body_iquat"][x])
+            c = rpos[x] + quat2mat(rquat[x]) @ m["body_ipos"][x] - com
+            I += R @ np.diag(m["body_inertia"][x]) @ R.T + m["body_mass"][x] * (c @ c * np.eye(3) - np.outer(c, c))
+        w, V = np.linalg.eigh(I)
+        order = np.argsort(-w)
+        w, V = w[order], V[:, order]
+        if np.linalg.det(V) < 0:
+            V[:, 2] = -V[:, 2]
+        mass[i], ipos[i], iquat[i], inertia[i] = M, com, mat2quat(V), w
+        g = sum(m["body_gcmass"][x] for x in members)
+        gcm[i] = g
+        if g != 0:
+            gcp[i] = sum(m["body_gcmass"][x] * (rpos[x] + quat2mat(rquat[x]) @ m["body_gcipos"][x]) for x in members) / g
+        gravcomp[i] = g / M
+    f["body_parentid"] = bp
+    f["body_pos"], f["body_quat"] = bpos, bquat
+    f["body_mass"], f["body_ipos"], f["body_iquat"], f["body_inertia"] = mass, ipos, iquat, inertia
+    f["body_gcmass"], f["body_gcipos"], f["body_gravcomp"] = gcm, gcp, gravcomp
+    for k in ("body_jntadr", "body_jntnum", "body_dofadr", "body_dofnum"):
+        f[k] = m[k][keep].copy()
+    f["body_weldid"] = np.arange(nk, dtype=np.int32)
+    root = np.zeros(nk, np.int32)
+    for i in range(1, nk):
+        root[i] = i if bp[i] == 0 else root[bp[i]]
+    f["body_rootid"] = root
+    remap = np.array([newid[anchor[b]] for b in range(nb)], np.int32)
+    f["jnt_bodyid"] = remap[m["jnt_bodyid"]]
+    f["dof_bodyid"] = remap[m["dof_bodyid"]]
+
+    def rebase(prefix, has_quat=True):
+        old = m[prefix + "_bodyid"]
+        pos = m[prefix + "_pos"].copy()
+        quat = m[prefix + "_quat"].copy()
+        for i, b in enumerate(old):
+            pos[i] = rpos[b] + quat2mat(rquat[b]) @ m[prefix + "_pos"][i]
+            quat[i] = quat_norm(quat_mul(rquat[b], m[prefix + "_quat"][i]))
+        f[prefix + "_bodyid"] = remap[old]
+        f[prefix + "_pos"], f[prefix + "_quat"] = pos, quat
+
+    f["geom_origbody"] = m["geom_bodyid"].copy(); f["site_origbody"] = m["site_bodyid"].copy()
+    rebase("geom"); rebase("site"); rebase("cam")
+    d = f["dims"].copy()
+    d[3] = nk
+    f["dims"] = d
+    giw = m["geom_invweight0"].copy()
+    _set_const(f)
+    f["geom_invweight0"] = giw
+    f["fused_from"] = np.array(keep, np.int32)
+    return f
+
+
+def kernel_tables(f: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """Lane-indexed scheduling tables for csrc/smj_kernels.hip (added in place, `k_` prefix)."""
+    nb, nv = len(f["body_parentid"]), len(f["dof_bodyid"])
+    if nb > 64 or nv > 64:
+        raise ValueError("kernels map bodies / dofs to the 64 lanes of one wavefront")
+    par = f["body_parentid"]
+    level = np.zeros(nb, np.int32)
+    for b in range(1, nb):
+        level[b] = level[par[b]] + 1
+    f["k_body_level"] = level
+    f["k_nlevel"] = np.array([level.max() + 1], np.int32)
+    child_adr, child_num, child_list = [], [], []
+    for b in range(nb):
+        ch = [c for c in range(1, nb) if par[c] == b]
+        child_adr.append(len(child_list)); child_num.append(len(ch)); child_list += ch
+    f["k_child_adr"] = np.array(child_adr, np.int32); f["k_child_num"] = np.array(child_num, np.int32)
+    f["k_child_list"] = np.array(child_list + [0], np.int32)
+    # dof ancestors (proper), nearest first; dof masks per body
+    dpar = f["dof_parentid"]
+    anc_adr, anc_num, anc = [], [], []
+    for i in range(nv):
+        chain = []
+        j = dpar[i]
+        while j >= 0:
+            chain.append(j); j = dpar[j]
+        anc_adr.append(len(anc)); anc_num.append(len(chain)); anc += chain
+    f["k_dof_anc_adr"] = np.array(anc_adr, np.int32); f["k_dof_anc_num"] = np.array(anc_num, np.int32)
+    f["k_dof_anc"] = np.array(anc + [0], np.int32)
+    mask = np.zeros(nb, np.uint64)
+    for b in range(1, nb):
+        x = b
+        while x > 0 and f["body_dofnum"][x] == 0:
+            x = par[x]
+        if x == 0:
+            continue
+        i = f["body_dofadr"][x] + f["body_dofnum"][x] - 1
+        while i >= 0:
+            mask[b] |= np.uint64(1) << np.uint64(i); i = dpar[i]
+    f["k_body_dofmask_lo"] = (mask & np.uint64(0xFFFFFFFF)).astype(np.int64).astype(np.uint32).view(np.int32)
+    f["k_body_dofmask_hi"] = (mask >> np.uint64(32)).astype(np.int64).astype(np.uint32).view(np.int32)
+    # sparse lower-triangular entries (i >= j, j ancestor-or-self of i), padded to a multiple of 64
+    ei, ej = [], []
+    for i in range(nv):
+        j = i
+        while j >= 0:
+            ei.append(i); ej.append(j); j = dpar[j]
+    pad = (-len(ei)) % 64
+    f["k_ldl_i"] = np.array(ei + [-1] * pad, np.int32); f["k_ldl_j"] = np.array(ej + [0] * pad, np.int32)
+    f["k_fric_dof"] = np.array([k for k in range(nv) if f["dof_frictionloss"][k] > 0] + [0], np.int32)
+    f["k_nfric"] = np.array([int((f["dof_frictionloss"] > 0).sum())], np.int32)
+    lim = [j for j in range(len(f["jnt_type"])) if f["jnt_limited"][j] and f["jnt_type"][j] != JNT_FREE]
+    f["k_limit_jnt"] = np.array(lim + [0], np.int32); f["k_nlimit"] = np.array([len(lim)], np.int32)
+    # geoms: local rotation matrices and bounding centre in the (fused) body frame
+    ng = len(f["geom_type"])
+    gmat = np.zeros((ng, 9)); gcen = np.zeros((ng, 3))
+    for g in range(ng):
+        R = quat2mat(f["geom_quat"][g])
+        gmat[g] = R.reshape(9)
+        gcen[g] = f["geom_pos"][g] + R @ f["geom_center"][g]
+    f["k_geom_mat"] = gmat; f["k_geom_bcenter"] = gcen
+    # plane pairs first-class list (geom1 is the plane)
+    pp = [p for p in range(len(f["pair_geom1"])) if f["geom_type"][f["pair_geom1"][p]] == GEOM_PLANE]
+    f["k_planepair"] = np.array(pp + [0], np.int32); f["k_nplanepair"] = np.array([len(pp)], np.int32)
+    # sites: local matrices
+    ns = len(f["site_bodyid"])
+    smat = np.zeros((ns, 9))
+    for s in range(ns):
+        smat[s] = quat2mat(f["site_quat"][s]).reshape(9)
+    f["k_site_mat"] = smat
+    # body-local inertia about the body origin as a 10-vector (same layout as cinert), in body axes
+    cin = np.zeros((nb, 10))
+    for b in range(1, nb):
+        R = quat2mat(f["body_iquat"][b])
+        I = R @ np.diag(f["body_inertia"][b]) @ R.T
+        cin[b, :6] = [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]]
+        cin[b, 6:9] = f["body_ipos"][b]
+        cin[b, 9] = f["body_mass"][b]
+    f["k_body_inertia_local"] = cin
+    # subtree sizes (bodies are in depth-first order, so a subtree is a contiguous id range)
+    size = np.ones(nb, np.int32)
+    for b in range(nb - 1, 0, -1):
+        size[par[b]] += size[b]
+    for b in range(1, nb):
+        assert all(_is_desc(par, x, b) for x in range(b, b + size[b])), "bodies must be in depth-first order"
+    f["k_body_subtreesize"] = size
+    roots = [b for b in range(1, nb) if par[b] == 0 and f["body_rootid"][b] == b and f["body_subtreemass"][b] > 0]
+    f["k_root_list"] = np.array(roots + [0], np.int32); f["k_nroot"] = np.array([len(roots)], np.int32)
+    gcb = [b for b in range(1, nb) if f["body_gcmass"][b] != 0]
+    f["k_gc_body"] = np.array(gcb + [0], np.int32); f["k_ngc"] = np.array([len(gcb)], np.int32)
+    # dofs whose velocity enters cdof_dot of dof d ([MJ] mj_comVel): all proper ancestors, except that the three
+    # rotational dofs of a free joint all see only that joint's translational dofs
+    vm = np.zeros(nv, np.uint64)
+    qadr = np.full(nv, -1, np.int32)
+    for i in range(nv):
+        j = f["dof_jntid"][i]
+        first = f["jnt_dofadr"][j]
+        a = dpar[i]
+        while a >= 0:
+            if not (f["jnt_type"][j] == JNT_FREE and f["dof_jntid"][a] == j and a - first >= 3):
+                vm[i] |= np.uint64(1) << np.uint64(a)
+            a = dpar[a]
+        if f["jnt_type"][j] != JNT_FREE:
+            qadr[i] = f["jnt_qposadr"][j]
+    f["k_dof_velmask_lo"] = (vm & np.uint64(0xFFFFFFFF)).astype(np.int64).astype(np.uint32).view(np.int32)
+    f["k_dof_velmask_hi"] = (vm >> np.uint64(32)).astype(np.int64).astype(np.uint32).view(np.int32)
+    f["k_dof_qposadr"] = qadr
+    # static actuator moments (joint and fixed-tendon transmissions have configuration-independent moments)
+    nu = len(f["actuator_trntype"])
+    mom = np.zeros((max(nu, 1), nv))
+    for a in range(nu):
+        gear = f["actuator_gear"][a]
+        if f["actuator_trntype"][a] == 0:
+            mom[a, f["jnt_dofadr"][f["actuator_trnid"][a]]] = gear
+        else:
+            t = f["actuator_trnid"][a]
+            for w in range(f["tendon_adr"][t], f["tendon_adr"][t] + f["tendon_num"][t]):
+                mom[a, f["jnt_dofadr"][f["wrap_objid"][w]]] += gear * f["wrap_prm"][w]
+    f["k_act_moment"] = mom
+    f["k_nldl"] = np.array([int((f["k_ldl_i"] >= 0).sum())], np.int32)
+    # geoms the lidar rays are tested against this round: visible (alpha != 0) planes and primitives
+    gob = f.get("geom_origbody", f["geom_bodyid"])
+    rg = [g for g in range(ng) if f["geom_type"][g] != 7 and f["geom_rgba"][g][3] != 0]
+    f["k_ray_geom"] = np.array(rg + [0], np.int32); f["k_nraygeom"] = np.array([len(rg)], np.int32)
+    f["k_ray_geom_origbody"] = np.array([gob[g] for g in rg] + [0], np.int32)
+    f["k_site_origbody"] = np.asarray(f.get("site_origbody", f["site_bodyid"]), np.int32)
+    if len(f["k_site_origbody"]) == 0:
+        f["k_site_origbody"] = np.zeros(1, np.int32)
+    return f
+
+
+def _is_desc(par, x, b):
+    while x > b:
+        x = par[x]
+    return x == b
+
+
+def prepare_for_kernels(m: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    return kernel_tables(fuse_static_bodies(m))

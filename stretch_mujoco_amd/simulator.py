@@ -1,0 +1,272 @@
+"""StretchBatchSimulator -- the reference's StretchMujocoSimulator API with a leading batch dimension.
+
+Reference: stretch_mujoco/stretch_mujoco_simulator.py:34-534 (client) + stretch_mujoco/mujoco_server.py (server).
+The server process, proxies, locks and the realtime sleep (mujoco_server.py:381-384) have no place in a batched
+throughput simulator: one Python object owns PyTorch-ROCm tensors (batch-major, [dim, B]) and drives the HIP
+library through the ctypes C-ABI (lib.py, include/smj.h).  New, without a reference counterpart: `step(n)`,
+`reset(env_ids)`.
+
+Ordering contract kept from `_ctrl_callback` (mujoco_server.py:450-463): commands issued between steps are
+folded into ctrl before the next physics step; status is the post-step readout.
+"""
+from __future__ import annotations
+
+import ctypes
+import json
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from . import model_blob
+from .datamodels import StatusStretchCameras, StatusStretchJoints, StatusStretchSensors
+from .enums import Actuators, StretchCameras, StretchSensors
+from .glue import Glue
+
+_MODELS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models")
+
+
+def _require_connection(fn):
+    def wrapper(self, *a, **k):
+        if not self.is_running():
+            raise ConnectionError("The Stretch Mujoco Simulator is not running. Use the start() method to start it.")
+        return fn(self, *a, **k)
+
+    wrapper.__name__ = fn.__name__
+    wrapper.__doc__ = fn.__doc__
+    return wrapper
+
+
+class StretchBatchSimulator:
+    def __init__(self, num_envs: int = 1, device: str = "cuda:0", scene: str = "stretch_empty",
+                 model_blob_bytes: Optional[bytes] = None, sensors_to_use: Sequence[StretchSensors] = (),
+                 cameras_to_use: Sequence[StretchCameras] = (), start_translation=None, start_rotation_quat=None,
+                 debug: bool = False):
+        self.num_envs = int(num_envs)
+        self.device = torch.device(device)
+        if model_blob_bytes is None:
+            with open(os.path.join(_MODELS, scene + ".smjb"), "rb") as f:
+                model_blob_bytes = f.read()
+        self._blob = model_blob_bytes
+        self.model = model_blob.loads(model_blob_bytes)
+        self.names = json.loads(model_blob.get_str(self.model, "names_json"))
+        self._sensors = list(sensors_to_use)
+        if cameras_to_use:
+            raise NotImplementedError("camera depth ray casting is not on the HIP path yet (DESIGN.md, scope)")
+        self._start_translation = start_translation
+        self._start_rotation_quat = start_rotation_quat
+        self._debug = debug
+        self._ctx = None
+        self._L = None
+        self.timestep = float(self.model["opt_timestep"][0])
+
+    # ------------------------------------------------------------------ lifecycle
+    def start(self, headless: bool = True, home: bool = True, **_ignored) -> None:
+        """Allocate, reset and (like the reference, stretch_mujoco_simulator.py:136) send the robot home."""
+        if self._ctx is not None:
+            return
+        if self.device.type != "cuda":
+            raise _lib.SmjError("the physics path runs on the ROCm device only; there is no CPU fallback")
+        L = self._L = _lib.load()
+        ctx = ctypes.c_void_p()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        rc = L.smj_create(self._blob, len(self._blob), self.num_envs, dev_index, ctypes.byref(ctx))
+        if rc != 0:
+            msg = L.smj_last_error(ctx).decode() if ctx else "smj_create failed"
+            if ctx:
+                L.smj_destroy(ctx)
+            raise _lib.SmjError(f"smj_create failed ({rc}): {msg}")
+        self._ctx = ctx
+        dims = (ctypes.c_int * 16)()
+        _lib.check(L, ctx, L.smj_dims(ctx, dims), "smj_dims")
+        D = _lib.DIM
+        self.nq, self.nv, self.nu = dims[D["NQ"]], dims[D["NV"]], dims[D["NU"]]
+        self.nlidar = dims[D["NLIDAR"]]
+        B, f = self.num_envs, dict(dtype=torch.float32, device=self.device)
+        i32 = dict(dtype=torch.int32, device=self.device)
+        self.qpos = torch.zeros(self.nq, B, **f); self.qvel = torch.zeros(self.nv, B, **f)
+        self.ctrl = torch.zeros(self.nu, B, **f); self.qacc_warmstart = torch.zeros(self.nv, B, **f)
+        self.nstep = torch.zeros(B, **i32)
+        self.actuator_length = torch.zeros(self.nu, B, **f); self.actuator_velocity = torch.zeros(self.nu, B, **f)
+        self.base_pose = torch.zeros(3, B, **f)
+        self.gyro = torch.zeros(3, B, **f); self.accel = torch.zeros(3, B, **f)
+        self.lidar = torch.zeros(max(self.nlidar, 1), B, **f)
+        self.info = torch.zeros(4, B, **i32)
+        S = _lib.SLOT
+        binds = [("QPOS", self.qpos), ("QVEL", self.qvel), ("CTRL", self.ctrl), ("WARMSTART", self.qacc_warmstart),
+                 ("NSTEP", self.nstep), ("ACT_LENGTH", self.actuator_length), ("ACT_VELOCITY", self.actuator_velocity),
+                 ("BASE_POSE", self.base_pose), ("GYRO", self.gyro), ("ACCEL", self.accel), ("LIDAR", self.lidar),
+                 ("INFO", self.info)]
+        if self._debug:
+            self.debug = torch.zeros(dims[D["DEBUG_FLOATS"]], B, **f)
+            binds.append(("DEBUG", self.debug))
+        for name, t in binds:
+            _lib.check(L, ctx, L.smj_bind(ctx, S[name], ctypes.c_void_p(t.data_ptr()), B), f"smj_bind({name})")
+        key_ctrl = torch.tensor(np.asarray(self.model["key_ctrl"], np.float32)[:, : self.nu])
+        self.glue = Glue(B, self.nu, key_ctrl, self.names["key"], self.device)
+        self._read_flags = 0
+        if StretchSensors.base_gyro in self._sensors or StretchSensors.base_accel in self._sensors:
+            self._read_flags |= _lib.READ_IMU
+        if StretchSensors.base_lidar in self._sensors:
+            self._read_flags |= _lib.READ_LIDAR
+        self.reset()
+        if home:
+            self.home()
+
+    def stop(self) -> None:
+        if self._ctx is not None:
+            torch.cuda.synchronize(self.device)
+            self._L.smj_destroy(self._ctx)
+            self._ctx = None
+
+    def is_running(self) -> bool:
+        return self._ctx is not None
+
+    def __del__(self):
+        try:
+            self.stop()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ new: reset / step
+    @_require_connection
+    def reset(self, env_ids=None) -> None:
+        """mj_resetData for the selected envs, then the start pose (change_start_pose, mujoco_server.py:206-229)."""
+        if env_ids is None:
+            mask_ptr = None
+            ids = slice(None)
+        else:
+            ids = torch.as_tensor(env_ids, device=self.device, dtype=torch.long)
+            mask = torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
+            mask[ids] = 1
+            mask_ptr = ctypes.c_void_p(mask.data_ptr())
+        _lib.check(self._L, self._ctx, self._L.smj_reset(self._ctx, mask_ptr, self._stream()), "smj_reset")
+        if self._start_translation is not None:  # [3] for every env or [B,3]
+            t = torch.as_tensor(self._start_translation, dtype=torch.float32, device=self.device).reshape(-1, 3)
+            self.qpos[0:3, ids] = t.expand(self.num_envs, 3).t()[:, ids]
+        if self._start_rotation_quat is not None:  # wxyz, [4] or [B,4]
+            q = torch.as_tensor(self._start_rotation_quat, dtype=torch.float32, device=self.device).reshape(-1, 4)
+            self.qpos[3:7, ids] = q.expand(self.num_envs, 4).t()[:, ids]
+        self.glue.reset(env_ids)
+        # readout of the reset state (one zero-length update is not available: refresh by a cheap kinematic fill)
+        self.actuator_length[:, ids] = 0
+        self.actuator_velocity[:, ids] = 0
+        self.base_pose[0:2, ids] = self.qpos[0:2, ids]
+        qw, qx, qy, qz = self.qpos[3, ids], self.qpos[4, ids], self.qpos[5, ids], self.qpos[6, ids]
+        self.base_pose[2, ids] = torch.atan2(2 * (qx * qy + qw * qz), qw * qw + qx * qx - qy * qy - qz * qz)
+
+    @_require_connection
+    def step(self, n: int = 1) -> None:
+        """Advance every env by n physics steps (n x `_physics_step`, mujoco_server.py:371-384, without the sleep)."""
+        n = int(n)
+        while n > 0:
+            self.glue.push_command(self.ctrl, self.actuator_length, self.base_pose)
+            k = 1 if self.glue.base_active() else n
+            _lib.check(self._L, self._ctx, self._L.smj_step(self._ctx, k, self._read_flags, self._stream()), "smj_step")
+            n -= k
+
+    # ------------------------------------------------------------------ reference API
+    @_require_connection
+    def home(self, env_ids=None, settle: bool = True) -> None:
+        """Keyframe 'home' then wait until the lift stops (stretch_mujoco_simulator.py:213-221)."""
+        self.glue.set_keyframe("home", env_ids)
+        if settle:
+            self.wait_while_is_moving(Actuators.lift)
+
+    @_require_connection
+    def stow(self, env_ids=None, settle: bool = True) -> None:
+        """Keyframe 'stow' then wait on wrist_pitch (stretch_mujoco_simulator.py:224-233)."""
+        self.glue.set_keyframe("stow", env_ids)
+        if settle:
+            self.wait_while_is_moving(Actuators.wrist_pitch)
+
+    @_require_connection
+    def move_to(self, actuator, pos, env_ids=None) -> None:
+        self.glue.move_to(actuator, pos, env_ids)
+
+    @_require_connection
+    def move_by(self, actuator, pos, env_ids=None) -> None:
+        self.glue.move_by(actuator, pos, env_ids)
+
+    @_require_connection
+    def set_base_velocity(self, v_linear, omega, env_ids=None) -> None:
+        self.glue.set_base_velocity(v_linear, omega, env_ids)
+
+    @_require_connection
+    def pull_status(self) -> StatusStretchJoints:
+        time = self.nstep.to(torch.float64) * self.timestep
+        return Glue.pull_status(time, self.actuator_length, self.actuator_velocity, self.base_pose)
+
+    @_require_connection
+    def pull_sensor_data(self) -> StatusStretchSensors:
+        """gyro [B,3], accel (field base_imu) [B,3], lidar [B,360]; values of the last physics step of the last launch.
+        The reference refreshes these at 15 Hz wall clock (mujoco_server.py:271); here the cadence is the caller's step(n)."""
+        out = StatusStretchSensors(time=self.nstep.to(torch.float64) * self.timestep, fps=0.0)
+        if self._read_flags & _lib.READ_IMU:
+            out.base_gyro = self.gyro.t().clone()
+            out.base_imu = self.accel.t().clone()
+        if self._read_flags & _lib.READ_LIDAR:
+            out.lidar = self.lidar[: self.nlidar].t().clone()
+        return out
+
+    @_require_connection
+    def pull_camera_data(self) -> StatusStretchCameras:
+        raise NotImplementedError("camera depth ray casting is not on the HIP path yet (DESIGN.md, scope)")
+
+    @_require_connection
+    def pull_joint_limits(self) -> dict:
+        """{Actuators: (lo, hi)} from jnt_range, later joints of one actuator overwrite earlier (mujoco_server.py:281-291)."""
+        out = {}
+        for j, name in enumerate(self.names["joint"]):
+            try:
+                act = Actuators.get_actuator_by_joint_names_in_mjcf(name)
+            except NotImplementedError:
+                continue
+            r = self.model["jnt_range"][j]
+            out[act] = (float(r[0]), float(r[1]))
+        return out
+
+    @_require_connection
+    def get_base_pose(self):
+        s = self.pull_status()
+        return (s.base.x, s.base.y, s.base.theta)
+
+    # ------------------------------------------------------------------ wait helpers as batched predicates
+    @_require_connection
+    def wait_while_is_moving(self, actuator, timeout: Optional[float] = 5.0, check_interval: float = 0.1,
+                             position_tolerance: float = 0.0005) -> torch.Tensor:
+        """Step until the actuator stops moving in every env (|dpos| <= tol over check_interval of SIM time) or
+        `timeout` sim-seconds elapse.  Returns a [B] bool mask of envs that came to rest.
+        Reference semantics: stretch_mujoco_simulator.py:299-358 (wall-clock there, sim-clock here)."""
+        if isinstance(actuator, str):
+            actuator = Actuators[actuator]
+        chunk = max(1, int(round(check_interval / self.timestep)))
+        budget = int(round((timeout if timeout is not None else 1e9) / self.timestep))
+
+        def position():
+            st = self.pull_status()
+            if actuator in (Actuators.left_wheel_vel, Actuators.base_translate):
+                return st.base.x
+            if actuator == Actuators.right_wheel_vel:
+                return st.base.y
+            if actuator == Actuators.base_rotate:
+                return st.base.theta
+            return actuator.get_position(st)
+
+        last = position()
+        still = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+        done_steps = 0
+        while done_steps < budget:
+            self.step(chunk)
+            done_steps += chunk
+            cur = position()
+            still = (cur - last).abs() <= position_tolerance
+            last = cur
+            if bool(still.all()):
+                break
+        return still

@@ -1,0 +1,58 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes wrapper of tests/emul/libsmj_emul.so (CPU lane emulator of the HIP kernel)."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+SLOTS = dict(qpos=0, qvel=1, ctrl=2, warm=3, nstep=4, act_len=5, act_vel=6, base=7, gyro=8, accel=9, lidar=10, info=11, debug=12)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        L = ctypes.CDLL(os.path.join(_HERE, "libsmj_emul.so"))
+        L.emul_create.restype = ctypes.c_void_p
+        L.emul_create.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+        L.emul_bind.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_long]
+        L.emul_step.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint]
+        L.emul_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double]
+        L.emul_destroy.argtypes = [ctypes.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+class Emul:
+    def __init__(self, blob: bytes, dims: dict, num_envs: int = 1, debug: bool = True):
+        self.L = lib()
+        self.B = B = num_envs
+        self.c = self.L.emul_create(blob, len(blob), B)
+        if not self.c:
+            raise ValueError("emul_create failed")
+        nq, nv, nu, nl = dims["nq"], dims["nv"], dims["nu"], dims["nlidar"]
+        f = np.float32
+        self.buf = dict(qpos=np.zeros((nq, B), f), qvel=np.zeros((nv, B), f), ctrl=np.zeros((nu, B), f),
+                        warm=np.zeros((nv, B), f), nstep=np.zeros(B, np.int32), act_len=np.zeros((nu, B), f),
+                        act_vel=np.zeros((nu, B), f), base=np.zeros((3, B), f), gyro=np.zeros((3, B), f),
+                        accel=np.zeros((3, B), f), lidar=np.zeros((max(nl, 1), B), f), info=np.zeros((4, B), np.int32))
+        if debug:
+            self.buf["debug"] = np.zeros((self.L.emul_debug_floats(), B), f)
+        for k, a in self.buf.items():
+            self.L.emul_bind(self.c, SLOTS[k], a.ctypes.data_as(ctypes.c_void_p), B)
+
+    def set_option(self, name, v):
+        assert self.L.emul_set_option(self.c, name.encode(), float(v)) == 0
+
+    def step(self, n=1, read_flags=0):
+        self.L.emul_step(self.c, n, read_flags)
+
+    def __getattr__(self, k):
+        if k in self.__dict__.get("buf", {}):
+            return self.buf[k]
+        raise AttributeError(k)

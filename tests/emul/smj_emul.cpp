@@ -1,0 +1,97 @@
+// TEST INFRASTRUCTURE ONLY -- lane emulator of the HIP step kernel.
+//
+// Compiles stretch_mujoco_amd/csrc/smj_step_impl.h with SMJ_EMUL (smj_wave.h): every lane region becomes a
+// loop over 64 lanes and cross-lane ops act on arrays, in fp32, with the same operation order as the GPU
+// code.  It exists so that the kernel LOGIC can be checked against the fp64 oracle on a machine without a
+// GPU (`pytest -m "not gpu"`).  It is never linked into libsmj.so and nothing in stretch_mujoco_amd/ loads it.
+#define SMJ_EMUL 1
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../stretch_mujoco_amd/csrc/smj_model_load.h"
+#include "../../stretch_mujoco_amd/csrc/smj_step_impl.h"
+
+struct HostUploader {
+  std::vector<void*>* keep;
+  template <class T>
+  const T* put(const std::vector<T>& h) {
+    T* p = (T*)malloc(h.size() * sizeof(T));
+    memcpy(p, h.data(), h.size() * sizeof(T));
+    keep->push_back(p);
+    return p;
+  }
+  const float* f32(const std::vector<float>& h) { return put(h); }
+  const int* i32(const std::vector<int>& h) { return put(h); }
+};
+
+struct emul_ctx {
+  DevModel m{};
+  DevState s{};
+  std::vector<void*> keep;
+  std::string err;
+  Smem smem;
+};
+
+extern "C" {
+
+emul_ctx* emul_create(const void* blob, size_t nbytes, int num_envs) {
+  emul_ctx* c = new emul_ctx();
+  HostUploader up{&c->keep};
+  if (smj_load_model(blob, nbytes, c->m, up, c->err)) {
+    fprintf(stderr, "emul_create: %s\n", c->err.c_str());
+    delete c;
+    return nullptr;
+  }
+  c->s.B = num_envs;
+  c->s.ld = num_envs;
+  return c;
+}
+void emul_destroy(emul_ctx* c) {
+  for (void* p : c->keep) free(p);
+  delete c;
+}
+// same slot numbering as include/smj.h
+int emul_bind(emul_ctx* c, int slot, void* p, long ld) {
+  DevState& s = c->s;
+  s.ld = ld;
+  switch (slot) {
+    case 0: s.qpos = (float*)p; break;
+    case 1: s.qvel = (float*)p; break;
+    case 2: s.ctrl = (float*)p; break;
+    case 3: s.warm = (float*)p; break;
+    case 4: s.nstep = (int*)p; break;
+    case 5: s.act_len = (float*)p; break;
+    case 6: s.act_vel = (float*)p; break;
+    case 7: s.base = (float*)p; break;
+    case 8: s.gyro = (float*)p; break;
+    case 9: s.accel = (float*)p; break;
+    case 10: s.lidar = (float*)p; break;
+    case 11: s.info = (int*)p; break;
+    case 12: s.debug = (float*)p; break;
+    default: return -1;
+  }
+  return 0;
+}
+int emul_set_option(emul_ctx* c, const char* name, double v) {
+  DevModel& m = c->m;
+  if (!strcmp(name, "iterations")) m.iterations = (int)v;
+  else if (!strcmp(name, "tolerance")) m.tolerance = (float)v;
+  else if (!strcmp(name, "warmstart")) m.warmstart = (int)v;
+  else if (!strcmp(name, "pgs_fixed_iter")) m.pgs_fixed_iter = (int)v;
+  else if (!strcmp(name, "max_contacts_per_pair")) m.max_con_pair = (int)v;
+  else return -1;
+  return 0;
+}
+int emul_step(emul_ctx* c, int nsteps, unsigned read_flags) {
+  for (int env = 0; env < c->s.B; env++) {
+    StepKernel* k = new StepKernel(c->m, c->s, c->smem, env);
+    k->run(nsteps, read_flags);
+    delete k;
+  }
+  return 0;
+}
+int emul_debug_floats() { return SMJ_DEBUG_FLOATS; }
+}

@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from stretch_mujoco_amd import mjcf_compiler as C, model_blob as B  # noqa: E402
+from stretch_mujoco_amd import mjcf_compiler as C, model_blob as B, model_fuse as F  # noqa: E402
 
 
 def main():
@@ -19,7 +19,8 @@ def main():
     out = os.path.join(os.path.dirname(HERE), "stretch_mujoco_amd", "models")
     os.makedirs(out, exist_ok=True)
     m = C.compile_string(C.empty_scene_xml(stretch))
-    B.save(os.path.join(out, "stretch_empty.smjb"), m)
+    B.save(os.path.join(out, "stretch_empty_full.smjb"), m)                          # body-for-body (oracle / fusion test)
+    B.save(os.path.join(out, "stretch_empty.smjb"), F.prepare_for_kernels(m))        # fused + kernel tables (product)
     print("stretch_empty:", dict(zip("nq nv nu nbody njnt ngeom nsite ncam neq ntendon nwrap nkey npair nhullvert".split(),
                                      [int(x) for x in m["dims"]])))
 
