@@ -116,6 +116,7 @@ int smj_bind(smj_ctx* c, int slot, void* p, long ld) {
     case SMJ_SLOT_LIDAR: s.lidar = (float*)p; break;
     case SMJ_SLOT_INFO: s.info = (int*)p; break;
     case SMJ_SLOT_DEBUG: s.debug = (float*)p; break;
+    case SMJ_SLOT_PROF: s.prof = (float*)p; break;
   }
   return 0;
 }
@@ -130,7 +131,7 @@ static int check_bound(smj_ctx* c) {
     if (ld < 0) ld = c->slot_ld[s];
     if (c->slot_ld[s] != ld) return fail(c, -5, "all batch-major slots must share one leading dimension");
   }
-  for (int s : {SMJ_SLOT_GYRO, SMJ_SLOT_ACCEL, SMJ_SLOT_LIDAR, SMJ_SLOT_DEBUG})
+  for (int s : {SMJ_SLOT_GYRO, SMJ_SLOT_ACCEL, SMJ_SLOT_LIDAR, SMJ_SLOT_DEBUG, SMJ_SLOT_PROF})
     if (c->slot_ptr[s] && c->slot_ld[s] != ld) return fail(c, -5, "slot %d: leading dimension differs", s);
   c->state.ld = ld;
   return 0;

@@ -64,8 +64,12 @@ struct DevState {
   float* lidar;    // [nlidar][B]
   int* info;       // [4][B]   nefc, ncon, solver iterations, flags (bit0: efc overflow, bit1: contact overflow, bit2: nan reset)
   float* debug;    // [SMJ_DEBUG_FLOATS][B] or null: stage dumps for parity tests
+  float* prof;     // [SMJ_PROF_SLOTS][B] or null: shader cycles per stage, summed over the launch
 };
 
+enum { SMJ_PROF_KIN = 0, SMJ_PROF_COMCRB, SMJ_PROF_SMOOTH, SMJ_PROF_FACTOR, SMJ_PROF_COLLISION, SMJ_PROF_MAKECON,
+       SMJ_PROF_PROJECT, SMJ_PROF_WARM, SMJ_PROF_PGS, SMJ_PROF_POST, SMJ_PROF_INTEGRATE, SMJ_PROF_TOTAL, SMJ_PROF_PGS_SWEEPS,
+       SMJ_PROF_SETUP, SMJ_PROF_SLOTS = 16 };
 enum { SMJ_INFO_NEFC = 0, SMJ_INFO_NCON = 1, SMJ_INFO_NITER = 2, SMJ_INFO_FLAGS = 3 };
 enum { SMJ_FLAG_EFC_OVERFLOW = 1, SMJ_FLAG_CON_OVERFLOW = 2, SMJ_FLAG_BAD_STATE = 4 };
 

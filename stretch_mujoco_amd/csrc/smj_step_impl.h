@@ -953,7 +953,8 @@ struct StepKernel {
   }
 
   // ------------------------------------------------------------------ projectConstraint + PGS
-  SMJ_DEV void solve(bool dbg) {
+  SMJ_DEV void solve(bool dbg, float* pc, long long& t0, bool prof) {
+#define TICK(slot) if (prof) { const long long t1 = smj_clock(); pc[slot] += (float)(t1 - t0); t0 = t1; }
     const int nv = M.nv, ne = nefc;
     // efc_vel, aref, warm-start residual jar (rows = lanes), all from J before it is transformed
     PL<float> aref, jar, Rr, bb;
@@ -1022,6 +1023,7 @@ struct StepKernel {
         }
     }
     SYNC();
+    TICK(SMJ_PROF_PROJECT)
     // warm start  [MJ] mj_warmstart (PGS branch): forces from the primal residual at qacc_warmstart
     LANES { s.earef[lane] = jar[lane]; }  // stash jar in LDS so a contact's first row can see its block
     SYNC();
@@ -1074,6 +1076,7 @@ struct StepKernel {
     if (wcost > 0) { LANES { f_r[lane] = 0.f; r_r[lane] = bb[lane]; } }
     LANES { ARinv_r[lane] = 1.0f / s.u.A[lane * NEFC + lane]; }
 
+    TICK(SMJ_PROF_WARM)
     // ---- PGS sweeps  [MJ] mj_solPGS
     const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
     int iter = 0;
@@ -1110,6 +1113,8 @@ struct StepKernel {
       if (!M.pgs_fixed_iter && improvement < M.tolerance) { iter++; break; }
     }
     niter = iter;
+    TICK(SMJ_PROF_PGS)
+#undef TICK
     LANES { s.ef[lane] = lane < ne ? f_r[lane] : 0.f; }
     SYNC();
     // w = Y' f (dof lanes); qfrc_constraint = L' w ; qacc = L^-1 ( Dinv (u + w) )
@@ -1472,24 +1477,44 @@ struct StepKernel {
   SMJ_DEV void run(int nsteps, unsigned read_flags) {
     const int want_imu = read_flags & 1, want_lidar = read_flags & 2;
     flags = 0; nefc = 0; ncon = 0; niter = 0;
+    float pc[SMJ_PROF_SLOTS];
+    for (int k = 0; k < SMJ_PROF_SLOTS; k++) pc[k] = 0.f;
+    const bool prof = S.prof != nullptr;
+    long long t0 = prof ? smj_clock() : 0, tstart = t0;
+#define TICK(slot) if (prof) { const long long t1 = smj_clock(); pc[slot] += (float)(t1 - t0); t0 = t1; }
     setup();
     load_state();
+    TICK(SMJ_PROF_SETUP)
     for (int st = 0; st < nsteps; st++) {
       const bool last = st == nsteps - 1;
       kinematics();
       if (last && want_lidar) lidar();
+      TICK(SMJ_PROF_KIN)
       com_crb();
       if (last) dump_debug();
+      TICK(SMJ_PROF_COMCRB)
       smooth_forces(last);
+      TICK(SMJ_PROF_SMOOTH)
       factor();
+      TICK(SMJ_PROF_FACTOR)
       collision();
       if (last) dump_contacts();
+      TICK(SMJ_PROF_COLLISION)
       make_constraint();
-      solve(last);
+      TICK(SMJ_PROF_MAKECON)
+      solve(last, pc, t0, prof);
       if (last && want_imu) imu();
+      TICK(SMJ_PROF_POST)
       integrate();
+      TICK(SMJ_PROF_INTEGRATE)
+      pc[SMJ_PROF_PGS_SWEEPS] += (float)niter;
     }
     store_state(nsteps);
     readout();
+    if (prof) {
+      pc[SMJ_PROF_TOTAL] = (float)(smj_clock() - tstart);
+      LANES { if (lane < SMJ_PROF_SLOTS) S.prof[lane * S.ld + env] = pc[lane]; }
+    }
+#undef TICK
   }
 };

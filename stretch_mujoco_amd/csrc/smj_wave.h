@@ -58,6 +58,7 @@ template <class T>
 static inline T wave_read(const PL<T>& x, int l) { return x.v[l]; }
 static inline int popc64(uint64_t x) { return __builtin_popcountll(x); }
 static inline int ffs64(uint64_t x) { return __builtin_ffsll((long long)x) - 1; }
+static inline long long smj_clock() { return 0; }
 #else
 #include <hip/hip_runtime.h>
 #define SMJ_DEV __device__ __forceinline__
@@ -95,6 +96,7 @@ __device__ __forceinline__ float wave_read(const PL<float>& x, int l) {
 __device__ __forceinline__ int wave_read(const PL<int>& x, int l) { return __builtin_amdgcn_readlane(x.v, l); }
 __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
 __device__ __forceinline__ int ffs64(uint64_t x) { return __ffsll((long long)x) - 1; }
+__device__ __forceinline__ long long smj_clock() { return (long long)__builtin_readcyclecounter(); }
 #endif
 
 // ---------------------------------------------------------------------------------------------- small math

@@ -22,11 +22,11 @@ MODE_NONE, MODE_TRANSLATE, MODE_ROTATE, MODE_VELOCITY = 0, 1, 2, 3
 
 
 class Glue:
-    def __init__(self, num_envs: int, nu: int, key_ctrl: torch.Tensor, key_names, device):
+    def __init__(self, num_envs: int, nu: int, key_ctrl: torch.Tensor, key_names, device, dtype=torch.float32):
         B = self.B = num_envs
         self.nu = nu
         self.device = device
-        f = dict(dtype=torch.float32, device=device)
+        f = dict(dtype=dtype, device=device)
         b = dict(dtype=torch.bool, device=device)
         self.key_ctrl = key_ctrl.to(**f)          # [nkey, nu]
         self.key_names = list(key_names)
@@ -147,7 +147,8 @@ class Glue:
         if not bool((mode != MODE_NONE).any()):
             return
         li, ri = CTRL_INDEX["left_wheel_vel"], CTRL_INDEX["right_wheel_vel"]
-        sign = torch.where(self.bc_inc > 0, 1.0, -1.0)
+        one = torch.ones_like(self.bc_inc)
+        sign = torch.where(self.bc_inc > 0, one, -one)
         # translate (mujoco_server.py:144-154)
         dist = torch.linalg.vector_norm(pose[:2] - self.bc_start[:2], dim=0)
         t_on = mode == MODE_TRANSLATE

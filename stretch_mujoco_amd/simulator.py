@@ -101,7 +101,9 @@ class StretchBatchSimulator:
                  ("INFO", self.info)]
         if self._debug:
             self.debug = torch.zeros(dims[D["DEBUG_FLOATS"]], B, **f)
+            self.prof = torch.zeros(16, B, **f)
             binds.append(("DEBUG", self.debug))
+            binds.append(("PROF", self.prof))
         for name, t in binds:
             _lib.check(L, ctx, L.smj_bind(ctx, S[name], ctypes.c_void_p(t.data_ptr()), B), f"smj_bind({name})")
         key_ctrl = torch.tensor(np.asarray(self.model["key_ctrl"], np.float32)[:, : self.nu])

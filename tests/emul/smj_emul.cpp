@@ -71,6 +71,7 @@ int emul_bind(emul_ctx* c, int slot, void* p, long ld) {
     case 10: s.lidar = (float*)p; break;
     case 11: s.info = (int*)p; break;
     case 12: s.debug = (float*)p; break;
+    case 13: s.prof = (float*)p; break;
     default: return -1;
   }
   return 0;

@@ -1,0 +1,97 @@
+"""Kernel LOGIC vs the fp64 oracle on the CPU: the HIP step kernel source compiled through the lane emulator
+(tests/emul, fp32, same operation order as the GPU code).  The `-m gpu` tests repeat these through libsmj.so."""
+import numpy as np
+import pytest
+
+from conftest import HOME_CTRL, MIX_CTRL
+from oracle.oracle import Oracle
+from emul.emul import Emul
+
+DIMS = dict(nq=27, nv=26, nu=10, nlidar=360)
+
+
+def _pair(blob, ctrl, B=1):
+    o = Oracle(blob)
+    o.arr("ctrl")[:] = ctrl
+    e = Emul(blob, DIMS, num_envs=B)
+    e.qpos[:] = o.arr("qpos")[:, None]
+    e.ctrl[:] = np.asarray(ctrl, np.float32)[:, None]
+    return o, e
+
+
+def test_single_step_stages(blob_fused):
+    o, e = _pair(blob_fused, MIX_CTRL)
+    o.forward()
+    e.step(1)
+    d, ne = e.debug[:, 0], o.nefc
+    M = o.arr("qM").reshape(26, 26)
+    assert np.abs(d[0:1024].reshape(32, 32)[:26, :26] - M).max() / np.abs(M).max() < 1e-6
+    assert np.abs(d[1408:1468].reshape(20, 3) - o.arr("xpos")).max() < 1e-6
+    assert np.abs(d[1504:1530] - o.arr("qfrc_bias")).max() < 1e-4
+    assert np.abs(d[1536:1562] - o.arr("qfrc_passive")).max() < 1e-4
+    assert np.abs(d[1568:1594] - o.arr("qfrc_actuator")).max() < 1e-4
+    assert (e.info[0, 0], e.info[1, 0]) == (ne, o.ncon)
+    assert np.abs(d[1216:1216 + ne] - o.arr("efc_R")).max() / np.abs(o.arr("efc_R")).max() < 1e-5
+    AR = o.arr("efc_AR").reshape(ne, ne)
+    assert np.abs(d[1728:1728 + 4096].reshape(64, 64)[:ne, :ne] - AR).max() / np.abs(AR).max() < 1e-5
+    assert np.abs(d[1152:1152 + ne] - o.arr("efc_b")).max() / np.abs(o.arr("efc_b")).max() < 1e-5
+    assert np.abs(d[1088:1088 + ne] - o.arr("efc_force")).max() / np.abs(o.arr("efc_force")).max() < 1e-4
+    assert np.abs(d[1056:1082] - o.arr("qacc")).max() / np.abs(o.arr("qacc")).max() < 2e-4
+    assert abs(int(e.info[2, 0]) - int(o.iarr("solver_niter")[0])) <= 2
+
+
+@pytest.mark.parametrize("ctrl", [HOME_CTRL, MIX_CTRL])
+def test_trajectory_drift_below_1e4(blob_fused, ctrl):
+    """north_star: qpos drift < 1e-4 over 1000 steps (here vs the fp64 oracle, the only oracle available)."""
+    o, e = _pair(blob_fused, ctrl)
+    for _ in range(10):
+        o.step(100); e.step(100)
+        assert np.abs(e.qpos[:, 0] - o.arr("qpos")).max() < 1e-4
+    assert e.info[3, 0] == 0 and e.nstep[0] == 1000
+    np.testing.assert_allclose(e.act_len[:, 0], _act_len(o), atol=2e-5)
+
+
+def _act_len(o):
+    o.forward()
+    return o.arr("actuator_length").copy()
+
+
+def test_sensors_and_readout(blob_fused):
+    o, e = _pair(blob_fused, MIX_CTRL)
+    o.step(299); e.step(300, 3)
+    o.forward(); o.sensors(True)      # sensor values belong to the forward pass of the last step
+    np.testing.assert_allclose(e.gyro[:, 0], o.arr("gyro"), atol=2e-5)
+    np.testing.assert_allclose(e.accel[:, 0], o.arr("accel"), atol=5e-3)
+    np.testing.assert_allclose(e.lidar[:, 0], o.arr("lidar"), atol=1e-4)
+    o.step(1); o.forward()
+    x, y = o.arr("xpos")[1][:2]
+    R = o.arr("xmat")[1]
+    np.testing.assert_allclose(e.base[:, 0], [x, y, np.arctan2(R[3], R[0])], atol=2e-5)
+    np.testing.assert_allclose(e.act_vel[:, 0], o.arr("actuator_velocity"), atol=2e-4)
+
+
+def test_envs_are_independent_and_deterministic(blob_fused):
+    o, e = _pair(blob_fused, HOME_CTRL, B=3)
+    e.ctrl[:, 1] = MIX_CTRL
+    e.qpos[0, 2] = 0.5; e.qpos[1, 2] = -0.25
+    e.step(40)
+    e2 = Emul(blob_fused, DIMS, num_envs=1)
+    e2.qpos[:, 0] = o.arr("qpos"); e2.ctrl[:, 0] = MIX_CTRL
+    e2.step(40)
+    np.testing.assert_array_equal(e.qpos[:, 1], e2.qpos[:, 0])   # bitwise: env 1 unaffected by its neighbours
+    assert np.abs(e.qpos[:, 0] - e.qpos[:, 2])[3:].max() < 1e-6 and abs(e.qpos[0, 2] - e.qpos[0, 0] - 0.5) < 1e-5
+
+
+def test_lidar_sees_a_wall(blob_fused):
+    """Plane + primitives are ray-cast this round: put the robot next to nothing -> -1 everywhere (no hit), the
+    cut-off applies, and the floor is hit when the base is tilted forward."""
+    o, e = _pair(blob_fused, HOME_CTRL)
+    q = np.array(o.arr("qpos"))
+    ang = 0.3  # pitch the base nose-down about y: rays toward +x of the laser hit the floor
+    q[2] = 0.3; q[3:7] = [np.cos(ang / 2), 0, np.sin(ang / 2), 0]
+    o.arr("qpos")[:] = q; e.qpos[:, 0] = q
+    o.forward(); o.sensors(True)
+    e.step(1, 2)
+    L = e.lidar[:, 0]
+    np.testing.assert_allclose(L, o.arr("lidar"), atol=1e-4)
+    assert (L > 0).sum() > 50 and (L == -1).sum() > 50 and L.max() <= 10.0
