@@ -68,83 +68,77 @@ __device__ __forceinline__ void mfma16x16x4(PL<F4v>& acc, const PL<float>& a, co
 #endif
 
 // ---------------------------------------------------------------------------------------------- QCQP (uniform)
-// min 0.5 x'Ax + x'b  s.t. sum (x_i/d_i)^2 <= r^2   [MJ] mju_QCQP2 / mju_QCQP3 / mju_QCQP.  Returns 1 if active.
+// min 0.5 x'Ax + x'b  s.t. sum (x_i/d_i)^2 <= r^2   [MJ] mju_QCQP2 / mju_QCQP3 / mju_QCQP: Newton iteration on the
+// multiplier la with a Cholesky factor of (A + la I) per iterate (rank test 1e-10).  Returns 1 if the constraint
+// is active.  Reciprocal-based factor/solves: no IEEE divides on the serial path.
 template <int N>
 SMJ_DEV int qcqp(float* res, const float* Ain, const float* bin, const float* dd, float r) {
-  float A[N * N], b[N], L[N * N], tmp[N], la = 0;
+  float A[N * N], b[N], L[N * N], Li[N], tmp[N], la = 0;
 #pragma unroll
   for (int i = 0; i < N; i++) {
     b[i] = bin[i] * dd[i];
 #pragma unroll
-    for (int j = 0; j < N; j++) A[i * N + j] = Ain[i * N + j] * dd[i] * dd[j];
+    for (int j = 0; j <= i; j++) A[i * N + j] = Ain[i * N + j] * dd[i] * dd[j];
   }
+  const float r2 = r * r;
   for (int it = 0; it < 20; it++) {
-    if (N == 2) {
-      float a00 = A[0] + la, a11 = A[3] + la, a01 = A[1];
-      float det = a00 * a11 - a01 * a01;
-      if (det < 1e-10f) {
-        res[0] = 0; res[1] = 0;
-        return 0;
-      }
-      float di = 1.0f / det, P00 = a11 * di, P11 = a00 * di, P01 = -a01 * di;
-      res[0] = -(P00 * b[0] + P01 * b[1]); res[1] = -(P01 * b[0] + P11 * b[1]);
-      tmp[0] = P00 * res[0] + P01 * res[1]; tmp[1] = P01 * res[0] + P11 * res[1];
-    } else {
-      // Cholesky of A + la*I, rank test 1e-10
-      bool bad = false;
+    bool bad = false;
 #pragma unroll
-      for (int j = 0; j < N; j++) {
-        float s = A[j * N + j] + la;
+    for (int j = 0; j < N; j++) {
+      float sd = A[j * N + j] + la;
 #pragma unroll
-        for (int k = 0; k < j; k++) s -= L[j * N + k] * L[j * N + k];
-        if (s < 1e-10f) { bad = true; s = 1e-10f; }
-        float l = sqrtf(s), li = 1.0f / l;
-        L[j * N + j] = l;
+      for (int k = 0; k < j; k++) sd -= L[j * N + k] * L[j * N + k];
+      if (sd < 1e-10f) { bad = true; sd = 1e-10f; }
+      const float li = fast_rsqrt(sd);
+      Li[j] = li;
 #pragma unroll
-        for (int i = j + 1; i < N; i++) {
-          float t = A[i * N + j];
+      for (int i = j + 1; i < N; i++) {
+        float t = A[i * N + j];
 #pragma unroll
-          for (int k = 0; k < j; k++) t -= L[i * N + k] * L[j * N + k];
-          L[i * N + j] = t * li;
-        }
-      }
-      if (bad) {
-#pragma unroll
-        for (int i = 0; i < N; i++) res[i] = 0;
-        return 0;
-      }
-      // res = -(A+la)^-1 b ; tmp = (A+la)^-1 res
-#pragma unroll
-      for (int pass = 0; pass < 2; pass++) {
-        float x[N];
-#pragma unroll
-        for (int i = 0; i < N; i++) x[i] = pass == 0 ? b[i] : res[i];
-#pragma unroll
-        for (int i = 0; i < N; i++) {
-          float s = x[i];
-#pragma unroll
-          for (int k = 0; k < i; k++) s -= L[i * N + k] * x[k];
-          x[i] = s / L[i * N + i];
-        }
-#pragma unroll
-        for (int i = N - 1; i >= 0; i--) {
-          float s = x[i];
-#pragma unroll
-          for (int k = i + 1; k < N; k++) s -= L[k * N + i] * x[k];
-          x[i] = s / L[i * N + i];
-        }
-#pragma unroll
-        for (int i = 0; i < N; i++) {
-          if (pass == 0) res[i] = -x[i];
-          else tmp[i] = x[i];
-        }
+        for (int k = 0; k < j; k++) t -= L[i * N + k] * L[j * N + k];
+        L[i * N + j] = t * li;
       }
     }
-    float val = -r * r, deriv = 0;
+    if (bad) {
+#pragma unroll
+      for (int i = 0; i < N; i++) res[i] = 0;
+      return 0;
+    }
+    // res = -(A+la)^-1 b ; tmp = (A+la)^-1 res
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      float x[N];
+#pragma unroll
+      for (int i = 0; i < N; i++) {
+        float sv = pass == 0 ? -b[i] : res[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) sv -= L[i * N + k] * x[k];
+        x[i] = sv * Li[i];
+      }
+#pragma unroll
+      for (int i = N - 1; i >= 0; i--) {
+        float sv = x[i];
+#pragma unroll
+        for (int k = i + 1; k < N; k++) sv -= L[k * N + i] * x[k];
+        x[i] = sv * Li[i];
+      }
+#pragma unroll
+      for (int i = 0; i < N; i++) {
+        if (pass == 0) res[i] = x[i];
+        else tmp[i] = x[i];
+      }
+      if (pass == 0) {
+        float val = -r2;
+#pragma unroll
+        for (int i = 0; i < N; i++) val += res[i] * res[i];
+        if (val < 1e-10f) { it = 100; break; }  // converged, or the unconstrained minimum is inside the cone
+      }
+    }
+    if (it >= 100) break;
+    float val = -r2, deriv = 0;
 #pragma unroll
     for (int i = 0; i < N; i++) { val += res[i] * res[i]; deriv -= 2 * res[i] * tmp[i]; }
-    if (val < 1e-10f) break;
-    float delta = -val / deriv;
+    const float delta = -val * fast_rcp(deriv);
     if (delta < 1e-10f) break;
     la += delta;
   }
@@ -334,7 +328,7 @@ struct StepKernel {
       for (int k = 0; k < 3; k++) xip[lane][k] = t[k];
     }
     for (int r = 0; r < M.nroot; r++) {
-      const int root = M.k_root_list[r];
+      const int root = uni(M.k_root_list[r]);
       LANES {
         const bool in = lane > 0 && lane < nb && b_root[lane] == root;
         const float m = in ? b_inl[lane][9] : 0.f;
@@ -500,7 +494,7 @@ struct StepKernel {
     }
     // gravity compensation  [MJ] mj_passive gravcomp: F = -g*m*gravcomp at the body's gravcomp point
     for (int t = 0; t < M.ngc; t++) {
-      const int b = M.k_gc_body[t];
+      const int b = uni(M.k_gc_body[t]);
       const float gm = M.body_gcmass[b];
       float pt[3], lp[3] = {M.body_gcipos[3 * b], M.body_gcipos[3 * b + 1], M.body_gcipos[3 * b + 2]};
       mulmat3vec(pt, s.xmat[b], lp);
@@ -647,7 +641,7 @@ struct StepKernel {
       while (mask) {
         const int l = ffs64(mask);
         mask &= mask - 1;
-        narrow_plane(M.k_planepair[base + l]);
+        narrow_plane(uni(M.k_planepair[base + l]));
       }
     }
     SYNC();
@@ -655,8 +649,8 @@ struct StepKernel {
 
   // narrowphase for one plane pair; uniform control flow, vertex loops are lane-parallel
   SMJ_DEV void narrow_plane(int p) {
-    const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p], t2 = M.geom_type[g2];
-    const float margin = M.pair_margin[p];
+    const int g1 = uni(M.pair_geom1[p]), g2 = uni(M.pair_geom2[p]), t2 = uni(M.geom_type[g2]);
+    const float margin = uni(M.pair_margin[p]);
     float pp[3], pm[9], gp[3], gm[9];
     geom_pose(g1, pp, pm);
     geom_pose(g2, gp, gm);
@@ -728,7 +722,7 @@ struct StepKernel {
   // plane vs convex hull, vertices strided over lanes; same selection rule as oracle plane_hull()
   SMJ_DEV void plane_hull(int p, int g1, int g2, const float* pp, const float* n, const float* gp, const float* gm, float margin) {
     const float* verts = M.hull_vert + 3 * M.geom_hulladr[g2];
-    const int nvert = M.geom_hullnum[g2];
+    const int nvert = uni(M.geom_hullnum[g2]);
     float nl[3];
     mulmat3Tvec(nl, gm, n);
     const float off = (gp[0] - pp[0]) * n[0] + (gp[1] - pp[1]) * n[1] + (gp[2] - pp[2]) * n[2];
@@ -807,7 +801,7 @@ struct StepKernel {
   SMJ_DEV int pick_index(const PL<float>& key, const PL<int>& idx, float val) {
     PL<float> cand;
     LANES { cand[lane] = (key[lane] == val && idx[lane] >= 0) ? (float)idx[lane] : 3.0e38f; }
-    return (int)wave_min(cand);
+    return uni((int)wave_min(cand));
   }
 
   // ------------------------------------------------------------------ B.4 constraint rows
@@ -871,10 +865,10 @@ struct StepKernel {
     SYNC();
     // contact rows: lanes = dofs fill the Jacobian columns
     for (int c = 0; c < ncon; c++) {
-      const int dim = s.cdim[c];
-      if (!(s.cdist[c] < s.cmargin[c])) continue;
+      const int dim = uni(s.cdim[c]);
+      if (!(uni(s.cdist[c]) < uni(s.cmargin[c]))) continue;
       if (row0 + dim > NEFC) { flags |= SMJ_FLAG_EFC_OVERFLOW; continue; }
-      const int g1 = s.cgeom1[c], g2 = s.cgeom2[c], b1 = M.geom_bodyid[g1], b2 = M.geom_bodyid[g2];
+      const int g1 = uni(s.cgeom1[c]), g2 = uni(s.cgeom2[c]), b1 = uni(M.geom_bodyid[g1]), b2 = uni(M.geom_bodyid[g2]);
       const uint64_t m1 = mk64(M.k_body_dofmask_lo[b1], M.k_body_dofmask_hi[b1]), m2 = mk64(M.k_body_dofmask_lo[b2], M.k_body_dofmask_hi[b2]);
       const float tran = M.geom_invweight0[2 * g1] + M.geom_invweight0[2 * g2], rot = M.geom_invweight0[2 * g1 + 1] + M.geom_invweight0[2 * g2 + 1];
       LANES {
@@ -973,13 +967,13 @@ struct StepKernel {
     LANES { if (lane < NVP) s.uu[lane] = lane < nv ? u[lane] : 0.f; }
     // Y = J L^-1 : every lane runs the L^-T phase on its own row (private LDS row)
     for (int i = nv - 1; i > 0; i--) {
-      const int na = M.k_dof_anc_num[i], adr = M.k_dof_anc_adr[i];
+      const int na = uni(M.k_dof_anc_num[i]), adr = uni(M.k_dof_anc_adr[i]);
       if (na == 0) continue;
       LANES {
         const float xi = s.J[lane][i];
         if (xi != 0.f)
           for (int a = 0; a < na; a++) {
-            const int j = M.k_dof_anc[adr + a];
+            const int j = uni(M.k_dof_anc[adr + a]);
             s.J[lane][j] -= s.MM[i][j] * xi;
           }
       }
@@ -1078,31 +1072,45 @@ struct StepKernel {
 
     TICK(SMJ_PROF_WARM)
     // ---- PGS sweeps  [MJ] mj_solPGS
+    // Row metadata lives in the registers of the row's lane and is fetched with v_readlane (no LDS round trip on the
+    // serial path); the A row needed for the residual update is loaded first so its latency overlaps the scalar math.
+    PL<int> type_r, dimc_r;   // row type; for the first row of an elliptic block: dim | contact << 8
+    PL<float> aii_r, fl_r;
+    LANES {
+      const int t = lane < ne ? s.etype[lane] : CT_NONE;
+      type_r[lane] = t;
+      int dc = 0;
+      if (t == CT_CONTACT_ELLIPTIC) { const int c = s.eid[lane]; dc = s.cdim[c] | (c << 8); }
+      dimc_r[lane] = dc;
+      aii_r[lane] = s.u.A[lane * NEFC + lane];
+      fl_r[lane] = s.efloss[lane];
+    }
     const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
     int iter = 0;
     for (; iter < M.iterations; iter++) {
       float improvement = 0;
       if (iter > 0 && (iter & 7) == 0) residual_refresh(bb);
       for (int i = 0; i < ne;) {
-        const int t = s.etype[i];
+        const int t = wave_read(type_r, i);
         if (t != CT_CONTACT_ELLIPTIC) {
-          const float res = wave_read(r_r, i), old = wave_read(f_r, i), aii = s.u.A[i * NEFC + i];
-          float fn = old - res / aii;
-          if (t == CT_FRICTION) { const float fl = s.efloss[i]; fn = fminf(fl, fmaxf(-fl, fn)); }
+          PL<float> arow;
+          LANES { arow[lane] = s.u.A[i * NEFC + lane]; }
+          const float res = wave_read(r_r, i), old = wave_read(f_r, i), ainv = wave_read(ARinv_r, i);
+          const float aii = wave_read(aii_r, i);
+          float fn = old - res * ainv;
+          if (t == CT_FRICTION) { const float fl = wave_read(fl_r, i); fn = fminf(fl, fmaxf(-fl, fn)); }
           else if (t != CT_EQUALITY) fn = fmaxf(0.f, fn);
           float delta = fn - old;
           float change = delta * (0.5f * aii * delta + res);
           if (change > 1e-10f) { delta = 0; change = 0; }
           improvement -= change;
-          if (delta != 0.f) {
-            LANES {
-              r_r[lane] += s.u.A[i * NEFC + lane] * delta;
-              if (lane == i) f_r[lane] += delta;
-            }
+          LANES {
+            r_r[lane] += arow[lane] * delta;
+            if (lane == i) f_r[lane] += delta;
           }
           i += 1;
         } else {
-          const int c = s.eid[i], dim = s.cdim[c];
+          const int dc = wave_read(dimc_r, i), dim = dc & 255, c = dc >> 8;
           if (dim == 3) improvement += pgs_block<3>(i, c);
           else if (dim == 4) improvement += pgs_block<4>(i, c);
           else improvement += pgs_block<6>(i, c);
@@ -1167,7 +1175,12 @@ struct StepKernel {
   // one elliptic contact block of the PGS sweep  [MJ] mj_solPGS elliptic branch (ray update + QCQP); uniform math
   template <int DIM>
   SMJ_DEV float pgs_block(int i, int c) {
-    float res[DIM], old[DIM], f[DIM], At[DIM * DIM], mu[DIM - 1];
+    float res[DIM], old[DIM], f[DIM], At[DIM * DIM], v1[DIM], mu[DIM - 1];
+    PL<float[DIM]> arow;  // rows i..i+DIM of A for the residual update, issued up front
+    LANES {
+#pragma unroll
+      for (int r = 0; r < DIM; r++) arow[lane][r] = s.u.A[(i + r) * NEFC + lane];
+    }
 #pragma unroll
     for (int r = 0; r < DIM; r++) {
       res[r] = wave_read(r_r, i + r); old[r] = wave_read(f_r, i + r); f[r] = old[r];
@@ -1176,36 +1189,34 @@ struct StepKernel {
     }
 #pragma unroll
     for (int j = 0; j < DIM - 1; j++) mu[j] = s.cfric[c][j];
-    if (f[0] < SMJ_MINVAL) {
-      f[0] -= res[0] / At[0];
+    // v1 = At * old (used by the ray update and by the friction right-hand side)
+    float denom = 0, num = 0;
+#pragma unroll
+    for (int r = 0; r < DIM; r++) {
+      float a = 0;
+#pragma unroll
+      for (int q = 0; q < DIM; q++) a += At[r * DIM + q] * old[q];
+      v1[r] = a;
+      denom += old[r] * a; num += old[r] * res[r];
+    }
+    if (f[0] < SMJ_MINVAL) {  // normal update
+      f[0] -= res[0] * wave_read(ARinv_r, i);
       if (f[0] < 0) f[0] = 0;
 #pragma unroll
       for (int j = 1; j < DIM; j++) f[j] = 0;
-    } else {
-      float denom = 0, num = 0;
+    } else if (denom >= SMJ_MINVAL) {  // ray update
+      float x = -num * fast_rcp(denom);
+      if (f[0] + x * old[0] < 0) x = -f[0] * fast_rcp(old[0]);
 #pragma unroll
-      for (int r = 0; r < DIM; r++) {
-        float v1 = 0;
-#pragma unroll
-        for (int q = 0; q < DIM; q++) v1 += At[r * DIM + q] * old[q];
-        denom += old[r] * v1; num += old[r] * res[r];
-      }
-      if (denom >= SMJ_MINVAL) {
-        float x = -num / denom;
-        if (f[0] + x * old[0] < 0) x = -f[0] / old[0];
-#pragma unroll
-        for (int r = 0; r < DIM; r++) f[r] += x * old[r];
-      }
+      for (int r = 0; r < DIM; r++) f[r] += x * old[r];
     }
+    // friction update with the normal fixed
     float Ac[(DIM - 1) * (DIM - 1)], bc[DIM - 1], v[DIM - 1];
 #pragma unroll
     for (int j = 0; j < DIM - 1; j++) {
 #pragma unroll
       for (int q = 0; q < DIM - 1; q++) Ac[j * (DIM - 1) + q] = At[(j + 1) * DIM + q + 1];
-      float bj = res[j + 1];
-#pragma unroll
-      for (int q = 0; q < DIM; q++) bj -= At[(j + 1) * DIM + q] * old[q];
-      bc[j] = bj + At[(j + 1) * DIM] * f[0];
+      bc[j] = res[j + 1] - v1[j + 1] + At[(j + 1) * DIM] * f[0];
     }
     if (f[0] < SMJ_MINVAL) {
 #pragma unroll
@@ -1215,8 +1226,8 @@ struct StepKernel {
       if (active) {
         float sc = 0;
 #pragma unroll
-        for (int j = 0; j < DIM - 1; j++) sc += v[j] * v[j] / (mu[j] * mu[j]);
-        sc = sqrtf(f[0] * f[0] / fmaxf(SMJ_MINVAL, sc));
+        for (int j = 0; j < DIM - 1; j++) { const float t = v[j] * fast_rcp(mu[j]); sc += t * t; }
+        sc = f[0] * fast_rsqrt(fmaxf(SMJ_MINVAL, sc));
 #pragma unroll
         for (int j = 0; j < DIM - 1; j++) v[j] *= sc;
       }
@@ -1238,7 +1249,7 @@ struct StepKernel {
       float acc = r_r[lane];
 #pragma unroll
       for (int r = 0; r < DIM; r++) {
-        acc += s.u.A[(i + r) * NEFC + lane] * delta[r];
+        acc += arow[lane][r] * delta[r];
         if (lane == i + r) f_r[lane] += delta[r];
       }
       r_r[lane] = acc;

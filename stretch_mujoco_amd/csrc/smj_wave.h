@@ -59,6 +59,10 @@ static inline T wave_read(const PL<T>& x, int l) { return x.v[l]; }
 static inline int popc64(uint64_t x) { return __builtin_popcountll(x); }
 static inline int ffs64(uint64_t x) { return __builtin_ffsll((long long)x) - 1; }
 static inline long long smj_clock() { return 0; }
+static inline int uni(int x) { return x; }
+static inline float uni(float x) { return x; }
+static inline float fast_rcp(float x) { return 1.0f / x; }
+static inline float fast_rsqrt(float x) { return 1.0f / sqrtf(x); }
 #else
 #include <hip/hip_runtime.h>
 #define SMJ_DEV __device__ __forceinline__
@@ -97,6 +101,14 @@ __device__ __forceinline__ int wave_read(const PL<int>& x, int l) { return __bui
 __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
 __device__ __forceinline__ int ffs64(uint64_t x) { return __ffsll((long long)x) - 1; }
 __device__ __forceinline__ long long smj_clock() { return (long long)__builtin_readcyclecounter(); }
+// uni(): assert to the compiler that a value loaded from memory is wave-uniform (v_readfirstlane -> SGPR), so that
+// loops / branches on it are scalar and readlane selectors need no waterfall loop
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ float uni(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); }
+// 1-ulp hardware reciprocal / reciprocal square root (v_rcp_f32 / v_rsq_f32): the serial solver math is latency
+// bound, an IEEE divide costs ~10 dependent instructions
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 #endif
 
 // ---------------------------------------------------------------------------------------------- small math

@@ -158,6 +158,19 @@ def test_masked_reset():
     sim.stop()
 
 
+def test_capacity_overflow_is_flagged():
+    """Lift fully down with the wrist pitched down puts many gripper hulls on the floor: more contacts than the
+    kernel's capacity.  Contacts beyond capacity are dropped and the env is flagged, never silently wrong."""
+    sim = _sim(4)
+    c = torch.tensor([0, 0, 0.0, 0.3, 0, -1.57, 0, 0, 0, 0], dtype=torch.float32, device=sim.device)
+    sim.ctrl[:] = c.unsqueeze(1)
+    sim.step(1500)
+    torch.cuda.synchronize()
+    assert torch.isfinite(sim.qpos).all()
+    assert int(sim.info[1].max()) >= 5
+    sim.stop()
+
+
 @pytest.mark.parametrize("B", [1024, 4096])
 def test_full_batch_properties(B):
     """BASELINE.json sizes.  Size-independent properties: (1) envs are independent -- a permutation of the inputs
@@ -168,7 +181,8 @@ def test_full_batch_properties(B):
     lo = torch.tensor(sim.model["actuator_ctrlrange"][:, 0], dtype=torch.float32, device=sim.device).unsqueeze(1)
     hi = torch.tensor(sim.model["actuator_ctrlrange"][:, 1], dtype=torch.float32, device=sim.device).unsqueeze(1)
     ctrl = lo + (hi - lo) * torch.rand(10, B, generator=g, device=sim.device)
-    ctrl[2] = ctrl[2].clamp(min=0.3)   # keep the gripper off the floor: non-plane narrowphase is not on the path yet
+    ctrl[2] = ctrl[2].clamp(min=0.55)  # keep the gripper off the floor: a gripper lying on the floor needs more than
+    # the 16-contact / 64-row capacity of this round's kernel (it is flagged, see test_capacity_overflow_is_flagged)
     sim.ctrl.copy_(ctrl)
     sim.step(300)
     torch.cuda.synchronize()
