@@ -25,11 +25,12 @@ BYTES_PER_ENV_STEP = 672.0  # physics-only algorithmic state traffic (BASELINE.m
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(blob: bytes, ctrl_script: np.ndarray, hold: int, seconds: float = 12.0):
+def cpu_baseline(blob: bytes, ctrl_script: np.ndarray, hold: int, seconds: float = 12.0, solver: str = "newton"):
     """fp64 CPU restatement (oracle, 'port') timed single-threaded on this host on a bounded sample."""
     from oracle.oracle import Oracle
 
     o = Oracle(blob)
+    o.set_option("solver", 2 if solver == "newton" else 0)
     o.arr("ctrl")[:] = [0, 0, 0.6, 0.1, 0, 0, 0, 0, 0, 0]
     o.step(500)
     t0 = time.perf_counter()
@@ -42,7 +43,8 @@ def cpu_baseline(blob: bytes, ctrl_script: np.ndarray, hold: int, seconds: float
         i += 1
     dt = time.perf_counter() - t0
     return dict(value=n / dt, unit="env-steps/s", cores=1, kind="port",
-                sample=f"1 env, {n} steps, same scene and action schedule (stand-in CPU restatement, not MuJoCo)")
+                sample=f"1 env, {n} steps, {solver} solver, same scene and action schedule "
+                       f"(stand-in fp64 CPU restatement, not MuJoCo)")
 
 
 def main():
@@ -52,6 +54,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--hold", type=int, default=50, help="physics steps per launch / per random action")
+    ap.add_argument("--solver", choices=["newton", "pgs"], default="newton",
+                    help="newton = the reference model's own solver (stretch.xml names none -> MuJoCo default); "
+                         "pgs = the solver named by BASELINE.json north_star")
+    ap.add_argument("--no-second-solver", action="store_true", help="skip the short run of the other solver")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -72,7 +78,7 @@ def main():
     from stretch_mujoco_amd.parallel import gather_returns
 
     B = args.envs_per_gpu
-    sim = StretchBatchSimulator(num_envs=B, device=str(dev))
+    sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver=args.solver)
     sim.start(home=False)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     lo = torch.tensor(sim.model["actuator_ctrlrange"][:, 0], dtype=torch.float32, device=dev).unsqueeze(1)
@@ -135,8 +141,9 @@ def main():
             "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{B} parallel Stretch envs per GPU, stretch.xml + ground plane (empty scene), "
-                                   f"physics-only, random ctrl in ctrlrange every {hold} steps, PGS solver "
-                                   f"(iterations<=100, tol 1e-8), implicitfast, dt=0.002",
+                                   f"physics-only, random ctrl in ctrlrange every {hold} steps, {args.solver} solver "
+                                   f"(iterations<=100, tol 1e-8), elliptic cones impratio 20, implicitfast, dt=0.002",
+                       "solver": args.solver,
                        "envs_per_gpu": B, "steps_per_launch": hold, "parallelism": f"env-sharded x{world}",
                        "returns_gathered": int(all_returns.numel()), "overflow_flags": flags},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -146,11 +153,25 @@ def main():
                          "note": "algorithmic bytes = 672 B/env-step x envs x steps per launch; the path is "
                                  "latency-bound (serial tree/Gauss-Seidel chains), HBM does not bind (DESIGN.md)"},
         }
+        if not args.no_second_solver:
+            other = "pgs" if args.solver == "newton" else "newton"
+            sim.set_option("solver", {"pgs": 0, "newton": 2}[other])
+            n2 = min(args.steps, 100)
+            random_action(); sim.step(hold)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            d2 = 0
+            while d2 < n2:
+                k = min(hold, n2 - d2)
+                random_action(); sim.step(k); d2 += k
+            torch.cuda.synchronize(dev)
+            out["other_solver"] = {"solver": other, "value": B * n2 / (time.perf_counter() - t1), "unit": "env-steps/s",
+                                   "n_gpus": 1, "steps": n2, "note": "rank 0 only, same workload, measured after the timed region"}
         if not args.no_cpu_baseline:
             rng = np.random.default_rng(1234)
             cr = np.asarray(sim.model["actuator_ctrlrange"])
             script = cr[:, 0] + (cr[:, 1] - cr[:, 0]) * rng.random((64, sim.nu))
-            out["cpu_baseline"] = cpu_baseline(sim._blob, script, hold, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(sim._blob, script, hold, args.cpu_seconds, args.solver)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
         print(json.dumps(out))
     sim.stop()

@@ -58,7 +58,8 @@ static int* blob_i32(const uint8_t* b, const char* name, int* count) {
 struct smjo_model {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, ncam, neq, ntendon, nwrap, nkey, npair, nhullvert, nlidar;
   double timestep, gravity[3], impratio, tolerance, meaninertia, lidar_cutoff;
-  int iterations, cone, warmstart, pgs_fixed_iter, max_con_pair;
+  int iterations, cone, warmstart, pgs_fixed_iter, max_con_pair, solver, ls_iterations;
+  double ls_tolerance;
   int *body_parentid, *body_weldid, *body_rootid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum;
   double *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_gravcomp, *body_invweight0,
       *body_subtreemass, *body_gcmass, *body_gcipos, *geom_invweight0;
@@ -130,7 +131,7 @@ smjo_model* smjo_load(const void* blob, size_t nbytes) {
   ti = blob_i32(b, "opt_cone", NULL); m->cone = ti[0]; free(ti);
   ti = blob_i32(b, "sensor_imu_site", NULL); m->imu_site = ti[0]; free(ti);
   m->lidar_site = blob_i32(b, "sensor_lidar_site", &m->nlidar);
-  m->warmstart = 1; m->pgs_fixed_iter = 0; m->max_con_pair = 4;
+  m->warmstart = 1; m->pgs_fixed_iter = 0; m->max_con_pair = 4; m->solver = 0; m->ls_iterations = 50; m->ls_tolerance = 0.01;
   LOADI(body_parentid); LOADI(body_weldid); LOADI(body_rootid); LOADI(body_jntadr); LOADI(body_jntnum);
   LOADI(body_dofadr); LOADI(body_dofnum);
   LOADF(body_pos); LOADF(body_quat); LOADF(body_ipos); LOADF(body_iquat); LOADF(body_mass); LOADF(body_inertia);
@@ -168,6 +169,7 @@ int smjo_set_option(smjo_model* m, const char* name, double v) {
   else if (!strcmp(name, "warmstart")) m->warmstart = (int)v;
   else if (!strcmp(name, "pgs_fixed_iter")) m->pgs_fixed_iter = (int)v;
   else if (!strcmp(name, "max_contacts_per_pair")) m->max_con_pair = (int)v;
+  else if (!strcmp(name, "solver")) m->solver = (int)v; /* 0 = PGS (north_star), 2 = Newton (the reference model's default) */
   else if (!strcmp(name, "timestep")) m->timestep = v;
   else if (!strcmp(name, "gravity_z")) m->gravity[2] = v;
   else if (!strcmp(name, "impratio")) m->impratio = v;
@@ -1168,6 +1170,266 @@ static void fwd_constraint(const smjo_model* m, smjo_data* d) {
   memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
 }
 
+
+/* ------------------------------------------------------------------ B.7' solver (Newton, primal)
+ * [MJ] mj_solNewton: minimise  0.5 (a-a_s)' M (a-a_s) + s(J a - aref)  over qacc with exact Newton steps
+ * (H = M + J' D_active J + cone Hessians) and an exact line search.  This is the solver the reference model
+ * actually runs (stretch.xml:7 names no solver -> MuJoCo default Newton).  The line search is a safeguarded
+ * 1-D Newton root finder on the directional derivative (same minimiser as MuJoCo's CGsearch to its tolerance). */
+typedef struct {
+  const smjo_model* m;
+  smjo_data* d;
+  double *Jaref, *Jv, *quad; /* per row: quad[3] */
+  double *cq;                /* per contact: u0 v0 uu uv vv Dm mu */
+  double quadGauss[3];
+} nctx;
+
+/* forces, cost and (optionally) per-contact cone Hessians at residual jar.  coneH: ncon x 36 or NULL */
+static double newton_update(const smjo_model* m, smjo_data* d, const double* jar, double* force, int* state, double* coneH) {
+  double cost = 0;
+  for (int i = 0; i < d->nefc; i++) {
+    int t = d->efc_type[i];
+    double D = d->efc_D[i], R = d->efc_R[i];
+    if (t == C_EQUALITY) { force[i] = -D * jar[i]; state[i] = 1; cost += 0.5 * D * jar[i] * jar[i]; }
+    else if (t == C_FRICTION_DOF) {
+      double fl = d->efc_frictionloss[i];
+      if (jar[i] <= -R * fl) { force[i] = fl; state[i] = 2; cost += -fl * (0.5 * R * fl + jar[i]); }
+      else if (jar[i] >= R * fl) { force[i] = -fl; state[i] = 3; cost += -fl * (0.5 * R * fl - jar[i]); }
+      else { force[i] = -D * jar[i]; state[i] = 1; cost += 0.5 * D * jar[i] * jar[i]; }
+    } else if (t == C_LIMIT_JOINT || t == C_CONTACT_FRICTIONLESS) {
+      if (jar[i] >= 0) { force[i] = 0; state[i] = 0; }
+      else { force[i] = -D * jar[i]; state[i] = 1; cost += 0.5 * D * jar[i] * jar[i]; }
+    } else {
+      int c = d->efc_id[i];
+      contact_t* con = d->contact + c;
+      int dim = con->dim;
+      double mu = con->mu, U[6], N, T = 0;
+      U[0] = jar[i] * mu;
+      for (int j = 1; j < dim; j++) { U[j] = jar[i + j] * con->friction[j - 1]; T += U[j] * U[j]; }
+      N = U[0]; T = sqrt(T);
+      if (N >= mu * T || (T <= 0 && N >= 0)) { for (int j = 0; j < dim; j++) { force[i + j] = 0; state[i + j] = 0; } }
+      else if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+        for (int j = 0; j < dim; j++) {
+          force[i + j] = -d->efc_D[i + j] * jar[i + j]; state[i + j] = 1;
+          cost += 0.5 * d->efc_D[i + j] * jar[i + j] * jar[i + j];
+        }
+      } else {
+        double Dm = d->efc_D[i] / fmax(mu * mu * (1 + mu * mu), MINVAL), NT = N - mu * T;
+        cost += 0.5 * Dm * NT * NT;
+        force[i] = -Dm * NT * mu;
+        for (int j = 1; j < dim; j++) force[i + j] = -force[i] / T * U[j] * con->friction[j - 1];
+        for (int j = 0; j < dim; j++) state[i + j] = 4;
+        if (coneH) { /* Hessian wrt jar: S' Hu S, S = diag(mu, friction), Hu from s(U) = 0.5 Dm (N - mu T)^2 */
+          double* H = coneH + 36 * c, S[6];
+          S[0] = mu;
+          for (int j = 1; j < dim; j++) S[j] = con->friction[j - 1];
+          H[0] = 1;
+          for (int j = 1; j < dim; j++) H[j] = H[j * dim] = -mu * U[j] / T;
+          for (int j = 1; j < dim; j++)
+            for (int k = 1; k < dim; k++)
+              H[j * dim + k] = mu * N / (T * T * T) * U[j] * U[k] - (j == k ? mu * NT / T : 0);
+          for (int j = 0; j < dim; j++)
+            for (int k = 0; k < dim; k++) H[j * dim + k] *= Dm * S[j] * S[k];
+        }
+      }
+      i += dim - 1;
+    }
+  }
+  return cost;
+}
+
+/* cost and first/second derivative along the search line at step alpha  ([MJ] CGeval) */
+static double ls_eval(const nctx* c, double a, double* d1, double* d2) {
+  const smjo_data* d = c->d;
+  double q0 = c->quadGauss[0], q1 = c->quadGauss[1], q2 = c->quadGauss[2], cost = 0, e1 = 0, e2 = 0;
+  for (int i = 0; i < d->nefc; i++) {
+    int t = d->efc_type[i];
+    const double* q = c->quad + 3 * i;
+    double x = c->Jaref[i] + a * c->Jv[i];
+    if (t == C_EQUALITY) { q0 += q[0]; q1 += q[1]; q2 += q[2]; }
+    else if (t == C_FRICTION_DOF) {
+      double fl = d->efc_frictionloss[i], rf = d->efc_R[i] * fl;
+      if (x <= -rf) { q0 += fl * (-0.5 * rf - c->Jaref[i]); q1 += -fl * c->Jv[i]; }
+      else if (x >= rf) { q0 += fl * (-0.5 * rf + c->Jaref[i]); q1 += fl * c->Jv[i]; }
+      else { q0 += q[0]; q1 += q[1]; q2 += q[2]; }
+    } else if (t == C_LIMIT_JOINT || t == C_CONTACT_FRICTIONLESS) {
+      if (x < 0) { q0 += q[0]; q1 += q[1]; q2 += q[2]; }
+    } else {
+      int ci = d->efc_id[i], dim = d->contact[ci].dim;
+      const double* k = c->cq + 7 * ci;
+      double mu = k[6], Dm = k[5], N = k[0] + a * k[1], Tsq = k[2] + a * (2 * k[3] + a * k[4]);
+      if (Tsq <= 0) { if (N < 0) { q0 += q[0]; q1 += q[1]; q2 += q[2]; } }
+      else {
+        double T = sqrt(Tsq);
+        if (N >= mu * T) { /* top: nothing */ }
+        else if (mu * N + T <= 0) { q0 += q[0]; q1 += q[1]; q2 += q[2]; }
+        else {
+          double N1 = k[1], T1 = (k[3] + a * k[4]) / T, T2 = k[4] / T - (k[3] + a * k[4]) * (k[3] + a * k[4]) / (T * T * T);
+          double NT = N - mu * T, NT1 = N1 - mu * T1;
+          cost += 0.5 * Dm * NT * NT; e1 += Dm * NT * NT1; e2 += Dm * (NT1 * NT1 + NT * (-mu * T2));
+        }
+      }
+      i += dim - 1;
+    }
+  }
+  *d1 = 2 * a * q2 + q1 + e1;
+  *d2 = 2 * q2 + e2;
+  return a * a * q2 + a * q1 + q0 + cost;
+}
+
+static double ls_search(const smjo_model* m, const nctx* c, double snorm, int* nls) {
+  double gtol = m->tolerance * m->ls_tolerance * snorm * m->meaninertia * (m->nv > 1 ? m->nv : 1);
+  double d1, d2, lo = 0, hi = -1, a = 0, dlo, best_a = 0;
+  double c0 = ls_eval(c, 0, &d1, &d2), bestc = c0;
+  *nls = 0;
+  if (d1 >= 0 || d2 <= 0) return 0; /* search is a descent direction for a convex cost: d1 < 0 */
+  dlo = d1;
+  a = -d1 / d2;
+  for (int it = 0; it < m->ls_iterations; it++) {
+    double cc = ls_eval(c, a, &d1, &d2);
+    (*nls)++;
+    if (cc < bestc) { bestc = cc; best_a = a; }
+    if (fabs(d1) < gtol) break;
+    if (d1 < 0) { lo = a; dlo = d1; } else hi = a;
+    double an = (d2 > 0) ? a - d1 / d2 : -1;
+    if (hi < 0) { if (an <= lo) an = 2 * a + 1e-12; }                 /* still unbracketed: Newton or expand */
+    else if (!(an > lo && an < hi)) an = 0.5 * (lo + hi);              /* bracketed: Newton or bisect */
+    if (hi >= 0 && hi - lo < 1e-14 * fmax(1, hi)) break;
+    a = an;
+  }
+  (void)dlo;
+  return best_a;
+}
+
+static void fwd_constraint_newton(const smjo_model* m, smjo_data* d) {
+  int nv = m->nv, ne = d->nefc, ncon = d->ncon;
+  if (ne == 0) {
+    memcpy(d->qacc, d->qacc_smooth, sizeof(double) * nv);
+    memcpy(d->qacc_warmstart, d->qacc_smooth, sizeof(double) * nv);
+    memset(d->qfrc_constraint, 0, sizeof(double) * nv);
+    d->solver_niter = 0;
+    return;
+  }
+  double* buf = (double*)calloc((size_t)ne * 8 + 8 * nv + (size_t)nv * nv * 2 + 36 * (ncon + 1) + 7 * (ncon + 1) + 64, sizeof(double));
+  double *Jaref = buf, *Jv = Jaref + ne, *quad = Jv + ne, *force = quad + 3 * ne, *ftmp = force + ne, *spare = ftmp + ne;
+  double *Ma = spare + ne, *Mv = Ma + nv, *grad = Mv + nv, *search = grad + nv, *qacc = search + nv, *tmpv = qacc + nv;
+  double *H = tmpv + 2 * nv, *Hf = H + nv * nv, *coneH = Hf + nv * nv, *cq = coneH + 36 * (ncon + 1);
+  int* state = (int*)calloc(2 * ne + 2, sizeof(int));
+  int* state2 = state + ne;
+  nctx ctx = {m, d, Jaref, Jv, quad, cq, {0, 0, 0}};
+  double scale = 1.0 / (m->meaninertia * (nv > 1 ? nv : 1));
+#define MATVEC_M(out, x) for (int i_ = 0; i_ < nv; i_++) { double s_ = 0; for (int k_ = 0; k_ < nv; k_++) s_ += d->qM[i_ * nv + k_] * (x)[k_]; (out)[i_] = s_; }
+#define JAREF(out, x) for (int i_ = 0; i_ < ne; i_++) { double s_ = 0; for (int k_ = 0; k_ < nv; k_++) s_ += d->efc_J[(size_t)i_ * nv + k_] * (x)[k_]; (out)[i_] = s_ - d->efc_aref[i_]; }
+#define GAUSS(x, Mx) ({ double g_ = 0; for (int k_ = 0; k_ < nv; k_++) g_ += 0.5 * ((Mx)[k_] - d->qfrc_smooth[k_]) * ((x)[k_] - d->qacc_smooth[k_]); g_; })
+  /* warm start ([MJ] mj_warmstart, primal branch): the cheaper of qacc_warmstart and qacc_smooth */
+  memcpy(qacc, m->warmstart ? d->qacc_warmstart : d->qacc_smooth, sizeof(double) * nv);
+  MATVEC_M(Ma, qacc);
+  JAREF(Jaref, qacc);
+  double cost = newton_update(m, d, Jaref, force, state, NULL) + GAUSS(qacc, Ma);
+  if (m->warmstart) {
+    JAREF(Jv, d->qacc_smooth); /* Gauss term is zero at qacc_smooth */
+    double cs = newton_update(m, d, Jv, ftmp, state2, NULL);
+    if (cs < cost) { memcpy(qacc, d->qacc_smooth, sizeof(double) * nv); MATVEC_M(Ma, qacc); memcpy(Jaref, Jv, sizeof(double) * ne); }
+  }
+  int iter = 0, nls_total = 0;
+  for (; iter < m->iterations;) {
+    cost = newton_update(m, d, Jaref, force, state, coneH) + GAUSS(qacc, Ma);
+    /* gradient */
+    for (int k = 0; k < nv; k++) {
+      double s = 0;
+      for (int i = 0; i < ne; i++) s += d->efc_J[(size_t)i * nv + k] * force[i];
+      d->qfrc_constraint[k] = s;
+      grad[k] = Ma[k] - d->qfrc_smooth[k] - s;
+    }
+    double gn = 0;
+    for (int k = 0; k < nv; k++) gn += grad[k] * grad[k];
+    if (iter > 0 && scale * sqrt(gn) < m->tolerance) break;
+    /* Hessian H = M + J' W J */
+    memcpy(H, d->qM, sizeof(double) * nv * nv);
+    for (int i = 0; i < ne; i++) {
+      if (d->efc_type[i] == C_CONTACT_ELLIPTIC && state[i] == 4) {
+        int c = d->efc_id[i], dim = d->contact[c].dim;
+        for (int r = 0; r < dim; r++)
+          for (int q = 0; q < dim; q++) {
+            double h = coneH[36 * c + r * dim + q];
+            if (h == 0) continue;
+            const double *Jr = d->efc_J + (size_t)(i + r) * nv, *Jq = d->efc_J + (size_t)(i + q) * nv;
+            for (int a = 0; a < nv; a++)
+              if (Jr[a] != 0)
+                for (int b = 0; b < nv; b++) H[a * nv + b] += h * Jr[a] * Jq[b];
+          }
+        i += dim - 1;
+      } else if (state[i] == 1) {
+        const double* Jr = d->efc_J + (size_t)i * nv;
+        double D = d->efc_D[i];
+        for (int a = 0; a < nv; a++)
+          if (Jr[a] != 0)
+            for (int b = 0; b < nv; b++) H[a * nv + b] += D * Jr[a] * Jr[b];
+      }
+    }
+    memcpy(Hf, H, sizeof(double) * nv * nv);
+    chol_factor(Hf, nv, MINVAL);
+    chol_solve(search, Hf, grad, nv);
+    double sn = 0;
+    for (int k = 0; k < nv; k++) { search[k] = -search[k]; sn += search[k] * search[k]; }
+    sn = sqrt(sn);
+    /* line-search preparation ([MJ] CGprepare) */
+    MATVEC_M(Mv, search);
+    for (int i = 0; i < ne; i++) {
+      double s = 0;
+      for (int k = 0; k < nv; k++) s += d->efc_J[(size_t)i * nv + k] * search[k];
+      Jv[i] = s;
+    }
+    ctx.quadGauss[0] = GAUSS(qacc, Ma);
+    ctx.quadGauss[1] = 0; ctx.quadGauss[2] = 0;
+    for (int k = 0; k < nv; k++) { ctx.quadGauss[1] += search[k] * (Ma[k] - d->qfrc_smooth[k]); ctx.quadGauss[2] += 0.5 * search[k] * Mv[k]; }
+    for (int i = 0; i < ne; i++) {
+      double D = d->efc_D[i];
+      quad[3 * i] = 0.5 * D * Jaref[i] * Jaref[i]; quad[3 * i + 1] = D * Jaref[i] * Jv[i]; quad[3 * i + 2] = 0.5 * D * Jv[i] * Jv[i];
+    }
+    for (int c = 0; c < ncon; c++) {
+      contact_t* con = d->contact + c;
+      int i = con->efc_address, dim = con->dim;
+      if (i < 0 || dim < 3) continue;
+      for (int j = 1; j < dim; j++) { quad[3 * i] += quad[3 * (i + j)]; quad[3 * i + 1] += quad[3 * (i + j) + 1]; quad[3 * i + 2] += quad[3 * (i + j) + 2]; }
+      double mu = con->mu, *k = cq + 7 * c;
+      k[0] = Jaref[i] * mu; k[1] = Jv[i] * mu; k[2] = k[3] = k[4] = 0;
+      for (int j = 1; j < dim; j++) {
+        double u = Jaref[i + j] * con->friction[j - 1], v = Jv[i + j] * con->friction[j - 1];
+        k[2] += u * u; k[3] += u * v; k[4] += v * v;
+      }
+      k[5] = d->efc_D[i] / fmax(mu * mu * (1 + mu * mu), MINVAL); k[6] = mu;
+    }
+    int nls;
+    double alpha = ls_search(m, &ctx, sn, &nls);
+    nls_total += nls;
+    iter++;
+    if (alpha == 0) break;
+    for (int k = 0; k < nv; k++) { qacc[k] += alpha * search[k]; Ma[k] += alpha * Mv[k]; }
+    for (int i = 0; i < ne; i++) Jaref[i] += alpha * Jv[i];
+    double newcost = newton_update(m, d, Jaref, ftmp, state2, NULL) + GAUSS(qacc, Ma);
+    double improvement = scale * (cost - newcost);
+    if (improvement < m->tolerance) {
+      newton_update(m, d, Jaref, force, state, NULL);
+      for (int k = 0; k < nv; k++) {
+        double s = 0;
+        for (int i = 0; i < ne; i++) s += d->efc_J[(size_t)i * nv + k] * force[i];
+        d->qfrc_constraint[k] = s;
+      }
+      break;
+    }
+  }
+  d->solver_niter = iter;
+  (void)nls_total;
+  memcpy(d->efc_force, force, sizeof(double) * ne);
+  memcpy(d->qacc, qacc, sizeof(double) * nv);
+  memcpy(d->qacc_warmstart, qacc, sizeof(double) * nv);
+  free(buf); free(state);
+#undef MATVEC_M
+#undef JAREF
+#undef GAUSS
+}
+
 /* ------------------------------------------------------------------ forward */
 void smjo_forward(const smjo_model* m, smjo_data* d) {
   int nv = m->nv;
@@ -1191,7 +1453,8 @@ void smjo_forward(const smjo_model* m, smjo_data* d) {
   for (int k = 0; k < nv; k++)
     d->qfrc_smooth[k] = d->qfrc_passive[k] - d->qfrc_bias[k] + d->qfrc_applied[k] + d->qfrc_actuator[k];
   chol_solve(d->qacc_smooth, d->qL, d->qfrc_smooth, nv);
-  fwd_constraint(m, d);
+  if (m->solver == 2) fwd_constraint_newton(m, d);
+  else fwd_constraint(m, d);
 }
 
 /* ------------------------------------------------------------------ B.8 integrate (implicitfast) */

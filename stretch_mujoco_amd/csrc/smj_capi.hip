@@ -168,6 +168,7 @@ int smj_set_option(smj_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "warmstart")) m.warmstart = (int)v;
   else if (!strcmp(name, "pgs_fixed_iter")) m.pgs_fixed_iter = (int)v;
   else if (!strcmp(name, "max_contacts_per_pair")) m.max_con_pair = (int)v;
+  else if (!strcmp(name, "solver")) m.solver = (int)v;
   else return fail(c, -1, "unknown option '%s'", name);
   return 0;
 }

@@ -37,7 +37,8 @@
 struct DevModel {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, neq, npair, nlevel, nfric, nlimit, nplanepair, nldl, nlidar, imu_site,
       ngc, nroot, nkey, nraygeom;
-  int iterations, warmstart, pgs_fixed_iter, max_con_pair;
+  int iterations, warmstart, pgs_fixed_iter, max_con_pair, solver /* 0 PGS, 2 Newton */, ls_iterations;
+  float ls_tolerance;
   float timestep, gravity[3], impratio, tolerance, meaninertia, lidar_cutoff;
 #define X(n) const int* n;
   SMJ_MODEL_I32(X)

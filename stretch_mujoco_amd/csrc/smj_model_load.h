@@ -63,7 +63,7 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
     const SmjBlobEntry* e = b.find("sensor_lidar_site");
     m.nlidar = e ? (int)(e->nbytes / 4) : 0;
   }
-  m.warmstart = 1; m.pgs_fixed_iter = 0; m.max_con_pair = 4;
+  m.warmstart = 1; m.pgs_fixed_iter = 0; m.max_con_pair = 4; m.solver = 0; m.ls_iterations = 50; m.ls_tolerance = 0.01f;
   char buf[256];
   if (m.nv > NVP || m.nbody > NBP || m.nq > NVP + 8 || m.nu > 16) {
     snprintf(buf, sizeof buf, "model exceeds kernel capacity (nv %d<=%d, nbody %d<=%d, nu %d<=16)", m.nv, NVP, m.nbody, NBP, m.nu);

@@ -27,8 +27,13 @@ struct TreeTmp {  // lives in the A region until A is built
 
 struct Smem {
   union {
-    float A[NEFC * NEFC];
+    float A[NEFC * NEFC];   // PGS: A = J M^-1 J' + R
     TreeTmp t;
+    struct {                // Newton: XA = W J (row-weighted Jacobian) and the Hessian H = M + J' W J / its factor
+      float XA[NEFC][JS];
+      float H[NVP][NVP + 1];
+      float cH[NCON][36];   // cone Hessians of contacts in the middle zone
+    } n;
   } u;
   float J[NEFC][JS];    // constraint Jacobian, transformed in place to Y = J L^-1
   float MM[NVP][MS];    // strict upper: M; lower + diag: working copy -> L (unit, strictly lower), D on diag
@@ -1257,6 +1262,467 @@ struct StepKernel {
     return -change;
   }
 
+
+  // ------------------------------------------------------------------ B.7' Newton solver (primal)
+  // [MJ] mj_solNewton: exact Newton steps on  0.5 (a-a_s)' M (a-a_s) + s(J a - aref)  with H = M + J' W J on the
+  // matrix cores, an in-register Cholesky (lane i owns row i of H) and an exact line search.  This is the solver
+  // the reference model runs (stretch.xml names none -> MuJoCo default Newton); same restatement as the oracle's.
+  struct NRow {            // lane = constraint row
+    PL<int> type, state, c0;          // c0: contact index if this lane is the first row of an elliptic contact, else -1
+    PL<float> aref, D, R, fl, jar, jv, force, q0, q1, q2;
+    PL<float[7]> cq;                  // u0 v0 uu uv vv Dm mu   (first row of an elliptic contact)
+  };
+
+  // constraint forces / states / cost at the residual nr.jar  ([MJ] mj_constraintUpdate).  Returns the cost.
+  SMJ_DEV float newton_update(NRow& nr, bool want_hess) {
+    const int ne = nefc;
+    PL<float> cost;
+    LANES { s.eb[lane] = nr.jar[lane]; }
+    SYNC();
+    LANES {
+      float c = 0, f = 0;
+      int st = 0;
+      const int i = lane, t = nr.type[lane];
+      const float jar = nr.jar[lane], D = nr.D[lane], R = nr.R[lane];
+      if (i < ne) {
+        if (t == CT_EQUALITY) { f = -D * jar; st = 1; c = 0.5f * D * jar * jar; }
+        else if (t == CT_FRICTION) {
+          const float fl = nr.fl[lane];
+          if (jar <= -R * fl) { f = fl; st = 2; c = -fl * (0.5f * R * fl + jar); }
+          else if (jar >= R * fl) { f = -fl; st = 3; c = -fl * (0.5f * R * fl - jar); }
+          else { f = -D * jar; st = 1; c = 0.5f * D * jar * jar; }
+        } else if (t == CT_LIMIT || t == CT_CONTACT_FRICTIONLESS) {
+          if (jar < 0) { f = -D * jar; st = 1; c = 0.5f * D * jar * jar; }
+        }
+      }
+      nr.force[lane] = f; nr.state[lane] = st; cost[lane] = c;
+      s.ef[lane] = f;
+    }
+    SYNC();
+    // elliptic contacts: the lane of the contact's first row handles the block
+    LANES {
+      const int c = nr.c0[lane];
+      if (c >= 0) {
+        const int i = lane, dim = s.cdim[c];
+        const float mu = nr.cq[lane][6];
+        float U[6], jr[6], T = 0;
+        for (int j = 0; j < dim; j++) jr[j] = s.eb[i + j];
+        U[0] = jr[0] * mu;
+        for (int j = 1; j < dim; j++) { U[j] = jr[j] * s.cfric[c][j - 1]; T += U[j] * U[j]; }
+        const float N = U[0];
+        T = sqrtf(T);
+        int st;
+        float cc = 0;
+        if (N >= mu * T || (T <= 0 && N >= 0)) { st = 0; for (int j = 0; j < dim; j++) s.ef[i + j] = 0; }
+        else if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+          st = 1;
+          for (int j = 0; j < dim; j++) { const float Dj = 1.0f / s.eR[i + j]; s.ef[i + j] = -Dj * jr[j]; cc += 0.5f * Dj * jr[j] * jr[j]; }
+        } else {
+          st = 4;
+          const float Dm = nr.cq[lane][5], NT = N - mu * T, Ti = 1.0f / T;
+          cc = 0.5f * Dm * NT * NT;
+          const float fn = -Dm * NT * mu;
+          s.ef[i] = fn;
+          for (int j = 1; j < dim; j++) s.ef[i + j] = -fn * Ti * U[j] * s.cfric[c][j - 1];
+          if (want_hess) {
+            float S[6];
+            S[0] = mu;
+            for (int j = 1; j < dim; j++) S[j] = s.cfric[c][j - 1];
+            float* H = s.u.n.cH[c];
+            const float a = mu * N * Ti * Ti * Ti, b = mu * NT * Ti;
+            H[0] = Dm * S[0] * S[0];
+            for (int j = 1; j < dim; j++) H[j] = H[j * dim] = -mu * U[j] * Ti * Dm * S[0] * S[j];
+            for (int j = 1; j < dim; j++)
+              for (int k = 1; k < dim; k++) H[j * dim + k] = (a * U[j] * U[k] - (j == k ? b : 0.f)) * Dm * S[j] * S[k];
+          }
+        }
+        cost[lane] += cc;
+        for (int j = 0; j < dim; j++) s.earef[i + j] = (float)st;  // block state broadcast through LDS
+      }
+    }
+    SYNC();
+    LANES {
+      if (nr.type[lane] == CT_CONTACT_ELLIPTIC && lane < ne) { nr.force[lane] = s.ef[lane]; nr.state[lane] = (int)s.earef[lane]; }
+    }
+    return wave_sum(cost);
+  }
+
+  // y = M x for lane-resident x (lane = dof); M = strict upper of MM + Mdiag (lower part holds the L'DL factor)
+  SMJ_DEV void mat_M(PL<float>& y, const PL<float>& x) {
+    const int nv = M.nv;
+    LANES { y[lane] = lane < nv ? s.Mdiag[lane] * x[lane] : 0.f; }
+    for (int j = 0; j < nv; j++) {
+      const float xj = wave_read(x, j);
+      LANES {
+        if (lane < nv && lane != j) y[lane] += (lane > j ? s.MM[j][lane] : s.MM[lane][j]) * xj;
+      }
+    }
+  }
+  // out[row] = J[row] . x - sub[row] evaluated with error-free transformations (TwoProduct / TwoSum: ~fp64
+  // accuracy from fp32 operations).  The primal residual jar = J qacc - aref cancels to |R f| << |aref|, and the
+  // constraint force is D * jar with D = 1/R up to 1e4: a plain fp32 dot product would put 1e-3 noise on the
+  // forces.  Only the starting residual needs this; the Newton loop then updates jar incrementally.
+  SMJ_DEV void mat_J_exact(PL<float>& out, const PL<float>& x, const PL<float>& sub) {
+    const int nv = M.nv;
+    PL<float> hi, lo;
+    LANES { hi[lane] = -sub[lane]; lo[lane] = 0.f; }
+    for (int k = 0; k < nv; k++) {
+      const float xk = wave_read(x, k);
+      LANES {
+        const float a = s.J[lane][k];
+        const float p = a * xk, pe = fmaf(a, xk, -p);          // p + pe = a*xk exactly
+        const float t = hi[lane] + p, z = t - hi[lane];
+        const float se = (hi[lane] - (t - z)) + (p - z);        // hi + p = t + se exactly
+        hi[lane] = t;
+        lo[lane] += se + pe;
+      }
+    }
+    LANES { out[lane] = hi[lane] + lo[lane]; }
+  }
+  // out[row] = J[row] . x   (lane = row, x lane-resident over dofs)
+  SMJ_DEV void mat_J(PL<float>& out, const PL<float>& x) {
+    const int nv = M.nv;
+    LANES { out[lane] = 0.f; }
+    for (int k = 0; k < nv; k++) {
+      const float xk = wave_read(x, k);
+      LANES { out[lane] += s.J[lane][k] * xk; }
+    }
+  }
+
+  // cost and derivatives along the search line  ([MJ] CGeval); lanes = rows, three wave reductions
+  SMJ_DEV float ls_eval(const NRow& nr, const float* qg, float a, float& d1, float& d2) {
+    const int ne = nefc;
+    PL<float> p0, p1, p2;
+    LANES {
+      float c0 = 0, c1 = 0, c2 = 0;
+      if (lane < ne) {
+        const int t = nr.type[lane];
+        const float x = nr.jar[lane] + a * nr.jv[lane];
+        if (t == CT_EQUALITY) { c0 = nr.q0[lane]; c1 = nr.q1[lane]; c2 = nr.q2[lane]; }
+        else if (t == CT_FRICTION) {
+          const float fl = nr.fl[lane], rf = nr.R[lane] * fl;
+          if (x <= -rf) { c0 = fl * (-0.5f * rf - nr.jar[lane]); c1 = -fl * nr.jv[lane]; }
+          else if (x >= rf) { c0 = fl * (-0.5f * rf + nr.jar[lane]); c1 = fl * nr.jv[lane]; }
+          else { c0 = nr.q0[lane]; c1 = nr.q1[lane]; c2 = nr.q2[lane]; }
+        } else if (t == CT_LIMIT || t == CT_CONTACT_FRICTIONLESS) {
+          if (x < 0) { c0 = nr.q0[lane]; c1 = nr.q1[lane]; c2 = nr.q2[lane]; }
+        } else if (nr.c0[lane] >= 0) {
+          const float* k = nr.cq[lane];
+          const float mu = k[6], Dm = k[5], N = k[0] + a * k[1], Tsq = k[2] + a * (2 * k[3] + a * k[4]);
+          if (Tsq <= 0) { if (N < 0) { c0 = nr.q0[lane]; c1 = nr.q1[lane]; c2 = nr.q2[lane]; } }
+          else {
+            const float T = sqrtf(Tsq);
+            if (N >= mu * T) {}
+            else if (mu * N + T <= 0) { c0 = nr.q0[lane]; c1 = nr.q1[lane]; c2 = nr.q2[lane]; }
+            else {
+              const float Ti = 1.0f / T, w = k[3] + a * k[4], N1 = k[1], T1 = w * Ti, T2 = k[4] * Ti - w * w * Ti * Ti * Ti;
+              const float NT = N - mu * T, NT1 = N1 - mu * T1;
+              // encode the non-quadratic cone piece so that the caller's quadratic formula reproduces it at this alpha:
+              // value v, slope g, curvature h  ->  c2 = h/2, c1 = g - h a, c0 = v - a g + h a a / 2
+              const float v = 0.5f * Dm * NT * NT, g = Dm * NT * NT1, h = Dm * (NT1 * NT1 - NT * mu * T2);
+              c2 = 0.5f * h; c1 = g - h * a; c0 = v - a * g + 0.5f * h * a * a;
+            }
+          }
+        }
+      }
+      p0[lane] = c0; p1[lane] = c1; p2[lane] = c2;
+    }
+    const float q0 = qg[0] + wave_sum(p0), q1 = qg[1] + wave_sum(p1), q2 = qg[2] + wave_sum(p2);
+    d1 = 2 * a * q2 + q1;
+    d2 = 2 * q2;
+    return a * a * q2 + a * q1 + q0;
+  }
+
+  SMJ_DEV void solve_newton(bool dbg, float* pc, long long& t0, bool prof) {
+#define TICK(slot) if (prof) { const long long t1 = smj_clock(); pc[slot] += (float)(t1 - t0); t0 = t1; }
+    const int nv = M.nv, ne = nefc;
+    NRow nr;
+    PL<float> qacc, qs, Ma, Mv, grad, search, tmpv;
+    // qacc_smooth = M^-1 g
+    LANES { qs[lane] = lane < nv ? g_r[lane] : 0.f; }
+    solve_LT(qs);
+    LANES { if (lane < nv) qs[lane] *= s.Dinv[lane]; }
+    solve_L(qs);
+    if (ne == 0) {
+      LANES {
+        qacc_r[lane] = qs[lane];
+        if (lane < nv) { s.qacc[lane] = qs[lane]; s.warm[lane] = qs[lane]; s.tmp[lane] = g_r[lane]; }
+      }
+      niter = 0;
+      SYNC();
+      return;
+    }
+    // per-row constants, efc_vel, aref
+    LANES {
+      float vel = 0;
+      const bool on = lane < ne;
+      if (on)
+        for (int k = 0; k < nv; k++) vel += s.J[lane][k] * s.qvel[k];
+      nr.type[lane] = on ? s.etype[lane] : CT_NONE;
+      nr.R[lane] = on ? s.eR[lane] : 1.f;
+      nr.D[lane] = on ? 1.0f / s.eR[lane] : 0.f;
+      nr.fl[lane] = on ? s.efloss[lane] : 0.f;
+      nr.aref[lane] = on ? -s.eBv[lane] * vel - s.eK[lane] * s.eimp[lane] * (s.epos[lane] - s.emargin[lane]) : 0.f;
+      int c0 = -1;
+      if (on && s.etype[lane] == CT_CONTACT_ELLIPTIC && s.cefc[s.eid[lane]] == lane) c0 = s.eid[lane];
+      nr.c0[lane] = c0;
+      for (int k = 0; k < 7; k++) nr.cq[lane][k] = 0.f;
+      if (c0 >= 0) {
+        const float mu = contact_mu(c0);
+        nr.cq[lane][6] = mu;
+        nr.cq[lane][5] = (1.0f / s.eR[lane]) / fmaxf(mu * mu * (1 + mu * mu), SMJ_MINVAL);
+      }
+      if (dbg) s.earef[lane] = nr.aref[lane];
+    }
+    const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
+    // warm start: the cheaper of qacc_warmstart and qacc_smooth  ([MJ] mj_warmstart, primal branch)
+    LANES { qacc[lane] = lane < nv ? (M.warmstart ? s.warm[lane] : qs[lane]) : 0.f; }
+    mat_M(Ma, qacc);
+    mat_J_exact(nr.jar, qacc, nr.aref);
+    float cost = newton_update(nr, false);
+    {
+      PL<float> gs;
+      LANES { gs[lane] = lane < nv ? 0.5f * (Ma[lane] - g_r[lane]) * (qacc[lane] - qs[lane]) : 0.f; }
+      cost += wave_sum(gs);
+    }
+    if (M.warmstart) {
+      PL<float> keep;
+      LANES { keep[lane] = nr.jar[lane]; }
+      mat_J_exact(nr.jar, qs, nr.aref);
+      const float cs = newton_update(nr, false);
+      if (cs < cost) {
+        LANES { qacc[lane] = qs[lane]; }
+        mat_M(Ma, qacc);
+      } else {
+        LANES { nr.jar[lane] = keep[lane]; }
+      }
+    }
+    TICK(SMJ_PROF_WARM)
+    int iter = 0;
+    for (; iter < M.iterations;) {
+      cost = newton_update(nr, true);
+      float gauss;
+      {
+        PL<float> gs;
+        LANES { gs[lane] = lane < nv ? 0.5f * (Ma[lane] - g_r[lane]) * (qacc[lane] - qs[lane]) : 0.f; }
+        gauss = wave_sum(gs);
+      }
+      cost += gauss;
+      // gradient = Ma - g - J'f   (lanes = dofs; force broadcast by readlane)
+      LANES { tmpv[lane] = 0.f; }
+      for (int r = 0; r < ne; r++) {
+        const float fr = wave_read(nr.force, r);
+        LANES { if (lane < nv) tmpv[lane] += s.J[r][lane] * fr; }
+      }
+      PL<float> g2;
+      LANES { grad[lane] = lane < nv ? Ma[lane] - g_r[lane] - tmpv[lane] : 0.f; g2[lane] = grad[lane] * grad[lane]; }
+      const float gnorm = sqrtf(wave_sum(g2));
+      if (iter > 0 && scale * gnorm < M.tolerance) break;
+      // XA = W J : quadratic rows D*J, cone rows Hc*Jc, others 0   (lanes = dofs, uniform loop over rows)
+      for (int r = 0; r < ne;) {
+        const int t = wave_read(nr.type, r), st = wave_read(nr.state, r);
+        if (t == CT_CONTACT_ELLIPTIC) {
+          const int c = uni(s.eid[r]), dim = uni(s.cdim[c]);
+          if (st == 4) {
+            LANES {
+              if (lane < NVP) {
+                float jc[6];
+                for (int q = 0; q < dim; q++) jc[q] = s.J[r + q][lane];
+                for (int rr = 0; rr < dim; rr++) {
+                  float v = 0;
+                  for (int q = 0; q < dim; q++) v += s.u.n.cH[c][rr * dim + q] * jc[q];
+                  s.u.n.XA[r + rr][lane] = v;
+                }
+              }
+            }
+          } else {
+            LANES {
+              if (lane < NVP)
+                for (int rr = 0; rr < dim; rr++) s.u.n.XA[r + rr][lane] = st == 1 ? s.J[r + rr][lane] / s.eR[r + rr] : 0.f;
+            }
+          }
+          r += dim;
+        } else {
+          const float w = st == 1 ? wave_read(nr.D, r) : 0.f;
+          LANES { if (lane < NVP) s.u.n.XA[r][lane] = w * s.J[r][lane]; }
+          r += 1;
+        }
+      }
+      SYNC();
+      // H = M + XA' J on the matrix cores: 2x2 tiles of 16x16 over dofs, K = constraint rows
+      {
+        const int ksteps = (ne + 3) >> 2;
+        for (int ta = 0; ta < 2; ta++)
+          for (int tb = 0; tb <= ta; tb++) {
+            PL<F4v> acc;
+            LANES { for (int r = 0; r < 4; r++) acc[lane].r[r] = 0.f; }
+            for (int ks = 0; ks < ksteps; ks++) {
+              PL<float> a, b;
+              LANES {
+                const int k = 4 * ks + (lane >> 4);
+                a[lane] = k < ne ? s.u.n.XA[k][16 * ta + (lane & 15)] : 0.f;
+                b[lane] = k < ne ? s.J[k][16 * tb + (lane & 15)] : 0.f;
+              }
+              mfma16x16x4(acc, a, b);
+            }
+            LANES {
+              for (int r = 0; r < 4; r++) {
+                const int row = 16 * ta + (lane >> 4) * 4 + r, col = 16 * tb + (lane & 15);
+                float v = acc[lane].r[r];
+                if (row < nv && col < nv) v += row == col ? s.Mdiag[row] : (row < col ? s.MM[row][col] : s.MM[col][row]);
+                else v = row == col ? 1.f : 0.f;
+                s.u.n.H[row][col] = v;
+                if (ta != tb) s.u.n.H[col][row] = v;
+              }
+            }
+          }
+      }
+      SYNC();
+      // Cholesky H = L L' with lane i owning row i in registers; L rows then go back to LDS for the L' solve
+      PL<float[NVP]> hrow;
+      PL<float> dinv;
+      LANES {
+        const int i = lane < NVP ? lane : 0;
+#pragma unroll
+        for (int k = 0; k < NVP; k++) hrow[lane][k] = (lane < NVP) ? s.u.n.H[i][k] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < NVP; k++) {
+        PL<float> col;
+        LANES { col[lane] = hrow[lane][k]; }
+        const float d = fmaxf(wave_read(col, k), 1e-30f), inv = fast_rsqrt(d);
+        LANES {
+          col[lane] = col[lane] * inv;   // L[i][k] for i >= k (lane k: sqrt(d))
+          hrow[lane][k] = col[lane];
+          if (lane == k) dinv[lane] = inv;
+        }
+#pragma unroll
+        for (int j = k + 1; j < NVP; j++) {
+          const float ljk = wave_read(col, j);
+          LANES { if (lane >= j) hrow[lane][j] -= col[lane] * ljk; }
+        }
+      }
+      LANES {
+        if (lane < NVP) {
+#pragma unroll
+          for (int k = 0; k < NVP; k++) s.u.n.H[lane][k] = hrow[lane][k];
+        }
+      }
+      SYNC();
+      // search = -H^-1 grad : forward with register rows, backward with LDS rows
+      LANES { search[lane] = lane < nv ? grad[lane] : 0.f; }
+#pragma unroll
+      for (int k = 0; k < NVP; k++) {
+        const float xk = wave_read(search, k) * wave_read(dinv, k);
+        LANES {
+          if (lane == k) search[lane] = xk;
+          else if (lane > k && lane < NVP) search[lane] -= hrow[lane][k] * xk;
+        }
+      }
+      for (int k = NVP - 1; k >= 0; k--) {
+        const float xk = wave_read(search, k) * wave_read(dinv, k);
+        LANES {
+          if (lane == k) search[lane] = xk;
+          else if (lane < k) search[lane] -= s.u.n.H[k][lane] * xk;
+        }
+      }
+      PL<float> sq;
+      LANES { search[lane] = lane < nv ? -search[lane] : 0.f; sq[lane] = search[lane] * search[lane]; }
+      const float snorm = sqrtf(wave_sum(sq));
+      // line-search preparation  ([MJ] CGprepare)
+      mat_M(Mv, search);
+      mat_J(nr.jv, search);
+      float qg[3];
+      {
+        PL<float> a1, a2;
+        LANES {
+          a1[lane] = lane < nv ? search[lane] * (Ma[lane] - g_r[lane]) : 0.f;
+          a2[lane] = lane < nv ? 0.5f * search[lane] * Mv[lane] : 0.f;
+        }
+        qg[0] = gauss; qg[1] = wave_sum(a1); qg[2] = wave_sum(a2);
+      }
+      LANES {
+        const float D = nr.D[lane], ja = nr.jar[lane], jv = nr.jv[lane];
+        nr.q0[lane] = 0.5f * D * ja * ja; nr.q1[lane] = D * ja * jv; nr.q2[lane] = 0.5f * D * jv * jv;
+        s.eb[lane] = ja; s.ef[lane] = jv; s.earef[lane] = nr.q0[lane]; s.eK[lane] = nr.q1[lane]; s.eBv[lane] = nr.q2[lane];
+      }
+      SYNC();
+      LANES {
+        const int c = nr.c0[lane];
+        if (c >= 0) {
+          const int i = lane, dim = s.cdim[c];
+          float a0 = 0, a1 = 0, a2 = 0, uu = 0, uv = 0, vv = 0;
+          for (int j = 1; j < dim; j++) {
+            a0 += s.earef[i + j]; a1 += s.eK[i + j]; a2 += s.eBv[i + j];
+            const float fr = s.cfric[c][j - 1], u = s.eb[i + j] * fr, v = s.ef[i + j] * fr;
+            uu += u * u; uv += u * v; vv += v * v;
+          }
+          nr.q0[lane] += a0; nr.q1[lane] += a1; nr.q2[lane] += a2;
+          const float mu = nr.cq[lane][6];
+          nr.cq[lane][0] = nr.jar[lane] * mu; nr.cq[lane][1] = nr.jv[lane] * mu;
+          nr.cq[lane][2] = uu; nr.cq[lane][3] = uv; nr.cq[lane][4] = vv;
+        }
+      }
+      // exact line search: safeguarded Newton on the directional derivative (same scheme as the oracle's ls_search).
+      // fp32 note: acceptance and the improvement estimate use derivatives, not cost differences -- near the optimum
+      // the decrease is far below one ulp of the cost.
+      float alpha = 0, d10 = 0;
+      {
+        const float gtol = M.tolerance * M.ls_tolerance * snorm * M.meaninertia * (float)(nv > 1 ? nv : 1);
+        float d1, d2, lo = 0, hi = -1;
+        ls_eval(nr, qg, 0.f, d1, d2);
+        d10 = d1;
+        float bestd = fabsf(d1), a = 0;
+        if (d1 < 0 && d2 > 0) {
+          a = -d1 / d2;
+          for (int it = 0; it < M.ls_iterations; it++) {
+            ls_eval(nr, qg, a, d1, d2);
+            if (fabsf(d1) < bestd) { bestd = fabsf(d1); alpha = a; }
+            if (fabsf(d1) < gtol) break;
+            if (d1 < 0) lo = a; else hi = a;
+            float an = (d2 > 0) ? a - d1 / d2 : -1.f;
+            if (hi < 0) { if (an <= lo) an = 2 * a + 1e-12f; }
+            else if (!(an > lo && an < hi)) an = 0.5f * (lo + hi);
+            if (hi >= 0 && hi - lo < 1e-6f * fmaxf(1.f, hi)) break;
+            if (fabsf(an - a) <= 1e-7f * fabsf(a)) break;
+            a = an;
+          }
+        }
+      }
+      iter++;
+      if (alpha == 0.f) break;
+      LANES {
+        qacc[lane] += alpha * search[lane]; Ma[lane] += alpha * Mv[lane];
+        nr.jar[lane] += alpha * nr.jv[lane];
+      }
+      // decrease of the cost along the accepted step, from the slope at 0 (exact for the quadratic pieces)
+      if (scale * (-0.5f * alpha * d10) < M.tolerance) break;
+    }
+    niter = iter;
+    TICK(SMJ_PROF_PGS)
+    // final forces at the accepted point, qfrc_constraint = J' f
+    newton_update(nr, false);
+    LANES { tmpv[lane] = 0.f; }
+    for (int r = 0; r < ne; r++) {
+      const float fr = wave_read(nr.force, r);
+      LANES { if (lane < nv) tmpv[lane] += s.J[r][lane] * fr; }
+    }
+    LANES {
+      qacc_r[lane] = lane < nv ? qacc[lane] : 0.f;
+      if (lane < nv) { s.qacc[lane] = qacc[lane]; s.warm[lane] = qacc[lane]; s.tmp[lane] = g_r[lane] + tmpv[lane]; }
+    }
+    SYNC();
+    if (dbg && S.debug) {
+      LANES {
+        if (lane < nv) S.debug[(SMJ_DBG_QACC + lane) * S.ld + env] = qacc[lane];
+        S.debug[(SMJ_DBG_EFC_FORCE + lane) * S.ld + env] = lane < ne ? nr.force[lane] : 0.f;
+        S.debug[(SMJ_DBG_EFC_R + lane) * S.ld + env] = lane < ne ? nr.R[lane] : 0.f;
+        S.debug[(SMJ_DBG_EFC_AREF + lane) * S.ld + env] = lane < ne ? nr.aref[lane] : 0.f;
+      }
+    }
+#undef TICK
+  }
+
   // ------------------------------------------------------------------ B.8 implicitfast integrate
   SMJ_DEV void integrate() {
     const int nv = M.nv, nu = M.nu;
@@ -1513,7 +1979,8 @@ struct StepKernel {
       TICK(SMJ_PROF_COLLISION)
       make_constraint();
       TICK(SMJ_PROF_MAKECON)
-      solve(last, pc, t0, prof);
+      if (M.solver == 2) solve_newton(last, pc, t0, prof);
+      else solve(last, pc, t0, prof);
       if (last && want_imu) imu();
       TICK(SMJ_PROF_POST)
       integrate();

@@ -43,7 +43,7 @@ class StretchBatchSimulator:
     def __init__(self, num_envs: int = 1, device: str = "cuda:0", scene: str = "stretch_empty",
                  model_blob_bytes: Optional[bytes] = None, sensors_to_use: Sequence[StretchSensors] = (),
                  cameras_to_use: Sequence[StretchCameras] = (), start_translation=None, start_rotation_quat=None,
-                 debug: bool = False):
+                 debug: bool = False, solver: str = "newton"):
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
         if model_blob_bytes is None:
@@ -58,6 +58,9 @@ class StretchBatchSimulator:
         self._start_translation = start_translation
         self._start_rotation_quat = start_rotation_quat
         self._debug = debug
+        if solver not in ("pgs", "newton"):
+            raise ValueError("solver must be 'pgs' (north_star) or 'newton' (the reference model's default)")
+        self.solver = solver
         self._ctx = None
         self._L = None
         self.timestep = float(self.model["opt_timestep"][0])
@@ -108,6 +111,7 @@ class StretchBatchSimulator:
             _lib.check(L, ctx, L.smj_bind(ctx, S[name], ctypes.c_void_p(t.data_ptr()), B), f"smj_bind({name})")
         key_ctrl = torch.tensor(np.asarray(self.model["key_ctrl"], np.float32)[:, : self.nu])
         self.glue = Glue(B, self.nu, key_ctrl, self.names["key"], self.device)
+        self.set_option("solver", {"pgs": 0, "newton": 2}[self.solver])
         self._read_flags = 0
         if StretchSensors.base_gyro in self._sensors or StretchSensors.base_accel in self._sensors:
             self._read_flags |= _lib.READ_IMU
@@ -131,6 +135,10 @@ class StretchBatchSimulator:
             self.stop()
         except Exception:
             pass
+
+    def set_option(self, name: str, value: float) -> None:
+        """mjOption-style knobs: iterations, tolerance, warmstart, pgs_fixed_iter, max_contacts_per_pair, solver."""
+        _lib.check(self._L, self._ctx, self._L.smj_set_option(self._ctx, name.encode(), float(value)), f"smj_set_option({name})")
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

@@ -107,3 +107,49 @@ def test_lidar_sees_a_wall(blob_fused):
     L = e.lidar[:, 0]
     np.testing.assert_allclose(L, o.arr("lidar"), atol=1e-4)
     assert (L > 0).sum() > 50 and (L == -1).sum() > 50 and L.max() <= 10.0
+
+
+# ---------------------------------------------------------------------------------------------- Newton solver
+def _pair_newton(blob, ctrl):
+    o, e = _pair(blob, ctrl)
+    o.set_option("solver", 2); e.set_option("solver", 2)
+    return o, e
+
+
+@pytest.mark.parametrize("ctrl", [HOME_CTRL, MIX_CTRL])
+def test_newton_trajectory_from_reset(blob_fused, ctrl):
+    """Newton (the reference model's own solver) converges to the unique optimum every step, so fp32 tracks fp64
+    through the reset transient as well: 1e-5 over 1000 steps from reset (PGS needs a settled start for 1e-4)."""
+    o, e = _pair_newton(blob_fused, ctrl)
+    for _ in range(10):
+        o.step(100); e.step(100)
+        assert np.abs(e.qpos[:, 0] - o.arr("qpos")).max() < 1e-5
+        assert abs(int(e.info[2, 0]) - int(o.iarr("solver_niter")[0])) <= 2
+    assert e.info[3, 0] == 0
+
+
+def test_newton_and_pgs_agree_on_the_optimum(blob_fused):
+    """Same convex problem: a tightly converged PGS and Newton give the same acceleration (oracle, fp64)."""
+    a, b = Oracle(blob_fused), Oracle(blob_fused)
+    a.set_option("iterations", 3000); a.set_option("tolerance", 1e-15)
+    b.set_option("solver", 2)
+    for o in (a, b):
+        o.arr("ctrl")[:] = MIX_CTRL
+    a.step(300)
+    for name in ("qpos", "qvel", "qacc_warmstart"):
+        b.arr(name)[:] = a.arr(name)
+    a.forward(); b.forward()
+    assert np.abs(a.arr("qacc") - b.arr("qacc")).max() < 1e-5 * max(1.0, np.abs(a.arr("qacc")).max())
+    assert int(b.iarr("solver_niter")[0]) <= 4
+
+
+def test_newton_single_step_forces(blob_fused):
+    o, e = _pair_newton(blob_fused, MIX_CTRL)
+    o.step(200)
+    e.qpos[:, 0] = o.arr("qpos"); e.qvel[:, 0] = o.arr("qvel"); e.warm[:, 0] = o.arr("qacc_warmstart")
+    o.forward(); e.step(1)
+    ne = o.nefc
+    assert e.info[0, 0] == ne
+    f = o.arr("efc_force")
+    assert np.abs(e.debug[1088:1088 + ne, 0] - f).max() < 2e-3 * max(1.0, np.abs(f).max())
+    assert np.abs(e.debug[1056:1082, 0] - o.arr("qacc")).max() < 1e-3 * max(1.0, np.abs(o.arr("qacc")).max())

@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 def _sim(B, **kw):
     from stretch_mujoco_amd import StretchBatchSimulator
 
+    kw.setdefault("solver", "pgs")
     sim = StretchBatchSimulator(num_envs=B, device="cuda:0", **kw)
     sim.start(home=False)
     return sim
@@ -77,6 +78,24 @@ def test_qpos_drift_1000_steps(ctrl):
     assert worst < 1e-4, worst
     assert int(sim.info[3].max()) == 0
     assert float((sim.qpos - sim.qpos[:, :1]).abs().max()) == 0.0   # identical envs stay bitwise identical
+    sim.stop()
+
+
+@pytest.mark.parametrize("ctrl", [HOME_CTRL, MIX_CTRL])
+def test_newton_qpos_drift_1000_steps_from_reset(ctrl):
+    """Newton solver (what CPU MuJoCo runs for this model): fp32 HIP vs fp64 oracle, from reset, 1000 steps."""
+    sim = _sim(4, solver="newton")
+    _set_ctrl(sim, ctrl)
+    o = Oracle(sim._blob)
+    o.set_option("solver", 2)
+    o.arr("ctrl")[:] = ctrl
+    worst = 0.0
+    for _ in range(10):
+        o.step(100); sim.step(100)
+        torch.cuda.synchronize()
+        worst = max(worst, float(np.abs(sim.qpos[:, 0].cpu().numpy() - o.arr("qpos")).max()))
+    assert worst < 2e-5, worst
+    assert int(sim.info[3].max()) == 0 and int(sim.info[2].max()) <= 6
     sim.stop()
 
 
@@ -171,12 +190,12 @@ def test_capacity_overflow_is_flagged():
     sim.stop()
 
 
-@pytest.mark.parametrize("B", [1024, 4096])
-def test_full_batch_properties(B):
+@pytest.mark.parametrize("B,solver", [(1024, "pgs"), (4096, "newton")])
+def test_full_batch_properties(B, solver):
     """BASELINE.json sizes.  Size-independent properties: (1) envs are independent -- a permutation of the inputs
     permutes the outputs bitwise; (2) unit quaternion; (3) equality constraints hold (arm segments equal,
     fingers follow the slider x10); (4) joint limits respected; (5) no capacity overflow flags."""
-    sim = _sim(B)
+    sim = _sim(B, solver=solver)
     g = torch.Generator(device=sim.device).manual_seed(7)
     lo = torch.tensor(sim.model["actuator_ctrlrange"][:, 0], dtype=torch.float32, device=sim.device).unsqueeze(1)
     hi = torch.tensor(sim.model["actuator_ctrlrange"][:, 1], dtype=torch.float32, device=sim.device).unsqueeze(1)
@@ -188,7 +207,7 @@ def test_full_batch_properties(B):
     torch.cuda.synchronize()
     q = sim.qpos.clone()
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).to(sim.device)
-    sim2 = _sim(B)
+    sim2 = _sim(B, solver=solver)
     sim2.ctrl.copy_(ctrl[:, perm])
     sim2.step(300)
     torch.cuda.synchronize()

@@ -37,8 +37,8 @@ def stage_parity(nsteps=1):
     print("env-to-env max diff (identical inputs):", ident)
     sim.stop()
 
-def profile(B, random_ctrl, steps=50):
-    sim = StretchBatchSimulator(num_envs=B, device="cuda:0", debug=True)
+def profile(B, random_ctrl, steps=50, solver="pgs"):
+    sim = StretchBatchSimulator(num_envs=B, device="cuda:0", debug=True, solver=solver)
     sim.start(home=False)
     dev = sim.device
     sim.ctrl[:] = torch.tensor(sim.model["key_ctrl"][0, :10], dtype=torch.float32, device=dev).unsqueeze(1)
@@ -55,7 +55,7 @@ def profile(B, random_ctrl, steps=50):
     ms = e0.elapsed_time(e1)
     p = sim.prof.cpu().numpy() / steps
     info = sim.info.cpu().numpy()
-    print(f"B={B} random={random_ctrl}: launch {ms:.2f} ms for {steps} steps -> {B*steps/ms*1e3:.0f} env-steps/s; nefc mean {info[0].mean():.1f} max {info[0].max()}, ncon mean {info[1].mean():.1f}, flags {np.bitwise_or.reduce(info[3])}")
+    print(f"[{solver}] B={B} random={random_ctrl}: launch {ms:.2f} ms for {steps} steps -> {B*steps/ms*1e3:.0f} env-steps/s; nefc mean {info[0].mean():.1f} max {info[0].max()}, ncon mean {info[1].mean():.1f}, flags {np.bitwise_or.reduce(info[3])}")
     print("  cycles/step (mean over envs):", {n: int(p[i].mean()) for i, n in enumerate(PROF)})
     print("  cycles/step (max over envs): ", {n: int(p[i].max()) for i, n in enumerate(PROF)})
     sim.stop()
@@ -63,7 +63,15 @@ def profile(B, random_ctrl, steps=50):
 if __name__ == "__main__":
     stage_parity(1)
     stage_parity(20)
-    profile(256, False)
-    profile(1024, False)
-    profile(1024, True)
-    profile(4096, True)
+    for solver in ("pgs", "newton"):
+        profile(1024, False, solver=solver)
+        profile(1024, True, solver=solver)
+        profile(4096, True, solver=solver)
+    # Newton parity on the GPU vs the fp64 Newton oracle, from reset
+    sim = StretchBatchSimulator(num_envs=2, device="cuda:0", solver="newton"); sim.start(home=False)
+    ctrl = np.array([2, -1, 0.6, 0.1, 1, -0.4, 0.5, 0.02, 0.3, -0.2], np.float32)
+    sim.ctrl[:] = torch.tensor(ctrl, device=sim.device).unsqueeze(1)
+    o = Oracle(sim._blob); o.set_option("solver", 2); o.arr("ctrl")[:] = ctrl
+    for k in range(10):
+        o.step(100); sim.step(100); torch.cuda.synchronize()
+        print("newton gpu-vs-oracle step", (k + 1) * 100, "max|dq| = %.2e" % np.abs(sim.qpos[:, 0].cpu().numpy() - o.arr("qpos")).max(), "iters", int(sim.info[2, 0]), int(o.iarr("solver_niter")[0]))
