@@ -1500,6 +1500,7 @@ struct StepKernel {
     TICK(SMJ_PROF_WARM)
     int iter = 0;
     for (; iter < M.iterations;) {
+      TICK(SMJ_PROF_PGS)
       cost = newton_update(nr, true);
       float gauss;
       {
@@ -1508,6 +1509,7 @@ struct StepKernel {
         gauss = wave_sum(gs);
       }
       cost += gauss;
+      TICK(SMJ_PROF_N_UPDATE)
       // gradient = Ma - g - J'f   (lanes = dofs; force broadcast by readlane)
       LANES { tmpv[lane] = 0.f; }
       for (int r = 0; r < ne; r++) {
@@ -1518,6 +1520,7 @@ struct StepKernel {
       LANES { grad[lane] = lane < nv ? Ma[lane] - g_r[lane] - tmpv[lane] : 0.f; g2[lane] = grad[lane] * grad[lane]; }
       const float gnorm = sqrtf(wave_sum(g2));
       if (iter > 0 && scale * gnorm < M.tolerance) break;
+      TICK(SMJ_PROF_N_GRAD)
       // XA = W J : quadratic rows D*J, cone rows Hc*Jc, others 0   (lanes = dofs, uniform loop over rows)
       for (int r = 0; r < ne;) {
         const int t = wave_read(nr.type, r), st = wave_read(nr.state, r);
@@ -1549,6 +1552,7 @@ struct StepKernel {
         }
       }
       SYNC();
+      TICK(SMJ_PROF_N_XA)
       // H = M + XA' J on the matrix cores: 2x2 tiles of 16x16 over dofs, K = constraint rows
       {
         const int ksteps = (ne + 3) >> 2;
@@ -1578,6 +1582,7 @@ struct StepKernel {
           }
       }
       SYNC();
+      TICK(SMJ_PROF_N_HMFMA)
       // Cholesky H = L L' with lane i owning row i in registers; L rows then go back to LDS for the L' solve
       PL<float[NVP]> hrow;
       PL<float> dinv;
@@ -1609,6 +1614,7 @@ struct StepKernel {
         }
       }
       SYNC();
+      TICK(SMJ_PROF_N_CHOL)
       // search = -H^-1 grad : forward with register rows, backward with LDS rows
       LANES { search[lane] = lane < nv ? grad[lane] : 0.f; }
 #pragma unroll
@@ -1629,6 +1635,7 @@ struct StepKernel {
       PL<float> sq;
       LANES { search[lane] = lane < nv ? -search[lane] : 0.f; sq[lane] = search[lane] * search[lane]; }
       const float snorm = sqrtf(wave_sum(sq));
+      TICK(SMJ_PROF_N_SOLVE)
       // line-search preparation  ([MJ] CGprepare)
       mat_M(Mv, search);
       mat_J(nr.jv, search);
@@ -1663,6 +1670,7 @@ struct StepKernel {
           nr.cq[lane][2] = uu; nr.cq[lane][3] = uv; nr.cq[lane][4] = vv;
         }
       }
+      TICK(SMJ_PROF_N_PREP)
       // exact line search: safeguarded Newton on the directional derivative (same scheme as the oracle's ls_search).
       // fp32 note: acceptance and the improvement estimate use derivatives, not cost differences -- near the optimum
       // the decrease is far below one ulp of the cost.
@@ -1677,6 +1685,7 @@ struct StepKernel {
           a = -d1 / d2;
           for (int it = 0; it < M.ls_iterations; it++) {
             ls_eval(nr, qg, a, d1, d2);
+            if (prof) pc[SMJ_PROF_N_LSEVALS] += 1.f;
             if (fabsf(d1) < bestd) { bestd = fabsf(d1); alpha = a; }
             if (fabsf(d1) < gtol) break;
             if (d1 < 0) lo = a; else hi = a;
@@ -1689,6 +1698,7 @@ struct StepKernel {
           }
         }
       }
+      TICK(SMJ_PROF_N_LS)
       iter++;
       if (alpha == 0.f) break;
       LANES {

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stretch_mujoco_amd import StretchBatchSimulator
 from oracle.oracle import Oracle
 np.set_printoptions(precision=5, suppress=True, linewidth=200)
-PROF = ["kin", "comcrb", "smooth", "factor", "collision", "makecon", "project", "warm", "pgs", "post", "integrate", "total", "sweeps", "setup"]
+PROF = ["kin", "comcrb", "smooth", "factor", "collision", "makecon", "project", "warm", "pgs", "post", "integrate", "total", "sweeps", "setup", "n_update", "n_grad", "n_xa", "n_hmfma", "n_chol", "n_solve", "n_prep", "n_ls", "n_lsevals"]
 
 def stage_parity(nsteps=1):
     sim = StretchBatchSimulator(num_envs=4, device="cuda:0", debug=True)
@@ -61,12 +61,9 @@ def profile(B, random_ctrl, steps=50, solver="pgs"):
     sim.stop()
 
 if __name__ == "__main__":
-    stage_parity(1)
-    stage_parity(20)
-    for solver in ("pgs", "newton"):
+    for solver in ("newton",):
         profile(1024, False, solver=solver)
         profile(1024, True, solver=solver)
-        profile(4096, True, solver=solver)
     # Newton parity on the GPU vs the fp64 Newton oracle, from reset
     sim = StretchBatchSimulator(num_envs=2, device="cuda:0", solver="newton"); sim.start(home=False)
     ctrl = np.array([2, -1, 0.6, 0.1, 1, -0.4, 0.5, 0.02, 0.3, -0.2], np.float32)
