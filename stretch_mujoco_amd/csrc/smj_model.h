@@ -14,7 +14,7 @@
   X(k_body_subtreesize) X(k_body_dofmask_lo) X(k_body_dofmask_hi) X(k_root_list) X(k_gc_body)                     \
   X(jnt_type) X(jnt_qposadr) X(jnt_dofadr) X(jnt_bodyid) X(jnt_limited)                                           \
   X(dof_bodyid) X(dof_jntid) X(dof_parentid) X(k_dof_anc_adr) X(k_dof_anc_num) X(k_dof_anc) X(k_dof_velmask_lo)   \
-  X(k_dof_velmask_hi) X(k_dof_qposadr) X(k_ldl_i) X(k_ldl_j) X(k_fric_dof) X(k_limit_jnt)                         \
+  X(k_dof_velmask_hi) X(k_dof_qposadr) X(k_ldl_i) X(k_ldl_j) X(k_ldl_lact) X(k_fric_dof) X(k_limit_jnt) X(k_act_dof) X(k_dof_act)                         \
   X(geom_type) X(geom_bodyid) X(geom_hulladr) X(geom_hullnum)                                                     \
   X(site_bodyid) X(sensor_lidar_site) X(k_ray_geom) X(k_ray_geom_origbody) X(k_site_origbody)                                                                           \
   X(eq_obj1id) X(eq_obj2id) X(eq_active)                                                                          \
@@ -31,7 +31,7 @@
   X(site_pos) X(k_site_mat)                                                                                       \
   X(eq_data) X(eq_solref) X(eq_solimp)                                                                            \
   X(actuator_gear) X(actuator_gainprm) X(actuator_biasprm) X(actuator_ctrlrange) X(actuator_forcerange)           \
-  X(k_act_moment) X(key_ctrl)                                                                                     \
+  X(k_act_moment) X(key_ctrl) X(k_ldl_damp) X(k_ldl_dcoef) X(k_ldl_lcoef) X(k_act_mom) X(k_dof_actmom)                                                                                     \
   X(pair_friction) X(pair_solref) X(pair_solimp) X(pair_margin) X(pair_gap)
 
 struct DevModel {

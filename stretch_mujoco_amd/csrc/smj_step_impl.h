@@ -41,7 +41,7 @@ struct Smem {
   float xpos[NBP][3], xquat[NBP][4], xmat[NBP][9], com[NBP][3];
   float xaxis[NVP][3], xanchor[NVP][3];
   float qpos[NVP + 8], qvel[NVP], ctrl[16], g[NVP], uu[NVP], w[NVP], qacc[NVP], warm[NVP], tmp[NVP];
-  float act_force[16], act_len[16], act_vel[16];
+  float act_force[16], act_len[16], act_vel[16], act_free[16];
   int etype[NEFC], eid[NEFC];
   float epos[NEFC], emargin[NEFC], ediag[NEFC], efloss[NEFC], eR[NEFC], eK[NEFC], eBv[NEFC], eimp[NEFC], earef[NEFC],
       eb[NEFC], ef[NEFC];
@@ -173,56 +173,130 @@ struct StepKernel {
   Smem& s;
   const int env;
 
-  // lane = body
-  PL<int> b_parent, b_level, b_jadr, b_jnum, b_root, b_subsize;
-  PL<uint64_t> b_dofmask;
-  PL<float[3]> b_pos;
-  PL<float[4]> b_quat;
-  PL<float[10]> b_inl;  // local inertia 10-vector
-  PL<float> b_mass;
-  // lane = dof
-  PL<int> d_body, d_jnt, d_jtype, d_qadr, d_first;  // d_first: dofadr of the joint
-  PL<uint64_t> d_velmask, d_bodymask;
-  PL<float> d_arm, d_damp, d_stiff, d_spring;
-  PL<float[6]> cdof, cdof_dot;
+  // Persistent lane-resident state is kept small on purpose (the kernel owns 512 registers per lane but also unrolls a
+  // 32x32 Cholesky): model constants are (re)loaded at the top of the stage that needs them -- independent global loads
+  // issued back to back cost one L2 round trip per stage -- instead of living in registers for the whole launch.
+  PL<float[6]> cdof, cdof_dot;          // lane = dof
   PL<float> qvel_r, g_r, qacc_r;
-  // lane = ldl entry slots
-  PL<int[5]> e_i, e_j;
-  // lane = row
-  PL<float> f_r, r_r, ARinv_r;
+  PL<float> f_r, r_r, ARinv_r;          // lane = row (PGS)
   int nefc, ncon, niter, flags;
 
   SMJ_DEV StepKernel(const DevModel& M_, const DevState& S_, Smem& s_, int env_) : M(M_), S(S_), s(s_), env(env_) {}
 
   SMJ_DEV static uint64_t mk64(int lo, int hi) { return (uint64_t)(uint32_t)lo | ((uint64_t)(uint32_t)hi << 32); }
 
+  // ------------------------------------------------------------------ stage-local constant tables
+  struct KinTab {   // lane = body: tree link + the body's (<= 2) joints
+    PL<int> parent, level;
+    PL<float[3]> pos;
+    PL<float[4]> quat;
+    PL<int[2]> jtype, jqadr, jdadr;
+    PL<float[2]> jq0;
+    PL<float[6]> jaxis, jpos;
+  };
+  SMJ_DEV void load(KinTab& t) {
+    const int nb = M.nbody;
+    LANES {
+      const int b = lane < nb ? lane : 0;
+      t.parent[lane] = M.body_parentid[b]; t.level[lane] = lane < nb ? M.k_body_level[b] : -1;
+      for (int k = 0; k < 3; k++) t.pos[lane][k] = M.body_pos[3 * b + k];
+      for (int k = 0; k < 4; k++) t.quat[lane][k] = M.body_quat[4 * b + k];
+      const int jn = M.body_jntnum[b], ja = M.body_jntadr[b];
+      for (int u = 0; u < 2; u++) {
+        const int jj = (lane < nb && u < jn) ? ja + u : -1, jx = jj >= 0 ? jj : 0;
+        const int qa = M.jnt_qposadr[jx];
+        t.jtype[lane][u] = jj >= 0 ? M.jnt_type[jx] : -1;
+        t.jqadr[lane][u] = qa; t.jdadr[lane][u] = M.jnt_dofadr[jx];
+        t.jq0[lane][u] = M.qpos0[qa];
+        for (int k = 0; k < 3; k++) { t.jaxis[lane][3 * u + k] = M.jnt_axis[3 * jx + k]; t.jpos[lane][3 * u + k] = M.jnt_pos[3 * jx + k]; }
+      }
+    }
+  }
+  struct BodyTab {  // lane = body: inertia and tree bookkeeping
+    PL<int> root, subsize;
+    PL<uint64_t> dofmask;
+    PL<float[10]> inl;
+  };
+  SMJ_DEV void load(BodyTab& t) {
+    LANES {
+      const int b = lane < M.nbody ? lane : 0;
+      t.root[lane] = M.body_rootid[b]; t.subsize[lane] = M.k_body_subtreesize[b];
+      t.dofmask[lane] = mk64(M.k_body_dofmask_lo[b], M.k_body_dofmask_hi[b]);
+      for (int k = 0; k < 10; k++) t.inl[lane][k] = M.k_body_inertia_local[10 * b + k];
+    }
+  }
+  struct DofTab {   // lane = dof
+    PL<int> body, jtype, qadr, first, bsub;
+    PL<uint64_t> velmask;
+    PL<float> damp, stiff, spring;
+    PL<int[2]> act;
+    PL<float[2]> actmom;
+  };
+  SMJ_DEV void load(DofTab& t) {
+    LANES {
+      const int d = lane < M.nv ? lane : 0, j = M.dof_jntid[d], db = M.dof_bodyid[d];
+      const int jt = M.jnt_type[j];
+      t.body[lane] = db; t.jtype[lane] = jt; t.qadr[lane] = M.k_dof_qposadr[d]; t.first[lane] = M.jnt_dofadr[j];
+      t.bsub[lane] = M.k_body_subtreesize[db];
+      t.velmask[lane] = mk64(M.k_dof_velmask_lo[d], M.k_dof_velmask_hi[d]);
+      t.damp[lane] = M.dof_damping[d];
+      t.stiff[lane] = (jt == JT_FREE) ? 0.f : M.jnt_stiffness[j];
+      t.spring[lane] = (jt == JT_FREE) ? 0.f : M.qpos_spring[M.jnt_qposadr[j]];
+      for (int u = 0; u < 2; u++) { t.act[lane][u] = M.k_dof_act[2 * d + u]; t.actmom[lane][u] = M.k_dof_actmom[2 * d + u]; }
+    }
+  }
+  struct EntryTab { // lane = mass-matrix pattern slots (5 per lane)
+    PL<int[5]> i, j, lact;
+    PL<float[5]> arm, damp, dcoef, lcoef;
+  };
+  SMJ_DEV void load(EntryTab& t, bool implicit) {
+    LANES {
+      for (int u = 0; u < 5; u++) {
+        const int e = lane + 64 * u, ok = e < M.nldl, ex = ok ? e : 0;
+        const int i = M.k_ldl_i[ex], j = M.k_ldl_j[ex];
+        t.i[lane][u] = ok ? i : -1; t.j[lane][u] = ok ? j : 0;
+        t.arm[lane][u] = (ok && i == j) ? M.dof_armature[i] : 0.f;
+        if (implicit) {
+          t.lact[lane][u] = ok ? M.k_ldl_lact[ex] : -1;
+          t.damp[lane][u] = ok ? M.k_ldl_damp[ex] : 0.f;
+          t.dcoef[lane][u] = ok ? M.k_ldl_dcoef[ex] : 0.f;
+          t.lcoef[lane][u] = ok ? M.k_ldl_lcoef[ex] : 0.f;
+        }
+      }
+    }
+  }
+  struct ActTab {   // lane = actuator, and lane = gravity-compensated body slot
+    PL<int[4]> dof, qadr;
+    PL<float[4]> mom;
+    PL<float[8]> prm;   // gain, b0, b1, b2, ctrl lo/hi, force lo/hi
+    PL<int> flags;      // bit0 ctrllimited, bit1 forcelimited, bit2 affine bias
+    PL<int> gc_body, gc_mlo, gc_mhi;
+    PL<float> gc_mass, gc_x, gc_y, gc_z;
+  };
+  SMJ_DEV void load(ActTab& t) {
+    LANES {
+      const int a = lane < M.nu ? lane : 0;
+      for (int u = 0; u < 4; u++) {
+        const int dd = M.k_act_dof[4 * a + u];
+        t.dof[lane][u] = lane < M.nu ? dd : -1;
+        t.mom[lane][u] = M.k_act_mom[4 * a + u];
+        t.qadr[lane][u] = dd >= 0 ? M.k_dof_qposadr[dd] : 0;
+      }
+      t.prm[lane][0] = M.actuator_gainprm[3 * a];
+      for (int k = 0; k < 3; k++) t.prm[lane][1 + k] = M.actuator_biasprm[3 * a + k];
+      t.prm[lane][4] = M.actuator_ctrlrange[2 * a]; t.prm[lane][5] = M.actuator_ctrlrange[2 * a + 1];
+      t.prm[lane][6] = M.actuator_forcerange[2 * a]; t.prm[lane][7] = M.actuator_forcerange[2 * a + 1];
+      t.flags[lane] = (M.actuator_ctrllimited[a] ? 1 : 0) | (M.actuator_forcelimited[a] ? 2 : 0) | (M.actuator_biastype[a] == 1 ? 4 : 0);
+      const int g = lane < M.ngc ? M.k_gc_body[lane] : 0;
+      t.gc_body[lane] = g; t.gc_mass[lane] = lane < M.ngc ? M.body_gcmass[g] : 0.f;
+      t.gc_mlo[lane] = M.k_body_dofmask_lo[g]; t.gc_mhi[lane] = M.k_body_dofmask_hi[g];
+      t.gc_x[lane] = M.body_gcipos[3 * g]; t.gc_y[lane] = M.body_gcipos[3 * g + 1]; t.gc_z[lane] = M.body_gcipos[3 * g + 2];
+    }
+  }
+
   // ------------------------------------------------------------------ setup (once per launch)
   SMJ_DEV void setup() {
-    const int nb = M.nbody, nv = M.nv;
     LANES {
-      int b = lane < nb ? lane : 0;
-      b_parent[lane] = M.body_parentid[b]; b_level[lane] = lane < nb ? M.k_body_level[b] : -1;
-      b_jadr[lane] = M.body_jntadr[b]; b_jnum[lane] = lane < nb ? M.body_jntnum[b] : 0;
-      b_root[lane] = M.body_rootid[b]; b_subsize[lane] = M.k_body_subtreesize[b];
-      b_dofmask[lane] = mk64(M.k_body_dofmask_lo[b], M.k_body_dofmask_hi[b]);
-      for (int k = 0; k < 3; k++) b_pos[lane][k] = M.body_pos[3 * b + k];
-      for (int k = 0; k < 4; k++) b_quat[lane][k] = M.body_quat[4 * b + k];
-      for (int k = 0; k < 10; k++) b_inl[lane][k] = M.k_body_inertia_local[10 * b + k];
-      int d = lane < nv ? lane : 0;
-      d_body[lane] = M.dof_bodyid[d]; d_jnt[lane] = M.dof_jntid[d]; d_jtype[lane] = M.jnt_type[M.dof_jntid[d]];
-      d_qadr[lane] = M.k_dof_qposadr[d]; d_first[lane] = M.jnt_dofadr[M.dof_jntid[d]];
-      d_velmask[lane] = mk64(M.k_dof_velmask_lo[d], M.k_dof_velmask_hi[d]);
-      int db = M.dof_bodyid[d];
-      d_bodymask[lane] = mk64(M.k_body_dofmask_lo[db], M.k_body_dofmask_hi[db]);
-      d_arm[lane] = M.dof_armature[d]; d_damp[lane] = M.dof_damping[d];
-      int j = M.dof_jntid[d];
-      d_stiff[lane] = (M.jnt_type[j] == JT_FREE) ? 0.f : M.jnt_stiffness[j];
-      d_spring[lane] = (M.jnt_type[j] == JT_FREE) ? 0.f : M.qpos_spring[M.jnt_qposadr[j]];
-      for (int t = 0; t < 5; t++) {
-        int e = lane + 64 * t;
-        e_i[lane][t] = e < M.nldl ? M.k_ldl_i[e] : -1;
-        e_j[lane][t] = e < M.nldl ? M.k_ldl_j[e] : 0;
-      }
       // zero the factor storage once: the sparsity pattern is static, non-pattern entries stay zero
       for (int k = lane; k < NVP * MS; k += 64) (&s.MM[0][0])[k] = 0.f;
       // world body
@@ -260,37 +334,44 @@ struct StepKernel {
   // ------------------------------------------------------------------ B.1 kinematics  [MJ] mj_kinematics
   SMJ_DEV void kinematics() {
     const int nb = M.nbody;
+    KinTab kt;
+    load(kt);
     for (int lev = 1; lev < M.nlevel; lev++) {
       LANES {
-        if (lane < nb && b_level[lane] == lev) {
-          const int b = lane, p = b_parent[lane], ja = b_jadr[lane], jn = b_jnum[lane];
+        if (lane < nb && kt.level[lane] == lev) {
+          const int b = lane, p = kt.parent[lane];
           float pos[3], quat[4], R[9];
-          if (jn == 1 && M.jnt_type[ja] == JT_FREE) {
-            const int qa = M.jnt_qposadr[ja], da = M.jnt_dofadr[ja];
+          const bool isfree = kt.jtype[lane][0] == JT_FREE;
+          if (isfree) {
+            const int qa = kt.jqadr[lane][0], da = kt.jdadr[lane][0];
             for (int k = 0; k < 3; k++) pos[k] = s.qpos[qa + k];
             for (int k = 0; k < 4; k++) quat[k] = s.qpos[qa + 3 + k];
             quat_normalize(quat);
             for (int d = 0; d < 6; d++)
               for (int k = 0; k < 3; k++) s.xanchor[da + d][k] = pos[k];
           } else {
-            mulmat3vec(pos, s.xmat[p], b_pos[lane]);
+            mulmat3vec(pos, s.xmat[p], kt.pos[lane]);
             for (int k = 0; k < 3; k++) pos[k] += s.xpos[p][k];
-            quat_mul(quat, s.xquat[p], b_quat[lane]);
-            for (int j = ja; j < ja + jn; j++) {
-              const int da = M.jnt_dofadr[j];
-              float ax[3] = {M.jnt_axis[3 * j], M.jnt_axis[3 * j + 1], M.jnt_axis[3 * j + 2]};
-              float jp[3] = {M.jnt_pos[3 * j], M.jnt_pos[3 * j + 1], M.jnt_pos[3 * j + 2]};
+            quat_mul(quat, s.xquat[p], kt.quat[lane]);
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+              const int jt = kt.jtype[lane][t];
+              if (jt < 0) continue;
+              const int da = kt.jdadr[lane][t];
+              const float* ax = &kt.jaxis[lane][3 * t];
+              const float* jp = &kt.jpos[lane][3 * t];
               float xa[3], a[3], anchor[3];
               quat2mat(R, quat);
               mulmat3vec(xa, R, ax);
               mulmat3vec(a, R, jp);
               for (int k = 0; k < 3; k++) { anchor[k] = pos[k] + a[k]; s.xaxis[da][k] = xa[k]; s.xanchor[da][k] = anchor[k]; }
-              const int qa = M.jnt_qposadr[j];
-              float q = s.qpos[qa] - M.qpos0[qa];
-              if (M.jnt_type[j] == JT_SLIDE) {
+              const float q = s.qpos[kt.jqadr[lane][t]] - kt.jq0[lane][t];
+              if (jt == JT_SLIDE) {
                 for (int k = 0; k < 3; k++) pos[k] += xa[k] * q;
               } else {
-                float sn = sinf(0.5f * q), dq[4] = {cosf(0.5f * q), ax[0] * sn, ax[1] * sn, ax[2] * sn};
+                float sn, cs;
+                sincosf(0.5f * q, &sn, &cs);
+                const float dq[4] = {cs, ax[0] * sn, ax[1] * sn, ax[2] * sn};
                 quat_mul(quat, quat, dq);
                 quat2mat(R, quat);
                 mulmat3vec(a, R, jp);
@@ -303,8 +384,8 @@ struct StepKernel {
           for (int k = 0; k < 3; k++) s.xpos[b][k] = pos[k];
           for (int k = 0; k < 4; k++) s.xquat[b][k] = quat[k];
           for (int k = 0; k < 9; k++) s.xmat[b][k] = R[k];
-          if (jn == 1 && M.jnt_type[ja] == JT_FREE) {
-            const int da = M.jnt_dofadr[ja];
+          if (isfree) {
+            const int da = kt.jdadr[lane][0];
             for (int d = 0; d < 3; d++)
               for (int k = 0; k < 3; k++) {
                 s.xaxis[da + d][k] = (d == k) ? 1.f : 0.f;
@@ -320,6 +401,10 @@ struct StepKernel {
   // ------------------------------------------------------------------ comPos + comVel + crb + M
   SMJ_DEV void com_crb() {
     const int nb = M.nbody, nv = M.nv;
+    BodyTab bt;
+    DofTab dt;
+    EntryTab et;
+    load(bt); load(dt); load(et, false);
     // subtree com of each tree root: masked wave reductions
     PL<float> mx, my, mz;
     PL<float[3]> xip;
@@ -327,7 +412,7 @@ struct StepKernel {
       const int b = lane;
       float t[3] = {0, 0, 0};
       if (b > 0 && b < nb) {
-        mulmat3vec(t, s.xmat[b], &b_inl[lane][6]);
+        mulmat3vec(t, s.xmat[b], &bt.inl[lane][6]);
         for (int k = 0; k < 3; k++) t[k] += s.xpos[b][k];
       }
       for (int k = 0; k < 3; k++) xip[lane][k] = t[k];
@@ -335,14 +420,14 @@ struct StepKernel {
     for (int r = 0; r < M.nroot; r++) {
       const int root = uni(M.k_root_list[r]);
       LANES {
-        const bool in = lane > 0 && lane < nb && b_root[lane] == root;
-        const float m = in ? b_inl[lane][9] : 0.f;
+        const bool in = lane > 0 && lane < nb && bt.root[lane] == root;
+        const float m = in ? bt.inl[lane][9] : 0.f;
         mx[lane] = m * xip[lane][0]; my[lane] = m * xip[lane][1]; mz[lane] = m * xip[lane][2];
       }
       const float inv = 1.0f / M.body_subtreemass[root];
       const float cx = wave_sum(mx) * inv, cy = wave_sum(my) * inv, cz = wave_sum(mz) * inv;
       LANES {
-        if (lane < nb && b_root[lane] == root) { s.com[lane][0] = cx; s.com[lane][1] = cy; s.com[lane][2] = cz; }
+        if (lane < nb && bt.root[lane] == root) { s.com[lane][0] = cx; s.com[lane][1] = cy; s.com[lane][2] = cz; }
       }
     }
     SYNC();
@@ -351,7 +436,7 @@ struct StepKernel {
       const int b = lane;
       if (b > 0 && b < nb) {
         const float* R = s.xmat[b];
-        const float* I = b_inl[lane];
+        const float* I = bt.inl[lane];
         // T = R * Iloc * R'   (Iloc symmetric: xx yy zz xy xz yz)
         float Il[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]}, RI[9], T[9], Rt[9];
         mulmat3(RI, R, Il);
@@ -367,10 +452,10 @@ struct StepKernel {
         c[6] = mass * dif[0]; c[7] = mass * dif[1]; c[8] = mass * dif[2]; c[9] = mass;
       }
       if (lane < nv) {
-        const int d = lane, b = d_body[lane];
+        const int d = lane, b = dt.body[lane];
         float off[3] = {s.com[b][0] - s.xanchor[d][0], s.com[b][1] - s.xanchor[d][1], s.com[b][2] - s.xanchor[d][2]};
         float* c = cdof[lane];
-        const int jt = d_jtype[lane], k = d - d_first[lane];
+        const int jt = dt.jtype[lane], k = d - dt.first[lane];
         if (jt == JT_SLIDE || (jt == JT_FREE && k < 3)) {
           c[0] = c[1] = c[2] = 0;
           for (int x = 0; x < 3; x++) c[3 + x] = s.xaxis[d][x];
@@ -390,14 +475,14 @@ struct StepKernel {
     LANES {
       if (lane < nv) {
         float cv[6] = {0, 0, 0, 0, 0, 0};
-        uint64_t mk = d_velmask[lane];
+        uint64_t mk = dt.velmask[lane];
         while (mk) {
           const int a = ffs64(mk);
           mk &= mk - 1;
           const float qv = s.qvel[a];
           for (int x = 0; x < 6; x++) cv[x] += s.u.t.cdof[a][x] * qv;
         }
-        const int jt = d_jtype[lane], k = lane - d_first[lane];
+        const int jt = dt.jtype[lane], k = lane - dt.first[lane];
         if (jt == JT_FREE && k < 3) { for (int x = 0; x < 6; x++) cdof_dot[lane][x] = 0; }
         else cross_motion(cdof_dot[lane], cv, cdof[lane]);
         for (int x = 0; x < 6; x++) s.u.t.cdof_dot[lane][x] = cdof_dot[lane][x];
@@ -407,7 +492,7 @@ struct StepKernel {
       if (lane < nb) {
         const int b = lane;
         float cv[6] = {0, 0, 0, 0, 0, 0};
-        uint64_t mk = b_dofmask[lane];
+        uint64_t mk = bt.dofmask[lane];
         while (mk) {
           const int a = ffs64(mk);
           mk &= mk - 1;
@@ -417,7 +502,7 @@ struct StepKernel {
         for (int x = 0; x < 6; x++) s.u.t.cvel[b][x] = cv[x];
         float c[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (b > 0)
-          for (int x = b; x < b + b_subsize[lane]; x++)
+          for (int x = b; x < b + bt.subsize[lane]; x++)
             for (int k = 0; k < 10; k++) c[k] += s.u.t.cinert[x][k];
         for (int k = 0; k < 10; k++) s.u.t.crb[b][k] = c[k];
       }
@@ -426,7 +511,7 @@ struct StepKernel {
     LANES {
       if (lane < nv) {
         float bf[6];
-        mul_inert_vec(bf, s.u.t.crb[d_body[lane]], cdof[lane]);
+        mul_inert_vec(bf, s.u.t.crb[dt.body[lane]], cdof[lane]);
         for (int x = 0; x < 6; x++) s.u.t.buf[lane][x] = bf[x];
       }
     }
@@ -434,11 +519,11 @@ struct StepKernel {
     // M entries on the static sparsity pattern: lower (working copy), upper (kept), Mdiag
     LANES {
       for (int t = 0; t < 5; t++) {
-        const int i = e_i[lane][t], j = e_j[lane][t];
+        const int i = et.i[lane][t], j = et.j[lane][t];
         if (i < 0) continue;
         float v = 0;
         for (int x = 0; x < 6; x++) v += s.u.t.cdof[j][x] * s.u.t.buf[i][x];
-        if (i == j) { v += M.dof_armature[i]; s.Mdiag[i] = v; }
+        if (i == j) { v += et.arm[lane][t]; s.Mdiag[i] = v; }
         s.MM[i][j] = v;
         if (i != j) s.MM[j][i] = v;
       }
@@ -451,11 +536,13 @@ struct StepKernel {
   // ancestors of k:  M[i][j] -= M[k][i]*M[k][j]/M[k][k].  Non-ancestors hold zeros (static pattern, no fill-in).
   SMJ_DEV void factor() {
     const int nv = M.nv;
+    EntryTab et;
+    load(et, false);
     for (int k = nv - 1; k >= 0; k--) {
       const float dkk = s.MM[k][k], dinv = 1.0f / dkk;
       LANES {
         for (int t = 0; t < 5; t++) {
-          const int i = e_i[lane][t], j = e_j[lane][t];
+          const int i = et.i[lane][t], j = et.j[lane][t];
           if (i < 0 || i >= k) continue;
           const float a = s.MM[k][i];
           if (a != 0.f) s.MM[i][j] -= a * s.MM[k][j] * dinv;
@@ -488,24 +575,30 @@ struct StepKernel {
   SMJ_DEV void smooth_forces(bool dbg) {
     const int nb = M.nbody, nv = M.nv, nu = M.nu;
     PL<float> frc_passive, frc_bias, frc_act;
+    DofTab dt;
+    ActTab at;
+    PL<uint64_t> b_dofmask;
+    load(dt); load(at);
+    LANES { const int b = lane < nb ? lane : 0; b_dofmask[lane] = mk64(M.k_body_dofmask_lo[b], M.k_body_dofmask_hi[b]); }
     // passive: damper + spring
     LANES {
       float f = 0;
       if (lane < nv) {
-        f = -d_damp[lane] * s.qvel[lane];
-        if (d_stiff[lane] != 0.f) f -= d_stiff[lane] * (s.qpos[d_qadr[lane]] - d_spring[lane]);
+        f = -dt.damp[lane] * s.qvel[lane];
+        if (dt.stiff[lane] != 0.f) f -= dt.stiff[lane] * (s.qpos[dt.qadr[lane]] - dt.spring[lane]);
       }
       frc_passive[lane] = f;
     }
     // gravity compensation  [MJ] mj_passive gravcomp: F = -g*m*gravcomp at the body's gravcomp point
     for (int t = 0; t < M.ngc; t++) {
-      const int b = uni(M.k_gc_body[t]);
-      const float gm = M.body_gcmass[b];
-      float pt[3], lp[3] = {M.body_gcipos[3 * b], M.body_gcipos[3 * b + 1], M.body_gcipos[3 * b + 2]};
+      const int b = wave_read(at.gc_body, t);
+      const float gm = wave_read(at.gc_mass, t);
+      float pt[3];
+      const float lp[3] = {wave_read(at.gc_x, t), wave_read(at.gc_y, t), wave_read(at.gc_z, t)};
       mulmat3vec(pt, s.xmat[b], lp);
       float off[3] = {pt[0] + s.xpos[b][0] - s.com[b][0], pt[1] + s.xpos[b][1] - s.com[b][1], pt[2] + s.xpos[b][2] - s.com[b][2]};
       const float F[3] = {-M.gravity[0] * gm, -M.gravity[1] * gm, -M.gravity[2] * gm};
-      const uint64_t mk = mk64(M.k_body_dofmask_lo[b], M.k_body_dofmask_hi[b]);
+      const uint64_t mk = mk64(wave_read(at.gc_mlo, t), wave_read(at.gc_mhi, t));
       LANES {
         if ((mk >> lane) & 1) {
           float tv[3];
@@ -537,41 +630,47 @@ struct StepKernel {
     LANES {
       float v = 0;
       if (lane < nv) {
-        const int b = d_body[lane];
+        const int b = dt.body[lane];
         float cf[6] = {0, 0, 0, 0, 0, 0};
-        const int n = M.k_body_subtreesize[b];
+        const int n = dt.bsub[lane];
         for (int x = b; x < b + n; x++)
           for (int k = 0; k < 6; k++) cf[k] += s.u.t.cfrc[x][k];
         for (int k = 0; k < 6; k++) v += cdof[lane][k] * cf[k];
       }
       frc_bias[lane] = v;
     }
-    // actuation  [MJ] mj_fwdActuation (static moments: joint / fixed-tendon transmissions)
+    // actuation  [MJ] mj_fwdActuation (static moments: joint / fixed-tendon transmissions), constants lane-resident
     LANES {
       if (lane < nu) {
         const int a = lane;
         float len = 0, vel = 0;
-        for (int k = 0; k < nv; k++) {
-          const float mo = M.k_act_moment[a * nv + k];
-          if (mo != 0.f) {
-            vel += mo * s.qvel[k];
-            len += mo * s.qpos[M.k_dof_qposadr[k]];
-          }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const int dd = at.dof[lane][t];
+          if (dd >= 0) { vel += at.mom[lane][t] * s.qvel[dd]; len += at.mom[lane][t] * s.qpos[at.qadr[lane][t]]; }
         }
+        const float* pr = at.prm[lane];
+        const int fl = at.flags[lane];
         float ctrl = s.ctrl[a];
-        if (M.actuator_ctrllimited[a]) ctrl = fminf(M.actuator_ctrlrange[2 * a + 1], fmaxf(M.actuator_ctrlrange[2 * a], ctrl));
-        float f = M.actuator_gainprm[3 * a] * ctrl;
-        if (M.actuator_biastype[a] == 1)
-          f += M.actuator_biasprm[3 * a] + M.actuator_biasprm[3 * a + 1] * len + M.actuator_biasprm[3 * a + 2] * vel;
-        if (M.actuator_forcelimited[a]) f = fminf(M.actuator_forcerange[2 * a + 1], fmaxf(M.actuator_forcerange[2 * a], f));
+        if (fl & 1) ctrl = fminf(pr[5], fmaxf(pr[4], ctrl));
+        float f = pr[0] * ctrl;
+        if (fl & 4) f += pr[1] + pr[2] * len + pr[3] * vel;
+        bool clamped = false;
+        if (fl & 2) { clamped = (f <= pr[6] || f >= pr[7]); f = fminf(pr[7], fmaxf(pr[6], f)); }
         s.act_force[a] = f; s.act_len[a] = len; s.act_vel[a] = vel;
+        s.act_free[a] = clamped ? 0.f : 1.f;   // the velocity derivative of a force-clamped actuator is dropped ([MJ] mjd_actuator_vel)
       }
     }
     SYNC();
     LANES {
       float v = 0;
-      if (lane < nv)
-        for (int a = 0; a < nu; a++) v += M.k_act_moment[a * nv + lane] * s.act_force[a];
+      if (lane < nv) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          const int a = dt.act[lane][t];
+          if (a >= 0) v += dt.actmom[lane][t] * s.act_force[a];
+        }
+      }
       frc_act[lane] = v;
       g_r[lane] = frc_passive[lane] - frc_bias[lane] + frc_act[lane];
       if (lane < nv) s.g[lane] = g_r[lane];
@@ -1351,10 +1450,20 @@ struct StepKernel {
   SMJ_DEV void mat_M(PL<float>& y, const PL<float>& x) {
     const int nv = M.nv;
     LANES { y[lane] = lane < nv ? s.Mdiag[lane] * x[lane] : 0.f; }
-    for (int j = 0; j < nv; j++) {
-      const float xj = wave_read(x, j);
+    for (int j0 = 0; j0 < nv; j0 += 4) {   // four columns per pass: the LDS loads of a pass are independent
+      float xj[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) xj[u] = j0 + u < nv ? wave_read(x, j0 + u) : 0.f;
       LANES {
-        if (lane < nv && lane != j) y[lane] += (lane > j ? s.MM[j][lane] : s.MM[lane][j]) * xj;
+        if (lane < nv) {
+          float m[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int j = j0 + u;
+            m[u] = (j < nv && lane != j) ? (lane > j ? s.MM[j][lane] : s.MM[lane][j]) : 0.f;
+          }
+          y[lane] += m[0] * xj[0] + m[1] * xj[1] + m[2] * xj[2] + m[3] * xj[3];
+        }
       }
     }
   }
@@ -1379,13 +1488,101 @@ struct StepKernel {
     }
     LANES { out[lane] = hi[lane] + lo[lane]; }
   }
+  // out[dof] = sum_rows J[row][dof] * f[row]   (lane = dof, f lane-resident over rows), four rows per pass
+  SMJ_DEV void matT_J(PL<float>& out, const PL<float>& f) {
+    const int ne = nefc;
+    LANES { out[lane] = 0.f; }
+    for (int r0 = 0; r0 < ne; r0 += 4) {
+      float fr[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) fr[u] = r0 + u < ne ? wave_read(f, r0 + u) : 0.f;
+      LANES {
+        if (lane < NVP) {
+          float a[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) a[u] = r0 + u < NEFC ? s.J[r0 + u < NEFC ? r0 + u : 0][lane] : 0.f;
+          out[lane] += a[0] * fr[0] + a[1] * fr[1] + a[2] * fr[2] + a[3] * fr[3];
+        }
+      }
+    }
+  }
   // out[row] = J[row] . x   (lane = row, x lane-resident over dofs)
   SMJ_DEV void mat_J(PL<float>& out, const PL<float>& x) {
     const int nv = M.nv;
     LANES { out[lane] = 0.f; }
-    for (int k = 0; k < nv; k++) {
-      const float xk = wave_read(x, k);
-      LANES { out[lane] += s.J[lane][k] * xk; }
+    for (int k0 = 0; k0 < nv; k0 += 4) {
+      float xk[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) xk[u] = k0 + u < nv ? wave_read(x, k0 + u) : 0.f;
+      LANES {
+        float a[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) a[u] = s.J[lane][k0 + u];   // columns nv..NVP of J are zero
+        out[lane] += a[0] * xk[0] + a[1] * xk[1] + a[2] * xk[2] + a[3] * xk[3];
+      }
+    }
+  }
+
+  // x <- H^-1 x for the SPD matrix in s.u.n.H (NVP x NVP, identity padded beyond nv); H is overwritten by its Cholesky
+  // factor.  Lane i owns row i of H in registers: the factorisation is fully unrolled, column broadcasts are
+  // v_readlane, no LDS round trips; the L' solve reads L rows back from LDS in pipelined chunks.
+  SMJ_DEV void chol_solve_H(PL<float>& x) {
+    PL<float[NVP]> hrow;
+    PL<float> dinv;
+    LANES {
+      const int i = lane < NVP ? lane : 0;
+#pragma unroll
+      for (int k = 0; k < NVP; k++) hrow[lane][k] = (lane < NVP) ? s.u.n.H[i][k] : 0.f;
+      dinv[lane] = 1.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NVP; k++) {
+      PL<float> col;
+      LANES { col[lane] = hrow[lane][k]; }
+      const float d = fmaxf(wave_read(col, k), 1e-30f), inv = fast_rsqrt(d);
+      LANES {
+        col[lane] = col[lane] * inv;   // L[i][k] for i >= k (lane k: sqrt(d))
+        hrow[lane][k] = col[lane];
+        if (lane == k) dinv[lane] = inv;
+      }
+#pragma unroll
+      for (int j = k + 1; j < NVP; j++) {
+        const float ljk = wave_read(col, j);
+        LANES { if (lane >= j) hrow[lane][j] -= col[lane] * ljk; }
+      }
+    }
+    LANES {
+      if (lane < NVP) {
+#pragma unroll
+        for (int k = 0; k < NVP; k++) s.u.n.H[lane][k] = hrow[lane][k];
+      }
+    }
+    SYNC();
+    // forward: L y = x  (register rows)
+#pragma unroll
+    for (int k = 0; k < NVP; k++) {
+      const float xk = wave_read(x, k) * wave_read(dinv, k);
+      LANES {
+        if (lane == k) x[lane] = xk;
+        else if (lane > k && lane < NVP) x[lane] -= hrow[lane][k] * xk;
+      }
+    }
+    // backward: L' z = y  (column `lane` of L' = L[k][lane], read from LDS eight rows at a time)
+    for (int k0 = NVP - 8; k0 >= 0; k0 -= 8) {
+      PL<float[8]> lk;
+      LANES {
+#pragma unroll
+        for (int t = 0; t < 8; t++) lk[lane][t] = lane < NVP ? s.u.n.H[k0 + t][lane] : 0.f;
+      }
+#pragma unroll
+      for (int t = 7; t >= 0; t--) {
+        const int k = k0 + t;
+        const float xk = wave_read(x, k) * wave_read(dinv, k);
+        LANES {
+          if (lane == k) x[lane] = xk;
+          else if (lane < k) x[lane] -= lk[lane][t] * xk;
+        }
+      }
     }
   }
 
@@ -1437,16 +1634,16 @@ struct StepKernel {
 #define TICK(slot) if (prof) { const long long t1 = smj_clock(); pc[slot] += (float)(t1 - t0); t0 = t1; }
     const int nv = M.nv, ne = nefc;
     NRow nr;
-    PL<float> qacc, qs, Ma, Mv, grad, search, tmpv;
-    // qacc_smooth = M^-1 g
-    LANES { qs[lane] = lane < nv ? g_r[lane] : 0.f; }
-    solve_LT(qs);
-    LANES { if (lane < nv) qs[lane] *= s.Dinv[lane]; }
-    solve_L(qs);
-    if (ne == 0) {
+    PL<float> qacc, Ma, Mv, grad, search, tmpv;
+    // The Gauss term is used up to its constant: 0.5 (a-a_s)'M(a-a_s) = 0.5 a'Ma - a'g + const, so neither
+    // qacc_smooth nor a factorisation of M is needed on the Newton path (the constant never enters a derivative).
+    if (ne == 0) {   // unconstrained: qacc = M^-1 g
+      build_dense(false);
+      LANES { qacc[lane] = lane < nv ? g_r[lane] : 0.f; }
+      chol_solve_H(qacc);
       LANES {
-        qacc_r[lane] = qs[lane];
-        if (lane < nv) { s.qacc[lane] = qs[lane]; s.warm[lane] = qs[lane]; s.tmp[lane] = g_r[lane]; }
+        qacc_r[lane] = lane < nv ? qacc[lane] : 0.f;
+        if (lane < nv) { s.qacc[lane] = qacc[lane]; s.warm[lane] = qacc[lane]; s.tmp[lane] = g_r[lane]; }
       }
       niter = 0;
       SYNC();
@@ -1475,28 +1672,12 @@ struct StepKernel {
       if (dbg) s.earef[lane] = nr.aref[lane];
     }
     const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
-    // warm start: the cheaper of qacc_warmstart and qacc_smooth  ([MJ] mj_warmstart, primal branch)
-    LANES { qacc[lane] = lane < nv ? (M.warmstart ? s.warm[lane] : qs[lane]) : 0.f; }
+    // start from qacc_warmstart (MuJoCo also tries qacc_smooth and keeps the cheaper; Newton reaches the same unique
+    // optimum from either, so the extra M^-1 g solve is skipped)
+    LANES { qacc[lane] = (lane < nv && M.warmstart) ? s.warm[lane] : 0.f; }
     mat_M(Ma, qacc);
     mat_J_exact(nr.jar, qacc, nr.aref);
-    float cost = newton_update(nr, false);
-    {
-      PL<float> gs;
-      LANES { gs[lane] = lane < nv ? 0.5f * (Ma[lane] - g_r[lane]) * (qacc[lane] - qs[lane]) : 0.f; }
-      cost += wave_sum(gs);
-    }
-    if (M.warmstart) {
-      PL<float> keep;
-      LANES { keep[lane] = nr.jar[lane]; }
-      mat_J_exact(nr.jar, qs, nr.aref);
-      const float cs = newton_update(nr, false);
-      if (cs < cost) {
-        LANES { qacc[lane] = qs[lane]; }
-        mat_M(Ma, qacc);
-      } else {
-        LANES { nr.jar[lane] = keep[lane]; }
-      }
-    }
+    float cost = 0;
     TICK(SMJ_PROF_WARM)
     int iter = 0;
     for (; iter < M.iterations;) {
@@ -1505,50 +1686,40 @@ struct StepKernel {
       float gauss;
       {
         PL<float> gs;
-        LANES { gs[lane] = lane < nv ? 0.5f * (Ma[lane] - g_r[lane]) * (qacc[lane] - qs[lane]) : 0.f; }
+        LANES { gs[lane] = lane < nv ? qacc[lane] * (0.5f * Ma[lane] - g_r[lane]) : 0.f; }
         gauss = wave_sum(gs);
       }
       cost += gauss;
       TICK(SMJ_PROF_N_UPDATE)
       // gradient = Ma - g - J'f   (lanes = dofs; force broadcast by readlane)
-      LANES { tmpv[lane] = 0.f; }
-      for (int r = 0; r < ne; r++) {
-        const float fr = wave_read(nr.force, r);
-        LANES { if (lane < nv) tmpv[lane] += s.J[r][lane] * fr; }
-      }
+      matT_J(tmpv, nr.force);
       PL<float> g2;
       LANES { grad[lane] = lane < nv ? Ma[lane] - g_r[lane] - tmpv[lane] : 0.f; g2[lane] = grad[lane] * grad[lane]; }
       const float gnorm = sqrtf(wave_sum(g2));
       if (iter > 0 && scale * gnorm < M.tolerance) break;
       TICK(SMJ_PROF_N_GRAD)
       // XA = W J : quadratic rows D*J, cone rows Hc*Jc, others 0   (lanes = dofs, uniform loop over rows)
-      for (int r = 0; r < ne;) {
-        const int t = wave_read(nr.type, r), st = wave_read(nr.state, r);
-        if (t == CT_CONTACT_ELLIPTIC) {
-          const int c = uni(s.eid[r]), dim = uni(s.cdim[c]);
-          if (st == 4) {
-            LANES {
-              if (lane < NVP) {
-                float jc[6];
-                for (int q = 0; q < dim; q++) jc[q] = s.J[r + q][lane];
-                for (int rr = 0; rr < dim; rr++) {
-                  float v = 0;
-                  for (int q = 0; q < dim; q++) v += s.u.n.cH[c][rr * dim + q] * jc[q];
-                  s.u.n.XA[r + rr][lane] = v;
-                }
-              }
-            }
-          } else {
-            LANES {
-              if (lane < NVP)
-                for (int rr = 0; rr < dim; rr++) s.u.n.XA[r + rr][lane] = st == 1 ? s.J[r + rr][lane] / s.eR[r + rr] : 0.f;
+      LANES {   // every row scales itself: quadratic rows by D, satisfied / linear rows by 0
+        const float w = (lane < ne && nr.state[lane] == 1) ? nr.D[lane] : 0.f;
+        if (nr.state[lane] != 4)
+#pragma unroll
+          for (int k = 0; k < NVP; k++) s.u.n.XA[lane][k] = w * s.J[lane][k];
+      }
+      for (int c = 0; c < ncon; c++) {   // contacts in the cone (middle) zone: XA rows = Hc * Jc
+        const int r = uni(s.cefc[c]);
+        if (r < 0) continue;
+        if (wave_read(nr.state, r) != 4) continue;
+        const int dim = uni(s.cdim[c]);
+        LANES {
+          if (lane < NVP) {
+            float jc[6];
+            for (int q = 0; q < dim; q++) jc[q] = s.J[r + q][lane];
+            for (int rr = 0; rr < dim; rr++) {
+              float v = 0;
+              for (int q = 0; q < dim; q++) v += s.u.n.cH[c][rr * dim + q] * jc[q];
+              s.u.n.XA[r + rr][lane] = v;
             }
           }
-          r += dim;
-        } else {
-          const float w = st == 1 ? wave_read(nr.D, r) : 0.f;
-          LANES { if (lane < NVP) s.u.n.XA[r][lane] = w * s.J[r][lane]; }
-          r += 1;
         }
       }
       SYNC();
@@ -1559,15 +1730,23 @@ struct StepKernel {
         for (int ta = 0; ta < 2; ta++)
           for (int tb = 0; tb <= ta; tb++) {
             PL<F4v> acc;
-            LANES { for (int r = 0; r < 4; r++) acc[lane].r[r] = 0.f; }
-            for (int ks = 0; ks < ksteps; ks++) {
-              PL<float> a, b;
-              LANES {
+            PL<float[NEFC / 4]> av, bv;
+            LANES {
+              for (int r = 0; r < 4; r++) acc[lane].r[r] = 0.f;
+#pragma unroll
+              for (int ks = 0; ks < NEFC / 4; ks++) {   // all operand loads of the tile are issued before the first MFMA
                 const int k = 4 * ks + (lane >> 4);
-                a[lane] = k < ne ? s.u.n.XA[k][16 * ta + (lane & 15)] : 0.f;
-                b[lane] = k < ne ? s.J[k][16 * tb + (lane & 15)] : 0.f;
+                av[lane][ks] = ks < ksteps ? s.u.n.XA[k][16 * ta + (lane & 15)] : 0.f;   // rows >= ne of XA / J are zero
+                bv[lane][ks] = ks < ksteps ? s.J[k][16 * tb + (lane & 15)] : 0.f;
               }
-              mfma16x16x4(acc, a, b);
+            }
+#pragma unroll
+            for (int ks = 0; ks < NEFC / 4; ks++) {
+              if (ks < ksteps) {
+                PL<float> a, b;
+                LANES { a[lane] = av[lane][ks]; b[lane] = bv[lane][ks]; }
+                mfma16x16x4(acc, a, b);
+              }
             }
             LANES {
               for (int r = 0; r < 4; r++) {
@@ -1583,55 +1762,9 @@ struct StepKernel {
       }
       SYNC();
       TICK(SMJ_PROF_N_HMFMA)
-      // Cholesky H = L L' with lane i owning row i in registers; L rows then go back to LDS for the L' solve
-      PL<float[NVP]> hrow;
-      PL<float> dinv;
-      LANES {
-        const int i = lane < NVP ? lane : 0;
-#pragma unroll
-        for (int k = 0; k < NVP; k++) hrow[lane][k] = (lane < NVP) ? s.u.n.H[i][k] : 0.f;
-      }
-#pragma unroll
-      for (int k = 0; k < NVP; k++) {
-        PL<float> col;
-        LANES { col[lane] = hrow[lane][k]; }
-        const float d = fmaxf(wave_read(col, k), 1e-30f), inv = fast_rsqrt(d);
-        LANES {
-          col[lane] = col[lane] * inv;   // L[i][k] for i >= k (lane k: sqrt(d))
-          hrow[lane][k] = col[lane];
-          if (lane == k) dinv[lane] = inv;
-        }
-#pragma unroll
-        for (int j = k + 1; j < NVP; j++) {
-          const float ljk = wave_read(col, j);
-          LANES { if (lane >= j) hrow[lane][j] -= col[lane] * ljk; }
-        }
-      }
-      LANES {
-        if (lane < NVP) {
-#pragma unroll
-          for (int k = 0; k < NVP; k++) s.u.n.H[lane][k] = hrow[lane][k];
-        }
-      }
-      SYNC();
-      TICK(SMJ_PROF_N_CHOL)
-      // search = -H^-1 grad : forward with register rows, backward with LDS rows
       LANES { search[lane] = lane < nv ? grad[lane] : 0.f; }
-#pragma unroll
-      for (int k = 0; k < NVP; k++) {
-        const float xk = wave_read(search, k) * wave_read(dinv, k);
-        LANES {
-          if (lane == k) search[lane] = xk;
-          else if (lane > k && lane < NVP) search[lane] -= hrow[lane][k] * xk;
-        }
-      }
-      for (int k = NVP - 1; k >= 0; k--) {
-        const float xk = wave_read(search, k) * wave_read(dinv, k);
-        LANES {
-          if (lane == k) search[lane] = xk;
-          else if (lane < k) search[lane] -= s.u.n.H[k][lane] * xk;
-        }
-      }
+      chol_solve_H(search);
+      TICK(SMJ_PROF_N_CHOL)
       PL<float> sq;
       LANES { search[lane] = lane < nv ? -search[lane] : 0.f; sq[lane] = search[lane] * search[lane]; }
       const float snorm = sqrtf(wave_sum(sq));
@@ -1712,11 +1845,7 @@ struct StepKernel {
     TICK(SMJ_PROF_PGS)
     // final forces at the accepted point, qfrc_constraint = J' f
     newton_update(nr, false);
-    LANES { tmpv[lane] = 0.f; }
-    for (int r = 0; r < ne; r++) {
-      const float fr = wave_read(nr.force, r);
-      LANES { if (lane < nv) tmpv[lane] += s.J[r][lane] * fr; }
-    }
+    matT_J(tmpv, nr.force);
     LANES {
       qacc_r[lane] = lane < nv ? qacc[lane] : 0.f;
       if (lane < nv) { s.qacc[lane] = qacc[lane]; s.warm[lane] = qacc[lane]; s.tmp[lane] = g_r[lane] + tmpv[lane]; }
@@ -1733,37 +1862,45 @@ struct StepKernel {
 #undef TICK
   }
 
-  // ------------------------------------------------------------------ B.8 implicitfast integrate
-  SMJ_DEV void integrate() {
-    const int nv = M.nv, nu = M.nu;
+  // dense symmetric NVP x NVP copy of M (implicit = false) or of M - h*D (implicit = true) into s.u.n.H, identity padded
+  SMJ_DEV void build_dense(bool implicit) {
     const float h = M.timestep;
-    // qH = M - h*D on the sparse pattern, written over the (dead) L storage; D: dof damping + actuator velocity bias
+    EntryTab et;
+    load(et, implicit);
     LANES {
-      for (int t = 0; t < 5; t++) {
-        const int i = e_i[lane][t], j = e_j[lane][t];
-        if (i < 0) continue;
-        float v = (i == j) ? s.Mdiag[i] + h * M.dof_damping[i] : s.MM[j][i];
-        for (int a = 0; a < nu; a++) {
-          if (M.actuator_biastype[a] != 1) continue;
-          const float bv = M.actuator_biasprm[3 * a + 2];
-          if (bv == 0.f) continue;
-          const float mi = M.k_act_moment[a * nv + i], mj = M.k_act_moment[a * nv + j];
-          if (mi == 0.f || mj == 0.f) continue;
-          if (M.actuator_forcelimited[a] &&
-              (s.act_force[a] <= M.actuator_forcerange[2 * a] || s.act_force[a] >= M.actuator_forcerange[2 * a + 1]))
-            continue;
-          v -= h * bv * mi * mj;
-        }
-        s.MM[i][j] = v;
+      for (int k = lane; k < NVP * (NVP + 1); k += 64) {
+        const int r = k / (NVP + 1), c = k - r * (NVP + 1);
+        (&s.u.n.H[0][0])[k] = (r == c && r >= M.nv) ? 1.f : 0.f;
       }
     }
     SYNC();
-    factor();
+    LANES {
+      for (int t = 0; t < 5; t++) {
+        const int i = et.i[lane][t], j = et.j[lane][t];
+        if (i < 0) continue;
+        float v = (i == j) ? s.Mdiag[i] : s.MM[j][i];
+        if (implicit) {
+          float d = et.damp[lane][t] - et.dcoef[lane][t];
+          const int la = et.lact[lane][t];
+          if (la >= 0) d -= et.lcoef[lane][t] * s.act_free[la];
+          v += h * d;
+        }
+        s.u.n.H[i][j] = v;
+        s.u.n.H[j][i] = v;
+      }
+    }
+    SYNC();
+  }
+
+  // ------------------------------------------------------------------ B.8 implicitfast integrate
+  // (M - h*D) qacc' = qfrc_smooth + qfrc_constraint, D = d(passive + actuator force)/d(qvel)  ([MJ] mj_implicit, fast)
+  SMJ_DEV void integrate() {
+    const int nv = M.nv;
+    const float h = M.timestep;
+    build_dense(true);
     PL<float> x;
     LANES { x[lane] = lane < nv ? s.tmp[lane] : 0.f; }
-    solve_LT(x);
-    LANES { if (lane < nv) x[lane] *= s.Dinv[lane]; }
-    solve_L(x);
+    chol_solve_H(x);
     LANES {
       if (lane < nv) s.qvel[lane] += h * x[lane];
     }
@@ -1982,7 +2119,7 @@ struct StepKernel {
       TICK(SMJ_PROF_COMCRB)
       smooth_forces(last);
       TICK(SMJ_PROF_SMOOTH)
-      factor();
+      if (M.solver != 2) factor();   // the sparse L'DL of M is only needed by the PGS path (Y = J L^-1)
       TICK(SMJ_PROF_FACTOR)
       collision();
       if (last) dump_contacts();

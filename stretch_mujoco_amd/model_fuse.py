@@ -226,6 +226,46 @@ def kernel_tables(f: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
                 mom[a, f["jnt_dofadr"][f["wrap_objid"][w]]] += gear * f["wrap_prm"][w]
     f["k_act_moment"] = mom
     f["k_nldl"] = np.array([int((f["k_ldl_i"] >= 0).sum())], np.int32)
+    # sparse views of the static moments: per actuator up to 4 (dof, moment) pairs, per dof up to 2 (actuator, moment)
+    adof = np.full((max(nu, 1), 4), -1, np.int32); amom = np.zeros((max(nu, 1), 4))
+    dact = np.full((nv, 2), -1, np.int32); dmom = np.zeros((nv, 2))
+    for a in range(nu):
+        nz = np.nonzero(mom[a])[0]
+        if len(nz) > 4:
+            raise ValueError("actuator transmission touches more than 4 dofs")
+        adof[a, :len(nz)] = nz; amom[a, :len(nz)] = mom[a, nz]
+    for k in range(nv):
+        nz = np.nonzero(mom[:nu, k])[0] if nu else []
+        if len(nz) > 2:
+            raise ValueError("more than 2 actuators on one dof")
+        dact[k, :len(nz)] = nz; dmom[k, :len(nz)] = mom[nz, k]
+    f["k_act_dof"], f["k_act_mom"], f["k_dof_act"], f["k_dof_actmom"] = adof, amom, dact, dmom
+    if any(f["body_jntnum"][b] > 2 for b in range(1, nb)):
+        raise ValueError("kernels support at most 2 joints per body (or one free joint)")
+    # implicitfast: d(qfrc)/d(qvel) on the mass-matrix pattern  ([MJ] mjd_smooth_vel, flg_bias=0).  Per pattern entry:
+    # dof damping (diagonal), the static part sum_a bv_a m_ai m_aj over actuators that can never be force-clamped, and
+    # for entries touched by ONE force-limited actuator its index and coefficient (skipped while its force is clamped)
+    ne_ = len(f["k_ldl_i"])
+    damp = np.zeros(ne_); dco = np.zeros(ne_); lact = np.full(ne_, -1, np.int32); lco = np.zeros(ne_)
+    for e in range(ne_):
+        i, j = int(f["k_ldl_i"][e]), int(f["k_ldl_j"][e])
+        if i < 0:
+            continue
+        if i == j:
+            damp[e] = f["dof_damping"][i]
+        for a in range(nu):
+            if f["actuator_biastype"][a] != 1:
+                continue
+            c = f["actuator_biasprm"][a][2] * mom[a, i] * mom[a, j]
+            if c == 0:
+                continue
+            if f["actuator_forcelimited"][a]:
+                if lact[e] >= 0:
+                    raise ValueError("two force-limited actuators share a mass-matrix entry: not supported")
+                lact[e], lco[e] = a, c
+            else:
+                dco[e] += c
+    f["k_ldl_damp"], f["k_ldl_dcoef"], f["k_ldl_lact"], f["k_ldl_lcoef"] = damp, dco, lact, lco
     # geoms the lidar rays are tested against this round: visible (alpha != 0) planes and primitives
     gob = f.get("geom_origbody", f["geom_bodyid"])
     rg = [g for g in range(ng) if f["geom_type"][g] != 7 and f["geom_rgba"][g][3] != 0]

@@ -40,6 +40,8 @@ def stage_parity(nsteps=1):
 def profile(B, random_ctrl, steps=50, solver="pgs"):
     sim = StretchBatchSimulator(num_envs=B, device="cuda:0", debug=True, solver=solver)
     sim.start(home=False)
+    import os
+    if os.environ.get("SMJ_REP"): sim.set_option("pgs_fixed_iter", int(os.environ["SMJ_REP"]))
     dev = sim.device
     sim.ctrl[:] = torch.tensor(sim.model["key_ctrl"][0, :10], dtype=torch.float32, device=dev).unsqueeze(1)
     sim.step(500)
