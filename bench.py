@@ -89,13 +89,24 @@ def main():
 
     # settle at the home keyframe
     sim.ctrl[:] = torch.tensor(sim.model["key_ctrl"][0, : sim.nu], dtype=torch.float32, device=dev).unsqueeze(1)
-    sim.step(500)
     hold = max(1, args.hold)
+    all_events = []   # every smj_step_kernel launch of this process (what `rocprofv3 --stats` averages over)
+
+    def timed_step(k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        sim.step(k)
+        e1.record()
+        all_events.append((e0, e1, k))
+        return e0, e1
+
+    for _ in range(500 // hold):
+        timed_step(hold)
     done = 0
     while done < args.warmup:
         k = min(hold, args.warmup - done)
         random_action()
-        sim.step(k)
+        timed_step(k)
         done += k
     returns = torch.zeros(B, device=dev)
     events = []
@@ -112,10 +123,7 @@ def main():
     while done < args.steps:
         k = min(hold, args.steps - done)
         random_action()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        sim.step(k)
-        e1.record()
+        e0, e1 = timed_step(k)
         events.append((e0, e1, k))
         returns += sim.base_pose[0]  # synthetic per-env return: accumulated forward displacement
         done += k
@@ -135,6 +143,14 @@ def main():
         per_launch_envsteps = B * hold
         avg_launch_s = (kern_ms / 1e3) / max(1, len(events))
         achieved = per_launch_envsteps * BYTES_PER_ENV_STEP / avg_launch_s / 1e9
+        all_ms = [a.elapsed_time(b) for a, b, _ in all_events][1:]   # the first launch also pays the one-time code-object load
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path):   # HBM bytes per launch measured with rocprofv3 --pmc on this same command
+            with open(pmc_path) as f:
+                pm = json.load(f)
+            if pm.get("envs_per_gpu") == B and pm.get("steps_per_launch") == hold and pm.get("solver") == args.solver:
+                traffic = pm["hbm_bytes_per_launch"]
         out = {
             "metric": "env-steps/sec (whole node), 4096 parallel Stretch envs per MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -147,7 +163,10 @@ def main():
                        "envs_per_gpu": B, "steps_per_launch": hold, "parallelism": f"env-sharded x{world}",
                        "returns_gathered": int(all_returns.numel()), "overflow_flags": flags},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "all_launches": {"count": len(all_ms), "avg_ms": sum(all_ms) / len(all_ms), "ms": [round(x, 2) for x in all_ms],
+                                          "note": "settle + warmup + timed launches except the very first (code-object load): the population "
+                                                  "rocprofv3 --stats averages (profiles/r01_rocprof_summary.md)"},
                          "kernel": "smj_step_kernel", "avg_launch_ms": avg_launch_s * 1e3,
                          "us_per_env_step_latency": avg_launch_s * 1e6 / hold,
                          "note": "algorithmic bytes = 672 B/env-step x envs x steps per launch; the path is "
