@@ -82,6 +82,7 @@ struct smjo_model {
   int *pair_geom1, *pair_geom2, *pair_condim;
   double *pair_friction, *pair_solref, *pair_solimp, *pair_margin, *pair_gap;
   int imu_site, *lidar_site;
+  double* lidar_static;
 };
 
 typedef struct {
@@ -131,6 +132,7 @@ smjo_model* smjo_load(const void* blob, size_t nbytes) {
   ti = blob_i32(b, "opt_cone", NULL); m->cone = ti[0]; free(ti);
   ti = blob_i32(b, "sensor_imu_site", NULL); m->imu_site = ti[0]; free(ti);
   m->lidar_site = blob_i32(b, "sensor_lidar_site", &m->nlidar);
+  m->lidar_static = blob_f64(b, "sensor_lidar_static", NULL);
   m->warmstart = 1; m->pgs_fixed_iter = 0; m->max_con_pair = 4; m->solver = 0; m->ls_iterations = 50; m->ls_tolerance = 0.01;
   LOADI(body_parentid); LOADI(body_weldid); LOADI(body_rootid); LOADI(body_jntadr); LOADI(body_jntnum);
   LOADI(body_dofadr); LOADI(body_dofnum);
@@ -1544,9 +1546,12 @@ void smjo_sensors(const smjo_model* m, smjo_data* d, int with_lidar) {
     for (int i = 0; i < m->nlidar; i++) {
       int s = m->lidar_site[i], sb = m->site_bodyid[s];
       const double* R = d->site_xmat + 9 * s;
-      double vec[3] = {R[2], R[5], R[8]}, best = -1;
+      /* geoms in the laser's weld group: state-independent hits ray-cast by the model compiler against the triangle
+       * meshes (sensor_lidar_static); all other geoms: plane and primitives at run time (meshes on moving bodies are
+       * outside this round's scope) */
+      double vec[3] = {R[2], R[5], R[8]}, best = m->lidar_static[i];
       for (int g = 0; g < m->ngeom; g++) {
-        if (m->geom_bodyid[g] == sb || m->geom_rgba[4 * g + 3] == 0) continue;
+        if (m->body_weldid[m->geom_bodyid[g]] == m->body_weldid[sb] || m->geom_rgba[4 * g + 3] == 0) continue;
         double x = ray_geom(m, d, g, d->site_xpos + 3 * s, vec);
         if (x >= 0 && (best < 0 || x < best)) best = x;
       }

@@ -2055,10 +2055,12 @@ struct StepKernel {
           for (int k = 0; k < 3; k++) pnt[k] += s.xpos[b][k];
           const float lz[3] = {M.k_site_mat[9 * sid + 2], M.k_site_mat[9 * sid + 5], M.k_site_mat[9 * sid + 8]};
           mulmat3vec(vec, s.xmat[b], lz);
-          float best = -1.f;
+          // geoms rigidly attached to the laser (its weld group) were ray-cast once by the model compiler against their
+          // true triangle meshes: state-independent distance per ray (the mast occludes rays 290-306 at 0.13-0.15 m)
+          float best = M.sensor_lidar_static[i];
           for (int t = 0; t < M.nraygeom; t++) {
             const int g = M.k_ray_geom[t];
-            if (M.k_ray_geom_origbody[t] == M.k_site_origbody[sid]) continue;  // bodyexclude = the site's own body
+            if (M.geom_bodyid[g] == b) continue;   // same weld group: covered by the static table (incl. the site's own body)
             const float x = ray_geom(g, pnt, vec);
             if (x >= 0 && (best < 0 || x < best)) best = x;
           }

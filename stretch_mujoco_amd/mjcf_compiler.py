@@ -223,6 +223,69 @@ def convex_hull_vertices(verts):
         return v[np.sort(hull.vertices)]
 
 
+def ray_triangles(orig, dirs, tri, chunk=20000):
+    """Nearest hit distance of rays (orig [R,3], unit dirs [R,3]) with triangles tri [T,3,3]; -1 where none.
+    Moeller-Trumbore, both faces, vectorised over rays x triangles in chunks."""
+    R = len(orig)
+    best = np.full(R, np.inf)
+    for s0 in range(0, len(tri), chunk):
+        t = tri[s0:s0 + chunk]
+        v0, e1, e2 = t[:, 0], t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]
+        for r in range(R):
+            p = np.cross(dirs[r], e2)
+            det = np.einsum("ij,ij->i", e1, p)
+            ok = np.abs(det) > 1e-20
+            inv = np.where(ok, 1.0 / np.where(ok, det, 1.0), 0.0)
+            tv = orig[r] - v0
+            u = np.einsum("ij,ij->i", tv, p) * inv
+            q = np.cross(tv, e1)
+            v = (q @ dirs[r]) * inv
+            x = np.einsum("ij,ij->i", e2, q) * inv
+            hit = ok & (u >= 0) & (v >= 0) & (u + v <= 1) & (x >= 0)
+            if hit.any():
+                best[r] = min(best[r], x[hit].min())
+    return np.where(np.isfinite(best), best, -1.0)
+
+
+def _ray_primitive(t, size, lp, lv):
+    """[MJ] mj_rayGeom for plane/sphere/cylinder/box in the geom frame (same rules as the kernels); -1 if no hit."""
+    def quad(a, b, c):
+        det = b * b - a * c
+        if det < MINVAL:
+            return -1.0
+        det = math.sqrt(det)
+        x0, x1 = (-b - det) / a, (-b + det) / a
+        return x0 if x0 >= 0 else (x1 if x1 >= 0 else -1.0)
+
+    if t == GEOM_SPHERE:
+        return quad(lv @ lv, lv @ lp, lp @ lp - size[0] ** 2)
+    if t == GEOM_CYLINDER:
+        best = -1.0
+        a, b, c = lv[0] ** 2 + lv[1] ** 2, lv[0] * lp[0] + lv[1] * lp[1], lp[0] ** 2 + lp[1] ** 2 - size[0] ** 2
+        if a > MINVAL:
+            x = quad(a, b, c)
+            if x >= 0 and abs(lp[2] + x * lv[2]) <= size[1]:
+                best = x
+        if abs(lv[2]) > MINVAL:
+            for sg in (-1, 1):
+                x = (sg * size[1] - lp[2]) / lv[2]
+                if x >= 0 and (lp[0] + x * lv[0]) ** 2 + (lp[1] + x * lv[1]) ** 2 <= size[0] ** 2 and (best < 0 or x < best):
+                    best = x
+        return best
+    if t == GEOM_BOX:
+        best = -1.0
+        for ax in range(3):
+            if abs(lv[ax]) < MINVAL:
+                continue
+            for sg in (-1, 1):
+                x = (sg * size[ax] - lp[ax]) / lv[ax]
+                a1, a2 = (ax + 1) % 3, (ax + 2) % 3
+                if x >= 0 and abs(lp[a1] + x * lv[a1]) <= size[a1] and abs(lp[a2] + x * lv[a2]) <= size[a2] and (best < 0 or x < best):
+                    best = x
+        return best
+    return -1.0
+
+
 # ----------------------------------------------------------------------------- defaults
 _GEOM_DEF = dict(type="sphere", size="0 0 0", pos="0 0 0", contype="1", conaffinity="1", condim="3", group="0",
                  priority="0", friction="1 0.005 0.0001", solmix="1", solref="0.02 1",
@@ -371,6 +434,7 @@ class MjcfCompiler:
         self.stat_extent: Optional[float] = None
         self.znear, self.zfar = 0.01, 50.0
         self.meshes_missing: List[str] = []
+        self._geom_mesh_names: List[Optional[str]] = []
 
     # ---- parsing
     def parse_file(self, path: str):
@@ -522,6 +586,10 @@ class MjcfCompiler:
                     raise ValueError("<inertial> not supported")
             else:
                 raise ValueError(f"unsupported element <{ch.tag}> in body")
+
+    def _lidar_static(self, m, mesh_cache, G):
+        sites = list(m["sensor_lidar_site"])
+        return _lidar_static_impl(m, mesh_cache, self._geom_mesh_names, sites)
 
     # ---- compile
     def compile(self) -> Dict[str, np.ndarray]:
@@ -727,6 +795,7 @@ class MjcfCompiler:
                 G["rgba"].append(rgba); G["rbound"].append(rb); G["center"].append(cen); G["aabb"].append(aabb)
                 G["hulladr"].append(adr); G["hullnum"].append(num); G["meshid"].append(meshid)
                 G["name"].append(g.get("name", ""))
+                self._geom_mesh_names.append(g.get("mesh") if t == GEOM_MESH else None)
             if parts:
                 M = sum(p[0] for p in parts)
                 c = sum(p[0] * p[1] for p in parts) / M
@@ -917,6 +986,7 @@ class MjcfCompiler:
                      missing_meshes=self.meshes_missing)
         m["names_json"] = np.frombuffer(json.dumps(names).encode(), np.uint8)
         _set_const(m)
+        m["sensor_lidar_static"] = self._lidar_static(m, mesh_cache, G)
         # per-body gravity-compensation mass/point and per-geom invweight0 are carried explicitly so that
         # static-body fusion (model_fuse.py) preserves them exactly
         m["body_gcmass"] = m["body_mass"] * m["body_gravcomp"]
@@ -926,6 +996,59 @@ class MjcfCompiler:
 
 
 # ----------------------------------------------------------------------------- constants at qpos0
+def _lidar_static_impl(m, mesh_cache, G_mesh_names, lidar_sites):
+    """Distance of every lidar ray to the geoms that are rigidly attached to the laser (same weld group, i.e. no joint
+    in between): these hits do not depend on the state, so they are ray-cast ONCE here against the true triangle
+    meshes ([MJ] mj_ray intersects mesh geoms by their triangles, in all groups, skipping the site's own body and
+    geoms with alpha 0) and stored per ray.  -1 = no static hit."""
+    n = len(lidar_sites)
+    out = np.full(n, -1.0)
+    if n == 0:
+        return out
+    xpos, xquat, _, _ = _fk(m, m["qpos0"])
+    sb = m["site_bodyid"][lidar_sites[0]]
+    weld = m["body_weldid"][sb]
+    orig = np.zeros((n, 3)); dirs = np.zeros((n, 3))
+    for i, sid in enumerate(lidar_sites):
+        b = m["site_bodyid"][sid]
+        R = quat2mat(xquat[b])
+        orig[i] = xpos[b] + R @ m["site_pos"][sid]
+        dirs[i] = (R @ quat2mat(m["site_quat"][sid]))[:, 2]
+    best = np.full(n, np.inf)
+    for g in range(len(m["geom_type"])):
+        b = m["geom_bodyid"][g]
+        if m["body_weldid"][b] != weld or b == sb or m["geom_rgba"][g][3] == 0:
+            continue
+        Rb = quat2mat(xquat[b])
+        gp = xpos[b] + Rb @ m["geom_pos"][g]
+        Rg = Rb @ quat2mat(m["geom_quat"][g])
+        lo = (orig - gp) @ Rg       # rays in the geom frame
+        ld = dirs @ Rg
+        t = m["geom_type"][g]
+        if t == GEOM_MESH:
+            md = mesh_cache.get(G_mesh_names[g])
+            if md is None:
+                continue
+            cen, half = m["geom_aabb"][g][:3], m["geom_aabb"][g][3:] + 1e-9
+            # slab test against the mesh AABB to skip rays that cannot hit
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t1 = (cen - half - lo) / ld; t2 = (cen + half - lo) / ld
+            tmin = np.nanmax(np.minimum(t1, t2), axis=1); tmax = np.nanmin(np.maximum(t1, t2), axis=1)
+            cand = np.nonzero((tmax >= np.maximum(tmin, 0)))[0]
+            if len(cand) == 0:
+                continue
+            tri = md["v"][md["f"]]
+            d = ray_triangles(lo[cand], ld[cand], tri)
+            hit = d >= 0
+            best[cand[hit]] = np.minimum(best[cand[hit]], d[hit])
+        elif t != GEOM_PLANE:
+            for i in range(n):
+                x = _ray_primitive(t, m["geom_size"][g], lo[i], ld[i])
+                if x >= 0:
+                    best[i] = min(best[i], x)
+    return np.where(np.isfinite(best), best, -1.0)
+
+
 def _fk(m, qpos):
     nbody = len(m["body_parentid"])
     xpos = np.zeros((nbody, 3)); xquat = np.tile([1.0, 0, 0, 0], (nbody, 1))

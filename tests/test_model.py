@@ -113,3 +113,32 @@ def test_mesh_inertia_of_a_cube_mesh(tmp_path):
         assert vol == pytest.approx(0.2 * 0.4 * 0.6, rel=1e-12)
         np.testing.assert_allclose(com, 0, atol=1e-14)
         np.testing.assert_allclose(np.diag(I), [vol / 3 * (.04 + .09), vol / 3 * (.01 + .09), vol / 3 * (.01 + .04)], rtol=1e-12)
+
+
+def test_static_lidar_table_sees_the_mast(blob_full):
+    """The compiler ray-casts the lidar against the meshes welded to the laser.  Independent check: the mast
+    (link_mast.obj: a 26.2 x 38.1 mm tube, stretch.xml:245-248) seen from the laser (stretch.xml:274) by a 2-D
+    ray / rectangle intersection written here from the MJCF numbers."""
+    m = B.loads(blob_full)
+    L = m["sensor_lidar_static"]
+    assert L.shape == (360,)
+    cx, cy, hx, hy = -0.067, 0.135, 0.013094, 0.019063     # body pos; quat (1 1 0 0) maps mesh -z -> +y
+    ox, oy = 0.004, 0.0                                     # laser body origin in base_link
+    hits = 0
+    for i in range(360):
+        a = np.deg2rad(i) * (0.0174533 / np.deg2rad(1.0)) + np.pi   # laser body is yawed 180 deg
+        dx, dy = np.cos(a), np.sin(a)
+        t0, t1 = -np.inf, np.inf
+        for o, d, lo, hi in ((ox, dx, cx - hx, cx + hx), (oy, dy, cy - hy, cy + hy)):
+            if abs(d) < 1e-12:
+                if not lo <= o <= hi:
+                    t0, t1 = 1, 0
+                continue
+            a0, a1 = (lo - o) / d, (hi - o) / d
+            t0, t1 = max(t0, min(a0, a1)), min(t1, max(a0, a1))
+        if t1 >= max(t0, 0):
+            hits += 1
+            assert L[i] == pytest.approx(t0, abs=1e-4), i
+        elif L[i] >= 0:
+            assert L[i] > 0.02   # some other welded geom; must not be the laser's own body
+    assert 15 <= hits <= 19 and (L >= 0).sum() >= hits
