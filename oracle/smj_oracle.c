@@ -69,7 +69,8 @@ struct smjo_model {
   double *dof_armature, *dof_damping, *dof_frictionloss, *dof_invweight0, *dof_solref, *dof_solimp;
   double *qpos0, *qpos_spring;
   int *geom_type, *geom_bodyid, *geom_hulladr, *geom_hullnum;
-  double *geom_pos, *geom_quat, *geom_size, *geom_rbound, *geom_center, *geom_rgba, *hull_vert;
+  double *geom_pos, *geom_quat, *geom_size, *geom_rbound, *geom_center, *geom_rgba, *hull_vert, *geom_aabb, *geom_ccenter;
+  int convex_pairs; /* 1: evaluate non-plane pairs with MPR */
   int *site_bodyid, *cam_bodyid;
   double *site_pos, *site_quat, *cam_pos, *cam_quat, *cam_fovy;
   int *tendon_adr, *tendon_num, *wrap_objid;
@@ -148,7 +149,8 @@ smjo_model* smjo_load(const void* blob, size_t nbytes) {
   LOADF(qpos0); LOADF(qpos_spring);
   LOADI(geom_type); LOADI(geom_bodyid); LOADI(geom_hulladr); LOADI(geom_hullnum);
   LOADF(geom_pos); LOADF(geom_quat); LOADF(geom_size); LOADF(geom_rbound); LOADF(geom_center); LOADF(geom_rgba);
-  LOADF(hull_vert);
+  LOADF(hull_vert); LOADF(geom_aabb); LOADF(geom_ccenter);
+  m->convex_pairs = 1;
   LOADI(site_bodyid); LOADI(cam_bodyid); LOADF(site_pos); LOADF(site_quat); LOADF(cam_pos); LOADF(cam_quat);
   LOADF(cam_fovy);
   LOADI(tendon_adr); LOADI(tendon_num); LOADI(wrap_objid); LOADF(wrap_prm);
@@ -172,6 +174,7 @@ int smjo_set_option(smjo_model* m, const char* name, double v) {
   else if (!strcmp(name, "pgs_fixed_iter")) m->pgs_fixed_iter = (int)v;
   else if (!strcmp(name, "max_contacts_per_pair")) m->max_con_pair = (int)v;
   else if (!strcmp(name, "solver")) m->solver = (int)v; /* 0 = PGS (north_star), 2 = Newton (the reference model's default) */
+  else if (!strcmp(name, "convex_pairs")) m->convex_pairs = (int)v;
   else if (!strcmp(name, "timestep")) m->timestep = v;
   else if (!strcmp(name, "gravity_z")) m->gravity[2] = v;
   else if (!strcmp(name, "impratio")) m->impratio = v;
@@ -711,6 +714,234 @@ static int plane_hull(const double* ppos, const double* pmat, const double* gpos
   return cnt;
 }
 
+
+/* ---- convex-convex narrowphase: Minkowski Portal Refinement, restating libccd's ccdMPRPenetration (mpr.c), the
+ * routine MuJoCo 3.2.6's mjc_Convex calls for mesh / cylinder / box pairs without an analytic function
+ * ([MJ]; libccd is a third-party dependency of mujoco, not in /root/reference).  One contact per pair (MuJoCo's
+ * multiccd adds up to three more by re-running with a perturbed normal: not restated).  mpr_tolerance 1e-6,
+ * mpr_iterations 50 are MuJoCo's option defaults. */
+typedef struct { double v[3], a[3], b[3]; } mprpt;
+typedef struct {
+  const smjo_model* m;
+  int g[2], type[2], nvert[2];
+  const double *pos[2], *mat[2], *size[2], *verts[2];
+} mprctx;
+
+static void shape_support(const mprctx* c, int k, const double* dir, double* out) {
+  double dl[3], pl[3] = {0, 0, 0};
+  mulmat3Tvec(dl, c->mat[k], dir);
+  const double* sz = c->size[k];
+  int t = c->type[k];
+  if (t == G_SPHERE) { double n = norm3(dl); if (n > MINVAL) for (int i = 0; i < 3; i++) pl[i] = sz[0] * dl[i] / n; }
+  else if (t == G_BOX) { for (int i = 0; i < 3; i++) pl[i] = dl[i] >= 0 ? sz[i] : -sz[i]; }
+  else if (t == G_CYLINDER) {
+    double n = sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
+    if (n > MINVAL) { pl[0] = sz[0] * dl[0] / n; pl[1] = sz[0] * dl[1] / n; }
+    pl[2] = dl[2] >= 0 ? sz[1] : -sz[1];
+  } else if (t == G_MESH) {
+    int best = 0;
+    double bd = -1e300;
+    for (int i = 0; i < c->nvert[k]; i++) {
+      double d = dot3(c->verts[k] + 3 * i, dl);
+      if (d > bd) { bd = d; best = i; }
+    }
+    memcpy(pl, c->verts[k] + 3 * best, 24);
+  }
+  mulmat3vec(out, c->mat[k], pl);
+  for (int i = 0; i < 3; i++) out[i] += c->pos[k][i];
+}
+static void mpr_support(const mprctx* c, const double* dir, mprpt* p) {
+  double nd[3] = {-dir[0], -dir[1], -dir[2]};
+  shape_support(c, 0, dir, p->a);
+  shape_support(c, 1, nd, p->b);
+  for (int i = 0; i < 3; i++) p->v[i] = p->a[i] - p->b[i];
+}
+#define CCD_EPS 2.220446049250313e-16
+static int ccd_zero(double x) { return fabs(x) < CCD_EPS; }
+static int ccd_eq(double a, double b) {
+  double ab = fabs(a - b);
+  if (ab < CCD_EPS) return 1;
+  double aa = fabs(a), bb = fabs(b);
+  return ab < CCD_EPS * (bb > aa ? bb : aa);
+}
+static void portal_dir(const mprpt* P, double* dir) {
+  double a[3], b[3];
+  for (int i = 0; i < 3; i++) { a[i] = P[2].v[i] - P[1].v[i]; b[i] = P[3].v[i] - P[1].v[i]; }
+  cross3(dir, a, b);
+  double n = norm3(dir);
+  if (n > 0) for (int i = 0; i < 3; i++) dir[i] /= n;
+}
+static void expand_portal(mprpt* P, const mprpt* v4) {
+  double v4v0[3];
+  cross3(v4v0, v4->v, P[0].v);
+  if (dot3(P[1].v, v4v0) > 0) { if (dot3(P[2].v, v4v0) > 0) P[1] = *v4; else P[3] = *v4; }
+  else { if (dot3(P[3].v, v4v0) > 0) P[2] = *v4; else P[1] = *v4; }
+}
+static int reach_tolerance(const mprpt* P, const mprpt* v4, const double* dir, double tol) {
+  double dv4 = dot3(v4->v, dir), d1 = dv4 - dot3(P[1].v, dir), d2 = dv4 - dot3(P[2].v, dir), d3 = dv4 - dot3(P[3].v, dir);
+  double d = fmin(d1, fmin(d2, d3));
+  return ccd_eq(d, tol) || d < tol;
+}
+/* squared distance from the origin to triangle (a,b,c), closest point in w  (libccd ccdVec3PointTriDist2) */
+static double origin_tri_dist2(const double* a, const double* b, const double* c, double* w) {
+  double d1[3], d2[3], av[3];
+  for (int i = 0; i < 3; i++) { d1[i] = b[i] - a[i]; d2[i] = c[i] - a[i]; av[i] = a[i]; }
+  double u = dot3(av, av), v = dot3(d1, d1), ww = dot3(d2, d2), p = dot3(av, d1), q = dot3(av, d2), r = dot3(d1, d2);
+  double den = ww * v - r * r, s = 0, t = 0, best = -1;
+  if (!ccd_zero(den)) { s = (q * r - ww * p) / den; t = (-s * r - q) / ww; } else s = t = -1;
+  if ((ccd_zero(s) || s > 0) && (ccd_eq(s, 1) || s < 1) && (ccd_zero(t) || t > 0) && (ccd_eq(t, 1) || t < 1) && (ccd_eq(t + s, 1) || t + s < 1)) {
+    for (int i = 0; i < 3; i++) w[i] = a[i] + s * d1[i] + t * d2[i];
+    return u + s * s * v + t * t * ww + 2 * s * p + 2 * t * q + 2 * s * t * r;
+  }
+  const double* seg[3][2] = {{a, b}, {a, c}, {b, c}};
+  for (int e = 0; e < 3; e++) {
+    double dd[3], tt, wp[3];
+    for (int i = 0; i < 3; i++) dd[i] = seg[e][1][i] - seg[e][0][i];
+    double l2 = dot3(dd, dd);
+    tt = l2 > 0 ? -dot3(seg[e][0], dd) / l2 : 0;
+    tt = tt < 0 ? 0 : (tt > 1 ? 1 : tt);
+    for (int i = 0; i < 3; i++) wp[i] = seg[e][0][i] + tt * dd[i];
+    double dist = dot3(wp, wp);
+    if (best < 0 || dist < best) { best = dist; memcpy(w, wp, 24); }
+  }
+  return best;
+}
+/* returns 1 and (depth, dir, pos) if the shapes penetrate */
+static int mpr_penetration(const mprctx* c, const double* c0, const double* c1, double* depth, double* pdir, double* pos) {
+  const double tol = 1e-6;
+  const int maxit = 50;
+  mprpt P[4], v4;
+  double dir[3], va[3], vb[3], dot;
+  for (int i = 0; i < 3; i++) { P[0].a[i] = c0[i]; P[0].b[i] = c1[i]; P[0].v[i] = c0[i] - c1[i]; }
+  if (ccd_zero(P[0].v[0]) && ccd_zero(P[0].v[1]) && ccd_zero(P[0].v[2])) P[0].v[0] += CCD_EPS * 10;
+  for (int i = 0; i < 3; i++) dir[i] = -P[0].v[i];
+  normalize3(dir);
+  mpr_support(c, dir, &P[1]);
+  dot = dot3(P[1].v, dir);
+  if (ccd_zero(dot) || dot < 0) return 0;
+  cross3(dir, P[0].v, P[1].v);
+  if (ccd_zero(dot3(dir, dir))) {
+    /* origin on v1 (touching) or on the v0-v1 segment: libccd findPenetrTouch / findPenetrSegment */
+    if (ccd_zero(P[1].v[0]) && ccd_zero(P[1].v[1]) && ccd_zero(P[1].v[2])) {
+      *depth = 0; pdir[0] = pdir[1] = pdir[2] = 0;
+    } else {
+      *depth = norm3(P[1].v);
+      for (int i = 0; i < 3; i++) pdir[i] = P[1].v[i];
+      normalize3(pdir);
+    }
+    for (int i = 0; i < 3; i++) pos[i] = 0.5 * (P[1].a[i] + P[1].b[i]);
+    return 1;
+  }
+  normalize3(dir);
+  mpr_support(c, dir, &P[2]);
+  dot = dot3(P[2].v, dir);
+  if (ccd_zero(dot) || dot < 0) return 0;
+  for (int i = 0; i < 3; i++) { va[i] = P[1].v[i] - P[0].v[i]; vb[i] = P[2].v[i] - P[0].v[i]; }
+  cross3(dir, va, vb);
+  normalize3(dir);
+  if (dot3(dir, P[0].v) > 0) { mprpt t = P[1]; P[1] = P[2]; P[2] = t; for (int i = 0; i < 3; i++) dir[i] = -dir[i]; }
+  for (int it = 0;; it++) {
+    if (it > 100) return 0;
+    mpr_support(c, dir, &P[3]);
+    dot = dot3(P[3].v, dir);
+    if (ccd_zero(dot) || dot < 0) return 0;
+    int cont = 0;
+    cross3(va, P[1].v, P[3].v);
+    dot = dot3(va, P[0].v);
+    if (dot < 0 && !ccd_zero(dot)) { P[2] = P[3]; cont = 1; }
+    if (!cont) {
+      cross3(va, P[3].v, P[2].v);
+      dot = dot3(va, P[0].v);
+      if (dot < 0 && !ccd_zero(dot)) { P[1] = P[3]; cont = 1; }
+    }
+    if (!cont) break;
+    for (int i = 0; i < 3; i++) { va[i] = P[1].v[i] - P[0].v[i]; vb[i] = P[2].v[i] - P[0].v[i]; }
+    cross3(dir, va, vb);
+    normalize3(dir);
+  }
+  /* refine portal */
+  for (int it = 0;; it++) {
+    portal_dir(P, dir);
+    dot = dot3(dir, P[1].v);
+    if (ccd_zero(dot) || dot > 0) break; /* origin inside */
+    mpr_support(c, dir, &v4);
+    dot = dot3(v4.v, dir);
+    if (!(ccd_zero(dot) || dot > 0) || reach_tolerance(P, &v4, dir, tol) || it > maxit) return 0;
+    expand_portal(P, &v4);
+  }
+  /* penetration info */
+  for (int it = 0;; it++) {
+    portal_dir(P, dir);
+    mpr_support(c, dir, &v4);
+    if (reach_tolerance(P, &v4, dir, tol) || it > maxit) {
+      *depth = sqrt(fmax(0.0, origin_tri_dist2(P[1].v, P[2].v, P[3].v, pdir)));
+      if (ccd_zero(pdir[0]) && ccd_zero(pdir[1]) && ccd_zero(pdir[2])) memcpy(pdir, dir, 24);
+      normalize3(pdir);
+      double b[4], vec[3], sum;
+      cross3(vec, P[1].v, P[2].v); b[0] = dot3(vec, P[3].v);
+      cross3(vec, P[3].v, P[2].v); b[1] = dot3(vec, P[0].v);
+      cross3(vec, P[0].v, P[1].v); b[2] = dot3(vec, P[3].v);
+      cross3(vec, P[2].v, P[1].v); b[3] = dot3(vec, P[0].v);
+      sum = b[0] + b[1] + b[2] + b[3];
+      if (ccd_zero(sum) || sum < 0) {
+        b[0] = 0;
+        cross3(vec, P[2].v, P[3].v); b[1] = dot3(vec, dir);
+        cross3(vec, P[3].v, P[1].v); b[2] = dot3(vec, dir);
+        cross3(vec, P[1].v, P[2].v); b[3] = dot3(vec, dir);
+        sum = b[1] + b[2] + b[3];
+      }
+      if (!(fabs(sum) > 1e-300)) { /* fully degenerate portal (exactly touching faces): use the portal vertex witnesses */
+        b[0] = 0; b[1] = b[2] = b[3] = 1; sum = 3;
+      }
+      for (int i = 0; i < 3; i++) {
+        double p1 = 0, p2 = 0;
+        for (int k = 0; k < 4; k++) { p1 += b[k] * P[k].a[i]; p2 += b[k] * P[k].b[i]; }
+        pos[i] = 0.5 * (p1 + p2) / sum;
+      }
+      return 1;
+    }
+    expand_portal(P, &v4);
+  }
+}
+
+/* broadphase for a non-plane pair: bounding spheres, then the 6 face axes of the two oriented bounding boxes */
+static int obb_overlap(const smjo_model* m, const smjo_data* d, int g1, int g2, double margin) {
+  const double *R1 = d->geom_xmat + 9 * g1, *R2 = d->geom_xmat + 9 * g2;
+  double c1[3], c2[3], dv[3];
+  mulmat3vec(c1, R1, m->geom_aabb + 6 * g1); mulmat3vec(c2, R2, m->geom_aabb + 6 * g2);
+  for (int k = 0; k < 3; k++) dv[k] = (d->geom_xpos[3 * g2 + k] + c2[k]) - (d->geom_xpos[3 * g1 + k] + c1[k]);
+  if (norm3(dv) > m->geom_rbound[g1] + m->geom_rbound[g2] + margin) return 0;
+  const double *h1 = m->geom_aabb + 6 * g1 + 3, *h2 = m->geom_aabb + 6 * g2 + 3;
+  for (int s = 0; s < 2; s++) {
+    const double *Ra = s ? R2 : R1, *Rb = s ? R1 : R2, *ha = s ? h2 : h1, *hb = s ? h1 : h2;
+    for (int k = 0; k < 3; k++) {
+      double ax[3] = {Ra[k], Ra[3 + k], Ra[6 + k]}, r = 0;
+      for (int j = 0; j < 3; j++) { double bj[3] = {Rb[j], Rb[3 + j], Rb[6 + j]}; r += fabs(dot3(ax, bj)) * hb[j]; }
+      if (fabs(dot3(ax, dv)) > ha[k] + r + margin) return 0;
+    }
+  }
+  return 1;
+}
+static int convex_pair(const smjo_model* m, const smjo_data* d, int g1, int g2, double margin, rawcon* rc) {
+  if (!obb_overlap(m, d, g1, g2, margin)) return 0;
+  mprctx c;
+  c.m = m;
+  double cen[2][3];
+  for (int k = 0; k < 2; k++) {
+    int g = k ? g2 : g1;
+    c.g[k] = g; c.type[k] = m->geom_type[g]; c.pos[k] = d->geom_xpos + 3 * g; c.mat[k] = d->geom_xmat + 9 * g;
+    c.size[k] = m->geom_size + 3 * g; c.verts[k] = m->hull_vert + 3 * (m->geom_hulladr[g] < 0 ? 0 : m->geom_hulladr[g]);
+    c.nvert[k] = m->geom_hullnum[g];
+    mulmat3vec(cen[k], c.mat[k], m->geom_ccenter + 3 * g);
+    for (int i = 0; i < 3; i++) cen[k][i] += c.pos[k][i];
+  }
+  double depth, dir[3], pos[3];
+  if (!mpr_penetration(&c, cen[0], cen[1], &depth, dir, pos)) return 0;
+  if (-depth > margin) return 0;
+  rc->dist = -depth; memcpy(rc->normal, dir, 24); memcpy(rc->pos, pos, 24);
+  return 1;
+}
+
 /* [MJ] mj_collision: static pair table (built by the model compiler with MuJoCo's filters) ->
  * bounding-sphere rejection -> narrowphase by type pair */
 static void collision(const smjo_model* m, smjo_data* d) {
@@ -735,7 +966,9 @@ static void collision(const smjo_model* m, smjo_data* d) {
         n = plane_hull(p1, R1, p2, R2, m->hull_vert + 3 * m->geom_hulladr[g2], m->geom_hullnum[g2], margin, m->max_con_pair, rc);
       else continue;
     } else {
-      continue; /* non-plane pairs: not yet on the restated path (DESIGN.md scope) */
+      if (!m->convex_pairs) continue;
+      n = convex_pair(m, d, g1, g2, margin, rc);
+      if (n && dot3(rc[0].normal, rc[0].normal) < 0.5) continue; /* degenerate touching contact without a direction */
     }
     for (int i = 0; i < n; i++) {
       if (d->ncon >= MAXCON) { d->ncon_dropped++; continue; }

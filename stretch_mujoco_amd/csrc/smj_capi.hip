@@ -169,6 +169,7 @@ int smj_set_option(smj_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "pgs_fixed_iter")) m.pgs_fixed_iter = (int)v;
   else if (!strcmp(name, "max_contacts_per_pair")) m.max_con_pair = (int)v;
   else if (!strcmp(name, "solver")) m.solver = (int)v;
+  else if (!strcmp(name, "convex_pairs")) m.convex_pairs = (int)v;
   else return fail(c, -1, "unknown option '%s'", name);
   return 0;
 }

@@ -29,6 +29,9 @@ struct Smem {
   union {
     float A[NEFC * NEFC];   // PGS: A = J M^-1 J' + R
     TreeTmp t;
+    struct {                // collision: world frames of the geoms taking part in convex pairs (tree temporaries are dead)
+      float pos[64][3], mat[64][9], cen[64][3];
+    } c;
     struct {                // Newton: XA = W J (row-weighted Jacobian) and the Hessian H = M + J' W J / its factor
       float XA[NEFC][JS];
       float H[NVP][NVP + 1];
@@ -906,6 +909,267 @@ struct StepKernel {
     PL<float> cand;
     LANES { cand[lane] = (key[lane] == val && idx[lane] >= 0) ? (float)idx[lane] : 3.0e38f; }
     return uni((int)wave_min(cand));
+  }
+
+
+  // ------------------------------------------------------------------ convex-convex narrowphase (MPR)
+  // Restates libccd's ccdMPRPenetration (the routine MuJoCo 3.2.6's mjc_Convex uses for mesh / cylinder / box pairs;
+  // third-party, not in /root/reference) with the same control flow as oracle/smj_oracle.c mpr_penetration.  Wave-uniform
+  // scalar logic; the hull support function is lane-parallel (vertices strided over lanes, arg-max by wave reduction).
+  struct Shape { int type, nvert; const float* verts; float pos[3], mat[9], size[3]; };
+  struct MprPt { float v[3], a[3], b[3]; };
+
+  SMJ_DEV void shape_support(const Shape& sh, const float* dir, float* out) {
+    float dl[3], pl[3] = {0, 0, 0};
+    mulmat3Tvec(dl, sh.mat, dir);
+    if (sh.type == GT_SPHERE) {
+      const float n = sqrtf(dot3(dl, dl));
+      if (n > SMJ_MINVAL) for (int i = 0; i < 3; i++) pl[i] = sh.size[0] * dl[i] / n;
+    } else if (sh.type == GT_BOX) {
+      for (int i = 0; i < 3; i++) pl[i] = dl[i] >= 0 ? sh.size[i] : -sh.size[i];
+    } else if (sh.type == GT_CYLINDER) {
+      const float n = sqrtf(dl[0] * dl[0] + dl[1] * dl[1]);
+      if (n > SMJ_MINVAL) { pl[0] = sh.size[0] * dl[0] / n; pl[1] = sh.size[0] * dl[1] / n; }
+      pl[2] = dl[2] >= 0 ? sh.size[1] : -sh.size[1];
+    } else {
+      PL<float> best;
+      PL<int> bidx;
+      const float* verts = sh.verts;
+      const int nvert = sh.nvert;
+      LANES {
+        float bd = -3.0e38f;
+        int bi = -1;
+        for (int i = lane; i < nvert; i += 64) {
+          const float d = verts[3 * i] * dl[0] + verts[3 * i + 1] * dl[1] + verts[3 * i + 2] * dl[2];
+          if (d > bd) { bd = d; bi = i; }
+        }
+        best[lane] = bd; bidx[lane] = bi;
+      }
+      const float mx = wave_max(best);
+      const int idx = pick_index(best, bidx, mx);
+      pl[0] = uni(verts[3 * idx]); pl[1] = uni(verts[3 * idx + 1]); pl[2] = uni(verts[3 * idx + 2]);
+    }
+    mulmat3vec(out, sh.mat, pl);
+    for (int i = 0; i < 3; i++) out[i] += sh.pos[i];
+  }
+  SMJ_DEV void mpr_support(const Shape& A, const Shape& Bs, const float* dir, MprPt& p) {
+    const float nd[3] = {-dir[0], -dir[1], -dir[2]};
+    shape_support(A, dir, p.a);
+    shape_support(Bs, nd, p.b);
+    for (int i = 0; i < 3; i++) p.v[i] = p.a[i] - p.b[i];
+  }
+  SMJ_DEV static bool ccd_zero(float x) { return fabsf(x) < 1.1920929e-7f; }
+  SMJ_DEV static bool ccd_eq(float a, float b) {
+    const float ab = fabsf(a - b);
+    if (ab < 1.1920929e-7f) return true;
+    return ab < 1.1920929e-7f * fmaxf(fabsf(a), fabsf(b));
+  }
+  SMJ_DEV static void portal_dir(const MprPt* P, float* dir) {
+    float a[3], b[3];
+    for (int i = 0; i < 3; i++) { a[i] = P[2].v[i] - P[1].v[i]; b[i] = P[3].v[i] - P[1].v[i]; }
+    cross3(dir, a, b);
+    const float n = sqrtf(dot3(dir, dir));
+    if (n > 0) for (int i = 0; i < 3; i++) dir[i] /= n;
+  }
+  SMJ_DEV static void expand_portal(MprPt* P, const MprPt& v4) {
+    float v4v0[3];
+    cross3(v4v0, v4.v, P[0].v);
+    if (dot3(P[1].v, v4v0) > 0) { if (dot3(P[2].v, v4v0) > 0) P[1] = v4; else P[3] = v4; }
+    else { if (dot3(P[3].v, v4v0) > 0) P[2] = v4; else P[1] = v4; }
+  }
+  SMJ_DEV static bool reach_tolerance(const MprPt* P, const MprPt& v4, const float* dir, float tol) {
+    const float dv4 = dot3(v4.v, dir);
+    const float d = fminf(dv4 - dot3(P[1].v, dir), fminf(dv4 - dot3(P[2].v, dir), dv4 - dot3(P[3].v, dir)));
+    return ccd_eq(d, tol) || d < tol;
+  }
+  SMJ_DEV static float origin_tri_dist2(const float* a, const float* b, const float* c, float* w) {
+    float d1[3], d2[3];
+    for (int i = 0; i < 3; i++) { d1[i] = b[i] - a[i]; d2[i] = c[i] - a[i]; }
+    const float u = dot3(a, a), v = dot3(d1, d1), ww = dot3(d2, d2), p = dot3(a, d1), q = dot3(a, d2), r = dot3(d1, d2);
+    const float den = ww * v - r * r;
+    float sc = -1, t = -1;
+    if (!ccd_zero(den)) { sc = (q * r - ww * p) / den; t = (-sc * r - q) / ww; }
+    if ((ccd_zero(sc) || sc > 0) && (ccd_eq(sc, 1) || sc < 1) && (ccd_zero(t) || t > 0) && (ccd_eq(t, 1) || t < 1) && (ccd_eq(t + sc, 1) || t + sc < 1)) {
+      for (int i = 0; i < 3; i++) w[i] = a[i] + sc * d1[i] + t * d2[i];
+      return u + sc * sc * v + t * t * ww + 2 * sc * p + 2 * t * q + 2 * sc * t * r;
+    }
+    float best = -1;
+    for (int e = 0; e < 3; e++) {
+      const float* s0 = e == 2 ? b : a;
+      const float* s1 = e == 0 ? b : c;
+      float dd[3], wp[3];
+      for (int i = 0; i < 3; i++) dd[i] = s1[i] - s0[i];
+      const float l2 = dot3(dd, dd);
+      float tt = l2 > 0 ? -dot3(s0, dd) / l2 : 0.f;
+      tt = tt < 0 ? 0.f : (tt > 1 ? 1.f : tt);
+      for (int i = 0; i < 3; i++) wp[i] = s0[i] + tt * dd[i];
+      const float dist = dot3(wp, wp);
+      if (best < 0 || dist < best) { best = dist; for (int i = 0; i < 3; i++) w[i] = wp[i]; }
+    }
+    return best;
+  }
+  SMJ_DEV bool mpr_penetration(const Shape& A, const Shape& Bs, const float* c0, const float* c1, float& depth, float* pdir, float* pos) {
+    const float tol = 1e-6f;
+    const int maxit = 50;
+    MprPt P[4], v4;
+    float dir[3], va[3], vb[3], dot;
+    for (int i = 0; i < 3; i++) { P[0].a[i] = c0[i]; P[0].b[i] = c1[i]; P[0].v[i] = c0[i] - c1[i]; }
+    if (ccd_zero(P[0].v[0]) && ccd_zero(P[0].v[1]) && ccd_zero(P[0].v[2])) P[0].v[0] += 1.1920929e-6f;
+    for (int i = 0; i < 3; i++) dir[i] = -P[0].v[i];
+    normalize3(dir);
+    mpr_support(A, Bs, dir, P[1]);
+    dot = dot3(P[1].v, dir);
+    if (ccd_zero(dot) || dot < 0) return false;
+    cross3(dir, P[0].v, P[1].v);
+    if (ccd_zero(dot3(dir, dir))) {
+      if (ccd_zero(P[1].v[0]) && ccd_zero(P[1].v[1]) && ccd_zero(P[1].v[2])) { depth = 0; pdir[0] = pdir[1] = pdir[2] = 0; }
+      else {
+        depth = sqrtf(dot3(P[1].v, P[1].v));
+        for (int i = 0; i < 3; i++) pdir[i] = P[1].v[i];
+        normalize3(pdir);
+      }
+      for (int i = 0; i < 3; i++) pos[i] = 0.5f * (P[1].a[i] + P[1].b[i]);
+      return true;
+    }
+    normalize3(dir);
+    mpr_support(A, Bs, dir, P[2]);
+    dot = dot3(P[2].v, dir);
+    if (ccd_zero(dot) || dot < 0) return false;
+    for (int i = 0; i < 3; i++) { va[i] = P[1].v[i] - P[0].v[i]; vb[i] = P[2].v[i] - P[0].v[i]; }
+    cross3(dir, va, vb);
+    normalize3(dir);
+    if (dot3(dir, P[0].v) > 0) { const MprPt t = P[1]; P[1] = P[2]; P[2] = t; for (int i = 0; i < 3; i++) dir[i] = -dir[i]; }
+    for (int it = 0;; it++) {
+      if (it > 100) return false;
+      mpr_support(A, Bs, dir, P[3]);
+      dot = dot3(P[3].v, dir);
+      if (ccd_zero(dot) || dot < 0) return false;
+      bool cont = false;
+      cross3(va, P[1].v, P[3].v);
+      dot = dot3(va, P[0].v);
+      if (dot < 0 && !ccd_zero(dot)) { P[2] = P[3]; cont = true; }
+      if (!cont) {
+        cross3(va, P[3].v, P[2].v);
+        dot = dot3(va, P[0].v);
+        if (dot < 0 && !ccd_zero(dot)) { P[1] = P[3]; cont = true; }
+      }
+      if (!cont) break;
+      for (int i = 0; i < 3; i++) { va[i] = P[1].v[i] - P[0].v[i]; vb[i] = P[2].v[i] - P[0].v[i]; }
+      cross3(dir, va, vb);
+      normalize3(dir);
+    }
+    for (int it = 0;; it++) {
+      portal_dir(P, dir);
+      dot = dot3(dir, P[1].v);
+      if (ccd_zero(dot) || dot > 0) break;
+      mpr_support(A, Bs, dir, v4);
+      dot = dot3(v4.v, dir);
+      if (!(ccd_zero(dot) || dot > 0) || reach_tolerance(P, v4, dir, tol) || it > maxit) return false;
+      expand_portal(P, v4);
+    }
+    for (int it = 0;; it++) {
+      portal_dir(P, dir);
+      mpr_support(A, Bs, dir, v4);
+      if (reach_tolerance(P, v4, dir, tol) || it > maxit) {
+        depth = sqrtf(fmaxf(0.f, origin_tri_dist2(P[1].v, P[2].v, P[3].v, pdir)));
+        if (ccd_zero(pdir[0]) && ccd_zero(pdir[1]) && ccd_zero(pdir[2])) { pdir[0] = dir[0]; pdir[1] = dir[1]; pdir[2] = dir[2]; }
+        normalize3(pdir);
+        float b[4], vec[3], sum;
+        cross3(vec, P[1].v, P[2].v); b[0] = dot3(vec, P[3].v);
+        cross3(vec, P[3].v, P[2].v); b[1] = dot3(vec, P[0].v);
+        cross3(vec, P[0].v, P[1].v); b[2] = dot3(vec, P[3].v);
+        cross3(vec, P[2].v, P[1].v); b[3] = dot3(vec, P[0].v);
+        sum = b[0] + b[1] + b[2] + b[3];
+        if (ccd_zero(sum) || sum < 0) {
+          b[0] = 0;
+          cross3(vec, P[2].v, P[3].v); b[1] = dot3(vec, dir);
+          cross3(vec, P[3].v, P[1].v); b[2] = dot3(vec, dir);
+          cross3(vec, P[1].v, P[2].v); b[3] = dot3(vec, dir);
+          sum = b[1] + b[2] + b[3];
+        }
+        if (!(fabsf(sum) > 1e-30f)) { b[0] = 0; b[1] = b[2] = b[3] = 1; sum = 3; }   // exactly touching faces
+        for (int i = 0; i < 3; i++) {
+          float p1 = 0, p2 = 0;
+          for (int k = 0; k < 4; k++) { p1 += b[k] * P[k].a[i]; p2 += b[k] * P[k].b[i]; }
+          pos[i] = 0.5f * (p1 + p2) / sum;
+        }
+        return true;
+      }
+      expand_portal(P, v4);
+    }
+  }
+
+  SMJ_DEV void load_shape(Shape& sh, int g, int slot, float* cen) {
+    sh.type = uni(M.geom_type[g]); sh.nvert = uni(M.geom_hullnum[g]);
+    const int adr = uni(M.geom_hulladr[g]);
+    sh.verts = M.hull_vert + 3 * (adr < 0 ? 0 : adr);
+    for (int k = 0; k < 3; k++) { sh.pos[k] = uni(s.u.c.pos[slot][k]); sh.size[k] = uni(M.geom_size[3 * g + k]); }
+    for (int k = 0; k < 9; k++) sh.mat[k] = uni(s.u.c.mat[slot][k]);
+    const float lc[3] = {uni(M.geom_ccenter[3 * g]), uni(M.geom_ccenter[3 * g + 1]), uni(M.geom_ccenter[3 * g + 2])};
+    mulmat3vec(cen, sh.mat, lc);
+    for (int k = 0; k < 3; k++) cen[k] += sh.pos[k];
+  }
+
+  // non-plane pairs: cache world frames of the participating geoms, sphere + oriented-box broadphase with lane = pair,
+  // MPR on the survivors in pair-table order
+  SMJ_DEV void collision_convex() {
+    if (!M.convex_pairs || M.nconvpair == 0) return;
+    LANES {
+      if (lane < M.ncgeom) {
+        const int g = M.k_cgeom[lane];
+        float pos[3], mat[9], cw[3];
+        geom_pose(g, pos, mat);
+        const float lc[3] = {M.geom_aabb[6 * g], M.geom_aabb[6 * g + 1], M.geom_aabb[6 * g + 2]};
+        mulmat3vec(cw, mat, lc);
+        for (int k = 0; k < 3; k++) { s.u.c.pos[lane][k] = pos[k]; s.u.c.cen[lane][k] = pos[k] + cw[k]; }
+        for (int k = 0; k < 9; k++) s.u.c.mat[lane][k] = mat[k];
+      }
+    }
+    SYNC();
+    for (int base = 0; base < M.nconvpair; base += 64) {
+      PL<int> hit;
+      LANES {
+        int h = 0;
+        const int t = base + lane;
+        if (t < M.nconvpair) {
+          const int s1 = M.k_convpair_s1[t], s2 = M.k_convpair_s2[t], p = M.k_convpair[t];
+          const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
+          const float margin = M.pair_margin[p];
+          const float dv[3] = {s.u.c.cen[s2][0] - s.u.c.cen[s1][0], s.u.c.cen[s2][1] - s.u.c.cen[s1][1], s.u.c.cen[s2][2] - s.u.c.cen[s1][2]};
+          const float rr = M.geom_rbound[g1] + M.geom_rbound[g2] + margin;
+          if (dot3(dv, dv) <= rr * rr) {
+            h = 1;
+            for (int sd = 0; sd < 2 && h; sd++) {
+              const float* Ra = sd ? s.u.c.mat[s2] : s.u.c.mat[s1];
+              const float* Rb = sd ? s.u.c.mat[s1] : s.u.c.mat[s2];
+              const int ga = sd ? g2 : g1, gb = sd ? g1 : g2;
+              for (int k = 0; k < 3 && h; k++) {
+                const float ax[3] = {Ra[k], Ra[3 + k], Ra[6 + k]};
+                float r = 0;
+                for (int j = 0; j < 3; j++) r += fabsf(ax[0] * Rb[j] + ax[1] * Rb[3 + j] + ax[2] * Rb[6 + j]) * M.geom_aabb[6 * gb + 3 + j];
+                if (fabsf(dot3(ax, dv)) > M.geom_aabb[6 * ga + 3 + k] + r + margin) h = 0;
+              }
+            }
+          }
+        }
+        hit[lane] = h;
+      }
+      uint64_t mask = wave_ballot(hit);
+      while (mask) {
+        const int l = ffs64(mask);
+        mask &= mask - 1;
+        const int t = base + l, p = uni(M.k_convpair[t]);
+        const int g1 = uni(M.pair_geom1[p]), g2 = uni(M.pair_geom2[p]);
+        Shape A, Bs;
+        float c0[3], c1[3], depth, dir[3], pos[3];
+        load_shape(A, g1, uni(M.k_convpair_s1[t]), c0);
+        load_shape(Bs, g2, uni(M.k_convpair_s2[t]), c1);
+        if (!mpr_penetration(A, Bs, c0, c1, depth, dir, pos)) continue;
+        if (-depth > uni(M.pair_margin[p]) || dot3(dir, dir) < 0.5f) continue;
+        add_contact(p, g1, g2, -depth, pos, dir);
+      }
+    }
+    SYNC();
   }
 
   // ------------------------------------------------------------------ B.4 constraint rows
@@ -2124,6 +2388,7 @@ struct StepKernel {
       if (M.solver != 2) factor();   // the sparse L'DL of M is only needed by the PGS path (Y = J L^-1)
       TICK(SMJ_PROF_FACTOR)
       collision();
+      collision_convex();
       if (last) dump_contacts();
       TICK(SMJ_PROF_COLLISION)
       make_constraint();

@@ -683,7 +683,7 @@ class MjcfCompiler:
         # ---------------- geoms + inertia
         G = dict(type=[], bodyid=[], pos=[], quat=[], size=[], contype=[], conaffinity=[], condim=[], group=[],
                  priority=[], friction=[], solmix=[], solref=[], solimp=[], margin=[], gap=[], rgba=[], rbound=[],
-                 center=[], aabb=[], hulladr=[], hullnum=[], meshid=[], name=[])
+                 center=[], aabb=[], hulladr=[], hullnum=[], meshid=[], name=[], ccenter=[])
         hull_verts: List[np.ndarray] = []
         hull_cache: Dict[str, Tuple[int, int]] = {}
         mesh_names: List[str] = []
@@ -794,6 +794,8 @@ class MjcfCompiler:
                 G["solimp"].append(_floats(g["solimp"], 5)); G["margin"].append(float(g["margin"])); G["gap"].append(float(g["gap"]))
                 G["rgba"].append(rgba); G["rbound"].append(rb); G["center"].append(cen); G["aabb"].append(aabb)
                 G["hulladr"].append(adr); G["hullnum"].append(num); G["meshid"].append(meshid)
+                # an interior point of the convex shape (MPR portal centre): hull-vertex mean, primitives: frame origin
+                G["ccenter"].append(hull_verts[mesh_names.index(g["mesh"])].mean(0) if (t == GEOM_MESH and num > 0) else np.zeros(3))
                 G["name"].append(g.get("name", ""))
                 self._geom_mesh_names.append(g.get("mesh") if t == GEOM_MESH else None)
             if parts:
@@ -954,6 +956,7 @@ class MjcfCompiler:
         m["geom_size"] = np.array(G["size"], float).reshape(-1, 3); m["geom_rgba"] = np.array(G["rgba"], float).reshape(-1, 4)
         m["geom_rbound"] = np.array(G["rbound"]); m["geom_center"] = np.array(G["center"], float).reshape(-1, 3)
         m["geom_aabb"] = np.array(G["aabb"], float).reshape(-1, 6)
+        m["geom_ccenter"] = np.array(G["ccenter"], float).reshape(-1, 3)
         m["geom_friction"] = np.array(G["friction"], float).reshape(-1, 3)
         m["hull_vert"] = np.concatenate(hull_verts, 0) if hull_verts else np.zeros((0, 3))
         m["site_bodyid"] = np.array(site_bodyid, np.int32); m["site_pos"] = np.array(site_pos, float).reshape(-1, 3)

@@ -27,3 +27,16 @@ def blob_fused() -> bytes:
 def blob_full() -> bytes:
     with open(os.path.join(MODELS, "stretch_empty_full.smjb"), "rb") as f:
         return f.read()
+
+
+def home_qpos(qpos0):
+    """qpos0 with the lift at 0.6 and the arm at 0.1 (the 'home' keyframe targets, stretch.xml:544).  At qpos0 itself the
+    lift is fully down and the wrist sits 5 cm inside the base hull: a legitimate MuJoCo start (the reference homes the
+    robot right after start), but the contact normal of such a deep, degenerate penetration is round-off sensitive, so
+    trajectory-parity tests start from this clear pose instead."""
+    import numpy as np
+
+    q = np.array(qpos0, dtype=np.float64).copy()
+    q[9] = 0.6
+    q[10:14] = 0.025
+    return q

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import HOME_CTRL, MIX_CTRL
+from conftest import HOME_CTRL, MIX_CTRL, home_qpos
 from oracle.oracle import Oracle
 
 pytestmark = pytest.mark.gpu
@@ -24,6 +24,13 @@ def _set_ctrl(sim, ctrl):
     sim.ctrl[:] = torch.tensor(ctrl, dtype=torch.float32, device=sim.device).unsqueeze(1)
 
 
+def _start_home(sim, o):
+    """Shared non-penetrating start (conftest.home_qpos): lift 0.6, arm 0.1."""
+    q = home_qpos(o.arr("qpos"))
+    o.arr("qpos")[:] = q
+    sim.qpos[:] = torch.tensor(q, dtype=torch.float32, device=sim.device).unsqueeze(1)
+
+
 def test_native_library_is_the_one_running():
     import ctypes
 
@@ -39,6 +46,7 @@ def test_single_step_stages_vs_oracle():
     _set_ctrl(sim, MIX_CTRL)
     o = Oracle(sim._blob)
     o.arr("ctrl")[:] = MIX_CTRL
+    _start_home(sim, o)
     o.forward()
     sim.step(1)
     torch.cuda.synchronize()
@@ -66,6 +74,7 @@ def test_qpos_drift_1000_steps(ctrl):
     _set_ctrl(sim, ctrl)
     o = Oracle(sim._blob)
     o.arr("ctrl")[:] = ctrl
+    o.arr("qpos")[:] = home_qpos(o.arr("qpos"))
     o.step(500)
     sim.qpos[:] = torch.tensor(o.arr("qpos"), dtype=torch.float32, device=sim.device).unsqueeze(1)
     sim.qvel[:] = torch.tensor(o.arr("qvel"), dtype=torch.float32, device=sim.device).unsqueeze(1)
@@ -82,13 +91,14 @@ def test_qpos_drift_1000_steps(ctrl):
 
 
 @pytest.mark.parametrize("ctrl", [HOME_CTRL, MIX_CTRL])
-def test_newton_qpos_drift_1000_steps_from_reset(ctrl):
+def test_newton_qpos_drift_1000_steps_from_home_pose(ctrl):
     """Newton solver (what CPU MuJoCo runs for this model): fp32 HIP vs fp64 oracle, from reset, 1000 steps."""
     sim = _sim(4, solver="newton")
     _set_ctrl(sim, ctrl)
     o = Oracle(sim._blob)
     o.set_option("solver", 2)
     o.arr("ctrl")[:] = ctrl
+    _start_home(sim, o)
     worst = 0.0
     for _ in range(10):
         o.step(100); sim.step(100)
@@ -104,6 +114,7 @@ def test_transient_from_reset_stays_close():
     _set_ctrl(sim, MIX_CTRL)
     o = Oracle(sim._blob)
     o.arr("ctrl")[:] = MIX_CTRL
+    _start_home(sim, o)
     o.step(200); sim.step(200)
     torch.cuda.synchronize()
     err = np.abs(sim.qpos[:, 0].cpu().numpy() - o.arr("qpos"))
@@ -118,6 +129,7 @@ def test_sensors_readout_and_status():
     _set_ctrl(sim, MIX_CTRL)
     o = Oracle(sim._blob)
     o.arr("ctrl")[:] = MIX_CTRL
+    _start_home(sim, o)
     o.step(299); sim.step(300)
     torch.cuda.synchronize()
     o.forward(); o.sensors(True)

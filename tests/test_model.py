@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import MIX_CTRL
+from conftest import MIX_CTRL, home_qpos
 from oracle.oracle import Oracle
 from stretch_mujoco_amd import mjcf_compiler as C
 from stretch_mujoco_amd import model_blob as B
@@ -61,6 +61,7 @@ def test_fusion_preserves_dynamics(blob_full, blob_fused):
     a, b = Oracle(blob_full), Oracle(blob_fused)
     for o in (a, b):
         o.arr("ctrl")[:] = MIX_CTRL
+        o.arr("qpos")[:] = home_qpos(o.arr("qpos"))
     for _ in range(3):
         a.step(100); b.step(100)
         assert np.abs(a.arr("qpos") - b.arr("qpos")).max() < 1e-12

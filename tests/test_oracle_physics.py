@@ -141,3 +141,44 @@ def test_stretch_head_tilt_limit(blob_full):
     o.step(4000)
     o.forward()
     assert o.arr("actuator_length")[9] == pytest.approx(-1.5226, abs=3e-3)
+
+
+def test_mpr_penetration_against_closed_forms():
+    """Convex narrowphase (MPR, restating libccd's ccdMPRPenetration): depth / normal / position of primitive pairs
+    with a closed-form answer.  geom1 is the lower MuJoCo type id (sphere 2 < cylinder 5 < box 6)."""
+    opt = '<option integrator="implicitfast" cone="elliptic" impratio="20" gravity="0 0 0"/>'
+
+    def first_contact(xml):
+        o = make(xml)
+        o.forward()
+        assert o.ncon == 1
+        c = o.arr("contact").reshape(1, -1)[0]
+        return c[0], c[1:4], c[4:7]
+
+    d, p, n = first_contact(f'<mujoco><compiler angle="radian"/>{opt}<worldbody><body><freejoint/><geom type="sphere" size="0.1"/></body>'
+                            '<body pos="0.15 0 0"><freejoint/><geom type="sphere" size="0.1"/></body></worldbody></mujoco>')
+    assert d == pytest.approx(-0.05, abs=1e-9) and np.allclose(n, [1, 0, 0], atol=1e-9) and np.allclose(p, [0.075, 0, 0], atol=1e-9)
+    d, p, n = first_contact(f'<mujoco><compiler angle="radian"/>{opt}<worldbody><body><freejoint/><geom type="box" size="0.2 0.2 0.1"/></body>'
+                            '<body pos="0.05 0.03 0.18"><freejoint/><geom type="box" size="0.1 0.1 0.1"/></body></worldbody></mujoco>')
+    assert d == pytest.approx(-0.02, abs=1e-6) and np.allclose(n, [0, 0, 1], atol=1e-6) and p[2] == pytest.approx(0.09, abs=1e-6)
+    d, p, n = first_contact(f'<mujoco><compiler angle="radian"/>{opt}<worldbody><body><freejoint/><geom type="box" size="0.2 0.2 0.1"/></body>'
+                            '<body pos="0 0 0.19" euler="1.5708 0 0"><freejoint/><geom type="cylinder" size="0.1 0.3"/></body></worldbody></mujoco>')
+    assert d == pytest.approx(-0.01, abs=1e-5) and np.allclose(n, [0, 0, -1], atol=1e-4)    # cylinder is geom1: normal towards the box
+    o = make(f'<mujoco><compiler angle="radian"/>{opt}<worldbody><body><freejoint/><geom type="box" size="0.2 0.2 0.1"/></body>'
+             '<body pos="0 0 0.25"><freejoint/><geom type="box" size="0.1 0.1 0.1"/></body></worldbody></mujoco>')
+    o.forward()
+    assert o.ncon == 0
+
+
+def test_sphere_rests_on_a_free_box():
+    """Convex pair in the loop: a sphere (MPR contact with the box, one contact per pair) on a box on the plane."""
+    o = make(f'<mujoco><compiler angle="radian"/>{OPT}<worldbody><geom type="plane" size="0 0 1"/>'
+             '<body pos="0 0 0.1"><freejoint/><geom type="box" size="0.2 0.2 0.1" mass="2"/></body>'
+             '<body pos="0.02 0.01 0.3"><freejoint/><geom type="sphere" size="0.1" mass="1"/></body></worldbody></mujoco>')
+    o.set_option("solver", 2)
+    o.step(1500)
+    o.forward()
+    q = o.arr("qpos")
+    assert abs(q[2] - 0.1) < 3e-3 and abs(q[9] - 0.3) < 6e-3 and np.abs(o.arr("qvel")).max() < 0.2   # the ball may roll slowly
+    c = o.arr("contact").reshape(o.ncon, -1)
+    assert o.ncon == 5 and -3e-3 < c[4][0] < 0 and np.allclose(c[4][4:7], [0, 0, -1], atol=1e-3)   # sphere (geom1) -> box: down
