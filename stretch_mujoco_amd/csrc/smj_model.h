@@ -19,7 +19,7 @@
   X(site_bodyid) X(sensor_lidar_site) X(k_ray_geom) X(k_ray_geom_origbody) X(k_site_origbody)                                                                           \
   X(eq_obj1id) X(eq_obj2id) X(eq_active)                                                                          \
   X(actuator_trntype) X(actuator_trnid) X(actuator_ctrllimited) X(actuator_forcelimited) X(actuator_biastype)     \
-  X(pair_geom1) X(pair_geom2) X(pair_condim) X(k_planepair) X(k_cgeom) X(k_convpair) X(k_convpair_s1) X(k_convpair_s2)
+  X(pair_geom1) X(pair_geom2) X(pair_condim) X(k_planepair) X(k_cgeom) X(k_convpair) X(k_convpair_s1) X(k_convpair_s2) X(k_convpair_ss)
 
 #define SMJ_MODEL_F32(X)                                                                                          \
   X(body_pos) X(body_quat) X(k_body_inertia_local) X(body_gcmass) X(body_gcipos) X(body_subtreemass)              \
@@ -27,7 +27,7 @@
   X(qpos_spring)                                                                                                  \
   X(dof_armature) X(dof_damping) X(dof_frictionloss) X(dof_invweight0) X(dof_solref) X(dof_solimp)                \
   X(geom_pos) X(k_geom_mat) X(geom_size) X(geom_rbound) X(k_geom_bcenter) X(geom_rgba) X(geom_invweight0)         \
-  X(hull_vert) X(sensor_lidar_static) X(geom_aabb) X(geom_ccenter)                                                                             \
+  X(hull_vert) X(sensor_lidar_static) X(geom_aabb) X(geom_ccenter) X(k_convpair_rsum) X(k_cgeom_half) X(k_cgeom_lcen)                                                                             \
   X(site_pos) X(k_site_mat)                                                                                       \
   X(eq_data) X(eq_solref) X(eq_solimp)                                                                            \
   X(actuator_gear) X(actuator_gainprm) X(actuator_biasprm) X(actuator_ctrlrange) X(actuator_forcerange)           \

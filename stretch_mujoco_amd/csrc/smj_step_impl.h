@@ -30,7 +30,7 @@ struct Smem {
     float A[NEFC * NEFC];   // PGS: A = J M^-1 J' + R
     TreeTmp t;
     struct {                // collision: world frames of the geoms taking part in convex pairs (tree temporaries are dead)
-      float pos[64][3], mat[64][9], cen[64][3];
+      float pos[64][3], mat[64][9], cen[64][3], half[64][3];
     } c;
     struct {                // Newton: XA = W J (row-weighted Jacobian) and the Hessian H = M + J' W J / its factor
       float XA[NEFC][JS];
@@ -1119,9 +1119,9 @@ struct StepKernel {
         const int g = M.k_cgeom[lane];
         float pos[3], mat[9], cw[3];
         geom_pose(g, pos, mat);
-        const float lc[3] = {M.geom_aabb[6 * g], M.geom_aabb[6 * g + 1], M.geom_aabb[6 * g + 2]};
+        const float lc[3] = {M.k_cgeom_lcen[3 * lane], M.k_cgeom_lcen[3 * lane + 1], M.k_cgeom_lcen[3 * lane + 2]};
         mulmat3vec(cw, mat, lc);
-        for (int k = 0; k < 3; k++) { s.u.c.pos[lane][k] = pos[k]; s.u.c.cen[lane][k] = pos[k] + cw[k]; }
+        for (int k = 0; k < 3; k++) { s.u.c.pos[lane][k] = pos[k]; s.u.c.cen[lane][k] = pos[k] + cw[k]; s.u.c.half[lane][k] = M.k_cgeom_half[3 * lane + k]; }
         for (int k = 0; k < 9; k++) s.u.c.mat[lane][k] = mat[k];
       }
     }
@@ -1132,22 +1132,20 @@ struct StepKernel {
         int h = 0;
         const int t = base + lane;
         if (t < M.nconvpair) {
-          const int s1 = M.k_convpair_s1[t], s2 = M.k_convpair_s2[t], p = M.k_convpair[t];
-          const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
-          const float margin = M.pair_margin[p];
+          const int ss = M.k_convpair_ss[t], s1 = ss & 255, s2 = ss >> 8;   // two coalesced loads per pair, nothing dependent
+          const float rr = M.k_convpair_rsum[t];
           const float dv[3] = {s.u.c.cen[s2][0] - s.u.c.cen[s1][0], s.u.c.cen[s2][1] - s.u.c.cen[s1][1], s.u.c.cen[s2][2] - s.u.c.cen[s1][2]};
-          const float rr = M.geom_rbound[g1] + M.geom_rbound[g2] + margin;
           if (dot3(dv, dv) <= rr * rr) {
             h = 1;
             for (int sd = 0; sd < 2 && h; sd++) {
-              const float* Ra = sd ? s.u.c.mat[s2] : s.u.c.mat[s1];
-              const float* Rb = sd ? s.u.c.mat[s1] : s.u.c.mat[s2];
-              const int ga = sd ? g2 : g1, gb = sd ? g1 : g2;
+              const int sa = sd ? s2 : s1, sb = sd ? s1 : s2;
+              const float* Ra = s.u.c.mat[sa];
+              const float* Rb = s.u.c.mat[sb];
               for (int k = 0; k < 3 && h; k++) {
                 const float ax[3] = {Ra[k], Ra[3 + k], Ra[6 + k]};
                 float r = 0;
-                for (int j = 0; j < 3; j++) r += fabsf(ax[0] * Rb[j] + ax[1] * Rb[3 + j] + ax[2] * Rb[6 + j]) * M.geom_aabb[6 * gb + 3 + j];
-                if (fabsf(dot3(ax, dv)) > M.geom_aabb[6 * ga + 3 + k] + r + margin) h = 0;
+                for (int j = 0; j < 3; j++) r += fabsf(ax[0] * Rb[j] + ax[1] * Rb[3 + j] + ax[2] * Rb[6 + j]) * s.u.c.half[sb][j];
+                if (fabsf(dot3(ax, dv)) > s.u.c.half[sa][k] + r) h = 0;
               }
             }
           }

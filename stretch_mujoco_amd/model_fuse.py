@@ -181,6 +181,11 @@ def kernel_tables(f: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     f["k_convpair"] = np.array(cp + [0], np.int32); f["k_nconvpair"] = np.array([len(cp)], np.int32)
     f["k_convpair_s1"] = np.array([slot[int(f["pair_geom1"][p])] for p in cp] + [0], np.int32)
     f["k_convpair_s2"] = np.array([slot[int(f["pair_geom2"][p])] for p in cp] + [0], np.int32)
+    f["k_convpair_ss"] = (f["k_convpair_s1"] | (f["k_convpair_s2"] << 8)).astype(np.int32)
+    f["k_convpair_rsum"] = np.array([f["geom_rbound"][f["pair_geom1"][p]] + f["geom_rbound"][f["pair_geom2"][p]] + f["pair_margin"][p]
+                                     for p in cp] + [0.0])
+    f["k_cgeom_half"] = np.array([f["geom_aabb"][g][3:] for g in cg] + [[0, 0, 0]], float)
+    f["k_cgeom_lcen"] = np.array([f["geom_aabb"][g][:3] for g in cg] + [[0, 0, 0]], float)
     # sites: local matrices
     ns = len(f["site_bodyid"])
     smat = np.zeros((ns, 9))

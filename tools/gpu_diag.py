@@ -71,6 +71,8 @@ if __name__ == "__main__":
     ctrl = np.array([2, -1, 0.6, 0.1, 1, -0.4, 0.5, 0.02, 0.3, -0.2], np.float32)
     sim.ctrl[:] = torch.tensor(ctrl, device=sim.device).unsqueeze(1)
     o = Oracle(sim._blob); o.set_option("solver", 2); o.arr("ctrl")[:] = ctrl
+    q0 = o.arr("qpos").copy(); q0[9] = 0.6; q0[10:14] = 0.025; o.arr("qpos")[:] = q0
+    sim.qpos[:] = torch.tensor(q0, dtype=torch.float32, device=sim.device).unsqueeze(1)
     for k in range(10):
         o.step(100); sim.step(100); torch.cuda.synchronize()
         print("newton gpu-vs-oracle step", (k + 1) * 100, "max|dq| = %.2e" % np.abs(sim.qpos[:, 0].cpu().numpy() - o.arr("qpos")).max(), "iters", int(sim.info[2, 0]), int(o.iarr("solver_niter")[0]))
