@@ -27,7 +27,7 @@
   X(qpos_spring)                                                                                                  \
   X(dof_armature) X(dof_damping) X(dof_frictionloss) X(dof_invweight0) X(dof_solref) X(dof_solimp)                \
   X(geom_pos) X(k_geom_mat) X(geom_size) X(geom_rbound) X(k_geom_bcenter) X(geom_rgba) X(geom_invweight0)         \
-  X(hull_vert) X(sensor_lidar_static) X(geom_aabb) X(geom_ccenter) X(k_convpair_rsum) X(k_cgeom_half) X(k_cgeom_lcen)                                                                             \
+  X(k_hull_vert4) X(sensor_lidar_static) X(geom_aabb) X(geom_ccenter) X(k_convpair_rsum) X(k_cgeom_half) X(k_cgeom_lcen)                                                                             \
   X(site_pos) X(k_site_mat)                                                                                       \
   X(eq_data) X(eq_solref) X(eq_solimp)                                                                            \
   X(actuator_gear) X(actuator_gainprm) X(actuator_biasprm) X(actuator_ctrlrange) X(actuator_forcerange)           \

@@ -31,7 +31,12 @@ struct Smem {
     TreeTmp t;
     struct {                // collision: world frames of the geoms taking part in convex pairs (tree temporaries are dead)
       float pos[64][3], mat[64][9], cen[64][3], half[64][3];
+      unsigned short list[1024];   // bounding-sphere survivors of the convex pair list, table order
     } c;
+    struct {                // plane narrowphase staging: contacts of the pair owned by each lane, emitted in pair order
+      int cnt[64], pair[64];
+      float dist[64][4], pos[64][4][3], nrm[64][3];
+    } p;
     struct {                // Newton: XA = W J (row-weighted Jacobian) and the Hessian H = M + J' W J / its factor
       float XA[NEFC][JS];
       float H[NVP][NVP + 1];
@@ -697,79 +702,113 @@ struct StepKernel {
     for (int k = 0; k < 9; k++) lm[k] = M.k_geom_mat[9 * g + k];
     mulmat3(mat, s.xmat[b], lm);
   }
+  // per-lane: fill contact slot c
+  SMJ_DEV void write_contact(int c, int pair, int g1, int g2, float dist, const float* pos, const float* n) {
+    s.cdist[c] = dist;
+    float fr[9] = {n[0], n[1], n[2], 0, 0, 0, 0, 0, 0};
+    normalize3(fr);
+    if (fr[1] > -0.5f && fr[1] < 0.5f) { fr[3] = 0; fr[4] = 1; fr[5] = 0; } else { fr[3] = 0; fr[4] = 0; fr[5] = 1; }
+    const float t = dot3(fr, fr + 3);
+    for (int k = 0; k < 3; k++) fr[3 + k] -= t * fr[k];
+    normalize3(fr + 3);
+    cross3(fr + 6, fr, fr + 3);
+    for (int k = 0; k < 9; k++) s.cframe[c][k] = fr[k];
+    for (int k = 0; k < 3; k++) s.cpos[c][k] = pos[k];
+    for (int k = 0; k < 5; k++) { s.cfric[c][k] = M.pair_friction[5 * pair + k]; s.csolimp[c][k] = M.pair_solimp[5 * pair + k]; }
+    s.csolref[c][0] = M.pair_solref[2 * pair]; s.csolref[c][1] = M.pair_solref[2 * pair + 1];
+    s.cmargin[c] = M.pair_margin[pair] - M.pair_gap[pair];
+    s.cdim[c] = M.pair_condim[pair]; s.cgeom1[c] = g1; s.cgeom2[c] = g2; s.cefc[c] = -1;
+  }
   SMJ_DEV void add_contact(int pair, int g1, int g2, float dist, const float* pos, const float* n) {
     // uniform: every lane calls with identical arguments; lane 0 writes
     if (ncon >= NCON) { flags |= SMJ_FLAG_CON_OVERFLOW; return; }
     const int c = ncon++;
-    LANES {
-      if (lane == 0) {
-        s.cdist[c] = dist;
-        float fr[9] = {n[0], n[1], n[2], 0, 0, 0, 0, 0, 0};
-        normalize3(fr);
-        if (fr[1] > -0.5f && fr[1] < 0.5f) { fr[3] = 0; fr[4] = 1; fr[5] = 0; } else { fr[3] = 0; fr[4] = 0; fr[5] = 1; }
-        const float t = dot3(fr, fr + 3);
-        for (int k = 0; k < 3; k++) fr[3 + k] -= t * fr[k];
-        normalize3(fr + 3);
-        cross3(fr + 6, fr, fr + 3);
-        for (int k = 0; k < 9; k++) s.cframe[c][k] = fr[k];
-        for (int k = 0; k < 3; k++) s.cpos[c][k] = pos[k];
-        for (int k = 0; k < 5; k++) { s.cfric[c][k] = M.pair_friction[5 * pair + k]; s.csolimp[c][k] = M.pair_solimp[5 * pair + k]; }
-        s.csolref[c][0] = M.pair_solref[2 * pair]; s.csolref[c][1] = M.pair_solref[2 * pair + 1];
-        s.cmargin[c] = M.pair_margin[pair] - M.pair_gap[pair];
-        s.cdim[c] = M.pair_condim[pair]; s.cgeom1[c] = g1; s.cgeom2[c] = g2; s.cefc[c] = -1;
-      }
-    }
+    LANES { if (lane == 0) write_contact(c, pair, g1, g2, dist, pos, n); }
   }
 
+  // Plane pairs.  Lane = pair: bounding sphere vs plane, then the primitive narrowphase of the hits runs lane-parallel
+  // (types diverge, the work of all hit pairs overlaps); mesh hulls take the wave-serial vertex scan.  Results are staged
+  // per lane and emitted by prefix sum, which keeps the contacts in pair-table order.
   SMJ_DEV void collision() {
     ncon = 0;
-    // broadphase over plane pairs: lane = pair (chunks of 64), bounding sphere vs plane
     for (int base = 0; base < M.nplanepair; base += 64) {
-      PL<int> hit;
+      PL<int> hull, cv;
       LANES {
-        int h = 0;
+        int cnt = 0, hl = 0;
         const int t = base + lane;
         if (t < M.nplanepair) {
           const int p = M.k_planepair[t], g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
-          const int b1 = M.geom_bodyid[g1], b2 = M.geom_bodyid[g2];
-          // plane: normal = z axis of plane geom frame
+          const int b2 = M.geom_bodyid[g2];
           float pp[3], pm[9];
           geom_pose(g1, pp, pm);
           float c2[3], lc[3] = {M.k_geom_bcenter[3 * g2], M.k_geom_bcenter[3 * g2 + 1], M.k_geom_bcenter[3 * g2 + 2]};
           mulmat3vec(c2, s.xmat[b2], lc);
-          const float n[3] = {pm[2], pm[5], pm[8]};
+          const float n[3] = {pm[2], pm[5], pm[8]};   // plane normal = z axis of the plane geom frame
           const float dif[3] = {c2[0] + s.xpos[b2][0] - pp[0], c2[1] + s.xpos[b2][1] - pp[1], c2[2] + s.xpos[b2][2] - pp[2]};
-          (void)b1;
-          h = (dot3(dif, n) - M.geom_rbound[g2] <= M.pair_margin[p]) ? 1 : 0;
+          const float margin = M.pair_margin[p];
+          if (dot3(dif, n) - M.geom_rbound[g2] <= margin) {
+            const int t2 = M.geom_type[g2];
+            if (t2 == GT_MESH) hl = 1;
+            else cnt = plane_prim(g2, t2, pp, n, margin, s.u.p.dist[lane], s.u.p.pos[lane]);
+            for (int k = 0; k < 3; k++) s.u.p.nrm[lane][k] = n[k];
+            s.u.p.pair[lane] = p;
+          }
         }
-        hit[lane] = h;
+        s.u.p.cnt[lane] = cnt;
+        hull[lane] = hl;
       }
-      uint64_t mask = wave_ballot(hit);
-      while (mask) {
-        const int l = ffs64(mask);
-        mask &= mask - 1;
-        narrow_plane(uni(M.k_planepair[base + l]));
+      uint64_t hm = wave_ballot(hull);
+      if (hm) {
+        SYNC();
+        while (hm) {
+          const int l = ffs64(hm);
+          hm &= hm - 1;
+          narrow_plane_hull(uni(M.k_planepair[base + l]), l);
+        }
+        SYNC();
+      }
+      // emit in pair order: exclusive prefix of the per-lane counts (0..4) from three ballots
+      PL<int> bit;
+      LANES { cv[lane] = s.u.p.cnt[lane]; bit[lane] = cv[lane] & 1; }
+      const uint64_t m0 = wave_ballot(bit);
+      LANES { bit[lane] = cv[lane] & 2; }
+      const uint64_t m1 = wave_ballot(bit);
+      LANES { bit[lane] = cv[lane] & 4; }
+      const uint64_t m2 = wave_ballot(bit);
+      const int total = popc64(m0) + 2 * popc64(m1) + 4 * popc64(m2);
+      if (total) {
+        LANES {
+          const int c = cv[lane];
+          if (c) {
+            const uint64_t lt = (1ull << lane) - 1;
+            const int off = ncon + popc64(m0 & lt) + 2 * popc64(m1 & lt) + 4 * popc64(m2 & lt);
+            const int p = s.u.p.pair[lane], g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
+            for (int k = 0; k < c; k++)
+              if (off + k < NCON) write_contact(off + k, p, g1, g2, s.u.p.dist[lane][k], s.u.p.pos[lane][k], s.u.p.nrm[lane]);
+          }
+        }
+        if (ncon + total > NCON) { flags |= SMJ_FLAG_CON_OVERFLOW; ncon = NCON; }
+        else ncon += total;
       }
     }
     SYNC();
   }
 
-  // narrowphase for one plane pair; uniform control flow, vertex loops are lane-parallel
-  SMJ_DEV void narrow_plane(int p) {
-    const int g1 = uni(M.pair_geom1[p]), g2 = uni(M.pair_geom2[p]), t2 = uni(M.geom_type[g2]);
-    const float margin = uni(M.pair_margin[p]);
-    float pp[3], pm[9], gp[3], gm[9];
-    geom_pose(g1, pp, pm);
+  // per-lane narrowphase of a plane against a sphere / cylinder / box; returns the number of contacts written
+  SMJ_DEV int plane_prim(int g2, int t2, const float* pp, const float* n, float margin, float* cdist, float (*cpos)[3]) const {
+    float gp[3], gm[9];
     geom_pose(g2, gp, gm);
-    const float n[3] = {pm[2], pm[5], pm[8]};
     const float size[3] = {M.geom_size[3 * g2], M.geom_size[3 * g2 + 1], M.geom_size[3 * g2 + 2]};
+    int cnt = 0;
+#define put(d, q) do { cdist[cnt] = (d); cpos[cnt][0] = (q)[0]; cpos[cnt][1] = (q)[1]; cpos[cnt][2] = (q)[2]; cnt++; } while (0)
     if (t2 == GT_SPHERE) {
       const float dif[3] = {gp[0] - pp[0], gp[1] - pp[1], gp[2] - pp[2]};
       const float dist = dot3(dif, n) - size[0];
-      if (dist > margin) return;
-      float pos[3];
-      for (int k = 0; k < 3; k++) pos[k] = gp[k] - n[k] * (size[0] + 0.5f * dist);
-      add_contact(p, g1, g2, dist, pos, n);
+      if (dist <= margin) {
+        float pos[3];
+        for (int k = 0; k < 3; k++) pos[k] = gp[k] - n[k] * (size[0] + 0.5f * dist);
+        put(dist, pos);
+      }
     } else if (t2 == GT_CYLINDER) {  // [MJ] mjc_PlaneCylinder
       float axis[3] = {gm[2], gm[5], gm[8]};
       float prjaxis = dot3(n, axis);
@@ -783,32 +822,32 @@ struct StepKernel {
       const float prjvec = dot3(vec, n);
       for (int k = 0; k < 3; k++) axis[k] *= size[1];
       prjaxis *= size[1];
-      if (dist0 + prjaxis + prjvec > margin) return;
-      float pos[3], dist = dist0 + prjaxis + prjvec;
-      for (int k = 0; k < 3; k++) pos[k] = gp[k] + vec[k] + axis[k] - n[k] * dist * 0.5f;
-      add_contact(p, g1, g2, dist, pos, n);
-      if (dist0 - prjaxis + prjvec <= margin) {
-        dist = dist0 - prjaxis + prjvec;
-        for (int k = 0; k < 3; k++) pos[k] = gp[k] + vec[k] - axis[k] - n[k] * dist * 0.5f;
-        add_contact(p, g1, g2, dist, pos, n);
-      }
-      const float prjvec1 = -prjvec * 0.5f;
-      if (dist0 + prjaxis + prjvec1 <= margin) {
-        float vec1[3];
-        cross3(vec1, vec, axis);
-        normalize3(vec1);
-        for (int k = 0; k < 3; k++) vec1[k] *= size[0] * 0.8660254037844386f;
-        dist = dist0 + prjaxis + prjvec1;
-        for (int sg = 0; sg < 2; sg++) {
-          const float sgn = sg ? -1.f : 1.f;
-          for (int k = 0; k < 3; k++) pos[k] = gp[k] + sgn * vec1[k] + axis[k] - vec[k] * 0.5f - n[k] * dist * 0.5f;
-          add_contact(p, g1, g2, dist, pos, n);
+      if (dist0 + prjaxis + prjvec <= margin) {
+        float pos[3], dist = dist0 + prjaxis + prjvec;
+        for (int k = 0; k < 3; k++) pos[k] = gp[k] + vec[k] + axis[k] - n[k] * dist * 0.5f;
+        put(dist, pos);
+        if (dist0 - prjaxis + prjvec <= margin) {
+          dist = dist0 - prjaxis + prjvec;
+          for (int k = 0; k < 3; k++) pos[k] = gp[k] + vec[k] - axis[k] - n[k] * dist * 0.5f;
+          put(dist, pos);
+        }
+        const float prjvec1 = -prjvec * 0.5f;
+        if (dist0 + prjaxis + prjvec1 <= margin) {
+          float vec1[3];
+          cross3(vec1, vec, axis);
+          normalize3(vec1);
+          for (int k = 0; k < 3; k++) vec1[k] *= size[0] * 0.8660254037844386f;
+          dist = dist0 + prjaxis + prjvec1;
+          for (int sg = 0; sg < 2 && cnt < 4; sg++) {
+            const float sgn = sg ? -1.f : 1.f;
+            for (int k = 0; k < 3; k++) pos[k] = gp[k] + sgn * vec1[k] + axis[k] - vec[k] * 0.5f - n[k] * dist * 0.5f;
+            put(dist, pos);
+          }
         }
       }
     } else if (t2 == GT_BOX) {  // [MJ] mjc_PlaneBox
       const float dif[3] = {gp[0] - pp[0], gp[1] - pp[1], gp[2] - pp[2]};
       const float dist = dot3(dif, n);
-      int cnt = 0;
       for (int i = 0; i < 8 && cnt < 4; i++) {
         const float v[3] = {(i & 1) ? size[0] : -size[0], (i & 2) ? size[1] : -size[1], (i & 4) ? size[2] : -size[2]};
         float corner[3];
@@ -818,17 +857,27 @@ struct StepKernel {
         const float cd = dist + ldist;
         float pos[3];
         for (int k = 0; k < 3; k++) pos[k] = gp[k] + corner[k] - n[k] * cd * 0.5f;
-        add_contact(p, g1, g2, cd, pos, n);
-        cnt++;
+        put(cd, pos);
       }
-    } else if (t2 == GT_MESH) {
-      plane_hull(p, g1, g2, pp, n, gp, gm, margin);
     }
+#undef put
+    return cnt;
+  }
+
+  // wave-serial narrowphase of plane pair p (a mesh hull), staged into row l
+  SMJ_DEV void narrow_plane_hull(int p, int l) {
+    const int g1 = uni(M.pair_geom1[p]), g2 = uni(M.pair_geom2[p]);
+    const float margin = uni(M.pair_margin[p]);
+    float pp[3], pm[9], gp[3], gm[9];
+    geom_pose(g1, pp, pm);
+    geom_pose(g2, gp, gm);
+    const float n[3] = {pm[2], pm[5], pm[8]};
+    plane_hull(l, g2, pp, n, gp, gm, margin);
   }
 
   // plane vs convex hull, vertices strided over lanes; same selection rule as oracle plane_hull()
-  SMJ_DEV void plane_hull(int p, int g1, int g2, const float* pp, const float* n, const float* gp, const float* gm, float margin) {
-    const float* verts = M.hull_vert + 3 * M.geom_hulladr[g2];
+  SMJ_DEV void plane_hull(int l, int g2, const float* pp, const float* n, const float* gp, const float* gm, float margin) {
+    const float* verts = M.k_hull_vert4 + 4 * uni(M.geom_hulladr[g2]);
     const int nvert = uni(M.geom_hullnum[g2]);
     float nl[3];
     mulmat3Tvec(nl, gm, n);
@@ -840,7 +889,7 @@ struct StepKernel {
       float bd = 3.0e38f;
       int bi = -1;
       for (int i = lane; i < nvert; i += 64) {
-        const float dd = nl[0] * verts[3 * i] + nl[1] * verts[3 * i + 1] + nl[2] * verts[3 * i + 2] + off;
+        const float dd = nl[0] * verts[4 * i] + nl[1] * verts[4 * i + 1] + nl[2] * verts[4 * i + 2] + off;
         if (dd <= margin && dd < bd) { bd = dd; bi = i; }
       }
       best[lane] = bd; bidx[lane] = bi;
@@ -849,15 +898,15 @@ struct StepKernel {
     if (dmin > margin) return;
     int i1 = pick_index(best, bidx, dmin);
     int idx[4] = {i1, -1, -1, -1};
-    const float v1[3] = {verts[3 * i1], verts[3 * i1 + 1], verts[3 * i1 + 2]};
+    const float v1[3] = {verts[4 * i1], verts[4 * i1 + 1], verts[4 * i1 + 2]};
     if (M.max_con_pair > 1) {
       LANES {
         float bd = 1e-12f;
         int bi = -1;
         for (int i = lane; i < nvert; i += 64) {
-          const float dd = nl[0] * verts[3 * i] + nl[1] * verts[3 * i + 1] + nl[2] * verts[3 * i + 2] + off;
+          const float dd = nl[0] * verts[4 * i] + nl[1] * verts[4 * i + 1] + nl[2] * verts[4 * i + 2] + off;
           if (dd > margin) continue;
-          const float e[3] = {verts[3 * i] - v1[0], verts[3 * i + 1] - v1[1], verts[3 * i + 2] - v1[2]};
+          const float e[3] = {verts[4 * i] - v1[0], verts[4 * i + 1] - v1[1], verts[4 * i + 2] - v1[2]};
           const float r2 = dot3(e, e);
           if (r2 > bd) { bd = r2; bi = i; }
         }
@@ -868,7 +917,7 @@ struct StepKernel {
     }
     if (idx[1] >= 0 && M.max_con_pair > 2) {
       const int i2 = idx[1];
-      float e12[3] = {verts[3 * i2] - v1[0], verts[3 * i2 + 1] - v1[1], verts[3 * i2 + 2] - v1[2]}, side[3];
+      float e12[3] = {verts[4 * i2] - v1[0], verts[4 * i2 + 1] - v1[1], verts[4 * i2 + 2] - v1[2]}, side[3];
       cross3(side, nl, e12);
       normalize3(side);
       PL<float> bmin;
@@ -877,9 +926,9 @@ struct StepKernel {
         float smax = 1e-6f, smin = -1e-6f;
         int i3 = -1, i4 = -1;
         for (int i = lane; i < nvert; i += 64) {
-          const float dd = nl[0] * verts[3 * i] + nl[1] * verts[3 * i + 1] + nl[2] * verts[3 * i + 2] + off;
+          const float dd = nl[0] * verts[4 * i] + nl[1] * verts[4 * i + 1] + nl[2] * verts[4 * i + 2] + off;
           if (dd > margin) continue;
-          const float e[3] = {verts[3 * i] - v1[0], verts[3 * i + 1] - v1[1], verts[3 * i + 2] - v1[2]};
+          const float e[3] = {verts[4 * i] - v1[0], verts[4 * i + 1] - v1[1], verts[4 * i + 2] - v1[2]};
           const float sv = dot3(e, side);
           if (sv > smax) { smax = sv; i3 = i; }
           if (sv < smin) { smin = sv; i4 = i; }
@@ -894,15 +943,22 @@ struct StepKernel {
         if (m4 < 1.0e38f) idx[3] = pick_index(bmin, imin, m4);
       }
     }
+    int cnt = 0;
     for (int k = 0; k < 4; k++) {
       if (idx[k] < 0) continue;
-      const float v[3] = {verts[3 * idx[k]], verts[3 * idx[k] + 1], verts[3 * idx[k] + 2]};
-      float wv[3], pos[3];
+      const float v[3] = {verts[4 * idx[k]], verts[4 * idx[k] + 1], verts[4 * idx[k] + 2]};
+      float wv[3];
       const float dd = dot3(nl, v) + off;
       mulmat3vec(wv, gm, v);
-      for (int j = 0; j < 3; j++) pos[j] = gp[j] + wv[j] - n[j] * dd * 0.5f;
-      add_contact(p, g1, g2, dd, pos, n);
+      LANES {
+        if (lane == 0) {
+          s.u.p.dist[l][cnt] = dd;
+          for (int j = 0; j < 3; j++) s.u.p.pos[l][cnt][j] = gp[j] + wv[j] - n[j] * dd * 0.5f;
+        }
+      }
+      cnt++;
     }
+    LANES { if (lane == 0) s.u.p.cnt[l] = cnt; }
   }
   // among lanes whose key equals `val`, the lowest stored index (deterministic tie-break)
   SMJ_DEV int pick_index(const PL<float>& key, const PL<int>& idx, float val) {
@@ -934,20 +990,27 @@ struct StepKernel {
     } else {
       PL<float> best;
       PL<int> bidx;
-      const float* verts = sh.verts;
+      const Vec4* verts = reinterpret_cast<const Vec4*>(sh.verts);
       const int nvert = sh.nvert;
       LANES {
         float bd = -3.0e38f;
         int bi = -1;
-        for (int i = lane; i < nvert; i += 64) {
-          const float d = verts[3 * i] * dl[0] + verts[3 * i + 1] * dl[1] + verts[3 * i + 2] * dl[2];
-          if (d > bd) { bd = d; bi = i; }
+        for (int i0 = lane; i0 < nvert; i0 += 256) {   // four independent 16-byte loads in flight per lane
+          Vec4 v[4];
+          int id[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { id[u] = i0 + 64 * u < nvert ? i0 + 64 * u : nvert - 1; v[u] = verts[id[u]]; }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const float d = v[u].x * dl[0] + v[u].y * dl[1] + v[u].z * dl[2];
+            if (d > bd) { bd = d; bi = id[u]; }
+          }
         }
         best[lane] = bd; bidx[lane] = bi;
       }
       const float mx = wave_max(best);
       const int idx = pick_index(best, bidx, mx);
-      pl[0] = uni(verts[3 * idx]); pl[1] = uni(verts[3 * idx + 1]); pl[2] = uni(verts[3 * idx + 2]);
+      pl[0] = uni(verts[idx].x); pl[1] = uni(verts[idx].y); pl[2] = uni(verts[idx].z);
     }
     mulmat3vec(out, sh.mat, pl);
     for (int i = 0; i < 3; i++) out[i] += sh.pos[i];
@@ -1102,7 +1165,7 @@ struct StepKernel {
   SMJ_DEV void load_shape(Shape& sh, int g, int slot, float* cen) {
     sh.type = uni(M.geom_type[g]); sh.nvert = uni(M.geom_hullnum[g]);
     const int adr = uni(M.geom_hulladr[g]);
-    sh.verts = M.hull_vert + 3 * (adr < 0 ? 0 : adr);
+    sh.verts = M.k_hull_vert4 + 4 * (adr < 0 ? 0 : adr);
     for (int k = 0; k < 3; k++) { sh.pos[k] = uni(s.u.c.pos[slot][k]); sh.size[k] = uni(M.geom_size[3 * g + k]); }
     for (int k = 0; k < 9; k++) sh.mat[k] = uni(s.u.c.mat[slot][k]);
     const float lc[3] = {uni(M.geom_ccenter[3 * g]), uni(M.geom_ccenter[3 * g + 1]), uni(M.geom_ccenter[3 * g + 2])};
@@ -1126,37 +1189,79 @@ struct StepKernel {
       }
     }
     SYNC();
-    for (int base = 0; base < M.nconvpair; base += 64) {
-      PL<int> hit;
+    // pass 1: bounding spheres of all pairs (lane = pair), survivors compacted in table order.  The pair words of eight
+    // chunks are fetched up front so that their load latency is paid once per group, not once per chunk.
+    int nsurv = 0;
+    const int ncp = M.nconvpair;
+    const int* const pair_ss = M.k_convpair_ss;
+    const float* const pair_rr = M.k_convpair_rsum;
+    for (int g0 = 0; g0 < ncp; g0 += 512) {
+      PL<int> ssv[8];
+      PL<float> rrv[8];
       LANES {
-        int h = 0;
-        const int t = base + lane;
-        if (t < M.nconvpair) {
-          const int ss = M.k_convpair_ss[t], s1 = ss & 255, s2 = ss >> 8;   // two coalesced loads per pair, nothing dependent
-          const float rr = M.k_convpair_rsum[t];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          int t = g0 + 64 * j + lane;
+          t = t < ncp ? t : ncp;   // entry ncp is padding with radius -1
+          ssv[j][lane] = pair_ss[t];
+          rrv[j][lane] = pair_rr[t];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int base = g0 + 64 * j;
+        if (base < ncp) {
+          PL<int> hit;
+          LANES {
+            const int ss = ssv[j][lane], s1 = ss & 255, s2 = ss >> 8;
+            const float rr = rrv[j][lane];
+            const float dv[3] = {s.u.c.cen[s2][0] - s.u.c.cen[s1][0], s.u.c.cen[s2][1] - s.u.c.cen[s1][1], s.u.c.cen[s2][2] - s.u.c.cen[s1][2]};
+            hit[lane] = rr >= 0.f && dot3(dv, dv) <= rr * rr;
+          }
+          const uint64_t mask = wave_ballot(hit);
+          LANES {
+            if (hit[lane]) {
+              const int at = nsurv + popc64(mask & ((1ull << lane) - 1));
+              if (at < 1024) s.u.c.list[at] = (unsigned short)(base + lane);
+            }
+          }
+          nsurv += popc64(mask);
+        }
+      }
+    }
+    if (nsurv > 1024) nsurv = 1024;
+    SYNC();
+    // pass 2: oriented boxes on the survivors, then MPR in table order
+    for (int base = 0; base < nsurv; base += 64) {
+      PL<int> hit;
+      PL<int> tt;
+      LANES {
+        int h = 0, t = 0;
+        if (base + lane < nsurv) {
+          t = s.u.c.list[base + lane];
+          const int ss = M.k_convpair_ss[t], s1 = ss & 255, s2 = ss >> 8;
           const float dv[3] = {s.u.c.cen[s2][0] - s.u.c.cen[s1][0], s.u.c.cen[s2][1] - s.u.c.cen[s1][1], s.u.c.cen[s2][2] - s.u.c.cen[s1][2]};
-          if (dot3(dv, dv) <= rr * rr) {
-            h = 1;
-            for (int sd = 0; sd < 2 && h; sd++) {
-              const int sa = sd ? s2 : s1, sb = sd ? s1 : s2;
-              const float* Ra = s.u.c.mat[sa];
-              const float* Rb = s.u.c.mat[sb];
-              for (int k = 0; k < 3 && h; k++) {
-                const float ax[3] = {Ra[k], Ra[3 + k], Ra[6 + k]};
-                float r = 0;
-                for (int j = 0; j < 3; j++) r += fabsf(ax[0] * Rb[j] + ax[1] * Rb[3 + j] + ax[2] * Rb[6 + j]) * s.u.c.half[sb][j];
-                if (fabsf(dot3(ax, dv)) > s.u.c.half[sa][k] + r) h = 0;
-              }
+          h = 1;
+          for (int sd = 0; sd < 2 && h; sd++) {
+            const int sa = sd ? s2 : s1, sb = sd ? s1 : s2;
+            const float* Ra = s.u.c.mat[sa];
+            const float* Rb = s.u.c.mat[sb];
+            for (int k = 0; k < 3 && h; k++) {
+              const float ax[3] = {Ra[k], Ra[3 + k], Ra[6 + k]};
+              float r = 0;
+              for (int j = 0; j < 3; j++) r += fabsf(ax[0] * Rb[j] + ax[1] * Rb[3 + j] + ax[2] * Rb[6 + j]) * s.u.c.half[sb][j];
+              if (fabsf(dot3(ax, dv)) > s.u.c.half[sa][k] + r) h = 0;
             }
           }
         }
         hit[lane] = h;
+        tt[lane] = t;
       }
       uint64_t mask = wave_ballot(hit);
       while (mask) {
         const int l = ffs64(mask);
         mask &= mask - 1;
-        const int t = base + l, p = uni(M.k_convpair[t]);
+        const int t = wave_read(tt, l), p = uni(M.k_convpair[t]);
         const int g1 = uni(M.pair_geom1[p]), g2 = uni(M.pair_geom2[p]);
         Shape A, Bs;
         float c0[3], c1[3], depth, dir[3], pos[3];
@@ -2185,6 +2290,22 @@ struct StepKernel {
       }
     }
     SYNC();
+    // [MJ] mj_checkPos / mj_checkVel: a non-finite or absurd state resets the environment (and is flagged)
+    PL<int> bad;
+    LANES {
+      int b = 0;
+      if (lane < M.nq) { const float q = s.qpos[lane]; b |= !(fabsf(q) < 1e10f); }
+      if (lane < nv) { const float v = s.qvel[lane]; b |= !(fabsf(v) < 1e10f); }
+      bad[lane] = b;
+    }
+    if (wave_ballot(bad) != 0) {
+      flags |= SMJ_FLAG_BAD_STATE;
+      LANES {
+        if (lane < M.nq) s.qpos[lane] = M.qpos0[lane];
+        if (lane < nv) { s.qvel[lane] = 0.f; s.warm[lane] = 0.f; }
+      }
+      SYNC();
+    }
   }
 
   // ------------------------------------------------------------------ readouts at the end of a launch

@@ -75,24 +75,37 @@ struct PL {
   __device__ __forceinline__ T& operator[](int) { return v; }
   __device__ __forceinline__ const T& operator[](int) const { return v; }
 };
+// Wave-wide reductions on the DPP data path (no LDS round trips): xor-1 / xor-2 quad permutes, half-row and row mirrors
+// leave every lane of a 16-lane row with the row total; row_bcast:15 / row_bcast:31 (gfx9 DPP controls) then carry the
+// totals across rows so that lane 63 holds the wave total, which v_readlane returns as a scalar.  Must be called with all
+// 64 lanes active (reductions sit between lane regions, never inside divergent code).
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float smj_dpp(float ident, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, v), CTRL,
+                                                                ROWMASK, 0xF, false));
+}
+#define SMJ_WAVE_REDUCE(OP, IDENT)                \
+  t = OP(t, smj_dpp<0xB1, 0xF>(IDENT, t));        \
+  t = OP(t, smj_dpp<0x4E, 0xF>(IDENT, t));        \
+  t = OP(t, smj_dpp<0x141, 0xF>(IDENT, t));       \
+  t = OP(t, smj_dpp<0x140, 0xF>(IDENT, t));       \
+  t = OP(t, smj_dpp<0x142, 0xA>(IDENT, t));       \
+  t = OP(t, smj_dpp<0x143, 0xC>(IDENT, t));       \
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63));
+__device__ __forceinline__ float smj_addf(float a, float b) { return a + b; }
 __device__ __forceinline__ float wave_sum(const PL<float>& x) {
   float t = x.v;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
-  return t;
+  SMJ_WAVE_REDUCE(smj_addf, 0.0f)
 }
 __device__ __forceinline__ float wave_min(const PL<float>& x) {
   float t = x.v;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) t = fminf(t, __shfl_xor(t, off, 64));
-  return t;
+  SMJ_WAVE_REDUCE(fminf, __builtin_inff())
 }
 __device__ __forceinline__ float wave_max(const PL<float>& x) {
   float t = x.v;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) t = fmaxf(t, __shfl_xor(t, off, 64));
-  return t;
+  SMJ_WAVE_REDUCE(fmaxf, -__builtin_inff())
 }
+#undef SMJ_WAVE_REDUCE
 __device__ __forceinline__ uint64_t wave_ballot(const PL<int>& p) { return __ballot(p.v != 0); }
 __device__ __forceinline__ float wave_read(const PL<float>& x, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x.v), l));
@@ -112,6 +125,7 @@ __device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_r
 #endif
 
 // ---------------------------------------------------------------------------------------------- small math
+struct alignas(16) Vec4 { float x, y, z, w; };
 struct F3 { float x, y, z; };
 struct F4 { float w, x, y, z; };
 struct F6 { float a[6]; };

@@ -183,7 +183,9 @@ def kernel_tables(f: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     f["k_convpair_s2"] = np.array([slot[int(f["pair_geom2"][p])] for p in cp] + [0], np.int32)
     f["k_convpair_ss"] = (f["k_convpair_s1"] | (f["k_convpair_s2"] << 8)).astype(np.int32)
     f["k_convpair_rsum"] = np.array([f["geom_rbound"][f["pair_geom1"][p]] + f["geom_rbound"][f["pair_geom2"][p]] + f["pair_margin"][p]
-                                     for p in cp] + [0.0])
+                                     for p in cp] + [-1.0])    # padding entry: negative radius = never in range
+    hv = np.asarray(f["hull_vert"], float).reshape(-1, 3)
+    f["k_hull_vert4"] = np.concatenate([hv, np.zeros((len(hv), 1))], axis=1) if len(hv) else np.zeros((1, 4))   # one 16-byte load per vertex
     f["k_cgeom_half"] = np.array([f["geom_aabb"][g][3:] for g in cg] + [[0, 0, 0]], float)
     f["k_cgeom_lcen"] = np.array([f["geom_aabb"][g][:3] for g in cg] + [[0, 0, 0]], float)
     # sites: local matrices

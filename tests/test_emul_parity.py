@@ -116,8 +116,8 @@ def test_lidar_sees_a_wall(blob_fused):
 
 
 # ---------------------------------------------------------------------------------------------- Newton solver
-def _pair_newton(blob, ctrl):
-    o, e = _pair(blob, ctrl)
+def _pair_newton(blob, ctrl, B=1):
+    o, e = _pair(blob, ctrl, B)
     o.set_option("solver", 2); e.set_option("solver", 2)
     return o, e
 
@@ -206,3 +206,12 @@ def test_convex_pairs_can_be_switched_off(blob_fused):
     assert abs(o.ncon - int(e.info[1, 0])) <= 2    # gripper hulls on the floor: manifolds may differ by a vertex
     assert np.abs(e.qpos[:, 0] - o.arr("qpos"))[7:17].max() < 0.03
     assert o.arr("qpos")[9] < 0.14 and abs(o.arr("qpos")[9] - e.qpos[9, 0]) < 0.02   # lower than with the base in the way (0.145+): now the floor stops the gripper
+
+
+def test_bad_state_resets_and_flags(blob_fused):
+    """mj_checkPos semantics: a non-finite state resets the env to qpos0 and raises the BAD_STATE flag."""
+    o, e = _pair_newton(blob_fused, HOME_CTRL, B=2)
+    e.qvel[3, 1] = np.nan
+    e.step(2)
+    assert e.info[3, 1] & 4 and not (e.info[3, 0] & 4)
+    assert np.isfinite(e.qpos).all() and np.isfinite(e.qvel).all()
