@@ -34,16 +34,20 @@ enum smj_slot {
   SMJ_SLOT_INFO = 11,     /* int32 [4][B] nefc, ncon, solver iterations, flags                             */
   SMJ_SLOT_DEBUG = 12,    /* [SMJ_DEBUG_FLOATS][B] optional stage dumps for parity tests (may stay unbound) */
   SMJ_SLOT_PROF = 13,     /* [16][B] optional per-stage shader-cycle counters (profiling builds of a launch)     */
-  SMJ_SLOT_COUNT = 14
+  SMJ_SLOT_XPOSE = 14,    /* [nbody*12][B] world pose (xpos 3 + xmat 9, row major) of every fused body at the last step:
+                             what Renderer.update_scene reads from MjData (mujoco_server_camera_manager.py:135); input of
+                             smj_render_depth                                                                            */
+  SMJ_SLOT_COUNT = 15
 };
 
 enum smj_dim {
   SMJ_DIM_NQ = 0, SMJ_DIM_NV = 1, SMJ_DIM_NU = 2, SMJ_DIM_NBODY = 3, SMJ_DIM_NLIDAR = 4, SMJ_DIM_NKEY = 5,
-  SMJ_DIM_NUM_ENVS = 6, SMJ_DIM_DEBUG_FLOATS = 7, SMJ_DIM_NEFC_MAX = 8, SMJ_DIM_NCON_MAX = 9, SMJ_DIM_COUNT = 10
+  SMJ_DIM_NUM_ENVS = 6, SMJ_DIM_DEBUG_FLOATS = 7, SMJ_DIM_NEFC_MAX = 8, SMJ_DIM_NCON_MAX = 9, SMJ_DIM_NCAM = 10,
+  SMJ_DIM_COUNT = 11
 };
 
 /* readout flags for smj_step */
-enum { SMJ_READ_IMU = 1, SMJ_READ_LIDAR = 2 };
+enum { SMJ_READ_IMU = 1, SMJ_READ_LIDAR = 2, SMJ_READ_POSES = 4 };
 
 /* Replaces MjModel.from_xml_path + MjData(model) (mujoco_server.py:252,258): `blob` is the compiled model
  * produced by stretch_mujoco_amd.mjcf_compiler / model_fuse (SMJB format, model_blob.py). */
@@ -70,6 +74,17 @@ int smj_step(smj_ctx* ctx, int nsteps, unsigned read_flags, void* stream);
 /* Solver / collision options (mjOption fields): "iterations", "tolerance", "warmstart", "pgs_fixed_iter",
  * "max_contacts_per_pair". */
 int smj_set_option(smj_ctx* ctx, const char* name, double value);
+
+/* Depth image of camera `camera_id` (index into the model's cameras, stretch.xml order: d405_rgb, d405_depth,
+ * d435i_camera_rgb, d435i_camera_depth, nav_camera_rgb) for every env, from the body poses in SMJ_SLOT_XPOSE (written by
+ * the last smj_step that had SMJ_READ_POSES set).  Replaces Renderer.update_scene + Renderer.render with depth enabled
+ * (mujoco_server_camera_manager.py:127-143) followed by StretchCameras.post_processing_callback
+ * (enums/stretch_cameras.py:87-102): out_dev is fp32 [num_envs][height][width], metres along the optical axis, row 0 at the
+ * top; values beyond max_depth are 0 (utils.limit_depth_distance, utils.py:87-91); max_depth <= 0 returns the raw render
+ * (far plane where nothing is hit).  fovy_deg is the vertical field of view set_camera_params writes into the model
+ * (mujoco_server_camera_manager.py:185-215). */
+int smj_render_depth(smj_ctx* ctx, int camera_id, int width, int height, float fovy_deg, float max_depth, void* out_dev,
+                     void* stream);
 
 const char* smj_last_error(const smj_ctx* ctx);
 const char* smj_version(void);

@@ -38,6 +38,9 @@ def lib():
         L.smjo_step_n.restype = None
         L.smjo_sensors.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.smjo_sensors.restype = None
+        L.smjo_render_depth.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
+        L.smjo_render_depth.restype = ctypes.c_int
         L.smjo_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double]
         L.smjo_get.restype = ctypes.POINTER(ctypes.c_double)
         L.smjo_get.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
@@ -121,6 +124,15 @@ class Oracle:
 
     def step(self, n: int = 1):
         self.L.smjo_step_n(self.m, self.d, n)
+
+    def render_depth(self, cam: int, width: int, height: int, fovy_deg: float, max_depth: float = 0.0) -> np.ndarray:
+        """Depth image [height, width] (fp32) of camera `cam` from the poses of the last forward()/step()."""
+        out = np.zeros((height, width), np.float32)
+        rc = self.L.smjo_render_depth(self.m, self.d, int(cam), int(width), int(height), float(fovy_deg), float(max_depth),
+                                      out.ctypes.data_as(ctypes.c_void_p))
+        if rc != 0:
+            raise ValueError("model blob has no render tables, or bad camera id")
+        return out
 
     def sensors(self, with_lidar: bool = True):
         self.L.smjo_sensors(self.m, self.d, int(with_lidar))

@@ -84,6 +84,11 @@ struct smjo_model {
   double *pair_friction, *pair_solref, *pair_solimp, *pair_margin, *pair_gap;
   int imu_site, *lidar_site;
   double* lidar_static;
+  /* depth cameras: camera-visible mesh geoms and their triangles (render tables of the product blob; may be absent) */
+  int *geom_group, *geom_rmeshid, *rmesh_vertadr, *rmesh_faceadr, *rmesh_facenum, *rmesh_face, nrmesh;
+  double* rmesh_vert;
+  double znear, zfar; /* absolute: vis.map.znear / zfar times stat.extent */
+  struct rbvh* rbvh;  /* one per render mesh, built on first use */
 };
 
 typedef struct {
@@ -162,6 +167,17 @@ smjo_model* smjo_load(const void* blob, size_t nbytes) {
   LOADF(key_ctrl);
   LOADI(pair_geom1); LOADI(pair_geom2); LOADI(pair_condim);
   LOADF(pair_friction); LOADF(pair_solref); LOADF(pair_solimp); LOADF(pair_margin); LOADF(pair_gap);
+  LOADI(geom_group);
+  if (blob_find(b, "geom_rmeshid") && blob_find(b, "rmesh_vert")) {
+    LOADI(geom_rmeshid); LOADI(rmesh_vertadr); LOADI(rmesh_faceadr); LOADI(rmesh_face);
+    m->rmesh_facenum = blob_i32(b, "rmesh_facenum", &m->nrmesh);
+    const blob_entry* e = blob_find(b, "rmesh_vert");
+    if (e->dtype != 3) { fprintf(stderr, "smj_oracle: rmesh_vert must be f32\n"); abort(); }
+    size_t cnt = e->nbytes / 4;
+    m->rmesh_vert = (double*)malloc((cnt ? cnt : 1) * sizeof(double));
+    for (size_t i = 0; i < cnt; i++) { float v; memcpy(&v, b + e->offset + 4 * i, 4); m->rmesh_vert[i] = v; }
+    t = blob_f64(b, "vis_znear_zfar_extent", NULL); m->znear = t[0] * t[2]; m->zfar = t[1] * t[2]; free(t);
+  }
   return m;
 }
 
@@ -1850,4 +1866,206 @@ static double ray_geom(const smjo_model* m, const smjo_data* d, int g, const dou
     return best;
   }
   return -1;
+}
+
+
+/* ------------------------------------------------------------------ depth cameras
+ * Restates what the reference obtains from mujoco.Renderer (update_scene + render with depth enabled,
+ * stretch_mujoco/mujoco_server_camera_manager.py:127-143) followed by utils.limit_depth_distance (utils.py:87-91):
+ * [MJ] geoms of groups 0-2 with alpha > 0 are drawn, the camera looks down -Z with +Y up, projection is the pure-fovy
+ * pinhole (cam_sensorsize 0), depth is the distance along the optical axis clipped to [znear, zfar] * extent, back faces
+ * are culled.  Ray casting at pixel centres instead of rasterisation: equal away from silhouette pixels.
+ * The mesh acceleration structure is a median-split tree walked with a stack -- deliberately not the Morton/heap layout
+ * of the HIP renderer (csrc/smj_bvh.h), so that the two share no traversal logic. */
+typedef struct { double lo[3], hi[3]; int left, right, first, count; } rnode;
+struct rbvh { rnode* node; int nnode; int* tri; /* face ids in leaf order */ };
+
+static void rb_bounds(const smjo_model* m, int mesh, const int* ids, int n, double* lo, double* hi) {
+  const double* V = m->rmesh_vert + 3 * (size_t)m->rmesh_vertadr[mesh];
+  const int* F = m->rmesh_face + 3 * (size_t)m->rmesh_faceadr[mesh];
+  for (int k = 0; k < 3; k++) { lo[k] = 1e300; hi[k] = -1e300; }
+  for (int i = 0; i < n; i++)
+    for (int c = 0; c < 3; c++) {
+      const double* v = V + 3 * F[3 * ids[i] + c];
+      for (int k = 0; k < 3; k++) { if (v[k] < lo[k]) lo[k] = v[k]; if (v[k] > hi[k]) hi[k] = v[k]; }
+    }
+}
+static const double* rb_cen; /* qsort context: centroid coordinate per face */
+static int rb_cmp(const void* a, const void* b) {
+  double x = rb_cen[*(const int*)a], y = rb_cen[*(const int*)b];
+  return (x > y) - (x < y);
+}
+static int rb_build(const smjo_model* m, int mesh, struct rbvh* t, int first, int count, double* cen3) {
+  int id = t->nnode++;
+  rnode* nd = &t->node[id];
+  rb_bounds(m, mesh, t->tri + first, count, nd->lo, nd->hi);
+  nd->first = first; nd->count = count; nd->left = nd->right = -1;
+  if (count <= 4) return id;
+  int ax = 0;
+  double ext[3] = {nd->hi[0] - nd->lo[0], nd->hi[1] - nd->lo[1], nd->hi[2] - nd->lo[2]};
+  if (ext[1] > ext[ax]) ax = 1;
+  if (ext[2] > ext[ax]) ax = 2;
+  rb_cen = cen3 + (size_t)ax * m->rmesh_facenum[mesh];
+  qsort(t->tri + first, count, sizeof(int), rb_cmp);
+  int half = count / 2;
+  int l = rb_build(m, mesh, t, first, half, cen3);
+  int r = rb_build(m, mesh, t, first + half, count - half, cen3);
+  t->node[id].left = l; t->node[id].right = r; t->node[id].count = 0;
+  return id;
+}
+static void rb_ensure(smjo_model* m) {
+  if (m->rbvh || !m->rmesh_vert) return;
+  m->rbvh = (struct rbvh*)calloc(m->nrmesh ? m->nrmesh : 1, sizeof(struct rbvh));
+  for (int mesh = 0; mesh < m->nrmesh; mesh++) {
+    int nf = m->rmesh_facenum[mesh];
+    struct rbvh* t = &m->rbvh[mesh];
+    t->node = (rnode*)calloc(2 * (size_t)(nf ? nf : 1), sizeof(rnode));
+    t->tri = (int*)malloc((nf ? nf : 1) * sizeof(int));
+    double* cen3 = (double*)malloc(3 * (size_t)(nf ? nf : 1) * sizeof(double));
+    const double* V = m->rmesh_vert + 3 * (size_t)m->rmesh_vertadr[mesh];
+    const int* F = m->rmesh_face + 3 * (size_t)m->rmesh_faceadr[mesh];
+    for (int f = 0; f < nf; f++) {
+      t->tri[f] = f;
+      for (int k = 0; k < 3; k++) cen3[(size_t)k * nf + f] = (V[3 * F[3 * f] + k] + V[3 * F[3 * f + 1] + k] + V[3 * F[3 * f + 2] + k]) / 3;
+    }
+    if (nf > 0) rb_build(m, mesh, t, 0, nf, cen3);
+    free(cen3);
+  }
+}
+/* nearest front-facing hit with t in [tnear, best) */
+static double rb_ray(const smjo_model* m, int mesh, const double* o, const double* dv, double tnear, double best) {
+  const struct rbvh* t = &m->rbvh[mesh];
+  if (t->nnode == 0) return best;
+  const double* V = m->rmesh_vert + 3 * (size_t)m->rmesh_vertadr[mesh];
+  const int* F = m->rmesh_face + 3 * (size_t)m->rmesh_faceadr[mesh];
+  int stack[128], sp = 0;
+  stack[sp++] = 0;
+  while (sp) {
+    const rnode* nd = &t->node[stack[--sp]];
+    double t0 = tnear, t1 = best;
+    int miss = 0;
+    for (int k = 0; k < 3 && !miss; k++) {
+      if (fabs(dv[k]) < 1e-300) { if (o[k] < nd->lo[k] || o[k] > nd->hi[k]) miss = 1; continue; }
+      double a = (nd->lo[k] - o[k]) / dv[k], b = (nd->hi[k] - o[k]) / dv[k];
+      if (a > b) { double s = a; a = b; b = s; }
+      if (a > t0) t0 = a;
+      if (b < t1) t1 = b;
+      if (t0 > t1) miss = 1;
+    }
+    if (miss) continue;
+    if (nd->left >= 0) { stack[sp++] = nd->left; stack[sp++] = nd->right; continue; }
+    for (int i = 0; i < nd->count; i++) {
+      const int f = t->tri[nd->first + i];
+      const double *a = V + 3 * F[3 * f], *b = V + 3 * F[3 * f + 1], *c = V + 3 * F[3 * f + 2];
+      double e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]}, p[3], q[3];
+      cross3(p, dv, e2);
+      double det = dot3(e1, p);
+      if (det <= 1e-30) continue; /* back face or edge-on */
+      double tv[3] = {o[0] - a[0], o[1] - a[1], o[2] - a[2]};
+      double u = dot3(tv, p);
+      if (u < 0 || u > det) continue;
+      cross3(q, tv, e1);
+      double v = dot3(dv, q);
+      if (v < 0 || u + v > det) continue;
+      double x = dot3(e2, q) / det;
+      if (x >= tnear && x < best) best = x;
+    }
+  }
+  return best;
+}
+/* entering intersection with a primitive (outside faces only), in the geom frame */
+static double ray_prim_front(int type, const double* size, const double* lp, const double* lv, double tnear) {
+  if (type == G_PLANE) {
+    if (lv[2] > -MINVAL) return -1;
+    double x = -lp[2] / lv[2];
+    if (x < tnear) return -1;
+    double px = lp[0] + x * lv[0], py = lp[1] + x * lv[1];
+    if ((size[0] <= 0 || fabs(px) <= size[0]) && (size[1] <= 0 || fabs(py) <= size[1])) return x;
+    return -1;
+  }
+  if (type == G_SPHERE) {
+    double a = dot3(lv, lv), b = dot3(lv, lp), c = dot3(lp, lp) - size[0] * size[0], det = b * b - a * c;
+    if (det < MINVAL) return -1;
+    double x = (-b - sqrt(det)) / a;
+    return x >= tnear ? x : -1;
+  }
+  if (type == G_CYLINDER) {
+    double best = -1;
+    double a = lv[0] * lv[0] + lv[1] * lv[1], b = lv[0] * lp[0] + lv[1] * lp[1], c = lp[0] * lp[0] + lp[1] * lp[1] - size[0] * size[0];
+    double det = b * b - a * c;
+    if (a > MINVAL && det >= MINVAL) {
+      double x = (-b - sqrt(det)) / a;
+      if (x >= tnear && fabs(lp[2] + x * lv[2]) <= size[1]) best = x;
+    }
+    if (fabs(lv[2]) > MINVAL) {
+      double sg = lv[2] < 0 ? 1 : -1;
+      double x = (sg * size[1] - lp[2]) / lv[2];
+      if (x >= tnear) {
+        double px = lp[0] + x * lv[0], py = lp[1] + x * lv[1];
+        if (px * px + py * py <= size[0] * size[0] && (best < 0 || x < best)) best = x;
+      }
+    }
+    return best;
+  }
+  if (type == G_BOX) {
+    double best = -1;
+    for (int ax = 0; ax < 3; ax++) {
+      if (fabs(lv[ax]) < MINVAL) continue;
+      double sg = lv[ax] < 0 ? 1 : -1;
+      double x = (sg * size[ax] - lp[ax]) / lv[ax];
+      if (x < tnear) continue;
+      int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+      if (fabs(lp[a1] + x * lv[a1]) <= size[a1] && fabs(lp[a2] + x * lv[a2]) <= size[a2] && (best < 0 || x < best)) best = x;
+    }
+    return best;
+  }
+  return -1;
+}
+/* out: float[H][W]; returns 0, or -1 when the blob has no render tables */
+int smjo_render_depth(smjo_model* m, const smjo_data* d, int cam, int W, int H, double fovy_deg, double max_depth, float* out) {
+  if (!m->rmesh_vert || cam < 0 || cam >= m->ncam) return -1;
+  rb_ensure(m);
+  const double* cp = d->cam_xpos + 3 * cam;
+  const double* cm = d->cam_xmat + 9 * cam;
+  const double th = tan(fovy_deg * 3.14159265358979323846 / 360.0), aspect = (double)W / (double)H;
+  const double tnear = m->znear, tfar = (max_depth > 0 && max_depth < m->zfar) ? max_depth : m->zfar;
+  for (int v = 0; v < H; v++)
+    for (int u = 0; u < W; u++) {
+      double dc[3] = {((u + 0.5) / W * 2 - 1) * th * aspect, (1 - (v + 0.5) / H * 2) * th, -1.0}, dv[3];
+      mulmat3vec(dv, cm, dc);
+      double best = tfar * (1 + 1e-6);
+      for (int g = 0; g < m->ngeom; g++) {
+        if (m->geom_group[g] > 2 || m->geom_rgba[4 * g + 3] == 0) continue;
+        int type = m->geom_type[g];
+        if (type == G_MESH && m->geom_rmeshid[g] < 0) continue;
+        const double *pos = d->geom_xpos + 3 * g, *R = d->geom_xmat + 9 * g;
+        double dif[3] = {cp[0] - pos[0], cp[1] - pos[1], cp[2] - pos[2]}, lp[3], lv[3];
+        mulmat3Tvec(lp, R, dif);
+        mulmat3Tvec(lv, R, dv);
+        if (type == G_MESH) {
+          /* cheap reject against the geom AABB (geom_aabb: centre, half sizes in the geom frame) */
+          const double* bb = m->geom_aabb + 6 * g;
+          double t0 = tnear, t1 = best;
+          int miss = 0;
+          for (int k = 0; k < 3 && !miss; k++) {
+            const double hs = bb[3 + k] + 1e-6; /* the box was taken before the vertices were rounded to fp32 */
+            if (fabs(lv[k]) < 1e-300) { if (fabs(lp[k] - bb[k]) > hs) miss = 1; continue; }
+            double a = (bb[k] - hs - lp[k]) / lv[k], b = (bb[k] + hs - lp[k]) / lv[k];
+            if (a > b) { double s = a; a = b; b = s; }
+            if (a > t0) t0 = a;
+            if (b < t1) t1 = b;
+            if (t0 > t1) miss = 1;
+          }
+          if (!miss) best = rb_ray(m, m->geom_rmeshid[g], lp, lv, tnear, best);
+        } else {
+          double x = ray_prim_front(type, m->geom_size + 3 * g, lp, lv, tnear);
+          if (x >= 0 && x < best) best = x;
+        }
+      }
+      double z = best;
+      if (z > tfar) z = max_depth > 0 ? 0 : m->zfar;
+      if (max_depth > 0 && z > max_depth) z = 0;
+      out[(size_t)v * W + u] = (float)z;
+    }
+  return 0;
 }

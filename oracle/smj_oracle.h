@@ -39,6 +39,10 @@ double* smjo_get(smjo_data* d, const char* name, int* n);
 int* smjo_get_int(smjo_data* d, const char* name, int* n);
 int smjo_dim(const smjo_model* m, const char* name);
 
+/* depth image float[H][W] of camera `cam` from the poses of the last smjo_forward / smjo_step; -1 if the blob has no
+ * render tables.  max_depth <= 0: raw render (far plane where nothing is hit). */
+int smjo_render_depth(smjo_model* m, const smjo_data* d, int cam, int W, int H, double fovy_deg, double max_depth, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,8 @@
 #include "../../include/smj.h"
 #include "smj_kernels.h"
 #include "smj_model_load.h"
+#include "smj_bvh.h"
+#include "smj_render.h"
 
 struct smj_ctx {
   int device = 0;
@@ -19,6 +21,8 @@ struct smj_ctx {
   std::vector<void*> allocs;
   std::string err;
   float* qpos0_dev = nullptr;
+  DevRender render{};
+  bool has_render = false;
   void* slot_ptr[SMJ_SLOT_COUNT] = {};
   long slot_ld[SMJ_SLOT_COUNT] = {};
 };
@@ -53,6 +57,78 @@ struct DeviceUploader {
   const int* i32(const std::vector<int>& h) { return put(h); }
 };
 
+// Depth-camera tables: visible-geom list, camera frames and one BVH per render mesh (built here, uploaded once).
+static int setup_render(smj_ctx* c, const void* blob, size_t nbytes) {
+  SmjBlob b{static_cast<const uint8_t*>(blob), nbytes};
+  const SmjBlobEntry* rg = b.find("k_rgeom");
+  const SmjBlobEntry* rv = b.find("rmesh_vert");
+  const SmjBlobEntry* rf = b.find("rmesh_face");
+  const SmjBlobEntry* va = b.find("rmesh_vertadr");
+  const SmjBlobEntry* vn = b.find("rmesh_vertnum");
+  const SmjBlobEntry* fa = b.find("rmesh_faceadr");
+  const SmjBlobEntry* fn = b.find("rmesh_facenum");
+  const SmjBlobEntry* gm = b.find("geom_rmeshid");
+  const SmjBlobEntry* cb = b.find("cam_bodyid");
+  const SmjBlobEntry* cp = b.find("cam_pos");
+  const SmjBlobEntry* cm = b.find("k_cam_mat");
+  const SmjBlobEntry* vz = b.find("vis_znear_zfar_extent");
+  const SmjBlobEntry* nr = b.find("k_nrgeom");
+  if (!rg || !rv || !rf || !va || !vn || !fa || !fn || !gm || !cb || !cp || !cm || !vz || !nr) return 0;   // model without render tables
+  if (rv->dtype != 3 || rf->dtype != 1 || vz->dtype != 0 || cp->dtype != 0 || cm->dtype != 0)
+    return fail(c, -3, "model blob: render tables have unexpected types");
+  DeviceUploader up{c};
+  DevRender& r = c->render;
+  int nrgeom = 0;
+  memcpy(&nrgeom, b.p + nr->offset, 4);
+  if (nrgeom > SMJ_RGEOM_MAX) return fail(c, -4, "model has %d camera-visible geoms, renderer capacity is %d", nrgeom, SMJ_RGEOM_MAX);
+  r.nrgeom = nrgeom;
+  r.ncam = (int)(cb->nbytes / 4);
+  r.nbody = c->model.nbody;
+  double z[3];
+  memcpy(z, b.p + vz->offset, 24);
+  r.znear = (float)(z[0] * z[2]);
+  r.zfar = (float)(z[1] * z[2]);
+  auto geti = [&](const SmjBlobEntry* e) { std::vector<int> h(e->nbytes / 4 ? e->nbytes / 4 : 1, 0); memcpy(h.data(), b.p + e->offset, e->nbytes); return h; };
+  auto getd = [&](const SmjBlobEntry* e) {
+    std::vector<float> h(e->nbytes / 8 ? e->nbytes / 8 : 1, 0.f);
+    const double* src = reinterpret_cast<const double*>(b.p + e->offset);
+    for (size_t i = 0; i < e->nbytes / 8; i++) h[i] = (float)src[i];
+    return h;
+  };
+  r.rgeom = up.i32(geti(rg));
+  r.geom_rmeshid = up.i32(geti(gm));
+  r.cam_bodyid = up.i32(geti(cb));
+  r.cam_pos = up.f32(getd(cp));
+  r.cam_mat = up.f32(getd(cm));
+  r.geom_type = c->model.geom_type; r.geom_bodyid = c->model.geom_bodyid; r.geom_pos = c->model.geom_pos;
+  r.geom_mat = c->model.k_geom_mat; r.geom_size = c->model.geom_size; r.geom_rbound = c->model.geom_rbound;
+  r.geom_bcenter = c->model.k_geom_bcenter;
+  // BVHs
+  const std::vector<int> vadr = geti(va), vnum = geti(vn), fadr = geti(fa), fnum = geti(fn);
+  const float* verts = reinterpret_cast<const float*>(b.p + rv->offset);
+  const int* faces = reinterpret_cast<const int*>(b.p + rf->offset);
+  const size_t nmesh = va->nbytes / 4;
+  SmjBvhSet set;
+  for (size_t i = 0; i < nmesh; i++) {
+    // faces index the vertices of their own mesh
+    smj_bvh_add_mesh(set, verts + 3 * (size_t)vadr[i], vnum[i], faces + 3 * (size_t)fadr[i], fnum[i]);
+  }
+  std::vector<int> meshtab(4 * (nmesh ? nmesh : 1), 0);
+  for (size_t i = 0; i < nmesh; i++) {
+    meshtab[4 * i] = set.mesh[i].nodebase; meshtab[4 * i + 1] = set.mesh[i].tribase; meshtab[4 * i + 2] = set.mesh[i].leaf0;
+    meshtab[4 * i + 3] = set.mesh[i].ntri;
+  }
+  if (set.node.empty()) set.node.assign(16, 0.f);
+  if (set.tri.empty()) set.tri.assign(12, 0.f);
+  r.node = reinterpret_cast<const float4*>(up.f32(set.node));
+  r.tri = reinterpret_cast<const float4*>(up.f32(set.tri));
+  r.mesh = reinterpret_cast<const int4*>(up.i32(meshtab));
+  if (!r.rgeom || !r.geom_rmeshid || !r.cam_bodyid || !r.cam_pos || !r.cam_mat || !r.node || !r.tri || !r.mesh)
+    return fail(c, -2, "device allocation failed for the render tables");
+  c->has_render = true;
+  return 0;
+}
+
 extern "C" {
 
 const char* smj_version(void) { return "smj 0.1 (gfx950)"; }
@@ -76,7 +152,7 @@ int smj_create(const void* blob, size_t nbytes, int num_envs, int device, smj_ct
   c->qpos0_dev = const_cast<float*>(m.qpos0);
   c->state.B = num_envs;
   c->state.ld = num_envs;
-  return 0;
+  return setup_render(c, blob, nbytes);
 }
 
 int smj_destroy(smj_ctx* c) {
@@ -91,7 +167,7 @@ int smj_dims(const smj_ctx* c, int* out) {
   out[SMJ_DIM_NQ] = c->model.nq; out[SMJ_DIM_NV] = c->model.nv; out[SMJ_DIM_NU] = c->model.nu;
   out[SMJ_DIM_NBODY] = c->model.nbody; out[SMJ_DIM_NLIDAR] = c->model.nlidar; out[SMJ_DIM_NKEY] = c->model.nkey;
   out[SMJ_DIM_NUM_ENVS] = c->num_envs; out[SMJ_DIM_DEBUG_FLOATS] = SMJ_DEBUG_FLOATS; out[SMJ_DIM_NEFC_MAX] = NEFC;
-  out[SMJ_DIM_NCON_MAX] = NCON;
+  out[SMJ_DIM_NCON_MAX] = NCON; out[SMJ_DIM_NCAM] = c->has_render ? c->render.ncam : 0;
   return 0;
 }
 
@@ -117,6 +193,7 @@ int smj_bind(smj_ctx* c, int slot, void* p, long ld) {
     case SMJ_SLOT_INFO: s.info = (int*)p; break;
     case SMJ_SLOT_DEBUG: s.debug = (float*)p; break;
     case SMJ_SLOT_PROF: s.prof = (float*)p; break;
+    case SMJ_SLOT_XPOSE: s.xpose = (float*)p; break;
   }
   return 0;
 }
@@ -131,7 +208,7 @@ static int check_bound(smj_ctx* c) {
     if (ld < 0) ld = c->slot_ld[s];
     if (c->slot_ld[s] != ld) return fail(c, -5, "all batch-major slots must share one leading dimension");
   }
-  for (int s : {SMJ_SLOT_GYRO, SMJ_SLOT_ACCEL, SMJ_SLOT_LIDAR, SMJ_SLOT_DEBUG, SMJ_SLOT_PROF})
+  for (int s : {SMJ_SLOT_GYRO, SMJ_SLOT_ACCEL, SMJ_SLOT_LIDAR, SMJ_SLOT_DEBUG, SMJ_SLOT_PROF, SMJ_SLOT_XPOSE})
     if (c->slot_ptr[s] && c->slot_ld[s] != ld) return fail(c, -5, "slot %d: leading dimension differs", s);
   c->state.ld = ld;
   return 0;
@@ -154,8 +231,23 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
   if (rc) return rc;
   if ((read_flags & SMJ_READ_IMU) && (!c->state.gyro || !c->state.accel)) return fail(c, -5, "IMU readout requested but GYRO/ACCEL not bound");
   if ((read_flags & SMJ_READ_LIDAR) && !c->state.lidar) return fail(c, -5, "lidar readout requested but LIDAR not bound");
+  if ((read_flags & SMJ_READ_POSES) && !c->state.xpose) return fail(c, -5, "pose readout requested but XPOSE not bound");
   HIPCHK(c, hipSetDevice(c->device));
   smj_launch_step(c->model, c->state, nsteps, read_flags, (hipStream_t)stream);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+int smj_render_depth(smj_ctx* c, int cam, int width, int height, float fovy_deg, float max_depth, void* out_dev, void* stream) {
+  if (!c) return -1;
+  if (!c->has_render) return fail(c, -6, "the model blob carries no render tables (k_rgeom / rmesh_*)");
+  if (cam < 0 || cam >= c->render.ncam) return fail(c, -1, "camera id %d out of range (ncam %d)", cam, c->render.ncam);
+  if (width <= 0 || height <= 0 || !(fovy_deg > 0.f && fovy_deg < 180.f)) return fail(c, -1, "bad image size / field of view");
+  if (!out_dev) return fail(c, -1, "null output image");
+  if (!c->state.xpose) return fail(c, -5, "XPOSE slot is not bound (step with SMJ_READ_POSES first)");
+  HIPCHK(c, hipSetDevice(c->device));
+  smj_launch_depth(c->render, c->state.xpose, c->slot_ld[SMJ_SLOT_XPOSE], c->num_envs, cam, width, height, fovy_deg, max_depth,
+                   (float*)out_dev, (hipStream_t)stream);
   HIPCHK(c, hipGetLastError());
   return 0;
 }

@@ -66,6 +66,7 @@ struct DevState {
   int* info;       // [4][B]   nefc, ncon, solver iterations, flags (bit0: efc overflow, bit1: contact overflow, bit2: nan reset)
   float* debug;    // [SMJ_DEBUG_FLOATS][B] or null: stage dumps for parity tests
   float* prof;     // [SMJ_PROF_SLOTS][B] or null: shader cycles per stage, summed over the launch
+  float* xpose;    // [nbody*12][B] or null: world pose (xpos 3, xmat 9) of every fused body at the last step (depth cameras)
 };
 
 enum { SMJ_PROF_KIN = 0, SMJ_PROF_COMCRB, SMJ_PROF_SMOOTH, SMJ_PROF_FACTOR, SMJ_PROF_COLLISION, SMJ_PROF_MAKECON,

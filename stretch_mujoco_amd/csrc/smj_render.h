@@ -1,0 +1,30 @@
+// Depth-camera renderer of the batched Stretch simulator (smj_render.hip): one thread per pixel ray, cast against the
+// geoms a MuJoCo camera draws (geom groups 0-2, alpha > 0), mesh geoms through per-mesh BVHs (smj_bvh.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define SMJ_RGEOM_MAX 128
+
+struct DevRender {
+  int nrgeom, ncam, nbody;
+  float znear, zfar;               // absolute clip distances = vis.map.znear/zfar * stat.extent
+  const int* rgeom;                // [nrgeom] geom ids a camera can see
+  const int* geom_type;
+  const int* geom_bodyid;
+  const int* geom_rmeshid;
+  const float* geom_pos;           // [ngeom][3]  (fused-body frame)
+  const float* geom_mat;           // [ngeom][9]
+  const float* geom_size;          // [ngeom][3]
+  const float* geom_rbound;        // [ngeom]
+  const float* geom_bcenter;       // [ngeom][3]  bounding-sphere centre, body frame
+  const int* cam_bodyid;           // [ncam]
+  const float* cam_pos;            // [ncam][3]
+  const float* cam_mat;            // [ncam][9]
+  const float4* node;              // BVH nodes, two float4 per node
+  const float4* tri;               // packed triangles, three float4 per triangle
+  const int4* mesh;                // per render mesh: nodebase, tribase, leaf0, ntri
+};
+
+// xpose: [nbody*12][ld] batch-major body poses (xpos 3 + xmat 9) written by the step kernel (SMJ_READ_POSES)
+void smj_launch_depth(const DevRender& r, const float* xpose, long ld, int num_envs, int cam, int width, int height,
+                      float fovy_deg, float max_depth, float* out, hipStream_t stream);

@@ -1,0 +1,254 @@
+// Depth cameras of the batched Stretch simulator on gfx950.
+//
+// Replaces mujoco.Renderer.update_scene + render with depth enabled (reference: mujoco_server_camera_manager.py:127-143)
+// and the post-processing of StretchCameras.post_processing_callback (enums/stretch_cameras.py:87-102 ->
+// utils.limit_depth_distance, utils.py:87-91).  [MJ] the depth image of mujoco.Renderer is the distance along the optical
+// axis (not along the ray), the camera looks down its -Z with +Y up, the projection is a pure-fovy pinhole when
+// cam_sensorsize is 0 (it is: enums/stretch_cameras.py leaves sensor_size None), fragments nearer than znear*extent or
+// farther than zfar*extent are clipped, back faces are culled.
+//
+// One thread per pixel ray, a 16x16 pixel tile per workgroup (coherent rays -> coherent BVH walks), blockIdx.y = env.
+// The tile first stages the world poses of the visible geoms in LDS; every ray then runs over those geoms with a
+// bounding-sphere reject and, for meshes, a stack-free walk of the mesh BVH (heap layout, see smj_bvh.h) in the mesh frame.
+#include "smj_render.h"
+
+namespace {
+
+struct RGeom {
+  float pos[3], mat[9], cen[3], rbound, size[3];
+  int type, rmesh;
+};
+
+enum { RT_PLANE = 0, RT_SPHERE = 2, RT_CAPSULE = 3, RT_ELLIPSOID = 4, RT_CYLINDER = 5, RT_BOX = 6, RT_MESH = 7 };
+
+__device__ __forceinline__ float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void mulT(float* r, const float* m, const float* v) {   // r = m' v
+  r[0] = m[0] * v[0] + m[3] * v[1] + m[6] * v[2];
+  r[1] = m[1] * v[0] + m[4] * v[1] + m[7] * v[2];
+  r[2] = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+}
+__device__ __forceinline__ void mul(float* r, const float* m, const float* v) {    // r = m v
+  r[0] = m[0] * v[0] + m[1] * v[1] + m[2] * v[2];
+  r[1] = m[3] * v[0] + m[4] * v[1] + m[5] * v[2];
+  r[2] = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+}
+
+// nearest front-facing hit of the ray o + t d with the mesh, t in (tnear, best); returns the new best
+__device__ float ray_mesh(const DevRender& R, int rmesh, const float* o, const float* d, float tnear, float best) {
+  const int4 mi = R.mesh[rmesh];
+  const float4* node = R.node + 2 * (long)mi.x;
+  const float4* tri = R.tri + 3 * (long)mi.y;
+  const int leaf0 = mi.z;
+  const float inv[3] = {1.f / d[0], 1.f / d[1], 1.f / d[2]};   // +-inf for axis-parallel rays: the slab test below copes
+  int n = 1;
+  while (true) {
+    const float4 lo = node[2 * n], hi = node[2 * n + 1];
+    float t0 = tnear, t1 = best;
+    {
+      const float a = (lo.x - o[0]) * inv[0], b = (hi.x - o[0]) * inv[0];
+      t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));
+    }
+    {
+      const float a = (lo.y - o[1]) * inv[1], b = (hi.y - o[1]) * inv[1];
+      t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));
+    }
+    {
+      const float a = (lo.z - o[2]) * inv[2], b = (hi.z - o[2]) * inv[2];
+      t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));
+    }
+    const bool hit = t0 <= t1;   // NaN (0 * inf) compares false: such a box is skipped only if the ray lies in its face plane
+    if (hit && n < leaf0) { n = 2 * n; continue; }
+    if (hit) {
+      const float4* T = tri + 3 * 4 * (long)(n - leaf0);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const float4 v0 = T[3 * k], e1 = T[3 * k + 1], e2 = T[3 * k + 2];
+        const float p[3] = {d[1] * e2.z - d[2] * e2.y, d[2] * e2.x - d[0] * e2.z, d[0] * e2.y - d[1] * e2.x};
+        const float det = e1.x * p[0] + e1.y * p[1] + e1.z * p[2];
+        if (det > 1e-30f) {   // front face only (GL_CULL_FACE)
+          const float tv[3] = {o[0] - v0.x, o[1] - v0.y, o[2] - v0.z};
+          const float u = tv[0] * p[0] + tv[1] * p[1] + tv[2] * p[2];
+          const float q[3] = {tv[1] * e1.z - tv[2] * e1.y, tv[2] * e1.x - tv[0] * e1.z, tv[0] * e1.y - tv[1] * e1.x};
+          const float v = d[0] * q[0] + d[1] * q[1] + d[2] * q[2];
+          if (u >= 0.f && v >= 0.f && u + v <= det) {
+            const float t = (e2.x * q[0] + e2.y * q[1] + e2.z * q[2]) / det;
+            if (t >= tnear && t < best) best = t;
+          }
+        }
+      }
+    }
+    n += 1;
+    n >>= __builtin_ctz(n);
+    if (n == 1) break;
+  }
+  return best;
+}
+
+// entering intersection of the ray with a primitive in its own frame (outside faces only), or -1
+__device__ float ray_prim(int type, const float* size, const float* lp, const float* lv, float tnear) {
+  if (type == RT_PLANE) {
+    if (lv[2] > -1e-15f) return -1.f;
+    const float x = -lp[2] / lv[2];
+    if (x < tnear) return -1.f;
+    const float px = lp[0] + x * lv[0], py = lp[1] + x * lv[1];
+    if ((size[0] <= 0 || fabsf(px) <= size[0]) && (size[1] <= 0 || fabsf(py) <= size[1])) return x;
+    return -1.f;
+  }
+  if (type == RT_SPHERE) {
+    const float a = dot3(lv, lv), b = dot3(lv, lp), c = dot3(lp, lp) - size[0] * size[0];
+    const float det = b * b - a * c;
+    if (det < 1e-15f) return -1.f;
+    const float x = (-b - sqrtf(det)) / a;
+    return x >= tnear ? x : -1.f;
+  }
+  if (type == RT_CYLINDER) {
+    float best = -1.f;
+    const float a = lv[0] * lv[0] + lv[1] * lv[1], b = lv[0] * lp[0] + lv[1] * lp[1], c = lp[0] * lp[0] + lp[1] * lp[1] - size[0] * size[0];
+    const float det = b * b - a * c;
+    if (a > 1e-15f && det >= 1e-15f) {
+      const float x = (-b - sqrtf(det)) / a;
+      if (x >= tnear && fabsf(lp[2] + x * lv[2]) <= size[1]) best = x;
+    }
+    if (fabsf(lv[2]) > 1e-15f) {
+      const float sg = lv[2] < 0 ? 1.f : -1.f;   // the cap facing the ray
+      const float x = (sg * size[1] - lp[2]) / lv[2];
+      if (x >= tnear) {
+        const float px = lp[0] + x * lv[0], py = lp[1] + x * lv[1];
+        if (px * px + py * py <= size[0] * size[0] && (best < 0 || x < best)) best = x;
+      }
+    }
+    return best;
+  }
+  if (type == RT_BOX) {
+    float best = -1.f;
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) {
+      if (fabsf(lv[ax]) < 1e-15f) continue;
+      const float sg = lv[ax] < 0 ? 1.f : -1.f;   // the face of this axis that faces the ray
+      const float x = (sg * size[ax] - lp[ax]) / lv[ax];
+      if (x < tnear) continue;
+      const int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+      if (fabsf(lp[a1] + x * lv[a1]) <= size[a1] && fabsf(lp[a2] + x * lv[a2]) <= size[a2] && (best < 0 || x < best)) best = x;
+    }
+    return best;
+  }
+  if (type == RT_CAPSULE) {
+    float best = -1.f;
+    const float a = lv[0] * lv[0] + lv[1] * lv[1], b = lv[0] * lp[0] + lv[1] * lp[1], c = lp[0] * lp[0] + lp[1] * lp[1] - size[0] * size[0];
+    const float det = b * b - a * c;
+    if (a > 1e-15f && det >= 1e-15f) {
+      const float x = (-b - sqrtf(det)) / a;
+      if (x >= tnear && fabsf(lp[2] + x * lv[2]) <= size[1]) best = x;
+    }
+    for (int sg = -1; sg <= 1; sg += 2) {
+      const float q[3] = {lp[0], lp[1], lp[2] - sg * size[1]};
+      const float aa = dot3(lv, lv), bb = dot3(lv, q), cc = dot3(q, q) - size[0] * size[0];
+      const float dd = bb * bb - aa * cc;
+      if (dd < 1e-15f) continue;
+      const float x = (-bb - sqrtf(dd)) / aa;
+      if (x >= tnear && sg * (lp[2] + x * lv[2]) >= size[1] && (best < 0 || x < best)) best = x;
+    }
+    return best;
+  }
+  if (type == RT_ELLIPSOID) {
+    const float s[3] = {1.f / size[0], 1.f / size[1], 1.f / size[2]};
+    const float v[3] = {lv[0] * s[0], lv[1] * s[1], lv[2] * s[2]}, p[3] = {lp[0] * s[0], lp[1] * s[1], lp[2] * s[2]};
+    const float a = dot3(v, v), b = dot3(v, p), c = dot3(p, p) - 1.f;
+    const float det = b * b - a * c;
+    if (det < 1e-15f) return -1.f;
+    const float x = (-b - sqrtf(det)) / a;
+    return x >= tnear ? x : -1.f;
+  }
+  return -1.f;
+}
+
+__global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const float* __restrict__ xpose, long ld, int cam, int width,
+                                                        int height, float tan_half_fovy, float max_depth, float* __restrict__ out) {
+  __shared__ RGeom geoms[SMJ_RGEOM_MAX];
+  __shared__ float cpos[3], cmat[9];
+  const int env = blockIdx.y;
+  const int tiles_x = (width + 15) / 16;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int tid = threadIdx.x;
+  // stage camera and geom world poses of this env
+  if (tid < R.nrgeom) {
+    const int g = R.rgeom[tid], b = R.geom_bodyid[g];
+    float bp[3], bm[9];
+    for (int k = 0; k < 3; k++) bp[k] = xpose[(12 * b + k) * ld + env];
+    for (int k = 0; k < 9; k++) bm[k] = xpose[(12 * b + 3 + k) * ld + env];
+    RGeom& G = geoms[tid];
+    const float lp[3] = {R.geom_pos[3 * g], R.geom_pos[3 * g + 1], R.geom_pos[3 * g + 2]};
+    const float lc[3] = {R.geom_bcenter[3 * g], R.geom_bcenter[3 * g + 1], R.geom_bcenter[3 * g + 2]};
+    float w[3];
+    mul(w, bm, lp);
+    for (int k = 0; k < 3; k++) G.pos[k] = bp[k] + w[k];
+    mul(w, bm, lc);
+    for (int k = 0; k < 3; k++) G.cen[k] = bp[k] + w[k];
+    const float* lm = R.geom_mat + 9 * g;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) G.mat[3 * i + j] = bm[3 * i] * lm[j] + bm[3 * i + 1] * lm[3 + j] + bm[3 * i + 2] * lm[6 + j];
+    G.type = R.geom_type[g];
+    G.rmesh = R.geom_rmeshid[g];
+    G.rbound = R.geom_rbound[g];
+    for (int k = 0; k < 3; k++) G.size[k] = R.geom_size[3 * g + k];
+  }
+  if (tid == 255) {
+    const int b = R.cam_bodyid[cam];
+    float bp[3], bm[9];
+    for (int k = 0; k < 3; k++) bp[k] = xpose[(12 * b + k) * ld + env];
+    for (int k = 0; k < 9; k++) bm[k] = xpose[(12 * b + 3 + k) * ld + env];
+    float w[3];
+    mul(w, bm, R.cam_pos + 3 * cam);
+    for (int k = 0; k < 3; k++) cpos[k] = bp[k] + w[k];
+    const float* lm = R.cam_mat + 9 * cam;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) cmat[3 * i + j] = bm[3 * i] * lm[j] + bm[3 * i + 1] * lm[3 + j] + bm[3 * i + 2] * lm[6 + j];
+  }
+  __syncthreads();
+  const int u = tx * 16 + (tid & 15), v = ty * 16 + (tid >> 4);
+  if (u >= width || v >= height) return;
+  // pixel centre -> ray in the camera frame (x right, y up, looking down -z); parameter t = distance along the optical axis
+  const float aspect = (float)width / (float)height;
+  const float xn = ((u + 0.5f) / width * 2.f - 1.f) * tan_half_fovy * aspect;
+  const float yn = (1.f - (v + 0.5f) / height * 2.f) * tan_half_fovy;
+  const float dc[3] = {xn, yn, -1.f};
+  float d[3], o[3] = {cpos[0], cpos[1], cpos[2]};
+  mul(d, cmat, dc);
+  const float dd = dot3(d, d), dl = sqrtf(dd);
+  const float tnear = R.znear;
+  const float tfar = (max_depth > 0.f && max_depth < R.zfar) ? max_depth : R.zfar;   // hits beyond the limit become 0 anyway
+  float best = tfar * (1.f + 1e-6f);
+  const int ng = R.nrgeom;
+  for (int i = 0; i < ng; i++) {
+    const RGeom& G = geoms[i];
+    if (G.type != RT_PLANE) {   // bounding sphere
+      const float oc[3] = {G.cen[0] - o[0], G.cen[1] - o[1], G.cen[2] - o[2]};
+      const float b = dot3(oc, d), r = G.rbound;
+      if (dot3(oc, oc) * dd - b * b > r * r * dd) continue;
+      if (b + r * dl < tnear * dd || b - r * dl > best * dd) continue;
+    }
+    const float dif[3] = {o[0] - G.pos[0], o[1] - G.pos[1], o[2] - G.pos[2]};
+    float lp[3], lv[3];
+    mulT(lp, G.mat, dif);
+    mulT(lv, G.mat, d);
+    if (G.type == RT_MESH) {
+      if (G.rmesh >= 0) best = ray_mesh(R, G.rmesh, lp, lv, tnear, best);
+    } else {
+      const float x = ray_prim(G.type, G.size, lp, lv, tnear);
+      if (x >= 0 && x < best) best = x;
+    }
+  }
+  float z = best;
+  if (z > tfar) z = (max_depth > 0.f) ? 0.f : R.zfar;   // nothing in range: the far plane, which limit_depth_distance zeroes
+  if (max_depth > 0.f && z > max_depth) z = 0.f;
+  out[((long)env * height + v) * width + u] = z;
+}
+
+}  // namespace
+
+void smj_launch_depth(const DevRender& r, const float* xpose, long ld, int num_envs, int cam, int width, int height,
+                      float fovy_deg, float max_depth, float* out, hipStream_t stream) {
+  const int tiles = ((width + 15) / 16) * ((height + 15) / 16);
+  const float th = tanf(fovy_deg * 3.14159265358979323846f / 360.f);
+  hipLaunchKernelGGL(smj_depth_kernel, dim3(tiles, num_envs), dim3(256), 0, stream, r, xpose, ld, cam, width, height, th, max_depth, out);
+}

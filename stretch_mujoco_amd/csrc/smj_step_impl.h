@@ -2454,6 +2454,16 @@ struct StepKernel {
     }
   }
 
+  // body poses of the last step for the depth renderer (smj_render.hip): what mjv_updateScene reads from mjData
+  SMJ_DEV void dump_poses() {
+    if (!S.xpose) return;
+    LANES {
+      if (lane < M.nbody) {
+        for (int k = 0; k < 3; k++) S.xpose[(long)(12 * lane + k) * S.ld + env] = s.xpos[lane][k];
+        for (int k = 0; k < 9; k++) S.xpose[(long)(12 * lane + 3 + k) * S.ld + env] = s.xmat[lane][k];
+      }
+    }
+  }
   SMJ_DEV void dump_debug() {
     if (!S.debug) return;
     LANES {
@@ -2498,6 +2508,7 @@ struct StepKernel {
       const bool last = st == nsteps - 1;
       kinematics();
       if (last && want_lidar) lidar();
+      if (last && (read_flags & 4)) dump_poses();
       TICK(SMJ_PROF_KIN)
       com_crb();
       if (last) dump_debug();

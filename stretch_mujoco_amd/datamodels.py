@@ -64,9 +64,52 @@ class StatusStretchSensors:  # status_stretch_sensors.py:10-77
 
 @dataclass
 class StatusStretchCameras:  # status_stretch_camera.py:10-125 (depth only on this path)
+    """Batched: every image is a torch tensor [B, H, W] (fp32 metres), K is the 3x3 intrinsic matrix shared by all envs.
+    The depth tensors are views of simulator-owned buffers that the next pull_camera_data() overwrites: .clone() to keep."""
     time: Any
     fps: float
+    cam_d405_rgb: Optional[Any] = None
     cam_d405_depth: Optional[Any] = None
-    cam_d435i_depth: Optional[Any] = None
     cam_d405_K: Optional[Any] = None
+    cam_d435i_rgb: Optional[Any] = None
+    cam_d435i_depth: Optional[Any] = None
     cam_d435i_K: Optional[Any] = None
+    cam_nav_rgb: Optional[Any] = None
+
+    def get_camera_data(self, camera, *, auto_rotate: bool = True, **_ignored):
+        """status_stretch_camera.py:48-86: the d435i frames come out of the (physically rotated) optical frame and are
+        turned upright with rot90(-1) when auto_rotate is set; ValueError when the image is empty."""
+        from .enums import StretchCameras
+        import torch
+
+        data = None
+        if camera == StretchCameras.cam_d405_depth and self.cam_d405_depth is not None:
+            data = self.cam_d405_depth
+        elif camera == StretchCameras.cam_d435i_depth and self.cam_d435i_depth is not None:
+            data = self.cam_d435i_depth
+            data = torch.rot90(data, -1, dims=(-2, -1)) if auto_rotate else data
+        if data is None:
+            raise ValueError(f"Tried to get {camera} data, but it is empty or not implemented.")
+        return data
+
+    def get_all(self, *, auto_rotate: bool = True, **kw) -> dict:
+        from .enums import StretchCameras
+
+        data = {}
+        for camera in StretchCameras.all():
+            try:
+                data[camera] = self.get_camera_data(camera, auto_rotate=auto_rotate, **kw)
+            except ValueError:
+                ...
+        return data
+
+    def set_camera_data(self, camera, data):
+        from .enums import StretchCameras
+
+        if camera not in list(StretchCameras):
+            raise NotImplementedError(f"Camera {camera} is not implemented.")
+        setattr(self, camera.name, data)
+
+    @staticmethod
+    def default():
+        return StatusStretchCameras(time=0, fps=0)

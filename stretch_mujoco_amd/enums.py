@@ -170,3 +170,46 @@ class StretchCameras(Enum):
     @property
     def is_depth(self) -> bool:
         return self in (StretchCameras.cam_d405_depth, StretchCameras.cam_d435i_depth)
+
+    @property
+    def depth_limit(self) -> float:
+        """Metres beyond which post_processing_callback zeroes the depth (enums/stretch_cameras.py:87-102, config.py:8)."""
+        from . import config
+
+        if self == StretchCameras.cam_d405_depth:
+            return float(config.depth_limits["d405"])
+        if self == StretchCameras.cam_d435i_depth:
+            return float(config.depth_limits["d435i"])
+        raise NotImplementedError(f"Camera {self} has no depth limit")
+
+    @property
+    def initial_camera_settings(self) -> "CameraSettings":
+        """enums/stretch_cameras.py:105-156: the depth cameras reuse the settings of their RGB twins."""
+        if self in (StretchCameras.cam_d405_rgb, StretchCameras.cam_d405_depth):
+            return CameraSettings(field_of_view_vertical_in_degrees=58, focal=(242.56, 242.34), width=480, height=270,
+                                  sensor_resolution=(1280, 720))
+        if self in (StretchCameras.cam_d435i_rgb, StretchCameras.cam_d435i_depth):
+            return CameraSettings(field_of_view_vertical_in_degrees=42, focal=(304.24, 304.07), width=424, height=240,
+                                  sensor_resolution=(1920, 1080))
+        if self == StretchCameras.cam_nav_rgb:
+            import math
+
+            fovy = int(abs(math.degrees(2 * math.atan(math.tan(math.radians(70) / 2) * (1280 / 720)))))
+            return CameraSettings(field_of_view_vertical_in_degrees=fovy, focal=(0.0, 0.0), width=800, height=600,
+                                  sensor_resolution=(1280, 720))
+        raise NotImplementedError(f"Camera {self} initial settings are not implemented")
+
+
+class CameraSettings:
+    """enums/stretch_cameras.py:184-206 (the fields the depth path uses)."""
+
+    def __init__(self, field_of_view_vertical_in_degrees, focal, width, height, sensor_resolution=None):
+        self.field_of_view_vertical_in_degrees = field_of_view_vertical_in_degrees
+        self.focal = focal
+        self.width = width
+        self.height = height
+        self.sensor_resolution = sensor_resolution
+
+    @property
+    def sensor_size(self):
+        return None   # pixel sizes are commented out in the reference: cam_sensorsize stays 0, pure-fovy pinhole

@@ -982,8 +982,34 @@ class MjcfCompiler:
         m["pair_margin"] = np.array(P["margin"], float); m["pair_gap"] = np.array(P["gap"], float)
         m["sensor_imu_site"] = np.array([imu_site], np.int32); m["sensor_lidar_site"] = np.array(lidar_sites, np.int32)
         m["sensor_lidar_cutoff"] = np.array([lidar_cutoff])
-        extent = self.stat_extent
-        m["vis_znear_zfar_extent"] = np.array([self.znear, self.zfar, extent if extent is not None else -1.0])
+        # ---------------- render meshes: triangles of the mesh geoms a camera can see.  [MJ] mjv_addGeoms draws geom groups
+        # 0-2 by default and skips geoms whose rgba alpha is 0; the collision class of stretch.xml is group 3 (hidden).
+        rm_index: Dict[str, int] = {}
+        rverts, rfaces, rvadr, rvnum, rfadr, rfnum, geom_rmeshid = [], [], [], [], [], [], []
+        nrv = nrf = 0
+        for g in range(ngeom):
+            name = self._geom_mesh_names[g]
+            md = mesh_cache.get(name) if name is not None else None
+            if md is None or G["group"][g] > 2 or G["rgba"][g][3] == 0:
+                geom_rmeshid.append(-1)
+                continue
+            if name not in rm_index:
+                rm_index[name] = len(rvadr)
+                # weld exactly repeated vertices (OBJ exporters repeat them per face); geometry is unchanged
+                v32 = np.ascontiguousarray(np.asarray(md["v"], np.float32))
+                uv, inv = np.unique(v32, axis=0, return_inverse=True)
+                fw = inv.reshape(-1)[np.asarray(md["f"], np.int64)].astype(np.int32)
+                rvadr.append(nrv); rvnum.append(len(uv)); rfadr.append(nrf); rfnum.append(len(fw))
+                rverts.append(uv); rfaces.append(fw)
+                nrv += len(uv); nrf += len(fw)
+            geom_rmeshid.append(rm_index[name])
+        m["geom_rmeshid"] = np.array(geom_rmeshid, np.int32).reshape(-1)
+        m["rmesh_vert"] = np.concatenate(rverts, 0).astype(np.float32) if rverts else np.zeros((0, 3), np.float32)
+        m["rmesh_face"] = np.concatenate(rfaces, 0).astype(np.int32) if rfaces else np.zeros((0, 3), np.int32)
+        m["rmesh_vertadr"] = np.array(rvadr, np.int32); m["rmesh_vertnum"] = np.array(rvnum, np.int32)
+        m["rmesh_faceadr"] = np.array(rfadr, np.int32); m["rmesh_facenum"] = np.array(rfnum, np.int32)
+        extent = self.stat_extent if self.stat_extent is not None else _stat_extent(m)
+        m["vis_znear_zfar_extent"] = np.array([self.znear, self.zfar, extent])
         names = dict(body=[b.name or "" for b in bodies], joint=jnt_names, geom=G["name"], site=site_names, camera=cam_names,
                      actuator=A["name"], tendon=ten_names, key=[k.get("name", "") for k in self.keys], mesh=mesh_names,
                      missing_meshes=self.meshes_missing)
@@ -999,6 +1025,33 @@ class MjcfCompiler:
 
 
 # ----------------------------------------------------------------------------- constants at qpos0
+def _stat_extent(m):
+    """[MJ] mj_setConst / set0: bounding box at qpos0 of body frames, body coms, joint anchors, sites and geoms (padded by
+    rbound; an infinite plane counts with rbound 1, a finite one with a tenth of its larger side); stat.extent is the
+    longest side of that box.  (MuJoCo is not importable here: restated from memory, flagged in DESIGN.md.)"""
+    xpos, xquat, xanchor, _ = _fk(m, m["qpos0"])
+    pts_lo, pts_hi = [], []
+
+    def add(p, r=0.0):
+        pts_lo.append(np.asarray(p) - r); pts_hi.append(np.asarray(p) + r)
+    for b in range(1, len(xpos)):
+        add(xpos[b]); add(xpos[b] + quat2mat(xquat[b]) @ m["body_ipos"][b])
+    for j in range(len(xanchor)):
+        add(xanchor[j])
+    for i, b in enumerate(m["site_bodyid"]):
+        add(xpos[b] + quat2mat(xquat[b]) @ m["site_pos"][i])
+    for g, b in enumerate(m["geom_bodyid"]):
+        r = m["geom_rbound"][g]
+        if m["geom_type"][g] == GEOM_PLANE:
+            sz = m["geom_size"][g]
+            r = 0.1 * max(sz[0], sz[1]) if (sz[0] > 0 or sz[1] > 0) else 1.0
+        add(xpos[b] + quat2mat(xquat[b]) @ m["geom_pos"][g], r)
+    if not pts_lo:
+        return 1.0
+    lo, hi = np.min(pts_lo, axis=0), np.max(pts_hi, axis=0)
+    return float(max(1e-5, np.max(hi - lo)))
+
+
 def _lidar_static_impl(m, mesh_cache, G_mesh_names, lidar_sites):
     """Distance of every lidar ray to the geoms that are rigidly attached to the laser (same weld group, i.e. no joint
     in between): these hits do not depend on the state, so they are ray-cast ONCE here against the true triangle

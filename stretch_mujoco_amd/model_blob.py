@@ -8,7 +8,7 @@ Layout (little endian):
     char[8]  magic  "SMJB0001"
     u32      n_entries
     u32      reserved
-    entry[n]: char name[48]; u32 dtype (0=f64, 1=i32, 2=u8); u32 ndim;
+    entry[n]: char name[48]; u32 dtype (0=f64, 1=i32, 2=u8, 3=f32); u32 ndim;
               u32 shape[4]; u64 offset (from file start); u64 nbytes
     payload, every array 16-byte aligned
 """
@@ -21,13 +21,13 @@ import numpy as np
 
 MAGIC = b"SMJB0001"
 _ENTRY = struct.Struct("<48sII4IQQ")
-_DTYPES = {0: np.float64, 1: np.int32, 2: np.uint8}
-_CODES = {np.dtype(np.float64): 0, np.dtype(np.int32): 1, np.dtype(np.uint8): 2}
+_DTYPES = {0: np.float64, 1: np.int32, 2: np.uint8, 3: np.float32}
+_CODES = {np.dtype(np.float64): 0, np.dtype(np.int32): 1, np.dtype(np.uint8): 2, np.dtype(np.float32): 3}
 
 
 def _canon(a) -> np.ndarray:
     a = np.asarray(a)
-    if a.dtype.kind == "f":
+    if a.dtype.kind == "f" and a.dtype != np.float32:   # float32 is kept as stored (bulk render-mesh vertices)
         a = a.astype(np.float64)
     elif a.dtype.kind in "iub" and a.dtype != np.uint8:
         a = a.astype(np.int32)

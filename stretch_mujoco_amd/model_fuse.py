@@ -289,6 +289,13 @@ def kernel_tables(f: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     rg = [g for g in range(ng) if f["geom_type"][g] != 7 and f["geom_rgba"][g][3] != 0]
     f["k_ray_geom"] = np.array(rg + [0], np.int32); f["k_nraygeom"] = np.array([len(rg)], np.int32)
     f["k_ray_geom_origbody"] = np.array([gob[g] for g in rg] + [0], np.int32)
+    # depth cameras: the geoms a MuJoCo camera draws ([MJ] geom groups 0-2, alpha > 0) and the camera frames
+    grp = f.get("geom_group", np.zeros(ng, np.int32))
+    rmid = f.get("geom_rmeshid", np.full(ng, -1, np.int32))
+    vis = [g for g in range(ng) if grp[g] <= 2 and f["geom_rgba"][g][3] != 0 and (f["geom_type"][g] != 7 or rmid[g] >= 0)]
+    f["k_rgeom"] = np.array(vis + [0], np.int32); f["k_nrgeom"] = np.array([len(vis)], np.int32)
+    ncam = len(f.get("cam_bodyid", []))
+    f["k_cam_mat"] = np.array([quat2mat(f["cam_quat"][c]).reshape(9) for c in range(ncam)] + [np.eye(3).reshape(9)])
     f["k_site_origbody"] = np.asarray(f.get("site_origbody", f["site_bodyid"]), np.int32)
     if len(f["k_site_origbody"]) == 0:
         f["k_site_origbody"] = np.zeros(1, np.int32)

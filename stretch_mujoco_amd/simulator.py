@@ -53,8 +53,11 @@ class StretchBatchSimulator:
         self.model = model_blob.loads(model_blob_bytes)
         self.names = json.loads(model_blob.get_str(self.model, "names_json"))
         self._sensors = list(sensors_to_use)
-        if cameras_to_use:
-            raise NotImplementedError("camera depth ray casting is not on the HIP path yet (DESIGN.md, scope)")
+        self._cameras = list(cameras_to_use)
+        for cam in self._cameras:
+            if not cam.is_depth:
+                raise NotImplementedError(f"{cam}: only the depth cameras are on the HIP path (RGB needs textures and "
+                                          "materials; DESIGN.md, scope)")
         self._start_translation = start_translation
         self._start_rotation_quat = start_rotation_quat
         self._debug = debug
@@ -117,6 +120,16 @@ class StretchBatchSimulator:
             self._read_flags |= _lib.READ_IMU
         if StretchSensors.base_lidar in self._sensors:
             self._read_flags |= _lib.READ_LIDAR
+        self._depth = {}
+        if self._cameras:
+            if dims[D["NCAM"]] == 0:
+                raise _lib.SmjError("the model blob carries no render tables: depth cameras are unavailable for this scene")
+            self.xpose = torch.zeros(dims[D["NBODY"]] * 12, B, **f)
+            _lib.check(L, ctx, L.smj_bind(ctx, S["XPOSE"], ctypes.c_void_p(self.xpose.data_ptr()), B), "smj_bind(XPOSE)")
+            self._read_flags |= _lib.READ_POSES
+            for cam in self._cameras:
+                st = cam.initial_camera_settings
+                self._depth[cam] = torch.zeros(B, st.height, st.width, **f)
         self.reset()
         if home:
             self.home()
@@ -226,7 +239,27 @@ class StretchBatchSimulator:
 
     @_require_connection
     def pull_camera_data(self) -> StatusStretchCameras:
-        raise NotImplementedError("camera depth ray casting is not on the HIP path yet (DESIGN.md, scope)")
+        """Depth images [B, H, W] of the cameras in cameras_to_use, rendered from the body poses of the last physics step
+        (what Renderer.update_scene sees, mujoco_server_camera_manager.py:127-143), limited like
+        StretchCameras.post_processing_callback; K as get_camera_params (:168-183: fovy with the SENSOR resolution).
+        The reference renders at 30 Hz wall clock (mujoco_server.py:272); here the cadence is the caller's.
+        The image tensors are simulator-owned and overwritten by the next call."""
+        from .utils import compute_K
+
+        out = StatusStretchCameras(time=self.nstep.to(torch.float64) * self.timestep, fps=0.0)
+        names = self.names["camera"]
+        for cam in self._cameras:
+            st = cam.initial_camera_settings
+            img = self._depth[cam]
+            rc = self._L.smj_render_depth(self._ctx, names.index(cam.camera_name_in_mjcf), st.width, st.height,
+                                          float(st.field_of_view_vertical_in_degrees), cam.depth_limit,
+                                          ctypes.c_void_p(img.data_ptr()), self._stream())
+            _lib.check(self._L, self._ctx, rc, "smj_render_depth")
+            out.set_camera_data(cam, img)
+        for attr, cam in (("cam_d405_K", StretchCameras.cam_d405_rgb), ("cam_d435i_K", StretchCameras.cam_d435i_rgb)):
+            st = cam.initial_camera_settings
+            setattr(out, attr, compute_K(st.field_of_view_vertical_in_degrees, st.sensor_resolution[0], st.sensor_resolution[1]))
+        return out
 
     @_require_connection
     def pull_joint_limits(self) -> dict:

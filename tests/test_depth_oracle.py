@@ -1,0 +1,151 @@
+"""Depth-camera restatement (oracle/smj_oracle.c smjo_render_depth) checked against closed forms and a brute-force ray
+caster, and the host-side camera data model against the reference's conventions.  CPU only."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import home_qpos
+from oracle.oracle import Oracle
+from stretch_mujoco_amd import model_blob
+from stretch_mujoco_amd.datamodels import StatusStretchCameras
+from stretch_mujoco_amd.enums import StretchCameras
+from stretch_mujoco_amd.utils import compute_K
+
+D405, D435 = 1, 3   # camera ids in stretch.xml order (d405_rgb, d405_depth, d435i_camera_rgb, d435i_camera_depth, nav)
+
+
+def quat2mat(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+@pytest.fixture(scope="module")
+def posed(blob_fused):
+    m = model_blob.loads(blob_fused)
+    o = Oracle(blob_fused)
+    q = home_qpos(m["qpos0"])
+    o.arr("qpos")[:] = q
+    o.forward()
+    return m, o
+
+
+def pixel_rays(cam_mat, W, H, fovy):
+    th = math.tan(fovy * math.pi / 360)
+    u, v = np.meshgrid(np.arange(W), np.arange(H))
+    dc = np.stack([((u + 0.5) / W * 2 - 1) * th * W / H, (1 - (v + 0.5) / H * 2) * th, -np.ones_like(u, float)], -1)
+    return dc @ cam_mat.T
+
+
+def test_names_order(posed):
+    m, _ = posed
+    import json
+    names = json.loads(model_blob.get_str(m, "names_json"))["camera"]
+    assert names == ["d405_rgb", "d405_depth", "d435i_camera_rgb", "d435i_camera_depth", "nav_camera_rgb"]
+    for cam in StretchCameras.depth():
+        assert names.index(cam.camera_name_in_mjcf) in (D405, D435)
+
+
+def test_plane_closed_form(posed):
+    """Wherever a ray of the head camera reaches the floor unobstructed the depth is the closed form -c_z / d_z, and no
+    pixel is ever deeper than the floor."""
+    m, o = posed
+    W, H, fovy = 106, 60, 42.0
+    img = o.render_depth(D435, W, H, fovy, 0.0)
+    cp = o.arr("cam_xpos").reshape(-1, 3)[D435]
+    cm = o.arr("cam_xmat").reshape(-1, 3, 3)[D435]
+    d = pixel_rays(cm, W, H, fovy)
+    zfar = m["vis_znear_zfar_extent"][1] * m["vis_znear_zfar_extent"][2]
+    with np.errstate(divide="ignore"):
+        floor = np.where(d[..., 2] < 0, -cp[2] / d[..., 2], np.inf)
+    floor = np.where(floor > zfar, zfar, floor)
+    assert np.all(img <= floor * (1 + 1e-6) + 1e-6)
+    on_floor = np.isclose(img, floor, rtol=1e-6, atol=1e-6) & np.isfinite(floor) & (floor < zfar)
+    assert on_floor.mean() > 0.2
+    sky = d[..., 2] >= 0
+    assert sky.any() and np.all(img[sky & (img == img.max())] == np.float32(zfar))
+
+
+def test_limit_semantics(posed):
+    """utils.limit_depth_distance (utils.py:87-91): strictly beyond the limit -> 0, the far plane included."""
+    _, o = posed
+    raw = o.render_depth(D435, 53, 30, 42.0, 0.0)
+    lim = o.render_depth(D435, 53, 30, 42.0, 10.0)
+    assert np.array_equal(lim, np.where(raw > 10.0, 0, raw))
+    assert (lim == 0).any() and (lim > 0).any()
+
+
+def test_bvh_matches_brute_force(posed):
+    """The median-split tree walk returns exactly what testing every front-facing triangle of every visible mesh does."""
+    m, o = posed
+    W, H, fovy = 24, 14, 58.0
+    img = o.render_depth(D405, W, H, fovy, 0.0)
+    cp = o.arr("cam_xpos").reshape(-1, 3)[D405]
+    cm = o.arr("cam_xmat").reshape(-1, 3, 3)[D405]
+    gx = o.arr("geom_xpos").reshape(-1, 3)
+    gm = o.arr("geom_xmat").reshape(-1, 3, 3)
+    rays = pixel_rays(cm, W, H, fovy).reshape(-1, 3)
+    zn, zf, ext = m["vis_znear_zfar_extent"]
+    near, far = zn * ext, zf * ext
+    best = np.full(len(rays), far * (1 + 1e-6))
+    V = m["rmesh_vert"].astype(np.float64)
+    for g in range(len(m["geom_type"])):
+        rm = m["geom_rmeshid"][g]
+        if m["geom_group"][g] > 2 or m["geom_rgba"][g][3] == 0:
+            continue
+        if m["geom_type"][g] == 0:   # plane
+            with np.errstate(divide="ignore"):
+                t = np.where(rays[:, 2] < 0, -cp[2] / rays[:, 2], np.inf)
+            best = np.where((t >= near) & (t < best), t, best)
+            continue
+        if rm < 0:
+            continue
+        v = V[m["rmesh_vertadr"][rm]: m["rmesh_vertadr"][rm] + m["rmesh_vertnum"][rm]]
+        f = m["rmesh_face"][m["rmesh_faceadr"][rm]: m["rmesh_faceadr"][rm] + m["rmesh_facenum"][rm]]
+        lo = (cp - gx[g]) @ gm[g]
+        ld = rays @ gm[g]
+        a, e1, e2 = v[f[:, 0]], v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]]
+        p = np.cross(ld[:, None, :], e2[None])                 # [R, T, 3]
+        det = np.einsum("tk,rtk->rt", e1, p)
+        tv = lo - a                                            # [T, 3]
+        u = np.einsum("tk,rtk->rt", tv, p)
+        q = np.cross(tv, e1)                                   # [T, 3]
+        w = ld @ q.T
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = (e2 * q).sum(-1)[None] / det
+        ok = (det > 1e-30) & (u >= 0) & (w >= 0) & (u + w <= det) & (t >= near)
+        t = np.where(ok, t, np.inf).min(axis=1)
+        best = np.minimum(best, t)
+    best = np.where(best > far, far, best).reshape(H, W)
+    assert np.allclose(img, best, rtol=1e-6, atol=1e-7)
+    assert (img < 0.5).sum() > 10      # the gripper is in view of the wrist camera
+
+
+def test_camera_intrinsics_and_rotation():
+    """get_camera_params (mujoco_server_camera_manager.py:168-183) builds K from fovy and the SENSOR resolution; the d435i
+    frames are turned upright by rot90(-1) (status_stretch_camera.py:73-76)."""
+    import torch
+
+    st = StretchCameras.cam_d405_depth.initial_camera_settings
+    assert (st.width, st.height, st.field_of_view_vertical_in_degrees) == (480, 270, 58)
+    K = compute_K(st.field_of_view_vertical_in_degrees, *st.sensor_resolution)
+    assert np.allclose(K, [[0.5 * 720 / math.tan(math.radians(29)), 0, 640], [0, 0.5 * 720 / math.tan(math.radians(29)), 360], [0, 0, 1]])
+    st = StretchCameras.cam_d435i_depth.initial_camera_settings
+    assert (st.width, st.height, st.field_of_view_vertical_in_degrees, st.sensor_resolution) == (424, 240, 42, (1920, 1080))
+    assert StretchCameras.cam_d405_depth.depth_limit == 1 and StretchCameras.cam_d435i_depth.depth_limit == 10
+    img = torch.arange(2 * 3 * 4, dtype=torch.float32).reshape(2, 3, 4)
+    s = StatusStretchCameras.default()
+    with pytest.raises(ValueError):
+        s.get_camera_data(StretchCameras.cam_d435i_depth)
+    s.set_camera_data(StretchCameras.cam_d435i_depth, img)
+    s.set_camera_data(StretchCameras.cam_d405_depth, img)
+    up = s.get_camera_data(StretchCameras.cam_d435i_depth)
+    assert up.shape == (2, 4, 3)
+    assert np.array_equal(up[1].numpy(), np.rot90(img[1].numpy(), -1))
+    assert s.get_camera_data(StretchCameras.cam_d435i_depth, auto_rotate=False) is img
+    assert s.get_camera_data(StretchCameras.cam_d405_depth) is img
+    assert set(s.get_all()) == {StretchCameras.cam_d405_depth, StretchCameras.cam_d435i_depth}
+    with pytest.raises(ValueError):
+        s.get_camera_data(StretchCameras.cam_nav_rgb)

@@ -19,7 +19,11 @@ def main():
     out = os.path.join(os.path.dirname(HERE), "stretch_mujoco_amd", "models")
     os.makedirs(out, exist_ok=True)
     m = C.compile_string(C.empty_scene_xml(stretch))
-    B.save(os.path.join(out, "stretch_empty_full.smjb"), m)                          # body-for-body (oracle / fusion test)
+    # body-for-body model (oracle / fusion test); the bulk render meshes live only in the product blob
+    full = {k: v for k, v in m.items() if k not in ("rmesh_vert", "rmesh_face")}
+    full["rmesh_vert"] = m["rmesh_vert"][:0]; full["rmesh_face"] = m["rmesh_face"][:0]
+    full["rmesh_vertnum"] = 0 * m["rmesh_vertnum"]; full["rmesh_facenum"] = 0 * m["rmesh_facenum"]
+    B.save(os.path.join(out, "stretch_empty_full.smjb"), full)
     B.save(os.path.join(out, "stretch_empty.smjb"), F.prepare_for_kernels(m))        # fused + kernel tables (product)
     print("stretch_empty:", dict(zip("nq nv nu nbody njnt ngeom nsite ncam neq ntendon nwrap nkey npair nhullvert".split(),
                                      [int(x) for x in m["dims"]])))
