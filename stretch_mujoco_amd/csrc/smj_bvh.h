@@ -3,7 +3,8 @@
 // Layout, chosen for a stack-free traversal on the GPU: the triangles of a mesh are sorted along a Morton curve of
 // their centroids and cut into leaves of four; the leaves are the last level of a COMPLETE binary tree stored as a
 // 1-based heap (children of n are 2n and 2n+1), padded with empty nodes to a power of two.  "Next subtree" is then pure
-// index arithmetic (n+1 with its trailing zero bits shifted out), so a ray needs no per-thread stack.
+// index arithmetic (sibling = n ^ 1, parent = n >> 1), so a ray needs no per-thread stack; every inner node carries the
+// axis that separates its children so that a ray can visit the nearer child first (node[...][3], see below).
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -95,10 +96,23 @@ static inline void smj_bvh_add_mesh(SmjBvhSet& set, const float* verts, int nv, 
       N[8 * n + 4 + k] = std::max(N[8 * n + 4 + k], std::max(a, std::max(b, c)));
     }
   }
-  for (int n = leaf0 - 1; n >= 1; n--)
+  for (int n = leaf0 - 1; n >= 1; n--) {
+    const float* L = N + 8 * (2 * n);
+    const float* Rr = N + 8 * (2 * n + 1);
     for (int k = 0; k < 3; k++) {
-      N[8 * n + k] = std::min(N[8 * (2 * n) + k], N[8 * (2 * n + 1) + k]);
-      N[8 * n + 4 + k] = std::max(N[8 * (2 * n) + 4 + k], N[8 * (2 * n + 1) + 4 + k]);
+      N[8 * n + k] = std::min(L[k], Rr[k]);
+      N[8 * n + 4 + k] = std::max(L[4 + k], Rr[4 + k]);
     }
+    // visiting order hint: the axis along which the two children are furthest apart, and whether the left child is the
+    // one with the larger coordinate (code = axis + 4 * swapped); a ray enters the child on its own side first
+    int axis = 0, swapped = 0;
+    float sep = -1.f;
+    if (L[0] <= L[4] && Rr[0] <= Rr[4])
+      for (int k = 0; k < 3; k++) {
+        const float dc = (Rr[k] + Rr[4 + k]) - (L[k] + L[4 + k]);
+        if (fabsf(dc) > sep) { sep = fabsf(dc); axis = k; swapped = dc < 0; }
+      }
+    N[8 * n + 3] = (float)(axis + 4 * swapped);
+  }
   set.mesh.push_back(m);
 }

@@ -56,8 +56,15 @@ __device__ float ray_mesh(const DevRender& R, int rmesh, const float* o, const f
       const float a = (lo.z - o[2]) * inv[2], b = (hi.z - o[2]) * inv[2];
       t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));
     }
-    const bool hit = t0 <= t1;   // NaN (0 * inf) compares false: such a box is skipped only if the ray lies in its face plane
-    if (hit && n < leaf0) { n = 2 * n; continue; }
+    // padding nodes are stored inverted (lo > hi): the slab test alone would accept them.  NaN (0 * inf) compares false:
+    // such a box is skipped only if the ray lies in its face plane
+    const bool hit = t0 <= t1 && lo.x <= hi.x;
+    if (hit && n < leaf0) {      // inner node: nearer child first
+      const int code = (int)lo.w, axis = code & 3;
+      const float da = axis == 0 ? d[0] : (axis == 1 ? d[1] : d[2]);
+      n = 2 * n + (((da >= 0.f) == ((code >> 2) != 0)) ? 1 : 0);
+      continue;
+    }
     if (hit) {
       const float4* T = tri + 3 * 4 * (long)(n - leaf0);
 #pragma unroll
@@ -77,9 +84,16 @@ __device__ float ray_mesh(const DevRender& R, int rmesh, const float* o, const f
         }
       }
     }
-    n += 1;
-    n >>= __builtin_ctz(n);
-    if (n == 1) break;
+    // next subtree: the sibling if this node was the first (nearer) child of its parent, otherwise climb
+    while (true) {
+      if (n == 1) return best;
+      const int par = n >> 1;
+      const int code = (int)node[2 * par].w, axis = code & 3;
+      const float da = axis == 0 ? d[0] : (axis == 1 ? d[1] : d[2]);
+      const int first = 2 * par + (((da >= 0.f) == ((code >> 2) != 0)) ? 1 : 0);
+      if (n == first) { n ^= 1; break; }
+      n = par;
+    }
   }
   return best;
 }
@@ -165,7 +179,8 @@ __device__ float ray_prim(int type, const float* size, const float* lp, const fl
 __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const float* __restrict__ xpose, long ld, int cam, int width,
                                                         int height, float tan_half_fovy, float max_depth, float* __restrict__ out) {
   __shared__ RGeom geoms[SMJ_RGEOM_MAX];
-  __shared__ float cpos[3], cmat[9];
+  __shared__ float cpos[3], cmat[9], gkey[SMJ_RGEOM_MAX];
+  __shared__ int gorder[SMJ_RGEOM_MAX];
   const int env = blockIdx.y;
   const int tiles_x = (width + 15) / 16;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
@@ -205,6 +220,21 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
       for (int j = 0; j < 3; j++) cmat[3 * i + j] = bm[3 * i] * lm[j] + bm[3 * i + 1] * lm[3 + j] + bm[3 * i + 2] * lm[6 + j];
   }
   __syncthreads();
+  // front-to-back geom order for the whole tile (rank sort on the distance from the camera to the bounding sphere): the
+  // nearest hit is found early and the bounding-sphere reject below then drops most of what lies behind it
+  if (tid < R.nrgeom) {
+    const RGeom& G = geoms[tid];
+    const float dc[3] = {G.cen[0] - cpos[0], G.cen[1] - cpos[1], G.cen[2] - cpos[2]};
+    gkey[tid] = G.type == RT_PLANE ? -1.f : sqrtf(dot3(dc, dc)) - G.rbound;
+  }
+  __syncthreads();
+  if (tid < R.nrgeom) {
+    const float key = gkey[tid];
+    int rank = 0;
+    for (int j = 0; j < R.nrgeom; j++) rank += (gkey[j] < key) || (gkey[j] == key && j < tid);
+    gorder[rank] = tid;
+  }
+  __syncthreads();
   const int u = tx * 16 + (tid & 15), v = ty * 16 + (tid >> 4);
   if (u >= width || v >= height) return;
   // pixel centre -> ray in the camera frame (x right, y up, looking down -z); parameter t = distance along the optical axis
@@ -220,7 +250,7 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
   float best = tfar * (1.f + 1e-6f);
   const int ng = R.nrgeom;
   for (int i = 0; i < ng; i++) {
-    const RGeom& G = geoms[i];
+    const RGeom& G = geoms[gorder[i]];
     if (G.type != RT_PLANE) {   // bounding sphere
       const float oc[3] = {G.cen[0] - o[0], G.cen[1] - o[1], G.cen[2] - o[2]};
       const float b = dot3(oc, d), r = G.rbound;
