@@ -1760,6 +1760,8 @@ void smjo_step_n(const smjo_model* m, smjo_data* d, int n) {
 
 /* ------------------------------------------------------------------ B.9 sensors */
 static double ray_geom(const smjo_model* m, const smjo_data* d, int g, const double* pnt, const double* vec);
+static void rb_ensure(smjo_model* m);
+static double rb_ray(const smjo_model* m, int mesh, const double* o, const double* dv, double tnear, double best, int cull);
 
 void smjo_sensors(const smjo_model* m, smjo_data* d, int with_lidar) {
   /* expects smjo_forward() state; [MJ] mj_rnePostConstraint for cacc, then mj_objectAcceleration/Velocity */
@@ -1796,12 +1798,24 @@ void smjo_sensors(const smjo_model* m, smjo_data* d, int with_lidar) {
       int s = m->lidar_site[i], sb = m->site_bodyid[s];
       const double* R = d->site_xmat + 9 * s;
       /* geoms in the laser's weld group: state-independent hits ray-cast by the model compiler against the triangle
-       * meshes (sensor_lidar_static); all other geoms: plane and primitives at run time (meshes on moving bodies are
-       * outside this round's scope) */
+       * meshes (sensor_lidar_static); all other geoms at run time: plane and primitives in closed form, mesh geoms
+       * ([MJ] mj_rayMesh: the mesh's own triangles, both sides, any geom group) through the triangle tree */
       double vec[3] = {R[2], R[5], R[8]}, best = m->lidar_static[i];
+      const double* pnt = d->site_xpos + 3 * s;
+      if (m->rmesh_vert) rb_ensure((smjo_model*)m);
       for (int g = 0; g < m->ngeom; g++) {
         if (m->body_weldid[m->geom_bodyid[g]] == m->body_weldid[sb] || m->geom_rgba[4 * g + 3] == 0) continue;
-        double x = ray_geom(m, d, g, d->site_xpos + 3 * s, vec);
+        if (m->geom_type[g] == G_MESH) {
+          if (!m->rmesh_vert || m->geom_rmeshid[g] < 0) continue;
+          const double *pos = d->geom_xpos + 3 * g, *Rg = d->geom_xmat + 9 * g;
+          double dif[3] = {pnt[0] - pos[0], pnt[1] - pos[1], pnt[2] - pos[2]}, lp[3], lv[3];
+          mulmat3Tvec(lp, Rg, dif);
+          mulmat3Tvec(lv, Rg, vec);
+          double x = rb_ray(m, m->geom_rmeshid[g], lp, lv, 0.0, best >= 0 ? best : 1e300, 0);
+          if (x < 1e299 && (best < 0 || x < best)) best = x;
+          continue;
+        }
+        double x = ray_geom(m, d, g, pnt, vec);
         if (x >= 0 && (best < 0 || x < best)) best = x;
       }
       if (best > m->lidar_cutoff && m->lidar_cutoff > 0) best = m->lidar_cutoff;
@@ -1933,7 +1947,7 @@ static void rb_ensure(smjo_model* m) {
   }
 }
 /* nearest front-facing hit with t in [tnear, best) */
-static double rb_ray(const smjo_model* m, int mesh, const double* o, const double* dv, double tnear, double best) {
+static double rb_ray(const smjo_model* m, int mesh, const double* o, const double* dv, double tnear, double best, int cull) {
   const struct rbvh* t = &m->rbvh[mesh];
   if (t->nnode == 0) return best;
   const double* V = m->rmesh_vert + 3 * (size_t)m->rmesh_vertadr[mesh];
@@ -1960,13 +1974,13 @@ static double rb_ray(const smjo_model* m, int mesh, const double* o, const doubl
       double e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]}, p[3], q[3];
       cross3(p, dv, e2);
       double det = dot3(e1, p);
-      if (det <= 1e-30) continue; /* back face or edge-on */
+      if (cull ? det <= 1e-30 : fabs(det) <= 1e-30) continue; /* back face (cameras only) or edge-on */
       double tv[3] = {o[0] - a[0], o[1] - a[1], o[2] - a[2]};
-      double u = dot3(tv, p);
-      if (u < 0 || u > det) continue;
+      double u = dot3(tv, p) / det;
+      if (u < 0 || u > 1) continue;
       cross3(q, tv, e1);
-      double v = dot3(dv, q);
-      if (v < 0 || u + v > det) continue;
+      double v = dot3(dv, q) / det;
+      if (v < 0 || u + v > 1) continue;
       double x = dot3(e2, q) / det;
       if (x >= tnear && x < best) best = x;
     }
@@ -2056,7 +2070,7 @@ int smjo_render_depth(smjo_model* m, const smjo_data* d, int cam, int W, int H, 
             if (b < t1) t1 = b;
             if (t0 > t1) miss = 1;
           }
-          if (!miss) best = rb_ray(m, m->geom_rmeshid[g], lp, lv, tnear, best);
+          if (!miss) best = rb_ray(m, m->geom_rmeshid[g], lp, lv, tnear, best, 1);
         } else {
           double x = ray_prim_front(type, m->geom_size + 3 * g, lp, lv, tnear);
           if (x >= 0 && x < best) best = x;

@@ -23,6 +23,7 @@ struct smj_ctx {
   float* qpos0_dev = nullptr;
   DevRender render{};
   bool has_render = false;
+  float* pose_ws = nullptr;   // internal [nbody*12][num_envs] body poses when the caller has not bound SMJ_SLOT_XPOSE
   void* slot_ptr[SMJ_SLOT_COUNT] = {};
   long slot_ld[SMJ_SLOT_COUNT] = {};
 };
@@ -73,7 +74,12 @@ static int setup_render(smj_ctx* c, const void* blob, size_t nbytes) {
   const SmjBlobEntry* cm = b.find("k_cam_mat");
   const SmjBlobEntry* vz = b.find("vis_znear_zfar_extent");
   const SmjBlobEntry* nr = b.find("k_nrgeom");
-  if (!rg || !rv || !rf || !va || !vn || !fa || !fn || !gm || !cb || !cp || !cm || !vz || !nr) return 0;   // model without render tables
+  const SmjBlobEntry* lg = b.find("k_lgeom");
+  const SmjBlobEntry* nl = b.find("k_nlgeom");
+  const SmjBlobEntry* ls = b.find("sensor_lidar_site");
+  const SmjBlobEntry* lt = b.find("sensor_lidar_static");
+  if (!rg || !rv || !rf || !va || !vn || !fa || !fn || !gm || !cb || !cp || !cm || !vz || !nr || !lg || !nl || !ls || !lt)
+    return 0;   // model without ray-casting tables: smj_render_depth / lidar readout report that
   if (rv->dtype != 3 || rf->dtype != 1 || vz->dtype != 0 || cp->dtype != 0 || cm->dtype != 0)
     return fail(c, -3, "model blob: render tables have unexpected types");
   DeviceUploader up{c};
@@ -100,6 +106,15 @@ static int setup_render(smj_ctx* c, const void* blob, size_t nbytes) {
   r.cam_bodyid = up.i32(geti(cb));
   r.cam_pos = up.f32(getd(cp));
   r.cam_mat = up.f32(getd(cm));
+  memcpy(&r.nlgeom, b.p + nl->offset, 4);
+  r.nlidar = c->model.nlidar;
+  r.lidar_cutoff = c->model.lidar_cutoff;
+  if (r.nlidar > 384) return fail(c, -4, "model has %d lidar rays, kernel capacity is 384", r.nlidar);
+  r.lgeom = up.i32(geti(lg));
+  r.lidar_site = up.i32(geti(ls));
+  r.lidar_static = up.f32(getd(lt));
+  r.site_bodyid = c->model.site_bodyid; r.site_pos = c->model.site_pos; r.site_mat = c->model.k_site_mat;
+  if (!r.lgeom || !r.lidar_site || !r.lidar_static) return fail(c, -2, "device allocation failed for the lidar tables");
   r.geom_type = c->model.geom_type; r.geom_bodyid = c->model.geom_bodyid; r.geom_pos = c->model.geom_pos;
   r.geom_mat = c->model.k_geom_mat; r.geom_size = c->model.geom_size; r.geom_rbound = c->model.geom_rbound;
   r.geom_bcenter = c->model.k_geom_bcenter;
@@ -233,8 +248,31 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
   if ((read_flags & SMJ_READ_LIDAR) && !c->state.lidar) return fail(c, -5, "lidar readout requested but LIDAR not bound");
   if ((read_flags & SMJ_READ_POSES) && !c->state.xpose) return fail(c, -5, "pose readout requested but XPOSE not bound");
   HIPCHK(c, hipSetDevice(c->device));
-  smj_launch_step(c->model, c->state, nsteps, read_flags, (hipStream_t)stream);
+  DevState st = c->state;
+  long pose_ld = c->slot_ld[SMJ_SLOT_XPOSE];
+  if (read_flags & SMJ_READ_LIDAR) {
+    // the lidar is ray-cast by its own kernel from the body poses of the last step
+    if (!c->has_render) return fail(c, -6, "the model blob carries no ray-casting tables (k_lgeom / rmesh_*): no lidar");
+    if (!st.xpose) {
+      if (!c->pose_ws) {
+        void* d = nullptr;
+        HIPCHK(c, hipMalloc(&d, sizeof(float) * 12 * (size_t)c->model.nbody * (size_t)c->num_envs));
+        c->allocs.push_back(d);
+        c->pose_ws = (float*)d;
+      }
+      st.xpose = c->pose_ws;
+      pose_ld = c->num_envs;
+      // the step kernel indexes every batch-major array with one leading dimension
+      if (st.ld != pose_ld) return fail(c, -5, "bind SMJ_SLOT_XPOSE when the leading dimension differs from num_envs");
+    }
+    read_flags |= SMJ_READ_POSES;
+  }
+  smj_launch_step(c->model, st, nsteps, read_flags, (hipStream_t)stream);
   HIPCHK(c, hipGetLastError());
+  if (read_flags & SMJ_READ_LIDAR) {
+    smj_launch_lidar(c->render, st.xpose, pose_ld, c->num_envs, st.lidar, st.ld, (hipStream_t)stream);
+    HIPCHK(c, hipGetLastError());
+  }
   return 0;
 }
 

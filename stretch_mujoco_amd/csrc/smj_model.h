@@ -16,7 +16,7 @@
   X(dof_bodyid) X(dof_jntid) X(dof_parentid) X(k_dof_anc_adr) X(k_dof_anc_num) X(k_dof_anc) X(k_dof_velmask_lo)   \
   X(k_dof_velmask_hi) X(k_dof_qposadr) X(k_ldl_i) X(k_ldl_j) X(k_ldl_lact) X(k_fric_dof) X(k_limit_jnt) X(k_act_dof) X(k_dof_act)                         \
   X(geom_type) X(geom_bodyid) X(geom_hulladr) X(geom_hullnum)                                                     \
-  X(site_bodyid) X(sensor_lidar_site) X(k_ray_geom) X(k_ray_geom_origbody) X(k_site_origbody)                                                                           \
+  X(site_bodyid)                                                                           \
   X(eq_obj1id) X(eq_obj2id) X(eq_active)                                                                          \
   X(actuator_trntype) X(actuator_trnid) X(actuator_ctrllimited) X(actuator_forcelimited) X(actuator_biastype)     \
   X(pair_geom1) X(pair_geom2) X(pair_condim) X(k_planepair) X(k_cgeom) X(k_convpair) X(k_convpair_s1) X(k_convpair_s2) X(k_convpair_ss)
@@ -27,7 +27,7 @@
   X(qpos_spring)                                                                                                  \
   X(dof_armature) X(dof_damping) X(dof_frictionloss) X(dof_invweight0) X(dof_solref) X(dof_solimp)                \
   X(geom_pos) X(k_geom_mat) X(geom_size) X(geom_rbound) X(k_geom_bcenter) X(geom_rgba) X(geom_invweight0)         \
-  X(k_hull_vert4) X(sensor_lidar_static) X(geom_aabb) X(geom_ccenter) X(k_convpair_rsum) X(k_cgeom_half) X(k_cgeom_lcen)                                                                             \
+  X(k_hull_vert4) X(geom_aabb) X(geom_ccenter) X(k_convpair_rsum) X(k_cgeom_half) X(k_cgeom_lcen)                                                                             \
   X(site_pos) X(k_site_mat)                                                                                       \
   X(eq_data) X(eq_solref) X(eq_solimp)                                                                            \
   X(actuator_gear) X(actuator_gainprm) X(actuator_biasprm) X(actuator_ctrlrange) X(actuator_forcerange)           \
@@ -36,7 +36,7 @@
 
 struct DevModel {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, neq, npair, nlevel, nfric, nlimit, nplanepair, nldl, nlidar, imu_site,
-      ngc, nroot, nkey, nraygeom, ncgeom, nconvpair;
+      ngc, nroot, nkey, ncgeom, nconvpair;
   int iterations, warmstart, pgs_fixed_iter, max_con_pair, solver /* 0 PGS, 2 Newton */, ls_iterations, convex_pairs;
   float ls_tolerance;
   float timestep, gravity[3], impratio, tolerance, meaninertia, lidar_cutoff;

@@ -23,8 +23,19 @@ struct DevRender {
   const float4* node;              // BVH nodes, two float4 per node
   const float4* tri;               // packed triangles, three float4 per triangle
   const int4* mesh;                // per render mesh: nodebase, tribase, leaf0, ntri
+  // 2-D lidar (rangefinder sites on the laser body)
+  int nlidar, nlgeom;
+  float lidar_cutoff;
+  const int* lgeom;                // [nlgeom] geoms tested at run time (everything not welded to the laser, alpha > 0)
+  const int* lidar_site;           // [nlidar] site ids, ray order
+  const int* site_bodyid;
+  const float* site_pos;           // [nsite][3]
+  const float* site_mat;           // [nsite][9]; the ray runs along the site's +Z
+  const float* lidar_static;       // [nlidar] distance to the geoms welded to the laser (ray-cast by the model compiler), -1 none
 };
 
 // xpose: [nbody*12][ld] batch-major body poses (xpos 3 + xmat 9) written by the step kernel (SMJ_READ_POSES)
+// lidar: [nlidar][ld] batch-major ranges, -1 = no hit, clipped to the sensor cutoff
+void smj_launch_lidar(const DevRender& r, const float* xpose, long ld, int num_envs, float* lidar, long lidar_ld, hipStream_t stream);
 void smj_launch_depth(const DevRender& r, const float* xpose, long ld, int num_envs, int cam, int width, int height,
                       float fovy_deg, float max_depth, float* out, hipStream_t stream);

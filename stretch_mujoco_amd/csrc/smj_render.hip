@@ -33,7 +33,9 @@ __device__ __forceinline__ void mul(float* r, const float* m, const float* v) { 
   r[2] = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
 }
 
-// nearest front-facing hit of the ray o + t d with the mesh, t in (tnear, best); returns the new best
+// nearest hit of the ray o + t d with the mesh, t in [tnear, best); returns the new best.  CULL: front faces only (cameras,
+// GL_CULL_FACE); otherwise both sides ([MJ] mj_rayMesh, lidar)
+template <bool CULL>
 __device__ float ray_mesh(const DevRender& R, int rmesh, const float* o, const float* d, float tnear, float best) {
   const int4 mi = R.mesh[rmesh];
   const float4* node = R.node + 2 * (long)mi.x;
@@ -72,13 +74,14 @@ __device__ float ray_mesh(const DevRender& R, int rmesh, const float* o, const f
         const float4 v0 = T[3 * k], e1 = T[3 * k + 1], e2 = T[3 * k + 2];
         const float p[3] = {d[1] * e2.z - d[2] * e2.y, d[2] * e2.x - d[0] * e2.z, d[0] * e2.y - d[1] * e2.x};
         const float det = e1.x * p[0] + e1.y * p[1] + e1.z * p[2];
-        if (det > 1e-30f) {   // front face only (GL_CULL_FACE)
+        if (CULL ? det > 1e-30f : fabsf(det) > 1e-30f) {
+          const float id = 1.f / det;
           const float tv[3] = {o[0] - v0.x, o[1] - v0.y, o[2] - v0.z};
-          const float u = tv[0] * p[0] + tv[1] * p[1] + tv[2] * p[2];
+          const float u = (tv[0] * p[0] + tv[1] * p[1] + tv[2] * p[2]) * id;
           const float q[3] = {tv[1] * e1.z - tv[2] * e1.y, tv[2] * e1.x - tv[0] * e1.z, tv[0] * e1.y - tv[1] * e1.x};
-          const float v = d[0] * q[0] + d[1] * q[1] + d[2] * q[2];
-          if (u >= 0.f && v >= 0.f && u + v <= det) {
-            const float t = (e2.x * q[0] + e2.y * q[1] + e2.z * q[2]) / det;
+          const float v = (d[0] * q[0] + d[1] * q[1] + d[2] * q[2]) * id;
+          if (u >= 0.f && v >= 0.f && u + v <= 1.f) {
+            const float t = (e2.x * q[0] + e2.y * q[1] + e2.z * q[2]) * id;
             if (t >= tnear && t < best) best = t;
           }
         }
@@ -176,6 +179,135 @@ __device__ float ray_prim(int type, const float* size, const float* lp, const fl
   return -1.f;
 }
 
+
+// nearest intersection (either side) of a ray with a primitive in its own frame, or -1.  [MJ] mj_rayGeom
+__device__ float ray_quad(float a, float b, float c) {
+  float det = b * b - a * c;
+  if (det < 1e-15f) return -1.f;
+  det = sqrtf(det);
+  const float x0 = (-b - det) / a, x1 = (-b + det) / a;
+  if (x0 >= 0) return x0;
+  if (x1 >= 0) return x1;
+  return -1.f;
+}
+__device__ float ray_prim_any(int type, const float* size, const float* lp, const float* lv) {
+  if (type == RT_PLANE) {
+    if (lv[2] > -1e-15f) return -1.f;
+    const float x = -lp[2] / lv[2];
+    if (x < 0) return -1.f;
+    const float px = lp[0] + x * lv[0], py = lp[1] + x * lv[1];
+    if ((size[0] <= 0 || fabsf(px) <= size[0]) && (size[1] <= 0 || fabsf(py) <= size[1])) return x;
+    return -1.f;
+  }
+  if (type == RT_SPHERE) return ray_quad(dot3(lv, lv), dot3(lv, lp), dot3(lp, lp) - size[0] * size[0]);
+  if (type == RT_CYLINDER) {
+    float best = -1.f;
+    const float a = lv[0] * lv[0] + lv[1] * lv[1], b = lv[0] * lp[0] + lv[1] * lp[1], c = lp[0] * lp[0] + lp[1] * lp[1] - size[0] * size[0];
+    if (a > 1e-15f) {
+      const float x = ray_quad(a, b, c);
+      if (x >= 0 && fabsf(lp[2] + x * lv[2]) <= size[1]) best = x;
+    }
+    if (fabsf(lv[2]) > 1e-15f)
+      for (int sg = -1; sg <= 1; sg += 2) {
+        const float x = (sg * size[1] - lp[2]) / lv[2];
+        if (x >= 0) {
+          const float px = lp[0] + x * lv[0], py = lp[1] + x * lv[1];
+          if (px * px + py * py <= size[0] * size[0] && (best < 0 || x < best)) best = x;
+        }
+      }
+    return best;
+  }
+  if (type == RT_BOX) {
+    float best = -1.f;
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) {
+      if (fabsf(lv[ax]) < 1e-15f) continue;
+      for (int sg = -1; sg <= 1; sg += 2) {
+        const float x = (sg * size[ax] - lp[ax]) / lv[ax];
+        if (x < 0) continue;
+        const int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+        if (fabsf(lp[a1] + x * lv[a1]) <= size[a1] && fabsf(lp[a2] + x * lv[a2]) <= size[a2] && (best < 0 || x < best)) best = x;
+      }
+    }
+    return best;
+  }
+  return -1.f;
+}
+
+// 2-D lidar.  Replaces the 360 rangefinder sensors mj_step evaluates (mujoco_server_sensor_manager.py:77-83 reads them):
+// [MJ] mj_sensorPos -> mj_ray from each site along its +Z against every geom (all groups, alpha > 0, both sides), the site's
+// own body excluded, -1 when nothing is hit, clipped to the sensor cutoff.  One workgroup per env, one thread per ray; geoms
+// welded to the laser were ray-cast once by the model compiler (lidar_static), the others are staged in LDS in chunks.
+__global__ __launch_bounds__(384) void smj_lidar_kernel(const DevRender R, const float* __restrict__ xpose, long ld, float* __restrict__ lidar, long lidar_ld) {
+  __shared__ RGeom geoms[SMJ_RGEOM_MAX];
+  const int env = blockIdx.x, tid = threadIdx.x;
+  float pnt[3] = {0, 0, 0}, vec[3] = {0, 0, 1}, best = -1.f;
+  const bool active = tid < R.nlidar;
+  if (active) {
+    const int sid = R.lidar_site[tid], b = R.site_bodyid[sid];
+    float bp[3], bm[9];
+    for (int k = 0; k < 3; k++) bp[k] = xpose[(12 * b + k) * ld + env];
+    for (int k = 0; k < 9; k++) bm[k] = xpose[(12 * b + 3 + k) * ld + env];
+    float w[3];
+    mul(w, bm, R.site_pos + 3 * sid);
+    for (int k = 0; k < 3; k++) pnt[k] = bp[k] + w[k];
+    const float lz[3] = {R.site_mat[9 * sid + 2], R.site_mat[9 * sid + 5], R.site_mat[9 * sid + 8]};
+    mul(vec, bm, lz);
+    best = R.lidar_static[tid];
+  }
+  for (int base = 0; base < R.nlgeom; base += SMJ_RGEOM_MAX) {
+    const int cnt = min(SMJ_RGEOM_MAX, R.nlgeom - base);
+    __syncthreads();
+    if (tid < cnt) {
+      const int g = R.lgeom[base + tid], b = R.geom_bodyid[g];
+      float bp[3], bm[9];
+      for (int k = 0; k < 3; k++) bp[k] = xpose[(12 * b + k) * ld + env];
+      for (int k = 0; k < 9; k++) bm[k] = xpose[(12 * b + 3 + k) * ld + env];
+      RGeom& G = geoms[tid];
+      float w[3];
+      mul(w, bm, R.geom_pos + 3 * g);
+      for (int k = 0; k < 3; k++) G.pos[k] = bp[k] + w[k];
+      mul(w, bm, R.geom_bcenter + 3 * g);
+      for (int k = 0; k < 3; k++) G.cen[k] = bp[k] + w[k];
+      const float* lm = R.geom_mat + 9 * g;
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) G.mat[3 * i + j] = bm[3 * i] * lm[j] + bm[3 * i + 1] * lm[3 + j] + bm[3 * i + 2] * lm[6 + j];
+      G.type = R.geom_type[g];
+      G.rmesh = R.geom_rmeshid[g];
+      G.rbound = R.geom_rbound[g];
+      for (int k = 0; k < 3; k++) G.size[k] = R.geom_size[3 * g + k];
+    }
+    __syncthreads();
+    if (!active) continue;
+    for (int i = 0; i < cnt; i++) {
+      const RGeom& G = geoms[i];
+      const float lim = best >= 0 ? best : 3.0e38f;
+      if (G.type != RT_PLANE) {   // bounding sphere (vec is a unit vector)
+        const float oc[3] = {G.cen[0] - pnt[0], G.cen[1] - pnt[1], G.cen[2] - pnt[2]};
+        const float b = dot3(oc, vec), r = G.rbound;
+        if (dot3(oc, oc) - b * b > r * r || b + r < 0.f || b - r > lim) continue;
+      }
+      const float dif[3] = {pnt[0] - G.pos[0], pnt[1] - G.pos[1], pnt[2] - G.pos[2]};
+      float lp[3], lv[3];
+      mulT(lp, G.mat, dif);
+      mulT(lv, G.mat, vec);
+      if (G.type == RT_MESH) {
+        if (G.rmesh >= 0) {
+          const float x = ray_mesh<false>(R, G.rmesh, lp, lv, 0.f, lim);
+          if (x < lim) best = x;
+        }
+      } else {
+        const float x = ray_prim_any(G.type, G.size, lp, lv);
+        if (x >= 0 && x < lim) best = x;
+      }
+    }
+  }
+  if (active) {
+    if (R.lidar_cutoff > 0 && best > R.lidar_cutoff) best = R.lidar_cutoff;
+    lidar[(long)tid * lidar_ld + env] = best;
+  }
+}
+
 __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const float* __restrict__ xpose, long ld, int cam, int width,
                                                         int height, float tan_half_fovy, float max_depth, float* __restrict__ out) {
   __shared__ RGeom geoms[SMJ_RGEOM_MAX];
@@ -262,7 +394,7 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
     mulT(lp, G.mat, dif);
     mulT(lv, G.mat, d);
     if (G.type == RT_MESH) {
-      if (G.rmesh >= 0) best = ray_mesh(R, G.rmesh, lp, lv, tnear, best);
+      if (G.rmesh >= 0) best = ray_mesh<true>(R, G.rmesh, lp, lv, tnear, best);
     } else {
       const float x = ray_prim(G.type, G.size, lp, lv, tnear);
       if (x >= 0 && x < best) best = x;
@@ -276,6 +408,9 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
 
 }  // namespace
 
+void smj_launch_lidar(const DevRender& r, const float* xpose, long ld, int num_envs, float* lidar, long lidar_ld, hipStream_t stream) {
+  hipLaunchKernelGGL(smj_lidar_kernel, dim3(num_envs), dim3(384), 0, stream, r, xpose, ld, lidar, lidar_ld);
+}
 void smj_launch_depth(const DevRender& r, const float* xpose, long ld, int num_envs, int cam, int width, int height,
                       float fovy_deg, float max_depth, float* out, hipStream_t stream) {
   const int tiles = ((width + 15) / 16) * ((height + 15) / 16);

@@ -2365,96 +2365,8 @@ struct StepKernel {
     }
   }
 
-  // 2-D lidar: 360 rangefinder rays from the laser sites along site +Z  [MJ] mj_sensorPos rangefinder -> mj_ray.
-  // Scope of this round: plane and primitive geoms (k_ray_geom); mesh geoms are not ray-cast yet.
-  SMJ_DEV float ray_geom(int g, const float* pnt, const float* vec) const {
-    float pos[3], R[9];
-    geom_pose(g, pos, R);
-    const float size[3] = {M.geom_size[3 * g], M.geom_size[3 * g + 1], M.geom_size[3 * g + 2]};
-    const float dif[3] = {pnt[0] - pos[0], pnt[1] - pos[1], pnt[2] - pos[2]};
-    float lp[3], lv[3];
-    mulmat3Tvec(lp, R, dif);
-    mulmat3Tvec(lv, R, vec);
-    const int t = M.geom_type[g];
-    if (t == GT_PLANE) {
-      if (lv[2] > -SMJ_MINVAL) return -1.f;
-      const float x = -lp[2] / lv[2];
-      if (x < 0) return -1.f;
-      const float px = lp[0] + x * lv[0], py = lp[1] + x * lv[1];
-      if ((size[0] <= 0 || fabsf(px) <= size[0]) && (size[1] <= 0 || fabsf(py) <= size[1])) return x;
-      return -1.f;
-    }
-    if (t == GT_SPHERE) return ray_quad(dot3(lv, lv), dot3(lv, lp), dot3(lp, lp) - size[0] * size[0]);
-    if (t == GT_CYLINDER) {
-      float best = -1.f;
-      const float a = lv[0] * lv[0] + lv[1] * lv[1], b = lv[0] * lp[0] + lv[1] * lp[1], c = lp[0] * lp[0] + lp[1] * lp[1] - size[0] * size[0];
-      if (a > SMJ_MINVAL) {
-        const float x = ray_quad(a, b, c);
-        if (x >= 0 && fabsf(lp[2] + x * lv[2]) <= size[1]) best = x;
-      }
-      if (fabsf(lv[2]) > SMJ_MINVAL)
-        for (int sg = -1; sg <= 1; sg += 2) {
-          const float x = (sg * size[1] - lp[2]) / lv[2];
-          if (x >= 0) {
-            const float px = lp[0] + x * lv[0], py = lp[1] + x * lv[1];
-            if (px * px + py * py <= size[0] * size[0] && (best < 0 || x < best)) best = x;
-          }
-        }
-      return best;
-    }
-    if (t == GT_BOX) {
-      float best = -1.f;
-      for (int ax = 0; ax < 3; ax++) {
-        if (fabsf(lv[ax]) < SMJ_MINVAL) continue;
-        for (int sg = -1; sg <= 1; sg += 2) {
-          const float x = (sg * size[ax] - lp[ax]) / lv[ax];
-          if (x < 0) continue;
-          const int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
-          if (fabsf(lp[a1] + x * lv[a1]) <= size[a1] && fabsf(lp[a2] + x * lv[a2]) <= size[a2] && (best < 0 || x < best)) best = x;
-        }
-      }
-      return best;
-    }
-    return -1.f;
-  }
-  SMJ_DEV static float ray_quad(float a, float b, float c) {
-    float det = b * b - a * c;
-    if (det < SMJ_MINVAL) return -1.f;
-    det = sqrtf(det);
-    const float x0 = (-b - det) / a, x1 = (-b + det) / a;
-    if (x0 >= 0) return x0;
-    if (x1 >= 0) return x1;
-    return -1.f;
-  }
-  SMJ_DEV void lidar() {
-    if (!S.lidar) return;
-    for (int base = 0; base < M.nlidar; base += 64) {
-      LANES {
-        const int i = base + lane;
-        if (i < M.nlidar) {
-          const int sid = M.sensor_lidar_site[i], b = M.site_bodyid[sid];
-          float lp[3] = {M.site_pos[3 * sid], M.site_pos[3 * sid + 1], M.site_pos[3 * sid + 2]}, pnt[3], vec[3];
-          mulmat3vec(pnt, s.xmat[b], lp);
-          for (int k = 0; k < 3; k++) pnt[k] += s.xpos[b][k];
-          const float lz[3] = {M.k_site_mat[9 * sid + 2], M.k_site_mat[9 * sid + 5], M.k_site_mat[9 * sid + 8]};
-          mulmat3vec(vec, s.xmat[b], lz);
-          // geoms rigidly attached to the laser (its weld group) were ray-cast once by the model compiler against their
-          // true triangle meshes: state-independent distance per ray (the mast occludes rays 290-306 at 0.13-0.15 m)
-          float best = M.sensor_lidar_static[i];
-          for (int t = 0; t < M.nraygeom; t++) {
-            const int g = M.k_ray_geom[t];
-            if (M.geom_bodyid[g] == b) continue;   // same weld group: covered by the static table (incl. the site's own body)
-            const float x = ray_geom(g, pnt, vec);
-            if (x >= 0 && (best < 0 || x < best)) best = x;
-          }
-          if (M.lidar_cutoff > 0 && best > M.lidar_cutoff) best = M.lidar_cutoff;
-          S.lidar[(long)i * S.ld + env] = best;
-        }
-      }
-    }
-  }
-
-  // body poses of the last step for the depth renderer (smj_render.hip): what mjv_updateScene reads from mjData
+  // body poses of the last step for the ray-casting kernels (smj_render.hip: lidar, depth cameras): what mj_sensorPos /
+  // mjv_updateScene read from mjData
   SMJ_DEV void dump_poses() {
     if (!S.xpose) return;
     LANES {
@@ -2494,7 +2406,7 @@ struct StepKernel {
 
   // ------------------------------------------------------------------ driver
   SMJ_DEV void run(int nsteps, unsigned read_flags) {
-    const int want_imu = read_flags & 1, want_lidar = read_flags & 2;
+    const int want_imu = read_flags & 1;
     flags = 0; nefc = 0; ncon = 0; niter = 0;
     float pc[SMJ_PROF_SLOTS];
     for (int k = 0; k < SMJ_PROF_SLOTS; k++) pc[k] = 0.f;
@@ -2507,7 +2419,6 @@ struct StepKernel {
     for (int st = 0; st < nsteps; st++) {
       const bool last = st == nsteps - 1;
       kinematics();
-      if (last && want_lidar) lidar();
       if (last && (read_flags & 4)) dump_poses();
       TICK(SMJ_PROF_KIN)
       com_crb();

@@ -982,15 +982,19 @@ class MjcfCompiler:
         m["pair_margin"] = np.array(P["margin"], float); m["pair_gap"] = np.array(P["gap"], float)
         m["sensor_imu_site"] = np.array([imu_site], np.int32); m["sensor_lidar_site"] = np.array(lidar_sites, np.int32)
         m["sensor_lidar_cutoff"] = np.array([lidar_cutoff])
-        # ---------------- render meshes: triangles of the mesh geoms a camera can see.  [MJ] mjv_addGeoms draws geom groups
-        # 0-2 by default and skips geoms whose rgba alpha is 0; the collision class of stretch.xml is group 3 (hidden).
+        # ---------------- ray-cast meshes: triangles of the mesh geoms a camera can see ([MJ] mjv_addGeoms draws geom groups
+        # 0-2 by default and skips alpha 0; the collision class of stretch.xml is group 3, hidden) or a lidar ray can meet.
         rm_index: Dict[str, int] = {}
         rverts, rfaces, rvadr, rvnum, rfadr, rfnum, geom_rmeshid = [], [], [], [], [], [], []
         nrv = nrf = 0
+        laser_weld = body_weldid[site_bodyid[lidar_sites[0]]] if lidar_sites else -1
         for g in range(ngeom):
             name = self._geom_mesh_names[g]
             md = mesh_cache.get(name) if name is not None else None
-            if md is None or G["group"][g] > 2 or G["rgba"][g][3] == 0:
+            camera_sees = G["group"][g] <= 2
+            # [MJ] mj_ray tests every geom group; geoms welded to the laser are covered by sensor_lidar_static instead
+            lidar_sees = laser_weld >= 0 and body_weldid[G["bodyid"][g]] != laser_weld
+            if md is None or G["rgba"][g][3] == 0 or not (camera_sees or lidar_sees):
                 geom_rmeshid.append(-1)
                 continue
             if name not in rm_index:

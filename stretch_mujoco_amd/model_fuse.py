@@ -294,6 +294,12 @@ def kernel_tables(f: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     rmid = f.get("geom_rmeshid", np.full(ng, -1, np.int32))
     vis = [g for g in range(ng) if grp[g] <= 2 and f["geom_rgba"][g][3] != 0 and (f["geom_type"][g] != 7 or rmid[g] >= 0)]
     f["k_rgeom"] = np.array(vis + [0], np.int32); f["k_nrgeom"] = np.array([len(vis)], np.int32)
+    # lidar: geoms tested at run time = everything not welded to the laser (those are in sensor_lidar_static) with alpha > 0
+    ls = f.get("sensor_lidar_site", [])
+    laser_body = int(f["site_bodyid"][ls[0]]) if len(ls) else -1
+    lg = [g for g in range(ng) if laser_body >= 0 and f["geom_bodyid"][g] != laser_body and f["geom_rgba"][g][3] != 0
+          and (f["geom_type"][g] != 7 or rmid[g] >= 0)]
+    f["k_lgeom"] = np.array(lg + [0], np.int32); f["k_nlgeom"] = np.array([len(lg)], np.int32)
     ncam = len(f.get("cam_bodyid", []))
     f["k_cam_mat"] = np.array([quat2mat(f["cam_quat"][c]).reshape(9) for c in range(ncam)] + [np.eye(3).reshape(9)])
     f["k_site_origbody"] = np.asarray(f.get("site_origbody", f["site_bodyid"]), np.int32)
