@@ -1890,67 +1890,51 @@ struct StepKernel {
     }
   }
 
-  // x <- H^-1 x for the SPD matrix in s.u.n.H (NVP x NVP, identity padded beyond nv); H is overwritten by its Cholesky
-  // factor.  Lane i owns row i of H in registers: the factorisation is fully unrolled, column broadcasts are
-  // v_readlane, no LDS round trips; the L' solve reads L rows back from LDS in pipelined chunks.
+  // x <- H^-1 x for the symmetric positive definite H in s.u.n.H (Newton Hessian, or M - h*D of the implicit integrator).
+  // Gauss-Jordan elimination with lane i owning row i of [H | x] in registers, fully unrolled.  Why not Cholesky plus two
+  // triangular solves: at one wavefront per SIMD a substitution step is a chain of dependent instructions (update ->
+  // v_readlane -> scale -> update), measured at ~300 cycles per row and 19k cycles per solve, more than the factorisation
+  // itself.  Eliminating above AND below the pivot costs the same n^2/2 (v_readlane, v_fma) pairs as the Cholesky update,
+  // all of them independent within a column step, and leaves the solution in x with no substitution and no LDS traffic.
+  // Pivots of an SPD matrix stay positive; no pivoting (same as the Cholesky it replaces).
+  template <int K, int J>
+  SMJ_DEV void gj_pair(PL<float[NVP]>& hrow, const PL<float>& mult) {
+    if constexpr (J < NVP) {
+      PL<float> cj;
+      LANES { cj[lane] = hrow[lane][J]; }
+      const float hkj = wave_read(cj, K);              // pivot-row entry H[K][J]
+      LANES { hrow[lane][J] -= mult[lane] * hkj; }
+      gj_pair<K, J + 1>(hrow, mult);
+    }
+  }
+  template <int K>
+  SMJ_DEV void gj_cols(PL<float[NVP]>& hrow, PL<float>& x, PL<float>& pinv) {
+    if constexpr (K < NVP) {
+      PL<float> col, mult;
+      LANES { col[lane] = hrow[lane][K]; }
+      const float rp = fast_rcp(fmaxf(wave_read(col, K), 1e-30f));
+      LANES {
+        mult[lane] = lane == K ? 0.f : col[lane] * rp;   // the pivot row itself is left alone; its scale is applied at the end
+        if (lane == K) pinv[lane] = rp;
+      }
+      gj_pair<K, K + 1>(hrow, mult);
+      const float xk = wave_read(x, K);
+      LANES { x[lane] -= mult[lane] * xk; }
+      gj_cols<K + 1>(hrow, x, pinv);
+    }
+  }
   SMJ_DEV void chol_solve_H(PL<float>& x) {
     PL<float[NVP]> hrow;
-    PL<float> dinv;
+    PL<float> pinv;
     LANES {
       const int i = lane < NVP ? lane : 0;
 #pragma unroll
       for (int k = 0; k < NVP; k++) hrow[lane][k] = (lane < NVP) ? s.u.n.H[i][k] : 0.f;
-      dinv[lane] = 1.f;
+      pinv[lane] = 0.f;
+      if (lane >= NVP) x[lane] = 0.f;
     }
-#pragma unroll
-    for (int k = 0; k < NVP; k++) {
-      PL<float> col;
-      LANES { col[lane] = hrow[lane][k]; }
-      const float d = fmaxf(wave_read(col, k), 1e-30f), inv = fast_rsqrt(d);
-      LANES {
-        col[lane] = col[lane] * inv;   // L[i][k] for i >= k (lane k: sqrt(d))
-        hrow[lane][k] = col[lane];
-        if (lane == k) dinv[lane] = inv;
-      }
-#pragma unroll
-      for (int j = k + 1; j < NVP; j++) {
-        const float ljk = wave_read(col, j);
-        LANES { if (lane >= j) hrow[lane][j] -= col[lane] * ljk; }
-      }
-    }
-    LANES {
-      if (lane < NVP) {
-#pragma unroll
-        for (int k = 0; k < NVP; k++) s.u.n.H[lane][k] = hrow[lane][k];
-      }
-    }
-    SYNC();
-    // forward: L y = x  (register rows)
-#pragma unroll
-    for (int k = 0; k < NVP; k++) {
-      const float xk = wave_read(x, k) * wave_read(dinv, k);
-      LANES {
-        if (lane == k) x[lane] = xk;
-        else if (lane > k && lane < NVP) x[lane] -= hrow[lane][k] * xk;
-      }
-    }
-    // backward: L' z = y  (column `lane` of L' = L[k][lane], read from LDS eight rows at a time)
-    for (int k0 = NVP - 8; k0 >= 0; k0 -= 8) {
-      PL<float[8]> lk;
-      LANES {
-#pragma unroll
-        for (int t = 0; t < 8; t++) lk[lane][t] = lane < NVP ? s.u.n.H[k0 + t][lane] : 0.f;
-      }
-#pragma unroll
-      for (int t = 7; t >= 0; t--) {
-        const int k = k0 + t;
-        const float xk = wave_read(x, k) * wave_read(dinv, k);
-        LANES {
-          if (lane == k) x[lane] = xk;
-          else if (lane < k) x[lane] -= lk[lane][t] * xk;
-        }
-      }
-    }
+    gj_cols<0>(hrow, x, pinv);
+    LANES { x[lane] *= pinv[lane]; }
   }
 
   // cost and derivatives along the search line  ([MJ] CGeval); lanes = rows, three wave reductions

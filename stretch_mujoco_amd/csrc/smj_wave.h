@@ -57,6 +57,9 @@ static inline uint64_t wave_ballot(const PL<int>& p) {
 template <class T>
 static inline T wave_read(const PL<T>& x, int l) { return x.v[l]; }
 static inline int popc64(uint64_t x) { return __builtin_popcountll(x); }
+// value of lane N of the caller's 16-lane row (DPP row_newbcast on the GPU)
+template <int N>
+static inline float wave_bcast16(const PL<float>& x, int lane) { return x.v[(lane & ~15) + N]; }
 static inline int ffs64(uint64_t x) { return __builtin_ffsll((long long)x) - 1; }
 static inline long long smj_clock() { return 0; }
 static inline int uni(int x) { return x; }
@@ -106,6 +109,11 @@ __device__ __forceinline__ float wave_max(const PL<float>& x) {
   SMJ_WAVE_REDUCE(fmaxf, -__builtin_inff())
 }
 #undef SMJ_WAVE_REDUCE
+// value of lane N of the caller's 16-lane row: one DPP move (row_newbcast), no SGPR round trip
+template <int N>
+__device__ __forceinline__ float wave_bcast16(const PL<float>& x, int) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x.v), 0x150 + N, 0xF, 0xF, false));
+}
 __device__ __forceinline__ uint64_t wave_ballot(const PL<int>& p) { return __ballot(p.v != 0); }
 __device__ __forceinline__ float wave_read(const PL<float>& x, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x.v), l));

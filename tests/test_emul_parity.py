@@ -207,15 +207,16 @@ def test_self_collision_contacts_match_the_oracle(blob_fused):
         np.testing.assert_allclose(ce[:, 1:4], co[:, 1:4], atol=1e-2)
         # plane contacts: identical normals.  Faceted hull pairs touching at an edge / vertex: MPR (like libccd's) returns the
         # normal of whichever facet of the Minkowski difference the origin ray leaves through; next to a vertex-vertex
-        # feature that facet, hence the direction, is round-off sensitive.  Required: same hemisphere always, close mostly.
+        # feature that facet, hence the direction, is round-off sensitive.  Required: same hemisphere always, and at least
+        # three quarters of all contacts seen within 18 degrees.
         cosn = np.sum(ce[:, 4:7] * co[:, 4:7], axis=1)
         assert (cosn[:5] > 0.9999).all() and (cosn > 0.0).all(), (k, cosn)
-        loose += int((cosn < 0.95).any()); checked += 1
+        loose += int((cosn < 0.95).sum()); checked += n
         seen_self += int(n > 5)
-        if (cosn > 0.9999).all():   # same contact frames -> same dynamics
+        if (cosn > 0.9999).all() and np.abs(ce[:, 0] - co[:, 0]).max() < 1e-6:   # same contact frames and depths -> same dynamics
             qa = o.arr("qacc")
             assert np.abs(e.debug[1056:1082, 0] - qa)[:18].max() < 2e-2 * max(1.0, np.abs(qa[:18]).max()), k
-    assert seen_self > 20 and e.info[3, 0] == 0 and loose < 0.25 * checked
+    assert seen_self > 20 and e.info[3, 0] == 0 and loose < 0.25 * checked, (seen_self, loose, checked)   # loose: per contact
     assert e.qpos[9, 0] > 0.12 and np.abs(e.qvel[:18, 0]).max() < 0.2     # the lift is held up by the contact (target 0.05), main joints at rest
 
 
