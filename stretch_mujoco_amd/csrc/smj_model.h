@@ -10,7 +10,7 @@
 #define NCON 16  // contact capacity
 
 #define SMJ_MODEL_I32(X)                                                                                          \
-  X(body_parentid) X(body_rootid) X(body_jntadr) X(body_jntnum) X(body_dofadr) X(body_dofnum) X(k_body_level)     \
+  X(body_parentid) X(k_body_jump) X(body_rootid) X(body_jntadr) X(body_jntnum) X(body_dofadr) X(body_dofnum) X(k_body_level)     \
   X(k_body_subtreesize) X(k_body_dofmask_lo) X(k_body_dofmask_hi) X(k_root_list) X(k_gc_body)                     \
   X(jnt_type) X(jnt_qposadr) X(jnt_dofadr) X(jnt_bodyid) X(jnt_limited)                                           \
   X(dof_bodyid) X(dof_jntid) X(dof_parentid) X(k_dof_anc_adr) X(k_dof_anc_num) X(k_dof_anc) X(k_dof_velmask_lo)   \
@@ -36,7 +36,7 @@
 
 struct DevModel {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, neq, npair, nlevel, nfric, nlimit, nplanepair, nldl, nlidar, imu_site,
-      ngc, nroot, nkey, ncgeom, nconvpair;
+      ngc, nroot, nkey, ncgeom, nconvpair, njump;
   int iterations, warmstart, pgs_fixed_iter, max_con_pair, solver /* 0 PGS, 2 Newton */, ls_iterations, convex_pairs;
   float ls_tolerance;
   float timestep, gravity[3], impratio, tolerance, meaninertia, lidar_cutoff;

@@ -340,70 +340,119 @@ struct StepKernel {
   }
 
   // ------------------------------------------------------------------ B.1 kinematics  [MJ] mj_kinematics
+  // Body poses in three phases instead of one dependent pass per tree level (13 levels, each a chain of a few hundred
+  // dependent instructions at one wave per SIMD):  A) every body's transform relative to its PARENT frame, joint motion
+  // included -- all bodies at once, this is where the sincos / quaternion work is;  B) pointer jumping: round r composes a
+  // body with its 2^r-th ancestor (k_body_jump), ceil(log2(depth)) = 4 rounds;  C) world matrices, joint anchors and axes
+  // from the parent's world frame, all bodies at once.
   SMJ_DEV void kinematics() {
     const int nb = M.nbody;
     KinTab kt;
     load(kt);
-    for (int lev = 1; lev < M.nlevel; lev++) {
-      LANES {
-        if (lane < nb && kt.level[lane] == lev) {
-          const int b = lane, p = kt.parent[lane];
-          float pos[3], quat[4], R[9];
-          const bool isfree = kt.jtype[lane][0] == JT_FREE;
-          if (isfree) {
-            const int qa = kt.jqadr[lane][0], da = kt.jdadr[lane][0];
-            for (int k = 0; k < 3; k++) pos[k] = s.qpos[qa + k];
-            for (int k = 0; k < 4; k++) quat[k] = s.qpos[qa + 3 + k];
-            quat_normalize(quat);
-            for (int d = 0; d < 6; d++)
-              for (int k = 0; k < 3; k++) s.xanchor[da + d][k] = pos[k];
-          } else {
-            mulmat3vec(pos, s.xmat[p], kt.pos[lane]);
-            for (int k = 0; k < 3; k++) pos[k] += s.xpos[p][k];
-            quat_mul(quat, s.xquat[p], kt.quat[lane]);
+    PL<float[3]> pl;          // position in the parent frame, later in the frame of the current jump ancestor
+    PL<float[4]> ql;
+    PL<float[6]> al, xl;      // joint anchors / axes in the parent frame
+    LANES {
+      float pos[3] = {0, 0, 0}, quat[4] = {1, 0, 0, 0};
+      for (int k = 0; k < 6; k++) { al[lane][k] = 0.f; xl[lane][k] = 0.f; }
+      if (lane > 0 && lane < nb) {
+        if (kt.jtype[lane][0] == JT_FREE) {
+          const int qa = kt.jqadr[lane][0];
+          for (int k = 0; k < 3; k++) pos[k] = s.qpos[qa + k];
+          for (int k = 0; k < 4; k++) quat[k] = s.qpos[qa + 3 + k];
+        } else {
+          for (int k = 0; k < 3; k++) pos[k] = kt.pos[lane][k];
+          for (int k = 0; k < 4; k++) quat[k] = kt.quat[lane][k];
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
-              const int jt = kt.jtype[lane][t];
-              if (jt < 0) continue;
-              const int da = kt.jdadr[lane][t];
-              const float* ax = &kt.jaxis[lane][3 * t];
-              const float* jp = &kt.jpos[lane][3 * t];
-              float xa[3], a[3], anchor[3];
-              quat2mat(R, quat);
-              mulmat3vec(xa, R, ax);
-              mulmat3vec(a, R, jp);
-              for (int k = 0; k < 3; k++) { anchor[k] = pos[k] + a[k]; s.xaxis[da][k] = xa[k]; s.xanchor[da][k] = anchor[k]; }
-              const float q = s.qpos[kt.jqadr[lane][t]] - kt.jq0[lane][t];
-              if (jt == JT_SLIDE) {
-                for (int k = 0; k < 3; k++) pos[k] += xa[k] * q;
-              } else {
-                float sn, cs;
-                sincosf(0.5f * q, &sn, &cs);
-                const float dq[4] = {cs, ax[0] * sn, ax[1] * sn, ax[2] * sn};
-                quat_mul(quat, quat, dq);
-                quat2mat(R, quat);
-                mulmat3vec(a, R, jp);
-                for (int k = 0; k < 3; k++) pos[k] = anchor[k] - a[k];
-              }
+          for (int t = 0; t < 2; t++) {
+            const int jt = kt.jtype[lane][t];
+            if (jt < 0) continue;
+            const float* ax = &kt.jaxis[lane][3 * t];
+            const float* jp = &kt.jpos[lane][3 * t];
+            float Rm[9], xa[3], a[3], anchor[3];
+            quat2mat(Rm, quat);
+            mulmat3vec(xa, Rm, ax);
+            mulmat3vec(a, Rm, jp);
+            for (int k = 0; k < 3; k++) { anchor[k] = pos[k] + a[k]; xl[lane][3 * t + k] = xa[k]; al[lane][3 * t + k] = anchor[k]; }
+            const float q = s.qpos[kt.jqadr[lane][t]] - kt.jq0[lane][t];
+            if (jt == JT_SLIDE) {
+              for (int k = 0; k < 3; k++) pos[k] += xa[k] * q;
+            } else {
+              float sn, cs;
+              sincosf(0.5f * q, &sn, &cs);
+              const float dq[4] = {cs, ax[0] * sn, ax[1] * sn, ax[2] * sn};
+              quat_mul(quat, quat, dq);
+              quat2mat(Rm, quat);
+              mulmat3vec(a, Rm, jp);
+              for (int k = 0; k < 3; k++) pos[k] = anchor[k] - a[k];
             }
           }
-          quat_normalize(quat);
-          quat2mat(R, quat);
-          for (int k = 0; k < 3; k++) s.xpos[b][k] = pos[k];
-          for (int k = 0; k < 4; k++) s.xquat[b][k] = quat[k];
-          for (int k = 0; k < 9; k++) s.xmat[b][k] = R[k];
-          if (isfree) {
-            const int da = kt.jdadr[lane][0];
-            for (int d = 0; d < 3; d++)
-              for (int k = 0; k < 3; k++) {
-                s.xaxis[da + d][k] = (d == k) ? 1.f : 0.f;
-                s.xaxis[da + 3 + d][k] = R[3 * k + d];
-              }
-          }
+        }
+        quat_normalize(quat);
+      }
+      for (int k = 0; k < 3; k++) { pl[lane][k] = pos[k]; if (lane < NBP) s.xpos[lane][k] = pos[k]; }
+      for (int k = 0; k < 4; k++) { ql[lane][k] = quat[k]; if (lane < NBP) s.xquat[lane][k] = quat[k]; }
+    }
+    SYNC();
+    for (int r = 0; r < M.njump; r++) {
+      PL<float[3]> pa;
+      PL<float[4]> qa;
+      PL<int> anc;
+      LANES {
+        const int a = (lane > 0 && lane < nb) ? M.k_body_jump[r * nb + lane] : 0;
+        anc[lane] = a;
+        for (int k = 0; k < 3; k++) pa[lane][k] = s.xpos[a][k];
+        for (int k = 0; k < 4; k++) qa[lane][k] = s.xquat[a][k];
+      }
+      SYNC();
+      LANES {
+        if (anc[lane] > 0) {   // ancestor 0 is the world: identity
+          float Rm[9], v[3], q[4];
+          quat2mat(Rm, qa[lane]);
+          mulmat3vec(v, Rm, pl[lane]);
+          quat_mul(q, qa[lane], ql[lane]);
+          for (int k = 0; k < 3; k++) { pl[lane][k] = pa[lane][k] + v[k]; s.xpos[lane][k] = pl[lane][k]; }
+          for (int k = 0; k < 4; k++) { ql[lane][k] = q[k]; s.xquat[lane][k] = q[k]; }
         }
       }
       SYNC();
     }
+    LANES {
+      if (lane < nb) {
+        float q[4] = {ql[lane][0], ql[lane][1], ql[lane][2], ql[lane][3]}, Rm[9];
+        quat_normalize(q);
+        quat2mat(Rm, q);
+        for (int k = 0; k < 4; k++) s.xquat[lane][k] = q[k];
+        for (int k = 0; k < 9; k++) s.xmat[lane][k] = Rm[k];
+      }
+    }
+    SYNC();
+    LANES {
+      if (lane > 0 && lane < nb) {
+        if (kt.jtype[lane][0] == JT_FREE) {
+          const int da = kt.jdadr[lane][0];
+          for (int d = 0; d < 6; d++)
+            for (int k = 0; k < 3; k++) s.xanchor[da + d][k] = s.xpos[lane][k];
+          for (int d = 0; d < 3; d++)
+            for (int k = 0; k < 3; k++) {
+              s.xaxis[da + d][k] = (d == k) ? 1.f : 0.f;
+              s.xaxis[da + 3 + d][k] = s.xmat[lane][3 * k + d];
+            }
+        } else {
+          const int p = kt.parent[lane];
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            if (kt.jtype[lane][t] < 0) continue;
+            const int da = kt.jdadr[lane][t];
+            float xa[3], an[3];
+            mulmat3vec(xa, s.xmat[p], &xl[lane][3 * t]);
+            mulmat3vec(an, s.xmat[p], &al[lane][3 * t]);
+            for (int k = 0; k < 3; k++) { s.xaxis[da][k] = xa[k]; s.xanchor[da][k] = s.xpos[p][k] + an[k]; }
+          }
+        }
+      }
+    }
+    SYNC();
   }
 
   // ------------------------------------------------------------------ comPos + comVel + crb + M

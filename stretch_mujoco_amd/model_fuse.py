@@ -118,6 +118,15 @@ def kernel_tables(f: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
         level[b] = level[par[b]] + 1
     f["k_body_level"] = level
     f["k_nlevel"] = np.array([level.max() + 1], np.int32)
+    # pointer-jumping schedule of the kinematics stage: jump[0] = parent, jump[r+1][b] = jump[r][jump[r][b]]; after
+    # ceil(log2(depth)) rounds every body has been composed up to the world
+    nround = max(1, int(np.ceil(np.log2(max(int(level.max()), 1)))))
+    jump = [np.asarray(par, np.int32).copy()]
+    jump[0][0] = 0
+    for _ in range(nround - 1):
+        jump.append(jump[-1][jump[-1]])
+    assert np.all(jump[-1][jump[-1]] == 0)
+    f["k_body_jump"] = np.stack(jump).astype(np.int32); f["k_njump"] = np.array([nround], np.int32)
     child_adr, child_num, child_list = [], [], []
     for b in range(nb):
         ch = [c for c in range(1, nb) if par[c] == b]
