@@ -8,6 +8,7 @@
 #define NBP 32   // fused-body capacity
 #define NEFC 64  // constraint-row capacity (= lanes of one wavefront)
 #define NCON 16  // contact capacity
+#define NCG 128  // geoms that take part in non-plane collision pairs (world-frame cache of the broadphase)
 
 #define SMJ_MODEL_I32(X)                                                                                          \
   X(body_parentid) X(k_body_jump) X(body_rootid) X(body_jntadr) X(body_jntnum) X(body_dofadr) X(body_dofnum) X(k_body_level)     \

@@ -30,7 +30,7 @@ struct Smem {
     float A[NEFC * NEFC];   // PGS: A = J M^-1 J' + R
     TreeTmp t;
     struct {                // collision: world frames of the geoms taking part in convex pairs (tree temporaries are dead)
-      float pos[64][3], mat[64][9], cen[64][3], half[64][3];
+      float pos[NCG][3], mat[NCG][9], cen[NCG][3], half[NCG][3];
       unsigned short list[1024];   // bounding-sphere survivors of the convex pair list, table order
     } c;
     struct {                // plane narrowphase staging: contacts of the pair owned by each lane, emitted in pair order
@@ -1226,15 +1226,18 @@ struct StepKernel {
   // MPR on the survivors in pair-table order
   SMJ_DEV void collision_convex() {
     if (!M.convex_pairs || M.nconvpair == 0) return;
-    LANES {
-      if (lane < M.ncgeom) {
-        const int g = M.k_cgeom[lane];
-        float pos[3], mat[9], cw[3];
-        geom_pose(g, pos, mat);
-        const float lc[3] = {M.k_cgeom_lcen[3 * lane], M.k_cgeom_lcen[3 * lane + 1], M.k_cgeom_lcen[3 * lane + 2]};
-        mulmat3vec(cw, mat, lc);
-        for (int k = 0; k < 3; k++) { s.u.c.pos[lane][k] = pos[k]; s.u.c.cen[lane][k] = pos[k] + cw[k]; s.u.c.half[lane][k] = M.k_cgeom_half[3 * lane + k]; }
-        for (int k = 0; k < 9; k++) s.u.c.mat[lane][k] = mat[k];
+    for (int c0 = 0; c0 < M.ncgeom; c0 += 64) {
+      LANES {
+        const int c = c0 + lane;
+        if (c < M.ncgeom) {
+          const int g = M.k_cgeom[c];
+          float pos[3], mat[9], cw[3];
+          geom_pose(g, pos, mat);
+          const float lc[3] = {M.k_cgeom_lcen[3 * c], M.k_cgeom_lcen[3 * c + 1], M.k_cgeom_lcen[3 * c + 2]};
+          mulmat3vec(cw, mat, lc);
+          for (int k = 0; k < 3; k++) { s.u.c.pos[c][k] = pos[k]; s.u.c.cen[c][k] = pos[k] + cw[k]; s.u.c.half[c][k] = M.k_cgeom_half[3 * c + k]; }
+          for (int k = 0; k < 9; k++) s.u.c.mat[c][k] = mat[k];
+        }
       }
     }
     SYNC();

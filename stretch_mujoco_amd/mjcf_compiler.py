@@ -1240,3 +1240,39 @@ def empty_scene_xml(stretch_xml_path: str) -> str:
     """The build's definition of the "empty scene" (SURVEY.md §0 finding 6): stretch.xml + one ground plane."""
     return (f'<mujoco model="stretch_empty"><include file="{stretch_xml_path}"/>'
             '<worldbody><geom name="floor" type="plane" size="0 0 0.05"/></worldbody></mujoco>')
+
+
+def kitchen_standin_xml(stretch_xml_path: str) -> str:
+    """Synthetic kitchen stand-in (Robocasa itself is unavailable here): the robot at
+    the origin in a 5 m x 5 m room with a counter run on its arm side (-y), wall cabinets above it, an island in front, a
+    fridge, a table and a few fixtures -- 24 STATIC boxes on the world body, all colliding with the robot ([MJ] default
+    contype = conaffinity = 1) and visible to lidar and depth cameras.  Free objects are not part of it (the step kernel's
+    dof capacity is the robot's)."""
+    boxes = []
+
+    def box(name, pos, half, rgba="0.7 0.7 0.7 1"):
+        boxes.append(f'<geom name="{name}" type="box" pos="{pos[0]} {pos[1]} {pos[2]}" size="{half[0]} {half[1]} {half[2]}" rgba="{rgba}"/>')
+    # walls (0.1 thick, 2.4 high)
+    box("wall_xp", (2.55, 0, 1.2), (0.05, 2.6, 1.2)); box("wall_xn", (-2.55, 0, 1.2), (0.05, 2.6, 1.2))
+    box("wall_yp", (0, 2.55, 1.2), (2.6, 0.05, 1.2)); box("wall_yn", (0, -2.55, 1.2), (2.6, 0.05, 1.2))
+    # counter run along the arm side: four base cabinets 0.6 wide, front face at y = -0.78, top at 0.88, slab on top
+    for i, x in enumerate((-0.9, -0.3, 0.3, 0.9)):
+        box(f"counter_{i}", (x, -1.08, 0.44), (0.30, 0.30, 0.44), "0.55 0.4 0.3 1")
+    box("countertop", (0, -1.07, 0.90), (1.22, 0.32, 0.02), "0.85 0.85 0.8 1")
+    # wall cabinets above the counter
+    for i, x in enumerate((-0.9, -0.3, 0.3, 0.9)):
+        box(f"wallcab_{i}", (x, -1.22, 1.75), (0.30, 0.17, 0.30), "0.55 0.4 0.3 1")
+    box("island", (1.45, 0.2, 0.45), (0.35, 0.6, 0.45), "0.5 0.5 0.55 1")
+    box("fridge", (-1.95, -1.95, 0.9), (0.35, 0.35, 0.9), "0.9 0.9 0.95 1")
+    box("hood", (0.3, -1.15, 1.35), (0.3, 0.22, 0.05), "0.6 0.6 0.6 1")
+    box("sink_block", (-0.9, -1.02, 0.96), (0.2, 0.15, 0.04), "0.75 0.75 0.8 1")
+    # table with four legs
+    box("table_top", (0.0, 1.6, 0.74), (0.6, 0.4, 0.02), "0.6 0.45 0.3 1")
+    for i, (x, y) in enumerate(((-0.55, 1.25), (0.55, 1.25), (-0.55, 1.95), (0.55, 1.95))):
+        box(f"table_leg_{i}", (x, y, 0.36), (0.025, 0.025, 0.36), "0.6 0.45 0.3 1")
+    box("shelf", (-2.3, 0.8, 1.0), (0.2, 0.5, 0.02), "0.55 0.4 0.3 1")
+    box("stool", (1.0, 1.2, 0.25), (0.18, 0.18, 0.25), "0.3 0.3 0.3 1")
+    assert len(boxes) == 24
+    return (f'<mujoco model="stretch_kitchen_standin"><include file="{stretch_xml_path}"/>'
+            '<worldbody><geom name="floor" type="plane" size="0 0 0.05"/>' + "".join(boxes) + '</worldbody></mujoco>')
+

@@ -182,8 +182,8 @@ def kernel_tables(f: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     f["k_planepair"] = np.array(pp + [0], np.int32); f["k_nplanepair"] = np.array([len(pp)], np.int32)
     # convex (non-plane) pairs: collision-geom slots for the per-step world OBB cache, pair list in table order
     cg = sorted({int(g) for p in range(len(f["pair_geom1"])) if p not in pp_set for g in (f["pair_geom1"][p], f["pair_geom2"][p])})
-    if len(cg) > 64:
-        raise ValueError("more than 64 geoms take part in non-plane collision pairs")
+    if len(cg) > 128:
+        raise ValueError("more than 128 geoms take part in non-plane collision pairs")
     slot = {g: i for i, g in enumerate(cg)}
     cp = [p for p in range(len(f["pair_geom1"])) if p not in pp_set]
     f["k_cgeom"] = np.array(cg + [0], np.int32); f["k_ncgeom"] = np.array([len(cg)], np.int32)

@@ -40,3 +40,9 @@ def home_qpos(qpos0):
     q[9] = 0.6
     q[10:14] = 0.025
     return q
+
+
+@pytest.fixture(scope="session")
+def blob_kitchen():
+    with open(os.path.join(MODELS, "stretch_kitchen_standin.smjb"), "rb") as f:
+        return f.read()
