@@ -47,6 +47,63 @@ def cpu_baseline(blob: bytes, ctrl_script: np.ndarray, hold: int, seconds: float
                        f"(stand-in fp64 CPU restatement, not MuJoCo)")
 
 
+def other_configs(B, dev, hold, solver):
+    """Short single-GPU runs of the other BASELINE.json configs (reported beside the headline line, never as `value`)."""
+    from stretch_mujoco_amd import StretchBatchSimulator, StretchSensors
+    from stretch_mujoco_amd.enums import StretchCameras
+
+    res = {}
+
+    def rollout(sim, n, chunk):
+        gen = torch.Generator(device=dev).manual_seed(99)
+        lo = torch.tensor(sim.model["actuator_ctrlrange"][:, 0], dtype=torch.float32, device=dev).unsqueeze(1)
+        hi = torch.tensor(sim.model["actuator_ctrlrange"][:, 1], dtype=torch.float32, device=dev).unsqueeze(1)
+        sim.ctrl[:] = torch.tensor(sim.model["key_ctrl"][0, : sim.nu], dtype=torch.float32, device=dev).unsqueeze(1)
+        sim.step(500)
+        sim.ctrl.copy_(lo + (hi - lo) * torch.rand(sim.nu, B, generator=gen, device=dev))
+        sim.step(chunk)
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        d = 0
+        while d < n:
+            if d % hold == 0:
+                sim.ctrl.copy_(lo + (hi - lo) * torch.rand(sim.nu, B, generator=gen, device=dev))
+            sim.step(chunk)
+            d += chunk
+        torch.cuda.synchronize(dev)
+        return B * d / (time.perf_counter() - t)
+
+    # config 3: + joint readout, IMU, 2-D lidar; at 15 Hz sim-time (every 33 steps) and every step
+    sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver=solver, sensors_to_use=StretchSensors.all())
+    sim.start(home=False)
+    res["lidar_imu_every_33_steps"] = {"value": rollout(sim, 330, 33), "unit": "env-steps/s"}
+    res["lidar_imu_every_step"] = {"value": rollout(sim, 50, 1), "unit": "env-steps/s"}
+    sim.stop()
+    # config 4 stand-in: 24 static kitchen fixtures around the robot (no free objects), physics only
+    sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver=solver, scene="stretch_kitchen_standin")
+    sim.start(home=False)
+    res["kitchen_standin_physics"] = {"value": rollout(sim, 200, hold), "unit": "env-steps/s",
+                                      "overflow_flags": int(sim.info[3].max().item())}
+    sim.stop()
+    # config 5 ingredient: both depth cameras, kitchen stand-in, rendered from the poses of the last step
+    sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver=solver, scene="stretch_kitchen_standin",
+                                cameras_to_use=StretchCameras.depth())
+    sim.start(home=False)
+    rollout(sim, hold, hold)
+    sim.pull_camera_data()
+    torch.cuda.synchronize(dev)
+    t = time.perf_counter()
+    for _ in range(3):
+        sim.pull_camera_data()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t) / 3
+    rays = B * (270 * 480 + 240 * 424)
+    res["depth_both_cameras"] = {"ms_per_render": dt * 1e3, "rays_per_s": rays / dt, "bytes_written_per_s": 4 * rays / dt,
+                                 "note": "d405 270x480 + d435i 240x424 per env, kitchen stand-in; at 30 Hz sim-time one render per 17 steps"}
+    sim.stop()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,6 +116,7 @@ def main():
                          "pgs = the solver named by BASELINE.json north_star")
     ap.add_argument("--no-second-solver", action="store_true", help="skip the short run of the other solver")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other BASELINE.json configs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -192,6 +250,9 @@ def main():
             script = cr[:, 0] + (cr[:, 1] - cr[:, 0]) * rng.random((64, sim.nu))
             out["cpu_baseline"] = cpu_baseline(sim._blob, script, hold, args.cpu_seconds, args.solver)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
+        if not args.no_extra and world == 1:
+            sim.stop()
+            out["other_configs"] = other_configs(B, dev, hold, args.solver)
         print(json.dumps(out))
     sim.stop()
     if dist_on:
