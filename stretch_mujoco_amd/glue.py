@@ -31,6 +31,7 @@ class Glue:
         self.key_ctrl = key_ctrl.to(**f)          # [nkey, nu]
         self.key_names = list(key_names)
         self.mt_val = torch.zeros(nu, B, **f); self.mt_trig = torch.zeros(nu, B, **b)
+        self.mt_has = torch.zeros(nu, B, **b)     # a move_to entry exists in the command (it outlives its trigger)
         self.mb_val = torch.zeros(nu, B, **f); self.mb_trig = torch.zeros(nu, B, **b)
         self.bt_val = torch.zeros(B, **f); self.bt_trig = torch.zeros(B, **b)
         self.br_val = torch.zeros(B, **f); self.br_trig = torch.zeros(B, **b)
@@ -62,6 +63,7 @@ class Glue:
         ids = self._ids(env_ids)
         self.mt_val[i, ids] = pos
         self.mt_trig[i, ids] = True
+        self.mt_has[i, ids] = True
         self.mb_trig[i, ids] = False  # set_move_to pops move_by (status_command.py:53-57)
 
     def move_by(self, actuator, pos, env_ids=None):
@@ -79,6 +81,7 @@ class Glue:
         self.mb_val[i, ids] = pos
         self.mb_trig[i, ids] = True
         self.mt_trig[i, ids] = False  # set_move_by pops move_to (status_command.py:59-63)
+        self.mt_has[i, ids] = False
 
     def set_base_velocity(self, v_linear, omega, env_ids=None):
         ids = self._ids(env_ids)
@@ -96,7 +99,7 @@ class Glue:
 
     def reset(self, env_ids=None):
         ids = self._ids(env_ids)
-        for t in (self.mt_trig, self.mb_trig):
+        for t in (self.mt_trig, self.mb_trig, self.mt_has):
             t[:, ids] = False
         for t in (self.bt_trig, self.br_trig, self.bv_trig, self.kf_trig):
             t[ids] = False

@@ -281,6 +281,39 @@ class StretchBatchSimulator:
 
     # ------------------------------------------------------------------ wait helpers as batched predicates
     @_require_connection
+    def is_reached_set_position(self, actuator, position_tolerance: float = 0.05) -> torch.Tensor:
+        """[B] bool: the joint is within `position_tolerance` of its last `move_to` target; envs whose command holds no
+        move_to entry for the actuator count as reached (stretch_mujoco_simulator.py:235-265, which warns and returns
+        True).  Base and wheel actuators are not supported, as in the reference."""
+        if isinstance(actuator, str):
+            actuator = Actuators[actuator]
+        if actuator in (Actuators.base_rotate, Actuators.base_translate, Actuators.left_wheel_vel, Actuators.right_wheel_vel):
+            raise NotImplementedError(f"Check joint reached is not supported for {actuator}.")
+        from .enums import CTRL_INDEX
+
+        i = CTRL_INDEX[actuator.name]
+        cur = actuator.get_position(self.pull_status())
+        target = self.glue.mt_val[i].to(cur.dtype)
+        return (~self.glue.mt_has[i]) | ((cur - target).abs() <= position_tolerance)
+
+    @_require_connection
+    def wait_until_at_setpoint(self, actuator, timeout: float = 5.0, position_tolerance: float = 0.05) -> torch.Tensor:
+        """Step until every env has reached the actuator's last move_to target or `timeout` SIM-seconds elapse; returns the
+        [B] bool mask of envs that got there (stretch_mujoco_simulator.py:267-297: wall clock there, sim clock here)."""
+        if isinstance(actuator, str):
+            actuator = Actuators[actuator]
+        budget = int(round(timeout / self.timestep))
+        chunk = max(1, int(round(0.05 / self.timestep)))
+        self.step(1)        # fold the pending command into ctrl before the first check
+        done_steps = 1
+        ok = self.is_reached_set_position(actuator, position_tolerance)
+        while not bool(ok.all()) and done_steps < budget:
+            self.step(chunk)
+            done_steps += chunk
+            ok = self.is_reached_set_position(actuator, position_tolerance)
+        return ok
+
+    @_require_connection
     def wait_while_is_moving(self, actuator, timeout: Optional[float] = 5.0, check_interval: float = 0.1,
                              position_tolerance: float = 0.0005) -> torch.Tensor:
         """Step until the actuator stops moving in every env (|dpos| <= tol over check_interval of SIM time) or

@@ -157,8 +157,16 @@ def test_api_flow_home_move_to_move_by_base():
     st = sim.pull_status()
     assert torch.allclose(st.lift.pos, torch.full_like(st.lift.pos, 0.589), atol=3e-3)     # README.md:138
     assert torch.allclose(st.arm.pos, torch.full_like(st.arm.pos, 0.0995), atol=2e-3)
+    assert bool(sim.is_reached_set_position(Actuators.lift).all())        # no move_to entry yet -> counts as reached
     sim.move_to(Actuators.lift, 1.0, env_ids=[0, 1, 2, 3])
     sim.move_to("head_pan", -1.0)
+    sim.step(1)
+    reached = sim.is_reached_set_position(Actuators.lift)
+    assert not bool(reached[:4].any()) and bool(reached[4:].all())
+    ok = sim.wait_until_at_setpoint(Actuators.lift, timeout=5.0)          # examples/move_joints.py:12
+    assert bool(ok.all()) and float(sim.pull_status().time.max()) < 0.6 + 5.0
+    with pytest.raises(NotImplementedError):
+        sim.is_reached_set_position(Actuators.base_translate)
     sim.step(1500)
     st = sim.pull_status()
     assert torch.allclose(st.lift.pos[:4], torch.full((4,), 1.0, device=sim.device), atol=0.05)   # examples/move_joints.py: atol 0.05
