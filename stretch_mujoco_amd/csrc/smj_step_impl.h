@@ -2101,28 +2101,26 @@ struct StepKernel {
       const float gnorm = sqrtf(wave_sum(g2));
       if (iter > 0 && scale * gnorm < M.tolerance) break;
       TICK(SMJ_PROF_N_GRAD)
-      // XA = W J : quadratic rows D*J, cone rows Hc*Jc, others 0   (lanes = dofs, uniform loop over rows)
-      LANES {   // every row scales itself: quadratic rows by D, satisfied / linear rows by 0
-        const float w = (lane < ne && nr.state[lane] == 1) ? nr.D[lane] : 0.f;
-        if (nr.state[lane] != 4)
+      // XA = W J, lane = row: quadratic rows D*J, satisfied / linear rows 0, rows of a contact in the cone (middle) zone
+      // (Hc Jc)[row] = sum_q Hc[row][q] * J[first row + q][:]  -- all cone rows at once instead of a loop over contacts
+      LANES {
+        if (lane < ne && nr.state[lane] == 4) {
+          const int c = s.eid[lane], r0 = s.cefc[c], dim = s.cdim[c], rr = lane - r0;
+          float h[6];
+          int rq[6];
+#pragma unroll
+          for (int q = 0; q < 6; q++) { h[q] = q < dim ? s.u.n.cH[c][rr * dim + q] : 0.f; rq[q] = r0 + (q < dim ? q : 0); }
+#pragma unroll 8
+          for (int k = 0; k < NVP; k++) {   // fixed trip counts (zero-padded block) so that the LDS reads are issued back to back
+            float v = 0;
+#pragma unroll
+            for (int q = 0; q < 6; q++) v += h[q] * s.J[rq[q]][k];
+            s.u.n.XA[lane][k] = v;
+          }
+        } else {
+          const float w = (lane < ne && nr.state[lane] == 1) ? nr.D[lane] : 0.f;
 #pragma unroll
           for (int k = 0; k < NVP; k++) s.u.n.XA[lane][k] = w * s.J[lane][k];
-      }
-      for (int c = 0; c < ncon; c++) {   // contacts in the cone (middle) zone: XA rows = Hc * Jc
-        const int r = uni(s.cefc[c]);
-        if (r < 0) continue;
-        if (wave_read(nr.state, r) != 4) continue;
-        const int dim = uni(s.cdim[c]);
-        LANES {
-          if (lane < NVP) {
-            float jc[6];
-            for (int q = 0; q < dim; q++) jc[q] = s.J[r + q][lane];
-            for (int rr = 0; rr < dim; rr++) {
-              float v = 0;
-              for (int q = 0; q < dim; q++) v += s.u.n.cH[c][rr * dim + q] * jc[q];
-              s.u.n.XA[r + rr][lane] = v;
-            }
-          }
         }
       }
       SYNC();
