@@ -1817,45 +1817,60 @@ struct StepKernel {
       s.ef[lane] = f;
     }
     SYNC();
-    // elliptic contacts: the lane of the contact's first row handles the block
+    // elliptic contacts: the lane of the contact's first row handles the block.  All loops run to the maximum block size 6
+    // with the tail masked off (zero friction coefficient, clamped row index): fixed trip counts let the LDS reads issue
+    // back to back instead of one latency per row.
     LANES {
       const int c = nr.c0[lane];
       if (c >= 0) {
         const int i = lane, dim = s.cdim[c];
         const float mu = nr.cq[lane][6];
-        float U[6], jr[6], T = 0;
-        for (int j = 0; j < dim; j++) jr[j] = s.eb[i + j];
-        U[0] = jr[0] * mu;
-        for (int j = 1; j < dim; j++) { U[j] = jr[j] * s.cfric[c][j - 1]; T += U[j] * U[j]; }
+        float U[6], jr[6], S[6], Rj[6], T = 0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          const int jj = j < dim ? j : 0;
+          jr[j] = s.eb[i + jj];
+          Rj[j] = s.eR[i + jj];
+          S[j] = j == 0 ? mu : (j < dim ? s.cfric[c][j - 1] : 0.f);
+          U[j] = jr[j] * S[j];
+          if (j > 0) T += U[j] * U[j];
+        }
         const float N = U[0];
         T = sqrtf(T);
         int st;
-        float cc = 0;
-        if (N >= mu * T || (T <= 0 && N >= 0)) { st = 0; for (int j = 0; j < dim; j++) s.ef[i + j] = 0; }
+        float cc = 0, ef[6] = {0, 0, 0, 0, 0, 0};
+        if (N >= mu * T || (T <= 0 && N >= 0)) { st = 0; }
         else if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
           st = 1;
-          for (int j = 0; j < dim; j++) { const float Dj = 1.0f / s.eR[i + j]; s.ef[i + j] = -Dj * jr[j]; cc += 0.5f * Dj * jr[j] * jr[j]; }
+#pragma unroll
+          for (int j = 0; j < 6; j++)
+            if (j < dim) { const float Dj = 1.0f / Rj[j]; ef[j] = -Dj * jr[j]; cc += 0.5f * Dj * jr[j] * jr[j]; }
         } else {
           st = 4;
           const float Dm = nr.cq[lane][5], NT = N - mu * T, Ti = 1.0f / T;
           cc = 0.5f * Dm * NT * NT;
           const float fn = -Dm * NT * mu;
-          s.ef[i] = fn;
-          for (int j = 1; j < dim; j++) s.ef[i + j] = -fn * Ti * U[j] * s.cfric[c][j - 1];
+          ef[0] = fn;
+#pragma unroll
+          for (int j = 1; j < 6; j++) ef[j] = -fn * Ti * U[j] * S[j];
           if (want_hess) {
-            float S[6];
-            S[0] = mu;
-            for (int j = 1; j < dim; j++) S[j] = s.cfric[c][j - 1];
             float* H = s.u.n.cH[c];
             const float a = mu * N * Ti * Ti * Ti, b = mu * NT * Ti;
             H[0] = Dm * S[0] * S[0];
-            for (int j = 1; j < dim; j++) H[j] = H[j * dim] = -mu * U[j] * Ti * Dm * S[0] * S[j];
-            for (int j = 1; j < dim; j++)
-              for (int k = 1; k < dim; k++) H[j * dim + k] = (a * U[j] * U[k] - (j == k ? b : 0.f)) * Dm * S[j] * S[k];
+#pragma unroll
+            for (int j = 1; j < 6; j++)
+              if (j < dim) H[j] = H[j * dim] = -mu * U[j] * Ti * Dm * S[0] * S[j];
+#pragma unroll
+            for (int j = 1; j < 6; j++)
+#pragma unroll
+              for (int k = 1; k < 6; k++)
+                if (j < dim && k < dim) H[j * dim + k] = (a * U[j] * U[k] - (j == k ? b : 0.f)) * Dm * S[j] * S[k];
           }
         }
         cost[lane] += cc;
-        for (int j = 0; j < dim; j++) s.earef[i + j] = (float)st;  // block state broadcast through LDS
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+          if (j < dim) { s.ef[i + j] = ef[j]; s.earef[i + j] = (float)st; }   // block state broadcast through LDS
       }
     }
     SYNC();
