@@ -1883,22 +1883,19 @@ struct StepKernel {
   // y = M x for lane-resident x (lane = dof); M = strict upper of MM + Mdiag (lower part holds the L'DL factor)
   SMJ_DEV void mat_M(PL<float>& y, const PL<float>& x) {
     const int nv = M.nv;
-    LANES { y[lane] = lane < nv ? s.Mdiag[lane] * x[lane] : 0.f; }
-    for (int j0 = 0; j0 < nv; j0 += 4) {   // four columns per pass: the LDS loads of a pass are independent
-      float xj[4];
+    PL<float[NVP]> m;   // row `lane` of M: all LDS reads are issued before the first use (fixed trip count, masked tail)
+    LANES {
 #pragma unroll
-      for (int u = 0; u < 4; u++) xj[u] = j0 + u < nv ? wave_read(x, j0 + u) : 0.f;
-      LANES {
-        if (lane < nv) {
-          float m[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const int j = j0 + u;
-            m[u] = (j < nv && lane != j) ? (lane > j ? s.MM[j][lane] : s.MM[lane][j]) : 0.f;
-          }
-          y[lane] += m[0] * xj[0] + m[1] * xj[1] + m[2] * xj[2] + m[3] * xj[3];
-        }
+      for (int j = 0; j < NVP; j++) {
+        const float v = lane > j ? s.MM[j][lane < NVP ? lane : 0] : s.MM[lane < NVP ? lane : 0][j];
+        m[lane][j] = (j < nv && lane < nv && lane != j) ? v : 0.f;
       }
+      y[lane] = lane < nv ? s.Mdiag[lane] * x[lane] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NVP; j++) {
+      const float xj = wave_read(x, j);
+      LANES { y[lane] += m[lane][j] * xj; }
     }
   }
   // out[row] = J[row] . x - sub[row] evaluated with error-free transformations (TwoProduct / TwoSum: ~fp64
@@ -1922,38 +1919,38 @@ struct StepKernel {
     }
     LANES { out[lane] = hi[lane] + lo[lane]; }
   }
-  // out[dof] = sum_rows J[row][dof] * f[row]   (lane = dof, f lane-resident over rows), four rows per pass
+  // out[dof] = sum_rows J[row][dof] * f[row]   (lane = dof, f lane-resident over rows), sixteen rows per pass
   SMJ_DEV void matT_J(PL<float>& out, const PL<float>& f) {
     const int ne = nefc;
     LANES { out[lane] = 0.f; }
-    for (int r0 = 0; r0 < ne; r0 += 4) {
-      float fr[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) fr[u] = r0 + u < ne ? wave_read(f, r0 + u) : 0.f;
-      LANES {
-        if (lane < NVP) {
-          float a[4];
+    for (int r0 = 0; r0 < NEFC; r0 += 16) {
+      if (r0 < ne) {
+        PL<float[16]> a;
+        LANES {
 #pragma unroll
-          for (int u = 0; u < 4; u++) a[u] = r0 + u < NEFC ? s.J[r0 + u < NEFC ? r0 + u : 0][lane] : 0.f;
-          out[lane] += a[0] * fr[0] + a[1] * fr[1] + a[2] * fr[2] + a[3] * fr[3];
+          for (int u = 0; u < 16; u++) a[lane][u] = (lane < NVP && r0 + u < ne) ? s.J[r0 + u][lane] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+          const float fr = wave_read(f, r0 + u);
+          LANES { out[lane] += a[lane][u] * fr; }
         }
       }
     }
   }
-  // out[row] = J[row] . x   (lane = row, x lane-resident over dofs)
+  // out[row] = J[row] . x   (lane = row, x lane-resident over dofs; columns nv..NVP of J are zero)
   SMJ_DEV void mat_J(PL<float>& out, const PL<float>& x) {
-    const int nv = M.nv;
-    LANES { out[lane] = 0.f; }
-    for (int k0 = 0; k0 < nv; k0 += 4) {
-      float xk[4];
+    PL<float[NVP]> a;
+    LANES {
 #pragma unroll
-      for (int u = 0; u < 4; u++) xk[u] = k0 + u < nv ? wave_read(x, k0 + u) : 0.f;
-      LANES {
-        float a[4];
+      for (int k = 0; k < NVP; k++) a[lane][k] = s.J[lane][k];
+      out[lane] = 0.f;
+    }
 #pragma unroll
-        for (int u = 0; u < 4; u++) a[u] = s.J[lane][k0 + u];   // columns nv..NVP of J are zero
-        out[lane] += a[0] * xk[0] + a[1] * xk[1] + a[2] * xk[2] + a[3] * xk[3];
-      }
+    for (int k = 0; k < NVP; k++) {
+      const float xk = wave_read(x, k);
+      LANES { out[lane] += a[lane][k] * xk; }
     }
   }
 
@@ -2208,9 +2205,12 @@ struct StepKernel {
         if (c >= 0) {
           const int i = lane, dim = s.cdim[c];
           float a0 = 0, a1 = 0, a2 = 0, uu = 0, uv = 0, vv = 0;
-          for (int j = 1; j < dim; j++) {
-            a0 += s.earef[i + j]; a1 += s.eK[i + j]; a2 += s.eBv[i + j];
-            const float fr = s.cfric[c][j - 1], u = s.eb[i + j] * fr, v = s.ef[i + j] * fr;
+#pragma unroll
+          for (int j = 1; j < 6; j++) {   // fixed trip count, tail masked by a zero weight
+            const int jj = j < dim ? j : 1;
+            const float on = j < dim ? 1.f : 0.f;
+            a0 += on * s.earef[i + jj]; a1 += on * s.eK[i + jj]; a2 += on * s.eBv[i + jj];
+            const float fr = on * s.cfric[c][jj - 1], u = s.eb[i + jj] * fr, v = s.ef[i + jj] * fr;
             uu += u * u; uv += u * v; vv += v * v;
           }
           nr.q0[lane] += a0; nr.q1[lane] += a1; nr.q2[lane] += a2;
