@@ -2137,41 +2137,51 @@ struct StepKernel {
       }
       SYNC();
       TICK(SMJ_PROF_N_XA)
-      // H = M + XA' J on the matrix cores: 2x2 tiles of 16x16 over dofs, K = constraint rows
+      // H = M + XA' J on the matrix cores: the three lower 16x16 tiles over dofs, K = constraint rows.  The operands of all
+      // tiles are fetched first (XA and J column halves, shared between tiles) and the three accumulation chains are
+      // interleaved, so that neither the LDS latency nor the MFMA latency of one tile serialises the others.
       {
         const int ksteps = (ne + 3) >> 2;
-        for (int ta = 0; ta < 2; ta++)
-          for (int tb = 0; tb <= ta; tb++) {
-            PL<F4v> acc;
-            PL<float[NEFC / 4]> av, bv;
-            LANES {
-              for (int r = 0; r < 4; r++) acc[lane].r[r] = 0.f;
+        PL<F4v> acc00, acc10, acc11;
+        PL<float[NEFC / 4]> a0, a1, b0, b1;
+        LANES {
+          for (int r = 0; r < 4; r++) { acc00[lane].r[r] = 0.f; acc10[lane].r[r] = 0.f; acc11[lane].r[r] = 0.f; }
 #pragma unroll
-              for (int ks = 0; ks < NEFC / 4; ks++) {   // all operand loads of the tile are issued before the first MFMA
-                const int k = 4 * ks + (lane >> 4);
-                av[lane][ks] = ks < ksteps ? s.u.n.XA[k][16 * ta + (lane & 15)] : 0.f;   // rows >= ne of XA / J are zero
-                bv[lane][ks] = ks < ksteps ? s.J[k][16 * tb + (lane & 15)] : 0.f;
-              }
-            }
+          for (int ks = 0; ks < NEFC / 4; ks++) {
+            const int k = 4 * ks + (lane >> 4), c = lane & 15;
+            const bool on = ks < ksteps;                       // rows >= ne of XA / J are zero
+            a0[lane][ks] = on ? s.u.n.XA[k][c] : 0.f;
+            a1[lane][ks] = on ? s.u.n.XA[k][16 + c] : 0.f;
+            b0[lane][ks] = on ? s.J[k][c] : 0.f;
+            b1[lane][ks] = on ? s.J[k][16 + c] : 0.f;
+          }
+        }
 #pragma unroll
-            for (int ks = 0; ks < NEFC / 4; ks++) {
-              if (ks < ksteps) {
-                PL<float> a, b;
-                LANES { a[lane] = av[lane][ks]; b[lane] = bv[lane][ks]; }
-                mfma16x16x4(acc, a, b);
-              }
-            }
-            LANES {
-              for (int r = 0; r < 4; r++) {
-                const int row = 16 * ta + (lane >> 4) * 4 + r, col = 16 * tb + (lane & 15);
-                float v = acc[lane].r[r];
-                if (row < nv && col < nv) v += row == col ? s.Mdiag[row] : (row < col ? s.MM[row][col] : s.MM[col][row]);
-                else v = row == col ? 1.f : 0.f;
-                s.u.n.H[row][col] = v;
-                if (ta != tb) s.u.n.H[col][row] = v;
-              }
+        for (int ks = 0; ks < NEFC / 4; ks++) {
+          if (ks < ksteps) {
+            PL<float> pa0, pa1, pb0, pb1;
+            LANES { pa0[lane] = a0[lane][ks]; pa1[lane] = a1[lane][ks]; pb0[lane] = b0[lane][ks]; pb1[lane] = b1[lane][ks]; }
+            mfma16x16x4(acc00, pa0, pb0);
+            mfma16x16x4(acc10, pa1, pb0);
+            mfma16x16x4(acc11, pa1, pb1);
+          }
+        }
+        LANES {
+#pragma unroll
+          for (int t = 0; t < 3; t++) {
+            const int ta = t > 0, tb = t > 1;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int row = 16 * ta + (lane >> 4) * 4 + r, col = 16 * tb + (lane & 15);
+              float v = t == 0 ? acc00[lane].r[r] : (t == 1 ? acc10[lane].r[r] : acc11[lane].r[r]);
+              const float mv = row == col ? s.Mdiag[row] : (row < col ? s.MM[row][col] : s.MM[col][row]);
+              if (row < nv && col < nv) v += mv;
+              else v = row == col ? 1.f : 0.f;
+              s.u.n.H[row][col] = v;
+              if (ta != tb) s.u.n.H[col][row] = v;
             }
           }
+        }
       }
       SYNC();
       TICK(SMJ_PROF_N_HMFMA)
