@@ -53,7 +53,7 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
   GI(nsite, "dims", 6) GI(neq, "dims", 8) GI(nkey, "dims", 11) GI(npair, "dims", 12)
   GI(nlevel, "k_nlevel", 0) GI(nfric, "k_nfric", 0) GI(nlimit, "k_nlimit", 0) GI(nplanepair, "k_nplanepair", 0)
   GI(nldl, "k_nldl", 0) GI(imu_site, "sensor_imu_site", 0) GI(ngc, "k_ngc", 0) GI(nroot, "k_nroot", 0)
-  GI(njump, "k_njump", 0) GI(ncgeom, "k_ncgeom", 0) GI(nconvpair, "k_nconvpair", 0) GI(iterations, "opt_iterations", 0)
+  GI(njump, "k_njump", 0) GI(maxsubtree, "k_maxsubtree", 0) GI(ncgeom, "k_ncgeom", 0) GI(nconvpair, "k_nconvpair", 0) GI(iterations, "opt_iterations", 0)
   GF(timestep, "opt_timestep", 0) GF(gravity[0], "opt_gravity", 0) GF(gravity[1], "opt_gravity", 1)
   GF(gravity[2], "opt_gravity", 2) GF(impratio, "opt_impratio", 0) GF(tolerance, "opt_tolerance", 0)
   GF(meaninertia, "stat_meaninertia", 0) GF(lidar_cutoff, "sensor_lidar_cutoff", 0)
@@ -73,6 +73,7 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
   if (m.nldl > 5 * 64) { err = "mass-matrix sparsity pattern too large"; return -4; }
   if (m.neq + m.nfric > NEFC) { err = "too many static constraint rows"; return -4; }
   if (2 * m.nlimit > 64) { err = "too many limited joints"; return -4; }
+  if (m.njump > 6) { err = "body tree deeper than 64 levels"; return -4; }
   if (m.ncgeom > NCG) { err = "too many geoms in non-plane collision pairs"; return -4; }
 #define X(n)                                                                               \
   {                                                                                        \

@@ -196,6 +196,7 @@ struct StepKernel {
   // ------------------------------------------------------------------ stage-local constant tables
   struct KinTab {   // lane = body: tree link + the body's (<= 2) joints
     PL<int> parent, level;
+    PL<int[6]> jump;        // k_body_jump rows (pointer-jumping ancestors), fetched with the rest of the table
     PL<float[3]> pos;
     PL<float[4]> quat;
     PL<int[2]> jtype, jqadr, jdadr;
@@ -207,6 +208,7 @@ struct StepKernel {
     LANES {
       const int b = lane < nb ? lane : 0;
       t.parent[lane] = M.body_parentid[b]; t.level[lane] = lane < nb ? M.k_body_level[b] : -1;
+      for (int r = 0; r < 6; r++) t.jump[lane][r] = (r < M.njump && lane > 0 && lane < nb) ? M.k_body_jump[r * nb + b] : 0;
       for (int k = 0; k < 3; k++) t.pos[lane][k] = M.body_pos[3 * b + k];
       for (int k = 0; k < 4; k++) t.quat[lane][k] = M.body_quat[4 * b + k];
       const int jn = M.body_jntnum[b], ja = M.body_jntadr[b];
@@ -221,7 +223,8 @@ struct StepKernel {
     }
   }
   struct BodyTab {  // lane = body: inertia and tree bookkeeping
-    PL<int> root, subsize;
+    PL<int> root, subsize, parent, dofadr, dofnum;
+    PL<int[6]> jump;
     PL<uint64_t> dofmask;
     PL<float[10]> inl;
   };
@@ -229,6 +232,8 @@ struct StepKernel {
     LANES {
       const int b = lane < M.nbody ? lane : 0;
       t.root[lane] = M.body_rootid[b]; t.subsize[lane] = M.k_body_subtreesize[b];
+      t.parent[lane] = M.body_parentid[b]; t.dofadr[lane] = M.body_dofadr[b]; t.dofnum[lane] = lane < M.nbody ? M.body_dofnum[b] : 0;
+      for (int r = 0; r < 6; r++) t.jump[lane][r] = (r < M.njump && lane > 0 && lane < M.nbody) ? M.k_body_jump[r * M.nbody + b] : 0;
       t.dofmask[lane] = mk64(M.k_body_dofmask_lo[b], M.k_body_dofmask_hi[b]);
       for (int k = 0; k < 10; k++) t.inl[lane][k] = M.k_body_inertia_local[10 * b + k];
     }
@@ -394,12 +399,14 @@ struct StepKernel {
       for (int k = 0; k < 4; k++) { ql[lane][k] = quat[k]; if (lane < NBP) s.xquat[lane][k] = quat[k]; }
     }
     SYNC();
-    for (int r = 0; r < M.njump; r++) {
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      if (r >= M.njump) break;
       PL<float[3]> pa;
       PL<float[4]> qa;
       PL<int> anc;
       LANES {
-        const int a = (lane > 0 && lane < nb) ? M.k_body_jump[r * nb + lane] : 0;
+        const int a = kt.jump[lane][r];
         anc[lane] = a;
         for (int k = 0; k < 3; k++) pa[lane][k] = s.xpos[a][k];
         for (int k = 0; k < 4; k++) qa[lane][k] = s.xquat[a][k];
@@ -528,16 +535,58 @@ struct StepKernel {
       }
     }
     SYNC();
-    // comVel: cdof_dot (dof lanes), cvel (body lanes); crb = sum of cinert over the (contiguous) subtree
+    // comVel.  cvel[b] = sum over the dofs on the path to b of cdof*qvel: own-body sums, then pointer jumping up the tree
+    // (k_body_jump, as in kinematics) instead of a loop over up to 26 ancestor dofs per lane.
+    LANES {
+      if (lane < nv)
+        for (int x = 0; x < 6; x++) s.u.t.buf[lane][x] = cdof[lane][x] * qvel_r[lane];
+    }
+    SYNC();
+    PL<float[6]> cvb;
+    LANES {
+      float sv[6] = {0, 0, 0, 0, 0, 0};
+      if (lane > 0 && lane < nb) {
+        const int da = bt.dofadr[lane], dn = bt.dofnum[lane];
+#pragma unroll
+        for (int u = 0; u < 6; u++) {   // a body carries at most six dofs; fixed trip count, masked tail
+          const float on = u < dn ? 1.f : 0.f;
+          const int a = da + (u < dn ? u : 0);
+          for (int x = 0; x < 6; x++) sv[x] += on * s.u.t.buf[dn > 0 ? a : 0][x];
+        }
+      }
+      for (int x = 0; x < 6; x++) { cvb[lane][x] = sv[x]; if (lane < NBP) s.u.t.cvel[lane][x] = sv[x]; }
+    }
+    SYNC();
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      if (r >= M.njump) break;
+      PL<float[6]> up;
+      PL<int> anc;
+      LANES {
+        const int a = bt.jump[lane][r];
+        anc[lane] = a;
+        for (int x = 0; x < 6; x++) up[lane][x] = s.u.t.cvel[a][x];
+      }
+      SYNC();
+      LANES {
+        if (anc[lane] > 0)
+          for (int x = 0; x < 6; x++) { cvb[lane][x] += up[lane][x]; s.u.t.cvel[lane][x] = cvb[lane][x]; }
+      }
+      SYNC();
+    }
+    // cdof_dot (dof lanes): the velocity seen by dof d is the parent body's cvel plus the earlier dofs of its own body
+    // that k_dof_velmask admits; crb = sum of cinert over the contiguous DFS subtree, four bodies per pass
     LANES {
       if (lane < nv) {
-        float cv[6] = {0, 0, 0, 0, 0, 0};
-        uint64_t mk = dt.velmask[lane];
-        while (mk) {
-          const int a = ffs64(mk);
-          mk &= mk - 1;
-          const float qv = s.qvel[a];
-          for (int x = 0; x < 6; x++) cv[x] += s.u.t.cdof[a][x] * qv;
+        const int b = dt.body[lane], pb = M.body_parentid[b], da = M.body_dofadr[b];
+        float cv[6];
+        for (int x = 0; x < 6; x++) cv[x] = s.u.t.cvel[pb][x];
+        const uint64_t mk = dt.velmask[lane];
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+          const int a = da + u;
+          const float on = (a < lane && ((mk >> a) & 1)) ? 1.f : 0.f;
+          for (int x = 0; x < 6; x++) cv[x] += on * s.u.t.buf[a < lane ? a : lane][x];
         }
         const int jt = dt.jtype[lane], k = lane - dt.first[lane];
         if (jt == JT_FREE && k < 3) { for (int x = 0; x < 6; x++) cdof_dot[lane][x] = 0; }
@@ -546,22 +595,27 @@ struct StepKernel {
       } else {
         for (int x = 0; x < 6; x++) cdof_dot[lane][x] = 0;
       }
-      if (lane < nb) {
-        const int b = lane;
-        float cv[6] = {0, 0, 0, 0, 0, 0};
-        uint64_t mk = bt.dofmask[lane];
-        while (mk) {
-          const int a = ffs64(mk);
-          mk &= mk - 1;
-          const float qv = s.qvel[a];
-          for (int x = 0; x < 6; x++) cv[x] += s.u.t.cdof[a][x] * qv;
+    }
+    {
+      PL<float[10]> cr;
+      LANES { for (int k = 0; k < 10; k++) cr[lane][k] = 0.f; }
+      for (int x0 = 0; x0 < M.maxsubtree; x0 += 4) {
+        LANES {
+          if (lane > 0 && lane < nb) {
+            const int sub = bt.subsize[lane];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const bool in = x0 + u < sub;
+              const int x = lane + (in ? x0 + u : 0);
+              const float on = in ? 1.f : 0.f;
+              for (int k = 0; k < 10; k++) cr[lane][k] += on * s.u.t.cinert[x][k];
+            }
+          }
         }
-        for (int x = 0; x < 6; x++) s.u.t.cvel[b][x] = cv[x];
-        float c[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (b > 0)
-          for (int x = b; x < b + bt.subsize[lane]; x++)
-            for (int k = 0; k < 10; k++) c[k] += s.u.t.cinert[x][k];
-        for (int k = 0; k < 10; k++) s.u.t.crb[b][k] = c[k];
+      }
+      LANES {
+        if (lane < nb)
+          for (int k = 0; k < 10; k++) s.u.t.crb[lane][k] = cr[lane][k];
       }
     }
     SYNC();

@@ -219,6 +219,7 @@ def kernel_tables(f: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     for b in range(1, nb):
         assert all(_is_desc(par, x, b) for x in range(b, b + size[b])), "bodies must be in depth-first order"
     f["k_body_subtreesize"] = size
+    f["k_maxsubtree"] = np.array([int(max([f["k_body_subtreesize"][b] for b in range(1, nb)] + [1]))], np.int32)
     roots = [b for b in range(1, nb) if par[b] == 0 and f["body_rootid"][b] == b and f["body_subtreemass"][b] > 0]
     f["k_root_list"] = np.array(roots + [0], np.int32); f["k_nroot"] = np.array([len(roots)], np.int32)
     gcb = [b for b in range(1, nb) if f["body_gcmass"][b] != 0]
