@@ -31,6 +31,8 @@ struct Smem {
     TreeTmp t;
     struct {                // collision: world frames of the geoms taking part in convex pairs (tree temporaries are dead)
       float pos[NCG][3], mat[NCG][9], cen[NCG][3], half[NCG][3];
+      float ccen[NCG][3], size[NCG][3];   // world centre used as MPR's interior point, geom size
+      int meta[NCG][3];                   // geom type, hull vertex count, hull address
       unsigned short list[1024];   // bounding-sphere survivors of the convex pair list, table order
     } c;
     struct {                // plane narrowphase staging: contacts of the pair owned by each lane, emitted in pair order
@@ -1075,7 +1077,9 @@ struct StepKernel {
   // Restates libccd's ccdMPRPenetration (the routine MuJoCo 3.2.6's mjc_Convex uses for mesh / cylinder / box pairs;
   // third-party, not in /root/reference) with the same control flow as oracle/smj_oracle.c mpr_penetration.  Wave-uniform
   // scalar logic; the hull support function is lane-parallel (vertices strided over lanes, arg-max by wave reduction).
-  struct Shape { int type, nvert; const float* verts; float pos[3], mat[9], size[3]; };
+  // vc: the first 256 hull vertices, strided over the lanes (vertex lane + 64 u in slot u), fetched once per pair by
+  // load_shape and reused by every support query of the MPR run
+  struct Shape { int type, nvert; const float* verts; float pos[3], mat[9], size[3]; PL<float[12]> vc; };
   struct MprPt { float v[3], a[3], b[3]; };
 
   SMJ_DEV void shape_support(const Shape& sh, const float* dir, float* out) {
@@ -1091,14 +1095,21 @@ struct StepKernel {
       if (n > SMJ_MINVAL) { pl[0] = sh.size[0] * dl[0] / n; pl[1] = sh.size[0] * dl[1] / n; }
       pl[2] = dl[2] >= 0 ? sh.size[1] : -sh.size[1];
     } else {
-      PL<float> best;
+      PL<float> best, bx, by, bz;
       PL<int> bidx;
       const Vec4* verts = reinterpret_cast<const Vec4*>(sh.verts);
       const int nvert = sh.nvert;
       LANES {
-        float bd = -3.0e38f;
+        float bd = -3.0e38f, b[3] = {0, 0, 0};
         int bi = -1;
-        for (int i0 = lane; i0 < nvert; i0 += 256) {   // four independent 16-byte loads in flight per lane
+#pragma unroll
+        for (int u = 0; u < 4; u++) {   // register-resident vertices
+          const int id = lane + 64 * u;
+          const float x = sh.vc[lane][3 * u], y = sh.vc[lane][3 * u + 1], z = sh.vc[lane][3 * u + 2];
+          const float d = x * dl[0] + y * dl[1] + z * dl[2];
+          if (id < nvert && d > bd) { bd = d; bi = id; b[0] = x; b[1] = y; b[2] = z; }
+        }
+        for (int i0 = 256 + lane; i0 < nvert; i0 += 256) {   // larger hulls: the rest from memory, four 16-byte loads in flight
           Vec4 v[4];
           int id[4];
 #pragma unroll
@@ -1106,14 +1117,15 @@ struct StepKernel {
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const float d = v[u].x * dl[0] + v[u].y * dl[1] + v[u].z * dl[2];
-            if (d > bd) { bd = d; bi = id[u]; }
+            if (d > bd) { bd = d; bi = id[u]; b[0] = v[u].x; b[1] = v[u].y; b[2] = v[u].z; }
           }
         }
-        best[lane] = bd; bidx[lane] = bi;
+        best[lane] = bd; bidx[lane] = bi; bx[lane] = b[0]; by[lane] = b[1]; bz[lane] = b[2];
       }
       const float mx = wave_max(best);
       const int idx = pick_index(best, bidx, mx);
-      pl[0] = uni(verts[idx].x); pl[1] = uni(verts[idx].y); pl[2] = uni(verts[idx].z);
+      const int owner = idx & 63;   // vertex i is scanned by lane i mod 64: the winner's coordinates come by v_readlane
+      pl[0] = wave_read(bx, owner); pl[1] = wave_read(by, owner); pl[2] = wave_read(bz, owner);
     }
     mulmat3vec(out, sh.mat, pl);
     for (int i = 0; i < 3; i++) out[i] += sh.pos[i];
@@ -1266,14 +1278,23 @@ struct StepKernel {
   }
 
   SMJ_DEV void load_shape(Shape& sh, int g, int slot, float* cen) {
-    sh.type = uni(M.geom_type[g]); sh.nvert = uni(M.geom_hullnum[g]);
-    const int adr = uni(M.geom_hulladr[g]);
-    sh.verts = M.k_hull_vert4 + 4 * (adr < 0 ? 0 : adr);
-    for (int k = 0; k < 3; k++) { sh.pos[k] = uni(s.u.c.pos[slot][k]); sh.size[k] = uni(M.geom_size[3 * g + k]); }
+    (void)g;
+    sh.type = uni(s.u.c.meta[slot][0]); sh.nvert = uni(s.u.c.meta[slot][1]);
+    sh.verts = M.k_hull_vert4 + 4 * uni(s.u.c.meta[slot][2]);
+    for (int k = 0; k < 3; k++) { sh.pos[k] = uni(s.u.c.pos[slot][k]); sh.size[k] = uni(s.u.c.size[slot][k]); cen[k] = uni(s.u.c.ccen[slot][k]); }
     for (int k = 0; k < 9; k++) sh.mat[k] = uni(s.u.c.mat[slot][k]);
-    const float lc[3] = {uni(M.geom_ccenter[3 * g]), uni(M.geom_ccenter[3 * g + 1]), uni(M.geom_ccenter[3 * g + 2])};
-    mulmat3vec(cen, sh.mat, lc);
-    for (int k = 0; k < 3; k++) cen[k] += sh.pos[k];
+    if (sh.type == GT_MESH) {
+      const Vec4* verts = reinterpret_cast<const Vec4*>(sh.verts);
+      const int nvert = sh.nvert;
+      LANES {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int id = lane + 64 * u < nvert ? lane + 64 * u : (nvert > 0 ? nvert - 1 : 0);
+          const Vec4 v = verts[id];
+          sh.vc[lane][3 * u] = v.x; sh.vc[lane][3 * u + 1] = v.y; sh.vc[lane][3 * u + 2] = v.z;
+        }
+      }
+    }
   }
 
   // non-plane pairs: cache world frames of the participating geoms, sphere + oriented-box broadphase with lane = pair,
@@ -1291,6 +1312,13 @@ struct StepKernel {
           mulmat3vec(cw, mat, lc);
           for (int k = 0; k < 3; k++) { s.u.c.pos[c][k] = pos[k]; s.u.c.cen[c][k] = pos[k] + cw[k]; s.u.c.half[c][k] = M.k_cgeom_half[3 * c + k]; }
           for (int k = 0; k < 9; k++) s.u.c.mat[c][k] = mat[k];
+          // everything load_shape needs, gathered here lane-parallel so that the (wave-serial) MPR set-up reads LDS only
+          const float lcc[3] = {M.geom_ccenter[3 * g], M.geom_ccenter[3 * g + 1], M.geom_ccenter[3 * g + 2]};
+          float wc[3];
+          mulmat3vec(wc, mat, lcc);
+          for (int k = 0; k < 3; k++) { s.u.c.ccen[c][k] = pos[k] + wc[k]; s.u.c.size[c][k] = M.geom_size[3 * g + k]; }
+          const int adr = M.geom_hulladr[g];
+          s.u.c.meta[c][0] = M.geom_type[g]; s.u.c.meta[c][1] = M.geom_hullnum[g]; s.u.c.meta[c][2] = adr < 0 ? 0 : adr;
         }
       }
     }
