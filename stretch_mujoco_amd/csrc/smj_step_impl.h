@@ -208,7 +208,8 @@ struct StepKernel {
   SMJ_DEV void load(KinTab& t) {
     const int nb = M.nbody;
     LANES {
-      const int b = lane < nb ? lane : 0;
+      const int ol = opaque(lane);
+      const int b = ol < nb ? ol : 0;
       t.parent[lane] = M.body_parentid[b]; t.level[lane] = lane < nb ? M.k_body_level[b] : -1;
       for (int r = 0; r < 6; r++) t.jump[lane][r] = (r < M.njump && lane > 0 && lane < nb) ? M.k_body_jump[r * nb + b] : 0;
       for (int k = 0; k < 3; k++) t.pos[lane][k] = M.body_pos[3 * b + k];
@@ -232,7 +233,8 @@ struct StepKernel {
   };
   SMJ_DEV void load(BodyTab& t) {
     LANES {
-      const int b = lane < M.nbody ? lane : 0;
+      const int ol = opaque(lane);
+      const int b = ol < M.nbody ? ol : 0;
       t.root[lane] = M.body_rootid[b]; t.subsize[lane] = M.k_body_subtreesize[b];
       t.parent[lane] = M.body_parentid[b]; t.dofadr[lane] = M.body_dofadr[b]; t.dofnum[lane] = lane < M.nbody ? M.body_dofnum[b] : 0;
       for (int r = 0; r < 6; r++) t.jump[lane][r] = (r < M.njump && lane > 0 && lane < M.nbody) ? M.k_body_jump[r * M.nbody + b] : 0;
@@ -249,7 +251,8 @@ struct StepKernel {
   };
   SMJ_DEV void load(DofTab& t) {
     LANES {
-      const int d = lane < M.nv ? lane : 0, j = M.dof_jntid[d], db = M.dof_bodyid[d];
+      const int ol = opaque(lane);
+      const int d = ol < M.nv ? ol : 0, j = M.dof_jntid[d], db = M.dof_bodyid[d];
       const int jt = M.jnt_type[j];
       t.body[lane] = db; t.jtype[lane] = jt; t.qadr[lane] = M.k_dof_qposadr[d]; t.first[lane] = M.jnt_dofadr[j];
       t.bsub[lane] = M.k_body_subtreesize[db];
@@ -266,8 +269,9 @@ struct StepKernel {
   };
   SMJ_DEV void load(EntryTab& t, bool implicit) {
     LANES {
+      const int ol = opaque(lane);
       for (int u = 0; u < 5; u++) {
-        const int e = lane + 64 * u, ok = e < M.nldl, ex = ok ? e : 0;
+        const int e = ol + 64 * u, ok = e < M.nldl, ex = ok ? e : 0;
         const int i = M.k_ldl_i[ex], j = M.k_ldl_j[ex];
         t.i[lane][u] = ok ? i : -1; t.j[lane][u] = ok ? j : 0;
         t.arm[lane][u] = (ok && i == j) ? M.dof_armature[i] : 0.f;
@@ -290,7 +294,8 @@ struct StepKernel {
   };
   SMJ_DEV void load(ActTab& t) {
     LANES {
-      const int a = lane < M.nu ? lane : 0;
+      const int ol = opaque(lane);
+      const int a = ol < M.nu ? ol : 0;
       for (int u = 0; u < 4; u++) {
         const int dd = M.k_act_dof[4 * a + u];
         t.dof[lane][u] = lane < M.nu ? dd : -1;
@@ -302,7 +307,7 @@ struct StepKernel {
       t.prm[lane][4] = M.actuator_ctrlrange[2 * a]; t.prm[lane][5] = M.actuator_ctrlrange[2 * a + 1];
       t.prm[lane][6] = M.actuator_forcerange[2 * a]; t.prm[lane][7] = M.actuator_forcerange[2 * a + 1];
       t.flags[lane] = (M.actuator_ctrllimited[a] ? 1 : 0) | (M.actuator_forcelimited[a] ? 2 : 0) | (M.actuator_biastype[a] == 1 ? 4 : 0);
-      const int g = lane < M.ngc ? M.k_gc_body[lane] : 0;
+      const int g = ol < M.ngc ? M.k_gc_body[ol] : 0;
       t.gc_body[lane] = g; t.gc_mass[lane] = lane < M.ngc ? M.body_gcmass[g] : 0.f;
       t.gc_mlo[lane] = M.k_body_dofmask_lo[g]; t.gc_mhi[lane] = M.k_body_dofmask_hi[g];
       t.gc_x[lane] = M.body_gcipos[3 * g]; t.gc_y[lane] = M.body_gcipos[3 * g + 1]; t.gc_z[lane] = M.body_gcipos[3 * g + 2];

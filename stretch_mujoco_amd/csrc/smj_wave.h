@@ -62,6 +62,7 @@ template <int N>
 static inline float wave_bcast16(const PL<float>& x, int lane) { return x.v[(lane & ~15) + N]; }
 static inline int ffs64(uint64_t x) { return __builtin_ffsll((long long)x) - 1; }
 static inline long long smj_clock() { return 0; }
+static inline int opaque(int x) { return x; }
 static inline int uni(int x) { return x; }
 static inline float uni(float x) { return x; }
 static inline float fast_rcp(float x) { return 1.0f / x; }
@@ -122,6 +123,9 @@ __device__ __forceinline__ int wave_read(const PL<int>& x, int l) { return __bui
 __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
 __device__ __forceinline__ int ffs64(uint64_t x) { return __ffsll((long long)x) - 1; }
 __device__ __forceinline__ long long smj_clock() { return (long long)__builtin_readcyclecounter(); }
+// hides a value from the optimiser: table loads indexed through it are not loop invariant, so the stage-local constant
+// tables are re-fetched from L2 in every step instead of being hoisted out of the step loop and kept alive (spilled)
+__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 // uni(): assert to the compiler that a value loaded from memory is wave-uniform (v_readfirstlane -> SGPR), so that
 // loops / branches on it are scalar and readlane selectors need no waterfall loop
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }

@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
-CMD="python bench.py --no-second-solver --no-cpu-baseline"
+CMD="python bench.py --no-second-solver --no-cpu-baseline --no-extra"
 $CMD > gpurun_out/prof/bench_plain.log 2>&1; tail -1 gpurun_out/prof/bench_plain.log | cut -c1-300
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/trace -o smj -- $CMD > gpurun_out/prof/bench_trace.log 2>&1
 rocprofv3 -L > gpurun_out/prof/counters_list.txt 2>&1

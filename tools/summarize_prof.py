@@ -15,7 +15,7 @@ KERNEL = "smj_step_kernel"
 
 def main():
     os.makedirs(DST, exist_ok=True)
-    out = [f"# {TAG}: rocprofv3 evidence for `python bench.py --no-second-solver --no-cpu-baseline` (4096 envs, Newton, 50 steps/launch)\n"]
+    out = [f"# {TAG}: rocprofv3 evidence for `python bench.py --no-second-solver --no-cpu-baseline --no-extra` (4096 envs, Newton, 50 steps/launch)\n"]
     with open(os.path.join(SRC, "trace", "smj_kernel_stats.csv")) as f:
         rows = list(csv.DictReader(f))
     k = [r for r in rows if KERNEL in r["Name"]][0]
