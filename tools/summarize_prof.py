@@ -55,7 +55,9 @@ def main():
                f"(KB counters x 1024, MI355X_MICROARCH.md section HBM).  The guide's x2 FETCH_SIZE correction is calibrated for wide "
                f"coalesced streams; this kernel issues narrow strided loads, so both are given: uncorrected {(fetch+write)/1e6:.1f} MB, "
                f"with x2 on the read side {(2*fetch+write)/1e6:.1f} MB.  Algorithmic bytes per launch (672 B x 4096 envs x 50 steps) = "
-               f"{alg/1e6:.1f} MB: measured traffic is BELOW it because the state stays in LDS for the 50 steps of a launch.")
+               f"{alg/1e6:.1f} MB: measured traffic is " + ("BELOW it because the state stays in LDS for the 50 steps of a launch "
+               "(the writes are mostly per-lane scratch of dynamically indexed arrays)." if 2 * fetch + write < alg else
+               "ABOVE it: register spills / scratch arrays are being written back -- reduce them."))
     wc, busy = vals.get("SQ_WAVE_CYCLES", 0), vals.get("SQ_BUSY_CYCLES", 0)
     if wc:
         out.append(f"\nIssue mix per launch: VALU {vals.get('SQ_INSTS_VALU',0):.3g}, SALU {vals.get('SQ_INSTS_SALU',0):.3g}, LDS {vals.get('SQ_INSTS_LDS',0):.3g}, "
