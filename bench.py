@@ -193,6 +193,7 @@ def main():
         dt = float(tmax.item())
     all_returns = gather_returns(returns)  # RCCL all-gather of per-env returns (the only collective)
     flags = int(sim.info[3].max().item())
+    flagged = float((sim.info[3] != 0).float().mean().item())   # envs in which some step since reset exceeded the 64-row / 16-contact capacity (flags are sticky until reset)
     kern_ms = sum(a.elapsed_time(b) for a, b, _ in events)
     kern_steps = sum(k for _, _, k in events)
     total_env_steps = float(B) * world * args.steps
@@ -219,7 +220,8 @@ def main():
                                    f"(iterations<=100, tol 1e-8), elliptic cones impratio 20, implicitfast, dt=0.002",
                        "solver": args.solver,
                        "envs_per_gpu": B, "steps_per_launch": hold, "parallelism": f"env-sharded x{world}",
-                       "returns_gathered": int(all_returns.numel()), "overflow_flags": flags},
+                       "returns_gathered": int(all_returns.numel()), "overflow_flags": flags,
+                       "envs_over_capacity_since_reset": flagged},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "all_launches": {"count": len(all_ms), "avg_ms": sum(all_ms) / len(all_ms), "ms": [round(x, 2) for x in all_ms],
