@@ -73,6 +73,7 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
   if (m.nldl > 5 * 64) { err = "mass-matrix sparsity pattern too large"; return -4; }
   if (m.neq + m.nfric > NEFC) { err = "too many static constraint rows"; return -4; }
   if (2 * m.nlimit > 64) { err = "too many limited joints"; return -4; }
+  if (m.ngc > 16) { err = "more than 16 gravity-compensated bodies"; return -4; }
   if (m.njump > 6) { err = "body tree deeper than 64 levels"; return -4; }
   if (m.ncgeom > NCG) { err = "too many geoms in non-plane collision pairs"; return -4; }
 #define X(n)                                                                               \

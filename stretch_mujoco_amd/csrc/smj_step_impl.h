@@ -695,9 +695,7 @@ struct StepKernel {
     PL<float> frc_passive, frc_bias, frc_act;
     DofTab dt;
     ActTab at;
-    PL<uint64_t> b_dofmask;
     load(dt); load(at);
-    LANES { const int b = lane < nb ? lane : 0; b_dofmask[lane] = mk64(M.k_body_dofmask_lo[b], M.k_body_dofmask_hi[b]); }
     // passive: damper + spring
     LANES {
       float f = 0;
@@ -707,55 +705,122 @@ struct StepKernel {
       }
       frc_passive[lane] = f;
     }
-    // gravity compensation  [MJ] mj_passive gravcomp: F = -g*m*gravcomp at the body's gravcomp point
-    for (int t = 0; t < M.ngc; t++) {
-      const int b = wave_read(at.gc_body, t);
-      const float gm = wave_read(at.gc_mass, t);
-      float pt[3];
-      const float lp[3] = {wave_read(at.gc_x, t), wave_read(at.gc_y, t), wave_read(at.gc_z, t)};
-      mulmat3vec(pt, s.xmat[b], lp);
-      float off[3] = {pt[0] + s.xpos[b][0] - s.com[b][0], pt[1] + s.xpos[b][1] - s.com[b][1], pt[2] + s.xpos[b][2] - s.com[b][2]};
-      const float F[3] = {-M.gravity[0] * gm, -M.gravity[1] * gm, -M.gravity[2] * gm};
-      const uint64_t mk = mk64(wave_read(at.gc_mlo, t), wave_read(at.gc_mhi, t));
-      LANES {
-        if ((mk >> lane) & 1) {
-          float tv[3];
-          cross3(tv, cdof[lane], off);
-          frc_passive[lane] += (cdof[lane][3] + tv[0]) * F[0] + (cdof[lane][4] + tv[1]) * F[1] + (cdof[lane][5] + tv[2]) * F[2];
-        }
-      }
-    }
-    // RNE bias: cacc (no qacc) per body, body force, subtree sum projected on cdof  [MJ] mj_rne(flg_acc=0)
+    // gravity compensation  [MJ] mj_passive gravcomp: F = -g*m*gravcomp at the body's gravcomp point.  Lane = gravcomp slot
+    // stages (offset from the subtree com, force, dof mask) in LDS; then every dof lane runs a fixed 16-slot loop.
+    BodyTab bt;
+    load(bt);
     LANES {
-      if (lane > 0 && lane < nb) {
-        const int b = lane;
-        float a[6] = {0, 0, 0, -M.gravity[0], -M.gravity[1], -M.gravity[2]};
-        uint64_t mk = b_dofmask[lane];
-        while (mk) {
-          const int d = ffs64(mk);
-          mk &= mk - 1;
-          const float qv = s.qvel[d];
-          for (int x = 0; x < 6; x++) a[x] += s.u.t.cdof_dot[d][x] * qv;
+      if (lane < 16) {
+        float off[3] = {0, 0, 0}, F[3] = {0, 0, 0};
+        int mlo = 0, mhi = 0;
+        if (lane < M.ngc) {
+          const int b = at.gc_body[lane];
+          const float gm = at.gc_mass[lane];
+          const float lp[3] = {at.gc_x[lane], at.gc_y[lane], at.gc_z[lane]};
+          float pt[3];
+          mulmat3vec(pt, s.xmat[b], lp);
+          for (int k = 0; k < 3; k++) { off[k] = pt[k] + s.xpos[b][k] - s.com[b][k]; F[k] = -M.gravity[k] * gm; }
+          mlo = at.gc_mlo[lane]; mhi = at.gc_mhi[lane];
         }
-        float t1[6], t2[6], cf[6];
-        mul_inert_vec(t1, s.u.t.cinert[b], a);
-        mul_inert_vec(t2, s.u.t.cinert[b], s.u.t.cvel[b]);
-        cross_force(cf, s.u.t.cvel[b], t2);
-        for (int x = 0; x < 6; x++) s.u.t.cfrc[b][x] = t1[x] + cf[x];
+        float* o = s.u.t.buf[lane];     // buf[slot] = off, F ; cfrc is free until the RNE pass below
+        for (int k = 0; k < 3; k++) { o[k] = off[k]; o[3 + k] = F[k]; }
+        s.u.t.cfrc[lane][0] = __builtin_bit_cast(float, mlo); s.u.t.cfrc[lane][1] = __builtin_bit_cast(float, mhi);
       }
     }
     SYNC();
     LANES {
-      float v = 0;
       if (lane < nv) {
-        const int b = dt.body[lane];
-        float cf[6] = {0, 0, 0, 0, 0, 0};
-        const int n = dt.bsub[lane];
-        for (int x = b; x < b + n; x++)
-          for (int k = 0; k < 6; k++) cf[k] += s.u.t.cfrc[x][k];
-        for (int k = 0; k < 6; k++) v += cdof[lane][k] * cf[k];
+        float acc = 0;
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+          const uint64_t mk = mk64(__builtin_bit_cast(int, s.u.t.cfrc[t][0]), __builtin_bit_cast(int, s.u.t.cfrc[t][1]));
+          const float* o = s.u.t.buf[t];
+          float tv[3];
+          cross3(tv, cdof[lane], o);
+          const float v = (cdof[lane][3] + tv[0]) * o[3] + (cdof[lane][4] + tv[1]) * o[4] + (cdof[lane][5] + tv[2]) * o[5];
+          acc += ((mk >> lane) & 1) ? v : 0.f;
+        }
+        frc_passive[lane] += acc;
       }
-      frc_bias[lane] = v;
+    }
+    SYNC();
+    // RNE bias: cacc (no qacc) per body = gravity + sum over the dofs on the path of cdof_dot*qvel (own-body sums, then
+    // pointer jumping up the tree), body force, subtree sum projected on cdof  [MJ] mj_rne(flg_acc=0)
+    LANES {
+      if (lane < nv)
+        for (int x = 0; x < 6; x++) s.u.t.buf[lane][x] = s.u.t.cdof_dot[lane][x] * s.qvel[lane];
+    }
+    SYNC();
+    PL<float[6]> ca;
+    LANES {
+      float sv[6] = {0, 0, 0, 0, 0, 0};
+      if (lane > 0 && lane < nb) {
+        const int da = bt.dofadr[lane], dn = bt.dofnum[lane];
+#pragma unroll
+        for (int u = 0; u < 6; u++) {
+          const float on = u < dn ? 1.f : 0.f;
+          const int a = dn > 0 ? da + (u < dn ? u : 0) : 0;
+          for (int x = 0; x < 6; x++) sv[x] += on * s.u.t.buf[a][x];
+        }
+      }
+      for (int x = 0; x < 6; x++) { ca[lane][x] = sv[x]; if (lane < NBP) s.u.t.cfrc[lane][x] = sv[x]; }
+    }
+    SYNC();
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      if (r >= M.njump) break;
+      PL<float[6]> up;
+      PL<int> anc;
+      LANES {
+        const int a = bt.jump[lane][r];
+        anc[lane] = a;
+        for (int x = 0; x < 6; x++) up[lane][x] = s.u.t.cfrc[a][x];
+      }
+      SYNC();
+      LANES {
+        if (anc[lane] > 0)
+          for (int x = 0; x < 6; x++) { ca[lane][x] += up[lane][x]; s.u.t.cfrc[lane][x] = ca[lane][x]; }
+      }
+      SYNC();
+    }
+    LANES {
+      if (lane < nb) {
+        const int b = lane;
+        float t1[6] = {0, 0, 0, 0, 0, 0}, cf[6] = {0, 0, 0, 0, 0, 0};
+        if (b > 0) {
+          const float a[6] = {ca[lane][0], ca[lane][1], ca[lane][2], ca[lane][3] - M.gravity[0], ca[lane][4] - M.gravity[1], ca[lane][5] - M.gravity[2]};
+          float t2[6];
+          mul_inert_vec(t1, s.u.t.cinert[b], a);
+          mul_inert_vec(t2, s.u.t.cinert[b], s.u.t.cvel[b]);
+          cross_force(cf, s.u.t.cvel[b], t2);
+        }
+        for (int x = 0; x < 6; x++) s.u.t.cfrc[b][x] = t1[x] + cf[x];
+      }
+    }
+    SYNC();
+    {
+      PL<float[6]> cfs;
+      LANES { for (int k = 0; k < 6; k++) cfs[lane][k] = 0.f; }
+      for (int x0 = 0; x0 < M.maxsubtree; x0 += 4) {   // subtree sums over the contiguous DFS range, four bodies per pass
+        LANES {
+          if (lane < nv) {
+            const int b = dt.body[lane], sub = dt.bsub[lane];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const bool in = x0 + u < sub;
+              const int x = b + (in ? x0 + u : 0);
+              const float on = in ? 1.f : 0.f;
+              for (int k = 0; k < 6; k++) cfs[lane][k] += on * s.u.t.cfrc[x][k];
+            }
+          }
+        }
+      }
+      LANES {
+        float v = 0;
+        if (lane < nv)
+          for (int k = 0; k < 6; k++) v += cdof[lane][k] * cfs[lane][k];
+        frc_bias[lane] = v;
+      }
     }
     // actuation  [MJ] mj_fwdActuation (static moments: joint / fixed-tendon transmissions), constants lane-resident
     LANES {
