@@ -39,6 +39,9 @@ struct Smem {
       int cnt[64], pair[64];
       float dist[64][4], pos[64][4][3], nrm[64][3];
     } p;
+    struct {                // constraint assembly: per-contact body dof masks gathered lane-parallel before the row loop
+      int m1lo[NCON], m1hi[NCON], m2lo[NCON], m2hi[NCON], b1[NCON], b2[NCON];
+    } k;
     struct {                // Newton: XA = W J (row-weighted Jacobian) and the Hessian H = M + J' W J / its factor
       float XA[NEFC][JS];
       float H[NVP][NVP + 1];
@@ -1538,14 +1541,56 @@ struct StepKernel {
     row0 += popc64(lm);
     if (row0 > NEFC) { row0 = NEFC; flags |= SMJ_FLAG_EFC_OVERFLOW; }
     SYNC();
-    // contact rows: lanes = dofs fill the Jacobian columns
+    // contact rows.  Phase 1, lane = contact: everything that needs model tables (body ids, dof masks, diagonal
+    // approximations) is gathered at once instead of per contact in the serial loop below; rows are assigned in contact
+    // order (a contact that does not fit is skipped and flagged, later smaller ones may still fit -- as before).
+    PL<int> cact, cdimv, crow;
+    PL<float> ctran, crot;
+    LANES {
+      int act = 0, dim = 0;
+      float tran = 0, rot = 0;
+      if (lane < ncon) {
+        const int c = lane;
+        dim = s.cdim[c];
+        act = s.cdist[c] < s.cmargin[c];
+        const int g1 = s.cgeom1[c], g2 = s.cgeom2[c], b1 = M.geom_bodyid[g1], b2 = M.geom_bodyid[g2];
+        s.u.k.b1[c] = b1; s.u.k.b2[c] = b2;
+        s.u.k.m1lo[c] = M.k_body_dofmask_lo[b1]; s.u.k.m1hi[c] = M.k_body_dofmask_hi[b1];
+        s.u.k.m2lo[c] = M.k_body_dofmask_lo[b2]; s.u.k.m2hi[c] = M.k_body_dofmask_hi[b2];
+        tran = M.geom_invweight0[2 * g1] + M.geom_invweight0[2 * g2];
+        rot = M.geom_invweight0[2 * g1 + 1] + M.geom_invweight0[2 * g2 + 1];
+      }
+      cact[lane] = act; cdimv[lane] = dim; ctran[lane] = tran; crot[lane] = rot; crow[lane] = -1;
+    }
     for (int c = 0; c < ncon; c++) {
-      const int dim = uni(s.cdim[c]);
-      if (!(uni(s.cdist[c]) < uni(s.cmargin[c]))) continue;
-      if (row0 + dim > NEFC) { flags |= SMJ_FLAG_EFC_OVERFLOW; continue; }
-      const int g1 = uni(s.cgeom1[c]), g2 = uni(s.cgeom2[c]), b1 = uni(M.geom_bodyid[g1]), b2 = uni(M.geom_bodyid[g2]);
-      const uint64_t m1 = mk64(M.k_body_dofmask_lo[b1], M.k_body_dofmask_hi[b1]), m2 = mk64(M.k_body_dofmask_lo[b2], M.k_body_dofmask_hi[b2]);
-      const float tran = M.geom_invweight0[2 * g1] + M.geom_invweight0[2 * g2], rot = M.geom_invweight0[2 * g1 + 1] + M.geom_invweight0[2 * g2 + 1];
+      const int d = wave_read(cdimv, c);
+      if (!wave_read(cact, c)) continue;
+      if (row0 + d > NEFC) { flags |= SMJ_FLAG_EFC_OVERFLOW; continue; }
+      LANES { if (lane == c) crow[lane] = row0; }
+      row0 += d;
+    }
+    LANES {
+      if (lane < ncon) {
+        const int c = lane, r0 = crow[lane], dim = cdimv[lane];
+        s.cefc[c] = r0;
+        if (r0 >= 0) {
+#pragma unroll
+          for (int r = 0; r < 6; r++)
+            if (r < dim) {
+              s.etype[r0 + r] = dim == 1 ? CT_CONTACT_FRICTIONLESS : CT_CONTACT_ELLIPTIC;
+              s.eid[r0 + r] = c; s.epos[r0 + r] = s.cdist[c]; s.emargin[r0 + r] = s.cmargin[c];
+              s.ediag[r0 + r] = r < 3 ? ctran[lane] : crot[lane];
+            }
+        }
+      }
+    }
+    SYNC();
+    // Phase 2, lanes = dofs fill the Jacobian columns; per contact only LDS is read
+    for (int c = 0; c < ncon; c++) {
+      const int r0 = uni(s.cefc[c]);
+      if (r0 < 0) continue;
+      const int dim = uni(s.cdim[c]), b1 = uni(s.u.k.b1[c]), b2 = uni(s.u.k.b2[c]);
+      const uint64_t m1 = mk64(uni(s.u.k.m1lo[c]), uni(s.u.k.m1hi[c])), m2 = mk64(uni(s.u.k.m2lo[c]), uni(s.u.k.m2hi[c]));
       LANES {
         if (lane < nv) {
           const float sg = (float)((int)((m2 >> lane) & 1) - (int)((m1 >> lane) & 1));
@@ -1556,20 +1601,16 @@ struct StepKernel {
             float tv[3];
             cross3(tv, cdof[lane], off);
             const float jp[3] = {cdof[lane][3] + tv[0], cdof[lane][4] + tv[1], cdof[lane][5] + tv[2]};
-            for (int r = 0; r < dim; r++) {
-              const float* ax = s.cframe[c] + 3 * (r < 3 ? r : r - 3);
-              s.J[row0 + r][lane] = sg * (r < 3 ? dot3(ax, jp) : dot3(ax, cdof[lane]));
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+              if (r < dim) {
+                const float* ax = s.cframe[c] + 3 * (r < 3 ? r : r - 3);
+                s.J[r0 + r][lane] = sg * (r < 3 ? dot3(ax, jp) : dot3(ax, cdof[lane]));
+              }
             }
           }
         }
-        if (lane < dim) {
-          const int r = row0 + lane;
-          s.etype[r] = dim == 1 ? CT_CONTACT_FRICTIONLESS : CT_CONTACT_ELLIPTIC;
-          s.eid[r] = c; s.epos[r] = s.cdist[c]; s.emargin[r] = s.cmargin[c]; s.ediag[r] = lane < 3 ? tran : rot;
-        }
-        if (lane == 0) s.cefc[c] = row0;
       }
-      row0 += dim;
     }
     nefc = row0;
     SYNC();
