@@ -41,6 +41,7 @@ struct Smem {
     } p;
     struct {                // constraint assembly: per-contact body dof masks gathered lane-parallel before the row loop
       int m1lo[NCON], m1hi[NCON], m2lo[NCON], m2hi[NCON], b1[NCON], b2[NCON];
+      float cd[NVP][6];     // cdof, so that both half-waves of the Jacobian fill can read any dof's motion axis
     } k;
     struct {                // Newton: XA = W J (row-weighted Jacobian) and the Hessian H = M + J' W J / its factor
       float XA[NEFC][JS];
@@ -1561,6 +1562,8 @@ struct StepKernel {
         rot = M.geom_invweight0[2 * g1 + 1] + M.geom_invweight0[2 * g2 + 1];
       }
       cact[lane] = act; cdimv[lane] = dim; ctran[lane] = tran; crot[lane] = rot; crow[lane] = -1;
+      if (lane < NVP)
+        for (int x = 0; x < 6; x++) s.u.k.cd[lane][x] = lane < nv ? cdof[lane][x] : 0.f;
     }
     for (int c = 0; c < ncon; c++) {
       const int d = wave_read(cdimv, c);
@@ -1585,27 +1588,31 @@ struct StepKernel {
       }
     }
     SYNC();
-    // Phase 2, lanes = dofs fill the Jacobian columns; per contact only LDS is read
-    for (int c = 0; c < ncon; c++) {
-      const int r0 = uni(s.cefc[c]);
-      if (r0 < 0) continue;
-      const int dim = uni(s.cdim[c]), b1 = uni(s.u.k.b1[c]), b2 = uni(s.u.k.b2[c]);
-      const uint64_t m1 = mk64(uni(s.u.k.m1lo[c]), uni(s.u.k.m1hi[c])), m2 = mk64(uni(s.u.k.m2lo[c]), uni(s.u.k.m2hi[c]));
+    // Phase 2, lanes = dofs fill the Jacobian columns; per contact only LDS is read.  Two contacts per pass: lanes 0-31
+    // take contact c0, lanes 32-63 contact c0 + 1.
+    for (int c0 = 0; c0 < ncon; c0 += 2) {
       LANES {
-        if (lane < nv) {
-          const float sg = (float)((int)((m2 >> lane) & 1) - (int)((m1 >> lane) & 1));
-          if (sg != 0.f) {
-            // both bodies hang off the same tree root here (or one is the world): offsets relative to that root's com
-            const int bb = ((m2 >> lane) & 1) ? b2 : b1;
-            const float off[3] = {s.cpos[c][0] - s.com[bb][0], s.cpos[c][1] - s.com[bb][1], s.cpos[c][2] - s.com[bb][2]};
-            float tv[3];
-            cross3(tv, cdof[lane], off);
-            const float jp[3] = {cdof[lane][3] + tv[0], cdof[lane][4] + tv[1], cdof[lane][5] + tv[2]};
+        const int c = c0 + (lane >> 5), d = lane & 31;
+        if (c < ncon && d < nv) {
+          const int r0 = s.cefc[c];
+          if (r0 >= 0) {
+            const int dim = s.cdim[c], b1 = s.u.k.b1[c], b2 = s.u.k.b2[c];
+            const uint64_t m1 = mk64(s.u.k.m1lo[c], s.u.k.m1hi[c]), m2 = mk64(s.u.k.m2lo[c], s.u.k.m2hi[c]);
+            const float sg = (float)((int)((m2 >> d) & 1) - (int)((m1 >> d) & 1));
+            if (sg != 0.f) {
+              // both bodies hang off the same tree root here (or one is the world): offsets relative to that root's com
+              const int bb = ((m2 >> d) & 1) ? b2 : b1;
+              const float off[3] = {s.cpos[c][0] - s.com[bb][0], s.cpos[c][1] - s.com[bb][1], s.cpos[c][2] - s.com[bb][2]};
+              float cd[6], tv[3];
+              for (int x = 0; x < 6; x++) cd[x] = s.u.k.cd[d][x];
+              cross3(tv, cd, off);
+              const float jp[3] = {cd[3] + tv[0], cd[4] + tv[1], cd[5] + tv[2]};
 #pragma unroll
-            for (int r = 0; r < 6; r++) {
-              if (r < dim) {
-                const float* ax = s.cframe[c] + 3 * (r < 3 ? r : r - 3);
-                s.J[r0 + r][lane] = sg * (r < 3 ? dot3(ax, jp) : dot3(ax, cdof[lane]));
+              for (int r = 0; r < 6; r++) {
+                if (r < dim) {
+                  const float* ax = s.cframe[c] + 3 * (r < 3 ? r : r - 3);
+                  s.J[r0 + r][d] = sg * (r < 3 ? dot3(ax, jp) : dot3(ax, cd));
+                }
               }
             }
           }
