@@ -2161,19 +2161,19 @@ struct StepKernel {
   // itself.  Eliminating above AND below the pivot costs the same n^2/2 (v_readlane, v_fma) pairs as the Cholesky update,
   // all of them independent within a column step, and leaves the solution in x with no substitution and no LDS traffic.
   // Pivots of an SPD matrix stay positive; no pivoting (same as the Cholesky it replaces).
-  template <int K, int J>
+  template <int K, int J, int N>
   SMJ_DEV void gj_pair(PL<float[NVP]>& hrow, const PL<float>& mult) {
-    if constexpr (J < NVP) {
+    if constexpr (J < N) {
       PL<float> cj;
       LANES { cj[lane] = hrow[lane][J]; }
       const float hkj = wave_read(cj, K);              // pivot-row entry H[K][J]
       LANES { hrow[lane][J] -= mult[lane] * hkj; }
-      gj_pair<K, J + 1>(hrow, mult);
+      gj_pair<K, J + 1, N>(hrow, mult);
     }
   }
-  template <int K>
+  template <int K, int N>
   SMJ_DEV void gj_cols(PL<float[NVP]>& hrow, PL<float>& x, PL<float>& pinv) {
-    if constexpr (K < NVP) {
+    if constexpr (K < N) {
       PL<float> col, mult;
       LANES { col[lane] = hrow[lane][K]; }
       const float rp = fast_rcp(fmaxf(wave_read(col, K), 1e-30f));
@@ -2181,24 +2181,30 @@ struct StepKernel {
         mult[lane] = lane == K ? 0.f : col[lane] * rp;   // the pivot row itself is left alone; its scale is applied at the end
         if (lane == K) pinv[lane] = rp;
       }
-      gj_pair<K, K + 1>(hrow, mult);
+      gj_pair<K, K + 1, N>(hrow, mult);
       const float xk = wave_read(x, K);
       LANES { x[lane] -= mult[lane] * xk; }
-      gj_cols<K + 1>(hrow, x, pinv);
+      gj_cols<K + 1, N>(hrow, x, pinv);
     }
   }
-  SMJ_DEV void chol_solve_H(PL<float>& x) {
+  // N = matrix order actually eliminated (rows / columns >= nv are identity padding and never touched)
+  template <int N>
+  SMJ_DEV void gj_solve(PL<float>& x) {
     PL<float[NVP]> hrow;
     PL<float> pinv;
     LANES {
-      const int i = lane < NVP ? lane : 0;
+      const int i = lane < N ? lane : 0;
 #pragma unroll
-      for (int k = 0; k < NVP; k++) hrow[lane][k] = (lane < NVP) ? s.u.n.H[i][k] : 0.f;
+      for (int k = 0; k < N; k++) hrow[lane][k] = (lane < N) ? s.u.n.H[i][k] : 0.f;
       pinv[lane] = 0.f;
-      if (lane >= NVP) x[lane] = 0.f;
+      if (lane >= N) x[lane] = 0.f;
     }
-    gj_cols<0>(hrow, x, pinv);
+    gj_cols<0, N>(hrow, x, pinv);
     LANES { x[lane] *= pinv[lane]; }
+  }
+  SMJ_DEV void chol_solve_H(PL<float>& x) {
+    if (M.nv <= 28) gj_solve<28>(x);   // Stretch: 26 dofs; a quarter fewer column pairs than the full 32
+    else gj_solve<NVP>(x);
   }
 
   // cost and derivatives along the search line  ([MJ] CGeval); lanes = rows, three wave reductions
