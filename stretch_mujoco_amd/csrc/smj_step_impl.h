@@ -2319,26 +2319,40 @@ struct StepKernel {
       const float gnorm = sqrtf(wave_sum(g2));
       if (iter > 0 && scale * gnorm < M.tolerance) break;
       TICK(SMJ_PROF_N_GRAD)
-      // XA = W J, lane = row: quadratic rows D*J, satisfied / linear rows 0, rows of a contact in the cone (middle) zone
-      // (Hc Jc)[row] = sum_q Hc[row][q] * J[first row + q][:]  -- all cone rows at once instead of a loop over contacts
+      // XA = W J.  Quadratic rows D*J, satisfied / linear rows 0 (lane = row).  Rows of a contact in the cone (middle) zone:
+      // (Hc Jc) with lanes = dofs, two contacts per pass (half-waves), the 6x6 block zero-padded so that every loop has a
+      // fixed trip count and the LDS reads issue back to back.
       LANES {
-        if (lane < ne && nr.state[lane] == 4) {
-          const int c = s.eid[lane], r0 = s.cefc[c], dim = s.cdim[c], rr = lane - r0;
-          float h[6];
-          int rq[6];
-#pragma unroll
-          for (int q = 0; q < 6; q++) { h[q] = q < dim ? s.u.n.cH[c][rr * dim + q] : 0.f; rq[q] = r0 + (q < dim ? q : 0); }
-#pragma unroll 8
-          for (int k = 0; k < NVP; k++) {   // fixed trip counts (zero-padded block) so that the LDS reads are issued back to back
-            float v = 0;
-#pragma unroll
-            for (int q = 0; q < 6; q++) v += h[q] * s.J[rq[q]][k];
-            s.u.n.XA[lane][k] = v;
-          }
-        } else {
+        if (!(lane < ne && nr.state[lane] == 4)) {
           const float w = (lane < ne && nr.state[lane] == 1) ? nr.D[lane] : 0.f;
 #pragma unroll
           for (int k = 0; k < NVP; k++) s.u.n.XA[lane][k] = w * s.J[lane][k];
+        }
+      }
+      PL<int> conerow;
+      LANES { conerow[lane] = lane < ne && nr.state[lane] == 4; }
+      const bool anycone = wave_ballot(conerow) != 0;
+      for (int c0 = 0; anycone && c0 < ncon; c0 += 2) {
+        LANES {
+          const int c = c0 + (lane >> 5), k = lane & 31;
+          const int r0 = c < ncon ? s.cefc[c] : -1;
+          if (r0 >= 0 && (int)s.earef[r0] == 4) {   // block state as broadcast by newton_update
+            const int dim = s.cdim[c];
+            float j[6], h[36];
+#pragma unroll
+            for (int q = 0; q < 6; q++) j[q] = s.J[r0 + (q < dim ? q : 0)][k];
+#pragma unroll
+            for (int rr = 0; rr < 6; rr++)
+#pragma unroll
+              for (int q = 0; q < 6; q++) h[6 * rr + q] = (rr < dim && q < dim) ? s.u.n.cH[c][(rr < dim ? rr : 0) * dim + (q < dim ? q : 0)] : 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 6; rr++) {
+              float v = 0;
+#pragma unroll
+              for (int q = 0; q < 6; q++) v += h[6 * rr + q] * j[q];
+              if (rr < dim) s.u.n.XA[r0 + rr][k] = v;
+            }
+          }
         }
       }
       SYNC();
