@@ -23,7 +23,11 @@ struct smj_ctx {
   float* qpos0_dev = nullptr;
   DevRender render{};
   bool has_render = false;
-  float* pose_ws = nullptr;   // internal [nbody*12][num_envs] body poses when the caller has not bound SMJ_SLOT_XPOSE
+  float* pose_ws = nullptr;
+  // camera-static depth layers: geoms welded to a camera's body always look the same from that camera, so they are
+  // rendered once per (camera, image size, field of view) and every later render starts its rays from that layer
+  struct Layer { int cam = -1, w = 0, h = 0; float fovy = 0; float* buf = nullptr; };
+  std::vector<Layer> layers;   // internal [nbody*12][num_envs] body poses when the caller has not bound SMJ_SLOT_XPOSE
   void* slot_ptr[SMJ_SLOT_COUNT] = {};
   long slot_ld[SMJ_SLOT_COUNT] = {};
 };
@@ -284,8 +288,24 @@ int smj_render_depth(smj_ctx* c, int cam, int width, int height, float fovy_deg,
   if (!out_dev) return fail(c, -1, "null output image");
   if (!c->state.xpose) return fail(c, -5, "XPOSE slot is not bound (step with SMJ_READ_POSES first)");
   HIPCHK(c, hipSetDevice(c->device));
+  smj_ctx::Layer* L = nullptr;
+  for (auto& l : c->layers)
+    if (l.cam == cam && l.w == width && l.h == height && l.fovy == fovy_deg) L = &l;
+  if (!L) {
+    smj_ctx::Layer l;
+    l.cam = cam; l.w = width; l.h = height; l.fovy = fovy_deg;
+    void* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, sizeof(float) * (size_t)width * (size_t)height));
+    c->allocs.push_back(d);
+    l.buf = (float*)d;
+    smj_launch_depth(c->render, c->state.xpose, c->slot_ld[SMJ_SLOT_XPOSE], c->num_envs, cam, width, height, fovy_deg, 0.f, l.buf,
+                     nullptr, 1, (hipStream_t)stream);
+    HIPCHK(c, hipGetLastError());
+    c->layers.push_back(l);
+    L = &c->layers.back();
+  }
   smj_launch_depth(c->render, c->state.xpose, c->slot_ld[SMJ_SLOT_XPOSE], c->num_envs, cam, width, height, fovy_deg, max_depth,
-                   (float*)out_dev, (hipStream_t)stream);
+                   (float*)out_dev, L->buf, 2, (hipStream_t)stream);
   HIPCHK(c, hipGetLastError());
   return 0;
 }

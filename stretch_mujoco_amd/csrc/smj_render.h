@@ -34,8 +34,11 @@ struct DevRender {
   const float* lidar_static;       // [nlidar] distance to the geoms welded to the laser (ray-cast by the model compiler), -1 none
 };
 
-// xpose: [nbody*12][ld] batch-major body poses (xpos 3 + xmat 9) written by the step kernel (SMJ_READ_POSES)
 // lidar: [nlidar][ld] batch-major ranges, -1 = no hit, clipped to the sensor cutoff
 void smj_launch_lidar(const DevRender& r, const float* xpose, long ld, int num_envs, float* lidar, long lidar_ld, hipStream_t stream);
+// xpose: [nbody*12][ld] batch-major body poses (xpos 3 + xmat 9) written by the step kernel (SMJ_READ_POSES).
+// mode 0: everything.  mode 1: render only the geoms rigidly attached to the camera's body, for env 0, raw depth into
+// out[height][width] (the camera-static layer: it does not depend on the state).  mode 2: skip those geoms and start every
+// ray from layer[height][width].
 void smj_launch_depth(const DevRender& r, const float* xpose, long ld, int num_envs, int cam, int width, int height,
-                      float fovy_deg, float max_depth, float* out, hipStream_t stream);
+                      float fovy_deg, float max_depth, float* out, const float* layer, int mode, hipStream_t stream);

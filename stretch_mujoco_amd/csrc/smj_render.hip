@@ -308,11 +308,14 @@ __global__ __launch_bounds__(384) void smj_lidar_kernel(const DevRender R, const
   }
 }
 
+// mode 0: all visible geoms.  mode 1: only the geoms rigidly attached to the camera's body, raw depth (one env) -- the
+// camera-static layer.  mode 2: all other geoms, every ray starting from the static layer's depth.
 __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const float* __restrict__ xpose, long ld, int cam, int width,
-                                                        int height, float tan_half_fovy, float max_depth, float* __restrict__ out) {
+                                                        int height, float tan_half_fovy, float max_depth, float* __restrict__ out,
+                                                        const float* __restrict__ layer, int mode) {
   __shared__ RGeom geoms[SMJ_RGEOM_MAX];
   __shared__ float cpos[3], cmat[9], gkey[SMJ_RGEOM_MAX];
-  __shared__ int gorder[SMJ_RGEOM_MAX];
+  __shared__ int gorder[SMJ_RGEOM_MAX], nkeep;
   const int env = blockIdx.y;
   const int tiles_x = (width + 15) / 16;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
@@ -352,25 +355,63 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
       for (int j = 0; j < 3; j++) cmat[3 * i + j] = bm[3 * i] * lm[j] + bm[3 * i + 1] * lm[3 + j] + bm[3 * i + 2] * lm[6 + j];
   }
   __syncthreads();
-  // front-to-back geom order for the whole tile (rank sort on the distance from the camera to the bounding sphere): the
-  // nearest hit is found early and the bounding-sphere reject below then drops most of what lies behind it
+  // Per-tile geom list.  Keep only the geoms whose bounding sphere can meet the cone of rays of this 16x16 tile within the
+  // depth range -- the per-ray loop over ALL visible geoms was the instruction-count floor of the kernel (74 sphere
+  // rejects per ray) -- and order them front to back (rank sort on the distance from the camera to the sphere): the nearest
+  // hit is found early and the per-ray reject then drops most of what lies behind it.
+  const float aspect = (float)width / (float)height;
+  const float tfar = (max_depth > 0.f && max_depth < R.zfar) ? max_depth : R.zfar;   // hits beyond the limit become 0 anyway
   if (tid < R.nrgeom) {
     const RGeom& G = geoms[tid];
     const float dc[3] = {G.cen[0] - cpos[0], G.cen[1] - cpos[1], G.cen[2] - cpos[2]};
-    gkey[tid] = G.type == RT_PLANE ? -1.f : sqrtf(dot3(dc, dc)) - G.rbound;
+    const float dist = sqrtf(dot3(dc, dc)), r = G.rbound;
+    float key = -1.f;
+    if (G.type != RT_PLANE) {
+      key = dist - r;
+      if (dist > r) {
+        // tile cone: axis through the tile centre, half angle alpha to the farthest tile corner (camera frame, -z forward)
+        const float xc = ((tx * 16 + 8.f) / width * 2.f - 1.f) * tan_half_fovy * aspect, yc = (1.f - (ty * 16 + 8.f) / height * 2.f) * tan_half_fovy;
+        const float hx = 16.f / width * tan_half_fovy * aspect, hy = 16.f / height * tan_half_fovy;   // half tile size at z = -1
+        const float cl = sqrtf(xc * xc + yc * yc + 1.f);
+        float cosa = 1.f, dlmax = 0.f;
+        for (int k = 0; k < 4; k++) {
+          const float x = xc + ((k & 1) ? hx : -hx), y = yc + ((k & 2) ? hy : -hy);
+          const float l = sqrtf(x * x + y * y + 1.f);
+          cosa = fminf(cosa, (x * xc + y * yc + 1.f) / (l * cl));
+          dlmax = fmaxf(dlmax, l);
+        }
+        const float sina = sqrtf(fmaxf(0.f, 1.f - cosa * cosa));
+        const float ac[3] = {xc / cl, yc / cl, -1.f / cl};
+        float aw[3];
+        mul(aw, cmat, ac);   // cone axis in the world
+        const float sinb = r / dist, cosb = sqrtf(fmaxf(0.f, 1.f - sinb * sinb));   // beta: angular radius of the sphere
+        const float cosab = cosa * cosb - sina * sinb;      // cos(alpha + beta), alpha + beta < pi
+        const float cost = dot3(dc, aw) / dist;             // angle between the cone axis and the sphere centre
+        if (cost < cosab - 1e-4f) key = 3.0e38f;            // outside the cone widened by the sphere
+        if (dist - r > tfar * dlmax) key = 3.0e38f;         // beyond the depth range for every ray of the tile
+      }
+    }
+    if (mode != 0) {
+      const bool attached = R.geom_bodyid[R.rgeom[tid]] == R.cam_bodyid[cam];
+      if (attached != (mode == 1)) key = 3.0e38f;
+    }
+    gkey[tid] = key;
   }
   __syncthreads();
   if (tid < R.nrgeom) {
     const float key = gkey[tid];
-    int rank = 0;
-    for (int j = 0; j < R.nrgeom; j++) rank += (gkey[j] < key) || (gkey[j] == key && j < tid);
+    int rank = 0, kept = 0;
+    for (int j = 0; j < R.nrgeom; j++) {
+      rank += (gkey[j] < key) || (gkey[j] == key && j < tid);
+      kept += gkey[j] < 1.0e38f;
+    }
     gorder[rank] = tid;
+    if (tid == 0) nkeep = kept;
   }
   __syncthreads();
   const int u = tx * 16 + (tid & 15), v = ty * 16 + (tid >> 4);
   if (u >= width || v >= height) return;
   // pixel centre -> ray in the camera frame (x right, y up, looking down -z); parameter t = distance along the optical axis
-  const float aspect = (float)width / (float)height;
   const float xn = ((u + 0.5f) / width * 2.f - 1.f) * tan_half_fovy * aspect;
   const float yn = (1.f - (v + 0.5f) / height * 2.f) * tan_half_fovy;
   const float dc[3] = {xn, yn, -1.f};
@@ -378,9 +419,9 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
   mul(d, cmat, dc);
   const float dd = dot3(d, d), dl = sqrtf(dd);
   const float tnear = R.znear;
-  const float tfar = (max_depth > 0.f && max_depth < R.zfar) ? max_depth : R.zfar;   // hits beyond the limit become 0 anyway
   float best = tfar * (1.f + 1e-6f);
-  const int ng = R.nrgeom;
+  if (mode == 2) best = fminf(best, layer[(long)v * width + u]);
+  const int ng = nkeep;
   for (int i = 0; i < ng; i++) {
     const RGeom& G = geoms[gorder[i]];
     if (G.type != RT_PLANE) {   // bounding sphere
@@ -401,6 +442,7 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
     }
   }
   float z = best;
+  if (mode == 1) { out[(long)v * width + u] = z; return; }   // raw nearest depth (or just beyond the far plane)
   if (z > tfar) z = (max_depth > 0.f) ? 0.f : R.zfar;   // nothing in range: the far plane, which limit_depth_distance zeroes
   if (max_depth > 0.f && z > max_depth) z = 0.f;
   out[((long)env * height + v) * width + u] = z;
@@ -412,8 +454,9 @@ void smj_launch_lidar(const DevRender& r, const float* xpose, long ld, int num_e
   hipLaunchKernelGGL(smj_lidar_kernel, dim3(num_envs), dim3(384), 0, stream, r, xpose, ld, lidar, lidar_ld);
 }
 void smj_launch_depth(const DevRender& r, const float* xpose, long ld, int num_envs, int cam, int width, int height,
-                      float fovy_deg, float max_depth, float* out, hipStream_t stream) {
+                      float fovy_deg, float max_depth, float* out, const float* layer, int mode, hipStream_t stream) {
   const int tiles = ((width + 15) / 16) * ((height + 15) / 16);
   const float th = tanf(fovy_deg * 3.14159265358979323846f / 360.f);
-  hipLaunchKernelGGL(smj_depth_kernel, dim3(tiles, num_envs), dim3(256), 0, stream, r, xpose, ld, cam, width, height, th, max_depth, out);
+  hipLaunchKernelGGL(smj_depth_kernel, dim3(tiles, mode == 1 ? 1 : num_envs), dim3(256), 0, stream, r, xpose, ld, cam, width, height, th,
+                     mode == 1 ? 0.f : max_depth, out, layer, mode);
 }
