@@ -72,7 +72,7 @@ struct DevState {
 
 enum { SMJ_PROF_KIN = 0, SMJ_PROF_COMCRB, SMJ_PROF_SMOOTH, SMJ_PROF_FACTOR, SMJ_PROF_COLLISION, SMJ_PROF_MAKECON,
        SMJ_PROF_PROJECT, SMJ_PROF_WARM, SMJ_PROF_PGS, SMJ_PROF_POST, SMJ_PROF_INTEGRATE, SMJ_PROF_TOTAL, SMJ_PROF_PGS_SWEEPS,
-       SMJ_PROF_SETUP, SMJ_PROF_N_UPDATE, SMJ_PROF_N_GRAD, SMJ_PROF_N_XA, SMJ_PROF_N_HMFMA, SMJ_PROF_N_CHOL, SMJ_PROF_N_SOLVE,
+       SMJ_PROF_SETUP, SMJ_PROF_N_UPDATE, SMJ_PROF_N_GRAD, SMJ_PROF_N_XA, SMJ_PROF_N_HMFMA, SMJ_PROF_N_FACTSOLVE, SMJ_PROF_N_SOLVE,
        SMJ_PROF_N_PREP, SMJ_PROF_N_LS, SMJ_PROF_N_LSEVALS, SMJ_PROF_SLOTS = 24 };
 enum { SMJ_INFO_NEFC = 0, SMJ_INFO_NCON = 1, SMJ_INFO_NITER = 2, SMJ_INFO_FLAGS = 3 };
 enum { SMJ_FLAG_EFC_OVERFLOW = 1, SMJ_FLAG_CON_OVERFLOW = 2, SMJ_FLAG_BAD_STATE = 4 };

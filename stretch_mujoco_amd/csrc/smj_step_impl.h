@@ -61,7 +61,6 @@ struct Smem {
       eb[NEFC], ef[NEFC];
   float cpos[NCON][3], cframe[NCON][9], cdist[NCON], cfric[NCON][5], csolref[NCON][2], csolimp[NCON][5], cmargin[NCON];
   int cdim[NCON], cgeom1[NCON], cgeom2[NCON], cefc[NCON];
-  int cand[64];
 };
 
 // ---------------------------------------------------------------------------------------------- MFMA tile
@@ -188,7 +187,7 @@ struct StepKernel {
   const int env;
 
   // Persistent lane-resident state is kept small on purpose (the kernel owns 512 registers per lane but also unrolls a
-  // 32x32 Cholesky): model constants are (re)loaded at the top of the stage that needs them -- independent global loads
+  // 32x32 elimination): model constants are (re)loaded at the top of the stage that needs them -- independent global loads
   // issued back to back cost one L2 round trip per stage -- instead of living in registers for the whole launch.
   PL<float[6]> cdof, cdof_dot;          // lane = dof
   PL<float> qvel_r, g_r, qacc_r;
@@ -1983,7 +1982,7 @@ struct StepKernel {
 
   // ------------------------------------------------------------------ B.7' Newton solver (primal)
   // [MJ] mj_solNewton: exact Newton steps on  0.5 (a-a_s)' M (a-a_s) + s(J a - aref)  with H = M + J' W J on the
-  // matrix cores, an in-register Cholesky (lane i owns row i of H) and an exact line search.  This is the solver
+  // matrix cores, an in-register Gauss-Jordan solve (lane i owns row i of [H | g]) and an exact line search.  This is the solver
   // the reference model runs (stretch.xml names none -> MuJoCo default Newton); same restatement as the oracle's.
   struct NRow {            // lane = constraint row
     PL<int> type, state, c0;          // c0: contact index if this lane is the first row of an elliptic contact, else -1
@@ -2202,7 +2201,7 @@ struct StepKernel {
     gj_cols<0, N>(hrow, x, pinv);
     LANES { x[lane] *= pinv[lane]; }
   }
-  SMJ_DEV void chol_solve_H(PL<float>& x) {
+  SMJ_DEV void solve_H(PL<float>& x) {
     if (M.nv <= 28) gj_solve<28>(x);   // Stretch: 26 dofs; a quarter fewer column pairs than the full 32
     else gj_solve<NVP>(x);
   }
@@ -2261,7 +2260,7 @@ struct StepKernel {
     if (ne == 0) {   // unconstrained: qacc = M^-1 g
       build_dense(false);
       LANES { qacc[lane] = lane < nv ? g_r[lane] : 0.f; }
-      chol_solve_H(qacc);
+      solve_H(qacc);
       LANES {
         qacc_r[lane] = lane < nv ? qacc[lane] : 0.f;
         if (lane < nv) { s.qacc[lane] = qacc[lane]; s.warm[lane] = qacc[lane]; s.tmp[lane] = g_r[lane]; }
@@ -2406,8 +2405,8 @@ struct StepKernel {
       SYNC();
       TICK(SMJ_PROF_N_HMFMA)
       LANES { search[lane] = lane < nv ? grad[lane] : 0.f; }
-      chol_solve_H(search);
-      TICK(SMJ_PROF_N_CHOL)
+      solve_H(search);
+      TICK(SMJ_PROF_N_FACTSOLVE)
       PL<float> sq;
       LANES { search[lane] = lane < nv ? -search[lane] : 0.f; sq[lane] = search[lane] * search[lane]; }
       const float snorm = sqrtf(wave_sum(sq));
@@ -2546,7 +2545,7 @@ struct StepKernel {
     build_dense(true);
     PL<float> x;
     LANES { x[lane] = lane < nv ? s.tmp[lane] : 0.f; }
-    chol_solve_H(x);
+    solve_H(x);
     LANES {
       if (lane < nv) s.qvel[lane] += h * x[lane];
     }

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stretch_mujoco_amd import StretchBatchSimulator
 from oracle.oracle import Oracle
 np.set_printoptions(precision=5, suppress=True, linewidth=200)
-PROF = ["kin", "comcrb", "smooth", "factor", "collision", "makecon", "project", "warm", "pgs", "post", "integrate", "total", "sweeps", "setup", "n_update", "n_grad", "n_xa", "n_hmfma", "n_chol", "n_solve", "n_prep", "n_ls", "n_lsevals"]
+PROF = ["kin", "comcrb", "smooth", "factor", "collision", "makecon", "project", "warm", "pgs", "post", "integrate", "total", "sweeps", "setup", "n_update", "n_grad", "n_xa", "n_hmfma", "n_gauss_jordan", "n_solve", "n_prep", "n_ls", "n_lsevals"]
 
 def stage_parity(nsteps=1):
     sim = StretchBatchSimulator(num_envs=4, device="cuda:0", debug=True)
