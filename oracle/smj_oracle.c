@@ -938,8 +938,56 @@ static int obb_overlap(const smjo_model* m, const smjo_data* d, int g1, int g2, 
   }
   return 1;
 }
+/* [MJ] mjc_SphereBox (primitive pairs do not go through the convex solver): sphere s against box b; normal from the
+ * sphere to the box */
+static int sphere_box(const double* spos, double r, const double* bpos, const double* bmat, const double* bsize, double margin,
+                      rawcon* rc) {
+  double tmp[3] = {spos[0] - bpos[0], spos[1] - bpos[1], spos[2] - bpos[2]}, cen[3], cl[3], dif[3];
+  mulmat3Tvec(cen, bmat, tmp);
+  for (int i = 0; i < 3; i++) { cl[i] = cen[i] > bsize[i] ? bsize[i] : (cen[i] < -bsize[i] ? -bsize[i] : cen[i]); dif[i] = cl[i] - cen[i]; }
+  double dist = norm3(dif), nl[3], pl[3];
+  if (dist - r > margin) return 0;
+  if (dist <= MINVAL) { /* centre inside the box: nearest face */
+    double closest = 2 * fmax(bsize[0], fmax(bsize[1], bsize[2]));
+    int k = 0;
+    for (int i = 0; i < 6; i++) {
+      double cd = fabs((i % 2 ? 1 : -1) * bsize[i / 2] - cen[i / 2]);
+      if (cd < closest) { closest = cd; k = i; }
+    }
+    nl[0] = nl[1] = nl[2] = 0; nl[k / 2] = k % 2 ? -1 : 1;
+    for (int i = 0; i < 3; i++) pl[i] = cen[i] + nl[i] * (r - closest) / 2;
+    rc->dist = -closest - r;
+  } else {
+    for (int i = 0; i < 3; i++) { nl[i] = dif[i] / dist; pl[i] = 0.5 * (cl[i] + cen[i] + dif[i] * (r / dist)); }
+    rc->dist = dist - r;
+  }
+  mulmat3vec(rc->normal, bmat, nl);
+  mulmat3vec(rc->pos, bmat, pl);
+  for (int i = 0; i < 3; i++) rc->pos[i] += bpos[i];
+  return 1;
+}
+/* [MJ] mjc_SphereSphere */
+static int sphere_sphere(const double* p1, double r1, const double* p2, double r2, double margin, rawcon* rc) {
+  double dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, cdist = norm3(dif);
+  if (cdist - r1 - r2 > margin) return 0;
+  if (cdist < MINVAL) { dif[0] = 1; dif[1] = dif[2] = 0; } else for (int i = 0; i < 3; i++) dif[i] /= cdist;
+  rc->dist = cdist - r1 - r2;
+  for (int i = 0; i < 3; i++) { rc->normal[i] = dif[i]; rc->pos[i] = p1[i] + dif[i] * (r1 + 0.5 * rc->dist); }
+  return 1;
+}
 static int convex_pair(const smjo_model* m, const smjo_data* d, int g1, int g2, double margin, rawcon* rc) {
   if (!obb_overlap(m, d, g1, g2, margin)) return 0;
+  {
+    const int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+    const double *x1 = d->geom_xpos + 3 * g1, *x2 = d->geom_xpos + 3 * g2;
+    if (t1 == G_SPHERE && t2 == G_SPHERE) return sphere_sphere(x1, m->geom_size[3 * g1], x2, m->geom_size[3 * g2], margin, rc);
+    if (t1 == G_SPHERE && t2 == G_BOX) return sphere_box(x1, m->geom_size[3 * g1], x2, d->geom_xmat + 9 * g2, m->geom_size + 3 * g2, margin, rc);
+    if (t1 == G_BOX && t2 == G_SPHERE) {
+      if (!sphere_box(x2, m->geom_size[3 * g2], x1, d->geom_xmat + 9 * g1, m->geom_size + 3 * g1, margin, rc)) return 0;
+      for (int i = 0; i < 3; i++) rc->normal[i] = -rc->normal[i]; /* the contact keeps the pair's geom order */
+      return 1;
+    }
+  }
   mprctx c;
   c.m = m;
   double cen[2][3];

@@ -1350,6 +1350,44 @@ struct StepKernel {
     }
   }
 
+  // [MJ] mjc_SphereBox / mjc_SphereSphere: primitive pairs have closed forms and do not go through MPR.  Wave-uniform.
+  // dist < 0 = penetration; dir from the sphere (first sphere) to the other geom
+  SMJ_DEV bool sphere_box(const float* spos, float r, const Shape& bx, float margin, float& dist_out, float* dir, float* pos) {
+    const float tmp[3] = {spos[0] - bx.pos[0], spos[1] - bx.pos[1], spos[2] - bx.pos[2]};
+    float cen[3], cl[3], dif[3], nl[3], pl[3];
+    mulmat3Tvec(cen, bx.mat, tmp);
+    for (int i = 0; i < 3; i++) { cl[i] = fminf(bx.size[i], fmaxf(-bx.size[i], cen[i])); dif[i] = cl[i] - cen[i]; }
+    const float dist = sqrtf(dot3(dif, dif));
+    if (dist - r > margin) return false;
+    if (dist <= SMJ_MINVAL) {   // centre inside the box: nearest face
+      float closest = 2.f * fmaxf(bx.size[0], fmaxf(bx.size[1], bx.size[2]));
+      int k = 0;
+      for (int i = 0; i < 6; i++) {
+        const float cd = fabsf(((i & 1) ? 1.f : -1.f) * bx.size[i >> 1] - cen[i >> 1]);
+        if (cd < closest) { closest = cd; k = i; }
+      }
+      for (int i = 0; i < 3; i++) nl[i] = (i == (k >> 1)) ? ((k & 1) ? -1.f : 1.f) : 0.f;
+      for (int i = 0; i < 3; i++) pl[i] = cen[i] + nl[i] * (r - closest) * 0.5f;
+      dist_out = -closest - r;
+    } else {
+      const float inv = 1.f / dist;
+      for (int i = 0; i < 3; i++) { nl[i] = dif[i] * inv; pl[i] = 0.5f * (cl[i] + cen[i] + dif[i] * (r * inv)); }
+      dist_out = dist - r;
+    }
+    mulmat3vec(dir, bx.mat, nl);
+    mulmat3vec(pos, bx.mat, pl);
+    for (int i = 0; i < 3; i++) pos[i] += bx.pos[i];
+    return true;
+  }
+  SMJ_DEV bool sphere_sphere(const float* p1, float r1, const float* p2, float r2, float margin, float& dist_out, float* dir, float* pos) {
+    float dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+    const float cdist = sqrtf(dot3(dif, dif));
+    if (cdist - r1 - r2 > margin) return false;
+    if (cdist < SMJ_MINVAL) { dif[0] = 1; dif[1] = dif[2] = 0; } else { const float inv = 1.f / cdist; for (int i = 0; i < 3; i++) dif[i] *= inv; }
+    dist_out = cdist - r1 - r2;
+    for (int i = 0; i < 3; i++) { dir[i] = dif[i]; pos[i] = p1[i] + dif[i] * (r1 + 0.5f * dist_out); }
+    return true;
+  }
   SMJ_DEV void load_shape(Shape& sh, int g, int slot, float* cen) {
     (void)g;
     sh.type = uni(s.u.c.meta[slot][0]); sh.nvert = uni(s.u.c.meta[slot][1]);
@@ -1474,8 +1512,24 @@ struct StepKernel {
         float c0[3], c1[3], depth, dir[3], pos[3];
         load_shape(A, g1, uni(M.k_convpair_s1[t]), c0);
         load_shape(Bs, g2, uni(M.k_convpair_s2[t]), c1);
+        const float margin = uni(M.pair_margin[p]);
+        if (A.type == GT_SPHERE && Bs.type == GT_SPHERE) {
+          if (sphere_sphere(A.pos, A.size[0], Bs.pos, Bs.size[0], margin, depth, dir, pos)) add_contact(p, g1, g2, depth, pos, dir);
+          continue;
+        }
+        if (A.type == GT_SPHERE && Bs.type == GT_BOX) {
+          if (sphere_box(A.pos, A.size[0], Bs, margin, depth, dir, pos)) add_contact(p, g1, g2, depth, pos, dir);
+          continue;
+        }
+        if (A.type == GT_BOX && Bs.type == GT_SPHERE) {
+          if (sphere_box(Bs.pos, Bs.size[0], A, margin, depth, dir, pos)) {
+            for (int k = 0; k < 3; k++) dir[k] = -dir[k];   // the contact keeps the pair's geom order
+            add_contact(p, g1, g2, depth, pos, dir);
+          }
+          continue;
+        }
         if (!mpr_penetration(A, Bs, c0, c1, depth, dir, pos)) continue;
-        if (-depth > uni(M.pair_margin[p]) || dot3(dir, dir) < 0.5f) continue;
+        if (-depth > margin || dot3(dir, dir) < 0.5f) continue;
         add_contact(p, g1, g2, -depth, pos, dir);
       }
     }

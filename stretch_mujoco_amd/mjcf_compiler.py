@@ -1242,12 +1242,12 @@ def empty_scene_xml(stretch_xml_path: str) -> str:
             '<worldbody><geom name="floor" type="plane" size="0 0 0.05"/></worldbody></mujoco>')
 
 
-def kitchen_standin_xml(stretch_xml_path: str) -> str:
+def kitchen_standin_xml(stretch_xml_path: str, free_ball: bool = False) -> str:
     """Synthetic kitchen stand-in (Robocasa itself is unavailable here): the robot at
     the origin in a 5 m x 5 m room with a counter run on its arm side (-y), wall cabinets above it, an island in front, a
     fridge, a table and a few fixtures -- 24 STATIC boxes on the world body, all colliding with the robot ([MJ] default
-    contype = conaffinity = 1) and visible to lidar and depth cameras.  Free objects are not part of it (the step kernel's
-    dof capacity is the robot's)."""
+    contype = conaffinity = 1) and visible to lidar and depth cameras.  free_ball adds ONE free object, a ball on the
+    countertop: 6 more dofs fill the step kernel's 32-dof capacity exactly."""
     boxes = []
 
     def box(name, pos, half, rgba="0.7 0.7 0.7 1"):
@@ -1273,6 +1273,10 @@ def kitchen_standin_xml(stretch_xml_path: str) -> str:
     box("shelf", (-2.3, 0.8, 1.0), (0.2, 0.5, 0.02), "0.55 0.4 0.3 1")
     box("stool", (1.0, 1.2, 0.25), (0.18, 0.18, 0.25), "0.3 0.3 0.3 1")
     assert len(boxes) == 24
+    # one free object: a ball resting on the countertop within reach of the gripper (6 dofs -- together with the robot's 26
+    # exactly the kernel's 32-dof capacity; sphere contacts are single-point exact, no multi-contact manifold needed)
+    ball = ('<body name="ball" pos="-0.3 -0.95 0.9597"><freejoint name="ball_free"/>'
+            '<geom name="ball" type="sphere" size="0.04" mass="0.1" rgba="0.9 0.3 0.2 1" condim="4" friction="1 0.01 0.001"/></body>') if free_ball else ""
     return (f'<mujoco model="stretch_kitchen_standin"><include file="{stretch_xml_path}"/>'
-            '<worldbody><geom name="floor" type="plane" size="0 0 0.05"/>' + "".join(boxes) + '</worldbody></mujoco>')
+            '<worldbody><geom name="floor" type="plane" size="0 0 0.05"/>' + "".join(boxes) + ball + '</worldbody></mujoco>')
 

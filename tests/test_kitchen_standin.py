@@ -7,16 +7,17 @@ from emul.emul import Emul
 from oracle.oracle import Oracle
 from stretch_mujoco_amd import model_blob
 
-DIMS = dict(nq=27, nv=26, nu=10, nlidar=360)
+DIMS = dict(nq=34, nv=32, nu=10, nlidar=360)   # robot 27/26 + one free ball 7/6
 
 
 def test_scene_tables(blob_kitchen):
     m = model_blob.loads(blob_kitchen)
-    assert int(m["dims"][5]) == 126 + 24
-    assert int(m["k_ncgeom"][0]) == 51 + 24 and int(m["k_nconvpair"][0]) == 848 + 51 * 24
-    assert int(m["k_nplanepair"][0]) == 51                      # static boxes do not pair with the static floor
-    assert int(m["k_nrgeom"][0]) == 74 + 24 and int(m["k_nlgeom"][0]) == 96 + 24
-    boxes = [g for g in range(150) if m["geom_type"][g] == 6 and m["geom_bodyid"][g] == 0]
+    assert int(m["dims"][5]) == 126 + 24 + 1 and int(m["dims"][0]) == 34 and int(m["dims"][1]) == 32
+    assert int(m["k_ncgeom"][0]) == 51 + 24 + 1 and int(m["k_nconvpair"][0]) == 848 + 51 * 24 + 51 + 24   # ball vs robot, ball vs fixtures
+    assert int(m["k_nplanepair"][0]) == 51 + 1                  # static boxes do not pair with the static floor, the ball does
+    assert int(m["k_nrgeom"][0]) == 74 + 24 + 1 and int(m["k_nlgeom"][0]) == 96 + 24 + 1
+    assert int(m["k_nroot"][0]) == 2                            # two kinematic trees: robot and ball
+    boxes = [g for g in range(151) if m["geom_type"][g] == 6 and m["geom_bodyid"][g] == 0]
     assert len(boxes) == 24
 
 
@@ -46,7 +47,7 @@ def test_arm_runs_into_the_counter(blob_kitchen):
         touching += int(n > 5)
         if int(e.info[0, 0]) == o.nefc and (cosn > 0.9999).all() and np.abs(ce[:, 0] - co[:, 0]).max() < 1e-6:
             qa = o.arr("qacc")
-            assert np.abs(e.debug[1056:1082, 0] - qa)[:18].max() < 2e-2 * max(1.0, np.abs(qa[:18]).max()), k
+            assert np.abs(e.debug[1056:1088, 0] - qa)[:18].max() < 2e-2 * max(1.0, np.abs(qa[:18]).max()), k
             compared += 1
         o.step(10)
     arm = o.arr("qpos")[10:14].sum()
@@ -74,3 +75,25 @@ def test_lidar_sees_the_room(blob_kitchen):
     assert abs(Z[i, 1] + 1) < 1e-3 and abs(L[i] - (P[i, 1] + 0.78)) < 2e-3, (Z[i], L[i])
     j = int(np.argmax(Z[:, 1]))                                    # +y: table leg? no -- clear path to the wall at y = 2.5
     assert abs(L[j] - (2.5 - P[j, 1])) < 0.02 or L[j] < 2.5
+
+
+def test_ball_rests_on_the_counter_and_is_pushed(blob_kitchen):
+    """The free ball (second kinematic tree, sphere-box contact in closed form) settles on the countertop at the height the
+    soft contact allows; kernel logic and oracle agree along the way, and a shove makes it roll (its dofs are live)."""
+    m = model_blob.loads(blob_kitchen)
+    o = Oracle(blob_kitchen); o.set_option("solver", 2)
+    q = home_qpos(m["qpos0"])
+    ctrl = [0, 0, 0.6, 0.1, 0, 0, 0, 0, 0, 0]
+    o.arr("qpos")[:] = q; o.arr("ctrl")[:] = ctrl
+    e = Emul(blob_kitchen, DIMS, num_envs=1); e.set_option("solver", 2)
+    e.qpos[:, 0] = q; e.ctrl[:, 0] = ctrl
+    o.step(400); e.step(400)
+    zb = o.arr("qpos")[29]
+    assert 0.9590 < zb < 0.9601                                   # countertop at 0.92, radius 0.04, sub-millimetre sink
+    assert abs(e.qpos[29, 0] - zb) < 2e-5 and np.abs(e.qpos[:, 0] - o.arr("qpos")).max() < 1e-4
+    assert np.abs(o.arr("qvel")[26:]).max() < 1e-3
+    o.arr("qvel")[26] = 0.5; e.qvel[26, 0] = 0.5                  # shove along x
+    o.step(100); e.step(100)
+    assert o.arr("qpos")[27] > -0.3 + 0.02 and abs(e.qpos[27, 0] - o.arr("qpos")[27]) < 2e-3
+    assert abs(o.arr("qvel")[30]) > 1.0                           # rolling: spin about y has built up from friction
+

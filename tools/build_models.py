@@ -25,8 +25,8 @@ def main():
     full["rmesh_vertnum"] = 0 * m["rmesh_vertnum"]; full["rmesh_facenum"] = 0 * m["rmesh_facenum"]
     B.save(os.path.join(out, "stretch_empty_full.smjb"), full)
     B.save(os.path.join(out, "stretch_empty.smjb"), F.prepare_for_kernels(m))        # fused + kernel tables (product)
-    k = C.compile_string(C.kitchen_standin_xml(stretch))
-    B.save(os.path.join(out, "stretch_kitchen_standin.smjb"), F.prepare_for_kernels(k))  # config 4 stand-in (static fixtures)
+    k = C.compile_string(C.kitchen_standin_xml(stretch, free_ball=True))
+    B.save(os.path.join(out, "stretch_kitchen_standin.smjb"), F.prepare_for_kernels(k))  # config 4 stand-in (static fixtures + one free ball)
     print("stretch_kitchen_standin:", dict(zip("nq nv nu nbody njnt ngeom".split(), [int(x) for x in k["dims"][:6]])),
           "npair", int(k["dims"][12]))
     print("stretch_empty:", dict(zip("nq nv nu nbody njnt ngeom nsite ncam neq ntendon nwrap nkey npair nhullvert".split(),
