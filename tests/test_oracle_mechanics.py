@@ -1,0 +1,103 @@
+"""The oracle's rigid-body algebra against analytical mechanics on the actual Stretch model -- checks that need no
+MuJoCo: (1) the joint-space inertia matrix M (composite rigid body) reproduces the kinetic energy obtained body by body
+from finite differences of the forward kinematics; (2) the bias force (recursive Newton-Euler) equals the Lagrangian
+expression Mdot qdot - dT/dq + dV/dq obtained from M(q) and the potential energy by numerical differentiation."""
+import numpy as np
+import pytest
+
+from conftest import home_qpos
+from oracle.oracle import Oracle
+from stretch_mujoco_amd import model_blob
+
+G = 9.81
+
+
+def _quat_mul(a, b):
+    w1, x1, y1, z1 = a; w2, x2, y2, z2 = b
+    return np.array([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                     w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2])
+
+
+def _advance(q, v, eps):
+    """q (+) eps*v with MuJoCo's conventions: free joint = world-frame linear, body-frame angular velocity."""
+    out = q.copy()
+    out[0:3] += eps * v[0:3]
+    w = v[3:6] * eps
+    ang = np.linalg.norm(w)
+    dq = np.array([1.0, 0, 0, 0]) if ang < 1e-15 else np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * w / ang])
+    out[3:7] = _quat_mul(q[3:7], dq)
+    out[7:27] += eps * v[6:26]
+    return out
+
+
+def _fk(o, q):
+    o.arr("qpos")[:] = q
+    o.forward()
+    n = o.dim("nbody")
+    return o.arr("xipos").reshape(n, 3).copy(), o.arr("ximat").reshape(n, 3, 3).copy(), o.arr("qM").reshape(26, 26).copy()
+
+
+def _rand_state(m, seed):
+    rng = np.random.default_rng(seed)
+    q = home_qpos(m["qpos0"])
+    q[0:3] = [0.3, -0.2, 0.02]
+    ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+    q[3:7] = np.concatenate([[np.cos(0.35)], np.sin(0.35) * ax])
+    lim = m["jnt_range"]
+    for j in range(1, len(m["jnt_type"])):
+        lo, hi = lim[j]
+        q[m["jnt_qposadr"][j]] = lo + (hi - lo) * (0.2 + 0.6 * rng.random()) if hi > lo else 0.3 * rng.normal()
+    return q, rng
+
+
+@pytest.mark.parametrize("which", ["full", "fused"])
+def test_mass_matrix_reproduces_the_kinetic_energy(which, blob_full, blob_fused):
+    blob = blob_full if which == "full" else blob_fused
+    m = model_blob.loads(blob)
+    o = Oracle(blob)
+    for seed in range(3):
+        q, rng = _rand_state(m, seed)
+        v = rng.normal(size=26) * np.r_[0.5 * np.ones(3), 1.0 * np.ones(3), 0.7 * np.ones(20)]
+        eps = 1e-6
+        p0, R0, M = _fk(o, _advance(q, v, -eps))
+        p1, R1, _ = _fk(o, _advance(q, v, +eps))
+        pc, Rc, M = _fk(o, q)
+        T = 0.0
+        for b in range(1, len(m["body_mass"])):
+            vc = (p1[b] - p0[b]) / (2 * eps)
+            dR = (R1[b] - R0[b]) / (2 * eps)
+            W = dR @ Rc[b].T                                         # skew(omega) in the world frame
+            w_world = np.array([W[2, 1] - W[1, 2], W[0, 2] - W[2, 0], W[1, 0] - W[0, 1]]) / 2
+            w_body = Rc[b].T @ w_world
+            T += 0.5 * m["body_mass"][b] * vc @ vc + 0.5 * w_body @ (m["body_inertia"][b] * w_body)
+        arm = 0.5 * np.sum(m["dof_armature"] * v * v)                # rotor inertia is added on the diagonal of M
+        assert abs(0.5 * v @ M @ v - (T + arm)) < 2e-7 * (T + arm), (seed, 0.5 * v @ M @ v, T + arm)
+
+
+def test_bias_force_is_the_lagrangian_expression(blob_full):
+    m = model_blob.loads(blob_full)
+    o = Oracle(blob_full)
+    nb = len(m["body_mass"])
+    for seed in range(2):
+        q, rng = _rand_state(m, seed + 10)
+        v = np.zeros(26)
+        v[6:] = rng.normal(size=20) * 0.8          # base at rest: the joint coordinates are ordinary generalised coordinates
+        o.arr("qpos")[:] = q; o.arr("qvel")[:] = v
+        o.forward()
+        bias = o.arr("qfrc_bias").copy()
+
+        def M_of(qq):
+            return _fk(o, qq)[2]
+
+        def V_of(qq):
+            p = _fk(o, qq)[0]
+            return float(np.sum(m["body_mass"][1:nb] * G * p[1:nb, 2]))
+        eps = 1e-5
+        Mdot_v = (M_of(_advance(q, v, eps)) - M_of(_advance(q, v, -eps))) @ v / (2 * eps)
+        for d in range(6, 26):
+            e = np.zeros(26); e[d] = 1.0
+            qp, qm = _advance(q, e, eps), _advance(q, e, -eps)
+            dT = 0.5 * v @ (M_of(qp) - M_of(qm)) @ v / (2 * eps)
+            dV = (V_of(qp) - V_of(qm)) / (2 * eps)
+            expect = Mdot_v[d] - dT + dV
+            assert abs(bias[d] - expect) < 2e-5 * max(1.0, abs(expect)) + 2e-6, (seed, d, bias[d], expect)
