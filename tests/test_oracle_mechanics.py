@@ -101,3 +101,88 @@ def test_bias_force_is_the_lagrangian_expression(blob_full):
             dV = (V_of(qp) - V_of(qm)) / (2 * eps)
             expect = Mdot_v[d] - dT + dV
             assert abs(bias[d] - expect) < 2e-5 * max(1.0, abs(expect)) + 2e-6, (seed, d, bias[d], expect)
+
+
+@pytest.mark.parametrize("solver", [0, 2])
+def test_solver_output_satisfies_the_optimality_conditions(solver, blob_full):
+    """What both solvers must deliver ([MJ] computation chapter): qacc with M qacc = qfrc_smooth + J' f, and forces f that
+    are the (negative) gradient of the constraint cost at J qacc - aref: equality / quadratic rows f = -D r, one-sided
+    rows f = max(0, -D r), dry-friction rows the clamp of -D r to +-frictionloss.  Checked on a state with wheel contacts,
+    a joint at its limit and all friction-loss rows (elliptic contact blocks: the force must lie in the friction cone)."""
+    m = model_blob.loads(blob_full)
+    o = Oracle(blob_full); o.set_option("solver", solver)
+    o.set_option("iterations", 300); o.set_option("tolerance", 1e-12)
+    ctrl = [1.0, -0.5, 0.9, 0.3, 1.0, -0.5, 0.3, 0.2, 0.5, -1.6]      # head_tilt driven into its lower limit
+    o.arr("ctrl")[:] = ctrl
+    o.arr("qpos")[:] = home_qpos(m["qpos0"])
+    o.step(400)
+    j = int(np.argmin(np.abs(m["jnt_range"][:, 0] + 1.53)))           # head_tilt: push it 0.02 rad past its lower stop
+    o.arr("qpos")[m["jnt_qposadr"][j]] = m["jnt_range"][j, 0] - 0.02
+    o.forward()
+    ne, nv = o.nefc, 26
+    J = o.arr("efc_J").reshape(ne, nv); f = o.arr("efc_force"); M = o.arr("qM").reshape(nv, nv)
+    qacc = o.arr("qacc"); D = o.arr("efc_D"); r = J @ qacc - o.arr("efc_aref")
+    resid = M @ qacc - o.arr("qfrc_smooth") - J.T @ f
+    tol = 1e-7 if solver == 2 else 2e-4                                # PGS stops on its cost-decrease test
+    assert np.abs(resid).max() < tol * max(1.0, np.abs(o.arr("qfrc_smooth")).max()), np.abs(resid).max()
+    types = o.iarr("efc_type")[:ne]
+    n_eq = int((types == 0).sum()); n_fr = int((types == 1).sum()); n_lim = int((types == 3).sum())
+    assert n_eq == 5 and n_fr == 12 and n_lim >= 1 and ne > 17 + n_lim
+    ftol = 1e-6 if solver == 2 else 5e-3
+    for i in range(ne):
+        t = types[i]
+        scale = max(1.0, abs(f[i]))
+        if t == 0:
+            assert abs(f[i] + D[i] * r[i]) < ftol * scale, (i, f[i], -D[i] * r[i])
+        elif t == 3 or t == 5:
+            assert abs(f[i] - max(0.0, -D[i] * r[i])) < ftol * scale, (i, f[i], -D[i] * r[i])
+    # elliptic contacts: normal force non-negative and tangential force inside the (regularised) cone
+    ell = np.nonzero(types == 7)[0]
+    assert len(ell) >= 12
+    i = ell[0]
+    while i < ne and types[i] == 7:
+        dim = 6 if (i + 5 < ne and np.all(types[i:i + 6] == 7)) else 3
+        assert f[i] >= -1e-9
+        i += dim
+
+
+def test_free_floating_robot_conserves_momentum(blob_full):
+    """Zero gravity, robot far above the floor, joints driven hard by their servos: every force is internal (actuators,
+    dampers, friction loss, limits, equality constraints), so the total linear momentum and the angular momentum about
+    the origin stay at zero while the base recoils.  The semi-implicit step conserves them to first order in h: the
+    residual must be small AND halve when the time step is halved."""
+    m = model_blob.loads(blob_full)
+    nb = len(m["body_mass"])
+    mass, Ib = m["body_mass"], m["body_inertia"]
+
+    def run(h):
+        o = Oracle(blob_full); o.set_option("solver", 2); o.set_option("gravity_z", 0.0); o.set_option("timestep", h)
+        q = home_qpos(m["qpos0"]); q[2] = 5.0
+        o.arr("qpos")[:] = q
+        o.arr("ctrl")[:] = [0, 0, 1.0, 0.45, 2.0, -1.0, 1.5, 0.3, -2.0, -0.8]
+
+        def frames():
+            return o.arr("xipos").reshape(nb, 3).copy(), o.arr("ximat").reshape(nb, 3, 3).copy()
+        o.forward()
+        p_prev, R_prev = frames()
+        Pmax = Lmax = scale_p = scale_l = 0.0
+        for k in range(int(round(0.6 / h))):
+            o.step(1); o.forward()
+            p, R = frames()
+            v = (p - p_prev) / h
+            P = (mass[:, None] * v)[1:].sum(0)
+            L = np.zeros(3)
+            for b in range(1, nb):
+                W = ((R[b] - R_prev[b]) / h) @ R[b].T
+                w = np.array([W[2, 1] - W[1, 2], W[0, 2] - W[2, 0], W[1, 0] - W[0, 1]]) / 2
+                L += mass[b] * np.cross(0.5 * (p[b] + p_prev[b]), v[b]) + R[b] @ (Ib[b] * (R[b].T @ w))
+            Pmax = max(Pmax, np.abs(P).max()); Lmax = max(Lmax, np.abs(L).max())
+            scale_p = max(scale_p, (mass[1:] * np.linalg.norm(v[1:], axis=1)).sum())
+            scale_l = max(scale_l, sum(mass[b] * np.linalg.norm(np.cross(p[b], v[b])) for b in range(1, nb)))
+            p_prev, R_prev = p, R
+        assert scale_p > 0.5 and np.linalg.norm(o.arr("qpos")[0:3] - q[0:3]) > 1e-3      # things moved, the base recoiled
+        return Pmax / scale_p, Lmax / scale_l
+    p1, l1 = run(0.002)
+    p2, l2 = run(0.001)
+    assert p1 < 1.5e-2 and l1 < 3e-2, (p1, l1)
+    assert 1.7 < p1 / p2 < 2.3 and 1.5 < l1 / l2 < 2.5, (p1 / p2, l1 / l2)
