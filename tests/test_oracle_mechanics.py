@@ -186,3 +186,51 @@ def test_free_floating_robot_conserves_momentum(blob_full):
     p2, l2 = run(0.001)
     assert p1 < 1.5e-2 and l1 < 3e-2, (p1, l1)
     assert 1.7 < p1 / p2 < 2.3 and 1.5 < l1 / l2 < 2.5, (p1 / p2, l1 / l2)
+
+
+def test_contact_jacobian_is_the_relative_velocity_of_the_contact_point(blob_fused):
+    """Rows of efc_J for a contact: the relative velocity (geom2's body minus geom1's body) of the material points under
+    the contact, in the contact frame (rows 0-2), and the relative angular velocity (rows 3-5) -- obtained here by moving
+    the bodies along qdot with the forward kinematics only.  Uses a self-collision state (gripper on the base) so that
+    both bodies of a contact move."""
+    m = model_blob.loads(blob_fused)
+    o = Oracle(blob_fused); o.set_option("solver", 2)
+    o.arr("ctrl")[:] = [0, 0, 0.05, 0.0, 1.0, -1.2, 0, 0, 0, 0]
+    o.arr("qpos")[:] = home_qpos(m["qpos0"])
+    o.step(500); o.forward()
+    n, ne, nv = o.ncon, o.nefc, 26
+    assert n > 5
+    raw = o.arr("contact").reshape(n, 29).copy()
+    ints = raw[:, 27:29].copy().view(np.int32).reshape(n, 4)          # dim, geom1, geom2, efc_address
+    J = o.arr("efc_J").reshape(ne, nv).copy()
+    q = o.arr("qpos").copy()
+    nbody = o.dim("nbody")
+    xpos = o.arr("xpos").reshape(nbody, 3).copy(); xmat = o.arr("xmat").reshape(nbody, 3, 3).copy()
+    rng = np.random.default_rng(3)
+    v = rng.normal(size=nv)
+    eps = 1e-6
+
+    def poses(qq):
+        o.arr("qpos")[:] = qq; o.forward()
+        return o.arr("xpos").reshape(nbody, 3).copy(), o.arr("xmat").reshape(nbody, 3, 3).copy()
+    pp, Rp = poses(_advance(q, v, eps))
+    pm, Rm = poses(_advance(q, v, -eps))
+    checked = 0
+    for c in range(n):
+        dim, g1, g2, adr = ints[c]
+        if adr < 0:
+            continue
+        pos, frame = raw[c, 1:4], raw[c, 4:13].reshape(3, 3)
+        vel, omg = [], []
+        for g in (g1, g2):
+            b = m["geom_bodyid"][g]
+            local = xmat[b].T @ (pos - xpos[b])                       # the material point of body b under the contact
+            vel.append(((pp[b] + Rp[b] @ local) - (pm[b] + Rm[b] @ local)) / (2 * eps))
+            W = ((Rp[b] - Rm[b]) / (2 * eps)) @ xmat[b].T
+            omg.append(np.array([W[2, 1] - W[1, 2], W[0, 2] - W[2, 0], W[1, 0] - W[0, 1]]) / 2)
+        rel_v, rel_w = frame @ (vel[1] - vel[0]), frame @ (omg[1] - omg[0])
+        got = J[adr:adr + dim] @ v
+        want = np.concatenate([rel_v, rel_w])[:dim]
+        assert np.allclose(got, want, rtol=1e-5, atol=1e-6), (c, dim, got, want)
+        checked += 1
+    assert checked > 5
