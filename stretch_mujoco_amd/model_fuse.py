@@ -95,6 +95,8 @@ def fuse_static_bodies(m: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
         f[prefix + "_bodyid"] = remap[old]
         f[prefix + "_pos"], f[prefix + "_quat"] = pos, quat
 
+    # every ORIGINAL body (the reference's link names, names_json["body"]) as a rigid offset on its fused body
+    f["link_fused"] = remap.copy(); f["link_relpos"] = np.array(rpos, float); f["link_relquat"] = np.array(rquat, float)
     f["geom_origbody"] = m["geom_bodyid"].copy(); f["site_origbody"] = m["site_bodyid"].copy()
     rebase("geom"); rebase("site"); rebase("cam")
     d = f["dims"].copy()

@@ -121,12 +121,13 @@ class StretchBatchSimulator:
         if StretchSensors.base_lidar in self._sensors:
             self._read_flags |= _lib.READ_LIDAR
         self._depth = {}
+        # body poses of the last step: input of the depth renderer and of get_link_pose (240 floats per env, always on)
+        self.xpose = torch.zeros(dims[D["NBODY"]] * 12, B, **f)
+        _lib.check(L, ctx, L.smj_bind(ctx, S["XPOSE"], ctypes.c_void_p(self.xpose.data_ptr()), B), "smj_bind(XPOSE)")
+        self._read_flags |= _lib.READ_POSES
         if self._cameras:
             if dims[D["NCAM"]] == 0:
                 raise _lib.SmjError("the model blob carries no render tables: depth cameras are unavailable for this scene")
-            self.xpose = torch.zeros(dims[D["NBODY"]] * 12, B, **f)
-            _lib.check(L, ctx, L.smj_bind(ctx, S["XPOSE"], ctypes.c_void_p(self.xpose.data_ptr()), B), "smj_bind(XPOSE)")
-            self._read_flags |= _lib.READ_POSES
             for cam in self._cameras:
                 st = cam.initial_camera_settings
                 self._depth[cam] = torch.zeros(B, st.height, st.width, **f)
@@ -280,6 +281,34 @@ class StretchBatchSimulator:
         return (s.base.x, s.base.y, s.base.theta)
 
     # ------------------------------------------------------------------ wait helpers as batched predicates
+    @_require_connection
+    def get_link_pose(self, link_name: str) -> torch.Tensor:
+        """World pose [B, 4, 4] of a link (a body name of stretch.xml, e.g. "link_grasp_center"), from the body poses of the
+        last physics step.  The reference (stretch_mujoco_simulator.py:468-486) evaluates the URDF at the joint positions and
+        places it at the planar base pose; here the simulated pose itself is returned, base roll / pitch / height included."""
+        names = self.names["body"]
+        if link_name not in names:
+            raise KeyError(link_name)
+        i = names.index(link_name)
+        fb = int(self.model["link_fused"][i])
+        rp = torch.tensor(np.asarray(self.model["link_relpos"][i], np.float32), device=self.device)
+        w, x, y, z = [float(v) for v in self.model["link_relquat"][i]]
+        Rl = torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                           [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                           [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]], dtype=torch.float32, device=self.device)
+        P = self.xpose[12 * fb: 12 * fb + 3].t()                       # [B, 3]
+        Rb = self.xpose[12 * fb + 3: 12 * fb + 12].t().reshape(-1, 3, 3)
+        T = torch.zeros(self.num_envs, 4, 4, dtype=torch.float32, device=self.device)
+        T[:, :3, :3] = Rb @ Rl
+        T[:, :3, 3] = P + (Rb @ rp)
+        T[:, 3, 3] = 1.0
+        return T
+
+    @_require_connection
+    def get_ee_pose(self) -> torch.Tensor:
+        """stretch_mujoco_simulator.py:464-466"""
+        return self.get_link_pose("link_grasp_center")
+
     @_require_connection
     def is_reached_set_position(self, actuator, position_tolerance: float = 0.05) -> torch.Tensor:
         """[B] bool: the joint is within `position_tolerance` of its last `move_to` target; envs whose command holds no

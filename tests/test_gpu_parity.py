@@ -172,6 +172,15 @@ def test_api_flow_home_move_to_move_by_base():
     assert torch.allclose(st.lift.pos[:4], torch.full((4,), 1.0, device=sim.device), atol=0.05)   # examples/move_joints.py: atol 0.05
     assert torch.allclose(st.lift.pos[4:], torch.full((12,), 0.589, device=sim.device), atol=5e-3)
     assert torch.allclose(st.head_pan.pos, torch.full((16,), -1.0, device=sim.device), atol=0.01)
+    # link poses: the grasp centre rides on the lift (z follows the lift position) and sits out on the arm side (-y)
+    ee = sim.get_ee_pose()
+    assert ee.shape == (16, 4, 4) and torch.allclose(ee[:, 3], torch.tensor([0, 0, 0, 1.0], device=sim.device).expand(16, 4))
+    assert float((ee[:4, 2, 3] - ee[4:8, 2, 3]).mean()) == pytest.approx(1.0 - 0.589, abs=0.02)
+    assert float(ee[4, 1, 3]) < -0.3 and torch.allclose(ee[:, :3, :3] @ ee[:, :3, :3].transpose(1, 2), torch.eye(3, device=sim.device).expand(16, 3, 3), atol=1e-5)
+    base = sim.get_link_pose("base_link")
+    assert torch.allclose(base[:, 0, 3], sim.pull_status().base.x.float(), atol=1e-5)
+    with pytest.raises(KeyError):
+        sim.get_link_pose("no_such_link")
     x0 = sim.pull_status().base.x.clone()
     sim.move_by(Actuators.base_translate, 0.07, env_ids=[5, 6])
     sim.step(2500)
