@@ -308,8 +308,8 @@ __global__ __launch_bounds__(384) void smj_lidar_kernel(const DevRender R, const
   }
 }
 
-// mode 0: all visible geoms.  mode 1: only the geoms rigidly attached to the camera's body, raw depth (one env) -- the
-// camera-static layer.  mode 2: all other geoms, every ray starting from the static layer's depth.
+// mode 0: all visible geoms.  mode 1: only the geoms rigidly attached to the camera's body, with that body at the
+// identity (no state is read), raw depth -- the camera-static layer.  mode 2: all other geoms, every ray starting from the static layer's depth.
 __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const float* __restrict__ xpose, long ld, int cam, int width,
                                                         int height, float tan_half_fovy, float max_depth, float* __restrict__ out,
                                                         const float* __restrict__ layer, int mode) {
@@ -324,8 +324,13 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
   if (tid < R.nrgeom) {
     const int g = R.rgeom[tid], b = R.geom_bodyid[g];
     float bp[3], bm[9];
-    for (int k = 0; k < 3; k++) bp[k] = xpose[(12 * b + k) * ld + env];
-    for (int k = 0; k < 9; k++) bm[k] = xpose[(12 * b + 3 + k) * ld + env];
+    if (mode == 1) {   // the static layer is a property of the model: camera body at the identity, no state involved
+      for (int k = 0; k < 3; k++) bp[k] = 0.f;
+      for (int k = 0; k < 9; k++) bm[k] = (k % 4 == 0) ? 1.f : 0.f;
+    } else {
+      for (int k = 0; k < 3; k++) bp[k] = xpose[(12 * b + k) * ld + env];
+      for (int k = 0; k < 9; k++) bm[k] = xpose[(12 * b + 3 + k) * ld + env];
+    }
     RGeom& G = geoms[tid];
     const float lp[3] = {R.geom_pos[3 * g], R.geom_pos[3 * g + 1], R.geom_pos[3 * g + 2]};
     const float lc[3] = {R.geom_bcenter[3 * g], R.geom_bcenter[3 * g + 1], R.geom_bcenter[3 * g + 2]};
@@ -345,8 +350,13 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
   if (tid == 255) {
     const int b = R.cam_bodyid[cam];
     float bp[3], bm[9];
-    for (int k = 0; k < 3; k++) bp[k] = xpose[(12 * b + k) * ld + env];
-    for (int k = 0; k < 9; k++) bm[k] = xpose[(12 * b + 3 + k) * ld + env];
+    if (mode == 1) {
+      for (int k = 0; k < 3; k++) bp[k] = 0.f;
+      for (int k = 0; k < 9; k++) bm[k] = (k % 4 == 0) ? 1.f : 0.f;
+    } else {
+      for (int k = 0; k < 3; k++) bp[k] = xpose[(12 * b + k) * ld + env];
+      for (int k = 0; k < 9; k++) bm[k] = xpose[(12 * b + 3 + k) * ld + env];
+    }
     float w[3];
     mul(w, bm, R.cam_pos + 3 * cam);
     for (int k = 0; k < 3; k++) cpos[k] = bp[k] + w[k];

@@ -83,6 +83,7 @@ def test_raw_render_and_errors():
         from stretch_mujoco_amd import StretchBatchSimulator
         StretchBatchSimulator(num_envs=1, device="cuda:0", cameras_to_use=[StretchCameras.cam_nav_rgb])
     sim = _sim(2, [StretchCameras.cam_d435i_depth])
+    sim.pull_camera_data()        # before any step: garbage poses must not poison the cached camera-static layer
     sim.qpos[:] = torch.tensor(sim_q(home_qpos(sim.model["qpos0"])), dtype=torch.float32, device=sim.device).unsqueeze(1)
     sim.step(1)
     L = lib.load()
@@ -94,6 +95,10 @@ def test_raw_render_and_errors():
     r = raw.cpu().numpy()
     assert np.isclose(r.max(), zfar, rtol=1e-6) and (r == r.max()).mean() > 0.1     # sky = far plane in the raw render
     assert torch.equal(raw[0], raw[1])                                              # identical envs, identical images
+    o = Oracle(sim._blob)
+    o.arr("qpos")[:] = sim_q(home_qpos(sim.model["qpos0"])); o.forward()
+    ref = o.render_depth(3, 106, 60, 42.0, 0.0)
+    assert (np.abs(r[0] - ref) <= 1e-4 + 1e-4 * np.abs(ref)).mean() > 0.995
     assert L.smj_render_depth(sim._ctx, 9, 106, 60, 42.0, 0.0, ctypes.c_void_p(raw.data_ptr()), sim._stream()) != 0
     assert b"camera id" in L.smj_last_error(sim._ctx)
     assert L.smj_render_depth(sim._ctx, 3, 106, 60, 42.0, 0.0, None, sim._stream()) != 0
