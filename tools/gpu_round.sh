@@ -1,11 +1,10 @@
 #!/bin/bash
-# pytest -m gpu, smoke, bench, rocprofv3 kernel-trace stats
+# One GPU round on a gpurun box: parity tests, smoke, bench, rocprofv3 evidence (summaries: tools/summarize_prof.py).
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/gpu_round.sh'
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
-tail -15 gpurun_out/pytest_gpu.log
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log; tail -3 gpurun_out/smoke.log
-timeout 900 python bench.py > gpurun_out/bench.log 2>&1; tail -1 gpurun_out/bench.log
-export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o smj -- python bench.py --steps 200 --warmup 50 --no-cpu-baseline > gpurun_out/prof_bench.log 2>&1
-ls -R gpurun_out/prof | head -30
+tail -4 gpurun_out/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log; tail -2 gpurun_out/smoke.log
+timeout 900 python bench.py > gpurun_out/bench.log 2>&1; tail -1 gpurun_out/bench.log > gpurun_out/bench_latest.json; cut -c1-400 gpurun_out/bench_latest.json
+bash tools/gpu_profile.sh | tail -2
