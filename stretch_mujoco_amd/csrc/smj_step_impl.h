@@ -880,16 +880,20 @@ struct StepKernel {
     for (int k = 0; k < 9; k++) lm[k] = M.k_geom_mat[9 * g + k];
     mulmat3(mat, s.xmat[b], lm);
   }
-  // per-lane: fill contact slot c
-  SMJ_DEV void write_contact(int c, int pair, int g1, int g2, float dist, const float* pos, const float* n) {
-    s.cdist[c] = dist;
-    float fr[9] = {n[0], n[1], n[2], 0, 0, 0, 0, 0, 0};
+  // [MJ] mju_makeFrame: fr[0:3] = normal given; tangents built around it
+  SMJ_DEV static void make_frame(float* fr) {
     normalize3(fr);
     if (fr[1] > -0.5f && fr[1] < 0.5f) { fr[3] = 0; fr[4] = 1; fr[5] = 0; } else { fr[3] = 0; fr[4] = 0; fr[5] = 1; }
     const float t = dot3(fr, fr + 3);
     for (int k = 0; k < 3; k++) fr[3 + k] -= t * fr[k];
     normalize3(fr + 3);
     cross3(fr + 6, fr, fr + 3);
+  }
+  // per-lane: fill contact slot c
+  SMJ_DEV void write_contact(int c, int pair, int g1, int g2, float dist, const float* pos, const float* n) {
+    s.cdist[c] = dist;
+    float fr[9] = {n[0], n[1], n[2], 0, 0, 0, 0, 0, 0};
+    make_frame(fr);
     for (int k = 0; k < 9; k++) s.cframe[c][k] = fr[k];
     for (int k = 0; k < 3; k++) s.cpos[c][k] = pos[k];
     for (int k = 0; k < 5; k++) { s.cfric[c][k] = M.pair_friction[5 * pair + k]; s.csolimp[c][k] = M.pair_solimp[5 * pair + k]; }
@@ -961,8 +965,26 @@ struct StepKernel {
             const uint64_t lt = (1ull << lane) - 1;
             const int off = ncon + popc64(m0 & lt) + 2 * popc64(m1 & lt) + 4 * popc64(m2 & lt);
             const int p = s.u.p.pair[lane], g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
-            for (int k = 0; k < c; k++)
-              if (off + k < NCON) write_contact(off + k, p, g1, g2, s.u.p.dist[lane][k], s.u.p.pos[lane][k], s.u.p.nrm[lane]);
+            // the contacts of one pair share normal, frame and parameters: fetch / build them once, then a fixed 4-slot loop
+            float fr[9] = {s.u.p.nrm[lane][0], s.u.p.nrm[lane][1], s.u.p.nrm[lane][2], 0, 0, 0, 0, 0, 0};
+            make_frame(fr);
+            float fric[5], simp[5];
+            for (int k = 0; k < 5; k++) { fric[k] = M.pair_friction[5 * p + k]; simp[k] = M.pair_solimp[5 * p + k]; }
+            const float sr0 = M.pair_solref[2 * p], sr1 = M.pair_solref[2 * p + 1], mg = M.pair_margin[p] - M.pair_gap[p];
+            const int cd = M.pair_condim[p];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const int ci = off + k;
+              if (k < c && ci < NCON) {
+                s.cdist[ci] = s.u.p.dist[lane][k];
+                for (int x = 0; x < 9; x++) s.cframe[ci][x] = fr[x];
+                for (int x = 0; x < 3; x++) s.cpos[ci][x] = s.u.p.pos[lane][k][x];
+                for (int x = 0; x < 5; x++) { s.cfric[ci][x] = fric[x]; s.csolimp[ci][x] = simp[x]; }
+                s.csolref[ci][0] = sr0; s.csolref[ci][1] = sr1;
+                s.cmargin[ci] = mg;
+                s.cdim[ci] = cd; s.cgeom1[ci] = g1; s.cgeom2[ci] = g2; s.cefc[ci] = -1;
+              }
+            }
           }
         }
         if (ncon + total > NCON) { flags |= SMJ_FLAG_CON_OVERFLOW; ncon = NCON; }
