@@ -1078,19 +1078,29 @@ struct StepKernel {
   // plane vs convex hull, vertices strided over lanes; same selection rule as oracle plane_hull()
   SMJ_DEV void plane_hull(int l, int g2, const float* pp, const float* n, const float* gp, const float* gm, float margin) {
     const float* verts = M.k_hull_vert4 + 4 * uni(M.geom_hulladr[g2]);
+    const Vec4* v4 = reinterpret_cast<const Vec4*>(verts);
     const int nvert = uni(M.geom_hullnum[g2]);
     float nl[3];
     mulmat3Tvec(nl, gm, n);
     const float off = (gp[0] - pp[0]) * n[0] + (gp[1] - pp[1]) * n[1] + (gp[2] - pp[2]) * n[2];
+    // Every pass scans the vertices strided over the lanes, four 16-byte loads in flight per lane (clamped tail: the last
+    // vertex may be visited twice, which changes neither an extreme nor its lowest index).
     // pass 1: deepest vertex (ties -> lowest index)
     PL<float> best;
     PL<int> bidx;
     LANES {
       float bd = 3.0e38f;
       int bi = -1;
-      for (int i = lane; i < nvert; i += 64) {
-        const float dd = nl[0] * verts[4 * i] + nl[1] * verts[4 * i + 1] + nl[2] * verts[4 * i + 2] + off;
-        if (dd <= margin && dd < bd) { bd = dd; bi = i; }
+      for (int i0 = lane; i0 < nvert; i0 += 256) {
+        Vec4 v[4];
+        int id[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { id[u] = i0 + 64 * u < nvert ? i0 + 64 * u : nvert - 1; v[u] = v4[id[u]]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const float dd = nl[0] * v[u].x + nl[1] * v[u].y + nl[2] * v[u].z + off;
+          if (dd <= margin && (dd < bd || (dd == bd && id[u] < bi))) { bd = dd; bi = id[u]; }
+        }
       }
       best[lane] = bd; bidx[lane] = bi;
     }
@@ -1103,12 +1113,18 @@ struct StepKernel {
       LANES {
         float bd = 1e-12f;
         int bi = -1;
-        for (int i = lane; i < nvert; i += 64) {
-          const float dd = nl[0] * verts[4 * i] + nl[1] * verts[4 * i + 1] + nl[2] * verts[4 * i + 2] + off;
-          if (dd > margin) continue;
-          const float e[3] = {verts[4 * i] - v1[0], verts[4 * i + 1] - v1[1], verts[4 * i + 2] - v1[2]};
-          const float r2 = dot3(e, e);
-          if (r2 > bd) { bd = r2; bi = i; }
+        for (int i0 = lane; i0 < nvert; i0 += 256) {
+          Vec4 v[4];
+          int id[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { id[u] = i0 + 64 * u < nvert ? i0 + 64 * u : nvert - 1; v[u] = v4[id[u]]; }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const float dd = nl[0] * v[u].x + nl[1] * v[u].y + nl[2] * v[u].z + off;
+            const float e[3] = {v[u].x - v1[0], v[u].y - v1[1], v[u].z - v1[2]};
+            const float r2 = dot3(e, e);
+            if (dd <= margin && (r2 > bd || (r2 == bd && bi >= 0 && id[u] < bi))) { bd = r2; bi = id[u]; }
+          }
         }
         best[lane] = bi >= 0 ? -bd : 3.0e38f; bidx[lane] = bi;
       }
@@ -1125,13 +1141,19 @@ struct StepKernel {
       LANES {
         float smax = 1e-6f, smin = -1e-6f;
         int i3 = -1, i4 = -1;
-        for (int i = lane; i < nvert; i += 64) {
-          const float dd = nl[0] * verts[4 * i] + nl[1] * verts[4 * i + 1] + nl[2] * verts[4 * i + 2] + off;
-          if (dd > margin) continue;
-          const float e[3] = {verts[4 * i] - v1[0], verts[4 * i + 1] - v1[1], verts[4 * i + 2] - v1[2]};
-          const float sv = dot3(e, side);
-          if (sv > smax) { smax = sv; i3 = i; }
-          if (sv < smin) { smin = sv; i4 = i; }
+        for (int i0 = lane; i0 < nvert; i0 += 256) {
+          Vec4 v[4];
+          int id[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { id[u] = i0 + 64 * u < nvert ? i0 + 64 * u : nvert - 1; v[u] = v4[id[u]]; }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const float dd = nl[0] * v[u].x + nl[1] * v[u].y + nl[2] * v[u].z + off;
+            const float e[3] = {v[u].x - v1[0], v[u].y - v1[1], v[u].z - v1[2]};
+            const float sv = dot3(e, side);
+            if (dd <= margin && (sv > smax || (sv == smax && i3 >= 0 && id[u] < i3))) { smax = sv; i3 = id[u]; }
+            if (dd <= margin && (sv < smin || (sv == smin && i4 >= 0 && id[u] < i4))) { smin = sv; i4 = id[u]; }
+          }
         }
         best[lane] = i3 >= 0 ? -smax : 3.0e38f; bidx[lane] = i3;
         bmin[lane] = i4 >= 0 ? smin : 3.0e38f; imin[lane] = i4;
