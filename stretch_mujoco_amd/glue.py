@@ -42,6 +42,10 @@ class Glue:
         self.bc_start = torch.zeros(3, B, **f)
         self.bc_inc = torch.zeros(B, **f)
         self.bc_v = torch.zeros(B, **f); self.bc_w = torch.zeros(B, **f)
+        # host-side hints: which command kinds were issued since the last push, and whether the base controller may be
+        # active -- so that an idle push_command() costs no device synchronisation at all
+        self._h = dict(bt=False, br=False, mb=False, mt=False, bv=False, kf=False)
+        self._h_base_live = False
 
     # ---------------------------------------------------------------- client side (stretch_mujoco_simulator.py)
     def _ids(self, env_ids):
@@ -64,6 +68,7 @@ class Glue:
         self.mt_val[i, ids] = pos
         self.mt_trig[i, ids] = True
         self.mt_has[i, ids] = True
+        self._h["mt"] = True
         self.mb_trig[i, ids] = False  # set_move_to pops move_by (status_command.py:53-57)
 
     def move_by(self, actuator, pos, env_ids=None):
@@ -73,19 +78,23 @@ class Glue:
         ids = self._ids(env_ids)
         if actuator == Actuators.base_translate:
             self.bt_val[ids] = pos; self.bt_trig[ids] = True
+            self._h["bt"] = True
             return
         if actuator == Actuators.base_rotate:
             self.br_val[ids] = pos; self.br_trig[ids] = True
+            self._h["br"] = True
             return
         i = CTRL_INDEX[actuator.name]
         self.mb_val[i, ids] = pos
         self.mb_trig[i, ids] = True
+        self._h["mb"] = True
         self.mt_trig[i, ids] = False  # set_move_by pops move_to (status_command.py:59-63)
         self.mt_has[i, ids] = False
 
     def set_base_velocity(self, v_linear, omega, env_ids=None):
         ids = self._ids(env_ids)
         self.bv_v[ids] = v_linear; self.bv_w[ids] = omega; self.bv_trig[ids] = True
+        self._h["bv"] = True
         # pops every base / wheel move (status_command.py:65-76)
         self.bt_trig[ids] = False; self.br_trig[ids] = False
 
@@ -96,6 +105,7 @@ class Glue:
             self.bt_trig[ids] = False; self.br_trig[ids] = False; self.bv_trig[ids] = False
         self.kf_id[ids] = self.key_names.index(name)
         self.kf_trig[ids] = True
+        self._h["kf"] = True
 
     def reset(self, env_ids=None):
         ids = self._ids(env_ids)
@@ -110,44 +120,55 @@ class Glue:
         """Fold pending commands into ctrl [nu,B] in place.  act_len [nu,B], base_pose [3,B] are the post-step readout."""
         g = CTRL_INDEX["gripper"]
         # move_by: base first (push to the controller), then joints
-        for trig, val, mode in ((self.bt_trig, self.bt_val, MODE_TRANSLATE), (self.br_trig, self.br_val, MODE_ROTATE)):
-            if bool(trig.any()):
+        h = self._h
+        if not (any(h.values()) or self._h_base_live):
+            return   # nothing was commanded since the last push and no base move is in flight
+        for key, trig, val, mode in (("bt", self.bt_trig, self.bt_val, MODE_TRANSLATE), ("br", self.br_trig, self.br_val, MODE_ROTATE)):
+            if h[key] and bool(trig.any()):
+                self._h_base_live = True
                 self.bc_mode = torch.where(trig, torch.full_like(self.bc_mode, mode), self.bc_mode)
                 self.bc_inc = torch.where(trig, val, self.bc_inc)
                 self.bc_start = torch.where(trig.unsqueeze(0), base_pose, self.bc_start)
                 trig.zero_()
-        if bool(self.mb_trig.any()):
+        if h["mb"] and bool(self.mb_trig.any()):
             target = act_len + self.mb_val
             target[g] = utils.to_sim_gripper_range(utils.to_real_gripper_range(act_len[g]) + self.mb_val[g])
             ctrl.copy_(torch.where(self.mb_trig, target, ctrl))
             self.mb_trig.zero_()
         # move_to
-        if bool(self.mt_trig.any()):
+        if h["mt"] and bool(self.mt_trig.any()):
             target = self.mt_val.clone()
             target[g] = utils.to_sim_gripper_range(self.mt_val[g])
             ctrl.copy_(torch.where(self.mt_trig, target, ctrl))
             self.mt_trig.zero_()
         # set_base_velocity
-        if bool(self.bv_trig.any()):
+        if h["bv"] and bool(self.bv_trig.any()):
+            self._h_base_live = True
             t = self.bv_trig
             self.bc_mode = torch.where(t, torch.full_like(self.bc_mode, MODE_VELOCITY), self.bc_mode)
             self.bc_v = torch.where(t, self.bv_v, self.bc_v); self.bc_w = torch.where(t, self.bv_w, self.bc_w)
             self.bc_start = torch.where(t.unsqueeze(0), base_pose, self.bc_start)
             t.zero_()
         # keyframe
-        if bool(self.kf_trig.any()):
+        if h["kf"] and bool(self.kf_trig.any()):
             kc = self.key_ctrl[self.kf_id].t()  # [nu,B]
             ctrl.copy_(torch.where(self.kf_trig.unsqueeze(0), kc, ctrl))
             self.kf_trig.zero_()
-        self._base_controller_update(ctrl, base_pose)
+        for k in h:
+            h[k] = False
+        if self._h_base_live:
+            self._base_controller_update(ctrl, base_pose)
 
     def base_active(self) -> bool:
         """True while any env has a relative base move in flight (needs per-step controller updates)."""
-        return bool(((self.bc_mode == MODE_TRANSLATE) | (self.bc_mode == MODE_ROTATE)).any())
+        if not (self._h_base_live or self._h["bt"] or self._h["br"]):
+            return False
+        return bool(((self.bc_mode == MODE_TRANSLATE) | (self.bc_mode == MODE_ROTATE)).any()) or self._h["bt"] or self._h["br"]
 
     def _base_controller_update(self, ctrl, pose):
         mode = self.bc_mode
         if not bool((mode != MODE_NONE).any()):
+            self._h_base_live = False
             return
         li, ri = CTRL_INDEX["left_wheel_vel"], CTRL_INDEX["right_wheel_vel"]
         one = torch.ones_like(self.bc_inc)
