@@ -100,6 +100,17 @@ def other_configs(B, dev, hold, solver):
     rays = B * (270 * 480 + 240 * 424)
     res["depth_both_cameras"] = {"ms_per_render": dt * 1e3, "rays_per_s": rays / dt, "bytes_written_per_s": 4 * rays / dt,
                                  "note": "d405 270x480 + d435i 240x424 per env, kitchen stand-in; at 30 Hz sim-time one render per 17 steps"}
+    # config 5 shape on one GPU: kitchen stand-in, both depth cameras every 17 steps (30 Hz sim-time), physics in between
+    torch.cuda.synchronize(dev)
+    t = time.perf_counter()
+    n = 0
+    for _ in range(6):
+        sim.step(17)
+        sim.pull_camera_data()
+        n += 17
+    torch.cuda.synchronize(dev)
+    res["kitchen_with_depth_30hz"] = {"value": B * n / (time.perf_counter() - t), "unit": "env-steps/s",
+                                      "note": "whole loop: 17 physics steps + one render of both depth cameras, repeated"}
     sim.stop()
     return res
 
