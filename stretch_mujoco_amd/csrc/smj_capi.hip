@@ -121,7 +121,7 @@ static int setup_render(smj_ctx* c, const void* blob, size_t nbytes) {
   if (!r.lgeom || !r.lidar_site || !r.lidar_static) return fail(c, -2, "device allocation failed for the lidar tables");
   r.geom_type = c->model.geom_type; r.geom_bodyid = c->model.geom_bodyid; r.geom_pos = c->model.geom_pos;
   r.geom_mat = c->model.k_geom_mat; r.geom_size = c->model.geom_size; r.geom_rbound = c->model.geom_rbound;
-  r.geom_bcenter = c->model.k_geom_bcenter;
+  r.geom_bcenter = c->model.k_geom_bcenter; r.geom_aabb = c->model.geom_aabb;
   // BVHs
   const std::vector<int> vadr = geti(va), vnum = geti(vn), fadr = geti(fa), fnum = geti(fn);
   const float* verts = reinterpret_cast<const float*>(b.p + rv->offset);

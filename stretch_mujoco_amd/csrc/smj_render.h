@@ -17,6 +17,7 @@ struct DevRender {
   const float* geom_size;          // [ngeom][3]
   const float* geom_rbound;        // [ngeom]
   const float* geom_bcenter;       // [ngeom][3]  bounding-sphere centre, body frame
+  const float* geom_aabb;          // [ngeom][6]  box in the geom frame: centre, half sizes
   const int* cam_bodyid;           // [ncam]
   const float* cam_pos;            // [ncam][3]
   const float* cam_mat;            // [ncam][9]

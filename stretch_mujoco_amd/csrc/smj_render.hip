@@ -378,10 +378,10 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
     float key = -1.f;
     if (G.type != RT_PLANE) {
       key = dist - r;
+      // tile cone: axis through the tile centre, half angle alpha to the farthest tile corner (camera frame, -z forward)
+      const float xc = ((tx * 16 + 8.f) / width * 2.f - 1.f) * tan_half_fovy * aspect, yc = (1.f - (ty * 16 + 8.f) / height * 2.f) * tan_half_fovy;
+      const float hx = 16.f / width * tan_half_fovy * aspect, hy = 16.f / height * tan_half_fovy;   // half tile size at z = -1
       if (dist > r) {
-        // tile cone: axis through the tile centre, half angle alpha to the farthest tile corner (camera frame, -z forward)
-        const float xc = ((tx * 16 + 8.f) / width * 2.f - 1.f) * tan_half_fovy * aspect, yc = (1.f - (ty * 16 + 8.f) / height * 2.f) * tan_half_fovy;
-        const float hx = 16.f / width * tan_half_fovy * aspect, hy = 16.f / height * tan_half_fovy;   // half tile size at z = -1
         const float cl = sqrtf(xc * xc + yc * yc + 1.f);
         float cosa = 1.f, dlmax = 0.f;
         for (int k = 0; k < 4; k++) {
@@ -399,6 +399,34 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
         const float cost = dot3(dc, aw) / dist;             // angle between the cone axis and the sphere centre
         if (cost < cosab - 1e-4f) key = 3.0e38f;            // outside the cone widened by the sphere
         if (dist - r > tfar * dlmax) key = 3.0e38f;         // beyond the depth range for every ray of the tile
+      }
+      if (key < 1.0e38f && G.type == RT_MESH) {
+        // the mesh's box (geom frame) against the tile's frustum: drop the geom when all eight corners lie outside one of
+        // the four side planes (planes through the eye) or in front of the near / beyond the far plane.  Long thin parts
+        // (fingers, arm segments) have large bounding spheres but project onto few tiles.
+        const float* bb = R.geom_aabb + 6 * R.rgeom[tid];
+        const float x0 = xc - hx, x1 = xc + hx, y0 = yc - hy, y1 = yc + hy;
+        int out = 63;   // bit k set: every corner so far is outside plane k
+        for (int cidx = 0; cidx < 8; cidx++) {
+          const float pad = 1e-5f;   // the box was taken before the vertices were rounded to fp32
+          const float lc[3] = {bb[0] + ((cidx & 1) ? bb[3] + pad : -bb[3] - pad), bb[1] + ((cidx & 2) ? bb[4] + pad : -bb[4] - pad),
+                               bb[2] + ((cidx & 4) ? bb[5] + pad : -bb[5] - pad)};
+          float w[3], pc[3];
+          mul(w, G.mat, lc);
+          const float dw[3] = {G.pos[0] + w[0] - cpos[0], G.pos[1] + w[1] - cpos[1], G.pos[2] + w[2] - cpos[2]};
+          mulT(pc, cmat, dw);
+          const float zd = -pc[2];   // distance along the optical axis
+          const float e = 1e-5f * (fabsf(pc[0]) + fabsf(pc[1]) + fabsf(zd)) + 1e-6f;   // stay conservative under round-off
+          int o = 0;
+          if (pc[0] - x1 * zd > e) o |= 1;
+          if (pc[0] - x0 * zd < -e) o |= 2;
+          if (pc[1] - y1 * zd > e) o |= 4;
+          if (pc[1] - y0 * zd < -e) o |= 8;
+          if (zd < R.znear - e) o |= 16;
+          if (zd > tfar + e) o |= 32;
+          out &= o;
+        }
+        if (out) key = 3.0e38f;
       }
     }
     if (mode != 0) {
