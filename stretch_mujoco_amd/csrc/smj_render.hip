@@ -447,7 +447,9 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
     if (tid == 0) nkeep = kept;
   }
   __syncthreads();
-  const int u = tx * 16 + (tid & 15), v = ty * 16 + (tid >> 4);
+  // each wavefront covers an 8x8 pixel square of the tile (not a 16x4 strip): neighbouring rays share more of their walk
+  const int wv = tid >> 6, ln = tid & 63;
+  const int u = tx * 16 + (wv & 1) * 8 + (ln & 7), v = ty * 16 + (wv >> 1) * 8 + (ln >> 3);
   if (u >= width || v >= height) return;
   // pixel centre -> ray in the camera frame (x right, y up, looking down -z); parameter t = distance along the optical axis
   const float xn = ((u + 0.5f) / width * 2.f - 1.f) * tan_half_fovy * aspect;
