@@ -14,6 +14,8 @@
 
 namespace {
 
+constexpr int TILE = 16;   // pixels per side of a workgroup's tile (32 was measured slower: coarser culling outweighs the shared staging)
+
 struct RGeom {
   float pos[3], mat[9], cen[3], rbound, size[3];
   int type, rmesh;
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
   __shared__ float cpos[3], cmat[9], gkey[SMJ_RGEOM_MAX];
   __shared__ int gorder[SMJ_RGEOM_MAX], nkeep;
   const int env = blockIdx.y;
-  const int tiles_x = (width + 15) / 16;
+  const int tiles_x = (width + TILE - 1) / TILE;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
   const int tid = threadIdx.x;
   // stage camera and geom world poses of this env
@@ -379,8 +381,8 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
     if (G.type != RT_PLANE) {
       key = dist - r;
       // tile cone: axis through the tile centre, half angle alpha to the farthest tile corner (camera frame, -z forward)
-      const float xc = ((tx * 16 + 8.f) / width * 2.f - 1.f) * tan_half_fovy * aspect, yc = (1.f - (ty * 16 + 8.f) / height * 2.f) * tan_half_fovy;
-      const float hx = 16.f / width * tan_half_fovy * aspect, hy = 16.f / height * tan_half_fovy;   // half tile size at z = -1
+      const float xc = ((tx * TILE + 0.5f * TILE) / width * 2.f - 1.f) * tan_half_fovy * aspect, yc = (1.f - (ty * TILE + 0.5f * TILE) / height * 2.f) * tan_half_fovy;
+      const float hx = (float)TILE / width * tan_half_fovy * aspect, hy = (float)TILE / height * tan_half_fovy;   // half tile size at z = -1
       if (dist > r) {
         const float cl = sqrtf(xc * xc + yc * yc + 1.f);
         float cosa = 1.f, dlmax = 0.f;
@@ -447,45 +449,49 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
     if (tid == 0) nkeep = kept;
   }
   __syncthreads();
-  // each wavefront covers an 8x8 pixel square of the tile (not a 16x4 strip): neighbouring rays share more of their walk
+  // A workgroup renders a TILE x TILE pixel tile with its 256 threads in (TILE/16)^2 rounds; each wavefront covers an 8x8
+  // pixel square (not a 16x4 strip): neighbouring rays share more of their walk.  The staging and culling above are paid
+  // once per tile, which is why the tile is larger than one round.
   const int wv = tid >> 6, ln = tid & 63;
-  const int u = tx * 16 + (wv & 1) * 8 + (ln & 7), v = ty * 16 + (wv >> 1) * 8 + (ln >> 3);
-  if (u >= width || v >= height) return;
-  // pixel centre -> ray in the camera frame (x right, y up, looking down -z); parameter t = distance along the optical axis
-  const float xn = ((u + 0.5f) / width * 2.f - 1.f) * tan_half_fovy * aspect;
-  const float yn = (1.f - (v + 0.5f) / height * 2.f) * tan_half_fovy;
-  const float dc[3] = {xn, yn, -1.f};
-  float d[3], o[3] = {cpos[0], cpos[1], cpos[2]};
-  mul(d, cmat, dc);
-  const float dd = dot3(d, d), dl = sqrtf(dd);
   const float tnear = R.znear;
-  float best = tfar * (1.f + 1e-6f);
-  if (mode == 2) best = fminf(best, layer[(long)v * width + u]);
   const int ng = nkeep;
-  for (int i = 0; i < ng; i++) {
-    const RGeom& G = geoms[gorder[i]];
-    if (G.type != RT_PLANE) {   // bounding sphere
-      const float oc[3] = {G.cen[0] - o[0], G.cen[1] - o[1], G.cen[2] - o[2]};
-      const float b = dot3(oc, d), r = G.rbound;
-      if (dot3(oc, oc) * dd - b * b > r * r * dd) continue;
-      if (b + r * dl < tnear * dd || b - r * dl > best * dd) continue;
+  for (int rd = 0; rd < (TILE / 16) * (TILE / 16); rd++) {
+    const int u = tx * TILE + (rd % (TILE / 16)) * 16 + (wv & 1) * 8 + (ln & 7), v = ty * TILE + (rd / (TILE / 16)) * 16 + (wv >> 1) * 8 + (ln >> 3);
+    if (u >= width || v >= height) continue;
+    // pixel centre -> ray in the camera frame (x right, y up, looking down -z); parameter t = distance along the optical axis
+    const float xn = ((u + 0.5f) / width * 2.f - 1.f) * tan_half_fovy * aspect;
+    const float yn = (1.f - (v + 0.5f) / height * 2.f) * tan_half_fovy;
+    const float dc[3] = {xn, yn, -1.f};
+    float d[3], o[3] = {cpos[0], cpos[1], cpos[2]};
+    mul(d, cmat, dc);
+    const float dd = dot3(d, d), dl = sqrtf(dd);
+    float best = tfar * (1.f + 1e-6f);
+    if (mode == 2) best = fminf(best, layer[(long)v * width + u]);
+    for (int i = 0; i < ng; i++) {
+      const RGeom& G = geoms[gorder[i]];
+      if (G.type != RT_PLANE) {   // bounding sphere
+        const float oc[3] = {G.cen[0] - o[0], G.cen[1] - o[1], G.cen[2] - o[2]};
+        const float b = dot3(oc, d), r = G.rbound;
+        if (dot3(oc, oc) * dd - b * b > r * r * dd) continue;
+        if (b + r * dl < tnear * dd || b - r * dl > best * dd) continue;
+      }
+      const float dif[3] = {o[0] - G.pos[0], o[1] - G.pos[1], o[2] - G.pos[2]};
+      float lp[3], lv[3];
+      mulT(lp, G.mat, dif);
+      mulT(lv, G.mat, d);
+      if (G.type == RT_MESH) {
+        if (G.rmesh >= 0) best = ray_mesh<true>(R, G.rmesh, lp, lv, tnear, best);
+      } else {
+        const float x = ray_prim(G.type, G.size, lp, lv, tnear);
+        if (x >= 0 && x < best) best = x;
+      }
     }
-    const float dif[3] = {o[0] - G.pos[0], o[1] - G.pos[1], o[2] - G.pos[2]};
-    float lp[3], lv[3];
-    mulT(lp, G.mat, dif);
-    mulT(lv, G.mat, d);
-    if (G.type == RT_MESH) {
-      if (G.rmesh >= 0) best = ray_mesh<true>(R, G.rmesh, lp, lv, tnear, best);
-    } else {
-      const float x = ray_prim(G.type, G.size, lp, lv, tnear);
-      if (x >= 0 && x < best) best = x;
-    }
+    float z = best;
+    if (mode == 1) { out[(long)v * width + u] = z; continue; }   // raw nearest depth (or just beyond the far plane)
+    if (z > tfar) z = (max_depth > 0.f) ? 0.f : R.zfar;   // nothing in range: the far plane, which limit_depth_distance zeroes
+    if (max_depth > 0.f && z > max_depth) z = 0.f;
+    out[((long)env * height + v) * width + u] = z;
   }
-  float z = best;
-  if (mode == 1) { out[(long)v * width + u] = z; return; }   // raw nearest depth (or just beyond the far plane)
-  if (z > tfar) z = (max_depth > 0.f) ? 0.f : R.zfar;   // nothing in range: the far plane, which limit_depth_distance zeroes
-  if (max_depth > 0.f && z > max_depth) z = 0.f;
-  out[((long)env * height + v) * width + u] = z;
 }
 
 }  // namespace
@@ -495,7 +501,7 @@ void smj_launch_lidar(const DevRender& r, const float* xpose, long ld, int num_e
 }
 void smj_launch_depth(const DevRender& r, const float* xpose, long ld, int num_envs, int cam, int width, int height,
                       float fovy_deg, float max_depth, float* out, const float* layer, int mode, hipStream_t stream) {
-  const int tiles = ((width + 15) / 16) * ((height + 15) / 16);
+  const int tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
   const float th = tanf(fovy_deg * 3.14159265358979323846f / 360.f);
   hipLaunchKernelGGL(smj_depth_kernel, dim3(tiles, mode == 1 ? 1 : num_envs), dim3(256), 0, stream, r, xpose, ld, cam, width, height, th,
                      mode == 1 ? 0.f : max_depth, out, layer, mode);
