@@ -219,7 +219,7 @@ def test_capacity_overflow_is_flagged():
     sim.stop()
 
 
-@pytest.mark.parametrize("B,solver", [(1024, "pgs"), (4096, "newton")])
+@pytest.mark.parametrize("B,solver", [(1024, "pgs"), (4096, "newton"), (32768, "newton")])
 def test_full_batch_properties(B, solver):
     """BASELINE.json sizes.  Size-independent properties: (1) envs are independent -- a permutation of the inputs
     permutes the outputs bitwise; (2) unit quaternion; (3) equality constraints hold (arm segments equal,
