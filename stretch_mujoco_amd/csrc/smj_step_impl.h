@@ -1663,9 +1663,18 @@ struct StepKernel {
         for (int x = 0; x < 6; x++) s.u.k.cd[lane][x] = lane < nv ? cdof[lane][x] : 0.f;
     }
     for (int c = 0; c < ncon; c++) {
-      const int d = wave_read(cdimv, c);
+      int d = wave_read(cdimv, c);
       if (!wave_read(cact, c)) continue;
-      if (row0 + d > NEFC) { flags |= SMJ_FLAG_EFC_OVERFLOW; continue; }
+      if (row0 + d > NEFC) {
+        // Out of rows (flagged: the result is outside parity from here on).  Degrade gracefully instead of dropping the
+        // contact: give up its rolling / torsional rows first, then its friction, and only then the contact itself -- a
+        // contact that keeps its normal row still prevents penetration.
+        flags |= SMJ_FLAG_EFC_OVERFLOW;
+        if (d > 3 && row0 + 3 <= NEFC) d = 3;
+        else if (row0 + 1 <= NEFC) d = 1;
+        else continue;
+        LANES { if (lane == c) { cdimv[lane] = d; s.cdim[c] = d; } }
+      }
       LANES { if (lane == c) crow[lane] = row0; }
       row0 += d;
     }
@@ -2433,8 +2442,10 @@ struct StepKernel {
         LANES {
           const int c = c0 + (lane >> 5), k = lane & 31;
           const int r0 = c < ncon ? s.cefc[c] : -1;
-          if (r0 >= 0 && (int)s.earef[r0] == 4) {   // block state as broadcast by newton_update
-            const int dim = s.cdim[c];
+          const int dim = c < ncon ? s.cdim[c] : 0;
+          // block state as broadcast by newton_update -- which writes it for elliptic blocks only: a frictionless contact
+          // (dim 1) must be excluded here, its earef slot holds unrelated data
+          if (r0 >= 0 && dim >= 3 && (int)s.earef[r0] == 4) {
             float j[6], h[36];
 #pragma unroll
             for (int q = 0; q < 6; q++) j[q] = s.J[r0 + (q < dim ? q : 0)][k];

@@ -49,6 +49,10 @@ class Emul:
     def set_option(self, name, v):
         assert self.L.emul_set_option(self.c, name.encode(), float(v)) == 0
 
+    def set_poison(self, byte):
+        """Fill the emulated LDS with `byte` before every launch (-1: leave whatever the previous launch left)."""
+        self.L.emul_set_poison(int(byte))
+
     def step(self, n=1, read_flags=0):
         self.L.emul_step(self.c, n, read_flags)
 

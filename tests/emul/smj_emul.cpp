@@ -89,8 +89,12 @@ int emul_set_option(emul_ctx* c, const char* name, double v) {
   else return -1;
   return 0;
 }
+// LDS is uninitialised when a workgroup starts: tests poison the emulated LDS to catch reads before writes
+int emul_poison = -1;
+void emul_set_poison(int byte) { emul_poison = byte; }
 int emul_step(emul_ctx* c, int nsteps, unsigned read_flags) {
   for (int env = 0; env < c->s.B; env++) {
+    if (emul_poison >= 0) memset(&c->smem, emul_poison, sizeof(Smem));
     StepKernel* k = new StepKernel(c->m, c->s, c->smem, env);
     k->run(nsteps, read_flags);
     delete k;

@@ -237,3 +237,31 @@ def test_bad_state_resets_and_flags(blob_fused):
     e.step(2)
     assert e.info[3, 1] & 4 and not (e.info[3, 0] & 4)
     assert np.isfinite(e.qpos).all() and np.isfinite(e.qvel).all()
+
+
+def test_no_read_of_uninitialised_lds(blob_fused):
+    """LDS holds whatever the previous workgroup left.  The emulator fills it with different byte patterns before every
+    launch (zeros, large finite values, NaNs): the trajectories of contact-rich random rollouts must not depend on it."""
+    from stretch_mujoco_amd import model_blob
+
+    m = model_blob.loads(blob_fused)
+    rng = np.random.default_rng(11)
+    cr = m["actuator_ctrlrange"]
+    n = 16
+    ctrls = cr[:, 0] + (cr[:, 1] - cr[:, 0]) * rng.random((n, 10))
+    ref = None
+    for poison in (0x00, 0x7F, 0xFF):
+        e = Emul(blob_fused, DIMS, num_envs=n); e.set_option("solver", 2); e.set_poison(poison)
+        e.qpos[:] = home_qpos(m["qpos0"])[:, None]; e.ctrl[:] = ctrls.T
+        out = []
+        for _ in range(30):
+            e.step(4, 1)
+            out.append(np.concatenate([e.qpos, e.qvel, e.gyro, e.accel]).copy())
+        e.set_poison(-1)
+        out = np.array(out)
+        assert np.isfinite(out).all()
+        if ref is None:
+            ref = out
+        else:
+            assert np.array_equal(out, ref), hex(poison)
+

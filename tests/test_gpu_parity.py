@@ -289,3 +289,29 @@ def test_lidar_floor_and_moving_meshes_vs_oracle():
         seen += int((ref > 0).sum())
     assert (L[1] > 0).sum() > 100 and (L[2] > 0).sum() > 60 and seen > 200
     sim.stop()
+
+
+def test_bitwise_determinism_across_runs():
+    """Two independent runs of the same rollout agree bitwise after every launch (not only at the end, where a damped system
+    may have forgotten a one-ulp difference).  Catches reads of uninitialised LDS / registers / scratch, whose content
+    depends on what ran on the compute unit before."""
+    B = 2048
+
+    def run():
+        sim = _sim(B, solver="newton")
+        g = torch.Generator(device=sim.device).manual_seed(7)
+        lo = torch.tensor(sim.model["actuator_ctrlrange"][:, 0], dtype=torch.float32, device=sim.device).unsqueeze(1)
+        hi = torch.tensor(sim.model["actuator_ctrlrange"][:, 1], dtype=torch.float32, device=sim.device).unsqueeze(1)
+        sim.qpos[:] = torch.tensor(home_qpos(sim.model["qpos0"]), dtype=torch.float32, device=sim.device).unsqueeze(1)
+        out = []
+        for k in range(24):
+            if k % 8 == 0:
+                sim.ctrl.copy_(lo + (hi - lo) * torch.rand(10, B, generator=g, device=sim.device))
+            sim.step(10)
+            out.append((sim.qpos.clone(), sim.qvel.clone(), sim.info.clone()))
+        sim.stop()
+        return out
+    a, b = run(), run()
+    for k, ((qa, va, ia), (qb, vb, ib)) in enumerate(zip(a, b)):
+        assert torch.equal(qa, qb) and torch.equal(va, vb) and torch.equal(ia, ib), (k, int((qa != qb).any(0).sum()))
+
