@@ -57,6 +57,7 @@ struct Smem {
   float qpos[NVP + 8], qvel[NVP], ctrl[16], g[NVP], uu[NVP], w[NVP], qacc[NVP], warm[NVP], tmp[NVP];
   float act_force[16], act_len[16], act_vel[16], act_free[16];
   int etype[NEFC], eid[NEFC];
+  int estate[NEFC];   // Newton: state of every row as of the last constraint update (cone blocks: the block's state)
   float epos[NEFC], emargin[NEFC], ediag[NEFC], efloss[NEFC], eR[NEFC], eK[NEFC], eBv[NEFC], eimp[NEFC], earef[NEFC],
       eb[NEFC], ef[NEFC];
   float cpos[NCON][3], cframe[NCON][9], cdist[NCON], cfric[NCON][5], csolref[NCON][2], csolimp[NCON][5], cmargin[NCON];
@@ -2176,12 +2177,13 @@ struct StepKernel {
         cost[lane] += cc;
 #pragma unroll
         for (int j = 0; j < 6; j++)
-          if (j < dim) { s.ef[i + j] = ef[j]; s.earef[i + j] = (float)st; }   // block state broadcast through LDS
+          if (j < dim) { s.ef[i + j] = ef[j]; s.estate[i + j] = st; }   // block state broadcast through LDS
       }
     }
     SYNC();
     LANES {
-      if (nr.type[lane] == CT_CONTACT_ELLIPTIC && lane < ne) { nr.force[lane] = s.ef[lane]; nr.state[lane] = (int)s.earef[lane]; }
+      if (nr.type[lane] == CT_CONTACT_ELLIPTIC && lane < ne) { nr.force[lane] = s.ef[lane]; nr.state[lane] = s.estate[lane]; }
+      s.estate[lane] = lane < ne ? nr.state[lane] : 0;   // every row's state, for stages that are not mapped lane = row
     }
     return wave_sum(cost);
   }
@@ -2443,9 +2445,7 @@ struct StepKernel {
           const int c = c0 + (lane >> 5), k = lane & 31;
           const int r0 = c < ncon ? s.cefc[c] : -1;
           const int dim = c < ncon ? s.cdim[c] : 0;
-          // block state as broadcast by newton_update -- which writes it for elliptic blocks only: a frictionless contact
-          // (dim 1) must be excluded here, its earef slot holds unrelated data
-          if (r0 >= 0 && dim >= 3 && (int)s.earef[r0] == 4) {
+          if (r0 >= 0 && dim >= 3 && s.estate[r0] == 4) {   // row states as left by newton_update
             float j[6], h[36];
 #pragma unroll
             for (int q = 0; q < 6; q++) j[q] = s.J[r0 + (q < dim ? q : 0)][k];
