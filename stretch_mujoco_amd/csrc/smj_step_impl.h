@@ -1267,11 +1267,26 @@ struct StepKernel {
     const float n = sqrtf(dot3(dir, dir));
     if (n > 0) for (int i = 0; i < 3; i++) dir[i] /= n;
   }
+  // P[t] <- q when `on`, component by component (selects): struct assignments under branches make the compiler address
+  // the portal array dynamically, which would put it in scratch memory
+  template <int T>
+  SMJ_DEV static void portal_set(MprPt* P, const MprPt& q, bool on) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      P[T].v[i] = on ? q.v[i] : P[T].v[i];
+      P[T].a[i] = on ? q.a[i] : P[T].a[i];
+      P[T].b[i] = on ? q.b[i] : P[T].b[i];
+    }
+  }
   SMJ_DEV static void expand_portal(MprPt* P, const MprPt& v4) {
     float v4v0[3];
     cross3(v4v0, v4.v, P[0].v);
-    if (dot3(P[1].v, v4v0) > 0) { if (dot3(P[2].v, v4v0) > 0) P[1] = v4; else P[3] = v4; }
-    else { if (dot3(P[3].v, v4v0) > 0) P[2] = v4; else P[1] = v4; }
+    int t;
+    if (dot3(P[1].v, v4v0) > 0) t = dot3(P[2].v, v4v0) > 0 ? 1 : 3;
+    else t = dot3(P[3].v, v4v0) > 0 ? 2 : 1;
+    portal_set<1>(P, v4, t == 1);
+    portal_set<2>(P, v4, t == 2);
+    portal_set<3>(P, v4, t == 3);
   }
   SMJ_DEV static bool reach_tolerance(const MprPt* P, const MprPt& v4, const float* dir, float tol) {
     const float dv4 = dot3(v4.v, dir);
@@ -1334,7 +1349,18 @@ struct StepKernel {
     for (int i = 0; i < 3; i++) { va[i] = P[1].v[i] - P[0].v[i]; vb[i] = P[2].v[i] - P[0].v[i]; }
     cross3(dir, va, vb);
     normalize3(dir);
-    if (dot3(dir, P[0].v) > 0) { const MprPt t = P[1]; P[1] = P[2]; P[2] = t; for (int i = 0; i < 3; i++) dir[i] = -dir[i]; }
+    {   // swap P[1] and P[2] when the portal faces away from the origin -- by per-component selects: a struct swap under a
+        // branch makes the compiler address the portal array dynamically, which puts it in scratch memory
+      const bool sw = dot3(dir, P[0].v) > 0;
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const float v1 = P[1].v[i], v2 = P[2].v[i], a1 = P[1].a[i], a2 = P[2].a[i], b1 = P[1].b[i], b2 = P[2].b[i];
+        P[1].v[i] = sw ? v2 : v1; P[2].v[i] = sw ? v1 : v2;
+        P[1].a[i] = sw ? a2 : a1; P[2].a[i] = sw ? a1 : a2;
+        P[1].b[i] = sw ? b2 : b1; P[2].b[i] = sw ? b1 : b2;
+        dir[i] = sw ? -dir[i] : dir[i];
+      }
+    }
     for (int it = 0;; it++) {
       if (it > 100) return false;
       mpr_support(A, Bs, dir, P[3]);
@@ -1343,11 +1369,11 @@ struct StepKernel {
       bool cont = false;
       cross3(va, P[1].v, P[3].v);
       dot = dot3(va, P[0].v);
-      if (dot < 0 && !ccd_zero(dot)) { P[2] = P[3]; cont = true; }
+      if (dot < 0 && !ccd_zero(dot)) { const MprPt q = P[3]; portal_set<2>(P, q, true); cont = true; }
       if (!cont) {
         cross3(va, P[3].v, P[2].v);
         dot = dot3(va, P[0].v);
-        if (dot < 0 && !ccd_zero(dot)) { P[1] = P[3]; cont = true; }
+        if (dot < 0 && !ccd_zero(dot)) { const MprPt q = P[3]; portal_set<1>(P, q, true); cont = true; }
       }
       if (!cont) break;
       for (int i = 0; i < 3; i++) { va[i] = P[1].v[i] - P[0].v[i]; vb[i] = P[2].v[i] - P[0].v[i]; }
@@ -1384,9 +1410,10 @@ struct StepKernel {
           sum = b[1] + b[2] + b[3];
         }
         if (!(fabsf(sum) > 1e-30f)) { b[0] = 0; b[1] = b[2] = b[3] = 1; sum = 3; }   // exactly touching faces
-        for (int i = 0; i < 3; i++) {
-          float p1 = 0, p2 = 0;
-          for (int k = 0; k < 4; k++) { p1 += b[k] * P[k].a[i]; p2 += b[k] * P[k].b[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {   // static indices only: a dynamically indexed portal array would live in scratch memory
+          const float p1 = b[0] * P[0].a[i] + b[1] * P[1].a[i] + b[2] * P[2].a[i] + b[3] * P[3].a[i];
+          const float p2 = b[0] * P[0].b[i] + b[1] * P[1].b[i] + b[2] * P[2].b[i] + b[3] * P[3].b[i];
           pos[i] = 0.5f * (p1 + p2) / sum;
         }
         return true;
