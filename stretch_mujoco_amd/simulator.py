@@ -47,8 +47,15 @@ class StretchBatchSimulator:
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
         if model_blob_bytes is None:
-            with open(os.path.join(_MODELS, scene + ".smjb"), "rb") as f:
-                model_blob_bytes = f.read()
+            if scene.endswith(".xml"):
+                # any MJCF scene that includes stretch.xml (the reference's `scene_xml_path`, stretch_mujoco_simulator.py:47-55):
+                # compiled here with the build's own MJCF compiler; needs the mesh assets next to the XML
+                from . import mjcf_compiler, model_fuse
+
+                model_blob_bytes = model_blob.dumps(model_fuse.prepare_for_kernels(mjcf_compiler.compile_file(scene)))
+            else:
+                with open(os.path.join(_MODELS, scene + ".smjb"), "rb") as f:
+                    model_blob_bytes = f.read()
         self._blob = model_blob_bytes
         self.model = model_blob.loads(model_blob_bytes)
         self.names = json.loads(model_blob.get_str(self.model, "names_json"))

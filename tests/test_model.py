@@ -148,3 +148,25 @@ def test_static_lidar_table_sees_the_mast(blob_full):
         elif L[i] >= 0:
             assert L[i] > 0.02   # some other welded geom; must not be the laser's own body
     assert hits >= 8 and (L >= 0).sum() >= hits
+
+
+def test_simulator_compiles_a_scene_xml(tmp_path):
+    """`scene="…xml"`: the reference lets the user pass any scene that includes stretch.xml (scene_xml_path); here it goes
+    through the build's MJCF compiler.  Needs the reference's assets, so it only runs where /root/reference is mounted."""
+    import os
+
+    stretch = "/root/reference/stretch_mujoco/models/stretch.xml"
+    if not os.path.exists(stretch):
+        pytest.skip("reference assets not mounted")
+    from stretch_mujoco_amd import StretchBatchSimulator, model_blob
+
+    xml = tmp_path / "my_scene.xml"
+    xml.write_text(f'<mujoco model="mine"><include file="{stretch}"/><worldbody><geom name="floor" type="plane" size="0 0 0.05"/>'
+                   '<geom name="crate" type="box" pos="1.2 0 0.2" size="0.2 0.3 0.2"/></worldbody></mujoco>')
+    sim = StretchBatchSimulator(num_envs=2, device="cpu", scene=str(xml))
+    m = sim.model
+    assert int(m["dims"][0]) == 27 and int(m["dims"][5]) == 127 and int(m["k_nconvpair"][0]) == 848 + 51
+    mm = model_blob.loads(sim._blob)
+    assert sum(1 for g in range(127) if mm["geom_type"][g] == 6 and mm["geom_bodyid"][g] == 0) == 1    # the crate, on the world body
+    with pytest.raises(Exception):
+        sim.start()          # no CPU fallback for the physics path
