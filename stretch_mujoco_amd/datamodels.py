@@ -5,7 +5,7 @@ Tensors returned by `pull_*` are fresh copies (the reference returns fresh pickl
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Any, Optional
 
 

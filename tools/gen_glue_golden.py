@@ -14,7 +14,6 @@ import json
 import os
 import sys
 import tempfile
-import types
 
 import numpy as np
 
