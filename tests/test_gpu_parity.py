@@ -315,3 +315,33 @@ def test_bitwise_determinism_across_runs():
     for k, ((qa, va, ia), (qb, vb, ib)) in enumerate(zip(a, b)):
         assert torch.equal(qa, qb) and torch.equal(va, vb) and torch.equal(ia, ib), (k, int((qa != qb).any(0).sum()))
 
+
+def test_per_env_start_pose():
+    """examples/start_pose.py, batched: every env starts at its own planar pose (change_start_pose, mujoco_server.py:206-229);
+    the robot settles where it was put, and a masked reset brings an env back to ITS start pose."""
+    from stretch_mujoco_amd import StretchBatchSimulator
+
+    B = 6
+    xy = torch.tensor([[0.0, 0.0], [1.0, -2.0], [-3.0, 0.5], [2.0, 2.0], [0.3, 0.3], [-1.0, -1.0]])
+    yaw = torch.tensor([0.0, 0.5, -1.0, 2.0, 3.0, -2.5])
+    trans = torch.cat([xy, torch.zeros(B, 1)], dim=1)
+    quat = torch.stack([torch.cos(yaw / 2), torch.zeros(B), torch.zeros(B), torch.sin(yaw / 2)], dim=1)
+    sim = StretchBatchSimulator(num_envs=B, device="cuda:0", start_translation=trans, start_rotation_quat=quat)
+    sim.start()
+    x, y, th = sim.get_base_pose()
+    # homing nudges the base a few mm along its heading; in the BODY frame that settle offset is the same for every env
+    d = torch.stack([x.cpu().float() - xy[:, 0], y.cpu().float() - xy[:, 1]])
+    body = torch.stack([torch.cos(yaw) * d[0] + torch.sin(yaw) * d[1], -torch.sin(yaw) * d[0] + torch.cos(yaw) * d[1]])
+    assert float(body.abs().max()) < 1e-2 and float((body - body[:, :1]).abs().max()) < 4e-3   # fp32 settle transients differ by heading
+    assert torch.allclose(th.cpu().float(), yaw, atol=5e-3)
+    sim.set_base_velocity(0.3, 0.0, env_ids=[1])
+    sim.step(1000)
+    moved = sim.get_base_pose()
+    assert abs(float(moved[0][1]) - 1.0) > 0.05
+    sim.reset(env_ids=[1])
+    sim.step(1)
+    back = sim.get_base_pose()
+    assert abs(float(back[0][1]) - 1.0) < 1e-2 and abs(float(back[1][1]) + 2.0) < 1e-2
+    assert abs(float(back[0][3]) - float(moved[0][3])) < 1e-3      # the other envs were not touched
+    sim.stop()
+
