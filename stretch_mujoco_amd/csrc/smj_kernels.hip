@@ -5,7 +5,9 @@
 #include "smj_step_impl.h"
 
 __global__ __launch_bounds__(64) void smj_step_kernel(const DevModel M, const DevState S, int nsteps, unsigned read_flags) {
-  __shared__ Smem smem;
+  // dynamic LDS: a Newton launch asks for sizeof(Smem), a PGS launch for the extra tail that holds A (smj_lds_bytes)
+  extern __shared__ __align__(16) unsigned char smj_lds[];
+  Smem& smem = *reinterpret_cast<Smem*>(smj_lds);
   const int env = blockIdx.x;
   if (env >= S.B) return;
   StepKernel k(M, S, smem, env);
@@ -25,7 +27,7 @@ __global__ __launch_bounds__(256) void smj_reset_kernel(const DevModel M, const 
 }
 
 void smj_launch_step(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream) {
-  hipLaunchKernelGGL(smj_step_kernel, dim3(s.B), dim3(64), 0, stream, m, s, nsteps, read_flags);
+  hipLaunchKernelGGL(smj_step_kernel, dim3(s.B), dim3(64), smj_lds_bytes(m.solver != 2), stream, m, s, nsteps, read_flags);
 }
 void smj_launch_reset(const DevModel& m, const DevState& s, const uint8_t* mask, hipStream_t stream) {
   hipLaunchKernelGGL(smj_reset_kernel, dim3((s.B + 255) / 256), dim3(256), 0, stream, m, s, mask);

@@ -8,6 +8,7 @@
 // projectConstraint (Y = J L^-1, A = Y D^-1 Y' + R on MFMA) -> PGS (dual, elliptic cones, QCQP blocks) ->
 // implicitfast integrate.
 #pragma once
+#include <cstddef>
 #include "smj_model.h"
 #include "smj_wave.h"
 
@@ -26,29 +27,6 @@ struct TreeTmp {  // lives in the A region until A is built
 };
 
 struct Smem {
-  union {
-    float A[NEFC * NEFC];   // PGS: A = J M^-1 J' + R
-    TreeTmp t;
-    struct {                // collision: world frames of the geoms taking part in convex pairs (tree temporaries are dead)
-      float pos[NCG][3], mat[NCG][9], cen[NCG][3], half[NCG][3];
-      float ccen[NCG][3], size[NCG][3];   // world centre used as MPR's interior point, geom size
-      int meta[NCG][3];                   // geom type, hull vertex count, hull address
-      unsigned short list[1024];   // bounding-sphere survivors of the convex pair list, table order
-    } c;
-    struct {                // plane narrowphase staging: contacts of the pair owned by each lane, emitted in pair order
-      int cnt[64], pair[64];
-      float dist[64][4], pos[64][4][3], nrm[64][3];
-    } p;
-    struct {                // constraint assembly: per-contact body dof masks gathered lane-parallel before the row loop
-      int m1lo[NCON], m1hi[NCON], m2lo[NCON], m2hi[NCON], b1[NCON], b2[NCON];
-      float cd[NVP][6];     // cdof, so that both half-waves of the Jacobian fill can read any dof's motion axis
-    } k;
-    struct {                // Newton: XA = W J (row-weighted Jacobian) and the Hessian H = M + J' W J / its factor
-      float XA[NEFC][JS];
-      float H[NVP][NVP + 1];
-      float cH[NCON][36];   // cone Hessians of contacts in the middle zone
-    } n;
-  } u;
   float J[NEFC][JS];    // constraint Jacobian, transformed in place to Y = J L^-1
   float MM[NVP][MS];    // strict upper: M; lower + diag: working copy -> L (unit, strictly lower), D on diag
   float Mdiag[NVP], Dinv[NVP];
@@ -62,7 +40,40 @@ struct Smem {
       eb[NEFC], ef[NEFC];
   float cpos[NCON][3], cframe[NCON][9], cdist[NCON], cfric[NCON][5], csolref[NCON][2], csolimp[NCON][5], cmargin[NCON];
   int cdim[NCON], cgeom1[NCON], cgeom2[NCON], cefc[NCON];
+  // Stage-local storage, LAST on purpose: the PGS matrix A = J M^-1 J' + R (NEFP x NEFP floats, see A()) starts here too and
+  // runs past the end of the struct into the extra dynamic LDS that only a PGS launch asks for (smj_lds_bytes).  A Newton
+  // launch stays at sizeof(Smem) <= 40 KB = four resident workgroups per CU.
+  union {
+    TreeTmp t;
+    struct {                // collision: world frames of the geoms taking part in convex pairs (tree temporaries are dead)
+      float pos[NCG][3], mat[NCG][9], cen[NCG][3], half[NCG][3];
+      float ccen[NCG][3], size[NCG][3];   // world centre used as MPR's interior point, geom size
+      int meta[NCG];                      // geom type (bits 0-3) | hull vertex count (4-15) | hull address (16-31)
+      unsigned short list[1024];   // bounding-sphere survivors of the convex pair list, table order
+    } c;
+    struct {                // plane narrowphase staging: contacts of the pair owned by each lane, emitted in pair order
+      int cnt[64], pair[64];
+      float dist[64][4], pos[64][4][3], nrm[64][3];
+    } p;
+    struct {                // constraint assembly: per-contact body dof masks gathered lane-parallel before the row loop
+      int m1lo[NCON], m1hi[NCON], m2lo[NCON], m2hi[NCON], b1[NCON], b2[NCON];
+      float cd[NVP][6];     // cdof, so that both half-waves of the Jacobian fill can read any dof's motion axis
+    } k;
+    struct {                // Newton: XA = W J (row-weighted Jacobian), then the Hessian H = M + J' W J / M - h*D in its place
+      union {
+        float XA[NEFC][JS];
+        float H[NVP][NVP + 1];   // written once the matrix cores have consumed XA (operands are fetched to registers first)
+      };
+      float cH[NCON][36];   // cone Hessians of contacts in the middle zone
+    } n;
+  } u;
+  SMJ_DEV float* A() { return reinterpret_cast<float*>(&u); }
 };
+#define NEFP 64   // PGS row capacity (rows = lanes in the PGS sweeps)
+static inline size_t smj_lds_bytes(bool pgs) {
+  const size_t a_end = offsetof(Smem, u) + sizeof(float) * NEFP * NEFP;
+  return (pgs && a_end > sizeof(Smem)) ? a_end : sizeof(Smem);
+}
 
 // ---------------------------------------------------------------------------------------------- MFMA tile
 // D(16x16) += A(16x4) * B(4x16), f32.  Lane l supplies A[l&15][l>>4] and B[l>>4][l&15]; holds D[(l>>4)*4+r][l&15].
@@ -1462,8 +1473,9 @@ struct StepKernel {
   }
   SMJ_DEV void load_shape(Shape& sh, int g, int slot, float* cen) {
     (void)g;
-    sh.type = uni(s.u.c.meta[slot][0]); sh.nvert = uni(s.u.c.meta[slot][1]);
-    sh.verts = M.k_hull_vert4 + 4 * uni(s.u.c.meta[slot][2]);
+    const unsigned meta = (unsigned)uni(s.u.c.meta[slot]);
+    sh.type = (int)(meta & 15u); sh.nvert = (int)((meta >> 4) & 4095u);
+    sh.verts = M.k_hull_vert4 + 4 * (int)(meta >> 16);
     for (int k = 0; k < 3; k++) { sh.pos[k] = uni(s.u.c.pos[slot][k]); sh.size[k] = uni(s.u.c.size[slot][k]); cen[k] = uni(s.u.c.ccen[slot][k]); }
     for (int k = 0; k < 9; k++) sh.mat[k] = uni(s.u.c.mat[slot][k]);
     if (sh.type == GT_MESH) {
@@ -1501,7 +1513,7 @@ struct StepKernel {
           mulmat3vec(wc, mat, lcc);
           for (int k = 0; k < 3; k++) { s.u.c.ccen[c][k] = pos[k] + wc[k]; s.u.c.size[c][k] = M.geom_size[3 * g + k]; }
           const int adr = M.geom_hulladr[g];
-          s.u.c.meta[c][0] = M.geom_type[g]; s.u.c.meta[c][1] = M.geom_hullnum[g]; s.u.c.meta[c][2] = adr < 0 ? 0 : adr;
+          s.u.c.meta[c] = (int)((unsigned)M.geom_type[g] | ((unsigned)M.geom_hullnum[g] << 4) | ((unsigned)(adr < 0 ? 0 : adr) << 16));
         }
       }
     }
@@ -1867,8 +1879,8 @@ struct StepKernel {
               const int row = 16 * tr + (lane >> 4) * 4 + r, col = 16 * tc + (lane & 15);
               float v = acc[lane].r[r];
               if (row == col) v += row < ne ? s.eR[row] : 1.f;
-              s.u.A[row * NEFC + col] = v;
-              if (tr != tc) s.u.A[col * NEFC + row] = v;
+              s.A()[row * NEFP + col] = v;
+              if (tr != tc) s.A()[col * NEFP + row] = v;
             }
           }
         }
@@ -1925,7 +1937,7 @@ struct StepKernel {
     LANES { cost[lane] = lane < ne ? f_r[lane] * 0.5f * (r_r[lane] + bb[lane]) : 0.f; }
     const float wcost = wave_sum(cost);
     if (wcost > 0) { LANES { f_r[lane] = 0.f; r_r[lane] = bb[lane]; } }
-    LANES { ARinv_r[lane] = 1.0f / s.u.A[lane * NEFC + lane]; }
+    LANES { ARinv_r[lane] = 1.0f / s.A()[lane * NEFP + lane]; }
 
     TICK(SMJ_PROF_WARM)
     // ---- PGS sweeps  [MJ] mj_solPGS
@@ -1939,7 +1951,7 @@ struct StepKernel {
       int dc = 0;
       if (t == CT_CONTACT_ELLIPTIC) { const int c = s.eid[lane]; dc = s.cdim[c] | (c << 8); }
       dimc_r[lane] = dc;
-      aii_r[lane] = s.u.A[lane * NEFC + lane];
+      aii_r[lane] = s.A()[lane * NEFP + lane];
       fl_r[lane] = s.efloss[lane];
     }
     const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
@@ -1951,7 +1963,7 @@ struct StepKernel {
         const int t = wave_read(type_r, i);
         if (t != CT_CONTACT_ELLIPTIC) {
           PL<float> arow;
-          LANES { arow[lane] = s.u.A[i * NEFC + lane]; }
+          LANES { arow[lane] = s.A()[i * NEFP + lane]; }
           const float res = wave_read(r_r, i), old = wave_read(f_r, i), ainv = wave_read(ARinv_r, i);
           const float aii = wave_read(aii_r, i);
           float fn = old - res * ainv;
@@ -2011,8 +2023,8 @@ struct StepKernel {
         S.debug[(SMJ_DBG_EFC_B + lane) * S.ld + env] = lane < ne ? bb[lane] : 0.f;
         S.debug[(SMJ_DBG_EFC_R + lane) * S.ld + env] = lane < ne ? s.eR[lane] : 0.f;
         S.debug[(SMJ_DBG_EFC_AREF + lane) * S.ld + env] = lane < ne ? aref[lane] : 0.f;
-        S.debug[(SMJ_DBG_AR_DIAG + lane) * S.ld + env] = lane < ne ? s.u.A[lane * NEFC + lane] : 0.f;
-        for (int k = 0; k < NEFC; k++) S.debug[(SMJ_DBG_AR + k * NEFC + lane) * S.ld + env] = (k < ne && lane < ne) ? s.u.A[k * NEFC + lane] : 0.f;
+        S.debug[(SMJ_DBG_AR_DIAG + lane) * S.ld + env] = lane < ne ? s.A()[lane * NEFP + lane] : 0.f;
+        for (int k = 0; k < NEFP; k++) S.debug[(SMJ_DBG_AR + k * NEFP + lane) * S.ld + env] = (k < ne && lane < ne) ? s.A()[k * NEFP + lane] : 0.f;
       }
     }
   }
@@ -2023,7 +2035,7 @@ struct StepKernel {
     LANES {
       float v = bb[lane];
       if (lane < nefc)
-        for (int k = 0; k < nefc; k++) v += s.u.A[k * NEFC + lane] * s.ef[k];
+        for (int k = 0; k < nefc; k++) v += s.A()[k * NEFP + lane] * s.ef[k];
       r_r[lane] = v;
     }
     SYNC();
@@ -2036,13 +2048,13 @@ struct StepKernel {
     PL<float[DIM]> arow;  // rows i..i+DIM of A for the residual update, issued up front
     LANES {
 #pragma unroll
-      for (int r = 0; r < DIM; r++) arow[lane][r] = s.u.A[(i + r) * NEFC + lane];
+      for (int r = 0; r < DIM; r++) arow[lane][r] = s.A()[(i + r) * NEFP + lane];
     }
 #pragma unroll
     for (int r = 0; r < DIM; r++) {
       res[r] = wave_read(r_r, i + r); old[r] = wave_read(f_r, i + r); f[r] = old[r];
 #pragma unroll
-      for (int q = 0; q < DIM; q++) At[r * DIM + q] = s.u.A[(i + r) * NEFC + i + q];
+      for (int q = 0; q < DIM; q++) At[r * DIM + q] = s.A()[(i + r) * NEFP + i + q];
     }
 #pragma unroll
     for (int j = 0; j < DIM - 1; j++) mu[j] = s.cfric[c][j];

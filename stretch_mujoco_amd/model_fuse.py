@@ -186,6 +186,8 @@ def kernel_tables(f: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     cg = sorted({int(g) for p in range(len(f["pair_geom1"])) if p not in pp_set for g in (f["pair_geom1"][p], f["pair_geom2"][p])})
     if len(cg) > 128:
         raise ValueError("more than 128 geoms take part in non-plane collision pairs")
+    if len(f["geom_hullnum"]) and (int(np.max(f["geom_hullnum"])) >= 4096 or int(np.max(f["geom_hulladr"])) >= 65536):
+        raise ValueError("convex hulls: the kernel packs vertex count (< 4096) and hull address (< 65536) into one word")
     slot = {g: i for i, g in enumerate(cg)}
     cp = [p for p in range(len(f["pair_geom1"])) if p not in pp_set]
     f["k_cgeom"] = np.array(cg + [0], np.int32); f["k_ncgeom"] = np.array([len(cg)], np.int32)

@@ -32,7 +32,7 @@ struct emul_ctx {
   DevState s{};
   std::vector<void*> keep;
   std::string err;
-  Smem smem;
+  struct { Smem s; unsigned char pgs_tail[sizeof(float) * NEFP * NEFP]; } lds;   // PGS: A runs past the end of Smem
 };
 
 extern "C" {
@@ -94,8 +94,8 @@ int emul_poison = -1;
 void emul_set_poison(int byte) { emul_poison = byte; }
 int emul_step(emul_ctx* c, int nsteps, unsigned read_flags) {
   for (int env = 0; env < c->s.B; env++) {
-    if (emul_poison >= 0) memset(&c->smem, emul_poison, sizeof(Smem));
-    StepKernel* k = new StepKernel(c->m, c->s, c->smem, env);
+    if (emul_poison >= 0) memset(&c->lds, emul_poison, sizeof(c->lds));
+    StepKernel* k = new StepKernel(c->m, c->s, c->lds.s, env);
     k->run(nsteps, read_flags);
     delete k;
   }
