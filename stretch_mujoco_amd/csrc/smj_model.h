@@ -6,7 +6,7 @@
 
 #define NVP 32   // dof capacity (model nv <= NVP)
 #define NBP 32   // fused-body capacity
-#define NEFC 64  // constraint-row capacity (= lanes of one wavefront)
+#define NEFC 80  // constraint-row capacity of the Newton path: rows 64..79 take a second pass on lanes 0..15 (PGS: 64)
 #define NCON 16  // contact capacity
 #define NCG 128  // geoms that take part in non-plane collision pairs (world-frame cache of the broadphase)
 

@@ -65,11 +65,24 @@ struct Smem {
         float H[NVP][NVP + 1];   // written once the matrix cores have consumed XA (operands are fetched to registers first)
       };
       float cH[NCON][36];   // cone Hessians of contacts in the middle zone
+      // per-row solver registers (NRow) of rows 64..NEFC-1: the second row pass loads them at the start of a stage and
+      // stores them back at its end, so that the (rare) second pass holds no registers across the Newton loop
+      int rxi[3][NEFC > 64 ? NEFC - 64 : 1];
+      float rxf[17][NEFC > 64 ? NEFC - 64 : 1];
     } n;
   } u;
   SMJ_DEV float* A() { return reinterpret_cast<float*>(&u); }
 };
 #define NEFP 64   // PGS row capacity (rows = lanes in the PGS sweeps)
+// Row passes of the Newton path: rows 0..63 on lanes 0..63 (rb = 0), then rows 64..NEFC-1 on lanes 0..NEFC-65 (rb = 64), the
+// second pass only for an env that has that many rows (wave-uniform test).
+#define ROWPASS(rb, ne) _Pragma("unroll") for (int rb = 0; rb < NEFC; rb += 64) if (rb == 0 || __builtin_expect((ne) > 64, 0))
+#define ROWPASS_ALL(rb) _Pragma("unroll") for (int rb = 0; rb < NEFC; rb += 64)
+// A solver stage over all rows: `nr` names the per-row registers of the pass -- nr0 (registers, live across the Newton loop)
+// in the first pass, a stage-local copy of the LDS-resident state (rx_load / rx_store) in the second.
+#define ROWS_BEGIN(rb, ne) ROWPASS(rb, ne) { NRow nrx_; if (rb != 0) rx_load(nrx_); NRow& nr = (rb != 0) ? nrx_ : nr0; (void)nr;
+#define ROWS_END_RW(rb) if (rb != 0) rx_store(nrx_); }
+#define ROWS_END_RO() }
 static inline size_t smj_lds_bytes(bool pgs) {
   const size_t a_end = offsetof(Smem, u) + sizeof(float) * NEFP * NEFP;
   return (pgs && a_end > sizeof(Smem)) ? a_end : sizeof(Smem);
@@ -205,6 +218,7 @@ struct StepKernel {
   PL<float> qvel_r, g_r, qacc_r;
   PL<float> f_r, r_r, ARinv_r;          // lane = row (PGS)
   int nefc, ncon, niter, flags;
+  bool hirows_dirty = true;   // rows 64..NEFC-1 of J / the row tables hold data of an earlier step (or nothing yet)
 
   SMJ_DEV StepKernel(const DevModel& M_, const DevState& S_, Smem& s_, int env_) : M(M_), S(S_), s(s_), env(env_) {}
 
@@ -1623,11 +1637,17 @@ struct StepKernel {
   // ------------------------------------------------------------------ B.4 constraint rows
   SMJ_DEV void make_constraint() {
     const int nv = M.nv, neq = M.neq, nfric = M.nfric, nlimit = M.nlimit;
-    LANES {
-      for (int k = 0; k < JS; k++) s.J[lane][k] = 0.f;
-      s.etype[lane] = CT_NONE; s.efloss[lane] = 0; s.eid[lane] = 0; s.epos[lane] = 0; s.emargin[lane] = 0; s.ediag[lane] = 0;
+    // rows 0..63 on lanes 0..63, rows 64..NEFC-1 on lanes 0..NEFC-65 (second pass of every row stage, ROWPASS)
+    // (rows 64.. are written only by a step with more than 64 rows: cleared on the first step and after such a step)
+    ROWPASS(rb, hirows_dirty ? NEFC : 0) LANES {
+      const int row = lane + rb;
+      if (row < NEFC) {
+        for (int k = 0; k < JS; k++) s.J[row][k] = 0.f;
+        s.etype[row] = CT_NONE; s.efloss[row] = 0; s.eid[row] = 0; s.epos[row] = 0; s.emargin[row] = 0; s.ediag[row] = 0;
+      }
     }
     SYNC();
+    const int cap = M.solver == 2 ? NEFC : NEFP;   // the PGS sweeps are lane = row: 64 rows
     // equality rows (all equalities active; inactive ones get an empty row with R large -> force 0)
     PL<int> act;
     LANES {
@@ -1667,7 +1687,7 @@ struct StepKernel {
     LANES {
       if (act[lane]) {
         const int r = row0 + popc64(lm & ((1ull << lane) - 1));
-        if (r < NEFC) {
+        if (r < cap) {
           const int j = M.k_limit_jnt[lane >> 1], side = (lane & 1) ? 1 : -1, d = M.jnt_dofadr[j];
           const float q = s.qpos[M.jnt_qposadr[j]];
           s.J[r][d] = (float)(-side);
@@ -1677,7 +1697,7 @@ struct StepKernel {
       }
     }
     row0 += popc64(lm);
-    if (row0 > NEFC) { row0 = NEFC; flags |= SMJ_FLAG_EFC_OVERFLOW; }
+    if (row0 > cap) { row0 = cap; flags |= SMJ_FLAG_EFC_OVERFLOW; }
     SYNC();
     // contact rows.  Phase 1, lane = contact: everything that needs model tables (body ids, dof masks, diagonal
     // approximations) is gathered at once instead of per contact in the serial loop below; rows are assigned in contact
@@ -1705,13 +1725,13 @@ struct StepKernel {
     for (int c = 0; c < ncon; c++) {
       int d = wave_read(cdimv, c);
       if (!wave_read(cact, c)) continue;
-      if (row0 + d > NEFC) {
+      if (row0 + d > cap) {
         // Out of rows (flagged: the result is outside parity from here on).  Degrade gracefully instead of dropping the
         // contact: give up its rolling / torsional rows first, then its friction, and only then the contact itself -- a
         // contact that keeps its normal row still prevents penetration.
         flags |= SMJ_FLAG_EFC_OVERFLOW;
-        if (d > 3 && row0 + 3 <= NEFC) d = 3;
-        else if (row0 + 1 <= NEFC) d = 1;
+        if (d > 3 && row0 + 3 <= cap) d = 3;
+        else if (row0 + 1 <= cap) d = 1;
         else continue;
         LANES { if (lane == c) { cdimv[lane] = d; s.cdim[c] = d; } }
       }
@@ -1766,10 +1786,11 @@ struct StepKernel {
       }
     }
     nefc = row0;
+    hirows_dirty = row0 > 64;
     SYNC();
     // impedance, R, K, B  [MJ] mj_makeImpedance
-    LANES {
-      const int i = lane;
+    ROWPASS(rb, nefc) LANES {
+      const int i = lane + rb;
       if (i < nefc) {
         const int t = s.etype[i], id = s.eid[i];
         float solref[2], solimp[5];
@@ -2137,16 +2158,43 @@ struct StepKernel {
     PL<float[7]> cq;                  // u0 v0 uu uv vv Dm mu   (first row of an elliptic contact)
   };
 
+  enum { RX_AREF = 0, RX_D, RX_R, RX_FL, RX_JAR, RX_JV, RX_FORCE, RX_Q0, RX_Q1, RX_Q2, RX_CQ };
+  SMJ_DEV void rx_load(NRow& t) {
+    LANES {
+      const bool on = lane < NEFC - 64;
+      const int l = on ? lane : 0;
+      t.type[lane] = on ? s.u.n.rxi[0][l] : CT_NONE; t.state[lane] = on ? s.u.n.rxi[1][l] : 0; t.c0[lane] = on ? s.u.n.rxi[2][l] : -1;
+      t.aref[lane] = on ? s.u.n.rxf[RX_AREF][l] : 0.f; t.D[lane] = on ? s.u.n.rxf[RX_D][l] : 0.f; t.R[lane] = on ? s.u.n.rxf[RX_R][l] : 1.f;
+      t.fl[lane] = on ? s.u.n.rxf[RX_FL][l] : 0.f; t.jar[lane] = on ? s.u.n.rxf[RX_JAR][l] : 0.f; t.jv[lane] = on ? s.u.n.rxf[RX_JV][l] : 0.f;
+      t.force[lane] = on ? s.u.n.rxf[RX_FORCE][l] : 0.f;
+      t.q0[lane] = on ? s.u.n.rxf[RX_Q0][l] : 0.f; t.q1[lane] = on ? s.u.n.rxf[RX_Q1][l] : 0.f; t.q2[lane] = on ? s.u.n.rxf[RX_Q2][l] : 0.f;
+      for (int k = 0; k < 7; k++) t.cq[lane][k] = on ? s.u.n.rxf[RX_CQ + k][l] : 0.f;
+    }
+  }
+  SMJ_DEV void rx_store(const NRow& t) {
+    LANES {
+      if (lane < NEFC - 64) {
+        s.u.n.rxi[0][lane] = t.type[lane]; s.u.n.rxi[1][lane] = t.state[lane]; s.u.n.rxi[2][lane] = t.c0[lane];
+        s.u.n.rxf[RX_AREF][lane] = t.aref[lane]; s.u.n.rxf[RX_D][lane] = t.D[lane]; s.u.n.rxf[RX_R][lane] = t.R[lane];
+        s.u.n.rxf[RX_FL][lane] = t.fl[lane]; s.u.n.rxf[RX_JAR][lane] = t.jar[lane]; s.u.n.rxf[RX_JV][lane] = t.jv[lane];
+        s.u.n.rxf[RX_FORCE][lane] = t.force[lane];
+        s.u.n.rxf[RX_Q0][lane] = t.q0[lane]; s.u.n.rxf[RX_Q1][lane] = t.q1[lane]; s.u.n.rxf[RX_Q2][lane] = t.q2[lane];
+        for (int k = 0; k < 7; k++) s.u.n.rxf[RX_CQ + k][lane] = t.cq[lane][k];
+      }
+    }
+  }
+
   // constraint forces / states / cost at the residual nr.jar  ([MJ] mj_constraintUpdate).  Returns the cost.
-  SMJ_DEV float newton_update(NRow& nr, bool want_hess) {
+  SMJ_DEV float newton_update(NRow& nr0, bool want_hess) {
     const int ne = nefc;
     PL<float> cost;
-    LANES { s.eb[lane] = nr.jar[lane]; }
+    LANES { cost[lane] = 0.f; }
+    ROWS_BEGIN(rb, ne) LANES { if (lane + rb < NEFC) s.eb[lane + rb] = nr.jar[lane]; } ROWS_END_RO()
     SYNC();
-    LANES {
+    ROWS_BEGIN(rb, ne) LANES {
       float c = 0, f = 0;
       int st = 0;
-      const int i = lane, t = nr.type[lane];
+      const int i = lane + rb, t = nr.type[lane];
       const float jar = nr.jar[lane], D = nr.D[lane], R = nr.R[lane];
       if (i < ne) {
         if (t == CT_EQUALITY) { f = -D * jar; st = 1; c = 0.5f * D * jar * jar; }
@@ -2159,17 +2207,17 @@ struct StepKernel {
           if (jar < 0) { f = -D * jar; st = 1; c = 0.5f * D * jar * jar; }
         }
       }
-      nr.force[lane] = f; nr.state[lane] = st; cost[lane] = c;
-      s.ef[lane] = f;
-    }
+      nr.force[lane] = f; nr.state[lane] = st; cost[lane] += c;
+      if (i < NEFC) s.ef[i] = f;
+    } ROWS_END_RW(rb)
     SYNC();
     // elliptic contacts: the lane of the contact's first row handles the block.  All loops run to the maximum block size 6
     // with the tail masked off (zero friction coefficient, clamped row index): fixed trip counts let the LDS reads issue
     // back to back instead of one latency per row.
-    LANES {
+    ROWS_BEGIN(rb, ne) LANES {
       const int c = nr.c0[lane];
       if (c >= 0) {
-        const int i = lane, dim = s.cdim[c];
+        const int i = lane + rb, dim = s.cdim[c];
         const float mu = nr.cq[lane][6];
         float U[6], jr[6], S[6], Rj[6], T = 0;
 #pragma unroll
@@ -2218,12 +2266,15 @@ struct StepKernel {
         for (int j = 0; j < 6; j++)
           if (j < dim) { s.ef[i + j] = ef[j]; s.estate[i + j] = st; }   // block state broadcast through LDS
       }
-    }
+    } ROWS_END_RO()
     SYNC();
-    LANES {
-      if (nr.type[lane] == CT_CONTACT_ELLIPTIC && lane < ne) { nr.force[lane] = s.ef[lane]; nr.state[lane] = s.estate[lane]; }
-      s.estate[lane] = lane < ne ? nr.state[lane] : 0;   // every row's state, for stages that are not mapped lane = row
-    }
+    ROWS_BEGIN(rb, ne) LANES {
+      const int i = lane + rb;
+      if (i < NEFC) {
+        if (nr.type[lane] == CT_CONTACT_ELLIPTIC && i < ne) { nr.force[lane] = s.ef[i]; nr.state[lane] = s.estate[i]; }
+        s.estate[i] = (i < ne) ? nr.state[lane] : 0;   // every row's state, for stages that are not mapped lane = row
+      }
+    } ROWS_END_RW(rb)
     return wave_sum(cost);
   }
 
@@ -2249,14 +2300,15 @@ struct StepKernel {
   // accuracy from fp32 operations).  The primal residual jar = J qacc - aref cancels to |R f| << |aref|, and the
   // constraint force is D * jar with D = 1/R up to 1e4: a plain fp32 dot product would put 1e-3 noise on the
   // forces.  Only the starting residual needs this; the Newton loop then updates jar incrementally.
-  SMJ_DEV void mat_J_exact(PL<float>& out, const PL<float>& x, const PL<float>& sub) {
+  SMJ_DEV void mat_J_exact(PL<float>& out, const PL<float>& x, const PL<float>& sub, int rb) {
     const int nv = M.nv;
     PL<float> hi, lo;
     LANES { hi[lane] = -sub[lane]; lo[lane] = 0.f; }
     for (int k = 0; k < nv; k++) {
       const float xk = wave_read(x, k);
       LANES {
-        const float a = s.J[lane][k];
+        const int row = lane + rb;
+        const float a = s.J[row < NEFC ? row : 0][k];
         const float p = a * xk, pe = fmaf(a, xk, -p);          // p + pe = a*xk exactly
         const float t = hi[lane] + p, z = t - hi[lane];
         const float se = (hi[lane] - (t - z)) + (p - z);        // hi + p = t + se exactly
@@ -2267,12 +2319,12 @@ struct StepKernel {
     LANES { out[lane] = hi[lane] + lo[lane]; }
   }
   // out[dof] = sum_rows J[row][dof] * f[row]   (lane = dof, f lane-resident over rows), sixteen rows per pass
-  SMJ_DEV void matT_J(PL<float>& out, const PL<float>& f) {
+  SMJ_DEV void matT_J(PL<float>& out, const NRow& nr0) {
     const int ne = nefc;
     LANES { out[lane] = 0.f; }
 #pragma unroll
     for (int r0 = 0; r0 < NEFC; r0 += 16) {
-      if (r0 < ne) {
+      if (r0 < 64 ? r0 < ne : __builtin_expect(r0 < ne, 0)) {
         PL<float[16]> a;
         LANES {
 #pragma unroll
@@ -2280,18 +2332,19 @@ struct StepKernel {
         }
 #pragma unroll
         for (int u = 0; u < 16; u++) {
-          const float fr = wave_read(f, r0 + u);
+          const float fr = r0 < 64 ? wave_read(nr0.force, (r0 & 63) + u) : s.u.n.rxf[RX_FORCE][(r0 & 63) + u];   // rows >= 64: LDS
           LANES { out[lane] += a[lane][u] * fr; }
         }
       }
     }
   }
-  // out[row] = J[row] . x   (lane = row, x lane-resident over dofs; columns nv..NVP of J are zero)
-  SMJ_DEV void mat_J(PL<float>& out, const PL<float>& x) {
+  // out[row] = J[row] . x   (lane = row - rb, x lane-resident over dofs; columns nv..NVP of J are zero)
+  SMJ_DEV void mat_J(PL<float>& out, const PL<float>& x, int rb) {
     PL<float[NVP]> a;
     LANES {
+      const int row = lane + rb < NEFC ? lane + rb : 0;
 #pragma unroll
-      for (int k = 0; k < NVP; k++) a[lane][k] = s.J[lane][k];
+      for (int k = 0; k < NVP; k++) a[lane][k] = s.J[row][k];
       out[lane] = 0.f;
     }
 #pragma unroll
@@ -2355,12 +2408,13 @@ struct StepKernel {
   }
 
   // cost and derivatives along the search line  ([MJ] CGeval); lanes = rows, three wave reductions
-  SMJ_DEV float ls_eval(const NRow& nr, const float* qg, float a, float& d1, float& d2) {
+  SMJ_DEV float ls_eval(NRow& nr0, const float* qg, float a, float& d1, float& d2) {
     const int ne = nefc;
     PL<float> p0, p1, p2;
-    LANES {
+    LANES { p0[lane] = 0.f; p1[lane] = 0.f; p2[lane] = 0.f; }
+    ROWS_BEGIN(rb, ne) LANES {
       float c0 = 0, c1 = 0, c2 = 0;
-      if (lane < ne) {
+      if (lane + rb < ne) {
         const int t = nr.type[lane];
         const float x = nr.jar[lane] + a * nr.jv[lane];
         if (t == CT_EQUALITY) { c0 = nr.q0[lane]; c1 = nr.q1[lane]; c2 = nr.q2[lane]; }
@@ -2390,8 +2444,8 @@ struct StepKernel {
           }
         }
       }
-      p0[lane] = c0; p1[lane] = c1; p2[lane] = c2;
-    }
+      p0[lane] += c0; p1[lane] += c1; p2[lane] += c2;
+    } ROWS_END_RO()
     const float q0 = qg[0] + wave_sum(p0), q1 = qg[1] + wave_sum(p1), q2 = qg[2] + wave_sum(p2);
     d1 = 2 * a * q2 + q1;
     d2 = 2 * q2;
@@ -2401,7 +2455,7 @@ struct StepKernel {
   SMJ_DEV void solve_newton(bool dbg, float* pc, long long& t0, bool prof) {
 #define TICK(slot) if (prof) { const long long t1 = smj_clock(); pc[slot] += (float)(t1 - t0); t0 = t1; }
     const int nv = M.nv, ne = nefc;
-    NRow nr;
+    NRow nr0;      // per-row registers of rows 0..63; rows 64.. keep theirs in LDS (ROWS_BEGIN)
     PL<float> qacc, Ma, Mv, grad, search, tmpv;
     // The Gauss term is used up to its constant: 0.5 (a-a_s)'M(a-a_s) = 0.5 a'Ma - a'g + const, so neither
     // qacc_smooth nor a factorisation of M is needed on the Newton path (the constant never enters a derivative).
@@ -2418,39 +2472,41 @@ struct StepKernel {
       return;
     }
     // per-row constants, efc_vel, aref
-    LANES {
+    ROWPASS(rb, ne) { NRow nrx_; NRow& nr = (rb != 0) ? nrx_ : nr0; LANES {   // the first stage: nothing to load yet
+      const int row = lane + rb;
       float vel = 0;
-      const bool on = lane < ne;
+      const bool on = row < ne;
       if (on)
-        for (int k = 0; k < nv; k++) vel += s.J[lane][k] * s.qvel[k];
-      nr.type[lane] = on ? s.etype[lane] : CT_NONE;
-      nr.R[lane] = on ? s.eR[lane] : 1.f;
-      nr.D[lane] = on ? 1.0f / s.eR[lane] : 0.f;
-      nr.fl[lane] = on ? s.efloss[lane] : 0.f;
-      nr.aref[lane] = on ? -s.eBv[lane] * vel - s.eK[lane] * s.eimp[lane] * (s.epos[lane] - s.emargin[lane]) : 0.f;
+        for (int k = 0; k < nv; k++) vel += s.J[row][k] * s.qvel[k];
+      nr.type[lane] = on ? s.etype[row] : CT_NONE;
+      nr.R[lane] = on ? s.eR[row] : 1.f;
+      nr.D[lane] = on ? 1.0f / s.eR[row] : 0.f;
+      nr.fl[lane] = on ? s.efloss[row] : 0.f;
+      nr.aref[lane] = on ? -s.eBv[row] * vel - s.eK[row] * s.eimp[row] * (s.epos[row] - s.emargin[row]) : 0.f;
       int c0 = -1;
-      if (on && s.etype[lane] == CT_CONTACT_ELLIPTIC && s.cefc[s.eid[lane]] == lane) c0 = s.eid[lane];
+      if (on && s.etype[row] == CT_CONTACT_ELLIPTIC && s.cefc[s.eid[row]] == row) c0 = s.eid[row];
       nr.c0[lane] = c0;
+      nr.state[lane] = 0; nr.jar[lane] = 0.f; nr.jv[lane] = 0.f; nr.force[lane] = 0.f; nr.q0[lane] = 0.f; nr.q1[lane] = 0.f; nr.q2[lane] = 0.f;
       for (int k = 0; k < 7; k++) nr.cq[lane][k] = 0.f;
       if (c0 >= 0) {
         const float mu = contact_mu(c0);
         nr.cq[lane][6] = mu;
-        nr.cq[lane][5] = (1.0f / s.eR[lane]) / fmaxf(mu * mu * (1 + mu * mu), SMJ_MINVAL);
+        nr.cq[lane][5] = (1.0f / s.eR[row]) / fmaxf(mu * mu * (1 + mu * mu), SMJ_MINVAL);
       }
-      if (dbg) s.earef[lane] = nr.aref[lane];
-    }
+      if (dbg && row < NEFC) s.earef[row] = nr.aref[lane];
+    } ROWS_END_RW(rb)
     const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
     // start from qacc_warmstart (MuJoCo also tries qacc_smooth and keeps the cheaper; Newton reaches the same unique
     // optimum from either, so the extra M^-1 g solve is skipped)
     LANES { qacc[lane] = (lane < nv && M.warmstart) ? s.warm[lane] : 0.f; }
     mat_M(Ma, qacc);
-    mat_J_exact(nr.jar, qacc, nr.aref);
+    ROWS_BEGIN(rb, ne) mat_J_exact(nr.jar, qacc, nr.aref, rb); ROWS_END_RW(rb)
     float cost = 0;
     TICK(SMJ_PROF_WARM)
     int iter = 0;
     for (; iter < M.iterations;) {
       TICK(SMJ_PROF_PGS)
-      cost = newton_update(nr, true);
+      cost = newton_update(nr0, true);
       float gauss;
       {
         PL<float> gs;
@@ -2460,7 +2516,7 @@ struct StepKernel {
       cost += gauss;
       TICK(SMJ_PROF_N_UPDATE)
       // gradient = Ma - g - J'f   (lanes = dofs; force broadcast by readlane)
-      matT_J(tmpv, nr.force);
+      matT_J(tmpv, nr0);
       PL<float> g2;
       LANES { grad[lane] = lane < nv ? Ma[lane] - g_r[lane] - tmpv[lane] : 0.f; g2[lane] = grad[lane] * grad[lane]; }
       const float gnorm = sqrtf(wave_sum(g2));
@@ -2469,15 +2525,18 @@ struct StepKernel {
       // XA = W J.  Quadratic rows D*J, satisfied / linear rows 0 (lane = row).  Rows of a contact in the cone (middle) zone:
       // (Hc Jc) with lanes = dofs, two contacts per pass (half-waves), the 6x6 block zero-padded so that every loop has a
       // fixed trip count and the LDS reads issue back to back.
-      LANES {
-        if (!(lane < ne && nr.state[lane] == 4)) {
-          const float w = (lane < ne && nr.state[lane] == 1) ? nr.D[lane] : 0.f;
-#pragma unroll
-          for (int k = 0; k < NVP; k++) s.u.n.XA[lane][k] = w * s.J[lane][k];
-        }
-      }
       PL<int> conerow;
-      LANES { conerow[lane] = lane < ne && nr.state[lane] == 4; }
+      LANES { conerow[lane] = 0; }
+      ROWS_BEGIN(rb, ne) LANES {
+        const int row = lane + rb;
+        const bool cone = row < ne && nr.state[lane] == 4;
+        if (!cone && row < NEFC) {
+          const float w = (row < ne && nr.state[lane] == 1) ? nr.D[lane] : 0.f;
+#pragma unroll
+          for (int k = 0; k < NVP; k++) s.u.n.XA[row][k] = w * s.J[row][k];
+        }
+        conerow[lane] |= cone;
+      } ROWS_END_RO()
       const bool anycone = wave_ballot(conerow) != 0;
       for (int c0 = 0; anycone && c0 < ncon; c0 += 2) {
         LANES {
@@ -2510,27 +2569,38 @@ struct StepKernel {
       {
         const int ksteps = (ne + 3) >> 2;
         PL<F4v> acc00, acc10, acc11;
-        PL<float[NEFC / 4]> a0, a1, b0, b1;
         LANES {
           for (int r = 0; r < 4; r++) { acc00[lane].r[r] = 0.f; acc10[lane].r[r] = 0.f; acc11[lane].r[r] = 0.f; }
-#pragma unroll
-          for (int ks = 0; ks < NEFC / 4; ks++) {
-            const int k = 4 * ks + (lane >> 4), c = lane & 15;
-            const bool on = ks < ksteps;                       // rows >= ne of XA / J are zero
-            a0[lane][ks] = on ? s.u.n.XA[k][c] : 0.f;
-            a1[lane][ks] = on ? s.u.n.XA[k][16 + c] : 0.f;
-            b0[lane][ks] = on ? s.J[k][c] : 0.f;
-            b1[lane][ks] = on ? s.J[k][16 + c] : 0.f;
-          }
         }
+        // rows 0..63 in one batch of 16 k-steps, rows 64..NEFC-1 (rare) in a second short one
 #pragma unroll
-        for (int ks = 0; ks < NEFC / 4; ks++) {
-          if (ks < ksteps) {
-            PL<float> pa0, pa1, pb0, pb1;
-            LANES { pa0[lane] = a0[lane][ks]; pa1[lane] = a1[lane][ks]; pb0[lane] = b0[lane][ks]; pb1[lane] = b1[lane][ks]; }
-            mfma16x16x4(acc00, pa0, pb0);
-            mfma16x16x4(acc10, pa1, pb0);
-            mfma16x16x4(acc11, pa1, pb1);
+        for (int kb = 0; kb < NEFC / 4; kb += 16) {
+          if (kb == 0 || __builtin_expect(kb < ksteps, 0)) {
+            constexpr int KB = 16;
+            PL<float[KB]> a0, a1, b0, b1;
+            LANES {
+#pragma unroll
+              for (int ks = 0; ks < KB; ks++) {
+                const int k = 4 * (kb + ks) + (lane >> 4), c = lane & 15;
+                if (kb + ks < NEFC / 4) {                      // compile-time: k stays inside XA / J
+                  const bool on = kb + ks < ksteps;            // rows >= ne of XA / J are zero
+                  a0[lane][ks] = on ? s.u.n.XA[k][c] : 0.f;
+                  a1[lane][ks] = on ? s.u.n.XA[k][16 + c] : 0.f;
+                  b0[lane][ks] = on ? s.J[k][c] : 0.f;
+                  b1[lane][ks] = on ? s.J[k][16 + c] : 0.f;
+                }
+              }
+            }
+#pragma unroll
+            for (int ks = 0; ks < KB; ks++) {
+              if (kb + ks < ksteps && kb + ks < NEFC / 4) {
+                PL<float> pa0, pa1, pb0, pb1;
+                LANES { pa0[lane] = a0[lane][ks]; pa1[lane] = a1[lane][ks]; pb0[lane] = b0[lane][ks]; pb1[lane] = b1[lane][ks]; }
+                mfma16x16x4(acc00, pa0, pb0);
+                mfma16x16x4(acc10, pa1, pb0);
+                mfma16x16x4(acc11, pa1, pb1);
+              }
+            }
           }
         }
         LANES {
@@ -2561,7 +2631,7 @@ struct StepKernel {
       TICK(SMJ_PROF_N_SOLVE)
       // line-search preparation  ([MJ] CGprepare)
       mat_M(Mv, search);
-      mat_J(nr.jv, search);
+      ROWS_BEGIN(rb, ne) mat_J(nr.jv, search, rb); ROWS_END_RW(rb)
       float qg[3];
       {
         PL<float> a1, a2;
@@ -2571,16 +2641,17 @@ struct StepKernel {
         }
         qg[0] = gauss; qg[1] = wave_sum(a1); qg[2] = wave_sum(a2);
       }
-      LANES {
+      ROWS_BEGIN(rb, ne) LANES {
+        const int row = lane + rb;
         const float D = nr.D[lane], ja = nr.jar[lane], jv = nr.jv[lane];
         nr.q0[lane] = 0.5f * D * ja * ja; nr.q1[lane] = D * ja * jv; nr.q2[lane] = 0.5f * D * jv * jv;
-        s.eb[lane] = ja; s.ef[lane] = jv; s.earef[lane] = nr.q0[lane]; s.eK[lane] = nr.q1[lane]; s.eBv[lane] = nr.q2[lane];
-      }
+        if (row < NEFC) { s.eb[row] = ja; s.ef[row] = jv; s.earef[row] = nr.q0[lane]; s.eK[row] = nr.q1[lane]; s.eBv[row] = nr.q2[lane]; }
+      } ROWS_END_RW(rb)
       SYNC();
-      LANES {
+      ROWS_BEGIN(rb, ne) LANES {
         const int c = nr.c0[lane];
         if (c >= 0) {
-          const int i = lane, dim = s.cdim[c];
+          const int i = lane + rb, dim = s.cdim[c];
           float a0 = 0, a1 = 0, a2 = 0, uu = 0, uv = 0, vv = 0;
 #pragma unroll
           for (int j = 1; j < 6; j++) {   // fixed trip count, tail masked by a zero weight
@@ -2595,7 +2666,7 @@ struct StepKernel {
           nr.cq[lane][0] = nr.jar[lane] * mu; nr.cq[lane][1] = nr.jv[lane] * mu;
           nr.cq[lane][2] = uu; nr.cq[lane][3] = uv; nr.cq[lane][4] = vv;
         }
-      }
+      } ROWS_END_RW(rb)
       TICK(SMJ_PROF_N_PREP)
       // exact line search: safeguarded Newton on the directional derivative (same scheme as the oracle's ls_search).
       // fp32 note: acceptance and the improvement estimate use derivatives, not cost differences -- near the optimum
@@ -2604,13 +2675,13 @@ struct StepKernel {
       {
         const float gtol = M.tolerance * M.ls_tolerance * snorm * M.meaninertia * (float)(nv > 1 ? nv : 1);
         float d1, d2, lo = 0, hi = -1;
-        ls_eval(nr, qg, 0.f, d1, d2);
+        ls_eval(nr0, qg, 0.f, d1, d2);
         d10 = d1;
         float bestd = fabsf(d1), a = 0;
         if (d1 < 0 && d2 > 0) {
           a = -d1 / d2;
           for (int it = 0; it < M.ls_iterations; it++) {
-            ls_eval(nr, qg, a, d1, d2);
+            ls_eval(nr0, qg, a, d1, d2);
             if (prof) pc[SMJ_PROF_N_LSEVALS] += 1.f;
             if (fabsf(d1) < bestd) { bestd = fabsf(d1); alpha = a; }
             if (fabsf(d1) < gtol) break;
@@ -2627,18 +2698,16 @@ struct StepKernel {
       TICK(SMJ_PROF_N_LS)
       iter++;
       if (alpha == 0.f) break;
-      LANES {
-        qacc[lane] += alpha * search[lane]; Ma[lane] += alpha * Mv[lane];
-        nr.jar[lane] += alpha * nr.jv[lane];
-      }
+      LANES { qacc[lane] += alpha * search[lane]; Ma[lane] += alpha * Mv[lane]; }
+      ROWS_BEGIN(rb, ne) LANES { nr.jar[lane] += alpha * nr.jv[lane]; } ROWS_END_RW(rb)
       // decrease of the cost along the accepted step, from the slope at 0 (exact for the quadratic pieces)
       if (scale * (-0.5f * alpha * d10) < M.tolerance) break;
     }
     niter = iter;
     TICK(SMJ_PROF_PGS)
     // final forces at the accepted point, qfrc_constraint = J' f
-    newton_update(nr, false);
-    matT_J(tmpv, nr.force);
+    newton_update(nr0, false);
+    matT_J(tmpv, nr0);
     LANES {
       qacc_r[lane] = lane < nv ? qacc[lane] : 0.f;
       if (lane < nv) { s.qacc[lane] = qacc[lane]; s.warm[lane] = qacc[lane]; s.tmp[lane] = g_r[lane] + tmpv[lane]; }
@@ -2647,6 +2716,7 @@ struct StepKernel {
     if (dbg && S.debug) {
       LANES {
         if (lane < nv) S.debug[(SMJ_DBG_QACC + lane) * S.ld + env] = qacc[lane];
+        const NRow& nr = nr0;   // the debug layout holds the first 64 rows
         S.debug[(SMJ_DBG_EFC_FORCE + lane) * S.ld + env] = lane < ne ? nr.force[lane] : 0.f;
         S.debug[(SMJ_DBG_EFC_R + lane) * S.ld + env] = lane < ne ? nr.R[lane] : 0.f;
         S.debug[(SMJ_DBG_EFC_AREF + lane) * S.ld + env] = lane < ne ? nr.aref[lane] : 0.f;

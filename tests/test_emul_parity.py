@@ -230,6 +230,54 @@ def test_convex_pairs_can_be_switched_off(blob_fused):
     assert o.arr("qpos")[9] < 0.14 and abs(o.arr("qpos")[9] - e.qpos[9, 0]) < 0.02   # lower than with the base in the way (0.145+): now the floor stops the gripper
 
 
+def test_rows_beyond_one_wavefront(blob_fused):
+    """Lift driven to the bottom with the wrist pitched down, from mj_resetData: 22 steps in, the gripper lands on the base
+    and the env needs 77, then 80 constraint rows (14 / 15 contacts) -- more than the 64 lanes of a wavefront.  The Newton
+    path takes rows 64..79 in a second pass on lanes 0..15; forces and accelerations match the oracle as on any other
+    step, no capacity flag.  One step later the oracle wants 89 rows / 18 contacts: over capacity, flagged."""
+    o = Oracle(blob_fused); o.set_option("solver", 2); o.reset()
+    ctrl = [0, 0, 0.0, 0.3, 0, -1.57, 0, 0, 0, 0]
+    o.arr("ctrl")[:10] = ctrl
+    e = Emul(blob_fused, DIMS, num_envs=1); e.set_option("solver", 2)
+    e.ctrl[:, 0] = np.asarray(ctrl, np.float32)
+    o.step(22)
+    for want in (77, 80, None):
+        e.qpos[:, 0] = o.arr("qpos"); e.qvel[:, 0] = o.arr("qvel"); e.warm[:, 0] = o.arr("qacc_warmstart")
+        o.step(1); e.step(1)
+        if want is None:
+            assert o.nefc > 80 and e.info[3, 0] != 0
+            break
+        assert (o.nefc, int(e.info[0, 0]), int(e.info[1, 0]), int(e.info[3, 0])) == (want, want, o.ncon, 0)
+        d, qa, f = e.debug[:, 0], o.arr("qacc"), o.arr("efc_force")[:64]
+        assert np.abs(d[1056:1082] - qa).max() / np.abs(qa).max() < 1e-4
+        assert np.abs(d[1088:1088 + 64] - f).max() / np.abs(f).max() < 1e-4       # the debug layout holds the first 64 rows
+        assert np.abs(e.qvel[:, 0] - o.arr("qvel")).max() < 1e-4
+        assert abs(int(e.info[2, 0]) - int(o.iarr("solver_niter")[0])) <= 2
+
+
+def test_second_row_pass_reads_no_stale_lds(blob_fused):
+    """Same 77- and 80-row steps with the LDS pre-filled with zeros / large values / NaNs before every launch: the rows of
+    the second pass (their registers live in LDS between stages) must not depend on what was there."""
+    o = Oracle(blob_fused); o.set_option("solver", 2); o.reset()
+    ctrl = [0, 0, 0.0, 0.3, 0, -1.57, 0, 0, 0, 0]
+    o.arr("ctrl")[:10] = ctrl
+    o.step(22)
+    q, v, w = o.arr("qpos").copy(), o.arr("qvel").copy(), o.arr("qacc_warmstart").copy()
+    ref = None
+    for poison in (0x00, 0x7F, 0xFF):
+        e = Emul(blob_fused, DIMS, num_envs=1); e.set_option("solver", 2); e.set_poison(poison)
+        e.ctrl[:, 0] = np.asarray(ctrl, np.float32)
+        e.qpos[:, 0] = q; e.qvel[:, 0] = v; e.warm[:, 0] = w
+        e.step(1); a = np.concatenate([e.qpos[:, 0], e.qvel[:, 0]]).copy(); n1 = int(e.info[0, 0])
+        e.step(1); b = np.concatenate([e.qpos[:, 0], e.qvel[:, 0]]).copy(); n2 = int(e.info[0, 0])
+        e.set_poison(-1)
+        assert n1 > 64 and n2 > 64 and np.isfinite(a).all() and np.isfinite(b).all()
+        if ref is None:
+            ref = (a, b)
+        else:
+            assert np.array_equal(a, ref[0]) and np.array_equal(b, ref[1]), hex(poison)
+
+
 def test_bad_state_resets_and_flags(blob_fused):
     """mj_checkPos semantics: a non-finite state resets the env to qpos0 and raises the BAD_STATE flag."""
     o, e = _pair_newton(blob_fused, HOME_CTRL, B=2)

@@ -206,6 +206,35 @@ def test_masked_reset():
     sim.stop()
 
 
+def test_rows_beyond_one_wavefront_vs_oracle():
+    """77 and 80 constraint rows (gripper landing on the base 22 steps after mj_resetData with the lift driven down): the
+    Newton path runs rows 64..79 in a second pass on lanes 0..15.  Same check as the emulator test, through the C-ABI, with
+    neighbours in the batch that stay at 30-odd rows."""
+    sim = _sim(8, debug=True, solver="newton")
+    o = Oracle(sim._blob); o.set_option("solver", 2); o.reset()
+    ctrl = [0, 0, 0.0, 0.3, 0, -1.57, 0, 0, 0, 0]
+    o.arr("ctrl")[:10] = ctrl
+    _set_ctrl(sim, HOME_CTRL)
+    sim.ctrl[:, 0] = torch.tensor(ctrl, dtype=torch.float32, device=sim.device)
+    sim.ctrl[:, 5] = sim.ctrl[:, 0]
+    o.step(22)
+    for want in (77, 80):
+        for e in (0, 5):
+            sim.qpos[:, e] = torch.tensor(o.arr("qpos"), dtype=torch.float32, device=sim.device)
+            sim.qvel[:, e] = torch.tensor(o.arr("qvel"), dtype=torch.float32, device=sim.device)
+            sim.qacc_warmstart[:, e] = torch.tensor(o.arr("qacc_warmstart"), dtype=torch.float32, device=sim.device)
+        o.step(1); sim.step(1)
+        torch.cuda.synchronize()
+        assert o.nefc == want
+        for e in (0, 5):
+            assert (int(sim.info[0, e]), int(sim.info[1, e]), int(sim.info[3, e])) == (want, o.ncon, 0)
+            d, qa = sim.debug[:, e].cpu().numpy(), o.arr("qacc")
+            assert np.abs(d[1056:1082] - qa).max() / np.abs(qa).max() < 1e-4
+            assert np.abs(sim.qvel[:, e].cpu().numpy() - o.arr("qvel")).max() < 1e-4
+        assert torch.equal(sim.qpos[:, 0], sim.qpos[:, 5]) and int(sim.info[0, 1]) < 64
+    sim.stop()
+
+
 def test_capacity_overflow_is_flagged():
     """Lift fully down with the wrist pitched down puts many gripper hulls on the floor: more contacts than the
     kernel's capacity.  Contacts beyond capacity are dropped and the env is flagged, never silently wrong."""
@@ -230,7 +259,7 @@ def test_full_batch_properties(B, solver):
     hi = torch.tensor(sim.model["actuator_ctrlrange"][:, 1], dtype=torch.float32, device=sim.device).unsqueeze(1)
     ctrl = lo + (hi - lo) * torch.rand(10, B, generator=g, device=sim.device)
     ctrl[2] = ctrl[2].clamp(min=0.55)  # keep the gripper off the floor: a gripper lying on the floor needs more than
-    # the 16-contact / 64-row capacity of this round's kernel (it is flagged, see test_capacity_overflow_is_flagged)
+    # the 16-contact / 80-row capacity of this round's kernel (it is flagged, see test_capacity_overflow_is_flagged)
     q0 = torch.tensor(home_qpos(sim.model["qpos0"]), dtype=torch.float32, device=sim.device).unsqueeze(1)
     sim.qpos[:] = q0
     sim.ctrl.copy_(ctrl)
