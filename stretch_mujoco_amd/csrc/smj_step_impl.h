@@ -218,7 +218,6 @@ struct StepKernel {
   PL<float> qvel_r, g_r, qacc_r;
   PL<float> f_r, r_r, ARinv_r;          // lane = row (PGS)
   int nefc, ncon, niter, flags;
-  bool hirows_dirty = true;   // rows 64..NEFC-1 of J / the row tables hold data of an earlier step (or nothing yet)
 
   SMJ_DEV StepKernel(const DevModel& M_, const DevState& S_, Smem& s_, int env_) : M(M_), S(S_), s(s_), env(env_) {}
 
@@ -1638,8 +1637,9 @@ struct StepKernel {
   SMJ_DEV void make_constraint() {
     const int nv = M.nv, neq = M.neq, nfric = M.nfric, nlimit = M.nlimit;
     // rows 0..63 on lanes 0..63, rows 64..NEFC-1 on lanes 0..NEFC-65 (second pass of every row stage, ROWPASS)
-    // (rows 64.. are written only by a step with more than 64 rows: cleared on the first step and after such a step)
-    ROWPASS(rb, hirows_dirty ? NEFC : 0) LANES {
+    // (rows 64.. are written only by a step with more than 64 rows: cleared on the first step of a launch -- run() starts
+    // with nefc = NEFC -- and after such a step; nefc still holds the previous step's row count here)
+    ROWPASS(rb, nefc) LANES {
       const int row = lane + rb;
       if (row < NEFC) {
         for (int k = 0; k < JS; k++) s.J[row][k] = 0.f;
@@ -1786,7 +1786,6 @@ struct StepKernel {
       }
     }
     nefc = row0;
-    hirows_dirty = row0 > 64;
     SYNC();
     // impedance, R, K, B  [MJ] mj_makeImpedance
     ROWPASS(rb, nefc) LANES {
@@ -2903,7 +2902,7 @@ struct StepKernel {
   // ------------------------------------------------------------------ driver
   SMJ_DEV void run(int nsteps, unsigned read_flags) {
     const int want_imu = read_flags & 1;
-    flags = 0; nefc = 0; ncon = 0; niter = 0;
+    flags = 0; nefc = NEFC; ncon = 0; niter = 0;   // nefc = NEFC: the first make_constraint clears every row
     float pc[SMJ_PROF_SLOTS];
     for (int k = 0; k < SMJ_PROF_SLOTS; k++) pc[k] = 0.f;
     const bool prof = S.prof != nullptr;
