@@ -204,7 +204,7 @@ def main():
         dt = float(tmax.item())
     all_returns = gather_returns(returns)  # RCCL all-gather of per-env returns (the only collective)
     flags = int(sim.info[3].max().item())
-    flagged = float((sim.info[3] != 0).float().mean().item())   # envs in which some step since reset exceeded the 64-row / 16-contact capacity (flags are sticky until reset)
+    flagged = float((sim.info[3] != 0).float().mean().item())   # envs in which some step since reset exceeded the 80-row / 16-contact capacity (flags are sticky until reset)
     kern_ms = sum(a.elapsed_time(b) for a, b, _ in events)
     kern_steps = sum(k for _, _, k in events)
     total_env_steps = float(B) * world * args.steps
