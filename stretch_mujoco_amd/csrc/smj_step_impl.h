@@ -355,6 +355,10 @@ struct StepKernel {
       }
     }
     SYNC();
+    // identity padding of the dof block nv..NVP-1, written once: the per-step mass-matrix entries never touch it, and the
+    // Newton Hessian H = M + J'WJ / the dense M x products can then take MM as it is, with no `< nv` select per element
+    LANES { if (lane >= M.nv && lane < NVP) s.MM[lane][lane] = 1.f; }
+    SYNC();
   }
 
   SMJ_DEV void load_state() {
@@ -2277,17 +2281,15 @@ struct StepKernel {
     return wave_sum(cost);
   }
 
-  // y = M x for lane-resident x (lane = dof); M = strict upper of MM + Mdiag (lower part holds the L'DL factor)
+  // y = M x for lane-resident x (lane = dof, x zero beyond nv).  Newton path only: factor() is not run there, so MM holds the
+  // full symmetric M (both triangles + diagonal, identity beyond nv) and lane i reads its row as it is -- no select per element.
+  // Lanes 32..63 mirror lanes 0..31; their y is never used.
   SMJ_DEV void mat_M(PL<float>& y, const PL<float>& x) {
-    const int nv = M.nv;
-    PL<float[NVP]> m;   // row `lane` of M: all LDS reads are issued before the first use (fixed trip count, masked tail)
+    PL<float[NVP]> m;   // row `lane` of M: all LDS reads are issued before the first use (fixed trip count)
     LANES {
 #pragma unroll
-      for (int j = 0; j < NVP; j++) {
-        const float v = lane > j ? s.MM[j][lane < NVP ? lane : 0] : s.MM[lane < NVP ? lane : 0][j];
-        m[lane][j] = (j < nv && lane < nv && lane != j) ? v : 0.f;
-      }
-      y[lane] = lane < nv ? s.Mdiag[lane] * x[lane] : 0.f;
+      for (int j = 0; j < NVP; j++) m[lane][j] = s.MM[lane & (NVP - 1)][j];
+      y[lane] = 0.f;
     }
 #pragma unroll
     for (int j = 0; j < NVP; j++) {
@@ -2327,7 +2329,9 @@ struct StepKernel {
         PL<float[16]> a;
         LANES {
 #pragma unroll
-          for (int u = 0; u < 16; u++) a[lane][u] = (lane < NVP && r0 + u < ne) ? s.J[r0 + u][lane] : 0.f;
+          // rows >= ne of J are zero.  Lanes 32..63 mirror lanes 0..31 (their `out` is never used): no `lane < NVP` select --
+          // that mask, hoisted and spilled, was reloaded with two v_readlane per use
+          for (int u = 0; u < 16; u++) a[lane][u] = s.J[r0 + u][lane & (NVP - 1)];
         }
 #pragma unroll
         for (int u = 0; u < 16; u++) {
@@ -2371,19 +2375,21 @@ struct StepKernel {
     }
   }
   template <int K, int N>
-  SMJ_DEV void gj_cols(PL<float[NVP]>& hrow, PL<float>& x, PL<float>& pinv) {
+  SMJ_DEV void gj_cols(PL<float[NVP]>& hrow, PL<float>& x, PL<float>& pinv, const PL<int>& ol) {
     if constexpr (K < N) {
       PL<float> col, mult;
       LANES { col[lane] = hrow[lane][K]; }
       const float rp = fast_rcp(fmaxf(wave_read(col, K), 1e-30f));
       LANES {
-        mult[lane] = lane == K ? 0.f : col[lane] * rp;   // the pivot row itself is left alone; its scale is applied at the end
-        if (lane == K) pinv[lane] = rp;
+        // (ol = the lane id made opaque once per solve: the 28-32 `lane == K` masks are then compared where they are used
+        // instead of being hoisted out of the step loop, where each would pin -- and spill -- an SGPR pair for the whole kernel)
+        mult[lane] = ol[lane] == K ? 0.f : col[lane] * rp;   // the pivot row itself is left alone; its scale is applied at the end
+        if (ol[lane] == K) pinv[lane] = rp;
       }
       gj_pair<K, K + 1, N>(hrow, mult);
       const float xk = wave_read(x, K);
       LANES { x[lane] -= mult[lane] * xk; }
-      gj_cols<K + 1, N>(hrow, x, pinv);
+      gj_cols<K + 1, N>(hrow, x, pinv, ol);
     }
   }
   // N = matrix order actually eliminated (rows / columns >= nv are identity padding and never touched)
@@ -2391,14 +2397,18 @@ struct StepKernel {
   SMJ_DEV void gj_solve(PL<float>& x) {
     PL<float[NVP]> hrow;
     PL<float> pinv;
+    PL<int> ol;
+    LANES { ol[lane] = opaque(lane); }
     LANES {
-      const int i = lane < N ? lane : 0;
+      // lanes >= N: rows N..31 are identity padding (never touched by the elimination), lanes 32..63 mirror lanes 0..31;
+      // their x is zeroed below and scaled by pinv = 0 at the end, so they need no `lane < N` select per element
+      const int i = lane & (NVP - 1);
 #pragma unroll
-      for (int k = 0; k < N; k++) hrow[lane][k] = (lane < N) ? s.u.n.H[i][k] : 0.f;
+      for (int k = 0; k < N; k++) hrow[lane][k] = s.u.n.H[i][k];
       pinv[lane] = 0.f;
       if (lane >= N) x[lane] = 0.f;
     }
-    gj_cols<0, N>(hrow, x, pinv);
+    gj_cols<0, N>(hrow, x, pinv, ol);
     LANES { x[lane] *= pinv[lane]; }
   }
   SMJ_DEV void solve_H(PL<float>& x) {
@@ -2582,11 +2592,11 @@ struct StepKernel {
               for (int ks = 0; ks < KB; ks++) {
                 const int k = 4 * (kb + ks) + (lane >> 4), c = lane & 15;
                 if (kb + ks < NEFC / 4) {                      // compile-time: k stays inside XA / J
-                  const bool on = kb + ks < ksteps;            // rows >= ne of XA / J are zero
-                  a0[lane][ks] = on ? s.u.n.XA[k][c] : 0.f;
-                  a1[lane][ks] = on ? s.u.n.XA[k][16 + c] : 0.f;
-                  b0[lane][ks] = on ? s.J[k][c] : 0.f;
-                  b1[lane][ks] = on ? s.J[k][16 + c] : 0.f;
+                  // unconditional: rows >= ne of XA / J are zero, and the k-steps beyond ne are skipped below anyway
+                  a0[lane][ks] = s.u.n.XA[k][c];
+                  a1[lane][ks] = s.u.n.XA[k][16 + c];
+                  b0[lane][ks] = s.J[k][c];
+                  b1[lane][ks] = s.J[k][16 + c];
                 }
               }
             }
@@ -2610,9 +2620,7 @@ struct StepKernel {
             for (int r = 0; r < 4; r++) {
               const int row = 16 * ta + (lane >> 4) * 4 + r, col = 16 * tb + (lane & 15);
               float v = t == 0 ? acc00[lane].r[r] : (t == 1 ? acc10[lane].r[r] : acc11[lane].r[r]);
-              const float mv = row == col ? s.Mdiag[row] : (row < col ? s.MM[row][col] : s.MM[col][row]);
-              if (row < nv && col < nv) v += mv;
-              else v = row == col ? 1.f : 0.f;
+              v += s.MM[row][col];   // the full symmetric M, identity beyond nv (setup); acc is zero there (J, XA columns >= nv are zero)
               s.u.n.H[row][col] = v;
               if (ta != tb) s.u.n.H[col][row] = v;
             }
