@@ -47,7 +47,12 @@ struct DevModel {
 #define X(n) const float* n;
   SMJ_MODEL_F32(X)
 #undef X
+  // Per-lane stage records, built at load time from the tables above (smj_build_lanerec): everything the kernel's stage-table
+  // loaders need for lane L, already gathered (no dependent loads) and contiguous -- one base pointer and a few wide loads
+  // instead of ~60 table pointers and three levels of pointer chasing.  Floats are stored as their bit patterns.
+  const int* k_lanerec;   // [64][SMJ_LR_STRIDE]
 };
+enum { SMJ_LR_KIN = 0, SMJ_LR_BODY = 36, SMJ_LR_DOF = 60, SMJ_LR_ENT = 76, SMJ_LR_ACT = 112, SMJ_LR_STRIDE = 140 };
 
 // Batch-major simulator state bound through smj_bind() (include/smj.h).  ld = row stride in elements (>= B).
 struct DevState {

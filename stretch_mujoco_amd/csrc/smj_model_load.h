@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -28,6 +29,80 @@ struct SmjBlob {
     return nullptr;
   }
 };
+
+// Host restatement of what the kernel's stage-table loaders (smj_step_impl.h: KinTab, BodyTab, DofTab, EntryTab, ActTab)
+// used to gather per lane from the individual tables, one record per lane.
+static inline std::vector<int> smj_build_lanerec(const DevModel& m, std::map<std::string, std::vector<int>>& I,
+                                                 std::map<std::string, std::vector<float>>& F) {
+  std::vector<int> rec(64 * SMJ_LR_STRIDE, 0);
+  auto fb = [](float v) { int b; memcpy(&b, &v, 4); return b; };
+  auto gi = [&](const char* n, size_t k) { const std::vector<int>& v = I[n]; return k < v.size() ? v[k] : 0; };
+  auto gf = [&](const char* n, size_t k) { const std::vector<float>& v = F[n]; return k < v.size() ? v[k] : 0.f; };
+  const int nb = m.nbody, nv = m.nv, nu = m.nu;
+  for (int L = 0; L < 64; L++) {
+    int* r = rec.data() + L * SMJ_LR_STRIDE;
+    {  // KinTab: parent, level, jump[6], pos[3], quat[4], jtype[2], jqadr[2], jdadr[2], jq0[2], jaxis[6], jpos[6]
+      int* k = r + SMJ_LR_KIN;
+      const int b = L < nb ? L : 0;
+      k[0] = gi("body_parentid", b); k[1] = L < nb ? gi("k_body_level", b) : -1;
+      for (int q = 0; q < 6; q++) k[2 + q] = (q < m.njump && L > 0 && L < nb) ? gi("k_body_jump", q * nb + b) : 0;
+      for (int q = 0; q < 3; q++) k[8 + q] = fb(gf("body_pos", 3 * b + q));
+      for (int q = 0; q < 4; q++) k[11 + q] = fb(gf("body_quat", 4 * b + q));
+      const int jn = gi("body_jntnum", b), ja = gi("body_jntadr", b);
+      for (int u = 0; u < 2; u++) {
+        const int jj = (L < nb && u < jn) ? ja + u : -1, jx = jj >= 0 ? jj : 0, qa = gi("jnt_qposadr", jx);
+        k[15 + u] = jj >= 0 ? gi("jnt_type", jx) : -1; k[17 + u] = qa; k[19 + u] = gi("jnt_dofadr", jx); k[21 + u] = fb(gf("qpos0", qa));
+        for (int q = 0; q < 3; q++) { k[23 + 3 * u + q] = fb(gf("jnt_axis", 3 * jx + q)); k[29 + 3 * u + q] = fb(gf("jnt_pos", 3 * jx + q)); }
+      }
+    }
+    {  // BodyTab: root, subsize, parent, dofadr, dofnum, jump[6], dofmask lo, hi, inertia_local[10]
+      int* k = r + SMJ_LR_BODY;
+      const int b = L < nb ? L : 0;
+      k[0] = gi("body_rootid", b); k[1] = gi("k_body_subtreesize", b); k[2] = gi("body_parentid", b); k[3] = gi("body_dofadr", b);
+      k[4] = L < nb ? gi("body_dofnum", b) : 0;
+      for (int q = 0; q < 6; q++) k[5 + q] = (q < m.njump && L > 0 && L < nb) ? gi("k_body_jump", q * nb + b) : 0;
+      k[11] = gi("k_body_dofmask_lo", b); k[12] = gi("k_body_dofmask_hi", b);
+      for (int q = 0; q < 10; q++) k[13 + q] = fb(gf("k_body_inertia_local", 10 * b + q));
+    }
+    {  // DofTab: body, jtype, qadr, first, bsub, velmask lo, hi, damp, stiff, spring, act[2], actmom[2]
+      int* k = r + SMJ_LR_DOF;
+      const int d = L < nv ? L : 0, j = gi("dof_jntid", d), db = gi("dof_bodyid", d), jt = gi("jnt_type", j);
+      k[0] = db; k[1] = jt; k[2] = gi("k_dof_qposadr", d); k[3] = gi("jnt_dofadr", j); k[4] = gi("k_body_subtreesize", db);
+      k[5] = gi("k_dof_velmask_lo", d); k[6] = gi("k_dof_velmask_hi", d);
+      k[7] = fb(gf("dof_damping", d));
+      k[8] = fb(jt == 0 ? 0.f : gf("jnt_stiffness", j));
+      k[9] = fb(jt == 0 ? 0.f : gf("qpos_spring", gi("jnt_qposadr", j)));
+      for (int u = 0; u < 2; u++) { k[10 + u] = gi("k_dof_act", 2 * d + u); k[12 + u] = fb(gf("k_dof_actmom", 2 * d + u)); }
+    }
+    {  // EntryTab, 5 mass-matrix pattern slots: i[5], j[5], arm[5] | lact[5], damp[5], dcoef[5], lcoef[5] (implicit only)
+      int* k = r + SMJ_LR_ENT;
+      for (int u = 0; u < 5; u++) {
+        const int e = L + 64 * u, ok = e < m.nldl, ex = ok ? e : 0, i = gi("k_ldl_i", ex), j = gi("k_ldl_j", ex);
+        k[u] = ok ? i : -1; k[5 + u] = ok ? j : 0; k[10 + u] = fb((ok && i == j) ? gf("dof_armature", i) : 0.f);
+        k[15 + u] = ok ? gi("k_ldl_lact", ex) : -1;
+        k[20 + u] = fb(ok ? gf("k_ldl_damp", ex) : 0.f); k[25 + u] = fb(ok ? gf("k_ldl_dcoef", ex) : 0.f); k[30 + u] = fb(ok ? gf("k_ldl_lcoef", ex) : 0.f);
+      }
+    }
+    {  // ActTab: dof[4], qadr[4], mom[4], prm[8], flags, gc_body, gc_mlo, gc_mhi, gc_mass, gc_x, gc_y, gc_z
+      int* k = r + SMJ_LR_ACT;
+      const int a = L < nu ? L : 0;
+      for (int u = 0; u < 4; u++) {
+        const int dd = gi("k_act_dof", 4 * a + u);
+        k[u] = L < nu ? dd : -1; k[4 + u] = dd >= 0 ? gi("k_dof_qposadr", dd) : 0; k[8 + u] = fb(gf("k_act_mom", 4 * a + u));
+      }
+      k[12] = fb(gf("actuator_gainprm", 3 * a));
+      for (int q = 0; q < 3; q++) k[13 + q] = fb(gf("actuator_biasprm", 3 * a + q));
+      k[16] = fb(gf("actuator_ctrlrange", 2 * a)); k[17] = fb(gf("actuator_ctrlrange", 2 * a + 1));
+      k[18] = fb(gf("actuator_forcerange", 2 * a)); k[19] = fb(gf("actuator_forcerange", 2 * a + 1));
+      k[20] = (gi("actuator_ctrllimited", a) ? 1 : 0) | (gi("actuator_forcelimited", a) ? 2 : 0) | (gi("actuator_biastype", a) == 1 ? 4 : 0);
+      const int g = L < m.ngc ? gi("k_gc_body", L) : 0;
+      k[21] = g; k[22] = gi("k_body_dofmask_lo", g); k[23] = gi("k_body_dofmask_hi", g);
+      k[24] = fb(L < m.ngc ? gf("body_gcmass", g) : 0.f);
+      for (int q = 0; q < 3; q++) k[25 + q] = fb(gf("body_gcipos", 3 * g + q));
+    }
+  }
+  return rec;
+}
 
 template <class Up>
 int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::string& err) {
@@ -76,6 +151,8 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
   if (m.ngc > 16) { err = "more than 16 gravity-compensated bodies"; return -4; }
   if (m.njump > 6) { err = "body tree deeper than 64 levels"; return -4; }
   if (m.ncgeom > NCG) { err = "too many geoms in non-plane collision pairs"; return -4; }
+  std::map<std::string, std::vector<int>> hosti;
+  std::map<std::string, std::vector<float>> hostf;
 #define X(n)                                                                               \
   {                                                                                        \
     const SmjBlobEntry* e = b.find(#n);                                                    \
@@ -83,6 +160,7 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
     std::vector<int> h(e->nbytes / 4 ? e->nbytes / 4 : 1, 0);                              \
     memcpy(h.data(), b.p + e->offset, e->nbytes);                                          \
     m.n = up.i32(h);                                                                       \
+    hosti[#n] = h;                                                                         \
     if (!m.n) { err = "device allocation failed for " #n; return -2; }                     \
   }
   SMJ_MODEL_I32(X)
@@ -96,9 +174,15 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
     const double* src = reinterpret_cast<const double*>(b.p + e->offset);                  \
     for (size_t i = 0; i < cnt; i++) h[i] = (float)src[i];                                 \
     m.n = up.f32(h);                                                                       \
+    hostf[#n] = h;                                                                         \
     if (!m.n) { err = "device allocation failed for " #n; return -2; }                     \
   }
   SMJ_MODEL_F32(X)
 #undef X
+  {
+    std::vector<int> rec = smj_build_lanerec(m, hosti, hostf);
+    m.k_lanerec = up.i32(rec);
+    if (!m.k_lanerec) { err = "device allocation failed for k_lanerec"; return -2; }
+  }
   return 0;
 }

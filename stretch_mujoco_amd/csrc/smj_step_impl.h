@@ -233,24 +233,24 @@ struct StepKernel {
     PL<float[2]> jq0;
     PL<float[6]> jaxis, jpos;
   };
+  // one lane's record of the per-lane stage tables (DevModel::k_lanerec): 16-byte aligned, contiguous
+  SMJ_DEV const int* lanerec(int ol, int off) const {
+    return static_cast<const int*>(__builtin_assume_aligned(M.k_lanerec + ol * SMJ_LR_STRIDE + off, 16));
+  }
+  SMJ_DEV static float asf(int b) { return __builtin_bit_cast(float, b); }
   SMJ_DEV void load(KinTab& t) {
-    const int nb = M.nbody;
     LANES {
-      const int ol = opaque(lane);
-      const int b = ol < nb ? ol : 0;
-      t.parent[lane] = M.body_parentid[b]; t.level[lane] = lane < nb ? M.k_body_level[b] : -1;
-      for (int r = 0; r < 6; r++) t.jump[lane][r] = (r < M.njump && lane > 0 && lane < nb) ? M.k_body_jump[r * nb + b] : 0;
-      for (int k = 0; k < 3; k++) t.pos[lane][k] = M.body_pos[3 * b + k];
-      for (int k = 0; k < 4; k++) t.quat[lane][k] = M.body_quat[4 * b + k];
-      const int jn = M.body_jntnum[b], ja = M.body_jntadr[b];
+      const int* r = lanerec(opaque(lane), SMJ_LR_KIN);
+      int v[35];
+      for (int k = 0; k < 35; k++) v[k] = r[k];
+      t.parent[lane] = v[0]; t.level[lane] = v[1];
+      for (int q = 0; q < 6; q++) t.jump[lane][q] = v[2 + q];
+      for (int k = 0; k < 3; k++) t.pos[lane][k] = asf(v[8 + k]);
+      for (int k = 0; k < 4; k++) t.quat[lane][k] = asf(v[11 + k]);
       for (int u = 0; u < 2; u++) {
-        const int jj = (lane < nb && u < jn) ? ja + u : -1, jx = jj >= 0 ? jj : 0;
-        const int qa = M.jnt_qposadr[jx];
-        t.jtype[lane][u] = jj >= 0 ? M.jnt_type[jx] : -1;
-        t.jqadr[lane][u] = qa; t.jdadr[lane][u] = M.jnt_dofadr[jx];
-        t.jq0[lane][u] = M.qpos0[qa];
-        for (int k = 0; k < 3; k++) { t.jaxis[lane][3 * u + k] = M.jnt_axis[3 * jx + k]; t.jpos[lane][3 * u + k] = M.jnt_pos[3 * jx + k]; }
+        t.jtype[lane][u] = v[15 + u]; t.jqadr[lane][u] = v[17 + u]; t.jdadr[lane][u] = v[19 + u]; t.jq0[lane][u] = asf(v[21 + u]);
       }
+      for (int k = 0; k < 6; k++) { t.jaxis[lane][k] = asf(v[23 + k]); t.jpos[lane][k] = asf(v[29 + k]); }
     }
   }
   struct BodyTab {  // lane = body: inertia and tree bookkeeping
@@ -261,13 +261,13 @@ struct StepKernel {
   };
   SMJ_DEV void load(BodyTab& t) {
     LANES {
-      const int ol = opaque(lane);
-      const int b = ol < M.nbody ? ol : 0;
-      t.root[lane] = M.body_rootid[b]; t.subsize[lane] = M.k_body_subtreesize[b];
-      t.parent[lane] = M.body_parentid[b]; t.dofadr[lane] = M.body_dofadr[b]; t.dofnum[lane] = lane < M.nbody ? M.body_dofnum[b] : 0;
-      for (int r = 0; r < 6; r++) t.jump[lane][r] = (r < M.njump && lane > 0 && lane < M.nbody) ? M.k_body_jump[r * M.nbody + b] : 0;
-      t.dofmask[lane] = mk64(M.k_body_dofmask_lo[b], M.k_body_dofmask_hi[b]);
-      for (int k = 0; k < 10; k++) t.inl[lane][k] = M.k_body_inertia_local[10 * b + k];
+      const int* r = lanerec(opaque(lane), SMJ_LR_BODY);
+      int v[23];
+      for (int k = 0; k < 23; k++) v[k] = r[k];
+      t.root[lane] = v[0]; t.subsize[lane] = v[1]; t.parent[lane] = v[2]; t.dofadr[lane] = v[3]; t.dofnum[lane] = v[4];
+      for (int q = 0; q < 6; q++) t.jump[lane][q] = v[5 + q];
+      t.dofmask[lane] = mk64(v[11], v[12]);
+      for (int k = 0; k < 10; k++) t.inl[lane][k] = asf(v[13 + k]);
     }
   }
   struct DofTab {   // lane = dof
@@ -279,16 +279,13 @@ struct StepKernel {
   };
   SMJ_DEV void load(DofTab& t) {
     LANES {
-      const int ol = opaque(lane);
-      const int d = ol < M.nv ? ol : 0, j = M.dof_jntid[d], db = M.dof_bodyid[d];
-      const int jt = M.jnt_type[j];
-      t.body[lane] = db; t.jtype[lane] = jt; t.qadr[lane] = M.k_dof_qposadr[d]; t.first[lane] = M.jnt_dofadr[j];
-      t.bsub[lane] = M.k_body_subtreesize[db];
-      t.velmask[lane] = mk64(M.k_dof_velmask_lo[d], M.k_dof_velmask_hi[d]);
-      t.damp[lane] = M.dof_damping[d];
-      t.stiff[lane] = (jt == JT_FREE) ? 0.f : M.jnt_stiffness[j];
-      t.spring[lane] = (jt == JT_FREE) ? 0.f : M.qpos_spring[M.jnt_qposadr[j]];
-      for (int u = 0; u < 2; u++) { t.act[lane][u] = M.k_dof_act[2 * d + u]; t.actmom[lane][u] = M.k_dof_actmom[2 * d + u]; }
+      const int* r = lanerec(opaque(lane), SMJ_LR_DOF);
+      int v[14];
+      for (int k = 0; k < 14; k++) v[k] = r[k];
+      t.body[lane] = v[0]; t.jtype[lane] = v[1]; t.qadr[lane] = v[2]; t.first[lane] = v[3]; t.bsub[lane] = v[4];
+      t.velmask[lane] = mk64(v[5], v[6]);
+      t.damp[lane] = asf(v[7]); t.stiff[lane] = asf(v[8]); t.spring[lane] = asf(v[9]);
+      for (int u = 0; u < 2; u++) { t.act[lane][u] = v[10 + u]; t.actmom[lane][u] = asf(v[12 + u]); }
     }
   }
   struct EntryTab { // lane = mass-matrix pattern slots (5 per lane)
@@ -297,19 +294,12 @@ struct StepKernel {
   };
   SMJ_DEV void load(EntryTab& t, bool implicit) {
     LANES {
-      const int ol = opaque(lane);
-      for (int u = 0; u < 5; u++) {
-        const int e = ol + 64 * u, ok = e < M.nldl, ex = ok ? e : 0;
-        const int i = M.k_ldl_i[ex], j = M.k_ldl_j[ex];
-        t.i[lane][u] = ok ? i : -1; t.j[lane][u] = ok ? j : 0;
-        t.arm[lane][u] = (ok && i == j) ? M.dof_armature[i] : 0.f;
-        if (implicit) {
-          t.lact[lane][u] = ok ? M.k_ldl_lact[ex] : -1;
-          t.damp[lane][u] = ok ? M.k_ldl_damp[ex] : 0.f;
-          t.dcoef[lane][u] = ok ? M.k_ldl_dcoef[ex] : 0.f;
-          t.lcoef[lane][u] = ok ? M.k_ldl_lcoef[ex] : 0.f;
+      const int* r = lanerec(opaque(lane), SMJ_LR_ENT);
+      for (int u = 0; u < 5; u++) { t.i[lane][u] = r[u]; t.j[lane][u] = r[5 + u]; t.arm[lane][u] = asf(r[10 + u]); }
+      if (implicit)
+        for (int u = 0; u < 5; u++) {
+          t.lact[lane][u] = r[15 + u]; t.damp[lane][u] = asf(r[20 + u]); t.dcoef[lane][u] = asf(r[25 + u]); t.lcoef[lane][u] = asf(r[30 + u]);
         }
-      }
     }
   }
   struct ActTab {   // lane = actuator, and lane = gravity-compensated body slot
@@ -322,23 +312,13 @@ struct StepKernel {
   };
   SMJ_DEV void load(ActTab& t) {
     LANES {
-      const int ol = opaque(lane);
-      const int a = ol < M.nu ? ol : 0;
-      for (int u = 0; u < 4; u++) {
-        const int dd = M.k_act_dof[4 * a + u];
-        t.dof[lane][u] = lane < M.nu ? dd : -1;
-        t.mom[lane][u] = M.k_act_mom[4 * a + u];
-        t.qadr[lane][u] = dd >= 0 ? M.k_dof_qposadr[dd] : 0;
-      }
-      t.prm[lane][0] = M.actuator_gainprm[3 * a];
-      for (int k = 0; k < 3; k++) t.prm[lane][1 + k] = M.actuator_biasprm[3 * a + k];
-      t.prm[lane][4] = M.actuator_ctrlrange[2 * a]; t.prm[lane][5] = M.actuator_ctrlrange[2 * a + 1];
-      t.prm[lane][6] = M.actuator_forcerange[2 * a]; t.prm[lane][7] = M.actuator_forcerange[2 * a + 1];
-      t.flags[lane] = (M.actuator_ctrllimited[a] ? 1 : 0) | (M.actuator_forcelimited[a] ? 2 : 0) | (M.actuator_biastype[a] == 1 ? 4 : 0);
-      const int g = ol < M.ngc ? M.k_gc_body[ol] : 0;
-      t.gc_body[lane] = g; t.gc_mass[lane] = lane < M.ngc ? M.body_gcmass[g] : 0.f;
-      t.gc_mlo[lane] = M.k_body_dofmask_lo[g]; t.gc_mhi[lane] = M.k_body_dofmask_hi[g];
-      t.gc_x[lane] = M.body_gcipos[3 * g]; t.gc_y[lane] = M.body_gcipos[3 * g + 1]; t.gc_z[lane] = M.body_gcipos[3 * g + 2];
+      const int* r = lanerec(opaque(lane), SMJ_LR_ACT);
+      int v[28];
+      for (int k = 0; k < 28; k++) v[k] = r[k];
+      for (int u = 0; u < 4; u++) { t.dof[lane][u] = v[u]; t.qadr[lane][u] = v[4 + u]; t.mom[lane][u] = asf(v[8 + u]); }
+      for (int k = 0; k < 8; k++) t.prm[lane][k] = asf(v[12 + k]);
+      t.flags[lane] = v[20]; t.gc_body[lane] = v[21]; t.gc_mlo[lane] = v[22]; t.gc_mhi[lane] = v[23];
+      t.gc_mass[lane] = asf(v[24]); t.gc_x[lane] = asf(v[25]); t.gc_y[lane] = asf(v[26]); t.gc_z[lane] = asf(v[27]);
     }
   }
 
