@@ -51,8 +51,20 @@ struct DevModel {
   // loaders need for lane L, already gathered (no dependent loads) and contiguous -- one base pointer and a few wide loads
   // instead of ~60 table pointers and three levels of pointer chasing.  Floats are stored as their bit patterns.
   const int* k_lanerec;   // [64][SMJ_LR_STRIDE]
+  // Same idea for the collision stage: one record per plane pair (table order) and per geom of the convex-pair cache.
+  const int* k_pprec;     // [nplanepair][SMJ_PP_STRIDE]
+  const int* k_cgrec;     // [ncgeom][SMJ_CG_STRIDE]
 };
 enum { SMJ_LR_KIN = 0, SMJ_LR_BODY = 36, SMJ_LR_DOF = 60, SMJ_LR_ENT = 76, SMJ_LR_ACT = 112, SMJ_LR_STRIDE = 140 };
+// plane-pair record: pair, geom1 (the plane), geom2, their bodies, geom2 type, margin, geom2 bounding radius / centre,
+// local frames of both geoms, geom2 size, then the contact parameters of the pair
+enum { SMJ_PP_PAIR = 0, SMJ_PP_G1, SMJ_PP_G2, SMJ_PP_B1, SMJ_PP_B2, SMJ_PP_T2, SMJ_PP_MARGIN, SMJ_PP_RBOUND2, SMJ_PP_BCEN2 = 8,
+       SMJ_PP_POS1 = 11, SMJ_PP_MAT1 = 14, SMJ_PP_POS2 = 23, SMJ_PP_MAT2 = 26, SMJ_PP_SIZE2 = 35, SMJ_PP_CONDIM = 38, SMJ_PP_MG = 39,
+       SMJ_PP_FRIC = 40, SMJ_PP_SOLIMP = 45, SMJ_PP_SOLREF = 50, SMJ_PP_STRIDE = 52 };
+// convex-cache geom record: geom, body, packed type|hull count|hull address, local frame, bounding-box centre and half
+// sizes, MPR interior point, geom size
+enum { SMJ_CG_GEOM = 0, SMJ_CG_BODY, SMJ_CG_META, SMJ_CG_POS = 3, SMJ_CG_MAT = 6, SMJ_CG_LCEN = 15, SMJ_CG_HALF = 18, SMJ_CG_CCEN = 21,
+       SMJ_CG_SIZE = 24, SMJ_CG_STRIDE = 28 };
 
 // Batch-major simulator state bound through smj_bind() (include/smj.h).  ld = row stride in elements (>= B).
 struct DevState {

@@ -104,6 +104,50 @@ static inline std::vector<int> smj_build_lanerec(const DevModel& m, std::map<std
   return rec;
 }
 
+static inline std::vector<int> smj_build_pprec(const DevModel& m, std::map<std::string, std::vector<int>>& I,
+                                               std::map<std::string, std::vector<float>>& F) {
+  std::vector<int> rec((size_t)(m.nplanepair > 0 ? m.nplanepair : 1) * SMJ_PP_STRIDE, 0);
+  auto fb = [](float v) { int b; memcpy(&b, &v, 4); return b; };
+  auto gi = [&](const char* n, size_t k) { const std::vector<int>& v = I[n]; return k < v.size() ? v[k] : 0; };
+  auto gf = [&](const char* n, size_t k) { const std::vector<float>& v = F[n]; return k < v.size() ? v[k] : 0.f; };
+  for (int t = 0; t < m.nplanepair; t++) {
+    int* k = rec.data() + (size_t)t * SMJ_PP_STRIDE;
+    const int p = gi("k_planepair", t), g1 = gi("pair_geom1", p), g2 = gi("pair_geom2", p);
+    k[SMJ_PP_PAIR] = p; k[SMJ_PP_G1] = g1; k[SMJ_PP_G2] = g2; k[SMJ_PP_B1] = gi("geom_bodyid", g1); k[SMJ_PP_B2] = gi("geom_bodyid", g2);
+    k[SMJ_PP_T2] = gi("geom_type", g2); k[SMJ_PP_MARGIN] = fb(gf("pair_margin", p)); k[SMJ_PP_RBOUND2] = fb(gf("geom_rbound", g2));
+    for (int q = 0; q < 3; q++) {
+      k[SMJ_PP_BCEN2 + q] = fb(gf("k_geom_bcenter", 3 * g2 + q));
+      k[SMJ_PP_POS1 + q] = fb(gf("geom_pos", 3 * g1 + q)); k[SMJ_PP_POS2 + q] = fb(gf("geom_pos", 3 * g2 + q));
+      k[SMJ_PP_SIZE2 + q] = fb(gf("geom_size", 3 * g2 + q));
+    }
+    for (int q = 0; q < 9; q++) { k[SMJ_PP_MAT1 + q] = fb(gf("k_geom_mat", 9 * g1 + q)); k[SMJ_PP_MAT2 + q] = fb(gf("k_geom_mat", 9 * g2 + q)); }
+    k[SMJ_PP_CONDIM] = gi("pair_condim", p); k[SMJ_PP_MG] = fb(gf("pair_margin", p) - gf("pair_gap", p));
+    for (int q = 0; q < 5; q++) { k[SMJ_PP_FRIC + q] = fb(gf("pair_friction", 5 * p + q)); k[SMJ_PP_SOLIMP + q] = fb(gf("pair_solimp", 5 * p + q)); }
+    k[SMJ_PP_SOLREF] = fb(gf("pair_solref", 2 * p)); k[SMJ_PP_SOLREF + 1] = fb(gf("pair_solref", 2 * p + 1));
+  }
+  return rec;
+}
+static inline std::vector<int> smj_build_cgrec(const DevModel& m, std::map<std::string, std::vector<int>>& I,
+                                               std::map<std::string, std::vector<float>>& F) {
+  std::vector<int> rec((size_t)(m.ncgeom > 0 ? m.ncgeom : 1) * SMJ_CG_STRIDE, 0);
+  auto fb = [](float v) { int b; memcpy(&b, &v, 4); return b; };
+  auto gi = [&](const char* n, size_t k) { const std::vector<int>& v = I[n]; return k < v.size() ? v[k] : 0; };
+  auto gf = [&](const char* n, size_t k) { const std::vector<float>& v = F[n]; return k < v.size() ? v[k] : 0.f; };
+  for (int c = 0; c < m.ncgeom; c++) {
+    int* k = rec.data() + (size_t)c * SMJ_CG_STRIDE;
+    const int g = gi("k_cgeom", c), adr = gi("geom_hulladr", g);
+    k[SMJ_CG_GEOM] = g; k[SMJ_CG_BODY] = gi("geom_bodyid", g);
+    k[SMJ_CG_META] = (int)((unsigned)gi("geom_type", g) | ((unsigned)gi("geom_hullnum", g) << 4) | ((unsigned)(adr < 0 ? 0 : adr) << 16));
+    for (int q = 0; q < 3; q++) {
+      k[SMJ_CG_POS + q] = fb(gf("geom_pos", 3 * g + q)); k[SMJ_CG_LCEN + q] = fb(gf("k_cgeom_lcen", 3 * c + q));
+      k[SMJ_CG_HALF + q] = fb(gf("k_cgeom_half", 3 * c + q)); k[SMJ_CG_CCEN + q] = fb(gf("geom_ccenter", 3 * g + q));
+      k[SMJ_CG_SIZE + q] = fb(gf("geom_size", 3 * g + q));
+    }
+    for (int q = 0; q < 9; q++) k[SMJ_CG_MAT + q] = fb(gf("k_geom_mat", 9 * g + q));
+  }
+  return rec;
+}
+
 template <class Up>
 int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::string& err) {
   if (!blob || nbytes < 16 || memcmp(blob, "SMJB0001", 8) != 0) { err = "not an SMJB model blob"; return -1; }
@@ -183,6 +227,10 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
     std::vector<int> rec = smj_build_lanerec(m, hosti, hostf);
     m.k_lanerec = up.i32(rec);
     if (!m.k_lanerec) { err = "device allocation failed for k_lanerec"; return -2; }
+    std::vector<int> pp = smj_build_pprec(m, hosti, hostf), cg = smj_build_cgrec(m, hosti, hostf);
+    m.k_pprec = up.i32(pp);
+    m.k_cgrec = up.i32(cg);
+    if (!m.k_pprec || !m.k_cgrec) { err = "device allocation failed for the collision records"; return -2; }
   }
   return 0;
 }

@@ -889,6 +889,12 @@ struct StepKernel {
     for (int k = 0; k < 9; k++) lm[k] = M.k_geom_mat[9 * g + k];
     mulmat3(mat, s.xmat[b], lm);
   }
+  // the same from a record: body id, local position and local frame already in registers
+  SMJ_DEV void pose_from(int b, const float* lp, const float* lm, float* pos, float* mat) const {
+    mulmat3vec(pos, s.xmat[b], lp);
+    for (int k = 0; k < 3; k++) pos[k] += s.xpos[b][k];
+    mulmat3(mat, s.xmat[b], lm);
+  }
   // [MJ] mju_makeFrame: fr[0:3] = normal given; tangents built around it
   SMJ_DEV static void make_frame(float* fr) {
     normalize3(fr);
@@ -928,21 +934,31 @@ struct StepKernel {
         int cnt = 0, hl = 0;
         const int t = base + lane;
         if (t < M.nplanepair) {
-          const int p = M.k_planepair[t], g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
-          const int b2 = M.geom_bodyid[g2];
-          float pp[3], pm[9];
-          geom_pose(g1, pp, pm);
-          float c2[3], lc[3] = {M.k_geom_bcenter[3 * g2], M.k_geom_bcenter[3 * g2 + 1], M.k_geom_bcenter[3 * g2 + 2]};
+          // the pair's record (DevModel::k_pprec): one level of wide loads instead of pair -> geoms -> bodies / frames / sizes
+          const int* r = static_cast<const int*>(__builtin_assume_aligned(M.k_pprec + opaque(t) * SMJ_PP_STRIDE, 16));
+          int v[SMJ_PP_CONDIM];
+          for (int k = 0; k < SMJ_PP_CONDIM; k++) v[k] = r[k];
+          const int b1 = v[SMJ_PP_B1], b2 = v[SMJ_PP_B2];
+          float lp1[3], lm1[9], pp[3], pm[9];
+          for (int k = 0; k < 3; k++) lp1[k] = asf(v[SMJ_PP_POS1 + k]);
+          for (int k = 0; k < 9; k++) lm1[k] = asf(v[SMJ_PP_MAT1 + k]);
+          pose_from(b1, lp1, lm1, pp, pm);
+          float c2[3], lc[3] = {asf(v[SMJ_PP_BCEN2]), asf(v[SMJ_PP_BCEN2 + 1]), asf(v[SMJ_PP_BCEN2 + 2])};
           mulmat3vec(c2, s.xmat[b2], lc);
           const float n[3] = {pm[2], pm[5], pm[8]};   // plane normal = z axis of the plane geom frame
           const float dif[3] = {c2[0] + s.xpos[b2][0] - pp[0], c2[1] + s.xpos[b2][1] - pp[1], c2[2] + s.xpos[b2][2] - pp[2]};
-          const float margin = M.pair_margin[p];
-          if (dot3(dif, n) - M.geom_rbound[g2] <= margin) {
-            const int t2 = M.geom_type[g2];
+          const float margin = asf(v[SMJ_PP_MARGIN]);
+          if (dot3(dif, n) - asf(v[SMJ_PP_RBOUND2]) <= margin) {
+            const int t2 = v[SMJ_PP_T2];
             if (t2 == GT_MESH) hl = 1;
-            else cnt = plane_prim(g2, t2, pp, n, margin, s.u.p.dist[lane], s.u.p.pos[lane]);
+            else {
+              float lp2[3], lm2[9], size[3];
+              for (int k = 0; k < 3; k++) { lp2[k] = asf(v[SMJ_PP_POS2 + k]); size[k] = asf(v[SMJ_PP_SIZE2 + k]); }
+              for (int k = 0; k < 9; k++) lm2[k] = asf(v[SMJ_PP_MAT2 + k]);
+              cnt = plane_prim(b2, lp2, lm2, size, t2, pp, n, margin, s.u.p.dist[lane], s.u.p.pos[lane]);
+            }
             for (int k = 0; k < 3; k++) s.u.p.nrm[lane][k] = n[k];
-            s.u.p.pair[lane] = p;
+            s.u.p.pair[lane] = t;   // table slot; the emission below reads the same record
           }
         }
         s.u.p.cnt[lane] = cnt;
@@ -954,7 +970,7 @@ struct StepKernel {
         while (hm) {
           const int l = ffs64(hm);
           hm &= hm - 1;
-          narrow_plane_hull(uni(M.k_planepair[base + l]), l);
+          narrow_plane_hull(uni(M.k_planepair[base + l]), l);   // (lane l staged the table slot; the hull scan wants the pair id)
         }
         SYNC();
       }
@@ -973,14 +989,15 @@ struct StepKernel {
           if (c) {
             const uint64_t lt = (1ull << lane) - 1;
             const int off = ncon + popc64(m0 & lt) + 2 * popc64(m1 & lt) + 4 * popc64(m2 & lt);
-            const int p = s.u.p.pair[lane], g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
+            const int* r = static_cast<const int*>(__builtin_assume_aligned(M.k_pprec + s.u.p.pair[lane] * SMJ_PP_STRIDE, 16));
+            const int g1 = r[SMJ_PP_G1], g2 = r[SMJ_PP_G2];
             // the contacts of one pair share normal, frame and parameters: fetch / build them once, then a fixed 4-slot loop
             float fr[9] = {s.u.p.nrm[lane][0], s.u.p.nrm[lane][1], s.u.p.nrm[lane][2], 0, 0, 0, 0, 0, 0};
             make_frame(fr);
             float fric[5], simp[5];
-            for (int k = 0; k < 5; k++) { fric[k] = M.pair_friction[5 * p + k]; simp[k] = M.pair_solimp[5 * p + k]; }
-            const float sr0 = M.pair_solref[2 * p], sr1 = M.pair_solref[2 * p + 1], mg = M.pair_margin[p] - M.pair_gap[p];
-            const int cd = M.pair_condim[p];
+            for (int k = 0; k < 5; k++) { fric[k] = asf(r[SMJ_PP_FRIC + k]); simp[k] = asf(r[SMJ_PP_SOLIMP + k]); }
+            const float sr0 = asf(r[SMJ_PP_SOLREF]), sr1 = asf(r[SMJ_PP_SOLREF + 1]), mg = asf(r[SMJ_PP_MG]);
+            const int cd = r[SMJ_PP_CONDIM];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
               const int ci = off + k;
@@ -1004,10 +1021,10 @@ struct StepKernel {
   }
 
   // per-lane narrowphase of a plane against a sphere / cylinder / box; returns the number of contacts written
-  SMJ_DEV int plane_prim(int g2, int t2, const float* pp, const float* n, float margin, float* cdist, float (*cpos)[3]) const {
+  SMJ_DEV int plane_prim(int b2, const float* lp2, const float* lm2, const float* size, int t2, const float* pp, const float* n,
+                         float margin, float* cdist, float (*cpos)[3]) const {
     float gp[3], gm[9];
-    geom_pose(g2, gp, gm);
-    const float size[3] = {M.geom_size[3 * g2], M.geom_size[3 * g2 + 1], M.geom_size[3 * g2 + 2]};
+    pose_from(b2, lp2, lm2, gp, gm);
     int cnt = 0;
 #define put(d, q) do { cdist[cnt] = (d); cpos[cnt][0] = (q)[0]; cpos[cnt][1] = (q)[1]; cpos[cnt][2] = (q)[2]; cnt++; } while (0)
     if (t2 == GT_SPHERE) {
@@ -1497,20 +1514,23 @@ struct StepKernel {
       LANES {
         const int c = c0 + lane;
         if (c < M.ncgeom) {
-          const int g = M.k_cgeom[c];
-          float pos[3], mat[9], cw[3];
-          geom_pose(g, pos, mat);
-          const float lc[3] = {M.k_cgeom_lcen[3 * c], M.k_cgeom_lcen[3 * c + 1], M.k_cgeom_lcen[3 * c + 2]};
+          const int* r = static_cast<const int*>(__builtin_assume_aligned(M.k_cgrec + opaque(c) * SMJ_CG_STRIDE, 16));
+          int v[SMJ_CG_STRIDE];
+          for (int k = 0; k < SMJ_CG_STRIDE; k++) v[k] = r[k];
+          float lp[3], lm[9], pos[3], mat[9], cw[3];
+          for (int k = 0; k < 3; k++) lp[k] = asf(v[SMJ_CG_POS + k]);
+          for (int k = 0; k < 9; k++) lm[k] = asf(v[SMJ_CG_MAT + k]);
+          pose_from(v[SMJ_CG_BODY], lp, lm, pos, mat);
+          const float lc[3] = {asf(v[SMJ_CG_LCEN]), asf(v[SMJ_CG_LCEN + 1]), asf(v[SMJ_CG_LCEN + 2])};
           mulmat3vec(cw, mat, lc);
-          for (int k = 0; k < 3; k++) { s.u.c.pos[c][k] = pos[k]; s.u.c.cen[c][k] = pos[k] + cw[k]; s.u.c.half[c][k] = M.k_cgeom_half[3 * c + k]; }
+          for (int k = 0; k < 3; k++) { s.u.c.pos[c][k] = pos[k]; s.u.c.cen[c][k] = pos[k] + cw[k]; s.u.c.half[c][k] = asf(v[SMJ_CG_HALF + k]); }
           for (int k = 0; k < 9; k++) s.u.c.mat[c][k] = mat[k];
           // everything load_shape needs, gathered here lane-parallel so that the (wave-serial) MPR set-up reads LDS only
-          const float lcc[3] = {M.geom_ccenter[3 * g], M.geom_ccenter[3 * g + 1], M.geom_ccenter[3 * g + 2]};
+          const float lcc[3] = {asf(v[SMJ_CG_CCEN]), asf(v[SMJ_CG_CCEN + 1]), asf(v[SMJ_CG_CCEN + 2])};
           float wc[3];
           mulmat3vec(wc, mat, lcc);
-          for (int k = 0; k < 3; k++) { s.u.c.ccen[c][k] = pos[k] + wc[k]; s.u.c.size[c][k] = M.geom_size[3 * g + k]; }
-          const int adr = M.geom_hulladr[g];
-          s.u.c.meta[c] = (int)((unsigned)M.geom_type[g] | ((unsigned)M.geom_hullnum[g] << 4) | ((unsigned)(adr < 0 ? 0 : adr) << 16));
+          for (int k = 0; k < 3; k++) { s.u.c.ccen[c][k] = pos[k] + wc[k]; s.u.c.size[c][k] = asf(v[SMJ_CG_SIZE + k]); }
+          s.u.c.meta[c] = v[SMJ_CG_META];
         }
       }
     }
