@@ -2364,14 +2364,30 @@ struct StepKernel {
   // itself.  Eliminating above AND below the pivot costs the same n^2/2 (v_readlane, v_fma) pairs as the Cholesky update,
   // all of them independent within a column step, and leaves the solution in x with no substitution and no LDS traffic.
   // Pivots of an SPD matrix stay positive; no pivoting (same as the Cholesky it replaces).
+  // columns J, J+1 of the update of pivot K together: two v_readlane + ONE packed fp32 FMA (v_pk_fma_f32) instead of two
   template <int K, int J, int N>
   SMJ_DEV void gj_pair(PL<float[NVP]>& hrow, const PL<float>& mult) {
-    if constexpr (J < N) {
+    if constexpr (J + 1 < N) {
+      PL<float> c0, c1;
+      LANES { c0[lane] = hrow[lane][J]; c1[lane] = hrow[lane][J + 1]; }
+      const float h0 = wave_read(c0, K), h1 = wave_read(c1, K);   // pivot-row entries H[K][J], H[K][J+1]
+#ifdef SMJ_EMUL
+      LANES { hrow[lane][J] -= mult[lane] * h0; hrow[lane][J + 1] -= mult[lane] * h1; }
+#else
+      LANES {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 m = {mult[lane], mult[lane]}, p = {h0, h1};
+        f2 h = {hrow[lane][J], hrow[lane][J + 1]};
+        h = h - m * p;
+        hrow[lane][J] = h.x; hrow[lane][J + 1] = h.y;
+      }
+#endif
+      gj_pair<K, J + 2, N>(hrow, mult);
+    } else if constexpr (J < N) {
       PL<float> cj;
       LANES { cj[lane] = hrow[lane][J]; }
       const float hkj = wave_read(cj, K);              // pivot-row entry H[K][J]
       LANES { hrow[lane][J] -= mult[lane] * hkj; }
-      gj_pair<K, J + 1, N>(hrow, mult);
     }
   }
   template <int K, int N>
