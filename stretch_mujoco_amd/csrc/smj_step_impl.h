@@ -2281,6 +2281,17 @@ struct StepKernel {
     return wave_sum(cost);
   }
 
+  // acc += a * b on two adjacent elements at once (v_pk_fma_f32); the emulator keeps the scalar form
+#ifdef SMJ_EMUL
+  struct F2 { float x, y; };
+  static inline void pk_fma(F2& acc, float a0, float a1, float b0, float b1) { acc.x += a0 * b0; acc.y += a1 * b1; }
+#else
+  typedef float F2 __attribute__((ext_vector_type(2)));
+  SMJ_DEV static void pk_fma(F2& acc, float a0, float a1, float b0, float b1) {
+    const F2 a = {a0, a1}, b = {b0, b1};
+    acc = acc + a * b;
+  }
+#endif
   // y = M x for lane-resident x (lane = dof, x zero beyond nv).  Newton path only: factor() is not run there, so MM holds the
   // full symmetric M (both triangles + diagonal, identity beyond nv) and lane i reads its row as it is -- no select per element.
   // Lanes 32..63 mirror lanes 0..31; their y is never used.
@@ -2289,13 +2300,15 @@ struct StepKernel {
     LANES {
 #pragma unroll
       for (int j = 0; j < NVP; j++) m[lane][j] = s.MM[lane & (NVP - 1)][j];
-      y[lane] = 0.f;
     }
+    PL<F2> acc;
+    LANES { acc[lane] = F2{0.f, 0.f}; }
 #pragma unroll
-    for (int j = 0; j < NVP; j++) {
-      const float xj = wave_read(x, j);
-      LANES { y[lane] += m[lane][j] * xj; }
+    for (int j = 0; j < NVP; j += 2) {
+      const float x0 = wave_read(x, j), x1 = wave_read(x, j + 1);
+      LANES { pk_fma(acc[lane], m[lane][j], m[lane][j + 1], x0, x1); }
     }
+    LANES { y[lane] = acc[lane].x + acc[lane].y; }
   }
   // out[row] = J[row] . x - sub[row] evaluated with error-free transformations (TwoProduct / TwoSum: ~fp64
   // accuracy from fp32 operations).  The primal residual jar = J qacc - aref cancels to |R f| << |aref|, and the
@@ -2333,11 +2346,15 @@ struct StepKernel {
           // that mask, hoisted and spilled, was reloaded with two v_readlane per use
           for (int u = 0; u < 16; u++) a[lane][u] = s.J[r0 + u][lane & (NVP - 1)];
         }
+        PL<F2> acc;
+        LANES { acc[lane] = F2{0.f, 0.f}; }
 #pragma unroll
-        for (int u = 0; u < 16; u++) {
-          const float fr = r0 < 64 ? wave_read(nr0.force, (r0 & 63) + u) : s.u.n.rxf[RX_FORCE][(r0 & 63) + u];   // rows >= 64: LDS
-          LANES { out[lane] += a[lane][u] * fr; }
+        for (int u = 0; u < 16; u += 2) {
+          const float f0 = r0 < 64 ? wave_read(nr0.force, (r0 & 63) + u) : s.u.n.rxf[RX_FORCE][(r0 & 63) + u];   // rows >= 64: LDS
+          const float f1 = r0 < 64 ? wave_read(nr0.force, (r0 & 63) + u + 1) : s.u.n.rxf[RX_FORCE][(r0 & 63) + u + 1];
+          LANES { pk_fma(acc[lane], a[lane][u], a[lane][u + 1], f0, f1); }
         }
+        LANES { out[lane] += acc[lane].x + acc[lane].y; }
       }
     }
   }
@@ -2348,13 +2365,15 @@ struct StepKernel {
       const int row = lane + rb < NEFC ? lane + rb : 0;
 #pragma unroll
       for (int k = 0; k < NVP; k++) a[lane][k] = s.J[row][k];
-      out[lane] = 0.f;
     }
+    PL<F2> acc;
+    LANES { acc[lane] = F2{0.f, 0.f}; }
 #pragma unroll
-    for (int k = 0; k < NVP; k++) {
-      const float xk = wave_read(x, k);
-      LANES { out[lane] += a[lane][k] * xk; }
+    for (int k = 0; k < NVP; k += 2) {
+      const float x0 = wave_read(x, k), x1 = wave_read(x, k + 1);
+      LANES { pk_fma(acc[lane], a[lane][k], a[lane][k + 1], x0, x1); }
     }
+    LANES { out[lane] = acc[lane].x + acc[lane].y; }
   }
 
   // x <- H^-1 x for the symmetric positive definite H in s.u.n.H (Newton Hessian, or M - h*D of the implicit integrator).
