@@ -54,7 +54,14 @@ struct DevModel {
   // Same idea for the collision stage: one record per plane pair (table order) and per geom of the convex-pair cache.
   const int* k_pprec;     // [nplanepair][SMJ_PP_STRIDE]
   const int* k_cgrec;     // [ncgeom][SMJ_CG_STRIDE]
+  // Constraint assembly: one record per static row (equalities, then friction-loss dofs -- rows 0..neq+nfric-1 of every step)
+  // followed by one per limit slot (2 per limited joint: lower, upper side)
+  const int* k_rowrec;    // [neq + nfric + 2 nlimit][SMJ_RR_STRIDE]
 };
+// row record: type, id (equality / dof / joint), dofs (limit: dof, side), qpos addresses, reference values (equality: qpos0 of
+// both joints; limit: range bound of the side, margin), equality polynomial, diagonal approximation, friction loss, solref, solimp
+enum { SMJ_RR_TYPE = 0, SMJ_RR_ID, SMJ_RR_D1, SMJ_RR_D2, SMJ_RR_Q1, SMJ_RR_Q2, SMJ_RR_V1, SMJ_RR_V2, SMJ_RR_DATA = 8, SMJ_RR_DIAG = 13,
+       SMJ_RR_FLOSS = 14, SMJ_RR_SOLREF = 15, SMJ_RR_SOLIMP = 17, SMJ_RR_USED = 22, SMJ_RR_STRIDE = 24 };
 enum { SMJ_LR_KIN = 0, SMJ_LR_BODY = 36, SMJ_LR_DOF = 60, SMJ_LR_ENT = 76, SMJ_LR_ACT = 112, SMJ_LR_STRIDE = 140 };
 // plane-pair record: pair, geom1 (the plane), geom2, their bodies, geom2 type, margin, geom2 bounding radius / centre,
 // local frames of both geoms, geom2 size, then the contact parameters of the pair

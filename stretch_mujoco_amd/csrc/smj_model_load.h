@@ -148,6 +148,47 @@ static inline std::vector<int> smj_build_cgrec(const DevModel& m, std::map<std::
   return rec;
 }
 
+static inline std::vector<int> smj_build_rowrec(const DevModel& m, std::map<std::string, std::vector<int>>& I,
+                                                std::map<std::string, std::vector<float>>& F) {
+  const int nstat = m.neq + m.nfric, n = nstat + 2 * m.nlimit;
+  std::vector<int> rec((size_t)(n > 0 ? n : 1) * SMJ_RR_STRIDE, 0);
+  auto fb = [](float v) { int b; memcpy(&b, &v, 4); return b; };
+  auto gi = [&](const char* nm, size_t k) { const std::vector<int>& v = I[nm]; return k < v.size() ? v[k] : 0; };
+  auto gf = [&](const char* nm, size_t k) { const std::vector<float>& v = F[nm]; return k < v.size() ? v[k] : 0.f; };
+  for (int e = 0; e < m.neq; e++) {      // CT_EQUALITY = 0 (joint equalities)
+    int* k = rec.data() + (size_t)e * SMJ_RR_STRIDE;
+    const int j1 = gi("eq_obj1id", e), j2 = gi("eq_obj2id", e), q1 = gi("jnt_qposadr", j1), d1 = gi("jnt_dofadr", j1);
+    k[SMJ_RR_TYPE] = 0; k[SMJ_RR_ID] = e; k[SMJ_RR_D1] = d1; k[SMJ_RR_Q1] = q1; k[SMJ_RR_V1] = fb(gf("qpos0", q1));
+    float diag = gf("dof_invweight0", d1);
+    if (j2 >= 0) {
+      const int q2 = gi("jnt_qposadr", j2), d2 = gi("jnt_dofadr", j2);
+      k[SMJ_RR_D2] = d2; k[SMJ_RR_Q2] = q2; k[SMJ_RR_V2] = fb(gf("qpos0", q2));
+      diag += gf("dof_invweight0", d2);
+    } else { k[SMJ_RR_D2] = -1; k[SMJ_RR_Q2] = 0; }
+    for (int q = 0; q < 5; q++) { k[SMJ_RR_DATA + q] = fb(gf("eq_data", 5 * e + q)); k[SMJ_RR_SOLIMP + q] = fb(gf("eq_solimp", 5 * e + q)); }
+    k[SMJ_RR_DIAG] = fb(diag);
+    k[SMJ_RR_SOLREF] = fb(gf("eq_solref", 2 * e)); k[SMJ_RR_SOLREF + 1] = fb(gf("eq_solref", 2 * e + 1));
+  }
+  for (int f = 0; f < m.nfric; f++) {    // CT_FRICTION = 1
+    int* k = rec.data() + (size_t)(m.neq + f) * SMJ_RR_STRIDE;
+    const int d = gi("k_fric_dof", f);
+    k[SMJ_RR_TYPE] = 1; k[SMJ_RR_ID] = d; k[SMJ_RR_D1] = d; k[SMJ_RR_D2] = -1;
+    k[SMJ_RR_DIAG] = fb(gf("dof_invweight0", d)); k[SMJ_RR_FLOSS] = fb(gf("dof_frictionloss", d));
+    k[SMJ_RR_SOLREF] = fb(gf("dof_solref", 2 * d)); k[SMJ_RR_SOLREF + 1] = fb(gf("dof_solref", 2 * d + 1));
+    for (int q = 0; q < 5; q++) k[SMJ_RR_SOLIMP + q] = fb(gf("dof_solimp", 5 * d + q));
+  }
+  for (int L = 0; L < 2 * m.nlimit; L++) {   // CT_LIMIT = 3; slot L = (joint, side), lower side first
+    int* k = rec.data() + (size_t)(nstat + L) * SMJ_RR_STRIDE;
+    const int j = gi("k_limit_jnt", L >> 1), d = gi("jnt_dofadr", j);
+    k[SMJ_RR_TYPE] = 3; k[SMJ_RR_ID] = j; k[SMJ_RR_D1] = d; k[SMJ_RR_D2] = (L & 1) ? 1 : -1; k[SMJ_RR_Q1] = gi("jnt_qposadr", j);
+    k[SMJ_RR_V1] = fb(gf("jnt_range", 2 * j + (L & 1))); k[SMJ_RR_V2] = fb(gf("jnt_margin", j));
+    k[SMJ_RR_DIAG] = fb(gf("dof_invweight0", d));
+    k[SMJ_RR_SOLREF] = fb(gf("jnt_solref", 2 * j)); k[SMJ_RR_SOLREF + 1] = fb(gf("jnt_solref", 2 * j + 1));
+    for (int q = 0; q < 5; q++) k[SMJ_RR_SOLIMP + q] = fb(gf("jnt_solimp", 5 * j + q));
+  }
+  return rec;
+}
+
 template <class Up>
 int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::string& err) {
   if (!blob || nbytes < 16 || memcmp(blob, "SMJB0001", 8) != 0) { err = "not an SMJB model blob"; return -1; }
@@ -190,7 +231,7 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
     return -4;
   }
   if (m.nldl > 5 * 64) { err = "mass-matrix sparsity pattern too large"; return -4; }
-  if (m.neq + m.nfric > NEFC) { err = "too many static constraint rows"; return -4; }
+  if (m.neq + m.nfric > 64) { err = "too many static constraint rows"; return -4; }
   if (2 * m.nlimit > 64) { err = "too many limited joints"; return -4; }
   if (m.ngc > 16) { err = "more than 16 gravity-compensated bodies"; return -4; }
   if (m.njump > 6) { err = "body tree deeper than 64 levels"; return -4; }
@@ -231,6 +272,9 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
     m.k_pprec = up.i32(pp);
     m.k_cgrec = up.i32(cg);
     if (!m.k_pprec || !m.k_cgrec) { err = "device allocation failed for the collision records"; return -2; }
+    std::vector<int> rr = smj_build_rowrec(m, hosti, hostf);
+    m.k_rowrec = up.i32(rr);
+    if (!m.k_rowrec) { err = "device allocation failed for k_rowrec"; return -2; }
   }
   return 0;
 }

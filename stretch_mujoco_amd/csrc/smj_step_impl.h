@@ -1652,51 +1652,62 @@ struct StepKernel {
     }
     SYNC();
     const int cap = M.solver == 2 ? NEFC : NEFP;   // the PGS sweeps are lane = row: 64 rows
-    // equality rows (all equalities active; inactive ones get an empty row with R large -> force 0)
-    PL<int> act;
+    // static rows (equalities -- all active, an inactive one gets an empty row with R large -> force 0 -- then friction-loss
+    // dofs) and the limit slots, each from its row record (DevModel::k_rowrec): one level of loads
+    const int nstat = neq + nfric;
+    PL<int> act, lrow[5];   // limit slot: joint dof, side, and (bit patterns) range bound, margin, diag
+    PL<float> lq;
     LANES {
-      if (lane < neq) {
-        const int e = lane, j1 = M.eq_obj1id[e], j2 = M.eq_obj2id[e];
-        const float* a = M.eq_data + 5 * e;
-        const int q1 = M.jnt_qposadr[j1], d1 = M.jnt_dofadr[j1];
-        float pos = s.qpos[q1] - M.qpos0[q1], deriv = 0, diag = M.dof_invweight0[d1];
-        if (j2 >= 0) {
-          const int q2 = M.jnt_qposadr[j2], d2 = M.jnt_dofadr[j2];
-          const float dif = s.qpos[q2] - M.qpos0[q2];
-          pos -= a[0] + dif * (a[1] + dif * (a[2] + dif * (a[3] + dif * a[4])));
-          deriv = a[1] + dif * (2 * a[2] + dif * (3 * a[3] + dif * 4 * a[4]));
-          diag += M.dof_invweight0[d2];
-          s.J[e][d2] = -deriv;
-        } else pos -= a[0];
-        s.J[e][d1] = 1.f;
-        s.etype[e] = CT_EQUALITY; s.eid[e] = e; s.epos[e] = pos; s.emargin[e] = 0; s.ediag[e] = diag;
-      }
-      if (lane < nfric) {
-        const int r = neq + lane, k = M.k_fric_dof[lane];
-        s.J[r][k] = 1.f;
-        s.etype[r] = CT_FRICTION; s.eid[r] = k; s.efloss[r] = M.dof_frictionloss[k]; s.ediag[r] = M.dof_invweight0[k];
+      const int ol = opaque(lane);
+      if (lane < nstat) {
+        const int* r = static_cast<const int*>(__builtin_assume_aligned(M.k_rowrec + ol * SMJ_RR_STRIDE, 16));
+        int v[SMJ_RR_SOLREF];
+        for (int k = 0; k < SMJ_RR_SOLREF; k++) v[k] = r[k];
+        const int e = lane, d1 = v[SMJ_RR_D1];
+        if (v[SMJ_RR_TYPE] == CT_EQUALITY) {
+          const int d2 = v[SMJ_RR_D2];
+          float pos = s.qpos[v[SMJ_RR_Q1]] - asf(v[SMJ_RR_V1]), deriv = 0;
+          const float a[5] = {asf(v[SMJ_RR_DATA]), asf(v[SMJ_RR_DATA + 1]), asf(v[SMJ_RR_DATA + 2]), asf(v[SMJ_RR_DATA + 3]), asf(v[SMJ_RR_DATA + 4])};
+          if (d2 >= 0) {
+            const float dif = s.qpos[v[SMJ_RR_Q2]] - asf(v[SMJ_RR_V2]);
+            pos -= a[0] + dif * (a[1] + dif * (a[2] + dif * (a[3] + dif * a[4])));
+            deriv = a[1] + dif * (2 * a[2] + dif * (3 * a[3] + dif * 4 * a[4]));
+            s.J[e][d2] = -deriv;
+          } else pos -= a[0];
+          s.J[e][d1] = 1.f;
+          s.etype[e] = CT_EQUALITY; s.eid[e] = v[SMJ_RR_ID]; s.epos[e] = pos; s.emargin[e] = 0; s.ediag[e] = asf(v[SMJ_RR_DIAG]);
+        } else {
+          s.J[e][d1] = 1.f;
+          s.etype[e] = CT_FRICTION; s.eid[e] = v[SMJ_RR_ID]; s.efloss[e] = asf(v[SMJ_RR_FLOSS]); s.ediag[e] = asf(v[SMJ_RR_DIAG]);
+        }
       }
       // limits: lane -> (joint, side), lower side first
       int a = 0;
+      float q = 0;
+      for (int k = 0; k < 5; k++) lrow[k][lane] = 0;
       if (lane < 2 * nlimit) {
-        const int j = M.k_limit_jnt[lane >> 1], side = (lane & 1) ? 1 : -1;
-        const float q = s.qpos[M.jnt_qposadr[j]];
-        const float dist = side * (M.jnt_range[2 * j + (lane & 1)] - q);
-        a = dist < M.jnt_margin[j];
+        const int* r = static_cast<const int*>(__builtin_assume_aligned(M.k_rowrec + (nstat + ol) * SMJ_RR_STRIDE, 16));
+        int v[SMJ_RR_DIAG + 1];
+        for (int k = 0; k < SMJ_RR_DIAG + 1; k++) v[k] = r[k];
+        const int side = v[SMJ_RR_D2];
+        q = s.qpos[v[SMJ_RR_Q1]];
+        const float dist = side * (asf(v[SMJ_RR_V1]) - q);
+        a = dist < asf(v[SMJ_RR_V2]);
+        lrow[0][lane] = v[SMJ_RR_D1]; lrow[1][lane] = side; lrow[2][lane] = v[SMJ_RR_V1]; lrow[3][lane] = v[SMJ_RR_V2]; lrow[4][lane] = v[SMJ_RR_DIAG];
       }
-      act[lane] = a;
+      act[lane] = a; lq[lane] = q;
     }
     const uint64_t lm = wave_ballot(act);
-    int row0 = neq + nfric;
+    int row0 = nstat;
     LANES {
       if (act[lane]) {
         const int r = row0 + popc64(lm & ((1ull << lane) - 1));
         if (r < cap) {
-          const int j = M.k_limit_jnt[lane >> 1], side = (lane & 1) ? 1 : -1, d = M.jnt_dofadr[j];
-          const float q = s.qpos[M.jnt_qposadr[j]];
-          s.J[r][d] = (float)(-side);
-          s.etype[r] = CT_LIMIT; s.eid[r] = j; s.epos[r] = side * (M.jnt_range[2 * j + (lane & 1)] - q);
-          s.emargin[r] = M.jnt_margin[j]; s.ediag[r] = M.dof_invweight0[d];
+          const int side = lrow[1][lane];
+          s.J[r][lrow[0][lane]] = (float)(-side);
+          s.etype[r] = CT_LIMIT; s.eid[r] = lane;   // the limit SLOT (its row record is k_rowrec[nstat + slot])
+          s.epos[r] = side * (asf(lrow[2][lane]) - lq[lane]);
+          s.emargin[r] = asf(lrow[3][lane]); s.ediag[r] = asf(lrow[4][lane]);
         }
       }
     }
@@ -1797,13 +1808,14 @@ struct StepKernel {
       if (i < nefc) {
         const int t = s.etype[i], id = s.eid[i];
         float solref[2], solimp[5];
-        const float *sr, *si;
-        if (t == CT_EQUALITY) { sr = M.eq_solref + 2 * id; si = M.eq_solimp + 5 * id; }
-        else if (t == CT_FRICTION) { sr = M.dof_solref + 2 * id; si = M.dof_solimp + 5 * id; }
-        else if (t == CT_LIMIT) { sr = M.jnt_solref + 2 * id; si = M.jnt_solimp + 5 * id; }
-        else { sr = s.csolref[id]; si = s.csolimp[id]; }
-        solref[0] = sr[0]; solref[1] = sr[1];
-        for (int k = 0; k < 5; k++) solimp[k] = si[k];
+        if (t == CT_CONTACT_FRICTIONLESS || t == CT_CONTACT_ELLIPTIC) {
+          solref[0] = s.csolref[id][0]; solref[1] = s.csolref[id][1];
+          for (int k = 0; k < 5; k++) solimp[k] = s.csolimp[id][k];
+        } else {   // static rows sit at their own index, limit rows carry their slot
+          const int* r = M.k_rowrec + (t == CT_LIMIT ? M.neq + M.nfric + id : i) * SMJ_RR_STRIDE;
+          solref[0] = asf(r[SMJ_RR_SOLREF]); solref[1] = asf(r[SMJ_RR_SOLREF + 1]);
+          for (int k = 0; k < 5; k++) solimp[k] = asf(r[SMJ_RR_SOLIMP + k]);
+        }
         const float imp = impedance(solimp, s.epos[i], s.emargin[i]);
         s.eR[i] = fmaxf(SMJ_MINVAL, (1 - imp) * s.ediag[i] / imp);
         const float dmax = fminf(SMJ_MAXIMP, fmaxf(SMJ_MINIMP, solimp[1]));
