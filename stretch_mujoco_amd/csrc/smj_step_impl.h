@@ -2265,15 +2265,15 @@ struct StepKernel {
           if (want_hess) {
             float* H = s.u.n.cH[c];
             const float a = mu * N * Ti * Ti * Ti, b = mu * NT * Ti;
+            // stored 6x6 with a fixed stride: S[j] = 0 beyond the contact's condim zero-pads the block by itself, and the
+            // readers (XA stage) get immediate offsets instead of condim-dependent addresses
             H[0] = Dm * S[0] * S[0];
 #pragma unroll
-            for (int j = 1; j < 6; j++)
-              if (j < dim) H[j] = H[j * dim] = -mu * U[j] * Ti * Dm * S[0] * S[j];
+            for (int j = 1; j < 6; j++) H[j] = H[6 * j] = -mu * U[j] * Ti * Dm * S[0] * S[j];
 #pragma unroll
             for (int j = 1; j < 6; j++)
 #pragma unroll
-              for (int k = 1; k < 6; k++)
-                if (j < dim && k < dim) H[j * dim + k] = (a * U[j] * U[k] - (j == k ? b : 0.f)) * Dm * S[j] * S[k];
+              for (int k = 1; k < 6; k++) H[6 * j + k] = (a * U[j] * U[k] - (j == k ? b : 0.f)) * Dm * S[j] * S[k];
           }
         }
         cost[lane] += cc;
@@ -2459,7 +2459,7 @@ struct StepKernel {
     LANES { x[lane] *= pinv[lane]; }
   }
   SMJ_DEV void solve_H(PL<float>& x) {
-    if (M.nv <= 28) gj_solve<28>(x);   // Stretch: 26 dofs; a quarter fewer column pairs than the full 32
+    if (M.nv <= 26) gj_solve<26>(x);   // Stretch: 26 dofs; a third fewer column pairs than the full 32
     else gj_solve<NVP>(x);
   }
 
@@ -2506,6 +2506,33 @@ struct StepKernel {
     d1 = 2 * a * q2 + q1;
     d2 = 2 * q2;
     return a * a * q2 + a * q1 + q0;
+  }
+
+  // XA rows of (up to) two cone-zone contacts: (Hc Jc), lanes 0..31 = dofs of contact ca, lanes 32..63 = dofs of contact cb.
+  // D = block size the pass is compiled for (3: both contacts condim 3; 6: zero-padded up to condim 6); fixed trip counts so
+  // that the LDS reads issue back to back.
+  template <int D>
+  SMJ_DEV void xa_cone_pass(int ca, int cb) {
+    LANES {
+      const int c = lane < 32 ? ca : cb, k = lane & 31;
+      if (c >= 0) {
+        const int r0 = s.cefc[c], dim = s.cdim[c];
+        float j[D], h[D * D];
+#pragma unroll
+        for (int q = 0; q < D; q++) j[q] = s.J[r0 + q < NEFC ? r0 + q : NEFC - 1][k];   // rows past the block meet zero padding of cH
+#pragma unroll
+        for (int rr = 0; rr < D; rr++)
+#pragma unroll
+          for (int q = 0; q < D; q++) h[D * rr + q] = s.u.n.cH[c][6 * rr + q];
+#pragma unroll
+        for (int rr = 0; rr < D; rr++) {
+          float v = 0;
+#pragma unroll
+          for (int q = 0; q < D; q++) v += h[D * rr + q] * j[q];
+          if (rr < dim) s.u.n.XA[r0 + rr][k] = v;
+        }
+      }
+    }
   }
 
   SMJ_DEV void solve_newton(bool dbg, float* pc, long long& t0, bool prof) {
@@ -2581,8 +2608,6 @@ struct StepKernel {
       // XA = W J.  Quadratic rows D*J, satisfied / linear rows 0 (lane = row).  Rows of a contact in the cone (middle) zone:
       // (Hc Jc) with lanes = dofs, two contacts per pass (half-waves), the 6x6 block zero-padded so that every loop has a
       // fixed trip count and the LDS reads issue back to back.
-      PL<int> conerow;
-      LANES { conerow[lane] = 0; }
       ROWS_BEGIN(rb, ne) LANES {
         const int row = lane + rb;
         const bool cone = row < ne && nr.state[lane] == 4;
@@ -2591,30 +2616,29 @@ struct StepKernel {
 #pragma unroll
           for (int k = 0; k < NVP; k++) s.u.n.XA[row][k] = w * s.J[row][k];
         }
-        conerow[lane] |= cone;
       } ROWS_END_RO()
-      const bool anycone = wave_ballot(conerow) != 0;
-      for (int c0 = 0; anycone && c0 < ncon; c0 += 2) {
+      // Rows of the contacts whose block is in the cone (middle) zone: only those contacts are visited, two per pass (half-waves),
+      // and a pass whose contacts are both condim 3 runs the 3x3 instead of the zero-padded 6x6 block product.
+      {
+        PL<int> cz, cdl;
         LANES {
-          const int c = c0 + (lane >> 5), k = lane & 31;
-          const int r0 = c < ncon ? s.cefc[c] : -1;
-          const int dim = c < ncon ? s.cdim[c] : 0;
-          if (r0 >= 0 && dim >= 3 && s.estate[r0] == 4) {   // row states as left by newton_update
-            float j[6], h[36];
-#pragma unroll
-            for (int q = 0; q < 6; q++) j[q] = s.J[r0 + (q < dim ? q : 0)][k];
-#pragma unroll
-            for (int rr = 0; rr < 6; rr++)
-#pragma unroll
-              for (int q = 0; q < 6; q++) h[6 * rr + q] = (rr < dim && q < dim) ? s.u.n.cH[c][(rr < dim ? rr : 0) * dim + (q < dim ? q : 0)] : 0.f;
-#pragma unroll
-            for (int rr = 0; rr < 6; rr++) {
-              float v = 0;
-#pragma unroll
-              for (int q = 0; q < 6; q++) v += h[6 * rr + q] * j[q];
-              if (rr < dim) s.u.n.XA[r0 + rr][k] = v;
-            }
+          int z = 0, d = 0;
+          if (lane < ncon) {
+            const int r0 = s.cefc[lane];
+            d = s.cdim[lane];
+            z = r0 >= 0 && d >= 3 && s.estate[r0 >= 0 ? r0 : 0] == 4;   // row states as left by newton_update
           }
+          cz[lane] = z; cdl[lane] = d;
+        }
+        uint64_t cm = wave_ballot(cz);
+        while (cm) {
+          const int ca = ffs64(cm);
+          cm &= cm - 1;
+          int cb = -1;
+          if (cm) { cb = ffs64(cm); cm &= cm - 1; }
+          const int da = wave_read(cdl, ca), db = cb >= 0 ? wave_read(cdl, cb) : 0;
+          if (da <= 3 && db <= 3) xa_cone_pass<3>(ca, cb);
+          else xa_cone_pass<6>(ca, cb);
         }
       }
       SYNC();
