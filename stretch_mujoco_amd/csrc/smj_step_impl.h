@@ -2245,7 +2245,8 @@ struct StepKernel {
           if (j > 0) T += U[j] * U[j];
         }
         const float N = U[0];
-        T = sqrtf(T);
+        const float Tinv = T > 0 ? fast_rsqrt(T) : 0.f;   // v_rsq_f32, see ls_eval
+        T = T * Tinv;
         int st;
         float cc = 0, ef[6] = {0, 0, 0, 0, 0, 0};
         if (N >= mu * T || (T <= 0 && N >= 0)) { st = 0; }
@@ -2253,10 +2254,10 @@ struct StepKernel {
           st = 1;
 #pragma unroll
           for (int j = 0; j < 6; j++)
-            if (j < dim) { const float Dj = 1.0f / Rj[j]; ef[j] = -Dj * jr[j]; cc += 0.5f * Dj * jr[j] * jr[j]; }
+            if (j < dim) { const float Dj = fast_rcp(Rj[j]); ef[j] = -Dj * jr[j]; cc += 0.5f * Dj * jr[j] * jr[j]; }
         } else {
           st = 4;
-          const float Dm = nr.cq[lane][5], NT = N - mu * T, Ti = 1.0f / T;
+          const float Dm = nr.cq[lane][5], NT = N - mu * T, Ti = Tinv;
           cc = 0.5f * Dm * NT * NT;
           const float fn = -Dm * NT * mu;
           ef[0] = fn;
@@ -2507,11 +2508,13 @@ struct StepKernel {
           const float mu = k[6], Dm = k[5], N = k[0] + a * k[1], Tsq = k[2] + a * (2 * k[3] + a * k[4]);
           if (Tsq <= 0) { if (N < 0) { c0 = nr.q0[lane]; c1 = nr.q1[lane]; c2 = nr.q2[lane]; } }
           else {
-            const float T = sqrtf(Tsq);
+            // v_rsq_f32 (1 ulp) instead of the IEEE sqrt + divide expansions (~25 instructions per evaluation): the cost is
+            // continuous across the zone tests, an ulp of T moves nothing that the 1e-8 solver tolerance can see
+            const float Ti = fast_rsqrt(Tsq), T = Tsq * Ti;
             if (N >= mu * T) {}
             else if (mu * N + T <= 0) { c0 = nr.q0[lane]; c1 = nr.q1[lane]; c2 = nr.q2[lane]; }
             else {
-              const float Ti = 1.0f / T, w = k[3] + a * k[4], N1 = k[1], T1 = w * Ti, T2 = k[4] * Ti - w * w * Ti * Ti * Ti;
+              const float w = k[3] + a * k[4], N1 = k[1], T1 = w * Ti, T2 = k[4] * Ti - w * w * Ti * Ti * Ti;
               const float NT = N - mu * T, NT1 = N1 - mu * T1;
               // encode the non-quadratic cone piece so that the caller's quadratic formula reproduces it at this alpha:
               // value v, slope g, curvature h  ->  c2 = h/2, c1 = g - h a, c0 = v - a g + h a a / 2
