@@ -67,7 +67,8 @@ enum { SMJ_LR_KIN = 0, SMJ_LR_BODY = 36, SMJ_LR_DOF = 60, SMJ_LR_ENT = 76, SMJ_L
 // local frames of both geoms, geom2 size, then the contact parameters of the pair
 enum { SMJ_PP_PAIR = 0, SMJ_PP_G1, SMJ_PP_G2, SMJ_PP_B1, SMJ_PP_B2, SMJ_PP_T2, SMJ_PP_MARGIN, SMJ_PP_RBOUND2, SMJ_PP_BCEN2 = 8,
        SMJ_PP_POS1 = 11, SMJ_PP_MAT1 = 14, SMJ_PP_POS2 = 23, SMJ_PP_MAT2 = 26, SMJ_PP_SIZE2 = 35, SMJ_PP_CONDIM = 38, SMJ_PP_MG = 39,
-       SMJ_PP_FRIC = 40, SMJ_PP_SOLIMP = 45, SMJ_PP_SOLREF = 50, SMJ_PP_STRIDE = 52 };
+       SMJ_PP_FRIC = 40, SMJ_PP_SOLIMP = 45, SMJ_PP_SOLREF = 50, SMJ_PP_BOX2 = 52 /* geom2's box in its frame: centre, half sizes */,
+       SMJ_PP_STRIDE = 60 };
 // convex-cache geom record: geom, body, packed type|hull count|hull address, local frame, bounding-box centre and half
 // sizes, MPR interior point, geom size
 enum { SMJ_CG_GEOM = 0, SMJ_CG_BODY, SMJ_CG_META, SMJ_CG_POS = 3, SMJ_CG_MAT = 6, SMJ_CG_LCEN = 15, SMJ_CG_HALF = 18, SMJ_CG_CCEN = 21,

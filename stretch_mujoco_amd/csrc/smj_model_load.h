@@ -124,6 +124,7 @@ static inline std::vector<int> smj_build_pprec(const DevModel& m, std::map<std::
     k[SMJ_PP_CONDIM] = gi("pair_condim", p); k[SMJ_PP_MG] = fb(gf("pair_margin", p) - gf("pair_gap", p));
     for (int q = 0; q < 5; q++) { k[SMJ_PP_FRIC + q] = fb(gf("pair_friction", 5 * p + q)); k[SMJ_PP_SOLIMP + q] = fb(gf("pair_solimp", 5 * p + q)); }
     k[SMJ_PP_SOLREF] = fb(gf("pair_solref", 2 * p)); k[SMJ_PP_SOLREF + 1] = fb(gf("pair_solref", 2 * p + 1));
+    for (int q = 0; q < 6; q++) k[SMJ_PP_BOX2 + q] = fb(gf("geom_aabb", 6 * g2 + q));
   }
   return rec;
 }

@@ -950,8 +950,19 @@ struct StepKernel {
           const float margin = asf(v[SMJ_PP_MARGIN]);
           if (dot3(dif, n) - asf(v[SMJ_PP_RBOUND2]) <= margin) {
             const int t2 = v[SMJ_PP_T2];
-            if (t2 == GT_MESH) hl = 1;
-            else {
+            if (t2 == GT_MESH) {
+              // the hull's box (geom frame) against the plane before the wave-serial vertex scan: the lowest point of the box
+              // along the normal bounds every vertex.  (The base hull's bounding sphere always reaches the floor, its box
+              // stays a centimetre above it: one vertex scan per step saved.)
+              float lp2[3], lm2[9], gp[3], gm[9], bc[3], wc[3];
+              for (int k = 0; k < 3; k++) { lp2[k] = asf(v[SMJ_PP_POS2 + k]); bc[k] = asf(r[SMJ_PP_BOX2 + k]); }
+              for (int k = 0; k < 9; k++) lm2[k] = asf(v[SMJ_PP_MAT2 + k]);
+              pose_from(b2, lp2, lm2, gp, gm);
+              mulmat3vec(wc, gm, bc);
+              float low = (gp[0] + wc[0] - pp[0]) * n[0] + (gp[1] + wc[1] - pp[1]) * n[1] + (gp[2] + wc[2] - pp[2]) * n[2];
+              for (int k = 0; k < 3; k++) low -= fabsf(n[0] * gm[k] + n[1] * gm[3 + k] + n[2] * gm[6 + k]) * (asf(r[SMJ_PP_BOX2 + 3 + k]) + 1e-5f);
+              hl = low <= margin + 1e-6f;
+            } else {
               float lp2[3], lm2[9], size[3];
               for (int k = 0; k < 3; k++) { lp2[k] = asf(v[SMJ_PP_POS2 + k]); size[k] = asf(v[SMJ_PP_SIZE2 + k]); }
               for (int k = 0; k < 9; k++) lm2[k] = asf(v[SMJ_PP_MAT2 + k]);
