@@ -57,7 +57,11 @@ struct DevModel {
   // Constraint assembly: one record per static row (equalities, then friction-loss dofs -- rows 0..neq+nfric-1 of every step)
   // followed by one per limit slot (2 per limited joint: lower, upper side)
   const int* k_rowrec;    // [neq + nfric + 2 nlimit][SMJ_RR_STRIDE]
+  // Convex pairs that reach the narrowphase: pair, geoms, cache slots, margin and the contact parameters in one record
+  const int* k_cprec;     // [nconvpair][SMJ_CP_STRIDE]
 };
+enum { SMJ_CP_PAIR = 0, SMJ_CP_G1, SMJ_CP_G2, SMJ_CP_S1, SMJ_CP_S2, SMJ_CP_MARGIN, SMJ_CP_MG, SMJ_CP_CONDIM, SMJ_CP_FRIC = 8, SMJ_CP_SOLIMP = 13,
+       SMJ_CP_SOLREF = 18, SMJ_CP_STRIDE = 20 };
 // row record: type, id (equality / dof / joint), dofs (limit: dof, side), qpos addresses, reference values (equality: qpos0 of
 // both joints; limit: range bound of the side, margin), equality polynomial, diagonal approximation, friction loss, solref, solimp
 enum { SMJ_RR_TYPE = 0, SMJ_RR_ID, SMJ_RR_D1, SMJ_RR_D2, SMJ_RR_Q1, SMJ_RR_Q2, SMJ_RR_V1, SMJ_RR_V2, SMJ_RR_DATA = 8, SMJ_RR_DIAG = 13,

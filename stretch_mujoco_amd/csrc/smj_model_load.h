@@ -190,6 +190,24 @@ static inline std::vector<int> smj_build_rowrec(const DevModel& m, std::map<std:
   return rec;
 }
 
+static inline std::vector<int> smj_build_cprec(const DevModel& m, std::map<std::string, std::vector<int>>& I,
+                                               std::map<std::string, std::vector<float>>& F) {
+  std::vector<int> rec((size_t)(m.nconvpair > 0 ? m.nconvpair : 1) * SMJ_CP_STRIDE, 0);
+  auto fb = [](float v) { int b; memcpy(&b, &v, 4); return b; };
+  auto gi = [&](const char* nm, size_t k) { const std::vector<int>& v = I[nm]; return k < v.size() ? v[k] : 0; };
+  auto gf = [&](const char* nm, size_t k) { const std::vector<float>& v = F[nm]; return k < v.size() ? v[k] : 0.f; };
+  for (int t = 0; t < m.nconvpair; t++) {
+    int* k = rec.data() + (size_t)t * SMJ_CP_STRIDE;
+    const int p = gi("k_convpair", t);
+    k[SMJ_CP_PAIR] = p; k[SMJ_CP_G1] = gi("pair_geom1", p); k[SMJ_CP_G2] = gi("pair_geom2", p);
+    k[SMJ_CP_S1] = gi("k_convpair_s1", t); k[SMJ_CP_S2] = gi("k_convpair_s2", t);
+    k[SMJ_CP_MARGIN] = fb(gf("pair_margin", p)); k[SMJ_CP_MG] = fb(gf("pair_margin", p) - gf("pair_gap", p)); k[SMJ_CP_CONDIM] = gi("pair_condim", p);
+    for (int q = 0; q < 5; q++) { k[SMJ_CP_FRIC + q] = fb(gf("pair_friction", 5 * p + q)); k[SMJ_CP_SOLIMP + q] = fb(gf("pair_solimp", 5 * p + q)); }
+    k[SMJ_CP_SOLREF] = fb(gf("pair_solref", 2 * p)); k[SMJ_CP_SOLREF + 1] = fb(gf("pair_solref", 2 * p + 1));
+  }
+  return rec;
+}
+
 template <class Up>
 int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::string& err) {
   if (!blob || nbytes < 16 || memcmp(blob, "SMJB0001", 8) != 0) { err = "not an SMJB model blob"; return -1; }
@@ -276,6 +294,9 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
     std::vector<int> rr = smj_build_rowrec(m, hosti, hostf);
     m.k_rowrec = up.i32(rr);
     if (!m.k_rowrec) { err = "device allocation failed for k_rowrec"; return -2; }
+    std::vector<int> cp = smj_build_cprec(m, hosti, hostf);
+    m.k_cprec = up.i32(cp);
+    if (!m.k_cprec) { err = "device allocation failed for k_cprec"; return -2; }
   }
   return 0;
 }

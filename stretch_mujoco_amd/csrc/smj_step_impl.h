@@ -904,23 +904,23 @@ struct StepKernel {
     normalize3(fr + 3);
     cross3(fr + 6, fr, fr + 3);
   }
-  // per-lane: fill contact slot c
-  SMJ_DEV void write_contact(int c, int pair, int g1, int g2, float dist, const float* pos, const float* n) {
+  // per-lane: fill contact slot c from the convex pair's record (DevModel::k_cprec)
+  SMJ_DEV void write_contact(int c, const int* r, float dist, const float* pos, const float* n) {
     s.cdist[c] = dist;
     float fr[9] = {n[0], n[1], n[2], 0, 0, 0, 0, 0, 0};
     make_frame(fr);
     for (int k = 0; k < 9; k++) s.cframe[c][k] = fr[k];
     for (int k = 0; k < 3; k++) s.cpos[c][k] = pos[k];
-    for (int k = 0; k < 5; k++) { s.cfric[c][k] = M.pair_friction[5 * pair + k]; s.csolimp[c][k] = M.pair_solimp[5 * pair + k]; }
-    s.csolref[c][0] = M.pair_solref[2 * pair]; s.csolref[c][1] = M.pair_solref[2 * pair + 1];
-    s.cmargin[c] = M.pair_margin[pair] - M.pair_gap[pair];
-    s.cdim[c] = M.pair_condim[pair]; s.cgeom1[c] = g1; s.cgeom2[c] = g2; s.cefc[c] = -1;
+    for (int k = 0; k < 5; k++) { s.cfric[c][k] = asf(r[SMJ_CP_FRIC + k]); s.csolimp[c][k] = asf(r[SMJ_CP_SOLIMP + k]); }
+    s.csolref[c][0] = asf(r[SMJ_CP_SOLREF]); s.csolref[c][1] = asf(r[SMJ_CP_SOLREF + 1]);
+    s.cmargin[c] = asf(r[SMJ_CP_MG]);
+    s.cdim[c] = r[SMJ_CP_CONDIM]; s.cgeom1[c] = r[SMJ_CP_G1]; s.cgeom2[c] = r[SMJ_CP_G2]; s.cefc[c] = -1;
   }
-  SMJ_DEV void add_contact(int pair, int g1, int g2, float dist, const float* pos, const float* n) {
+  SMJ_DEV void add_contact(const int* r, float dist, const float* pos, const float* n) {
     // uniform: every lane calls with identical arguments; lane 0 writes
     if (ncon >= NCON) { flags |= SMJ_FLAG_CON_OVERFLOW; return; }
     const int c = ncon++;
-    LANES { if (lane == 0) write_contact(c, pair, g1, g2, dist, pos, n); }
+    LANES { if (lane == 0) write_contact(c, r, dist, pos, n); }
   }
 
   // Plane pairs.  Lane = pair: bounding sphere vs plane, then the primitive narrowphase of the hits runs lane-parallel
@@ -1618,31 +1618,33 @@ struct StepKernel {
       while (mask) {
         const int l = ffs64(mask);
         mask &= mask - 1;
-        const int t = wave_read(tt, l), p = uni(M.k_convpair[t]);
-        const int g1 = uni(M.pair_geom1[p]), g2 = uni(M.pair_geom2[p]);
+        // the pair's record: one wide scalar load instead of pair -> geoms / slots / margin / parameters
+        const int t = wave_read(tt, l);
+        const int* r = static_cast<const int*>(__builtin_assume_aligned(M.k_cprec + t * SMJ_CP_STRIDE, 16));
+        const int g1 = uni(r[SMJ_CP_G1]), g2 = uni(r[SMJ_CP_G2]);
         Shape A, Bs;
         float c0[3], c1[3], depth, dir[3], pos[3];
-        load_shape(A, g1, uni(M.k_convpair_s1[t]), c0);
-        load_shape(Bs, g2, uni(M.k_convpair_s2[t]), c1);
-        const float margin = uni(M.pair_margin[p]);
+        load_shape(A, g1, uni(r[SMJ_CP_S1]), c0);
+        load_shape(Bs, g2, uni(r[SMJ_CP_S2]), c1);
+        const float margin = asf(uni(r[SMJ_CP_MARGIN]));
         if (A.type == GT_SPHERE && Bs.type == GT_SPHERE) {
-          if (sphere_sphere(A.pos, A.size[0], Bs.pos, Bs.size[0], margin, depth, dir, pos)) add_contact(p, g1, g2, depth, pos, dir);
+          if (sphere_sphere(A.pos, A.size[0], Bs.pos, Bs.size[0], margin, depth, dir, pos)) add_contact(r, depth, pos, dir);
           continue;
         }
         if (A.type == GT_SPHERE && Bs.type == GT_BOX) {
-          if (sphere_box(A.pos, A.size[0], Bs, margin, depth, dir, pos)) add_contact(p, g1, g2, depth, pos, dir);
+          if (sphere_box(A.pos, A.size[0], Bs, margin, depth, dir, pos)) add_contact(r, depth, pos, dir);
           continue;
         }
         if (A.type == GT_BOX && Bs.type == GT_SPHERE) {
           if (sphere_box(Bs.pos, Bs.size[0], A, margin, depth, dir, pos)) {
             for (int k = 0; k < 3; k++) dir[k] = -dir[k];   // the contact keeps the pair's geom order
-            add_contact(p, g1, g2, depth, pos, dir);
+            add_contact(r, depth, pos, dir);
           }
           continue;
         }
         if (!mpr_penetration(A, Bs, c0, c1, depth, dir, pos)) continue;
         if (-depth > margin || dot3(dir, dir) < 0.5f) continue;
-        add_contact(p, g1, g2, -depth, pos, dir);
+        add_contact(r, -depth, pos, dir);
       }
     }
     SYNC();
