@@ -1658,8 +1658,13 @@ struct StepKernel {
     // with nefc = NEFC -- and after such a step; nefc still holds the previous step's row count here)
     ROWPASS(rb, nefc) LANES {
       const int row = lane + rb;
+      // J rows rb .. rb+63 (or up to NEFC-1) cleared as one 16-byte-aligned block: 9 wide stores per lane instead of 33
+      constexpr int NROW = 64, NF4 = NROW * JS / 4;   // 64 rows x 33 floats = 528 float4
+      static_assert((NROW * JS) % 4 == 0 && ((NEFC - 64) * JS) % 4 == 0, "row blocks are whole float4s");
+      const int nf4 = rb == 0 ? NF4 : (NEFC - 64) * JS / 4;
+      Vec4* jz = reinterpret_cast<Vec4*>(&s.J[rb][0]);
+      for (int k = lane; k < nf4; k += 64) jz[k] = Vec4{0.f, 0.f, 0.f, 0.f};
       if (row < NEFC) {
-        for (int k = 0; k < JS; k++) s.J[row][k] = 0.f;
         s.etype[row] = CT_NONE; s.efloss[row] = 0; s.eid[row] = 0; s.epos[row] = 0; s.emargin[row] = 0; s.ediag[row] = 0;
       }
     }
@@ -2341,22 +2346,41 @@ struct StepKernel {
   // constraint force is D * jar with D = 1/R up to 1e4: a plain fp32 dot product would put 1e-3 noise on the
   // forces.  Only the starting residual needs this; the Newton loop then updates jar incrementally.
   SMJ_DEV void mat_J_exact(PL<float>& out, const PL<float>& x, const PL<float>& sub, int rb) {
-    const int nv = M.nv;
-    PL<float> hi, lo;
-    LANES { hi[lane] = -sub[lane]; lo[lane] = 0.f; }
-    for (int k = 0; k < nv; k++) {
-      const float xk = wave_read(x, k);
+    // the row is fetched up front (fixed trip count: columns >= nv of J and entries >= nv of x are zero) and the compensated
+    // sum runs as two independent chains (even / odd columns), merged by a last TwoSum
+    PL<float[NVP]> a;
+    PL<float> hi0, lo0, hi1, lo1;
+    LANES {
+      const int row = lane + rb < NEFC ? lane + rb : 0;
+#pragma unroll
+      for (int k = 0; k < NVP; k++) a[lane][k] = s.J[row][k];
+      hi0[lane] = -sub[lane]; lo0[lane] = 0.f; hi1[lane] = 0.f; lo1[lane] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NVP; k += 2) {
+      const float x0 = wave_read(x, k), x1 = wave_read(x, k + 1);
       LANES {
-        const int row = lane + rb;
-        const float a = s.J[row < NEFC ? row : 0][k];
-        const float p = a * xk, pe = fmaf(a, xk, -p);          // p + pe = a*xk exactly
-        const float t = hi[lane] + p, z = t - hi[lane];
-        const float se = (hi[lane] - (t - z)) + (p - z);        // hi + p = t + se exactly
-        hi[lane] = t;
-        lo[lane] += se + pe;
+        {
+          const float av = a[lane][k];
+          const float p = av * x0, pe = fmaf(av, x0, -p);          // p + pe = a*x exactly
+          const float t = hi0[lane] + p, z = t - hi0[lane];
+          const float se = (hi0[lane] - (t - z)) + (p - z);        // hi + p = t + se exactly
+          hi0[lane] = t; lo0[lane] += se + pe;
+        }
+        {
+          const float av = a[lane][k + 1];
+          const float p = av * x1, pe = fmaf(av, x1, -p);
+          const float t = hi1[lane] + p, z = t - hi1[lane];
+          const float se = (hi1[lane] - (t - z)) + (p - z);
+          hi1[lane] = t; lo1[lane] += se + pe;
+        }
       }
     }
-    LANES { out[lane] = hi[lane] + lo[lane]; }
+    LANES {
+      const float t = hi0[lane] + hi1[lane], z = t - hi0[lane];
+      const float se = (hi0[lane] - (t - z)) + (hi1[lane] - z);
+      out[lane] = t + (se + lo0[lane] + lo1[lane]);
+    }
   }
   // out[dof] = sum_rows J[row][dof] * f[row]   (lane = dof, f lane-resident over rows), sixteen rows per pass
   SMJ_DEV void matT_J(PL<float>& out, const NRow& nr0) {
