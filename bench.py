@@ -263,6 +263,8 @@ def main():
             script = cr[:, 0] + (cr[:, 1] - cr[:, 0]) * rng.random((64, sim.nu))
             out["cpu_baseline"] = cpu_baseline(sim._blob, script, hold, args.cpu_seconds, args.solver)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
+        import __graft_entry__ as _ge
+        out["parity_oracle"] = _ge.mujoco_status()
         if not args.no_extra and world == 1:
             sim.stop()
             out["other_configs"] = other_configs(B, dev, hold, args.solver)
