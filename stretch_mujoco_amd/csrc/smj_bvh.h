@@ -37,11 +37,11 @@ static inline void smj_bvh_add_mesh(SmjBvhSet& set, const float* verts, int nv, 
   m.ntri = 4 * leaf0;
   m.nodebase = (int)(set.node.size() / 8);
   m.tribase = (int)(set.tri.size() / 12);
-  // Triangle order: recursive object split.  The node that covers leaves [l0, l1) splits its triangles in two halves (as
-  // even as the leaf capacities allow) along the axis whose split gives the smallest surface-area cost, and hands each half
-  // to one half of its leaves -- the tree stays complete (index arithmetic instead of child pointers), but its boxes follow
-  // the geometry far better than a Morton curve cut into equal runs: fewer node visits per ray.  Leaves may be partly
-  // filled; the empty slots are degenerate (all-zero) triangles that no ray hits.
+  // Triangle order: recursive object split.  The node that covers leaves [l0, l1) splits its triangles by the binned
+  // surface-area heuristic -- any plane whose two sides fit the capacity of the two halves of the leaves is admissible --
+  // and hands each side to one half of its leaves.  The tree stays complete (index arithmetic instead of child pointers),
+  // but its boxes follow the geometry far better than a Morton curve cut into equal runs: fewer node visits per ray.
+  // Leaves may be partly filled; the empty slots are degenerate (all-zero) triangles that no ray hits.
   std::vector<float> cen(3 * (size_t)nf), tlo(3 * (size_t)nf), thi(3 * (size_t)nf);
   for (int f = 0; f < nf; f++)
     for (int k = 0; k < 3; k++) {
@@ -55,14 +55,6 @@ static inline void smj_bvh_add_mesh(SmjBvhSet& set, const float* verts, int nv, 
   struct Job { int t0, t1, l0, l1; };
   std::vector<Job> stack;
   stack.push_back({0, nf, 0, leaf0});
-  auto area = [&](int a, int b) {   // surface area of the box of triangles idx[a:b)
-    if (b <= a) return 0.f;
-    float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
-    for (int i = a; i < b; i++)
-      for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], tlo[3 * idx[i] + k]); hi[k] = std::max(hi[k], thi[3 * idx[i] + k]); }
-    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-    return 2.f * (dx * dy + dy * dz + dz * dx);
-  };
   while (!stack.empty()) {
     const Job j = stack.back();
     stack.pop_back();
@@ -72,20 +64,66 @@ static inline void smj_bvh_add_mesh(SmjBvhSet& set, const float* verts, int nv, 
       continue;
     }
     const int cap = 4 * (nl / 2);                                   // triangle capacity of each half
-    const int left = std::min(cap, std::max(n - cap, (n + 1) / 2));   // as even as the capacities allow
-    if (n > 1 && left > 0 && left < n) {
-      int best_axis = 0;
+    const int lmin = std::max(n - cap, n > 1 ? 1 : 0), lmax = std::min(cap, n > 1 ? n - 1 : n);   // admissible left counts
+    int left = std::min(cap, std::max(n - cap, (n + 1) / 2));        // default: as even as the capacities allow
+    if (n > 1 && lmin <= lmax) {
+      // binned surface-area heuristic: 32 bins of the centroid range per axis, every bin boundary whose left count is
+      // admissible is a candidate; cost = area(left) * count(left) + area(right) * count(right)
+      constexpr int NB = 32;
+      float clo[3] = {3e38f, 3e38f, 3e38f}, chi[3] = {-3e38f, -3e38f, -3e38f};
+      for (int i = j.t0; i < j.t1; i++)
+        for (int k = 0; k < 3; k++) { clo[k] = std::min(clo[k], cen[3 * idx[i] + k]); chi[k] = std::max(chi[k], cen[3 * idx[i] + k]); }
+      int best_axis = -1, best_left = left, best_bin = 0;
       float best_cost = 3e38f;
       for (int ax = 0; ax < 3; ax++) {
+        const float ext = chi[ax] - clo[ax];
+        if (!(ext > 0.f)) continue;
+        int cnt[NB] = {0};
+        float blo[NB][3], bhi[NB][3];
+        for (int b = 0; b < NB; b++)
+          for (int k = 0; k < 3; k++) { blo[b][k] = 3e38f; bhi[b][k] = -3e38f; }
+        auto bin_of = [&](int f) { return std::min(NB - 1, std::max(0, (int)((cen[3 * f + ax] - clo[ax]) / ext * NB))); };
+        for (int i = j.t0; i < j.t1; i++) {
+          const int f = idx[i], b = bin_of(f);
+          cnt[b]++;
+          for (int k = 0; k < 3; k++) { blo[b][k] = std::min(blo[b][k], tlo[3 * f + k]); bhi[b][k] = std::max(bhi[b][k], thi[3 * f + k]); }
+        }
+        float rarea[NB];   // area of bins b..NB-1
+        {
+          float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+          for (int b = NB - 1; b >= 0; b--) {
+            for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], blo[b][k]); hi[k] = std::max(hi[k], bhi[b][k]); }
+            const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+            rarea[b] = (hi[0] >= lo[0]) ? 2.f * (dx * dy + dy * dz + dz * dx) : 0.f;
+          }
+        }
+        float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+        int nleft = 0;
+        for (int b = 0; b + 1 < NB; b++) {   // split after bin b
+          nleft += cnt[b];
+          for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], blo[b][k]); hi[k] = std::max(hi[k], bhi[b][k]); }
+          if (nleft < lmin || nleft > lmax) continue;
+          const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+          const float la = (hi[0] >= lo[0]) ? 2.f * (dx * dy + dy * dz + dz * dx) : 0.f;
+          const float cost = la * nleft + rarea[b + 1] * (n - nleft);
+          if (cost < best_cost) { best_cost = cost; best_axis = ax; best_left = nleft; best_bin = b + 1; }
+        }
+      }
+      if (best_axis >= 0) {
+        // partition by bin membership (same rule as the counting pass), stable in the triangle index
+        const int ax = best_axis;
+        const float ext = chi[ax] - clo[ax];
+        auto bin_of = [&](int f) { return std::min(NB - 1, std::max(0, (int)((cen[3 * f + ax] - clo[ax]) / ext * NB))); };
+        std::stable_partition(idx.begin() + j.t0, idx.begin() + j.t1, [&](int f) { return bin_of(f) < best_bin; });
+        left = best_left;
+      } else {
+        // no admissible plane (degenerate centroids or capacity limits): even split along the widest axis
+        int ax = 0;
+        for (int k = 1; k < 3; k++)
+          if (chi[k] - clo[k] > chi[ax] - clo[ax]) ax = k;
         std::nth_element(idx.begin() + j.t0, idx.begin() + j.t0 + left, idx.begin() + j.t1,
                          [&](int a, int b) { return cen[3 * a + ax] < cen[3 * b + ax] || (cen[3 * a + ax] == cen[3 * b + ax] && a < b); });
-        const float cost = area(j.t0, j.t0 + left) * left + area(j.t0 + left, j.t1) * (n - left);
-        if (cost < best_cost) { best_cost = cost; best_axis = ax; }
       }
-      if (best_axis != 2)
-        std::nth_element(idx.begin() + j.t0, idx.begin() + j.t0 + left, idx.begin() + j.t1, [&](int a, int b) {
-          return cen[3 * a + best_axis] < cen[3 * b + best_axis] || (cen[3 * a + best_axis] == cen[3 * b + best_axis] && a < b);
-        });
     }
     const int lmid = j.l0 + nl / 2;
     stack.push_back({j.t0, j.t0 + left, j.l0, lmid});
