@@ -27,7 +27,8 @@ struct smj_ctx {
   // camera-static depth layers: geoms welded to a camera's body always look the same from that camera, so they are
   // rendered once per (camera, image size, field of view) and every later render starts its rays from that layer
   struct Layer { int cam = -1, w = 0, h = 0; float fovy = 0; float* buf = nullptr; };
-  std::vector<Layer> layers;   // internal [nbody*12][num_envs] body poses when the caller has not bound SMJ_SLOT_XPOSE
+  std::vector<Layer> layers;
+  float* depth_ws = nullptr;   // scratch of the depth renderer's per-env staging pass (allocated at the first render)   // internal [nbody*12][num_envs] body poses when the caller has not bound SMJ_SLOT_XPOSE
   void* slot_ptr[SMJ_SLOT_COUNT] = {};
   long slot_ld[SMJ_SLOT_COUNT] = {};
 };
@@ -288,6 +289,12 @@ int smj_render_depth(smj_ctx* c, int cam, int width, int height, float fovy_deg,
   if (!out_dev) return fail(c, -1, "null output image");
   if (!c->state.xpose) return fail(c, -5, "XPOSE slot is not bound (step with SMJ_READ_POSES first)");
   HIPCHK(c, hipSetDevice(c->device));
+  if (!c->depth_ws) {
+    void* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, smj_depth_workspace_bytes(c->num_envs)));
+    c->allocs.push_back(d);
+    c->depth_ws = (float*)d;
+  }
   smj_ctx::Layer* L = nullptr;
   for (auto& l : c->layers)
     if (l.cam == cam && l.w == width && l.h == height && l.fovy == fovy_deg) L = &l;
@@ -299,13 +306,13 @@ int smj_render_depth(smj_ctx* c, int cam, int width, int height, float fovy_deg,
     c->allocs.push_back(d);
     l.buf = (float*)d;
     smj_launch_depth(c->render, c->state.xpose, c->slot_ld[SMJ_SLOT_XPOSE], c->num_envs, cam, width, height, fovy_deg, 0.f, l.buf,
-                     nullptr, 1, (hipStream_t)stream);
+                     nullptr, 1, c->depth_ws, (hipStream_t)stream);
     HIPCHK(c, hipGetLastError());
     c->layers.push_back(l);
     L = &c->layers.back();
   }
   smj_launch_depth(c->render, c->state.xpose, c->slot_ld[SMJ_SLOT_XPOSE], c->num_envs, cam, width, height, fovy_deg, max_depth,
-                   (float*)out_dev, L->buf, 2, (hipStream_t)stream);
+                   (float*)out_dev, L->buf, 2, c->depth_ws, (hipStream_t)stream);
   HIPCHK(c, hipGetLastError());
   return 0;
 }

@@ -41,5 +41,7 @@ void smj_launch_lidar(const DevRender& r, const float* xpose, long ld, int num_e
 // mode 0: everything.  mode 1: render only the geoms rigidly attached to the camera's body, for env 0, raw depth into
 // out[height][width] (the camera-static layer: it does not depend on the state).  mode 2: skip those geoms and start every
 // ray from layer[height][width].
+// workspace: smj_depth_workspace_bytes(num_envs) of device memory, scratch of the per-env staging pass (smj_render.hip).
+size_t smj_depth_workspace_bytes(int num_envs);
 void smj_launch_depth(const DevRender& r, const float* xpose, long ld, int num_envs, int cam, int width, int height,
-                      float fovy_deg, float max_depth, float* out, const float* layer, int mode, hipStream_t stream);
+                      float fovy_deg, float max_depth, float* out, const float* layer, int mode, float* workspace, hipStream_t stream);

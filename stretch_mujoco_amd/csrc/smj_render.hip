@@ -12,6 +12,8 @@
 // bounding-sphere reject and, for meshes, a stack-free walk of the mesh BVH (heap layout, see smj_bvh.h) in the mesh frame.
 #include "smj_render.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int TILE = 16;   // pixels per side of a workgroup's tile (32 was measured slower: coarser culling outweighs the shared staging)
@@ -310,22 +312,28 @@ __global__ __launch_bounds__(384) void smj_lidar_kernel(const DevRender R, const
   }
 }
 
+// ------------------------------------------------------------------------------------------------ depth cameras
+// Per-env staging pass (one workgroup per env, lane = visible geom), run once per render instead of once per tile:
+// world poses of the geoms and of the camera, each geom's conservative SCREEN RECTANGLE (bounds of x/depth and y/depth over
+// its bounding sphere, tightened by the box of a mesh) and the front-to-back order (distance from the camera to the
+// bounding sphere).  Geoms that cannot be seen at all -- behind the near plane, beyond the depth range, filtered by the
+// layer mode -- are dropped here.  The tile kernel then keeps a geom iff its rectangle meets the tile: four compares
+// instead of a cone test plus an eight-corner frustum test, no sorting, and only the kept geoms are staged in LDS.
+// Everything here is a superset test: the image does not depend on it.
+//
+// Workspace per env (floats): header cpos[3], cmat[9], count; then one 32-float slot per surviving geom in front-to-back
+// order: RGeom (pos 3, mat 9, cen 3, rbound, size 3, type, rmesh = 23 words), rect x0 x1 y0 y1.
+constexpr int WS_HDR = 16, WS_SLOT = 32, WS_RECT = 24;
+constexpr int WS_STRIDE = WS_HDR + SMJ_RGEOM_MAX * WS_SLOT;
+
 // mode 0: all visible geoms.  mode 1: only the geoms rigidly attached to the camera's body, with that body at the
-// identity (no state is read), raw depth -- the camera-static layer.  mode 2: all other geoms, every ray starting from the static layer's depth.
-__global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const float* __restrict__ xpose, long ld, int cam, int width,
-                                                        int height, float tan_half_fovy, float max_depth, float* __restrict__ out,
-                                                        const float* __restrict__ layer, int mode) {
-  __shared__ RGeom geoms[SMJ_RGEOM_MAX];
+// identity (no state is read) -- the camera-static layer.  mode 2: all other geoms.
+__global__ __launch_bounds__(128) void smj_depth_prepass(const DevRender R, const float* __restrict__ xpose, long ld, int cam,
+                                                         float max_depth, float* __restrict__ ws, int mode, int nocull) {
   __shared__ float cpos[3], cmat[9], gkey[SMJ_RGEOM_MAX];
-  __shared__ int gorder[SMJ_RGEOM_MAX], nkeep;
-  const int env = blockIdx.y;
-  const int tiles_x = (width + TILE - 1) / TILE;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  const int tid = threadIdx.x;
-  // stage camera and geom world poses of this env
-  if (tid < R.nrgeom) {
-    const int g = R.rgeom[tid], b = R.geom_bodyid[g];
-    float bp[3], bm[9];
+  const int env = blockIdx.x, tid = threadIdx.x;
+  float* W = ws + (long)env * WS_STRIDE;
+  auto body_pose = [&](int b, float* bp, float* bm) {
     if (mode == 1) {   // the static layer is a property of the model: camera body at the identity, no state involved
       for (int k = 0; k < 3; k++) bp[k] = 0.f;
       for (int k = 0; k < 9; k++) bm[k] = (k % 4 == 0) ? 1.f : 0.f;
@@ -333,10 +341,23 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
       for (int k = 0; k < 3; k++) bp[k] = xpose[(12 * b + k) * ld + env];
       for (int k = 0; k < 9; k++) bm[k] = xpose[(12 * b + 3 + k) * ld + env];
     }
-    RGeom& G = geoms[tid];
+  };
+  if (tid == 127) {
+    float bp[3], bm[9], w[3];
+    body_pose(R.cam_bodyid[cam], bp, bm);
+    mul(w, bm, R.cam_pos + 3 * cam);
+    for (int k = 0; k < 3; k++) cpos[k] = bp[k] + w[k];
+    const float* lm = R.cam_mat + 9 * cam;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) cmat[3 * i + j] = bm[3 * i] * lm[j] + bm[3 * i + 1] * lm[3 + j] + bm[3 * i + 2] * lm[6 + j];
+  }
+  RGeom G{};
+  if (tid < R.nrgeom) {
+    const int g = R.rgeom[tid];
+    float bp[3], bm[9], w[3];
+    body_pose(R.geom_bodyid[g], bp, bm);
     const float lp[3] = {R.geom_pos[3 * g], R.geom_pos[3 * g + 1], R.geom_pos[3 * g + 2]};
     const float lc[3] = {R.geom_bcenter[3 * g], R.geom_bcenter[3 * g + 1], R.geom_bcenter[3 * g + 2]};
-    float w[3];
     mul(w, bm, lp);
     for (int k = 0; k < 3; k++) G.pos[k] = bp[k] + w[k];
     mul(w, bm, lc);
@@ -349,112 +370,134 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
     G.rbound = R.geom_rbound[g];
     for (int k = 0; k < 3; k++) G.size[k] = R.geom_size[3 * g + k];
   }
-  if (tid == 255) {
-    const int b = R.cam_bodyid[cam];
-    float bp[3], bm[9];
-    if (mode == 1) {
-      for (int k = 0; k < 3; k++) bp[k] = 0.f;
-      for (int k = 0; k < 9; k++) bm[k] = (k % 4 == 0) ? 1.f : 0.f;
-    } else {
-      for (int k = 0; k < 3; k++) bp[k] = xpose[(12 * b + k) * ld + env];
-      for (int k = 0; k < 9; k++) bm[k] = xpose[(12 * b + 3 + k) * ld + env];
-    }
-    float w[3];
-    mul(w, bm, R.cam_pos + 3 * cam);
-    for (int k = 0; k < 3; k++) cpos[k] = bp[k] + w[k];
-    const float* lm = R.cam_mat + 9 * cam;
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++) cmat[3 * i + j] = bm[3 * i] * lm[j] + bm[3 * i + 1] * lm[3 + j] + bm[3 * i + 2] * lm[6 + j];
-  }
   __syncthreads();
-  // Per-tile geom list.  Keep only the geoms whose bounding sphere can meet the cone of rays of this 16x16 tile within the
-  // depth range -- the per-ray loop over ALL visible geoms was the instruction-count floor of the kernel (74 sphere
-  // rejects per ray) -- and order them front to back (rank sort on the distance from the camera to the sphere): the nearest
-  // hit is found early and the per-ray reject then drops most of what lies behind it.
-  const float aspect = (float)width / (float)height;
   const float tfar = (max_depth > 0.f && max_depth < R.zfar) ? max_depth : R.zfar;   // hits beyond the limit become 0 anyway
+  const float BIG = 3.0e38f;
+  float key = BIG, rect[4] = {-BIG, BIG, -BIG, BIG};
   if (tid < R.nrgeom) {
-    const RGeom& G = geoms[tid];
     const float dc[3] = {G.cen[0] - cpos[0], G.cen[1] - cpos[1], G.cen[2] - cpos[2]};
-    const float dist = sqrtf(dot3(dc, dc)), r = G.rbound;
-    float key = -1.f;
-    if (G.type != RT_PLANE) {
-      key = dist - r;
-      // tile cone: axis through the tile centre, half angle alpha to the farthest tile corner (camera frame, -z forward)
-      const float xc = ((tx * TILE + 0.5f * TILE) / width * 2.f - 1.f) * tan_half_fovy * aspect, yc = (1.f - (ty * TILE + 0.5f * TILE) / height * 2.f) * tan_half_fovy;
-      const float hx = (float)TILE / width * tan_half_fovy * aspect, hy = (float)TILE / height * tan_half_fovy;   // half tile size at z = -1
-      if (dist > r) {
-        const float cl = sqrtf(xc * xc + yc * yc + 1.f);
-        float cosa = 1.f, dlmax = 0.f;
-        for (int k = 0; k < 4; k++) {
-          const float x = xc + ((k & 1) ? hx : -hx), y = yc + ((k & 2) ? hy : -hy);
-          const float l = sqrtf(x * x + y * y + 1.f);
-          cosa = fminf(cosa, (x * xc + y * yc + 1.f) / (l * cl));
-          dlmax = fmaxf(dlmax, l);
+    if (G.type == RT_PLANE) key = -1.f;
+    else {
+      float pc[3];
+      mulT(pc, cmat, dc);   // bounding-sphere centre in the camera frame (x right, y up, looking down -z)
+      const float D = -pc[2], r = G.rbound * (1.f + 1e-5f) + 1e-6f;
+      key = sqrtf(dot3(dc, dc)) - G.rbound;
+      if (D + r < R.znear) key = BIG;                       // entirely behind the near plane: t >= znear never reaches it
+      else if (D - r > tfar * (1.f + 1e-5f)) key = BIG;     // entirely beyond the depth range
+      else if (D - r > 1e-4f && !nocull) {
+        // bounds of x / depth and y / depth over the sphere: tangents from the eye to the circle (X, D, r) in the x-z plane
+        const float den = D * D - r * r;
+        for (int a = 0; a < 2; a++) {
+          const float X = pc[a], sq = r * sqrtf(fmaxf(0.f, X * X + den));
+          float lo = (X * D - sq) / den, hi = (X * D + sq) / den;
+          const float e = 1e-5f * (1.f + fabsf(lo) + fabsf(hi));
+          rect[2 * a] = lo - e; rect[2 * a + 1] = hi + e;
         }
-        const float sina = sqrtf(fmaxf(0.f, 1.f - cosa * cosa));
-        const float ac[3] = {xc / cl, yc / cl, -1.f / cl};
-        float aw[3];
-        mul(aw, cmat, ac);   // cone axis in the world
-        const float sinb = r / dist, cosb = sqrtf(fmaxf(0.f, 1.f - sinb * sinb));   // beta: angular radius of the sphere
-        const float cosab = cosa * cosb - sina * sinb;      // cos(alpha + beta), alpha + beta < pi
-        const float cost = dot3(dc, aw) / dist;             // angle between the cone axis and the sphere centre
-        if (cost < cosab - 1e-4f) key = 3.0e38f;            // outside the cone widened by the sphere
-        if (dist - r > tfar * dlmax) key = 3.0e38f;         // beyond the depth range for every ray of the tile
-      }
-      if (key < 1.0e38f && G.type == RT_MESH) {
-        // the mesh's box (geom frame) against the tile's frustum: drop the geom when all eight corners lie outside one of
-        // the four side planes (planes through the eye) or in front of the near / beyond the far plane.  Long thin parts
-        // (fingers, arm segments) have large bounding spheres but project onto few tiles.
-        const float* bb = R.geom_aabb + 6 * R.rgeom[tid];
-        const float x0 = xc - hx, x1 = xc + hx, y0 = yc - hy, y1 = yc + hy;
-        int out = 63;   // bit k set: every corner so far is outside plane k
-        for (int cidx = 0; cidx < 8; cidx++) {
-          const float pad = 1e-5f;   // the box was taken before the vertices were rounded to fp32
-          const float lc[3] = {bb[0] + ((cidx & 1) ? bb[3] + pad : -bb[3] - pad), bb[1] + ((cidx & 2) ? bb[4] + pad : -bb[4] - pad),
-                               bb[2] + ((cidx & 4) ? bb[5] + pad : -bb[5] - pad)};
-          float w[3], pc[3];
-          mul(w, G.mat, lc);
-          const float dw[3] = {G.pos[0] + w[0] - cpos[0], G.pos[1] + w[1] - cpos[1], G.pos[2] + w[2] - cpos[2]};
-          mulT(pc, cmat, dw);
-          const float zd = -pc[2];   // distance along the optical axis
-          const float e = 1e-5f * (fabsf(pc[0]) + fabsf(pc[1]) + fabsf(zd)) + 1e-6f;   // stay conservative under round-off
-          int o = 0;
-          if (pc[0] - x1 * zd > e) o |= 1;
-          if (pc[0] - x0 * zd < -e) o |= 2;
-          if (pc[1] - y1 * zd > e) o |= 4;
-          if (pc[1] - y0 * zd < -e) o |= 8;
-          if (zd < R.znear - e) o |= 16;
-          if (zd > tfar + e) o |= 32;
-          out &= o;
+        if (G.type == RT_MESH) {
+          // a mesh's box (geom frame): long thin parts have large bounding spheres but small projections
+          const float* bb = R.geom_aabb + 6 * R.rgeom[tid];
+          float lo[2] = {BIG, BIG}, hi[2] = {-BIG, -BIG}, dmin = BIG;
+          bool ok = true;
+          for (int cidx = 0; cidx < 8; cidx++) {
+            const float pad = 1e-5f;   // the box was taken before the vertices were rounded to fp32
+            const float lc[3] = {bb[0] + ((cidx & 1) ? bb[3] + pad : -bb[3] - pad), bb[1] + ((cidx & 2) ? bb[4] + pad : -bb[4] - pad),
+                                 bb[2] + ((cidx & 4) ? bb[5] + pad : -bb[5] - pad)};
+            float w[3], q[3];
+            mul(w, G.mat, lc);
+            const float dw[3] = {G.pos[0] + w[0] - cpos[0], G.pos[1] + w[1] - cpos[1], G.pos[2] + w[2] - cpos[2]};
+            mulT(q, cmat, dw);
+            const float zd = -q[2];
+            if (zd < 1e-3f) { ok = false; break; }   // a corner at or behind the eye plane: no valid projection, keep the sphere's
+            dmin = fminf(dmin, zd);
+            for (int a = 0; a < 2; a++) { const float v = q[a] / zd; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+          }
+          if (ok) {
+            for (int a = 0; a < 2; a++) {
+              const float e = 1e-5f * (1.f + fabsf(lo[a]) + fabsf(hi[a]));
+              rect[2 * a] = fmaxf(rect[2 * a], lo[a] - e); rect[2 * a + 1] = fminf(rect[2 * a + 1], hi[a] + e);
+            }
+            if (dmin > tfar * (1.f + 1e-5f) + 1e-5f) key = BIG;
+          }
         }
-        if (out) key = 3.0e38f;
       }
     }
-    if (mode != 0) {
+    if (mode != 0 && key < 1.0e38f) {
       const bool attached = R.geom_bodyid[R.rgeom[tid]] == R.cam_bodyid[cam];
-      if (attached != (mode == 1)) key = 3.0e38f;
+      if (attached != (mode == 1)) key = BIG;
     }
     gkey[tid] = key;
   }
   __syncthreads();
   if (tid < R.nrgeom) {
-    const float key = gkey[tid];
     int rank = 0, kept = 0;
     for (int j = 0; j < R.nrgeom; j++) {
       rank += (gkey[j] < key) || (gkey[j] == key && j < tid);
       kept += gkey[j] < 1.0e38f;
     }
-    gorder[rank] = tid;
-    if (tid == 0) nkeep = kept;
+    if (key < 1.0e38f) {
+      float* S = W + WS_HDR + (long)rank * WS_SLOT;
+      for (int k = 0; k < 3; k++) { S[k] = G.pos[k]; S[12 + k] = G.cen[k]; S[16 + k] = G.size[k]; }
+      for (int k = 0; k < 9; k++) S[3 + k] = G.mat[k];
+      S[15] = G.rbound;
+      S[19] = __int_as_float(G.type); S[20] = __int_as_float(G.rmesh);
+      for (int k = 0; k < 4; k++) S[WS_RECT + k] = rect[k];
+    }
+    if (tid == 0) {
+      for (int k = 0; k < 3; k++) W[k] = cpos[k];
+      for (int k = 0; k < 9; k++) W[3 + k] = cmat[k];
+      W[12] = __int_as_float(kept);
+    }
   }
+}
+
+__global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const float* __restrict__ ws, int width, int height,
+                                                        float tan_half_fovy, float max_depth, float* __restrict__ out,
+                                                        const float* __restrict__ layer, int mode) {
+  __shared__ RGeom geoms[SMJ_RGEOM_MAX];
+  __shared__ float cpos[3], cmat[9];
+  __shared__ int wcount[2];
+  const int env = blockIdx.y;
+  const int tiles_x = (width + TILE - 1) / TILE;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int tid = threadIdx.x;
+  const float* W = ws + (long)env * WS_STRIDE;
+  const float aspect = (float)width / (float)height;
+  const float tfar = (max_depth > 0.f && max_depth < R.zfar) ? max_depth : R.zfar;   // hits beyond the limit become 0 anyway
+  if (tid < 3) cpos[tid] = W[tid];
+  else if (tid < 12) cmat[tid - 3] = W[tid];
+  // Per-tile geom list: the staged geoms (front to back) whose screen rectangle meets this tile, compacted in order.  The
+  // nearest hit is found early and the per-ray bounding-sphere reject then drops most of what lies behind it.
+  const int nk = __float_as_int(W[12]);
+  int keep = 0;
+  if (tid < nk) {
+    const float* S = W + WS_HDR + (long)tid * WS_SLOT + WS_RECT;
+    const float x0 = ((float)(tx * TILE) / width * 2.f - 1.f) * tan_half_fovy * aspect;
+    const float x1 = ((float)(tx * TILE + TILE) / width * 2.f - 1.f) * tan_half_fovy * aspect;
+    const float y1 = (1.f - (float)(ty * TILE) / height * 2.f) * tan_half_fovy;
+    const float y0 = (1.f - (float)(ty * TILE + TILE) / height * 2.f) * tan_half_fovy;
+    keep = S[1] >= x0 && S[0] <= x1 && S[3] >= y0 && S[2] <= y1;
+  }
+  const unsigned long long bal = __ballot(keep);
+  const int wv0 = tid >> 6, ln0 = tid & 63;
+  if (wv0 < 2 && ln0 == 0) wcount[wv0] = __popcll(bal);
+  __syncthreads();
+  if (keep) {
+    const int at = (wv0 ? wcount[0] : 0) + __popcll(bal & ((1ull << ln0) - 1ull));
+    const float* S = W + WS_HDR + (long)tid * WS_SLOT;
+    RGeom& G = geoms[at];
+    for (int k = 0; k < 3; k++) { G.pos[k] = S[k]; G.cen[k] = S[12 + k]; G.size[k] = S[16 + k]; }
+    for (int k = 0; k < 9; k++) G.mat[k] = S[3 + k];
+    G.rbound = S[15];
+    G.type = __float_as_int(S[19]); G.rmesh = __float_as_int(S[20]);
+  }
+  const int nkeep_total = wcount[0] + wcount[1];
   __syncthreads();
   // A workgroup renders a TILE x TILE pixel tile with its 256 threads in (TILE/16)^2 rounds; each wavefront covers an 8x8
   // pixel square (not a 16x4 strip): neighbouring rays share more of their walk.  The staging and culling above are paid
   // once per tile, which is why the tile is larger than one round.
   const int wv = tid >> 6, ln = tid & 63;
   const float tnear = R.znear;
-  const int ng = nkeep;
+  const int ng = nkeep_total;
   for (int rd = 0; rd < (TILE / 16) * (TILE / 16); rd++) {
     const int u = tx * TILE + (rd % (TILE / 16)) * 16 + (wv & 1) * 8 + (ln & 7), v = ty * TILE + (rd / (TILE / 16)) * 16 + (wv >> 1) * 8 + (ln >> 3);
     if (u >= width || v >= height) continue;
@@ -468,7 +511,7 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
     float best = tfar * (1.f + 1e-6f);
     if (mode == 2) best = fminf(best, layer[(long)v * width + u]);
     for (int i = 0; i < ng; i++) {
-      const RGeom& G = geoms[gorder[i]];
+      const RGeom& G = geoms[i];
       if (G.type != RT_PLANE) {   // bounding sphere
         const float oc[3] = {G.cen[0] - o[0], G.cen[1] - o[1], G.cen[2] - o[2]};
         const float b = dot3(oc, d), r = G.rbound;
@@ -499,10 +542,15 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
 void smj_launch_lidar(const DevRender& r, const float* xpose, long ld, int num_envs, float* lidar, long lidar_ld, hipStream_t stream) {
   hipLaunchKernelGGL(smj_lidar_kernel, dim3(num_envs), dim3(384), 0, stream, r, xpose, ld, lidar, lidar_ld);
 }
+size_t smj_depth_workspace_bytes(int num_envs) { return sizeof(float) * (size_t)WS_STRIDE * (size_t)(num_envs + 1); }
 void smj_launch_depth(const DevRender& r, const float* xpose, long ld, int num_envs, int cam, int width, int height,
-                      float fovy_deg, float max_depth, float* out, const float* layer, int mode, hipStream_t stream) {
+                      float fovy_deg, float max_depth, float* out, const float* layer, int mode, float* workspace, hipStream_t stream) {
   const int tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
   const float th = tanf(fovy_deg * 3.14159265358979323846f / 360.f);
-  hipLaunchKernelGGL(smj_depth_kernel, dim3(tiles, mode == 1 ? 1 : num_envs), dim3(256), 0, stream, r, xpose, ld, cam, width, height, th,
-                     mode == 1 ? 0.f : max_depth, out, layer, mode);
+  const int nenv = mode == 1 ? 1 : num_envs;
+  float* ws = mode == 1 ? workspace + (size_t)WS_STRIDE * num_envs : workspace;   // the static layer stages into the last block
+  const float md = mode == 1 ? 0.f : max_depth;
+  static const int nocull = getenv("SMJ_DEPTH_NOCULL") ? 1 : 0;   // debug: every geom in every tile (the image must not change)
+  hipLaunchKernelGGL(smj_depth_prepass, dim3(nenv), dim3(128), 0, stream, r, xpose, ld, cam, md, ws, mode, nocull);
+  hipLaunchKernelGGL(smj_depth_kernel, dim3(tiles, nenv), dim3(256), 0, stream, r, ws, width, height, th, md, out, layer, mode);
 }

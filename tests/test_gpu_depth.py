@@ -126,3 +126,19 @@ def test_depth_full_batch_properties():
     ref = img[0]
     d = (img - ref).abs()
     assert (d[near & near[0:1]] < 2e-4).float().mean() > 0.995
+
+
+def test_culling_does_not_change_the_image():
+    """The staging pass drops geoms per env (near / far / layer) and the tile kernel per screen rectangle: both are superset tests,
+    so the image with the culling switched off (SMJ_DEPTH_NOCULL=1, read once per process -> child process) is the same, bit
+    for bit.  64 envs at random poses in the kitchen stand-in, both cameras (tools/gpu_depth_cullcheck.py)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_depth_cullcheck.py"), "64", "stretch_kitchen_standin"],
+                         cwd=root, capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if "differing" in l]
+    assert out.returncode == 0 and len(lines) == 2, out.stdout + out.stderr
+    assert all(l.rstrip().endswith("differing 0") for l in lines), out.stdout
