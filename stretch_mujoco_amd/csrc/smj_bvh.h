@@ -1,7 +1,7 @@
 // Host-side builder of the per-mesh bounding-volume hierarchies the depth renderer traverses (smj_render.hip).
 //
 // Layout, chosen for a stack-free traversal on the GPU: the triangles of a mesh are partitioned by recursive object splits
-// (see below) into leaves of up to four; the leaves are the last level of a COMPLETE binary tree stored as a
+// (see below) into leaves of up to SMJ_BVH_LEAF; the leaves are the last level of a COMPLETE binary tree stored as a
 // 1-based heap (children of n are 2n and 2n+1), padded with empty nodes to a power of two.  "Next subtree" is then pure
 // index arithmetic (sibling = n ^ 1, parent = n >> 1), so a ray needs no per-thread stack; every inner node carries the
 // axis that separates its children so that a ray can visit the nearer child first (node[...][3], see below).
@@ -13,11 +13,13 @@
 #include <utility>
 #include <vector>
 
+#define SMJ_BVH_LEAF 2   // triangle slots per leaf (the traversal in smj_render.hip unrolls over them)
+
 struct SmjBvhMesh {
   int nodebase;  // heap node n of this mesh lives at node[nodebase + n]
   int tribase;   // first packed triangle of this mesh
   int leaf0;     // heap index of the first leaf (= number of leaves, a power of two)
-  int ntri;      // packed (padded) triangle count = 4 * leaf0
+  int ntri;      // packed (padded) triangle count = SMJ_BVH_LEAF * leaf0
 };
 
 struct SmjBvhSet {
@@ -30,11 +32,11 @@ struct SmjBvhSet {
 static inline void smj_bvh_add_mesh(SmjBvhSet& set, const float* verts, int nv, const int* faces, int nf) {
   (void)nv;
   SmjBvhMesh m{};
-  const int nleaf_real = std::max(1, (nf + 3) / 4);
+  const int nleaf_real = std::max(1, (nf + SMJ_BVH_LEAF - 1) / SMJ_BVH_LEAF);
   int leaf0 = 1;
   while (leaf0 < nleaf_real) leaf0 <<= 1;
   m.leaf0 = leaf0;
-  m.ntri = 4 * leaf0;
+  m.ntri = SMJ_BVH_LEAF * leaf0;
   m.nodebase = (int)(set.node.size() / 8);
   m.tribase = (int)(set.tri.size() / 12);
   // Triangle order: recursive object split.  The node that covers leaves [l0, l1) splits its triangles by the binned
@@ -60,10 +62,10 @@ static inline void smj_bvh_add_mesh(SmjBvhSet& set, const float* verts, int nv, 
     stack.pop_back();
     const int n = j.t1 - j.t0, nl = j.l1 - j.l0;
     if (nl == 1) {
-      for (int i = 0; i < n; i++) slot[idx[j.t0 + i]] = 4 * j.l0 + i;
+      for (int i = 0; i < n; i++) slot[idx[j.t0 + i]] = SMJ_BVH_LEAF * j.l0 + i;
       continue;
     }
-    const int cap = 4 * (nl / 2);                                   // triangle capacity of each half
+    const int cap = SMJ_BVH_LEAF * (nl / 2);                                   // triangle capacity of each half
     const int lmin = std::max(n - cap, n > 1 ? 1 : 0), lmax = std::min(cap, n > 1 ? n - 1 : n);   // admissible left counts
     int left = std::min(cap, std::max(n - cap, (n + 1) / 2));        // default: as even as the capacities allow
     if (n > 1 && lmin <= lmax) {
@@ -150,7 +152,7 @@ static inline void smj_bvh_add_mesh(SmjBvhSet& set, const float* verts, int nv, 
   for (int n = 0; n < nnode; n++)
     for (int k = 0; k < 3; k++) { N[8 * n + k] = 3e38f; N[8 * n + 4 + k] = -3e38f; }
   for (int f = 0; f < nf; f++) {
-    const int i = slot[f], n = leaf0 + i / 4;
+    const int i = slot[f], n = leaf0 + i / SMJ_BVH_LEAF;
     for (int k = 0; k < 3; k++) {
       const float a = T[12 * i + k], b = a + T[12 * i + 4 + k], c = a + T[12 * i + 8 + k];
       N[8 * n + k] = std::min(N[8 * n + k], std::min(a, std::min(b, c)));

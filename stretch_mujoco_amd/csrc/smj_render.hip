@@ -11,6 +11,7 @@
 // The tile first stages the world poses of the visible geoms in LDS; every ray then runs over those geoms with a
 // bounding-sphere reject and, for meshes, a stack-free walk of the mesh BVH (heap layout, see smj_bvh.h) in the mesh frame.
 #include "smj_render.h"
+#include "smj_bvh.h"   // SMJ_BVH_LEAF
 
 #include <stdlib.h>
 
@@ -46,7 +47,11 @@ __device__ float ray_mesh(const DevRender& R, int rmesh, const float* o, const f
   const float4* tri = R.tri + 3 * (long)mi.y;
   const int leaf0 = mi.z;
   const float inv[3] = {1.f / d[0], 1.f / d[1], 1.f / d[2]};   // +-inf for axis-parallel rays: the slab test below copes
-  int n = 1;
+  // Stack-free walk of the complete tree with a TRAIL register: bit `level` says whether the sibling of the node on the current
+  // path at that level has been visited.  Descending clears the bit; finishing a node either steps to the sibling (bit 0 ->
+  // set it, n ^= 1) or climbs (bit 1 -> n >>= 1) -- index arithmetic only, no node is re-read on the way up.
+  int n = 1, level = 0;
+  unsigned trail = 0;
   while (true) {
     const float4 lo = node[2 * n], hi = node[2 * n + 1];
     float t0 = tnear, t1 = best;
@@ -69,12 +74,14 @@ __device__ float ray_mesh(const DevRender& R, int rmesh, const float* o, const f
       const int code = (int)lo.w, axis = code & 3;
       const float da = axis == 0 ? d[0] : (axis == 1 ? d[1] : d[2]);
       n = 2 * n + (((da >= 0.f) == ((code >> 2) != 0)) ? 1 : 0);
+      level++;
+      trail &= ~(1u << level);
       continue;
     }
     if (hit) {
-      const float4* T = tri + 3 * 4 * (long)(n - leaf0);
+      const float4* T = tri + 3 * SMJ_BVH_LEAF * (long)(n - leaf0);
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < SMJ_BVH_LEAF; k++) {
         const float4 v0 = T[3 * k], e1 = T[3 * k + 1], e2 = T[3 * k + 2];
         const float p[3] = {d[1] * e2.z - d[2] * e2.y, d[2] * e2.x - d[0] * e2.z, d[0] * e2.y - d[1] * e2.x};
         const float det = e1.x * p[0] + e1.y * p[1] + e1.z * p[2];
@@ -91,15 +98,12 @@ __device__ float ray_mesh(const DevRender& R, int rmesh, const float* o, const f
         }
       }
     }
-    // next subtree: the sibling if this node was the first (nearer) child of its parent, otherwise climb
+    // next subtree: the sibling if it has not been visited yet, otherwise climb
     while (true) {
-      if (n == 1) return best;
-      const int par = n >> 1;
-      const int code = (int)node[2 * par].w, axis = code & 3;
-      const float da = axis == 0 ? d[0] : (axis == 1 ? d[1] : d[2]);
-      const int first = 2 * par + (((da >= 0.f) == ((code >> 2) != 0)) ? 1 : 0);
-      if (n == first) { n ^= 1; break; }
-      n = par;
+      if (level == 0) return best;
+      if (!(trail & (1u << level))) { trail |= 1u << level; n ^= 1; break; }
+      n >>= 1;
+      level--;
     }
   }
   return best;

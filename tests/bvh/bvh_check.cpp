@@ -37,8 +37,8 @@ static float walk(const SmjBvhSet& s, const SmjBvhMesh& m, int n, const float* o
   if (!box_hit(N, o, d)) return 3e38f;
   if (n >= m.leaf0) {
     float best = 3e38f, t;
-    for (int k = 0; k < 4; k++)
-      if (tri_hit(&s.tri[12 * (size_t)(m.tribase + 4 * (n - m.leaf0) + k)], o, d, t)) best = std::min(best, t);
+    for (int k = 0; k < SMJ_BVH_LEAF; k++)
+      if (tri_hit(&s.tri[12 * (size_t)(m.tribase + SMJ_BVH_LEAF * (n - m.leaf0) + k)], o, d, t)) best = std::min(best, t);
     return best;
   }
   return std::min(walk(s, m, 2 * n, o, d), walk(s, m, 2 * n + 1, o, d));
@@ -61,7 +61,7 @@ int main() {
     if (trial % 2) smj_bvh_add_mesh(s, v.data(), nv, f.data(), std::min(nf, 7));   // a second mesh in the same set: bases
     smj_bvh_add_mesh(s, v.data(), nv, f.data(), nf);
     const SmjBvhMesh& m = s.mesh.back();
-    if (m.ntri != 4 * m.leaf0 || (m.leaf0 & (m.leaf0 - 1)) || 4 * m.leaf0 < nf) { printf("layout\n"); return 1; }
+    if (m.ntri != SMJ_BVH_LEAF * m.leaf0 || (m.leaf0 & (m.leaf0 - 1)) || SMJ_BVH_LEAF * m.leaf0 < nf) { printf("layout\n"); return 1; }
     // every input triangle appears exactly once; the other slots are all-zero
     std::map<std::array<float, 9>, int> want;
     for (int i = 0; i < nf; i++) {
@@ -88,7 +88,7 @@ int main() {
       bool z = true;
       for (int q = 0; q < 12; q++) z &= T[q] == 0.f;
       if (z) continue;
-      const float* N = &s.node[8 * (size_t)(m.nodebase + m.leaf0 + i / 4)];
+      const float* N = &s.node[8 * (size_t)(m.nodebase + m.leaf0 + i / SMJ_BVH_LEAF)];
       for (int q = 0; q < 3; q++) {
         const float a = T[q], b = a + T[4 + q], c = a + T[8 + q];
         if (std::min(a, std::min(b, c)) < N[q] || std::max(a, std::max(b, c)) > N[4 + q]) { printf("triangle outside its leaf box\n"); return 1; }
