@@ -3,8 +3,9 @@
 // Layout, chosen for a stack-free traversal on the GPU: the triangles of a mesh are partitioned by recursive object splits
 // (see below) into leaves of up to SMJ_BVH_LEAF; the leaves are the last level of a COMPLETE binary tree stored as a
 // 1-based heap (children of n are 2n and 2n+1), padded with empty nodes to a power of two.  "Next subtree" is then pure
-// index arithmetic (sibling = n ^ 1, parent = n >> 1), so a ray needs no per-thread stack; every inner node carries the
-// axis that separates its children so that a ray can visit the nearer child first (node[...][3], see below).
+// index arithmetic (sibling = n ^ 1, parent = n >> 1), so a ray needs no per-thread stack.  An inner node stores the boxes of
+// BOTH its children (64 bytes): one visit tests the two boxes, orders them by entry distance and skips a missed child without
+// ever fetching it; leaves have no node record of their own.
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -16,14 +17,14 @@
 #define SMJ_BVH_LEAF 2   // triangle slots per leaf (the traversal in smj_render.hip unrolls over them)
 
 struct SmjBvhMesh {
-  int nodebase;  // heap node n of this mesh lives at node[nodebase + n]
+  int nodebase;  // inner heap node n (1 <= n < leaf0) of this mesh lives at node[nodebase + n] (16 floats each)
   int tribase;   // first packed triangle of this mesh
   int leaf0;     // heap index of the first leaf (= number of leaves, a power of two)
   int ntri;      // packed (padded) triangle count = SMJ_BVH_LEAF * leaf0
 };
 
 struct SmjBvhSet {
-  std::vector<float> node;  // [nnode][8]: lo.xyz, 0, hi.xyz, 0   (empty node: lo = +big, hi = -big)
+  std::vector<float> node;  // [inner node][16]: child 2n lo.xyz,0 hi.xyz,0, child 2n+1 lo.xyz,0 hi.xyz,0  (empty child: lo = +big, hi = -big)
   std::vector<float> tri;   // [ntri][12]: v0.xyz, 0, e1.xyz, 0, e2.xyz, 0  (padding triangles are all zero)
   std::vector<SmjBvhMesh> mesh;
 };
@@ -37,7 +38,7 @@ static inline void smj_bvh_add_mesh(SmjBvhSet& set, const float* verts, int nv, 
   while (leaf0 < nleaf_real) leaf0 <<= 1;
   m.leaf0 = leaf0;
   m.ntri = SMJ_BVH_LEAF * leaf0;
-  m.nodebase = (int)(set.node.size() / 8);
+  m.nodebase = (int)(set.node.size() / 16);
   m.tribase = (int)(set.tri.size() / 12);
   // Triangle order: recursive object split.  The node that covers leaves [l0, l1) splits its triangles by the binned
   // surface-area heuristic -- any plane whose two sides fit the capacity of the two halves of the leaves is admissible --
@@ -145,12 +146,11 @@ static inline void smj_bvh_add_mesh(SmjBvhSet& set, const float* verts, int nv, 
       T[12 * i + 8 + k] = c[k] - a[k];
     }
   }
-  // boxes, bottom-up
+  // boxes, bottom-up, then packed into the parents
   const int nnode = 2 * leaf0;
-  set.node.resize(set.node.size() + 8 * (size_t)nnode, 0.f);
-  float* N = set.node.data() + 8 * (size_t)m.nodebase;
+  std::vector<float> N(8 * (size_t)nnode);
   for (int n = 0; n < nnode; n++)
-    for (int k = 0; k < 3; k++) { N[8 * n + k] = 3e38f; N[8 * n + 4 + k] = -3e38f; }
+    for (int k = 0; k < 4; k++) { N[8 * n + k] = k < 3 ? 3e38f : 0.f; N[8 * n + 4 + k] = k < 3 ? -3e38f : 0.f; }
   for (int f = 0; f < nf; f++) {
     const int i = slot[f], n = leaf0 + i / SMJ_BVH_LEAF;
     for (int k = 0; k < 3; k++) {
@@ -159,23 +159,15 @@ static inline void smj_bvh_add_mesh(SmjBvhSet& set, const float* verts, int nv, 
       N[8 * n + 4 + k] = std::max(N[8 * n + 4 + k], std::max(a, std::max(b, c)));
     }
   }
-  for (int n = leaf0 - 1; n >= 1; n--) {
-    const float* L = N + 8 * (2 * n);
-    const float* Rr = N + 8 * (2 * n + 1);
+  for (int n = leaf0 - 1; n >= 1; n--)
     for (int k = 0; k < 3; k++) {
-      N[8 * n + k] = std::min(L[k], Rr[k]);
-      N[8 * n + 4 + k] = std::max(L[4 + k], Rr[4 + k]);
+      N[8 * n + k] = std::min(N[8 * (2 * n) + k], N[8 * (2 * n + 1) + k]);
+      N[8 * n + 4 + k] = std::max(N[8 * (2 * n) + 4 + k], N[8 * (2 * n + 1) + 4 + k]);
     }
-    // visiting order hint: the axis along which the two children are furthest apart, and whether the left child is the
-    // one with the larger coordinate (code = axis + 4 * swapped); a ray enters the child on its own side first
-    int axis = 0, swapped = 0;
-    float sep = -1.f;
-    if (L[0] <= L[4] && Rr[0] <= Rr[4])
-      for (int k = 0; k < 3; k++) {
-        const float dc = (Rr[k] + Rr[4 + k]) - (L[k] + L[4 + k]);
-        if (fabsf(dc) > sep) { sep = fabsf(dc); axis = k; swapped = dc < 0; }
-      }
-    N[8 * n + 3] = (float)(axis + 4 * swapped);
-  }
+  set.node.resize(set.node.size() + 16 * (size_t)leaf0, 0.f);
+  float* P = set.node.data() + 16 * (size_t)m.nodebase;
+  for (int n = 1; n < leaf0; n++)
+    for (int k = 0; k < 8; k++) { P[16 * n + k] = N[8 * (2 * n) + k]; P[16 * n + 8 + k] = N[8 * (2 * n + 1) + k]; }
+  for (int k = 0; k < 8; k++) P[k] = N[8 + k];   // slot 0 (no heap node 0): the root's own box, for hosts that want it
   set.mesh.push_back(m);
 }

@@ -21,7 +21,7 @@ struct DevRender {
   const int* cam_bodyid;           // [ncam]
   const float* cam_pos;            // [ncam][3]
   const float* cam_mat;            // [ncam][9]
-  const float4* node;              // BVH nodes, two float4 per node
+  const float4* node;              // BVH inner nodes, four float4 each: the boxes of both children (smj_bvh.h)
   const float4* tri;               // packed triangles, three float4 per triangle
   const int4* mesh;                // per render mesh: nodebase, tribase, leaf0, ntri
   // 2-D lidar (rangefinder sites on the laser body)

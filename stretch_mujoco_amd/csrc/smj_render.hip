@@ -41,67 +41,79 @@ __device__ __forceinline__ void mul(float* r, const float* m, const float* v) { 
 // nearest hit of the ray o + t d with the mesh, t in [tnear, best); returns the new best.  CULL: front faces only (cameras,
 // GL_CULL_FACE); otherwise both sides ([MJ] mj_rayMesh, lidar)
 template <bool CULL>
+__device__ __forceinline__ float ray_leaf(const float4* T, const float* o, const float* d, float tnear, float best) {
+#pragma unroll
+  for (int k = 0; k < SMJ_BVH_LEAF; k++) {
+    const float4 v0 = T[3 * k], e1 = T[3 * k + 1], e2 = T[3 * k + 2];
+    const float p[3] = {d[1] * e2.z - d[2] * e2.y, d[2] * e2.x - d[0] * e2.z, d[0] * e2.y - d[1] * e2.x};
+    const float det = e1.x * p[0] + e1.y * p[1] + e1.z * p[2];
+    if (CULL ? det > 1e-30f : fabsf(det) > 1e-30f) {
+      const float id = 1.f / det;
+      const float tv[3] = {o[0] - v0.x, o[1] - v0.y, o[2] - v0.z};
+      const float u = (tv[0] * p[0] + tv[1] * p[1] + tv[2] * p[2]) * id;
+      const float q[3] = {tv[1] * e1.z - tv[2] * e1.y, tv[2] * e1.x - tv[0] * e1.z, tv[0] * e1.y - tv[1] * e1.x};
+      const float v = (d[0] * q[0] + d[1] * q[1] + d[2] * q[2]) * id;
+      if (u >= 0.f && v >= 0.f && u + v <= 1.f) {
+        const float t = (e2.x * q[0] + e2.y * q[1] + e2.z * q[2]) * id;
+        if (t >= tnear && t < best) best = t;
+      }
+    }
+  }
+  return best;
+}
+// slab test of one box against the ray, clipped to [tnear, best]; returns the entry distance or -1 (miss / empty box).
+// NaN (0 * inf, a ray lying in a face plane of the box) compares false and reads as a miss of that slab only.
+__device__ __forceinline__ float ray_box(const float4 lo, const float4 hi, const float* o, const float* inv, float tnear, float best) {
+  float t0 = tnear, t1 = best;
+  {
+    const float a = (lo.x - o[0]) * inv[0], b = (hi.x - o[0]) * inv[0];
+    t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));
+  }
+  {
+    const float a = (lo.y - o[1]) * inv[1], b = (hi.y - o[1]) * inv[1];
+    t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));
+  }
+  {
+    const float a = (lo.z - o[2]) * inv[2], b = (hi.z - o[2]) * inv[2];
+    t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));
+  }
+  return (t0 <= t1 && lo.x <= hi.x) ? t0 : -1.f;   // padding boxes are stored inverted: the slab test alone would accept them
+}
+template <bool CULL>
 __device__ float ray_mesh(const DevRender& R, int rmesh, const float* o, const float* d, float tnear, float best) {
   const int4 mi = R.mesh[rmesh];
-  const float4* node = R.node + 2 * (long)mi.x;
+  const float4* node = R.node + 4 * (long)mi.x;
   const float4* tri = R.tri + 3 * (long)mi.y;
   const int leaf0 = mi.z;
-  const float inv[3] = {1.f / d[0], 1.f / d[1], 1.f / d[2]};   // +-inf for axis-parallel rays: the slab test below copes
+  if (leaf0 == 1) return ray_leaf<CULL>(tri, o, d, tnear, best);   // a mesh of one leaf has no inner node
+  const float inv[3] = {1.f / d[0], 1.f / d[1], 1.f / d[2]};   // +-inf for axis-parallel rays: the slab test copes
   // Stack-free walk of the complete tree with a TRAIL register: bit `level` says whether the sibling of the node on the current
-  // path at that level has been visited.  Descending clears the bit; finishing a node either steps to the sibling (bit 0 ->
-  // set it, n ^= 1) or climbs (bit 1 -> n >>= 1) -- index arithmetic only, no node is re-read on the way up.
+  // path at that level still has to be visited (0) or not (1: already visited, or its box was missed when the parent was
+  // tested).  An inner node tests the boxes of both children, stored in the node itself, and enters the nearer hit one first.
   int n = 1, level = 0;
   unsigned trail = 0;
   while (true) {
-    const float4 lo = node[2 * n], hi = node[2 * n + 1];
-    float t0 = tnear, t1 = best;
-    {
-      const float a = (lo.x - o[0]) * inv[0], b = (hi.x - o[0]) * inv[0];
-      t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));
-    }
-    {
-      const float a = (lo.y - o[1]) * inv[1], b = (hi.y - o[1]) * inv[1];
-      t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));
-    }
-    {
-      const float a = (lo.z - o[2]) * inv[2], b = (hi.z - o[2]) * inv[2];
-      t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));
-    }
-    // padding nodes are stored inverted (lo > hi): the slab test alone would accept them.  NaN (0 * inf) compares false:
-    // such a box is skipped only if the ray lies in its face plane
-    const bool hit = t0 <= t1 && lo.x <= hi.x;
-    if (hit && n < leaf0) {      // inner node: nearer child first
-      const int code = (int)lo.w, axis = code & 3;
-      const float da = axis == 0 ? d[0] : (axis == 1 ? d[1] : d[2]);
-      n = 2 * n + (((da >= 0.f) == ((code >> 2) != 0)) ? 1 : 0);
+    // n is an inner node
+    const float4 l0 = node[4 * n], h0 = node[4 * n + 1], l1 = node[4 * n + 2], h1 = node[4 * n + 3];
+    const float e0 = ray_box(l0, h0, o, inv, tnear, best), e1 = ray_box(l1, h1, o, inv, tnear, best);
+    bool down = false;
+    if (e0 >= 0.f || e1 >= 0.f) {
+      const bool both = e0 >= 0.f && e1 >= 0.f;
+      const int first = (e0 >= 0.f && (e1 < 0.f || e0 <= e1)) ? 0 : 1;
+      n = 2 * n + first;
       level++;
-      trail &= ~(1u << level);
-      continue;
+      trail = both ? (trail & ~(1u << level)) : (trail | (1u << level));
+      down = true;
     }
-    if (hit) {
-      const float4* T = tri + 3 * SMJ_BVH_LEAF * (long)(n - leaf0);
-#pragma unroll
-      for (int k = 0; k < SMJ_BVH_LEAF; k++) {
-        const float4 v0 = T[3 * k], e1 = T[3 * k + 1], e2 = T[3 * k + 2];
-        const float p[3] = {d[1] * e2.z - d[2] * e2.y, d[2] * e2.x - d[0] * e2.z, d[0] * e2.y - d[1] * e2.x};
-        const float det = e1.x * p[0] + e1.y * p[1] + e1.z * p[2];
-        if (CULL ? det > 1e-30f : fabsf(det) > 1e-30f) {
-          const float id = 1.f / det;
-          const float tv[3] = {o[0] - v0.x, o[1] - v0.y, o[2] - v0.z};
-          const float u = (tv[0] * p[0] + tv[1] * p[1] + tv[2] * p[2]) * id;
-          const float q[3] = {tv[1] * e1.z - tv[2] * e1.y, tv[2] * e1.x - tv[0] * e1.z, tv[0] * e1.y - tv[1] * e1.x};
-          const float v = (d[0] * q[0] + d[1] * q[1] + d[2] * q[2]) * id;
-          if (u >= 0.f && v >= 0.f && u + v <= 1.f) {
-            const float t = (e2.x * q[0] + e2.y * q[1] + e2.z * q[2]) * id;
-            if (t >= tnear && t < best) best = t;
-          }
-        }
-      }
-    }
-    // next subtree: the sibling if it has not been visited yet, otherwise climb
     while (true) {
+      if (down) {
+        if (n < leaf0) break;   // an inner node: test its children next
+        best = ray_leaf<CULL>(tri + 3 * SMJ_BVH_LEAF * (long)(n - leaf0), o, d, tnear, best);
+        down = false;
+      }
+      // next subtree: the sibling if it is still pending, otherwise climb
       if (level == 0) return best;
-      if (!(trail & (1u << level))) { trail |= 1u << level; n ^= 1; break; }
+      if (!(trail & (1u << level))) { trail |= 1u << level; n ^= 1; down = true; continue; }
       n >>= 1;
       level--;
     }

@@ -32,8 +32,12 @@ static bool box_hit(const float* N, const float* o, const float* d) {
   }
   return t0 <= t1 * (1 + 1e-5f) + 1e-6f;
 }
+// box of heap node n: stored in its parent (child 2p at floats 0..7, child 2p+1 at 8..15); the root's own box sits in slot 0
+static const float* node_box(const SmjBvhSet& s, const SmjBvhMesh& m, int n) {
+  return n == 1 ? &s.node[16 * (size_t)m.nodebase] : &s.node[16 * (size_t)(m.nodebase + n / 2) + 8 * (n & 1)];
+}
 static float walk(const SmjBvhSet& s, const SmjBvhMesh& m, int n, const float* o, const float* d) {
-  const float* N = &s.node[8 * (size_t)(m.nodebase + n)];
+  const float* N = node_box(s, m, n);
   if (!box_hit(N, o, d)) return 3e38f;
   if (n >= m.leaf0) {
     float best = 3e38f, t;
@@ -88,19 +92,18 @@ int main() {
       bool z = true;
       for (int q = 0; q < 12; q++) z &= T[q] == 0.f;
       if (z) continue;
-      const float* N = &s.node[8 * (size_t)(m.nodebase + m.leaf0 + i / SMJ_BVH_LEAF)];
+      const float* N = node_box(s, m, m.leaf0 + i / SMJ_BVH_LEAF);
       for (int q = 0; q < 3; q++) {
         const float a = T[q], b = a + T[4 + q], c = a + T[8 + q];
         if (std::min(a, std::min(b, c)) < N[q] || std::max(a, std::max(b, c)) > N[4 + q]) { printf("triangle outside its leaf box\n"); return 1; }
       }
     }
     for (int n = 2; n < 2 * m.leaf0; n++) {
-      const float* C = &s.node[8 * (size_t)(m.nodebase + n)];
-      const float* P = &s.node[8 * (size_t)(m.nodebase + n / 2)];
+      const float* C = node_box(s, m, n);
+      const float* P = node_box(s, m, n / 2);
       if (C[0] > C[4]) continue;
       for (int q = 0; q < 3; q++) if (C[q] < P[q] || C[4 + q] > P[4 + q]) { printf("child box outside parent\n"); return 1; }
     }
-    for (int n = 1; n < m.leaf0; n++) { const float h = s.node[8 * (size_t)(m.nodebase + n) + 3]; if (h < 0 || h > 7) { printf("order hint\n"); return 1; } }
     // nearest hit through the hierarchy == brute force over all triangles
     for (int r = 0; r < 60; r++) {
       float o[3], d[3];
