@@ -2658,6 +2658,7 @@ struct StepKernel {
         gauss = wave_sum(gs);
       }
       cost += gauss;
+      (void)cost;   // the total cost is not needed: acceptance and termination use derivatives (see the fp32 note below)
       TICK(SMJ_PROF_N_UPDATE)
       // gradient = Ma - g - J'f   (lanes = dofs; force broadcast by readlane)
       matT_J(tmpv, nr0);
