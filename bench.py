@@ -241,9 +241,10 @@ def main():
                          "kernel": "smj_step_kernel", "avg_launch_ms": avg_launch_s * 1e3,
                          "us_per_env_step_latency": avg_launch_s * 1e6 / hold,
                          "note": "algorithmic bytes = 672 B/env-step x envs x steps per launch; the path is "
-                                 "latency-bound (serial tree/Gauss-Seidel chains), HBM does not bind (DESIGN.md)"},
+                                 "bound by the instruction issue of one wavefront per SIMD (8.3 cycles per instruction), HBM does not bind "
+                                 "(DESIGN.md section 4)"},
         }
-        if not args.no_second_solver:
+        if not args.no_second_solver and world == 1:
             other = "pgs" if args.solver == "newton" else "newton"
             sim.set_option("solver", {"pgs": 0, "newton": 2}[other])
             n2 = min(args.steps, 100)
@@ -257,7 +258,7 @@ def main():
             torch.cuda.synchronize(dev)
             out["other_solver"] = {"solver": other, "value": B * n2 / (time.perf_counter() - t1), "unit": "env-steps/s",
                                    "n_gpus": 1, "steps": n2, "note": "rank 0 only, same workload, measured after the timed region"}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the contract: rank 0 at N=1 only
             rng = np.random.default_rng(1234)
             cr = np.asarray(sim.model["actuator_ctrlrange"])
             script = cr[:, 0] + (cr[:, 1] - cr[:, 0]) * rng.random((64, sim.nu))
