@@ -1,54 +1,102 @@
 #!/usr/bin/env python
 """Throughput bench of the batched physics path (contract: see the task's bench.py section).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1 without WORLD_SIZE: re-executes itself under
+                                                               torch.distributed.run, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one physics step (mj_step) of every environment on every rank.  Workload: 4096
-Stretch envs per GPU (weak scaling), stretch.xml + ground plane, home keyframe settled, then synthetic random
-actions drawn uniformly in ctrlrange every 50 steps.  Envs are independent: no data-path collective; RCCL is
-used once at the end to gather per-env returns (and for the barrier / max-over-ranks timing).
+A "step" is one physics step (mj_step) of every environment on every rank.  Workload: Stretch envs,
+stretch.xml + ground plane, home keyframe settled (500 steps), then synthetic random actions drawn uniformly in ctrlrange
+every 50 steps.  Before anything is timed the rollout runs 200 random-action steps so that the timed region is the steady
+state of that workload whatever --warmup / --steps are; the W warm-up steps and the K timed steps continue the same
+50-step action schedule (a launch never spans an action change, so K < 50 simply times a shorter launch).
+--scaling weak (default): 4096 envs per GPU.  --scaling strong: 4096 envs in total (BASELINE.json's metric), split over
+the ranks.  Envs are independent: no data-path collective; RCCL is used once at the end to gather per-env returns (through
+the library's own smj_allgather_returns) and for the barrier / max-over-ranks timing.
 """
 import argparse
 import json
+import multiprocessing as mp
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BYTES_PER_ENV_STEP = 672.0  # physics-only algorithmic state traffic
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FLOPS_PER_ENV_STEP_FILE = os.path.join(ROOT, "profiles", "flops_per_env_step.json")
+HOME_CTRL = [0, 0, 0.6, 0.1, 0, 0, 0, 0, 0, 0]
 
 
-def cpu_baseline(blob: bytes, ctrl_script: np.ndarray, hold: int, seconds: float = 12.0, solver: str = "newton"):
-    """fp64 CPU restatement (oracle, 'port') timed single-threaded on this host on a bounded sample."""
+# ---------------------------------------------------------------------------------------------- CPU baseline
+def _cpu_worker(args):
+    """One oracle process: `seconds` of the bench workload (or its C2 / C3 variants) on one core; returns (steps, seconds)."""
+    blob_path, seed, hold, seconds, solver, sensors = args
     from oracle.oracle import Oracle
 
+    with open(blob_path, "rb") as f:
+        blob = f.read()
     o = Oracle(blob)
     o.set_option("solver", 2 if solver == "newton" else 0)
-    o.arr("ctrl")[:] = [0, 0, 0.6, 0.1, 0, 0, 0, 0, 0, 0]
+    nu = o.dim("nu")
+    o.arr("ctrl")[:nu] = HOME_CTRL[:nu]
     o.step(500)
+    import stretch_mujoco_amd.model_blob as mb
+
+    cr = np.asarray(mb.loads(blob)["actuator_ctrlrange"])
+    rng = np.random.default_rng(seed)
     t0 = time.perf_counter()
     n = 0
-    i = 0
     while time.perf_counter() - t0 < seconds:
-        o.arr("ctrl")[:] = ctrl_script[i % len(ctrl_script)]
-        o.step(hold)
+        o.arr("ctrl")[:nu] = cr[:, 0] + (cr[:, 1] - cr[:, 0]) * rng.random(nu)
+        if sensors:   # C2: what mj_step does with the 360 rangefinders + IMU enabled: sensors evaluated every step
+            for _ in range(hold):
+                o.step(1)
+                o.sensors(True)
+        else:
+            o.step(hold)
         n += hold
-        i += 1
-    dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit="env-steps/s", cores=1, kind="port",
-                sample=f"1 env, {n} steps, {solver} solver, same scene and action schedule "
-                       f"(stand-in fp64 CPU restatement, not MuJoCo)")
+    return n, time.perf_counter() - t0
 
 
+def cpu_baseline(hold: int, seconds: float, solver: str):
+    """BASELINE.md section 3, C1-C4 on the fp64 CPU restatement ('port'; MuJoCo itself is not installable here).
+    `value` is C4, the whole-host aggregate (one independent oracle process per core)."""
+    models = os.path.join(ROOT, "stretch_mujoco_amd", "models")
+    empty = os.path.join(models, "stretch_empty.smjb")
+    scene = os.path.join(models, "stretch_scene.smjb")          # scene.xml equivalent: table + 2 free objects
+    if not os.path.exists(scene):
+        scene = os.path.join(models, "stretch_kitchen_standin.smjb")
+    ncpu = os.cpu_count() or 1
+    ctx = mp.get_context("fork")
+    single = {}
+    with ctx.Pool(3) as pool:   # C1-C3 single-thread rates, measured side by side on three otherwise idle cores
+        r = pool.map(_cpu_worker, [(empty, 1, hold, seconds / 2, solver, False), (empty, 2, hold, seconds / 2, solver, True),
+                                   (scene, 3, hold, seconds / 2, solver, False)])
+    for key, (n, dt) in zip(("C1_empty_sensors_off", "C2_empty_lidar_imu_every_step", "C3_" + os.path.basename(scene)[:-5]), r):
+        single[key] = {"value": n / dt, "unit": "env-steps/s", "steps": n}
+    with ctx.Pool(ncpu) as pool:
+        r = pool.map(_cpu_worker, [(empty, 100 + i, hold, seconds, solver, False) for i in range(ncpu)])
+    total = sum(n / dt for n, dt in r)
+    return dict(value=total, unit="env-steps/s", cores=ncpu, kind="port",
+                sample=f"C4 whole-host aggregate: {ncpu} independent oracle processes (one per core), {seconds:.0f} s each of the bench "
+                       f"workload (1 env, empty scene, random ctrl every {hold} steps, {solver}); {sum(n for n, _ in r)} steps in total. "
+                       f"Stand-in fp64 CPU restatement, NOT MuJoCo.",
+                single_thread=single, host_cpus=ncpu,
+                reference_as_shipped="<= 500 steps/s by construction (realtime sleep, mujoco_server.py:381-384); not measured")
+
+
+# ---------------------------------------------------------------------------------------------- other configs
 def other_configs(B, dev, hold, solver):
     """Short single-GPU runs of the other BASELINE.json configs (reported beside the headline line, never as `value`)."""
+    import torch
+
     from stretch_mujoco_amd import StretchBatchSimulator, StretchSensors
     from stretch_mujoco_amd.enums import StretchCameras
 
@@ -60,31 +108,44 @@ def other_configs(B, dev, hold, solver):
         hi = torch.tensor(sim.model["actuator_ctrlrange"][:, 1], dtype=torch.float32, device=dev).unsqueeze(1)
         sim.ctrl[:] = torch.tensor(sim.model["key_ctrl"][0, : sim.nu], dtype=torch.float32, device=dev).unsqueeze(1)
         sim.step(500)
-        sim.ctrl.copy_(lo + (hi - lo) * torch.rand(sim.nu, B, generator=gen, device=dev))
-        sim.step(chunk)
+        for _ in range(4):   # into the steady state of the random-action rollout
+            sim.ctrl.copy_(lo + (hi - lo) * torch.rand(sim.nu, sim.num_envs, generator=gen, device=dev))
+            sim.step(hold)
         torch.cuda.synchronize(dev)
         t = time.perf_counter()
         d = 0
         while d < n:
             if d % hold == 0:
-                sim.ctrl.copy_(lo + (hi - lo) * torch.rand(sim.nu, B, generator=gen, device=dev))
+                sim.ctrl.copy_(lo + (hi - lo) * torch.rand(sim.nu, sim.num_envs, generator=gen, device=dev))
             sim.step(chunk)
             d += chunk
         torch.cuda.synchronize(dev)
-        return B * d / (time.perf_counter() - t)
+        return sim.num_envs * d / (time.perf_counter() - t)
 
+    def flags_of(sim):
+        f = sim.info[3]
+        return {"overflow_flags": int(torch.bitwise_or(torch.bitwise_or((f & 1).max(), (f & 2).max()), (f & 4).max()).item()),
+                "envs_flagged": float((f != 0).float().mean().item())}
+
+    # config 2: 1024 envs, physics only
+    sim = StretchBatchSimulator(num_envs=1024, device=str(dev), solver=solver)
+    sim.start(home=False)
+    res["config2_1024_envs_physics"] = {"value": rollout(sim, 200, hold), "unit": "env-steps/s"}
+    sim.stop()
     # config 3: + joint readout, IMU, 2-D lidar; at 15 Hz sim-time (every 33 steps) and every step
     sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver=solver, sensors_to_use=StretchSensors.all())
     sim.start(home=False)
     res["lidar_imu_every_33_steps"] = {"value": rollout(sim, 330, 33), "unit": "env-steps/s"}
     res["lidar_imu_every_step"] = {"value": rollout(sim, 50, 1), "unit": "env-steps/s"}
     sim.stop()
-    # config 4 stand-in: 24 static kitchen fixtures around the robot (no free objects), physics only
-    sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver=solver, scene="stretch_kitchen_standin")
-    sim.start(home=False)
-    res["kitchen_standin_physics"] = {"value": rollout(sim, 200, hold), "unit": "env-steps/s",
-                                      "overflow_flags": int(sim.info[3].max().item())}
-    sim.stop()
+    # config 4 stand-in: static kitchen fixtures around the robot + free objects, physics only
+    for scene in ("stretch_kitchen_standin", "stretch_kitchen4", "stretch_scene"):
+        if not os.path.exists(os.path.join(ROOT, "stretch_mujoco_amd", "models", scene + ".smjb")):
+            continue
+        sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver=solver, scene=scene)
+        sim.start(home=False)
+        res[scene + "_physics"] = {"value": rollout(sim, 200, hold), "unit": "env-steps/s", **flags_of(sim)}
+        sim.stop()
     # config 5 ingredient: both depth cameras, kitchen stand-in, rendered from the poses of the last step
     sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver=solver, scene="stretch_kitchen_standin",
                                 cameras_to_use=StretchCameras.depth())
@@ -99,6 +160,7 @@ def other_configs(B, dev, hold, solver):
     dt = (time.perf_counter() - t) / 3
     rays = B * (270 * 480 + 240 * 424)
     res["depth_both_cameras"] = {"ms_per_render": dt * 1e3, "rays_per_s": rays / dt, "bytes_written_per_s": 4 * rays / dt,
+                                 "hbm_frac": 4 * rays / dt / 1e9 / HBM_PEAK_GBS,
                                  "note": "d405 270x480 + d435i 240x424 per env, kitchen stand-in; at 30 Hz sim-time one render per 17 steps"}
     # config 5 shape on one GPU: kitchen stand-in, both depth cameras every 17 steps (30 Hz sim-time), physics in between
     torch.cuda.synchronize(dev)
@@ -115,13 +177,23 @@ def other_configs(B, dev, hold, solver):
     return res
 
 
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--envs-per-gpu", type=int, default=4096)
-    ap.add_argument("--hold", type=int, default=50, help="physics steps per launch / per random action")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --envs per GPU; strong: --envs in total (BASELINE.json: 4096 envs at 1/2/4/8 GPUs)")
+    ap.add_argument("--envs", "--envs-per-gpu", dest="envs", type=int, default=4096)
+    ap.add_argument("--hold", type=int, default=50, help="physics steps per random action (and per launch)")
     ap.add_argument("--solver", choices=["newton", "pgs"], default="newton",
                     help="newton = the reference model's own solver (stretch.xml names none -> MuJoCo default); "
                          "pgs = the solver named by BASELINE.json north_star")
@@ -131,9 +203,23 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, RCCL rendezvous on 127.0.0.1)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+
+    import torch
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(torch.distributed.run --nproc-per-node {args.gpus}) or drop WORLD_SIZE")
+    if torch.cuda.device_count() < max(1, local_rank + 1):
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, this host exposes {torch.cuda.device_count()}")
     dist_on = world > 1
     if dist_on:
         import torch.distributed as dist
@@ -144,9 +230,14 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from stretch_mujoco_amd import StretchBatchSimulator
-    from stretch_mujoco_amd.parallel import gather_returns
+    from stretch_mujoco_amd import parallel
 
-    B = args.envs_per_gpu
+    if args.scaling == "strong":
+        lo_e, hi_e = parallel.shard_range(args.envs, rank, world)
+        B = hi_e - lo_e
+    else:
+        B = args.envs
+    B_total = args.envs if args.scaling == "strong" else args.envs * world
     sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver=args.solver)
     sim.start(home=False)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -156,27 +247,37 @@ def main():
     def random_action():
         sim.ctrl.copy_(lo + (hi - lo) * torch.rand(sim.nu, B, generator=gen, device=dev))
 
-    # settle at the home keyframe
-    sim.ctrl[:] = torch.tensor(sim.model["key_ctrl"][0, : sim.nu], dtype=torch.float32, device=dev).unsqueeze(1)
     hold = max(1, args.hold)
     all_events = []   # every smj_step_kernel launch of this process (what `rocprofv3 --stats` averages over)
+    phase = [0]       # steps since the last action change
 
-    def timed_step(k):
+    def timed_step(k, tag):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         sim.step(k)
         e1.record()
-        all_events.append((e0, e1, k))
+        all_events.append((e0, e1, k, tag))
         return e0, e1
 
+    def rollout(nsteps, tag, on_launch=None):
+        """nsteps of the random-action schedule, continuing it: a new action whenever `hold` steps have passed."""
+        done = 0
+        while done < nsteps:
+            if phase[0] == 0:
+                random_action()
+            k = min(hold - phase[0], nsteps - done)
+            ev = timed_step(k, tag)
+            if on_launch:
+                on_launch(ev, k)
+            phase[0] = (phase[0] + k) % hold
+            done += k
+
+    # settle at the home keyframe (SURVEY.md 8(d)), then into the steady state of the random-action rollout
+    sim.ctrl[:] = torch.tensor(sim.model["key_ctrl"][0, : sim.nu], dtype=torch.float32, device=dev).unsqueeze(1)
     for _ in range(500 // hold):
-        timed_step(hold)
-    done = 0
-    while done < args.warmup:
-        k = min(hold, args.warmup - done)
-        random_action()
-        timed_step(k)
-        done += k
+        timed_step(hold, "settle")
+    rollout(max(200, 4 * hold), "preroll")
+    rollout(args.warmup, "warmup")
     returns = torch.zeros(B, device=dev)
     events = []
 
@@ -186,64 +287,70 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def on_launch(ev, k):
+        events.append((ev[0], ev[1], k))
+        returns.add_(sim.base_pose[0])   # synthetic per-env return: accumulated forward displacement
+
     barrier()
     t0 = time.perf_counter()
-    done = 0
-    while done < args.steps:
-        k = min(hold, args.steps - done)
-        random_action()
-        e0, e1 = timed_step(k)
-        events.append((e0, e1, k))
-        returns += sim.base_pose[0]  # synthetic per-env return: accumulated forward displacement
-        done += k
+    rollout(args.steps, "timed", on_launch)
     barrier()
     dt = time.perf_counter() - t0
     if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    all_returns = gather_returns(returns)  # RCCL all-gather of per-env returns (the only collective)
-    flags = int(sim.info[3].max().item())
-    flagged = float((sim.info[3] != 0).float().mean().item())   # envs in which some step since reset exceeded the 80-row / 16-contact capacity (flags are sticky until reset)
+    all_returns, gather_path = parallel.gather_returns_native(sim, returns)   # RCCL all-gather of per-env returns (the only collective)
+    f = sim.info[3]
+    flags = int(((f & 1).max() | (f & 2).max() | (f & 4).max()).item())   # union of the sticky overflow / bad-state bits
+    flagged = float((f != 0).float().mean().item())
     kern_ms = sum(a.elapsed_time(b) for a, b, _ in events)
     kern_steps = sum(k for _, _, k in events)
-    total_env_steps = float(B) * world * args.steps
+    total_env_steps = float(B_total) * args.steps
     value = total_env_steps / dt
     if rank == 0:
-        per_launch_envsteps = B * hold
-        avg_launch_s = (kern_ms / 1e3) / max(1, len(events))
-        achieved = per_launch_envsteps * BYTES_PER_ENV_STEP / avg_launch_s / 1e9
-        all_ms = [a.elapsed_time(b) for a, b, _ in all_events][1:]   # the first launch also pays the one-time code-object load
+        # roofline of the dominant kernel: algorithmic bytes of the timed launches / their summed duration (HIP events on the
+        # launch stream), i.e. 672 B x envs x steps-per-launch / average launch duration
+        achieved = B * kern_steps * BYTES_PER_ENV_STEP / (kern_ms / 1e3) / 1e9
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path):   # HBM bytes per launch measured with rocprofv3 --pmc on this same command
-            with open(pmc_path) as f:
-                pm = json.load(f)
+        if os.path.exists(pmc_path):   # HBM bytes per 50-step launch measured with rocprofv3 --pmc on this same command
+            with open(pmc_path) as fh:
+                pm = json.load(fh)
             if pm.get("envs_per_gpu") == B and pm.get("steps_per_launch") == hold and pm.get("solver") == args.solver:
                 traffic = pm["hbm_bytes_per_launch"]
+        flops = None
+        if os.path.exists(FLOPS_PER_ENV_STEP_FILE):
+            with open(FLOPS_PER_ENV_STEP_FILE) as fh:
+                flops = json.load(fh)
+        launches = [{"tag": tag, "steps": k, "ms": round(a.elapsed_time(b), 3)} for a, b, k, tag in all_events]
         out = {
-            "metric": "env-steps/sec (whole node), 4096 parallel Stretch envs per MI355X",
+            "metric": "env-steps/sec (whole node), 4096 parallel Stretch envs" + (" per MI355X" if args.scaling == "weak" else " in total"),
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{B} parallel Stretch envs per GPU, stretch.xml + ground plane (empty scene), "
-                                   f"physics-only, random ctrl in ctrlrange every {hold} steps, {args.solver} solver "
+            "config": {"workload": f"{B_total} parallel Stretch envs ({B} per GPU), stretch.xml + ground plane (empty scene), "
+                                   f"physics-only, random ctrl in ctrlrange every {hold} steps (steady state: 500 settle + 200 "
+                                   f"untimed random-action steps precede warm-up), {args.solver} solver "
                                    f"(iterations<=100, tol 1e-8), elliptic cones impratio 20, implicitfast, dt=0.002",
-                       "solver": args.solver,
-                       "envs_per_gpu": B, "steps_per_launch": hold, "parallelism": f"env-sharded x{world}",
-                       "returns_gathered": int(all_returns.numel()), "overflow_flags": flags,
-                       "envs_over_capacity_since_reset": flagged},
+                       "solver": args.solver, "envs_total": B_total,
+                       "envs_per_gpu": B, "steps_per_action": hold, "parallelism": f"env-sharded x{world}",
+                       "returns_gathered": int(all_returns.numel()), "returns_gather_path": gather_path,
+                       "overflow_flags": flags, "envs_over_capacity_since_reset": flagged},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "all_launches": {"count": len(all_ms), "avg_ms": sum(all_ms) / len(all_ms), "ms": [round(x, 2) for x in all_ms],
-                                          "note": "settle + warmup + timed launches except the very first (code-object load): the population "
-                                                  "rocprofv3 --stats averages (profiles/r01_rocprof_summary.md)"},
-                         "kernel": "smj_step_kernel", "avg_launch_ms": avg_launch_s * 1e3,
-                         "us_per_env_step_latency": avg_launch_s * 1e6 / hold,
-                         "note": "algorithmic bytes = 672 B/env-step x envs x steps per launch; the path is "
-                                 "bound by the instruction issue of one wavefront per SIMD (8.3 cycles per instruction), HBM does not bind "
-                                 "(DESIGN.md section 4)"},
+                         "kernel": "smj_step_kernel", "timed_launches": len(events), "timed_kernel_ms": kern_ms,
+                         "kernel_ms_per_step": kern_ms / max(1, kern_steps),
+                         "us_per_env_step_latency": kern_ms * 1e3 / max(1, kern_steps),
+                         "launches": launches,
+                         "note": "achieved = 672 B/env-step x envs x steps of the timed launches / their summed duration (HIP events); "
+                                 "`traffic` = HBM bytes per 50-step launch from the rocprofv3 --pmc passes of this command (profiles/); "
+                                 "the path is bound by the instruction issue of one wavefront per SIMD, HBM does not bind (DESIGN.md section 4)"},
         }
+        if flops:
+            fl = flops.get("flops_per_env_step")
+            out["roofline"]["fp32"] = {"flops_per_env_step": fl, "achieved_tflops": fl * B * kern_steps / (kern_ms / 1e3) / 1e12,
+                                       "peak_tflops": 157.3, "source": flops.get("source")}
         if not args.no_second_solver and world == 1:
             other = "pgs" if args.solver == "newton" else "newton"
             sim.set_option("solver", {"pgs": 0, "newton": 2}[other])
@@ -258,17 +365,13 @@ def main():
             torch.cuda.synchronize(dev)
             out["other_solver"] = {"solver": other, "value": B * n2 / (time.perf_counter() - t1), "unit": "env-steps/s",
                                    "n_gpus": 1, "steps": n2, "note": "rank 0 only, same workload, measured after the timed region"}
-        if not args.no_cpu_baseline and world == 1:   # the contract: rank 0 at N=1 only
-            rng = np.random.default_rng(1234)
-            cr = np.asarray(sim.model["actuator_ctrlrange"])
-            script = cr[:, 0] + (cr[:, 1] - cr[:, 0]) * rng.random((64, sim.nu))
-            out["cpu_baseline"] = cpu_baseline(sim._blob, script, hold, args.cpu_seconds, args.solver)
-            out["cpu_baseline"]["host_cpus"] = os.cpu_count()
         import __graft_entry__ as _ge
         out["parity_oracle"] = _ge.mujoco_status()
         if not args.no_extra and world == 1:
             sim.stop()
             out["other_configs"] = other_configs(B, dev, hold, args.solver)
+        if not args.no_cpu_baseline and world == 1:   # the contract: rank 0 at N=1 only
+            out["cpu_baseline"] = cpu_baseline(hold, args.cpu_seconds, args.solver)
         print(json.dumps(out))
     sim.stop()
     if dist_on:

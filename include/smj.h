@@ -37,7 +37,11 @@ enum smj_slot {
   SMJ_SLOT_XPOSE = 14,    /* [nbody*12][B] world pose (xpos 3 + xmat 9, row major) of every fused body at the last step:
                              what Renderer.update_scene reads from MjData (mujoco_server_camera_manager.py:135); input of
                              smj_render_depth                                                                            */
-  SMJ_SLOT_COUNT = 15
+  SMJ_SLOT_BASECTL = 15,  /* [8][B] optional: relative base move in flight, per env (BaseController, mujoco_server.py:93-176): row 0 mode
+                             (0 none, 1 translate-by, 2 rotate-by, 3 velocity), rows 1-3 start pose x, y, theta, row 4 increment,
+                             rows 5-6 v, omega.  Written by the host when a base command is pushed (push_command, :541,:566-568);
+                             smj_step runs BaseController.update() inside the kernel after every physics step */
+  SMJ_SLOT_COUNT = 16
 };
 
 enum smj_dim {
@@ -67,9 +71,17 @@ int smj_dims(const smj_ctx* ctx, int* out /* SMJ_DIM_COUNT ints */);
 int smj_reset(smj_ctx* ctx, const uint8_t* mask_dev, void* stream);
 
 /* `nsteps` x mj_step (mujoco_server.py:378) for every env with ctrl held constant, one wavefront per env.
- * On return (stream order) the bound ACT_LENGTH / ACT_VELOCITY / BASE_POSE hold the post-step readout and,
- * if requested in read_flags, GYRO/ACCEL (+ LIDAR) hold the sensor values of the last step. */
+ * On return (stream order) the bound ACT_LENGTH / ACT_VELOCITY / BASE_POSE hold what MjData holds after the last mj_step --
+ * the values of its forward pass, one step behind qpos, exactly what pull_status reads (mujoco_server.py:465-515) -- and,
+ * if requested in read_flags, GYRO/ACCEL (+ LIDAR) hold the sensor values of the last step.  With BASECTL bound the relative
+ * base moves advance inside the launch (BaseController.update after every step) and CTRL's wheel entries are written back. */
 int smj_step(smj_ctx* ctx, int nsteps, unsigned read_flags, void* stream);
+
+/* One BaseController.update() (mujoco_server.py:110-122) on the bound arrays: reads BASE_POSE and BASECTL, writes the wheel
+ * entries of CTRL and the controller mode.  smj_step does this after every physics step inside the kernel; this entry runs
+ * the same arithmetic once, for the tick that follows a freshly pushed command and for the parity tests (golden sequences
+ * of the reference's controller on scripted poses). */
+int smj_base_controller_tick(smj_ctx* ctx, void* stream);
 
 /* Solver / collision options (mjOption fields): "iterations", "tolerance", "warmstart", "pgs_fixed_iter",
  * "max_contacts_per_pair". */
@@ -85,6 +97,18 @@ int smj_set_option(smj_ctx* ctx, const char* name, double value);
  * (mujoco_server_camera_manager.py:185-215). */
 int smj_render_depth(smj_ctx* ctx, int camera_id, int width, int height, float fovy_deg, float max_depth, void* out_dev,
                      void* stream);
+
+/* Multi-GPU: envs shard across one process per GPU with no exchange while stepping -- the reference itself is
+ * one env per process with no coupling (stretch_mujoco_simulator.py:102-118).  The only collective of the path gathers the
+ * per-env returns of all ranks, rank-major, with RCCL (ncclAllGather over xGMI), issued on the caller's stream.
+ * smj_comm_init joins this context to a communicator of `world` ranks: rank 0 creates the ncclUniqueId and publishes it
+ * atomically in the file `id_path` (a path all ranks of the node can read, unique per job); the other ranks wait for it up to
+ * `timeout_s` seconds.  librccl is bound at run time (dlopen; a copy already mapped by PyTorch is reused), so a single-GPU
+ * process never loads it.  Without smj_comm_init (or with world == 1) smj_allgather_returns is a device copy. */
+int smj_comm_init(smj_ctx* ctx, int rank, int world, const char* id_path, double timeout_s);
+int smj_allgather_returns(smj_ctx* ctx, const float* send_dev /* [count] */, float* recv_dev /* [world*count] */, int count,
+                          void* stream);
+int smj_comm_destroy(smj_ctx* ctx);
 
 const char* smj_last_error(const smj_ctx* ctx);
 const char* smj_version(void);

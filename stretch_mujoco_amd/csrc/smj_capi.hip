@@ -1,6 +1,11 @@
 // C-ABI (include/smj.h) of the batched Stretch physics path for gfx950.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 #include <stdarg.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -21,6 +26,7 @@ struct smj_ctx {
   std::vector<void*> allocs;
   std::string err;
   float* qpos0_dev = nullptr;
+  float* stage = nullptr;      // env-major staging copy of the state, [num_envs][SMJ_ST_STRIDE] (DevState::stage)
   DevRender render{};
   bool has_render = false;
   float* pose_ws = nullptr;
@@ -31,7 +37,42 @@ struct smj_ctx {
   float* depth_ws = nullptr;   // scratch of the depth renderer's per-env staging pass (allocated at the first render)   // internal [nbody*12][num_envs] body poses when the caller has not bound SMJ_SLOT_XPOSE
   void* slot_ptr[SMJ_SLOT_COUNT] = {};
   long slot_ld[SMJ_SLOT_COUNT] = {};
+  // RCCL communicator of the env-sharded job (smj_comm_init); null in a single-GPU run
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
 };
+
+// RCCL is bound at run time (dlopen): a single-GPU user never loads it, and inside a PyTorch process the copy PyTorch has
+// already mapped is reused instead of a second one.
+struct RcclApi {
+  void* h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi* rccl_api(std::string& err) {
+  static RcclApi api;
+  if (api.h) return &api;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names)
+    if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+  for (int i = 0; !h && i < 3; i++) h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+  if (!h) { err = std::string("librccl not found: ") + dlerror(); return nullptr; }
+  api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+  api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
+  api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
+  api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+  api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+  if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy || !api.GetErrorString) {
+    err = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy";
+    return nullptr;
+  }
+  api.h = h;
+  return &api;
+}
 
 static int fail(smj_ctx* c, int code, const char* fmt, ...) {
   char buf[512];
@@ -172,11 +213,92 @@ int smj_create(const void* blob, size_t nbytes, int num_envs, int device, smj_ct
   c->qpos0_dev = const_cast<float*>(m.qpos0);
   c->state.B = num_envs;
   c->state.ld = num_envs;
+  {
+    void* d = nullptr;
+    const size_t bytes = sizeof(float) * (size_t)SMJ_ST_STRIDE * (size_t)num_envs;
+    HIPCHK(c, hipMalloc(&d, bytes));
+    c->allocs.push_back(d);
+    HIPCHK(c, hipMemset(d, 0, bytes));
+    c->stage = (float*)d;
+  }
   return setup_render(c, blob, nbytes);
+}
+
+int smj_comm_init(smj_ctx* c, int rank, int world, const char* id_path, double timeout_s) {
+  if (!c) return -1;
+  if (world < 1 || rank < 0 || rank >= world) return fail(c, -1, "bad rank %d / world %d", rank, world);
+  if (c->comm) return fail(c, -1, "communicator already initialised");
+  if (world > 1 && (!id_path || !*id_path)) return fail(c, -1, "id_path is required for world > 1");
+  RcclApi* R = rccl_api(c->err);
+  if (!R) return -7;
+  HIPCHK(c, hipSetDevice(c->device));
+  ncclUniqueId id;
+  memset(&id, 0, sizeof id);
+  if (rank == 0) {
+    ncclResult_t r = R->GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(c, -7, "ncclGetUniqueId: %s", R->GetErrorString(r));
+    if (world > 1) {   // publish atomically: write a temporary, then rename
+      std::string tmp = std::string(id_path) + ".tmp";
+      FILE* f = fopen(tmp.c_str(), "wb");
+      if (!f || fwrite(&id, sizeof id, 1, f) != 1) { if (f) fclose(f); return fail(c, -7, "cannot write %s", tmp.c_str()); }
+      fclose(f);
+      if (rename(tmp.c_str(), id_path) != 0) return fail(c, -7, "cannot publish %s", id_path);
+    }
+  } else {
+    const double t_end = (timeout_s > 0 ? timeout_s : 120.0);
+    double waited = 0;
+    for (;;) {
+      FILE* f = fopen(id_path, "rb");
+      if (f) {
+        const size_t n = fread(&id, 1, sizeof id, f);
+        fclose(f);
+        if (n == sizeof id) break;
+      }
+      if (waited >= t_end) return fail(c, -7, "timed out waiting for the RCCL id file %s", id_path);
+      struct timespec ts = {0, 20 * 1000 * 1000};
+      nanosleep(&ts, nullptr);
+      waited += 0.02;
+    }
+  }
+  ncclResult_t r = R->CommInitRank(&c->comm, world, id, rank);
+  if (r != ncclSuccess) { c->comm = nullptr; return fail(c, -7, "ncclCommInitRank: %s", R->GetErrorString(r)); }
+  c->comm_rank = rank;
+  c->comm_world = world;
+  return 0;
+}
+
+int smj_allgather_returns(smj_ctx* c, const float* send_dev, float* recv_dev, int count, void* stream) {
+  if (!c) return -1;
+  if (!send_dev || !recv_dev || count <= 0) return fail(c, -1, "bad buffers / count");
+  if (!c->comm) {   // single-GPU job: the gather is a copy
+    HIPCHK(c, hipSetDevice(c->device));
+    if (send_dev != recv_dev)
+      HIPCHK(c, hipMemcpyAsync(recv_dev, send_dev, sizeof(float) * (size_t)count, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+  }
+  RcclApi* R = rccl_api(c->err);
+  if (!R) return -7;
+  HIPCHK(c, hipSetDevice(c->device));
+  ncclResult_t r = R->AllGather(send_dev, recv_dev, (size_t)count, ncclFloat, c->comm, (hipStream_t)stream);
+  if (r != ncclSuccess) return fail(c, -7, "ncclAllGather: %s", R->GetErrorString(r));
+  return 0;
+}
+
+int smj_comm_destroy(smj_ctx* c) {
+  if (!c) return -1;
+  if (c->comm) {
+    RcclApi* R = rccl_api(c->err);
+    if (R) R->CommDestroy(c->comm);
+    c->comm = nullptr;
+    c->comm_world = 1;
+    c->comm_rank = 0;
+  }
+  return 0;
 }
 
 int smj_destroy(smj_ctx* c) {
   if (!c) return -1;
+  smj_comm_destroy(c);
   for (void* p : c->allocs) (void)hipFree(p);
   delete c;
   return 0;
@@ -214,6 +336,7 @@ int smj_bind(smj_ctx* c, int slot, void* p, long ld) {
     case SMJ_SLOT_DEBUG: s.debug = (float*)p; break;
     case SMJ_SLOT_PROF: s.prof = (float*)p; break;
     case SMJ_SLOT_XPOSE: s.xpose = (float*)p; break;
+    case SMJ_SLOT_BASECTL: s.bctl = (float*)p; break;
   }
   return 0;
 }
@@ -228,7 +351,7 @@ static int check_bound(smj_ctx* c) {
     if (ld < 0) ld = c->slot_ld[s];
     if (c->slot_ld[s] != ld) return fail(c, -5, "all batch-major slots must share one leading dimension");
   }
-  for (int s : {SMJ_SLOT_GYRO, SMJ_SLOT_ACCEL, SMJ_SLOT_LIDAR, SMJ_SLOT_DEBUG, SMJ_SLOT_PROF, SMJ_SLOT_XPOSE})
+  for (int s : {SMJ_SLOT_GYRO, SMJ_SLOT_ACCEL, SMJ_SLOT_LIDAR, SMJ_SLOT_DEBUG, SMJ_SLOT_PROF, SMJ_SLOT_XPOSE, SMJ_SLOT_BASECTL})
     if (c->slot_ptr[s] && c->slot_ld[s] != ld) return fail(c, -5, "slot %d: leading dimension differs", s);
   c->state.ld = ld;
   return 0;
@@ -272,12 +395,36 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
     }
     read_flags |= SMJ_READ_POSES;
   }
+  // batch-major slots -> env-major staging rows, the step kernel on contiguous rows, and back (smj_model.h, DevState::stage)
+  const DevModel& m = c->model;
+  StagePlan in, out;
+  in.add(st.qpos, m.nq, SMJ_ST_QPOS); in.add(st.qvel, m.nv, SMJ_ST_QVEL); in.add(st.warm, m.nv, SMJ_ST_WARM);
+  in.add(st.ctrl, m.nu, SMJ_ST_CTRL); in.add(st.bctl, SMJ_BC_ROWS, SMJ_ST_BCTL); in.add(st.nstep, 1, SMJ_ST_NSTEP);
+  in.add(st.info, 4, SMJ_ST_INFO);
+  out = in;
+  out.add(st.act_len, m.nu, SMJ_ST_ACTLEN); out.add(st.act_vel, m.nu, SMJ_ST_ACTVEL); out.add(st.base, 3, SMJ_ST_BASE);
+  if (read_flags & SMJ_READ_IMU) { out.add(st.gyro, 3, SMJ_ST_GYRO); out.add(st.accel, 3, SMJ_ST_ACCEL); }
+  if (read_flags & SMJ_READ_POSES) out.add(st.xpose, 12 * m.nbody, SMJ_ST_XPOSE);
+  st.stage = c->stage;
+  smj_launch_stage(in, c->stage, c->num_envs, st.ld, false, (hipStream_t)stream);
   smj_launch_step(c->model, st, nsteps, read_flags, (hipStream_t)stream);
+  smj_launch_stage(out, c->stage, c->num_envs, st.ld, true, (hipStream_t)stream);
   HIPCHK(c, hipGetLastError());
   if (read_flags & SMJ_READ_LIDAR) {
     smj_launch_lidar(c->render, st.xpose, pose_ld, c->num_envs, st.lidar, st.ld, (hipStream_t)stream);
     HIPCHK(c, hipGetLastError());
   }
+  return 0;
+}
+
+int smj_base_controller_tick(smj_ctx* c, void* stream) {
+  if (!c) return -1;
+  int rc = check_bound(c);
+  if (rc) return rc;
+  if (!c->state.bctl) return fail(c, -5, "BASECTL slot is not bound");
+  HIPCHK(c, hipSetDevice(c->device));
+  smj_launch_base_tick(c->state, (hipStream_t)stream);
+  HIPCHK(c, hipGetLastError());
   return 0;
 }
 

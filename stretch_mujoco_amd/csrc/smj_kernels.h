@@ -5,5 +5,14 @@
 
 #include "smj_model.h"
 
+// One batch-major array [rows][ld] (4-byte words) <-> words off..off+rows of every env's staging row
+struct StageSeg { void* ptr; int rows, off; };
+struct StagePlan { StageSeg seg[16]; int nseg = 0; void add(void* p, int rows, int off) { if (p && rows > 0) seg[nseg++] = StageSeg{p, rows, off}; } };
+
 void smj_launch_step(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);
 void smj_launch_reset(const DevModel& m, const DevState& s, const uint8_t* mask, hipStream_t stream);
+// batch-major -> env-major staging rows (import) and back (export); tiles of 64 envs transposed through LDS
+void smj_launch_stage(const StagePlan& plan, float* stage, int B, long ld, bool is_export, hipStream_t stream);
+// one BaseController.update() on the bound BASE_POSE / BASECTL / CTRL arrays (lane = env); the same device function the
+// step kernel runs after every step
+void smj_launch_base_tick(const DevState& s, hipStream_t stream);

@@ -22,10 +22,72 @@ __global__ __launch_bounds__(256) void smj_reset_kernel(const DevModel M, const 
   for (int k = 0; k < M.nq; k++) S.qpos[k * S.ld + e] = M.qpos0[k];
   for (int k = 0; k < M.nv; k++) { S.qvel[k * S.ld + e] = 0.f; S.warm[k * S.ld + e] = 0.f; }
   for (int k = 0; k < M.nu; k++) S.ctrl[k * S.ld + e] = 0.f;
+  if (S.bctl)
+    for (int k = 0; k < SMJ_BC_ROWS; k++) S.bctl[k * S.ld + e] = 0.f;
   S.nstep[e] = 0;
   for (int k = 0; k < 4; k++) S.info[k * S.ld + e] = 0;
 }
 
+// Staging transposes.  A block moves 64 envs: rows of the batch-major array are read / written with lanes = envs (256-byte
+// coalesced runs), the env-major rows with lanes = consecutive words; the tile turns in LDS (row stride 65: conflict-free).
+__global__ __launch_bounds__(256) void smj_stage_kernel(const StagePlan P, float* stage, int B, long ld, int is_export) {
+  __shared__ float tile[128][65];
+  const int t = threadIdx.x, w = t >> 6, l = t & 63, env0 = blockIdx.x * 64;
+  for (int sg = 0; sg < P.nseg; sg++) {
+    float* arr = static_cast<float*>(P.seg[sg].ptr);
+    const int rows = P.seg[sg].rows, off = P.seg[sg].off;
+    for (int r0 = 0; r0 < rows; r0 += 128) {
+      const int nr = rows - r0 < 128 ? rows - r0 : 128;
+      if (!is_export) {
+        for (int k = w; k < nr; k += 4) tile[k][l] = env0 + l < B ? arr[(long)(r0 + k) * ld + env0 + l] : 0.f;
+        __syncthreads();
+        for (int idx = t; idx < 64 * nr; idx += 256) {
+          const int e = idx / nr, k = idx - e * nr;
+          if (env0 + e < B) stage[(size_t)(env0 + e) * SMJ_ST_STRIDE + off + r0 + k] = tile[k][e];
+        }
+      } else {
+        for (int idx = t; idx < 64 * nr; idx += 256) {
+          const int e = idx / nr, k = idx - e * nr;
+          if (env0 + e < B) tile[k][e] = stage[(size_t)(env0 + e) * SMJ_ST_STRIDE + off + r0 + k];
+        }
+        __syncthreads();
+        for (int k = w; k < nr; k += 4)
+          if (env0 + l < B) arr[(long)(r0 + k) * ld + env0 + l] = tile[k][l];
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// BaseController.update() for every env on the bound arrays (lane = env): same arithmetic as StepKernel::base_controller
+__global__ __launch_bounds__(256) void smj_base_tick_kernel(const DevState S) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= S.B || !S.bctl) return;
+  const long ld = S.ld;
+  const int mode = (int)S.bctl[SMJ_BC_MODE * ld + e];
+  if (mode == 0) return;
+  const float x = S.base[e], y = S.base[ld + e], th = S.base[2 * ld + e];
+  const float inc = S.bctl[SMJ_BC_INC * ld + e], sign = inc > 0.f ? 1.f : -1.f;
+  float v = 0.f, w = 0.f;
+  int next = mode;
+  if (mode == 1) {
+    const float dx = x - S.bctl[SMJ_BC_X0 * ld + e], dy = y - S.bctl[SMJ_BC_Y0 * ld + e];
+    if (!(sqrtf(dx * dx + dy * dy) <= fabsf(inc))) next = 0; else v = SMJ_BASE_X_VEL * sign;
+  } else if (mode == 2) {
+    if (!(fabsf(S.bctl[SMJ_BC_TH0 * ld + e] - th) <= fabsf(inc))) next = 0; else w = SMJ_BASE_R_VEL * sign;
+  } else { v = S.bctl[SMJ_BC_V * ld + e]; w = S.bctl[SMJ_BC_W * ld + e]; }
+  S.ctrl[e] = (v - (w * SMJ_WHEEL_SEPARATION / 2.f)) / SMJ_WHEEL_RADIUS;
+  S.ctrl[ld + e] = (v + (w * SMJ_WHEEL_SEPARATION / 2.f)) / SMJ_WHEEL_RADIUS;
+  S.bctl[SMJ_BC_MODE * ld + e] = (float)next;
+}
+
+void smj_launch_stage(const StagePlan& plan, float* stage, int B, long ld, bool is_export, hipStream_t stream) {
+  if (plan.nseg == 0) return;
+  hipLaunchKernelGGL(smj_stage_kernel, dim3((B + 63) / 64), dim3(256), 0, stream, plan, stage, B, ld, is_export ? 1 : 0);
+}
+void smj_launch_base_tick(const DevState& s, hipStream_t stream) {
+  hipLaunchKernelGGL(smj_base_tick_kernel, dim3((s.B + 255) / 256), dim3(256), 0, stream, s);
+}
 void smj_launch_step(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream) {
   hipLaunchKernelGGL(smj_step_kernel, dim3(s.B), dim3(64), smj_lds_bytes(m.solver != 2), stream, m, s, nsteps, read_flags);
 }

@@ -97,7 +97,28 @@ struct DevState {
   float* debug;    // [SMJ_DEBUG_FLOATS][B] or null: stage dumps for parity tests
   float* prof;     // [SMJ_PROF_SLOTS][B] or null: shader cycles per stage, summed over the launch
   float* xpose;    // [nbody*12][B] or null: world pose (xpos 3, xmat 9) of every fused body at the last step (depth cameras)
+  float* bctl;     // [8][B] or null: per-env state of the relative base moves (BaseController, mujoco_server.py:93-176), SMJ_BC_*
+  // Env-major staging copy of the state, [B][SMJ_ST_STRIDE] words, owned by the library (null: the step kernel reads / writes
+  // the batch-major arrays directly -- the lane emulator does).  One env per wavefront means lane = dim: on the batch-major
+  // arrays every lane of a load / store touches its own 64-byte sector.  smj_step therefore runs import (batch-major ->
+  // env-major, tiles transposed through LDS, both sides coalesced), the step kernel on contiguous 512-byte rows, export.
+  float* stage;
 };
+// BaseController state rows (floats; mode: 0 none, 1 translate-by, 2 rotate-by, 3 velocity)
+enum { SMJ_BC_MODE = 0, SMJ_BC_X0, SMJ_BC_Y0, SMJ_BC_TH0, SMJ_BC_INC, SMJ_BC_V, SMJ_BC_W, SMJ_BC_ROWS = 8 };
+// layout of one env's staging row (4-byte words)
+enum {
+  SMJ_ST_QPOS = 0, SMJ_ST_QVEL = SMJ_ST_QPOS + NVP + 8, SMJ_ST_WARM = SMJ_ST_QVEL + NVP, SMJ_ST_CTRL = SMJ_ST_WARM + NVP,
+  SMJ_ST_BCTL = SMJ_ST_CTRL + 16, SMJ_ST_NSTEP = SMJ_ST_BCTL + 8, SMJ_ST_INFO = SMJ_ST_NSTEP + 4, SMJ_ST_ACTLEN = SMJ_ST_INFO + 4,
+  SMJ_ST_ACTVEL = SMJ_ST_ACTLEN + 16, SMJ_ST_BASE = SMJ_ST_ACTVEL + 16, SMJ_ST_GYRO = SMJ_ST_BASE + 4, SMJ_ST_ACCEL = SMJ_ST_GYRO + 4,
+  SMJ_ST_XPOSE = SMJ_ST_ACCEL + 4, SMJ_ST_STRIDE = SMJ_ST_XPOSE + 12 * NBP
+};
+static_assert(SMJ_ST_STRIDE % 4 == 0, "staging rows are whole 16-byte words");
+// wheel geometry and default speeds of the relative base moves (stretch_mujoco/config.py:2-3,11)
+#define SMJ_WHEEL_RADIUS 0.0508f
+#define SMJ_WHEEL_SEPARATION 0.3153f
+#define SMJ_BASE_X_VEL 0.3f
+#define SMJ_BASE_R_VEL 1.0f
 
 enum { SMJ_PROF_KIN = 0, SMJ_PROF_COMCRB, SMJ_PROF_SMOOTH, SMJ_PROF_FACTOR, SMJ_PROF_COLLISION, SMJ_PROF_MAKECON,
        SMJ_PROF_PROJECT, SMJ_PROF_WARM, SMJ_PROF_PGS, SMJ_PROF_POST, SMJ_PROF_INTEGRATE, SMJ_PROF_TOTAL, SMJ_PROF_PGS_SWEEPS,
@@ -120,7 +141,7 @@ enum {
   SMJ_DBG_QFRC_BIAS = 1504,   // 32
   SMJ_DBG_QFRC_PASSIVE = 1536,// 32
   SMJ_DBG_QFRC_ACT = 1568,    // 32
-  SMJ_DBG_CON = 1600,         // 16 contacts x (dist, pos3, normal3, dim) = 8 floats
+  SMJ_DBG_CON = 1600,         // 16 contacts x (dist, pos3, normal3, condim | geom1 << 4 | geom2 << 14) = 8 floats
   SMJ_DBG_AR = 1728,          // 64*64 AR
   SMJ_DEBUG_FLOATS = 1728 + 4096
 };

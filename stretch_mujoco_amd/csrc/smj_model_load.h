@@ -20,6 +20,17 @@ struct SmjBlobEntry {
 struct SmjBlob {
   const uint8_t* p;
   size_t n;
+  // the entry table and every entry's payload lie inside the blob (a truncated / corrupt blob is rejected, not read past)
+  bool valid() const {
+    if (!p || n < 16) return false;
+    uint32_t cnt;
+    memcpy(&cnt, p + 8, 4);
+    if ((size_t)cnt > (n - 16) / sizeof(SmjBlobEntry)) return false;
+    const SmjBlobEntry* e = reinterpret_cast<const SmjBlobEntry*>(p + 16);
+    for (uint32_t i = 0; i < cnt; i++)
+      if (e[i].offset > n || e[i].nbytes > n - e[i].offset) return false;
+    return true;
+  }
   const SmjBlobEntry* find(const char* name) const {
     uint32_t cnt;
     memcpy(&cnt, p + 8, 4);
@@ -212,6 +223,7 @@ template <class Up>
 int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::string& err) {
   if (!blob || nbytes < 16 || memcmp(blob, "SMJB0001", 8) != 0) { err = "not an SMJB model blob"; return -1; }
   SmjBlob b{static_cast<const uint8_t*>(blob), nbytes};
+  if (!b.valid()) { err = "model blob: truncated or corrupt entry table"; return -3; }
   auto geti = [&](const char* name, int idx, int* out) -> bool {
     const SmjBlobEntry* e = b.find(name);
     if (!e || e->dtype != 1 || e->nbytes < 4u * (idx + 1)) { err = std::string("model blob: missing int ") + name; return false; }
@@ -255,6 +267,7 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
   if (m.ngc > 16) { err = "more than 16 gravity-compensated bodies"; return -4; }
   if (m.njump > 6) { err = "body tree deeper than 64 levels"; return -4; }
   if (m.ncgeom > NCG) { err = "too many geoms in non-plane collision pairs"; return -4; }
+  if (m.nconvpair >= 65536) { err = "more than 65535 non-plane collision pairs (the survivor list holds 16-bit pair indices)"; return -4; }
   std::map<std::string, std::vector<int>> hosti;
   std::map<std::string, std::vector<float>> hostf;
 #define X(n)                                                                               \

@@ -34,6 +34,7 @@ struct Smem {
   float xaxis[NVP][3], xanchor[NVP][3];
   float qpos[NVP + 8], qvel[NVP], ctrl[16], g[NVP], uu[NVP], w[NVP], qacc[NVP], warm[NVP], tmp[NVP];
   float act_force[16], act_len[16], act_vel[16], act_free[16];
+  float bctl[SMJ_BC_ROWS];   // relative base move in flight (BaseController): mode, start pose, increment, v, omega
   int etype[NEFC], eid[NEFC];
   int estate[NEFC];   // Newton: state of every row as of the last constraint update (cone blocks: the block's state)
   float epos[NEFC], emargin[NEFC], ediag[NEFC], efloss[NEFC], eR[NEFC], eK[NEFC], eBv[NEFC], eimp[NEFC], earef[NEFC],
@@ -341,26 +342,89 @@ struct StepKernel {
     SYNC();
   }
 
+  // One env's row of the env-major staging copy (DevState::stage): contiguous words, lanes = consecutive words
+  SMJ_DEV float* stage_row() const { return S.stage + (size_t)env * SMJ_ST_STRIDE; }
   SMJ_DEV void load_state() {
     const long ld = S.ld;
-    LANES {
-      if (lane < M.nq) s.qpos[lane] = S.qpos[lane * ld + env];
-      if (lane < M.nv) { s.qvel[lane] = S.qvel[lane * ld + env]; s.warm[lane] = S.warm[lane * ld + env]; }
-      if (lane < M.nu) s.ctrl[lane] = S.ctrl[lane * ld + env];
+    if (S.stage) {
+      const float* st = stage_row();
+      LANES {
+        for (int k = lane; k < M.nq; k += 64) s.qpos[k] = st[SMJ_ST_QPOS + k];
+        if (lane < M.nv) { s.qvel[lane] = st[SMJ_ST_QVEL + lane]; s.warm[lane] = st[SMJ_ST_WARM + lane]; }
+        if (lane < M.nu) s.ctrl[lane] = st[SMJ_ST_CTRL + lane];
+        if (lane < SMJ_BC_ROWS) s.bctl[lane] = st[SMJ_ST_BCTL + lane];
+      }
+    } else {
+      LANES {
+        for (int k = lane; k < M.nq; k += 64) s.qpos[k] = S.qpos[k * ld + env];
+        if (lane < M.nv) { s.qvel[lane] = S.qvel[lane * ld + env]; s.warm[lane] = S.warm[lane * ld + env]; }
+        if (lane < M.nu) s.ctrl[lane] = S.ctrl[lane * ld + env];
+        if (lane < SMJ_BC_ROWS) s.bctl[lane] = S.bctl ? S.bctl[lane * ld + env] : 0.f;
+      }
     }
     SYNC();
   }
+  // State, counters and the post-step readout.  actuator_length / velocity and the base pose are those of the LAST FORWARD
+  // PASS -- what MjData holds after mj_step, which integrates after computing them (pull_status reads exactly these fields,
+  // mujoco_server.py:465-515, :124-129): they lag qpos by one step, as in the reference.
   SMJ_DEV void store_state(int nsteps) {
     const long ld = S.ld;
-    LANES {
-      if (lane < M.nq) S.qpos[lane * ld + env] = s.qpos[lane];
-      if (lane < M.nv) { S.qvel[lane * ld + env] = s.qvel[lane]; S.warm[lane * ld + env] = s.warm[lane]; }
-      if (lane == 0) {
-        S.nstep[env] += nsteps;
-        S.info[SMJ_INFO_NEFC * ld + env] = nefc; S.info[SMJ_INFO_NCON * ld + env] = ncon;
-        S.info[SMJ_INFO_NITER * ld + env] = niter; S.info[SMJ_INFO_FLAGS * ld + env] |= flags;
+    const int b = 1;  // base_link is the first body after the world
+    const float bx = s.xpos[b][0], by = s.xpos[b][1], bth = atan2f(s.xmat[b][3], s.xmat[b][0]);
+    if (S.stage) {
+      float* st = stage_row();
+      int* sti = reinterpret_cast<int*>(st);
+      LANES {
+        for (int k = lane; k < M.nq; k += 64) st[SMJ_ST_QPOS + k] = s.qpos[k];
+        if (lane < M.nv) { st[SMJ_ST_QVEL + lane] = s.qvel[lane]; st[SMJ_ST_WARM + lane] = s.warm[lane]; }
+        if (lane < M.nu) { st[SMJ_ST_CTRL + lane] = s.ctrl[lane]; st[SMJ_ST_ACTLEN + lane] = s.act_len[lane]; st[SMJ_ST_ACTVEL + lane] = s.act_vel[lane]; }
+        if (lane < SMJ_BC_ROWS) st[SMJ_ST_BCTL + lane] = s.bctl[lane];
+        if (lane == 0) {
+          sti[SMJ_ST_NSTEP] += nsteps;
+          sti[SMJ_ST_INFO + SMJ_INFO_NEFC] = nefc; sti[SMJ_ST_INFO + SMJ_INFO_NCON] = ncon;
+          sti[SMJ_ST_INFO + SMJ_INFO_NITER] = niter; sti[SMJ_ST_INFO + SMJ_INFO_FLAGS] |= flags;
+          st[SMJ_ST_BASE] = bx; st[SMJ_ST_BASE + 1] = by; st[SMJ_ST_BASE + 2] = bth;
+        }
+      }
+    } else {
+      LANES {
+        for (int k = lane; k < M.nq; k += 64) S.qpos[k * ld + env] = s.qpos[k];
+        if (lane < M.nv) { S.qvel[lane * ld + env] = s.qvel[lane]; S.warm[lane * ld + env] = s.warm[lane]; }
+        if (lane < M.nu) { S.ctrl[lane * ld + env] = s.ctrl[lane]; S.act_len[lane * ld + env] = s.act_len[lane]; S.act_vel[lane * ld + env] = s.act_vel[lane]; }
+        if (lane < SMJ_BC_ROWS && S.bctl) S.bctl[lane * ld + env] = s.bctl[lane];
+        if (lane == 0) {
+          S.nstep[env] += nsteps;
+          S.info[SMJ_INFO_NEFC * ld + env] = nefc; S.info[SMJ_INFO_NCON * ld + env] = ncon;
+          S.info[SMJ_INFO_NITER * ld + env] = niter; S.info[SMJ_INFO_FLAGS * ld + env] |= flags;
+          S.base[0 * ld + env] = bx; S.base[1 * ld + env] = by; S.base[2 * ld + env] = bth;
+        }
       }
     }
+  }
+
+  // BaseController.update (mujoco_server.py:110-176) after every step, with the base pose of the step's forward pass (what
+  // get_base_pose reads from MjData after mj_step): a translate-by / rotate-by in flight drives the wheels at the default
+  // speed until the travelled distance / heading change exceeds the increment, then stops them and clears itself; velocity
+  // mode keeps writing its wheel speeds.  No angle wrap in rotate-by (:160-163), as in the reference.  Wave-uniform.
+  SMJ_DEV void base_controller() {
+    const int mode = (int)uni(s.bctl[SMJ_BC_MODE]);
+    if (mode == 0) return;
+    const int b = 1;
+    const float x = uni(s.xpos[b][0]), y = uni(s.xpos[b][1]), th = atan2f(uni(s.xmat[b][3]), uni(s.xmat[b][0]));
+    const float inc = uni(s.bctl[SMJ_BC_INC]), sign = inc > 0.f ? 1.f : -1.f;
+    float v = 0.f, w = 0.f;
+    int next = mode;
+    if (mode == 1) {
+      const float dx = x - uni(s.bctl[SMJ_BC_X0]), dy = y - uni(s.bctl[SMJ_BC_Y0]);
+      if (!(sqrtf(dx * dx + dy * dy) <= fabsf(inc))) next = 0; else v = SMJ_BASE_X_VEL * sign;
+    } else if (mode == 2) {
+      if (!(fabsf(uni(s.bctl[SMJ_BC_TH0]) - th) <= fabsf(inc))) next = 0; else w = SMJ_BASE_R_VEL * sign;
+    } else { v = uni(s.bctl[SMJ_BC_V]); w = uni(s.bctl[SMJ_BC_W]); }
+    const float wl = (v - (w * SMJ_WHEEL_SEPARATION / 2.f)) / SMJ_WHEEL_RADIUS, wr = (v + (w * SMJ_WHEEL_SEPARATION / 2.f)) / SMJ_WHEEL_RADIUS;
+    LANES {
+      if (lane == 0) { s.ctrl[0] = wl; s.ctrl[1] = wr; s.bctl[SMJ_BC_MODE] = (float)next; }
+    }
+    SYNC();
   }
 
   // ------------------------------------------------------------------ B.1 kinematics  [MJ] mj_kinematics
@@ -1290,11 +1354,16 @@ struct StepKernel {
     shape_support(Bs, nd, p.b);
     for (int i = 0; i < 3; i++) p.v[i] = p.a[i] - p.b[i];
   }
-  SMJ_DEV static bool ccd_zero(float x) { return fabsf(x) < 1.1920929e-7f; }
+  // libccd's CCD_EPS as MuJoCo builds it (double precision: DBL_EPSILON).  These are ABSOLUTE tests on squared lengths and
+  // triple products of centimetre-scale vectors: with FLT_EPSILON, |v0 x v1|^2 < eps holds for any two vectors shorter than
+  // ~2 cm, and the "origin on the v0-v1 segment" exit of the portal discovery reported a 3 mm penetration for finger hulls
+  // that are 0.5 mm apart.  fp32 represents 2.2e-16 without trouble, so the thresholds stay where the reference has them.
+  static constexpr float CCD_EPS = 2.220446e-16f;
+  SMJ_DEV static bool ccd_zero(float x) { return fabsf(x) < CCD_EPS; }
   SMJ_DEV static bool ccd_eq(float a, float b) {
     const float ab = fabsf(a - b);
-    if (ab < 1.1920929e-7f) return true;
-    return ab < 1.1920929e-7f * fmaxf(fabsf(a), fabsf(b));
+    if (ab < CCD_EPS) return true;
+    return ab < CCD_EPS * fmaxf(fabsf(a), fabsf(b));
   }
   SMJ_DEV static void portal_dir(const MprPt* P, float* dir) {
     float a[3], b[3];
@@ -1338,7 +1407,9 @@ struct StepKernel {
     if (!ccd_zero(den)) { sc = (q * r - ww * p) / den; t = (-sc * r - q) / ww; }
     if ((ccd_zero(sc) || sc > 0) && (ccd_eq(sc, 1) || sc < 1) && (ccd_zero(t) || t > 0) && (ccd_eq(t, 1) || t < 1) && (ccd_eq(t + sc, 1) || t + sc < 1)) {
       for (int i = 0; i < 3; i++) w[i] = a[i] + sc * d1[i] + t * d2[i];
-      return u + sc * sc * v + t * t * ww + 2 * sc * p + 2 * t * q + 2 * sc * t * r;
+      // |w|^2 from the witness point itself: libccd's expanded form (u + s^2 v + t^2 w + 2sp + 2tq + 2str) cancels to noise in
+      // fp32 when the penetration (1e-5 m) is small against the portal's distance from the origin (1e-2 m)
+      return dot3(w, w);
     }
     float best = -1;
     for (int e = 0; e < 3; e++) {
@@ -1361,7 +1432,7 @@ struct StepKernel {
     MprPt P[4], v4;
     float dir[3], va[3], vb[3], dot;
     for (int i = 0; i < 3; i++) { P[0].a[i] = c0[i]; P[0].b[i] = c1[i]; P[0].v[i] = c0[i] - c1[i]; }
-    if (ccd_zero(P[0].v[0]) && ccd_zero(P[0].v[1]) && ccd_zero(P[0].v[2])) P[0].v[0] += 1.1920929e-6f;
+    if (ccd_zero(P[0].v[0]) && ccd_zero(P[0].v[1]) && ccd_zero(P[0].v[2])) P[0].v[0] += 10.f * CCD_EPS;
     for (int i = 0; i < 3; i++) dir[i] = -P[0].v[i];
     normalize3(dir);
     mpr_support(A, Bs, dir, P[1]);
@@ -1586,7 +1657,7 @@ struct StepKernel {
         }
       }
     }
-    if (nsurv > 1024) nsurv = 1024;
+    if (nsurv > 1024) { nsurv = 1024; flags |= SMJ_FLAG_CON_OVERFLOW; }   // pairs beyond the survivor list are lost: flagged
     SYNC();
     // pass 2: oriented boxes on the survivors, then MPR in table order
     for (int base = 0; base < nsurv; base += 64) {
@@ -2944,31 +3015,9 @@ struct StepKernel {
     }
   }
 
-  // ------------------------------------------------------------------ readouts at the end of a launch
-  SMJ_DEV void readout() {
-    const long ld = S.ld;
-    // actuator_length / velocity of the post-step state and base pose (pull_status, mujoco_server.py:465-515, :124-129)
-    kinematics();
-    LANES {
-      if (lane < M.nu) {
-        float len = 0, vel = 0;
-        for (int k = 0; k < M.nv; k++) {
-          const float mo = M.k_act_moment[lane * M.nv + k];
-          if (mo != 0.f) { vel += mo * s.qvel[k]; len += mo * s.qpos[M.k_dof_qposadr[k]]; }
-        }
-        S.act_len[lane * ld + env] = len; S.act_vel[lane * ld + env] = vel;
-      }
-      if (lane == 0) {
-        const int b = 1;  // base_link is the first body after the world
-        S.base[0 * ld + env] = s.xpos[b][0]; S.base[1 * ld + env] = s.xpos[b][1];
-        S.base[2 * ld + env] = atan2f(s.xmat[b][3], s.xmat[b][0]);
-      }
-    }
-  }
-
   // IMU: gyro + accelerometer at the IMU site from the last forward pass  [MJ] mj_sensorVel / mj_sensorAcc
   SMJ_DEV void imu() {
-    if (M.imu_site < 0 || !S.gyro) return;
+    if (M.imu_site < 0 || (!S.gyro && !S.stage)) return;
     const int sid = M.imu_site, b = M.site_bodyid[sid];
     const uint64_t mk = mk64(M.k_body_dofmask_lo[b], M.k_body_dofmask_hi[b]);
     float cv[6], ca[6];
@@ -2996,14 +3045,27 @@ struct StepKernel {
     for (int k = 0; k < 3; k++) alin[k] += c2[k];
     mulmat3Tvec(gy, R, cv);
     mulmat3Tvec(ac, R, alin);
-    LANES {
-      if (lane < 3) { S.gyro[lane * S.ld + env] = gy[lane]; S.accel[lane * S.ld + env] = ac[lane]; }
+    if (S.stage) {
+      float* st = stage_row();
+      LANES { if (lane < 3) { st[SMJ_ST_GYRO + lane] = gy[lane]; st[SMJ_ST_ACCEL + lane] = ac[lane]; } }
+    } else {
+      LANES { if (lane < 3) { S.gyro[lane * S.ld + env] = gy[lane]; S.accel[lane * S.ld + env] = ac[lane]; } }
     }
   }
 
   // body poses of the last step for the ray-casting kernels (smj_render.hip: lidar, depth cameras): what mj_sensorPos /
   // mjv_updateScene read from mjData
   SMJ_DEV void dump_poses() {
+    if (S.stage) {   // contiguous: 12 words per body
+      float* st = stage_row() + SMJ_ST_XPOSE;
+      LANES {
+        for (int k = lane; k < 12 * M.nbody; k += 64) {
+          const int b = k / 12, c = k - 12 * b;
+          st[k] = c < 3 ? s.xpos[b][c] : s.xmat[b][c - 3];
+        }
+      }
+      return;
+    }
     if (!S.xpose) return;
     LANES {
       if (lane < M.nbody) {
@@ -3033,7 +3095,8 @@ struct StepKernel {
         float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (c < ncon) {
           v[0] = s.cdist[c]; v[1] = s.cpos[c][0]; v[2] = s.cpos[c][1]; v[3] = s.cpos[c][2];
-          v[4] = s.cframe[c][0]; v[5] = s.cframe[c][1]; v[6] = s.cframe[c][2]; v[7] = (float)s.cdim[c];
+          v[4] = s.cframe[c][0]; v[5] = s.cframe[c][1]; v[6] = s.cframe[c][2];
+          v[7] = (float)(s.cdim[c] + 16 * s.cgeom1[c] + 16 * 1024 * s.cgeom2[c]);   // condim | geom1 << 4 | geom2 << 14 (exact in fp32)
         }
         for (int k = 0; k < 8; k++) S.debug[(SMJ_DBG_CON + 8 * c + k) * S.ld + env] = v[k];
       }
@@ -3075,11 +3138,11 @@ struct StepKernel {
       if (last && want_imu) imu();
       TICK(SMJ_PROF_POST)
       integrate();
+      base_controller();   // _ctrl_callback order: after mj_step, with the pose of its forward pass; sets the next step's wheel ctrl
       TICK(SMJ_PROF_INTEGRATE)
       pc[SMJ_PROF_PGS_SWEEPS] += (float)niter;
     }
     store_state(nsteps);
-    readout();
     if (prof) {
       pc[SMJ_PROF_TOTAL] = (float)(smj_clock() - tstart);
       LANES { if (lane < SMJ_PROF_SLOTS) S.prof[lane * S.ld + env] = pc[lane]; }

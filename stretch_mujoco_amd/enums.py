@@ -24,89 +24,67 @@ class Actuators(Enum):
     gripper_right_finger = 13
 
     def get_joint_names_in_mjcf(self) -> list:
-        table = {
-            Actuators.left_wheel_vel: ["joint_left_wheel"], Actuators.right_wheel_vel: ["joint_right_wheel"],
-            Actuators.lift: ["joint_lift"],
-            Actuators.arm: ["joint_arm_l0", "joint_arm_l1", "joint_arm_l2", "joint_arm_l3"],
-            Actuators.wrist_yaw: ["joint_wrist_yaw"], Actuators.wrist_pitch: ["joint_wrist_pitch"],
-            Actuators.wrist_roll: ["joint_wrist_roll"], Actuators.gripper: ["joint_gripper_slide"],
-            Actuators.gripper_left_finger: ["joint_gripper_finger_left_open"],
-            Actuators.gripper_right_finger: ["joint_gripper_finger_right_open"],
-            Actuators.head_pan: ["joint_head_pan"], Actuators.head_tilt: ["joint_head_tilt"],
-        }
-        if self not in table:
-            raise NotImplementedError(f"Joint names for {self} are not defined.")
-        return table[self]
+        """MJCF joints driven by this actuator (actuators.py:27-61)."""
+        names = [j for j, a in _JOINT_TO_ACTUATOR.items() if a == self.name and j.startswith("joint_") and "*" not in j]
+        names += [f"{j[:-1]}_open" for j, a in _JOINT_PREFIX_TO_ACTUATOR if a == self.name and "finger" in j]
+        if self is Actuators.arm:
+            names = [f"joint_arm_l{k}" for k in range(4)]
+        if not names:
+            raise NotImplementedError(f"{self.name} drives no MJCF joint")
+        return names
 
     @staticmethod
     @lru_cache(maxsize=None)
     def get_actuator_by_joint_names_in_mjcf(joint_name: str) -> "Actuators":
-        """stretch_mujoco/enums/actuators.py:63-120 (same matching order)."""
-        if joint_name == "joint_left_wheel":
-            return Actuators.left_wheel_vel
-        if joint_name == "joint_right_wheel":
-            return Actuators.right_wheel_vel
-        if joint_name in ("translate_mobile_base", "position"):
-            return Actuators.base_translate
-        if joint_name == "rotate_mobile_base":
-            return Actuators.base_rotate
-        if joint_name == "joint_lift":
-            return Actuators.lift
-        if "joint_arm" in joint_name:
-            return Actuators.arm
-        if joint_name == "joint_wrist_yaw":
-            return Actuators.wrist_yaw
-        if joint_name == "joint_wrist_pitch":
-            return Actuators.wrist_pitch
-        if joint_name == "joint_wrist_roll":
-            return Actuators.wrist_roll
-        if joint_name in ("joint_gripper_slide", "gripper_aperture"):
-            return Actuators.gripper
-        if "joint_gripper_finger_left" in joint_name:
-            return Actuators.gripper_left_finger
-        if "joint_gripper_finger_right" in joint_name:
-            return Actuators.gripper_right_finger
-        if joint_name == "joint_head_pan":
-            return Actuators.head_pan
-        if joint_name == "joint_head_tilt":
-            return Actuators.head_tilt
-        raise NotImplementedError(f"Actuator for {joint_name} is not defined.")
+        """Joint (or tendon / alias) name -> actuator, with the precedence of actuators.py:63-120: exact names first in table
+        order, where the two substring rules (arm segments, finger joints) sit at their reference positions."""
+        for rule, actuator in _MATCH_ORDER:
+            if (rule.endswith("*") and rule[:-1] in joint_name) or rule == joint_name:
+                return Actuators[actuator]
+        raise NotImplementedError(f"no actuator is mapped to MJCF joint '{joint_name}'")
 
-    # status accessors (actuators.py:124-182)
-    def _get_status_attribute(self, is_position: bool, status):
-        attribute_name = "pos" if is_position else "vel"
-        if self in (Actuators.arm, Actuators.gripper, Actuators.head_pan, Actuators.head_tilt, Actuators.lift,
-                    Actuators.wrist_pitch, Actuators.wrist_roll, Actuators.wrist_yaw):
-            return getattr(getattr(status, self.name), attribute_name)
-        raise NotImplementedError(f"Get {'Position' if is_position else 'Velocity'} for {self.name} is not implemented.")
-
-    def _get_base_status_attribute(self, is_position: bool, status):
-        x = "x" if is_position else "x_vel"
-        y = "y" if is_position else "y_vel"
-        theta = "theta" if is_position else "theta_vel"
-        if self in (Actuators.base_rotate, Actuators.base_translate):
-            return (getattr(status.base, x), getattr(status.base, y), getattr(status.base, theta))
-        raise NotImplementedError(f"Get {'Position' if is_position else 'Velocity'}  for {self.name} is not implemented.")
+    # status accessors (actuators.py:124-182): joint actuators read status.<name>.pos / .vel, the two relative base moves
+    # read the (x, y, theta) triple of status.base, everything else (wheels, finger pseudo-actuators) has no status entry
+    def _read(self, status, want_base: bool, field: str):
+        what = "position" if field == "pos" else "velocity"
+        if (self.name in _BASE_MOVES) != want_base:   # wrong accessor family: a plain Exception, as in the reference
+            right = f"get_{what}()" if want_base else f"get_{what}_relative()"
+            raise Exception(f"{self.name}: read it with {right}")
+        if want_base:
+            sfx = "" if field == "pos" else "_vel"
+            return tuple(getattr(status.base, k + sfx) for k in ("x", "y", "theta"))
+        if self.name not in _STATUS_JOINTS:
+            raise NotImplementedError(f"{self.name} has no {what} entry in the status")
+        return getattr(getattr(status, self.name), field)
 
     def get_position(self, status):
-        if self in (Actuators.base_rotate, Actuators.base_translate):
-            raise Exception(f"Please use `get_position_relative()` for {self.name}")
-        return self._get_status_attribute(True, status)
+        return self._read(status, False, "pos")
 
     def get_position_relative(self, status):
-        if self not in (Actuators.base_rotate, Actuators.base_translate):
-            raise Exception(f"Please use `get_position()` for {self.name}")
-        return self._get_base_status_attribute(True, status)
+        return self._read(status, True, "pos")
 
     def get_velocity(self, status):
-        if self in (Actuators.base_rotate, Actuators.base_translate):
-            raise Exception(f"Please use `get_velocity_relative()` for {self.name}")
-        return self._get_status_attribute(False, status)
+        return self._read(status, False, "vel")
 
     def get_velocity_relative(self, status):
-        if self not in (Actuators.base_rotate, Actuators.base_translate):
-            raise Exception(f"Please use `get_velocity()` for {self.name}")
-        return self._get_base_status_attribute(False, status)
+        return self._read(status, True, "vel")
+
+
+# joint / tendon / alias name -> actuator.  A trailing "*" marks a substring rule.  ORDER is part of the contract
+# (actuators.py:63-120 tests the names top to bottom).
+_MATCH_ORDER = (
+    ("joint_left_wheel", "left_wheel_vel"), ("joint_right_wheel", "right_wheel_vel"),
+    ("translate_mobile_base", "base_translate"), ("position", "base_translate"), ("rotate_mobile_base", "base_rotate"),
+    ("joint_lift", "lift"), ("joint_arm*", "arm"),
+    ("joint_wrist_yaw", "wrist_yaw"), ("joint_wrist_pitch", "wrist_pitch"), ("joint_wrist_roll", "wrist_roll"),
+    ("joint_gripper_slide", "gripper"), ("gripper_aperture", "gripper"),
+    ("joint_gripper_finger_left*", "gripper_left_finger"), ("joint_gripper_finger_right*", "gripper_right_finger"),
+    ("joint_head_pan", "head_pan"), ("joint_head_tilt", "head_tilt"),
+)
+_JOINT_TO_ACTUATOR = {rule: act for rule, act in _MATCH_ORDER if not rule.endswith("*")}
+_JOINT_PREFIX_TO_ACTUATOR = tuple((rule, act) for rule, act in _MATCH_ORDER if rule.endswith("*"))
+_STATUS_JOINTS = ("arm", "gripper", "head_pan", "head_tilt", "lift", "wrist_pitch", "wrist_roll", "wrist_yaw")
+_BASE_MOVES = ("base_rotate", "base_translate")
 
 
 # ctrl index of each MJCF actuator (stretch.xml:525-534)
@@ -132,8 +110,9 @@ class StretchSensors(Enum):
     @staticmethod
     @lru_cache(maxsize=None)
     def lidar_names(resolution: int = 720):
-        num_digits = len(str(resolution))
-        return [f"{StretchSensors.base_lidar.name}{str(i).zfill(num_digits)}" for i in range(resolution)]
+        """Sensor names base_lidar<i>, zero-padded to the width of `resolution` (stretch_sensors.py:33-40)."""
+        width = len(f"{resolution}")
+        return ["%s%0*d" % (StretchSensors.base_lidar.name, width, i) for i in range(resolution)]
 
 
 class StretchCameras(Enum):

@@ -8,6 +8,7 @@ Restates, with a leading batch dimension, the Python that runs around `mj_step` 
 All state lives in torch tensors on the simulator's device; nothing here touches the physics.
 Quirks kept on purpose: no angle wrap in base rotate-by (:160-163); gripper velocity stays in sim units
 (:499-501); base x_vel/theta_vel are computed from actuator_velocity = gear*qvel (the x3 wheel quirk).
+Nothing in here reads a device value back to the host: commands are folded in with masks.
 """
 from __future__ import annotations
 
@@ -37,15 +38,22 @@ class Glue:
         self.br_val = torch.zeros(B, **f); self.br_trig = torch.zeros(B, **b)
         self.bv_v = torch.zeros(B, **f); self.bv_w = torch.zeros(B, **f); self.bv_trig = torch.zeros(B, **b)
         self.kf_id = torch.zeros(B, dtype=torch.long, device=device); self.kf_trig = torch.zeros(B, **b)
-        # BaseController state (mujoco_server.py:95-103)
-        self.bc_mode = torch.zeros(B, dtype=torch.int32, device=device)
-        self.bc_start = torch.zeros(3, B, **f)
-        self.bc_inc = torch.zeros(B, **f)
-        self.bc_v = torch.zeros(B, **f); self.bc_w = torch.zeros(B, **f)
-        # host-side hints: which command kinds were issued since the last push, and whether the base controller may be
-        # active -- so that an idle push_command() costs no device synchronisation at all
+        # BaseController state (mujoco_server.py:95-103), one column per env: row 0 mode, rows 1-3 start pose, row 4 increment,
+        # rows 5-6 (v, omega).  On the GPU this tensor is bound to SMJ_SLOT_BASECTL: the step kernel runs the controller's
+        # update() after every physics step, the host only writes it when a command is pushed.
+        self.bctl = torch.zeros(8, B, **f)
+        # host-side hints: which command kinds were issued since the last push -- an idle push_command() launches nothing, and
+        # nothing here ever reads a device value back (no synchronisation)
         self._h = dict(bt=False, br=False, mb=False, mt=False, bv=False, kf=False)
-        self._h_base_live = False
+
+    # views kept for tests / introspection
+    @property
+    def bc_mode(self):
+        return self.bctl[0].to(torch.int32)
+
+    @property
+    def bc_start(self):
+        return self.bctl[1:4]
 
     # ---------------------------------------------------------------- client side (stretch_mujoco_simulator.py)
     def _ids(self, env_ids):
@@ -102,6 +110,7 @@ class Glue:
         ids = self._ids(env_ids)
         if replace_command:  # home()/stow() install a brand-new StatusCommand (stretch_mujoco_simulator.py:217-231)
             self.mt_trig[:, ids] = False; self.mb_trig[:, ids] = False
+            self.mt_has[:, ids] = False   # the new command holds no move_to entry: is_reached_set_position() is True again
             self.bt_trig[ids] = False; self.br_trig[ids] = False; self.bv_trig[ids] = False
         self.kf_id[ids] = self.key_names.index(name)
         self.kf_trig[ids] = True
@@ -113,84 +122,80 @@ class Glue:
             t[:, ids] = False
         for t in (self.bt_trig, self.br_trig, self.bv_trig, self.kf_trig):
             t[ids] = False
-        self.bc_mode[ids] = MODE_NONE
+        self.bctl[:, ids] = 0
 
     # ---------------------------------------------------------------- server side (mujoco_server.py:527-578)
-    def push_command(self, ctrl: torch.Tensor, act_len: torch.Tensor, base_pose: torch.Tensor) -> None:
-        """Fold pending commands into ctrl [nu,B] in place.  act_len [nu,B], base_pose [3,B] are the post-step readout."""
+    def push_command(self, ctrl: torch.Tensor, act_len: torch.Tensor, base_pose: torch.Tensor, tick_base=True) -> bool:
+        """Fold pending commands into ctrl [nu,B] and the base-controller state in place.  act_len [nu,B], base_pose [3,B] are
+        the status readout of the last step.  Masked tensor ops only: no value is read back from the device.
+        tick_base: run BaseController.update() once at the end, as the reference does after every push (mujoco_server.py:576)
+        -- True in the host-only replays; the simulator passes False and lets the HIP tick (smj_base_controller_tick) and the
+        step kernel do it.  Returns whether a base tick is due (a base command or a keyframe was folded in)."""
         g = CTRL_INDEX["gripper"]
-        # move_by: base first (push to the controller), then joints
         h = self._h
-        if not (any(h.values()) or self._h_base_live):
-            return   # nothing was commanded since the last push and no base move is in flight
+        need_tick = h["bt"] or h["br"] or h["bv"] or h["kf"]
+        # move_by: base first (push to the controller: last_command, start_pose), then joints
         for key, trig, val, mode in (("bt", self.bt_trig, self.bt_val, MODE_TRANSLATE), ("br", self.br_trig, self.br_val, MODE_ROTATE)):
-            if h[key] and bool(trig.any()):
-                self._h_base_live = True
-                self.bc_mode = torch.where(trig, torch.full_like(self.bc_mode, mode), self.bc_mode)
-                self.bc_inc = torch.where(trig, val, self.bc_inc)
-                self.bc_start = torch.where(trig.unsqueeze(0), base_pose, self.bc_start)
+            if h[key]:
+                self.bctl[0] = torch.where(trig, torch.full_like(self.bctl[0], float(mode)), self.bctl[0])
+                self.bctl[4] = torch.where(trig, val, self.bctl[4])
+                self.bctl[1:4] = torch.where(trig.unsqueeze(0), base_pose.to(self.bctl.dtype), self.bctl[1:4])
                 trig.zero_()
-        if h["mb"] and bool(self.mb_trig.any()):
+        if h["mb"]:
             target = act_len + self.mb_val
             target[g] = utils.to_sim_gripper_range(utils.to_real_gripper_range(act_len[g]) + self.mb_val[g])
-            ctrl.copy_(torch.where(self.mb_trig, target, ctrl))
+            ctrl.copy_(torch.where(self.mb_trig, target.to(ctrl.dtype), ctrl))
             self.mb_trig.zero_()
         # move_to
-        if h["mt"] and bool(self.mt_trig.any()):
+        if h["mt"]:
             target = self.mt_val.clone()
             target[g] = utils.to_sim_gripper_range(self.mt_val[g])
-            ctrl.copy_(torch.where(self.mt_trig, target, ctrl))
+            ctrl.copy_(torch.where(self.mt_trig, target.to(ctrl.dtype), ctrl))
             self.mt_trig.zero_()
         # set_base_velocity
-        if h["bv"] and bool(self.bv_trig.any()):
-            self._h_base_live = True
+        if h["bv"]:
             t = self.bv_trig
-            self.bc_mode = torch.where(t, torch.full_like(self.bc_mode, MODE_VELOCITY), self.bc_mode)
-            self.bc_v = torch.where(t, self.bv_v, self.bc_v); self.bc_w = torch.where(t, self.bv_w, self.bc_w)
-            self.bc_start = torch.where(t.unsqueeze(0), base_pose, self.bc_start)
+            self.bctl[0] = torch.where(t, torch.full_like(self.bctl[0], float(MODE_VELOCITY)), self.bctl[0])
+            self.bctl[5] = torch.where(t, self.bv_v, self.bctl[5]); self.bctl[6] = torch.where(t, self.bv_w, self.bctl[6])
+            self.bctl[1:4] = torch.where(t.unsqueeze(0), base_pose.to(self.bctl.dtype), self.bctl[1:4])
             t.zero_()
         # keyframe
-        if h["kf"] and bool(self.kf_trig.any()):
+        if h["kf"]:
             kc = self.key_ctrl[self.kf_id].t()  # [nu,B]
-            ctrl.copy_(torch.where(self.kf_trig.unsqueeze(0), kc, ctrl))
+            ctrl.copy_(torch.where(self.kf_trig.unsqueeze(0), kc.to(ctrl.dtype), ctrl))
             self.kf_trig.zero_()
         for k in h:
             h[k] = False
-        if self._h_base_live:
-            self._base_controller_update(ctrl, base_pose)
+        if tick_base:
+            self.base_controller_update(ctrl, base_pose)
+        return need_tick
 
-    def base_active(self) -> bool:
-        """True while any env has a relative base move in flight (needs per-step controller updates)."""
-        if not (self._h_base_live or self._h["bt"] or self._h["br"]):
-            return False
-        return bool(((self.bc_mode == MODE_TRANSLATE) | (self.bc_mode == MODE_ROTATE)).any()) or self._h["bt"] or self._h["br"]
-
-    def _base_controller_update(self, ctrl, pose):
-        mode = self.bc_mode
-        if not bool((mode != MODE_NONE).any()):
-            self._h_base_live = False
-            return
+    def base_controller_update(self, ctrl, pose):
+        """BaseController.update() (mujoco_server.py:110-176) in torch -- the host twin of the HIP controller
+        (csrc/smj_step_impl.h base_controller, csrc/smj_kernels.hip smj_base_tick_kernel), used by the CPU replays."""
+        mode, inc = self.bctl[0], self.bctl[4]
+        start = self.bctl[1:4]
         li, ri = CTRL_INDEX["left_wheel_vel"], CTRL_INDEX["right_wheel_vel"]
-        one = torch.ones_like(self.bc_inc)
-        sign = torch.where(self.bc_inc > 0, one, -one)
+        one = torch.ones_like(inc)
+        sign = torch.where(inc > 0, one, -one)
         # translate (mujoco_server.py:144-154)
-        dist = torch.linalg.vector_norm(pose[:2] - self.bc_start[:2], dim=0)
+        dist = torch.linalg.vector_norm(pose[:2].to(start.dtype) - start[:2], dim=0)
         t_on = mode == MODE_TRANSLATE
-        t_done = t_on & ~(dist <= self.bc_inc.abs())
+        t_done = t_on & ~(dist <= inc.abs())
         # rotate (mujoco_server.py:156-165; no angle wrap)
         r_on = mode == MODE_ROTATE
-        r_done = r_on & ~((self.bc_start[2] - pose[2]).abs() <= self.bc_inc.abs())
+        r_done = r_on & ~((start[2] - pose[2].to(start.dtype)).abs() <= inc.abs())
         v_on = mode == MODE_VELOCITY
-        zero = torch.zeros_like(self.bc_v)
+        zero = torch.zeros_like(inc)
         v = torch.where(t_on & ~t_done, config.base_motion["default_x_vel"] * sign, zero)
-        v = torch.where(v_on, self.bc_v, v)
+        v = torch.where(v_on, self.bctl[5], v)
         w = torch.where(r_on & ~r_done, config.base_motion["default_r_vel"] * sign, zero)
-        w = torch.where(v_on, self.bc_w, w)
+        w = torch.where(v_on, self.bctl[6], w)
         wl, wr = utils.diff_drive_inv_kinematics(v, w)
         active = mode != MODE_NONE
-        ctrl[li] = torch.where(active, wl, ctrl[li])
-        ctrl[ri] = torch.where(active, wr, ctrl[ri])
-        self.bc_mode = torch.where(t_done | r_done, torch.zeros_like(mode), mode)
+        ctrl[li] = torch.where(active, wl.to(ctrl.dtype), ctrl[li])
+        ctrl[ri] = torch.where(active, wr.to(ctrl.dtype), ctrl[ri])
+        self.bctl[0] = torch.where(t_done | r_done, torch.zeros_like(mode), mode)
 
     # ---------------------------------------------------------------- status (mujoco_server.py:465-515)
     @staticmethod

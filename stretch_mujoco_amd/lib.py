@@ -11,11 +11,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsmj.so")
 
 SLOT = dict(QPOS=0, QVEL=1, CTRL=2, WARMSTART=3, NSTEP=4, ACT_LENGTH=5, ACT_VELOCITY=6, BASE_POSE=7, GYRO=8, ACCEL=9,
-            LIDAR=10, INFO=11, DEBUG=12, PROF=13, XPOSE=14)
+            LIDAR=10, INFO=11, DEBUG=12, PROF=13, XPOSE=14, BASECTL=15)
 DIM = dict(NQ=0, NV=1, NU=2, NBODY=3, NLIDAR=4, NKEY=5, NUM_ENVS=6, DEBUG_FLOATS=7, NEFC_MAX=8, NCON_MAX=9, NCAM=10)
 READ_IMU, READ_LIDAR, READ_POSES = 1, 2, 4
 EXPORTS = ("smj_create", "smj_destroy", "smj_bind", "smj_dims", "smj_reset", "smj_step", "smj_set_option",
-           "smj_last_error", "smj_version", "smj_render_depth")
+           "smj_last_error", "smj_version", "smj_render_depth", "smj_comm_init", "smj_allgather_returns", "smj_comm_destroy",
+           "smj_base_controller_tick")
 
 _lib = None
 
@@ -41,6 +42,10 @@ def load() -> ctypes.CDLL:
     L.smj_step.argtypes = [vp, ci, cu, vp]
     L.smj_render_depth.argtypes = [vp, ci, ci, ci, ctypes.c_float, ctypes.c_float, vp, vp]
     L.smj_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_double]
+    L.smj_base_controller_tick.argtypes = [vp, vp]
+    L.smj_comm_init.argtypes = [vp, ci, ci, ctypes.c_char_p, ctypes.c_double]
+    L.smj_allgather_returns.argtypes = [vp, vp, vp, ci, vp]
+    L.smj_comm_destroy.argtypes = [vp]
     L.smj_last_error.argtypes = [vp]
     L.smj_last_error.restype = ctypes.c_char_p
     L.smj_version.restype = ctypes.c_char_p

@@ -121,6 +121,9 @@ class StretchBatchSimulator:
             _lib.check(L, ctx, L.smj_bind(ctx, S[name], ctypes.c_void_p(t.data_ptr()), B), f"smj_bind({name})")
         key_ctrl = torch.tensor(np.asarray(self.model["key_ctrl"], np.float32)[:, : self.nu])
         self.glue = Glue(B, self.nu, key_ctrl, self.names["key"], self.device)
+        # the relative base moves (BaseController) advance inside the step kernel: its per-env state is the glue's tensor
+        _lib.check(L, ctx, L.smj_bind(ctx, S["BASECTL"], ctypes.c_void_p(self.glue.bctl.data_ptr()), B), "smj_bind(BASECTL)")
+        self.launches = 0   # smj_step launches so far (tests: a base move in flight must not multiply them)
         self.set_option("solver", {"pgs": 0, "newton": 2}[self.solver])
         self._read_flags = 0
         if StretchSensors.base_gyro in self._sensors or StretchSensors.base_accel in self._sensors:
@@ -195,11 +198,19 @@ class StretchBatchSimulator:
     def step(self, n: int = 1) -> None:
         """Advance every env by n physics steps (n x `_physics_step`, mujoco_server.py:371-384, without the sleep)."""
         n = int(n)
-        while n > 0:
-            self.glue.push_command(self.ctrl, self.actuator_length, self.base_pose)
-            k = 1 if self.glue.base_active() else n
-            _lib.check(self._L, self._ctx, self._L.smj_step(self._ctx, k, self._read_flags, self._stream()), "smj_step")
-            n -= k
+        if n <= 0:
+            return
+        self._push_command()
+        _lib.check(self._L, self._ctx, self._L.smj_step(self._ctx, n, self._read_flags, self._stream()), "smj_step")
+        self.launches += 1
+
+    def _push_command(self) -> None:
+        """`_ctrl_callback` -> push_command (mujoco_server.py:450-463, :527-578): commands issued since the last step are folded
+        into ctrl / the base-controller state on the device (masked ops, no host synchronisation); when one of them concerns
+        the base (or a keyframe overwrote the wheel ctrl) one BaseController.update() runs as a HIP tick -- every later
+        update happens inside the step kernel, after each physics step."""
+        if self.glue.push_command(self.ctrl, self.actuator_length, self.base_pose, tick_base=False):
+            _lib.check(self._L, self._ctx, self._L.smj_base_controller_tick(self._ctx, self._stream()), "smj_base_controller_tick")
 
     # ------------------------------------------------------------------ reference API
     @_require_connection

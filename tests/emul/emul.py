@@ -10,7 +10,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-SLOTS = dict(qpos=0, qvel=1, ctrl=2, warm=3, nstep=4, act_len=5, act_vel=6, base=7, gyro=8, accel=9, lidar=10, info=11, debug=12)
+SLOTS = dict(qpos=0, qvel=1, ctrl=2, warm=3, nstep=4, act_len=5, act_vel=6, base=7, gyro=8, accel=9, lidar=10, info=11, debug=12, bctl=15)
 
 
 def lib():
@@ -40,7 +40,8 @@ class Emul:
         self.buf = dict(qpos=np.zeros((nq, B), f), qvel=np.zeros((nv, B), f), ctrl=np.zeros((nu, B), f),
                         warm=np.zeros((nv, B), f), nstep=np.zeros(B, np.int32), act_len=np.zeros((nu, B), f),
                         act_vel=np.zeros((nu, B), f), base=np.zeros((3, B), f), gyro=np.zeros((3, B), f),
-                        accel=np.zeros((3, B), f), lidar=np.zeros((max(nl, 1), B), f), info=np.zeros((4, B), np.int32))
+                        accel=np.zeros((3, B), f), lidar=np.zeros((max(nl, 1), B), f), info=np.zeros((4, B), np.int32),
+                        bctl=np.zeros((8, B), f))
         if debug:
             self.buf["debug"] = np.zeros((self.L.emul_debug_floats(), B), f)
         for k, a in self.buf.items():

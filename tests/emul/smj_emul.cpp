@@ -73,6 +73,7 @@ int emul_bind(emul_ctx* c, int slot, void* p, long ld) {
     case 12: s.debug = (float*)p; break;
     case 13: s.prof = (float*)p; break;
     case 14: s.xpose = (float*)p; break;
+    case 15: s.bctl = (float*)p; break;
     default: return -1;
   }
   return 0;

@@ -1,0 +1,210 @@
+"""Shared logic of the rollout-parity tests: the bench workload (random ctrl in ctrlrange every 50 steps, heterogeneous envs,
+Newton) through a kernel backend -- the HIP library on the GPU (`-m gpu`) or the lane emulator on the CPU -- against one fp64
+oracle per env.  TEST INFRASTRUCTURE (imports oracle/).
+
+Two protocols:
+  * free-running: both sides integrate their own state for the whole rollout; reports the qpos drift of the "arm" coordinates
+    (lift, arm, wrist, gripper, head) and of the "driving base" (free joint + wheel angles) separately.
+  * state-synchronised: the oracle's state is copied into the kernel before every step, so each discrepancy belongs to the
+    step that produced it.  A step whose acceleration differs by more than EVENT_TOL must be a BIFURCATION of the reference
+    algorithm itself: the oracle, evaluated at inputs perturbed by 1e-7, has to reproduce the kernel's result.  (MPR returns
+    the exit facet of the Minkowski difference; where two facets are equally close the normal jumps by tens of degrees for a
+    1e-8 change of the pose -- in fp64 as well, tools/parity_probe.py.)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from oracle.oracle import Oracle
+
+HOLD = 50
+HOME = [0, 0, 0.6, 0.1, 0, 0, 0, 0, 0, 0]
+EVENT_TOL = 2e-2      # relative one-step acceleration error above which a step counts as an event (a gross difference)
+TYPICAL_TOL = 1.5e-3  # bound on the 99th percentile of the relative one-step acceleration error
+
+
+def ctrl_schedule(model, nu, B, windows, seed):
+    cr = np.asarray(model["actuator_ctrlrange"], np.float64)
+    rng = np.random.default_rng(seed)
+    return [(cr[:, 0][:, None] + (cr[:, 1] - cr[:, 0])[:, None] * rng.random((nu, B))).astype(np.float32) for _ in range(windows)]
+
+
+def settled_oracles(blob, B, solver=2, settle=500):
+    """B oracles settled at the home keyframe from qpos0 (the bench's start)."""
+    out = []
+    for _ in range(B):
+        o = Oracle(blob)
+        o.set_option("solver", solver)
+        nu = o.dim("nu")
+        o.arr("ctrl")[:nu] = HOME[:nu]
+        o.step(settle)
+        out.append(o)
+    return out
+
+
+def state_of(oracles):
+    return (np.stack([o.arr("qpos") for o in oracles], 1), np.stack([o.arr("qvel") for o in oracles], 1),
+            np.stack([o.arr("qacc_warmstart") for o in oracles], 1))
+
+
+def drift_groups(nq):
+    """Index sets of the drift report: driving base = free joint (7) + the two wheel angles; arm = every other robot
+    coordinate; objects = anything beyond the robot's 27 coordinates."""
+    base = list(range(0, 9))
+    arm = list(range(9, 27))
+    obj = list(range(27, nq))
+    return base, arm, obj
+
+
+def free_running(backend, blob, model, B, windows, seed, solver=2):
+    """Returns per-env max drift over the rollout: dict(base=[B], arm=[B], obj=[B]), the per-window history and the flags."""
+    oracles = settled_oracles(blob, B, solver)
+    nq, nu = oracles[0].dim("nq"), oracles[0].dim("nu")
+    backend.upload(*state_of(oracles))
+    sched = ctrl_schedule(model, nu, B, windows, seed)
+    base, arm, obj = drift_groups(nq)
+    hist = []
+    for w in range(windows):
+        backend.set_ctrl(sched[w])
+        for b, o in enumerate(oracles):
+            o.arr("ctrl")[:nu] = sched[w][:, b]
+            o.step(HOLD)
+        backend.step(HOLD)
+        q = backend.download()["qpos"]
+        d = np.abs(q - np.stack([o.arr("qpos") for o in oracles], 1))
+        hist.append((d[base].max(0), d[arm].max(0), d[obj].max(0) if obj else np.zeros(B)))
+    mx = lambda k: np.max(np.stack([h[k] for h in hist]), 0)
+    return dict(base=mx(0), arm=mx(1), obj=mx(2), hist=hist, flags=backend.download()["info"][3], oracles=oracles)
+
+
+def _bifurcation_explains(blob, solver, state, ctrl, qacc_kernel, trials=24, eps=1e-7, tol=EVENT_TOL):
+    """Does the oracle reproduce the kernel's acceleration at an input within `eps` of the shared state?"""
+    qpos, qvel, warm = state
+    rng = np.random.default_rng(12345)
+    scale = max(1.0, np.abs(qacc_kernel).max())
+    best = np.inf
+    for t in range(trials):
+        o = Oracle(blob)
+        o.set_option("solver", solver)
+        q = qpos.copy()
+        if t:
+            q += rng.normal(size=q.shape) * eps
+        o.arr("qpos")[:] = q; o.arr("qvel")[:] = qvel; o.arr("qacc_warmstart")[:] = warm
+        o.arr("ctrl")[: len(ctrl)] = ctrl
+        o.forward()
+        err = np.abs(o.arr("qacc") - qacc_kernel).max() / scale
+        best = min(best, err)
+        if err < tol:
+            return True, err
+    return False, best
+
+
+def state_synchronised(backend, blob, model, B, windows, seed, solver=2):
+    """Per-step comparison on identical inputs.  Returns (relative qacc errors [steps*B], events) where every event is a dict
+    with the step, the error and whether a 1e-7 perturbation of the oracle's input reproduces the kernel's result."""
+    oracles = settled_oracles(blob, B, solver)
+    nu, nv = oracles[0].dim("nu"), oracles[0].dim("nv")
+    sched = ctrl_schedule(model, nu, B, windows, seed)
+    rel, events = [], []
+    cstat = dict(n=0, depth=[], pos=[], cosn=[], mismatched_steps=0)   # contact geometry on identical states
+    for w in range(windows):
+        backend.set_ctrl(sched[w])
+        for b, o in enumerate(oracles):
+            o.arr("ctrl")[:nu] = sched[w][:, b]
+        for s in range(HOLD):
+            st = state_of(oracles)
+            backend.upload(*st)
+            backend.step(1)
+            out = backend.download()
+            for b, o in enumerate(oracles):
+                o.step(1)
+                qa = o.arr("qacc")
+                qk = out["qacc"][:nv, b]
+                r = np.abs(qk - qa).max() / max(1.0, np.abs(qa).max())
+                rel.append(r)
+                _compare_contacts(cstat, out["contacts"][:, b], int(out["info"][1, b]), o)
+                if r > EVENT_TOL or int(out["info"][1, b]) != o.ncon:
+                    ok, err = _bifurcation_explains(blob, solver, (st[0][:, b], st[1][:, b], st[2][:, b]), sched[w][:, b], qk)
+                    events.append(dict(env=b, window=w, step=s, rel=float(r), ncon_kernel=int(out["info"][1, b]), ncon_oracle=o.ncon,
+                                       explained=bool(ok), residual=float(err), flags=int(out["info"][3, b])))
+    state_synchronised.contacts = cstat
+    return np.array(rel), events
+
+
+def _compare_contacts(cstat, dump, ncon_k, o):
+    """Contact list of the kernel (debug slot: dist, pos, normal, condim | geom1 << 4 | geom2 << 14 per contact) against the
+    oracle's on the same state, contact by contact in list order (both emit in pair-table order)."""
+    n = o.ncon
+    ck = dump.reshape(16, 8)[:ncon_k]
+    co = o.arr("contact").reshape(n, -1) if n else np.zeros((0, 29))
+    code = ck[:, 7].astype(np.int64)
+    gk = [(int((c >> 4) & 1023), int(c >> 14)) for c in code]
+    go = [tuple(int(v) for v in co[k, -2:].copy().view(np.int32)[1:3]) for k in range(n)]
+    if gk != go:
+        cstat["mismatched_steps"] += 1
+        return
+    for k in range(n):
+        cstat["n"] += 1
+        cstat["depth"].append(abs(ck[k, 0] - co[k, 0]))
+        cstat["pos"].append(np.abs(ck[k, 1:4] - co[k, 1:4]).max())
+        cstat["cosn"].append(float(np.dot(ck[k, 4:7], co[k, 4:7])))
+
+
+class EmulBackend:
+    """The kernel source through the CPU lane emulator (tests/emul)."""
+
+    def __init__(self, blob, B, solver=2):
+        from emul.emul import Emul
+
+        o = Oracle(blob)
+        self.e = Emul(blob, dict(nq=o.dim("nq"), nv=o.dim("nv"), nu=o.dim("nu"), nlidar=360), num_envs=B, debug=True)
+        self.e.set_option("solver", solver)
+
+    def upload(self, qpos, qvel, warm):
+        self.e.qpos[:] = qpos; self.e.qvel[:] = qvel; self.e.warm[:] = warm
+
+    def set_ctrl(self, ctrl):
+        self.e.ctrl[:] = ctrl
+
+    def step(self, n):
+        self.e.step(n)
+
+    def download(self):
+        e = self.e
+        return dict(qpos=e.qpos.astype(np.float64), qvel=e.qvel.astype(np.float64), info=e.info.copy(),
+                    qacc=e.debug[1056:1056 + 32].astype(np.float64), contacts=e.debug[1600:1728].copy())
+
+
+class HipBackend:
+    """libsmj.so through StretchBatchSimulator (the C-ABI path)."""
+
+    def __init__(self, scene, B, solver=2):
+        import torch
+
+        from stretch_mujoco_amd import StretchBatchSimulator
+
+        self.torch = torch
+        self.sim = StretchBatchSimulator(num_envs=B, device="cuda:0", scene=scene, solver={0: "pgs", 2: "newton"}[solver], debug=True)
+        self.sim.start(home=False)
+
+    def _put(self, dst, a):
+        dst.copy_(self.torch.as_tensor(np.ascontiguousarray(a), dtype=self.torch.float32).to(dst.device))
+
+    def upload(self, qpos, qvel, warm):
+        self._put(self.sim.qpos, qpos); self._put(self.sim.qvel, qvel); self._put(self.sim.qacc_warmstart, warm)
+
+    def set_ctrl(self, ctrl):
+        self._put(self.sim.ctrl, ctrl)
+
+    def step(self, n):
+        self.sim.step(n)
+
+    def download(self):
+        s = self.sim
+        self.torch.cuda.synchronize()
+        return dict(qpos=s.qpos.cpu().numpy().astype(np.float64), qvel=s.qvel.cpu().numpy().astype(np.float64),
+                    info=s.info.cpu().numpy(), qacc=s.debug[1056:1056 + 32].cpu().numpy().astype(np.float64),
+                    contacts=s.debug[1600:1728].cpu().numpy())
+
+    def close(self):
+        self.sim.stop()

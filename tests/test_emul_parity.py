@@ -70,7 +70,8 @@ def test_reset_transient_stays_close(blob_fused):
 
 
 def _act_len(o):
-    o.forward()
+    """MjData.actuator_length after mj_step: the value of the step's forward pass (one step behind qpos) -- what pull_status
+    reads in the reference and what the kernel reports."""
     return o.arr("actuator_length").copy()
 
 
@@ -80,7 +81,7 @@ def test_sensors_and_readout(blob_fused):
     o.forward(); o.sensors(True)      # sensor values belong to the forward pass of the last step
     np.testing.assert_allclose(e.gyro[:, 0], o.arr("gyro"), atol=2e-5)
     np.testing.assert_allclose(e.accel[:, 0], o.arr("accel"), atol=5e-3)
-    o.step(1); o.forward()
+    o.step(1)    # MjData after mj_step: xpos / actuator_velocity of the step's forward pass
     x, y = o.arr("xpos")[1][:2]
     R = o.arr("xmat")[1]
     np.testing.assert_allclose(e.base[:, 0], [x, y, np.arctan2(R[3], R[0])], atol=2e-5)
@@ -213,7 +214,9 @@ def test_self_collision_contacts_match_the_oracle(blob_fused):
         assert (cosn[:5] > 0.9999).all() and (cosn > 0.0).all(), (k, cosn)
         loose += int((cosn < 0.95).sum()); checked += n
         seen_self += int(n > 5)
-        if (cosn > 0.9999).all() and np.abs(ce[:, 0] - co[:, 0]).max() < 1e-6:   # same contact frames and depths -> same dynamics
+        # same contact frames (within 0.03 degree: a servo-stiff contact turns 0.5 degree of normal into 5 % of a finger's
+        # acceleration) and depths -> same dynamics
+        if (cosn > 0.9999999).all() and np.abs(ce[:, 0] - co[:, 0]).max() < 1e-6:
             qa = o.arr("qacc")
             assert np.abs(e.debug[1056:1082, 0] - qa)[:18].max() < 2e-2 * max(1.0, np.abs(qa[:18]).max()), k
     assert seen_self > 20 and e.info[3, 0] == 0 and loose < 0.25 * checked, (seen_self, loose, checked)   # loose: per contact

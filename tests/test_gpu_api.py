@@ -1,0 +1,149 @@
+"""The host glue THROUGH the device path: the golden command sequences of the reference (tests/golden/glue_golden.json, captured
+from mujoco_server.push_command + BaseController) replayed through StretchBatchSimulator on cuda:0 -- commands issued through
+the public API, folded by `_push_command()` on the device, the controller ticked by the HIP kernel -- plus the API calls that
+had no test: pull_joint_limits, stow, home() clearing move_to, and the launch count with a base move in flight."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+with open(os.path.join(GOLDEN, "glue_golden.json")) as f:
+    G = json.load(f)
+
+
+def _sim(B, **kw):
+    from stretch_mujoco_amd import StretchBatchSimulator
+
+    sim = StretchBatchSimulator(num_envs=B, device="cuda:0", **kw)
+    sim.start(home=False)
+    return sim
+
+
+def _apply(sim, op, env):
+    if op[0] == "move_to":
+        sim.move_to(op[1], op[2], env_ids=[env])
+    elif op[0] == "move_by":
+        sim.move_by(op[1], op[2], env_ids=[env])
+    elif op[0] == "base_velocity":
+        sim.set_base_velocity(op[1], op[2], env_ids=[env])
+    else:
+        sim.glue.set_keyframe(op[1], env_ids=[env])   # home() / stow() without the settle loop
+
+
+def test_golden_push_command_sequences_on_the_device():
+    """Every golden scenario is one env of a batch; per tick the fixture's MjData values (actuator lengths, base pose) are
+    written into the simulator's readout tensors, the ops go through the public API, `_push_command()` folds them on the device
+    and the HIP controller tick runs -- the reference calls BaseController.update() after every push (mujoco_server.py:576).
+    ctrl and the controller mode must equal the reference's, tick by tick."""
+    scen = G["push_command"]
+    B, T = len(scen), max(len(s["ticks"]) for s in scen)
+    sim = _sim(B)
+    dev = sim.device
+    for k in range(T):
+        length = np.zeros((10, B), np.float32)
+        pose = np.zeros((3, B), np.float32)
+        for e, sc in enumerate(scen):
+            t = sc["ticks"][min(k, len(sc["ticks"]) - 1)]
+            length[:, e] = t["length"]; pose[:, e] = t["pose"]
+            if k < len(sc["ticks"]):
+                for op in t["ops"]:
+                    _apply(sim, op, e)
+        sim.actuator_length.copy_(torch.from_numpy(length).to(dev))
+        sim.base_pose.copy_(torch.from_numpy(pose).to(dev))
+        ticked = sim.glue.push_command(sim.ctrl, sim.actuator_length, sim.base_pose, tick_base=False)
+        assert isinstance(ticked, bool)
+        sim._L.smj_base_controller_tick(sim._ctx, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        ctrl = sim.ctrl.cpu().numpy()
+        mode = sim.glue.bc_mode.cpu().numpy()
+        start = sim.glue.bc_start.cpu().numpy()
+        for e, sc in enumerate(scen):
+            if k >= len(sc["ticks"]):
+                continue
+            exp = sc["expect"][k]
+            np.testing.assert_allclose(ctrl[:, e], exp["ctrl"], rtol=3e-6, atol=3e-6, err_msg=f"scenario {e} tick {k}")
+            assert int(mode[e]) == exp["mode"], f"scenario {e} tick {k}: controller mode"
+            if exp["mode"] != 0:
+                np.testing.assert_allclose(start[:, e], exp["start"], rtol=1e-6, atol=1e-6)
+    sim.stop()
+
+
+def test_base_move_in_flight_keeps_one_launch_per_step_call():
+    """A relative base move on ONE env of 4096 must not change how the batch is launched: the controller runs inside the step
+    kernel.  The moving env travels its increment and stops; its controller clears itself; everybody else stays put."""
+    from stretch_mujoco_amd import Actuators
+
+    B = 4096
+    sim = _sim(B)
+    sim.glue.set_keyframe("home")
+    sim.step(500)
+    x0, y0, th0 = [v.clone() for v in sim.get_base_pose()]
+    sim.move_by(Actuators.base_translate, 0.10, env_ids=[77])
+    sim.move_by(Actuators.base_rotate, -0.5, env_ids=[78])
+    before = sim.launches
+    for _ in range(8):
+        sim.step(250)
+    assert sim.launches - before == 8
+    x, y, th = sim.get_base_pose()
+    d = torch.sqrt((x - x0) ** 2 + (y - y0) ** 2)
+    # the wheel velocity servo realises 1/3 of the commanded speed (actuator_velocity = gear * qvel): 0.1 m/s
+    assert 0.095 < float(d[77]) < 0.12, float(d[77])
+    assert 0.49 < abs(float(th[78] - th0[78])) < 0.56, float(th[78] - th0[78])
+    others = torch.ones(B, dtype=torch.bool, device=sim.device); others[[77, 78]] = False
+    assert float(d[others].max()) < 2e-3 and float((th - th0)[others].abs().max()) < 2e-3
+    mode = sim.glue.bc_mode
+    assert int(mode[77]) == 0 and int(mode[78]) == 0 and int(mode.abs().sum()) == 0
+    assert float(sim.ctrl[:2, [77, 78]].abs().max()) == 0.0      # _clear_command(is_stop_motion=True): wheels stopped
+    # velocity mode keeps driving until told otherwise
+    sim.set_base_velocity(0.3, 0.0, env_ids=[5])
+    sim.step(500)
+    assert int(sim.glue.bc_mode[5]) == 3 and float(sim.get_base_pose()[0][5] - x[5]) > 0.05
+    sim.stop()
+
+
+def test_pull_joint_limits_matches_the_compiled_model():
+    """mujoco_server.py:281-291: {Actuators: (lo, hi)} from jnt_range, later joints of one actuator overwrite earlier ones.
+    The values are those of the reference's own dump of the compiled model (enums/actuators.py:70-89)."""
+    from stretch_mujoco_amd import Actuators
+
+    sim = _sim(2)
+    lim = sim.pull_joint_limits()
+    exp = {Actuators.lift: (0.0, 1.1), Actuators.arm: (0.0, 0.13), Actuators.wrist_yaw: (-1.39, 4.42), Actuators.wrist_pitch: (-1.57, 0.56),
+           Actuators.wrist_roll: (-3.14, 3.14), Actuators.gripper: (-0.02, 0.04), Actuators.head_pan: (-4.04, 1.73),
+           Actuators.head_tilt: (-1.53, 0.79)}
+    for a, (lo, hi) in exp.items():
+        assert lim[a] == pytest.approx((lo, hi), abs=6e-3), a
+    assert Actuators.left_wheel_vel in lim and Actuators.gripper_left_finger in lim   # every MJCF joint maps to an actuator
+    assert Actuators.base_translate not in lim
+    sim.stop()
+
+
+def test_stow_and_home_replace_the_command():
+    """home()/stow() install a brand-new command (stretch_mujoco_simulator.py:213-233): an earlier move_to target no longer
+    counts, is_reached_set_position is True again; stow drives to the 'stow' keyframe."""
+    from stretch_mujoco_amd import Actuators
+
+    sim = _sim(4)
+    sim.home()
+    sim.move_to(Actuators.lift, 1.0)
+    sim.step(5)
+    assert not bool(sim.is_reached_set_position(Actuators.lift).any())
+    sim.home()
+    assert bool(sim.is_reached_set_position(Actuators.lift).all())
+    t0 = float(sim.pull_status().time[0])
+    sim.stow()
+    st = sim.pull_status()
+    key = np.asarray(sim.model["key_ctrl"])[1]      # stretch.xml: keyframe 'stow'
+    assert torch.allclose(sim.ctrl[:, 0].cpu(), torch.tensor(key[:10], dtype=torch.float32))
+    assert float(st.time[0]) > t0
+    sim.step(2000)
+    st = sim.pull_status()
+    assert float(st.lift.pos[0]) == pytest.approx(key[2], abs=0.02)
+    assert float(st.wrist_pitch.pos[0]) == pytest.approx(key[5], abs=0.05)
+    sim.stop()

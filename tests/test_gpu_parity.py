@@ -138,7 +138,7 @@ def test_sensors_readout_and_status():
     np.testing.assert_allclose(s.base_gyro[0].cpu().numpy(), o.arr("gyro"), atol=1e-4)
     np.testing.assert_allclose(s.base_imu[0].cpu().numpy(), o.arr("accel"), atol=2e-2)
     np.testing.assert_allclose(s.lidar[0].cpu().numpy(), o.arr("lidar"), atol=1e-3)
-    o.step(1); o.forward()
+    o.step(1)    # status = MjData after mj_step: actuator_length / xpos of the step's forward pass (one step behind qpos)
     st = sim.pull_status()
     assert float(st.time[0]) == pytest.approx(0.6, abs=1e-9)
     assert float(st.lift.pos[0]) == pytest.approx(o.arr("actuator_length")[2], abs=1e-4)

@@ -1,0 +1,103 @@
+"""The BENCH workload (heterogeneous random ctrl every 50 steps, Newton) against the fp64 oracle, env by env: through the lane
+emulator on the CPU and through libsmj.so on the GPU (`-m gpu`).  Drift is reported separately for the arm coordinates and the
+driving base; one-step discrepancies above EVENT_TOL must be bifurcations of the reference algorithm itself
+(rollout_common.py)."""
+import numpy as np
+import pytest
+
+import rollout_common as rc
+import stretch_mujoco_amd.model_blob as mb
+from conftest import MODELS
+
+SCENES = ["stretch_empty", "stretch_kitchen_standin"]
+
+
+def _blob(scene):
+    with open(f"{MODELS}/{scene}.smjb", "rb") as f:
+        b = f.read()
+    return b, mb.loads(b)
+
+
+def _report(tag, r):
+    print(f"\n[{tag}] max qpos drift over the rollout, per env:")
+    print("   driving base:", np.array2string(r["base"], precision=1, floatmode="fixed", formatter={"float_kind": lambda v: f"{v:.1e}"}))
+    print("   arm         :", np.array2string(r["arm"], formatter={"float_kind": lambda v: f"{v:.1e}"}))
+    if r["obj"].any():
+        print("   free object :", np.array2string(r["obj"], formatter={"float_kind": lambda v: f"{v:.1e}"}))
+
+
+def _check_free_running(r, min_frac):
+    B = len(r["base"])
+    ok = (r["base"] < 1e-4) & (r["arm"] < 1e-4)
+    assert (r["flags"] == 0).all(), r["flags"]
+    # north_star: drift < 1e-4 over 1000 steps.  Envs that run into a bifurcation of the contact algorithm (see the
+    # state-synchronised test) leave that band; everything else must stay inside it.
+    assert ok.mean() >= min_frac, (ok.mean(), r["base"], r["arm"])
+    assert np.median(np.maximum(r["base"], r["arm"])) < 2e-5
+
+
+def _check_contacts():
+    """Contact geometry of the kernel vs the oracle on identical states (same list order, same geom pairs)."""
+    c = rc.state_synchronised.contacts
+    depth, pos, cosn = np.array(c["depth"]), np.array(c["pos"]), np.array(c["cosn"])
+    print(f"contacts compared: {c['n']} (steps with differing pair lists: {c['mismatched_steps']}); |ddist| p99 {np.percentile(depth, 99):.1e} "
+          f"max {depth.max():.1e}; |dpos| p99 {np.percentile(pos, 99):.1e} max {pos.max():.1e}; normals within 0.5 deg: {(cosn > 0.99996).mean():.4f}, "
+          f"within 20 deg: {(cosn > 0.94).mean():.4f}")
+    assert c["n"] > 500
+    assert np.percentile(depth, 99) < 2e-5 and np.percentile(pos, 99) < 5e-4
+    # faceted hull pairs: MPR's exit facet next to an edge / vertex is round-off sensitive (in fp64 too); everything else is tight
+    assert (cosn > 0.99996).mean() > 0.97 and (cosn > 0.0).mean() > 0.995
+
+
+def _check_events(rel, events):
+    print(f"\none-step relative qacc error over {len(rel)} env-steps: p50 {np.percentile(rel, 50):.1e} p99 {np.percentile(rel, 99):.1e} "
+          f"max {rel.max():.1e}; events {len(events)}")
+    for ev in events:
+        print("   ", ev)
+    assert np.percentile(rel, 99) < rc.TYPICAL_TOL
+    assert all(ev["flags"] == 0 for ev in events)
+    unexplained = [ev for ev in events if not ev["explained"]]
+    assert not unexplained, unexplained
+    assert len(events) <= 0.005 * len(rel) + 2
+
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_emul_random_ctrl_free_running(scene):
+    blob, model = _blob(scene)
+    be = rc.EmulBackend(blob, 6)
+    r = rc.free_running(be, blob, model, 6, 10, seed=11)
+    _report(f"emulator {scene}", r)
+    _check_free_running(r, 0.6)
+
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_emul_state_synchronised_steps(scene):
+    blob, model = _blob(scene)
+    be = rc.EmulBackend(blob, 4)
+    rel, events = rc.state_synchronised(be, blob, model, 4, 5, seed=5)
+    _check_events(rel, events)
+    _check_contacts()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", SCENES)
+def test_gpu_random_ctrl_free_running_1000_steps(scene):
+    """16 heterogeneous envs x 1000 steps of the bench's action schedule on the HIP path, each against its own oracle."""
+    blob, model = _blob(scene)
+    be = rc.HipBackend(scene, 16)
+    r = rc.free_running(be, blob, model, 16, 20, seed=7)
+    be.close()
+    _report(f"HIP {scene}", r)
+    _check_free_running(r, 0.7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", SCENES)
+def test_gpu_state_synchronised_steps(scene):
+    """8 envs x 400 steps with the oracle's state uploaded before every step: per-step errors and explained events."""
+    blob, model = _blob(scene)
+    be = rc.HipBackend(scene, 8)
+    rel, events = rc.state_synchronised(be, blob, model, 8, 8, seed=3)
+    be.close()
+    _check_events(rel, events)
+    _check_contacts()

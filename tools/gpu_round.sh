@@ -3,8 +3,8 @@
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/gpu_round.sh'
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
+timeout 1500 python -m pytest tests -m gpu -x -q -s > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
 tail -4 gpurun_out/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log; tail -2 gpurun_out/smoke.log
 timeout 900 python bench.py > gpurun_out/bench.log 2>&1; tail -1 gpurun_out/bench.log > gpurun_out/bench_latest.json; cut -c1-400 gpurun_out/bench_latest.json
-bash tools/gpu_profile.sh | tail -2
+if [ "$1" != "noprof" ]; then bash tools/gpu_profile.sh | tail -2; fi
