@@ -6,8 +6,19 @@
 #include "smj_model.h"
 
 // One batch-major array [rows][ld] (4-byte words) <-> words off..off+rows of every env's staging row
+// (a run of at most 128 rows: one LDS tile per block)
 struct StageSeg { void* ptr; int rows, off; };
-struct StagePlan { StageSeg seg[16]; int nseg = 0; void add(void* p, int rows, int off) { if (p && rows > 0) seg[nseg++] = StageSeg{p, rows, off}; } };
+struct StagePlan {
+  StageSeg seg[24];
+  int row0[24] = {};   // first row of the run inside its array
+  int nseg = 0;
+  void add(void* p, int rows, int off) {
+    for (int r0 = 0; p && r0 < rows && nseg < 24; r0 += 128) {
+      seg[nseg] = StageSeg{p, rows - r0 < 128 ? rows - r0 : 128, off + r0};
+      row0[nseg++] = r0;
+    }
+  }
+};
 
 void smj_launch_step(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);
 void smj_launch_reset(const DevModel& m, const DevState& s, const uint8_t* mask, hipStream_t stream);

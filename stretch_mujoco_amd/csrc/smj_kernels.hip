@@ -28,34 +28,29 @@ __global__ __launch_bounds__(256) void smj_reset_kernel(const DevModel M, const 
   for (int k = 0; k < 4; k++) S.info[k * S.ld + e] = 0;
 }
 
-// Staging transposes.  A block moves 64 envs: rows of the batch-major array are read / written with lanes = envs (256-byte
-// coalesced runs), the env-major rows with lanes = consecutive words; the tile turns in LDS (row stride 65: conflict-free).
+// Staging transposes.  A block moves one tile: 64 envs x up to 128 rows of one batch-major array (blockIdx.y = tile).  Rows of
+// the batch-major array are read / written with lanes = envs (256-byte coalesced runs), the env-major rows with lanes =
+// consecutive words; the tile turns in LDS (row stride 65: conflict-free).
 __global__ __launch_bounds__(256) void smj_stage_kernel(const StagePlan P, float* stage, int B, long ld, int is_export) {
   __shared__ float tile[128][65];
-  const int t = threadIdx.x, w = t >> 6, l = t & 63, env0 = blockIdx.x * 64;
-  for (int sg = 0; sg < P.nseg; sg++) {
-    float* arr = static_cast<float*>(P.seg[sg].ptr);
-    const int rows = P.seg[sg].rows, off = P.seg[sg].off;
-    for (int r0 = 0; r0 < rows; r0 += 128) {
-      const int nr = rows - r0 < 128 ? rows - r0 : 128;
-      if (!is_export) {
-        for (int k = w; k < nr; k += 4) tile[k][l] = env0 + l < B ? arr[(long)(r0 + k) * ld + env0 + l] : 0.f;
-        __syncthreads();
-        for (int idx = t; idx < 64 * nr; idx += 256) {
-          const int e = idx / nr, k = idx - e * nr;
-          if (env0 + e < B) stage[(size_t)(env0 + e) * SMJ_ST_STRIDE + off + r0 + k] = tile[k][e];
-        }
-      } else {
-        for (int idx = t; idx < 64 * nr; idx += 256) {
-          const int e = idx / nr, k = idx - e * nr;
-          if (env0 + e < B) tile[k][e] = stage[(size_t)(env0 + e) * SMJ_ST_STRIDE + off + r0 + k];
-        }
-        __syncthreads();
-        for (int k = w; k < nr; k += 4)
-          if (env0 + l < B) arr[(long)(r0 + k) * ld + env0 + l] = tile[k][l];
-      }
-      __syncthreads();
+  const int t = threadIdx.x, w = t >> 6, l = t & 63, env0 = blockIdx.x * 64, sg = blockIdx.y;
+  float* arr = static_cast<float*>(P.seg[sg].ptr) + (long)P.row0[sg] * ld;
+  const int nr = P.seg[sg].rows, off = P.seg[sg].off;
+  if (!is_export) {
+    for (int k = w; k < nr; k += 4) tile[k][l] = env0 + l < B ? arr[(long)k * ld + env0 + l] : 0.f;
+    __syncthreads();
+    for (int idx = t; idx < 64 * nr; idx += 256) {
+      const int e = idx / nr, k = idx - e * nr;
+      if (env0 + e < B) stage[(size_t)(env0 + e) * SMJ_ST_STRIDE + off + k] = tile[k][e];
     }
+  } else {
+    for (int idx = t; idx < 64 * nr; idx += 256) {
+      const int e = idx / nr, k = idx - e * nr;
+      if (env0 + e < B) tile[k][e] = stage[(size_t)(env0 + e) * SMJ_ST_STRIDE + off + k];
+    }
+    __syncthreads();
+    for (int k = w; k < nr; k += 4)
+      if (env0 + l < B) arr[(long)k * ld + env0 + l] = tile[k][l];
   }
 }
 
@@ -83,7 +78,7 @@ __global__ __launch_bounds__(256) void smj_base_tick_kernel(const DevState S) {
 
 void smj_launch_stage(const StagePlan& plan, float* stage, int B, long ld, bool is_export, hipStream_t stream) {
   if (plan.nseg == 0) return;
-  hipLaunchKernelGGL(smj_stage_kernel, dim3((B + 63) / 64), dim3(256), 0, stream, plan, stage, B, ld, is_export ? 1 : 0);
+  hipLaunchKernelGGL(smj_stage_kernel, dim3((B + 63) / 64, plan.nseg), dim3(256), 0, stream, plan, stage, B, ld, is_export ? 1 : 0);
 }
 void smj_launch_base_tick(const DevState& s, hipStream_t stream) {
   hipLaunchKernelGGL(smj_base_tick_kernel, dim3((s.B + 255) / 256), dim3(256), 0, stream, s);

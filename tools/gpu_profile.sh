@@ -1,15 +1,22 @@
 #!/bin/bash
-# rocprofv3 evidence for the bench command: kernel-trace stats, then PMC passes in their own runs.
+# rocprofv3 evidence: kernel-trace stats of the bench command, then PMC passes in their own runs (never combined with the
+# sys / hip / hsa trace domains); the same for the ray-casting kernels (tools/gpu_render_prof.py).
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
 CMD="python bench.py --no-second-solver --no-cpu-baseline --no-extra"
 $CMD > gpurun_out/prof/bench_plain.log 2>&1; tail -1 gpurun_out/prof/bench_plain.log | cut -c1-300
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/trace -o smj -- $CMD > gpurun_out/prof/bench_trace.log 2>&1
-rocprofv3 -L > gpurun_out/prof/counters_list.txt 2>&1
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   tag=$(echo $C | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/prof/pmc_$tag -o smj -- $CMD > gpurun_out/prof/pmc_$tag.log 2>&1
   echo "pmc $tag rc=$?"
 done
-find gpurun_out/prof -name "*.csv" | head -40
+RCMD="python tools/gpu_render_prof.py"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/rtrace -o smj -- $RCMD > gpurun_out/prof/render_trace.log 2>&1
+for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
+  tag=$(echo $C | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/prof/rpmc_$tag -o smj -- $RCMD > gpurun_out/prof/rpmc_$tag.log 2>&1
+  echo "render pmc $tag rc=$?"
+done
+find gpurun_out/prof -name "*.csv" | wc -l

@@ -9,8 +9,48 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 KERNEL = "smj_step_kernel"
+
+
+def render_summary(out):
+    """Ray-casting kernels (tools/gpu_render_prof.py): stats + per-kernel PMC means."""
+    path = os.path.join(SRC, "rtrace", "smj_kernel_stats.csv")
+    if not os.path.exists(path):
+        return
+    out.append("\n## Ray-casting kernels: `rocprofv3 --kernel-trace --stats -- python tools/gpu_render_prof.py` (kitchen stand-in, 4096 envs, both depth cameras + lidar)\n")
+    out.append("| kernel | calls | total ms | avg ms | % | min ms | max ms |\n|---|---|---|---|---|---|---|")
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if any(k in r["Name"] for k in ("smj_depth", "smj_lidar", "smj_stage", "smj_base")):
+                out.append(f"| `{r['Name'][:50]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e6:.3f} | {float(r['Percentage']):.2f} | {float(r['MinNs'])/1e6:.3f} | {float(r['MaxNs'])/1e6:.3f} |")
+    per = collections.defaultdict(dict)
+    for d in sorted(glob.glob(os.path.join(SRC, "rpmc_*", "smj_counter_collection.csv"))):
+        acc = collections.defaultdict(list)
+        with open(d) as f:
+            for r in csv.DictReader(f):
+                for kn in ("smj_depth_kernel", "smj_depth_prepass", "smj_lidar_kernel"):
+                    if kn in r["Kernel_Name"]:
+                        acc[(kn, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (kn, cn), v in acc.items():
+            v = v[2:] if kn == "smj_depth_kernel" and len(v) > 4 else v   # skip the two one-off camera-static layer renders
+            per[kn][cn] = sum(v) / len(v)
+    out.append("\nPMC means per dispatch (separate `--pmc` passes):\n")
+    names = sorted({c for k in per.values() for c in k})
+    out.append("| counter | " + " | ".join(per.keys()) + " |\n|---|" + "---|" * len(per))
+    for c in names:
+        out.append(f"| {c} | " + " | ".join(f"{per[k].get(c, float('nan')):.4g}" for k in per) + " |")
+    for kn, v in per.items():
+        bits = []
+        if "SQ_THREAD_CYCLES_VALU" in v and v.get("SQ_ACTIVE_INST_VALU"):
+            bits.append(f"VALU lane utilisation {v['SQ_THREAD_CYCLES_VALU'] / (64 * v['SQ_ACTIVE_INST_VALU']):.2f}")
+        if v.get("SQ_BUSY_CYCLES") and v.get("SQ_ACTIVE_INST_VALU"):
+            bits.append(f"VALU-active / wave-cycles {v['SQ_ACTIVE_INST_VALU'] / max(1.0, 4 * v.get('SQ_WAVE_CYCLES', 1)):.2f}")
+        if v.get("TCC_HIT_sum") is not None and (v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0)) > 0:
+            bits.append(f"L2 hit rate {v['TCC_HIT_sum'] / (v['TCC_HIT_sum'] + v['TCC_MISS_sum']):.3f}")
+        if "FETCH_SIZE" in v or "WRITE_SIZE" in v:
+            bits.append(f"HBM: FETCH_SIZE {v.get('FETCH_SIZE', 0) * 1024 / 1e6:.1f} MB (x2 for wide streams), WRITE_SIZE {v.get('WRITE_SIZE', 0) * 1024 / 1e6:.1f} MB per dispatch")
+        out.append(f"\n`{kn}`: " + "; ".join(bits))
 
 
 def main():
@@ -29,7 +69,7 @@ def main():
         tr = [r for r in csv.DictReader(f) if KERNEL in r["Kernel_Name"]]
     dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in tr]
     out.append(f"\nPer-dispatch durations of `{KERNEL}` (ms): {[round(x, 1) for x in dur]}")
-    out.append("(dispatches 1-10: settle at the home keyframe; 11-12 warm-up; 13-22 the timed region with random ctrl)")
+    out.append("(dispatches 1-10: settle at the home keyframe; 11-14 untimed random-action pre-roll; 15-16 warm-up; the last 10 the timed region)")
     timed = dur[-10:]
     out.append(f"Timed-region average: **{sum(timed)/len(timed):.2f} ms** per launch of 4096 envs x 50 steps "
                f"(bench.py reports the same launches from HIP events).")
@@ -53,13 +93,14 @@ def main():
             out.append(f"| {name} | {vals[name]:.4g} | {min(v):.4g} | {max(v):.4g} |")
     fetch, write = vals.get("FETCH_SIZE", 0) * 1024, vals.get("WRITE_SIZE", 0) * 1024
     alg = 672 * 4096 * 50
-    out.append(f"\nHBM traffic per launch: FETCH_SIZE {fetch/1e6:.1f} MB + WRITE_SIZE {write/1e6:.1f} MB = {(fetch+write)/1e6:.1f} MB "
-               f"(KB counters x 1024, MI355X_MICROARCH.md section HBM).  The guide's x2 FETCH_SIZE correction is calibrated for wide "
-               f"coalesced streams; this kernel issues narrow strided loads, so both are given: uncorrected {(fetch+write)/1e6:.1f} MB, "
-               f"with x2 on the read side {(2*fetch+write)/1e6:.1f} MB.  Algorithmic bytes per launch (672 B x 4096 envs x 50 steps) = "
-               f"{alg/1e6:.1f} MB: measured traffic is " + ("BELOW it because the state stays in LDS for the 50 steps of a launch "
-               "(the writes are mostly per-lane scratch of dynamically indexed arrays)." if 2 * fetch + write < alg else
-               "ABOVE it: register spills / scratch arrays are being written back -- reduce them."))
+    moved = (672 + 92 + 4 * 12 * 20) * 4096   # state in + out, joint readout, body poses of the last step: what one launch moves
+    out.append(f"\nHBM traffic per launch (3 dispatches: import transposes, `smj_step_kernel`, export transposes; the step kernel's "
+               f"share is listed): FETCH_SIZE {fetch/1e6:.2f} MB + WRITE_SIZE {write/1e6:.2f} MB = {(fetch+write)/1e6:.2f} MB "
+               f"(KB counters x 1024, MI355X_MICROARCH.md section HBM; with the guide's x2 on the read side {(2*fetch+write)/1e6:.2f} MB).  "
+               f"Algorithmic bytes per launch (672 B x 4096 envs x 50 steps) = {alg/1e6:.1f} MB; the state stays in LDS for the 50 "
+               f"steps of a launch, so what a launch has to move is {moved/1e6:.2f} MB (state in and out once, readout, body poses).  "
+               f"The step kernel reads and writes contiguous env-major rows (DevState::stage); round 1 measured 60.7 MB per launch with "
+               f"lane = dim accesses on the batch-major arrays.")
     wc, busy = vals.get("SQ_WAVE_CYCLES", 0), vals.get("SQ_BUSY_CYCLES", 0)
     if wc:
         out.append(f"\nIssue mix per launch: VALU {vals.get('SQ_INSTS_VALU',0):.3g}, SALU {vals.get('SQ_INSTS_SALU',0):.3g}, LDS {vals.get('SQ_INSTS_LDS',0):.3g}, "
@@ -75,6 +116,9 @@ def main():
                    "hbm_bytes_per_launch": 2 * fetch + write, "fetch_bytes_raw": fetch, "write_bytes_raw": write,
                    "source": f"profiles/{TAG}_rocprof_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                              f"timed-region launches; read side x2 per MI355X_MICROARCH.md section HBM)"}, f, indent=1)
+    render_summary(out)
+    with open(os.path.join(DST, f"{TAG}_rocprof_summary.md"), "w") as f:
+        f.write("\n".join(out) + "\n")
     for name in ("smj_kernel_stats.csv", "smj_domain_stats.csv"):
         src = os.path.join(SRC, "trace", name)
         if os.path.exists(src):
