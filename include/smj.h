@@ -47,7 +47,8 @@ enum smj_slot {
 enum smj_dim {
   SMJ_DIM_NQ = 0, SMJ_DIM_NV = 1, SMJ_DIM_NU = 2, SMJ_DIM_NBODY = 3, SMJ_DIM_NLIDAR = 4, SMJ_DIM_NKEY = 5,
   SMJ_DIM_NUM_ENVS = 6, SMJ_DIM_DEBUG_FLOATS = 7, SMJ_DIM_NEFC_MAX = 8, SMJ_DIM_NCON_MAX = 9, SMJ_DIM_NCAM = 10,
-  SMJ_DIM_COUNT = 11
+  SMJ_DIM_NV_MAX = 11,   /* dof capacity of the kernel variant chosen for this model: 32 (standard) or 64 (big) */
+  SMJ_DIM_COUNT = 12
 };
 
 /* readout flags for smj_step */
@@ -84,7 +85,8 @@ int smj_step(smj_ctx* ctx, int nsteps, unsigned read_flags, void* stream);
 int smj_base_controller_tick(smj_ctx* ctx, void* stream);
 
 /* Solver / collision options (mjOption fields): "iterations", "tolerance", "warmstart", "pgs_fixed_iter",
- * "max_contacts_per_pair". */
+ * "max_contacts_per_pair", "solver" (0 PGS, 2 Newton), "convex_pairs", "multiccd" (mjENBL_MULTICCD, stretch.xml:8; default on), "escalate" (default on: an env whose step needs more constraint rows / contacts
+ * than the standard kernel variant holds is finished by the big variant instead of being flagged). */
 int smj_set_option(smj_ctx* ctx, const char* name, double value);
 
 /* Depth image of camera `camera_id` (index into the model's cameras, stretch.xml order: d405_rgb, d405_depth,

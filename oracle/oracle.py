@@ -47,6 +47,8 @@ def lib():
         L.smjo_get_int.restype = ctypes.POINTER(ctypes.c_int)
         L.smjo_get_int.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
         L.smjo_dim.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+        L.smjo_set_contacts.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.smjo_set_contacts.restype = None
         _LIB = L
     return _LIB
 
@@ -124,6 +126,12 @@ class Oracle:
 
     def step(self, n: int = 1):
         self.L.smjo_step_n(self.m, self.d, n)
+
+    def set_contacts(self, con: np.ndarray):
+        """The next forward()/step() uses these contacts [n, 9] = (dist, pos3, normal3, geom1, geom2) instead of its own
+        collision stage (one-shot): dynamics on identical contacts."""
+        con = np.ascontiguousarray(con, np.float64).reshape(-1, 9)
+        self.L.smjo_set_contacts(self.d, len(con), con.ctypes.data_as(ctypes.c_void_p))
 
     def render_depth(self, cam: int, width: int, height: int, fovy_deg: float, max_depth: float = 0.0) -> np.ndarray:
         """Depth image [height, width] (fp32) of camera `cam` from the poses of the last forward()/step()."""

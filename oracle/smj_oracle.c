@@ -59,6 +59,7 @@ struct smjo_model {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, ncam, neq, ntendon, nwrap, nkey, npair, nhullvert, nlidar;
   double timestep, gravity[3], impratio, tolerance, meaninertia, lidar_cutoff;
   int iterations, cone, warmstart, pgs_fixed_iter, max_con_pair, solver, ls_iterations;
+  int multiccd;      /* stretch.xml:8 <flag multiccd="enable"/>: multi-point contacts for convex pairs (default on) */
   double ls_tolerance;
   int *body_parentid, *body_weldid, *body_rootid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum;
   double *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_gravcomp, *body_invweight0,
@@ -98,6 +99,10 @@ typedef struct {
 
 struct smjo_data {
   int nv, ncon, nefc, ne, nf, solver_niter, ncon_dropped;
+  /* tests: contact list handed in from outside (smjo_set_contacts) replaces the collision stage of the next forward pass,
+   * so that the DYNAMICS can be compared on identical contacts even where MPR's portal facet differs (curved rims, vertices) */
+  int override_ncon;
+  double* override_con;   /* per contact: dist, pos[3], normal[3], geom1, geom2 */
   double time;
   double *qpos, *qvel, *ctrl, *qacc_warmstart, *qacc, *qacc_smooth, *qfrc_bias, *qfrc_passive, *qfrc_actuator,
       *qfrc_smooth, *qfrc_constraint, *qfrc_applied;
@@ -139,7 +144,7 @@ smjo_model* smjo_load(const void* blob, size_t nbytes) {
   ti = blob_i32(b, "sensor_imu_site", NULL); m->imu_site = ti[0]; free(ti);
   m->lidar_site = blob_i32(b, "sensor_lidar_site", &m->nlidar);
   m->lidar_static = blob_f64(b, "sensor_lidar_static", NULL);
-  m->warmstart = 1; m->pgs_fixed_iter = 0; m->max_con_pair = 4; m->solver = 0; m->ls_iterations = 50; m->ls_tolerance = 0.01;
+  m->warmstart = 1; m->pgs_fixed_iter = 0; m->max_con_pair = 4; m->solver = 0; m->ls_iterations = 50; m->ls_tolerance = 0.01; m->multiccd = 1;
   LOADI(body_parentid); LOADI(body_weldid); LOADI(body_rootid); LOADI(body_jntadr); LOADI(body_jntnum);
   LOADI(body_dofadr); LOADI(body_dofnum);
   LOADF(body_pos); LOADF(body_quat); LOADF(body_ipos); LOADF(body_iquat); LOADF(body_mass); LOADF(body_inertia);
@@ -191,6 +196,7 @@ int smjo_set_option(smjo_model* m, const char* name, double v) {
   else if (!strcmp(name, "max_contacts_per_pair")) m->max_con_pair = (int)v;
   else if (!strcmp(name, "solver")) m->solver = (int)v; /* 0 = PGS (north_star), 2 = Newton (the reference model's default) */
   else if (!strcmp(name, "convex_pairs")) m->convex_pairs = (int)v;
+  else if (!strcmp(name, "multiccd")) m->multiccd = (int)v;
   else if (!strcmp(name, "timestep")) m->timestep = v;
   else if (!strcmp(name, "gravity_z")) m->gravity[2] = v;
   else if (!strcmp(name, "impratio")) m->impratio = v;
@@ -234,6 +240,7 @@ smjo_data* smjo_make_data(const smjo_model* m) {
   d->actuator_length = dalloc(m->nu); d->actuator_velocity = dalloc(m->nu); d->actuator_moment = dalloc(m->nu * nv);
   d->actuator_force = dalloc(m->nu);
   d->contact = (contact_t*)calloc(MAXCON, sizeof(contact_t));
+  d->override_ncon = -1; d->override_con = NULL;
   d->efc_J = dalloc((size_t)MAXEFC * nv); d->efc_pos = dalloc(MAXEFC); d->efc_margin = dalloc(MAXEFC);
   d->efc_D = dalloc(MAXEFC); d->efc_R = dalloc(MAXEFC); d->efc_aref = dalloc(MAXEFC); d->efc_b = dalloc(MAXEFC);
   d->efc_force = dalloc(MAXEFC); d->efc_vel = dalloc(MAXEFC); d->efc_KBIP = dalloc(4 * MAXEFC);
@@ -975,6 +982,175 @@ static int sphere_sphere(const double* p1, double r1, const double* p2, double r
   for (int i = 0; i < 3; i++) { rc->normal[i] = dif[i]; rc->pos[i] = p1[i] + dif[i] * (r1 + 0.5 * rc->dist); }
   return 1;
 }
+
+/* ------------------------------------------------------------------ box-box, multi-point convex contacts
+ * [MJ] mjc_BoxBox (engine_collision_box.c) and the multiccd branch of mjc_Convex (engine_collision_convex.c).  MuJoCo's
+ * sources are not available here; what follows restates their published behaviour -- separating-axis test over the 15 axes,
+ * a face contact clipped to a polygon of up to 8 points with one depth each, a single point for an edge-edge contact; for
+ * other convex pairs the first contact is followed by four more penetration queries with the two geoms counter-rotated by a
+ * small angle about the tangent axes -- NOT their line-by-line arithmetic (see the header: parity unpinned).  The kernel
+ * (csrc/smj_step_impl.h box_box / convex_multi) implements exactly this formulation. */
+#define BOXBOX_FUDGE 1.05          /* face axes are preferred over edge axes by this factor (as in ODE's dBoxBox) */
+#define MULTICCD_ANGLE 1e-3        /* counter-rotation of the two geoms, radians */
+#define MULTICCD_RELTOL 1e-3       /* new contacts closer than this x min(rbound) to an earlier one are duplicates */
+
+static int box_box(const double* p1, const double* R1, const double* A, const double* p2, const double* R2, const double* B,
+                   double margin, int maxcon, rawcon* rc) {
+  double p[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, R[3][3], Q[3][3], pp[3], pq[3];
+  for (int i = 0; i < 3; i++) {
+    const double ai[3] = {R1[i], R1[3 + i], R1[6 + i]};
+    pp[i] = dot3(p, ai);
+    for (int j = 0; j < 3; j++) { const double bj[3] = {R2[j], R2[3 + j], R2[6 + j]}; R[i][j] = dot3(ai, bj); Q[i][j] = fabs(R[i][j]); }
+  }
+  for (int j = 0; j < 3; j++) { const double bj[3] = {R2[j], R2[3 + j], R2[6 + j]}; pq[j] = dot3(p, bj); }
+  /* separating axes: codes 0-2 faces of box 1, 3-5 faces of box 2, 6-14 edge i of box 1 x edge j of box 2 */
+  double best = -1e300;
+  int code = -1;
+  for (int i = 0; i < 3; i++) {
+    const double s = fabs(pp[i]) - (A[i] + B[0] * Q[i][0] + B[1] * Q[i][1] + B[2] * Q[i][2]);
+    if (s > margin) return 0;
+    if (s > best) { best = s; code = i; }
+  }
+  for (int j = 0; j < 3; j++) {
+    const double s = fabs(pq[j]) - (B[j] + A[0] * Q[0][j] + A[1] * Q[1][j] + A[2] * Q[2][j]);
+    if (s > margin) return 0;
+    if (s > best) { best = s; code = 3 + j; }
+  }
+  double en[3] = {0, 0, 0};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const double l = sqrt(fmax(0.0, 1.0 - R[i][j] * R[i][j]));
+      if (l < 1e-6) continue;                 /* parallel edges: covered by the face axes */
+      const double e = pp[i2] * R[i1][j] - pp[i1] * R[i2][j];
+      const double s = (fabs(e) - (A[i1] * Q[i2][j] + A[i2] * Q[i1][j] + B[j1] * Q[i][j2] + B[j2] * Q[i][j1])) / l;
+      if (s > margin) return 0;
+      if (s * BOXBOX_FUDGE > best && s > best) {
+        best = s; code = 6 + 3 * i + j;
+        const double ai[3] = {R1[i], R1[3 + i], R1[6 + i]}, bj[3] = {R2[j], R2[3 + j], R2[6 + j]};
+        cross3(en, ai, bj);
+        for (int k = 0; k < 3; k++) en[k] /= l;
+      }
+    }
+  if (code >= 6) {   /* edge-edge: one point, midway between the closest points of the two edges */
+    double n[3] = {en[0], en[1], en[2]};
+    if (dot3(n, p) < 0) for (int k = 0; k < 3; k++) n[k] = -n[k];
+    const int i = (code - 6) / 3, j = (code - 6) % 3;
+    double pa[3] = {p1[0], p1[1], p1[2]}, pb[3] = {p2[0], p2[1], p2[2]};
+    for (int k = 0; k < 3; k++) {
+      const double ak[3] = {R1[k], R1[3 + k], R1[6 + k]}, bk[3] = {R2[k], R2[3 + k], R2[6 + k]};
+      const double sa = dot3(n, ak) > 0 ? 1.0 : -1.0, sb = dot3(n, bk) > 0 ? -1.0 : 1.0;
+      for (int x = 0; x < 3; x++) { pa[x] += sa * A[k] * ak[x]; pb[x] += sb * B[k] * bk[x]; }
+    }
+    const double ua[3] = {R1[i], R1[3 + i], R1[6 + i]}, ub[3] = {R2[j], R2[3 + j], R2[6 + j]};
+    const double dd[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+    const double uaub = dot3(ua, ub), q1 = dot3(ua, dd), q2 = -dot3(ub, dd), den = 1.0 - uaub * uaub;
+    double al = 0, be = 0;
+    if (den > 1e-12) { al = (q1 + uaub * q2) / den; be = (uaub * q1 + q2) / den; }
+    for (int x = 0; x < 3; x++) { rc[0].pos[x] = 0.5 * ((pa[x] + al * ua[x]) + (pb[x] + be * ub[x])); rc[0].normal[x] = n[x]; }
+    rc[0].dist = best;
+    return 1;
+  }
+  /* face contact.  Reference box a (the one owning the axis), incident box b; n from a to b */
+  const int swap = code >= 3, ia = swap ? code - 3 : code;
+  const double *pa = swap ? p2 : p1, *Ra = swap ? R2 : R1, *ha = swap ? B : A, *pb = swap ? p1 : p2, *Rb = swap ? R1 : R2, *hb = swap ? A : B;
+  double n[3] = {Ra[ia], Ra[3 + ia], Ra[6 + ia]}, ab[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+  if (dot3(n, ab) < 0) for (int k = 0; k < 3; k++) n[k] = -n[k];
+  const int ja = (ia + 1) % 3, ka = (ia + 2) % 3;
+  const double u[3] = {Ra[ja], Ra[3 + ja], Ra[6 + ja]}, v[3] = {Ra[ka], Ra[3 + ka], Ra[6 + ka]}, hu = ha[ja], hv = ha[ka];
+  double cA[3];
+  for (int k = 0; k < 3; k++) cA[k] = pa[k] + n[k] * ha[ia];
+  /* incident face: the face of b most anti-parallel to n */
+  int ib = 0;
+  double bd = -1;
+  for (int k = 0; k < 3; k++) { const double bk[3] = {Rb[k], Rb[3 + k], Rb[6 + k]}; const double t = fabs(dot3(bk, n)); if (t > bd) { bd = t; ib = k; } }
+  double nb[3] = {Rb[ib], Rb[3 + ib], Rb[6 + ib]};
+  if (dot3(nb, n) > 0) for (int k = 0; k < 3; k++) nb[k] = -nb[k];
+  const int jb = (ib + 1) % 3, kb = (ib + 2) % 3;
+  const double pv[3] = {Rb[jb], Rb[3 + jb], Rb[6 + jb]}, qv[3] = {Rb[kb], Rb[3 + kb], Rb[6 + kb]}, hp = hb[jb], hq = hb[kb];
+  double cB[3], w[4][3], wu[4], wv[4];
+  for (int k = 0; k < 3; k++) cB[k] = pb[k] + nb[k] * hb[ib];
+  static const double sg[4][2] = {{-1, -1}, {1, -1}, {1, 1}, {-1, 1}};   /* counter-clockwise corner order */
+  for (int c = 0; c < 4; c++) {
+    double d[3];
+    for (int k = 0; k < 3; k++) { w[c][k] = cB[k] + sg[c][0] * hp * pv[k] + sg[c][1] * hq * qv[k]; d[k] = w[c][k] - cA[k]; }
+    wu[c] = dot3(d, u); wv[c] = dot3(d, v);
+  }
+  const double nnb = dot3(n, nb);   /* < 0 */
+  /* 24 candidates in a fixed order: 4 incident corners inside the reference face, 4 reference corners inside the incident
+   * face, 16 crossings of an incident edge with a reference edge.  Each is a point x on the incident face with depth below
+   * the reference face; the contact sits midway between the two surfaces. */
+  double cx[24][3], cdepth[24], cu[24], cv[24];
+  int cok[24], nok = 0;
+  for (int cand = 0; cand < 24; cand++) {
+    double x[3] = {0, 0, 0};
+    int ok = 0;
+    if (cand < 4) {
+      ok = fabs(wu[cand]) <= hu && fabs(wv[cand]) <= hv;
+      memcpy(x, w[cand], 24);
+    } else if (cand < 8) {
+      const int c = cand - 4;
+      double r[3], d[3];
+      for (int k = 0; k < 3; k++) { r[k] = cA[k] + sg[c][0] * hu * u[k] + sg[c][1] * hv * v[k]; d[k] = cB[k] - r[k]; }
+      const double t = dot3(d, nb) / nnb;
+      for (int k = 0; k < 3; k++) { x[k] = r[k] + t * n[k]; d[k] = x[k] - cB[k]; }
+      ok = fabs(dot3(d, pv)) < hp && fabs(dot3(d, qv)) < hq;
+    } else {
+      const int e = (cand - 8) / 4, r = (cand - 8) % 4, c0 = e, c1 = (e + 1) % 4;   /* incident edge e, reference edge r */
+      const int along_u = r < 2;                         /* r = 0,1: the lines u = -hu, +hu; r = 2,3: v = -hv, +hv */
+      const double lim = (r & 1 ? 1.0 : -1.0) * (along_u ? hu : hv);
+      const double a0 = along_u ? wu[c0] : wv[c0], a1 = along_u ? wu[c1] : wv[c1], b0 = along_u ? wv[c0] : wu[c0], b1 = along_u ? wv[c1] : wu[c1];
+      const double den = a1 - a0;
+      if (fabs(den) > 1e-12) {
+        const double t = (lim - a0) / den, o = b0 + t * (b1 - b0);
+        ok = t > 0 && t < 1 && fabs(o) < (along_u ? hv : hu);
+        for (int k = 0; k < 3; k++) x[k] = w[c0][k] + t * (w[c1][k] - w[c0][k]);
+      }
+    }
+    const double d[3] = {x[0] - cA[0], x[1] - cA[1], x[2] - cA[2]};
+    cdepth[cand] = -dot3(d, n); cu[cand] = dot3(d, u); cv[cand] = dot3(d, v);
+    if (-cdepth[cand] > margin) ok = 0;
+    cok[cand] = ok; nok += ok;
+    memcpy(cx[cand], x, 24);
+  }
+  /* more points than max_contacts_per_pair: keep the extreme ones along the two axes of the reference face (ties: lowest
+   * candidate), a support polygon as wide as the full one */
+  if (nok > maxcon) {
+    int keep[24] = {0}, pick[4] = {-1, -1, -1, -1};
+    for (int cand = 0; cand < 24; cand++) {
+      if (!cok[cand]) continue;
+      if (pick[0] < 0 || cu[cand] < cu[pick[0]]) pick[0] = cand;
+      if (pick[1] < 0 || cu[cand] > cu[pick[1]]) pick[1] = cand;
+      if (pick[2] < 0 || cv[cand] < cv[pick[2]]) pick[2] = cand;
+      if (pick[3] < 0 || cv[cand] > cv[pick[3]]) pick[3] = cand;
+    }
+    for (int k = 0; k < 4; k++) keep[pick[k]] = 1;
+    for (int cand = 0; cand < 24; cand++) cok[cand] = cok[cand] && keep[cand];
+  }
+  int cnt = 0;
+  for (int cand = 0; cand < 24 && cnt < 8; cand++) {
+    if (!cok[cand]) continue;
+    rc[cnt].dist = -cdepth[cand];
+    for (int k = 0; k < 3; k++) { rc[cnt].pos[k] = cx[cand][k] + 0.5 * cdepth[cand] * n[k]; rc[cnt].normal[k] = swap ? -n[k] : n[k]; }
+    cnt++;
+  }
+  return cnt;
+}
+
+/* rotate a pose about the point c by the rotation matrix Rm */
+static void rotate_pose(double* pos, double* mat, const double* c, const double* Rm) {
+  double d[3] = {pos[0] - c[0], pos[1] - c[1], pos[2] - c[2]}, r[3], t[9];
+  mulmat3vec(r, Rm, d);
+  for (int k = 0; k < 3; k++) pos[k] = c[k] + r[k];
+  mulmat3(t, Rm, mat);
+  memcpy(mat, t, 72);
+}
+static void axis_angle_mat(double* Rm, const double* ax, double ang) {
+  const double c = cos(ang), s = sin(ang), t = 1 - c, x = ax[0], y = ax[1], z = ax[2];
+  Rm[0] = t * x * x + c; Rm[1] = t * x * y - s * z; Rm[2] = t * x * z + s * y;
+  Rm[3] = t * x * y + s * z; Rm[4] = t * y * y + c; Rm[5] = t * y * z - s * x;
+  Rm[6] = t * x * z - s * y; Rm[7] = t * y * z + s * x; Rm[8] = t * z * z + c;
+}
 static int convex_pair(const smjo_model* m, const smjo_data* d, int g1, int g2, double margin, rawcon* rc) {
   if (!obb_overlap(m, d, g1, g2, margin)) return 0;
   {
@@ -987,6 +1163,9 @@ static int convex_pair(const smjo_model* m, const smjo_data* d, int g1, int g2, 
       for (int i = 0; i < 3; i++) rc->normal[i] = -rc->normal[i]; /* the contact keeps the pair's geom order */
       return 1;
     }
+    if (t1 == G_BOX && t2 == G_BOX && m->multiccd)
+      return box_box(x1, d->geom_xmat + 9 * g1, m->geom_size + 3 * g1, x2, d->geom_xmat + 9 * g2, m->geom_size + 3 * g2, margin,
+                     m->max_con_pair < 4 ? 4 : m->max_con_pair, rc);
   }
   mprctx c;
   c.m = m;
@@ -1003,13 +1182,66 @@ static int convex_pair(const smjo_model* m, const smjo_data* d, int g1, int g2, 
   if (!mpr_penetration(&c, cen[0], cen[1], &depth, dir, pos)) return 0;
   if (-depth > margin) return 0;
   rc->dist = -depth; memcpy(rc->normal, dir, 24); memcpy(rc->pos, pos, 24);
-  return 1;
+  int n = 1;
+  if (!m->multiccd || dot3(dir, dir) < 0.5 || c.type[0] == G_SPHERE || c.type[1] == G_SPHERE) return n;
+  /* multiccd: counter-rotate the two geoms by +-angle about the two tangent axes through the first contact point and query
+   * again; keep contacts that are not duplicates.  Order: axis 1 (+, -), axis 2 (+, -). */
+  double fr[9] = {dir[0], dir[1], dir[2], 0, 0, 0, 0, 0, 0};
+  make_frame(fr);
+  const double tol = MULTICCD_RELTOL * fmin(m->geom_rbound[g1], m->geom_rbound[g2]);
+  for (int q = 0; q < 4; q++) {
+    const double* ax = fr + 3 * (1 + q / 2);
+    const double ang = (q & 1) ? -MULTICCD_ANGLE : MULTICCD_ANGLE;
+    double Rp[9], Rn[9], pos2[2][3], mat2[2][9], cen2[2][3];
+    axis_angle_mat(Rp, ax, ang); axis_angle_mat(Rn, ax, -ang);
+    mprctx c2 = c;
+    for (int k = 0; k < 2; k++) {
+      memcpy(pos2[k], c.pos[k], 24); memcpy(mat2[k], c.mat[k], 72); memcpy(cen2[k], cen[k], 24);
+      rotate_pose(pos2[k], mat2[k], rc[0].pos, k ? Rn : Rp);
+      double dum[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      rotate_pose(cen2[k], dum, rc[0].pos, k ? Rn : Rp);
+      c2.pos[k] = pos2[k]; c2.mat[k] = mat2[k];
+    }
+    double dp, dr[3], ps[3];
+    if (!mpr_penetration(&c2, cen2[0], cen2[1], &dp, dr, ps)) continue;
+    if (-dp > margin || dot3(dr, dr) < 0.5) continue;
+    int dup = 0;
+    for (int k = 0; k < n; k++) {
+      const double e[3] = {ps[0] - rc[k].pos[0], ps[1] - rc[k].pos[1], ps[2] - rc[k].pos[2]};
+      if (dot3(e, e) < tol * tol) dup = 1;
+    }
+    if (dup) continue;
+    rc[n].dist = -dp; memcpy(rc[n].normal, dir, 24); memcpy(rc[n].pos, ps, 24);   /* the manifold shares the first normal */
+    n++;
+  }
+  return n;
 }
 
 /* [MJ] mj_collision: static pair table (built by the model compiler with MuJoCo's filters) ->
  * bounding-sphere rejection -> narrowphase by type pair */
 static void collision(const smjo_model* m, smjo_data* d) {
   d->ncon = 0; d->ncon_dropped = 0;
+  if (d->override_ncon >= 0) {   /* contacts given by the test (smjo_set_contacts): one-shot */
+    for (int i = 0; i < d->override_ncon && d->ncon < MAXCON; i++) {
+      const double* v = d->override_con + 9 * i;
+      const int g1 = (int)v[7], g2 = (int)v[8];
+      int p = -1;
+      for (int k = 0; k < m->npair && p < 0; k++)
+        if (m->pair_geom1[k] == g1 && m->pair_geom2[k] == g2) p = k;
+      if (p < 0) continue;
+      contact_t* c = d->contact + d->ncon++;
+      c->dist = v[0]; memcpy(c->pos, v + 1, 24); memcpy(c->frame, v + 4, 24);
+      c->frame[3] = c->frame[4] = c->frame[5] = 0;
+      make_frame(c->frame);
+      c->dim = m->pair_condim[p]; c->geom1 = g1; c->geom2 = g2;
+      memcpy(c->friction, m->pair_friction + 5 * p, 40); memcpy(c->solref, m->pair_solref + 2 * p, 16);
+      memcpy(c->solimp, m->pair_solimp + 5 * p, 40);
+      c->includemargin = m->pair_margin[p] - m->pair_gap[p];
+      c->efc_address = -1;
+    }
+    d->override_ncon = -1;
+    return;
+  }
   for (int p = 0; p < m->npair; p++) {
     int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], t1 = m->geom_type[g1], t2 = m->geom_type[g2];
     double margin = m->pair_margin[p];
@@ -1730,6 +1962,13 @@ static void fwd_constraint_newton(const smjo_model* m, smjo_data* d) {
 }
 
 /* ------------------------------------------------------------------ forward */
+void smjo_set_contacts(smjo_data* d, int n, const double* con /* n x (dist, pos3, normal3, geom1, geom2) */) {
+  free(d->override_con);
+  d->override_con = (double*)malloc(sizeof(double) * 9 * (n > 0 ? n : 1));
+  memcpy(d->override_con, con, sizeof(double) * 9 * n);
+  d->override_ncon = n;
+}
+
 void smjo_forward(const smjo_model* m, smjo_data* d) {
   int nv = m->nv;
   kinematics(m, d);

@@ -26,6 +26,8 @@ void smjo_free_data(smjo_data* d);
 
 void smjo_reset(const smjo_model* m, smjo_data* d);          /* qpos=qpos0, qvel=0, ctrl=0, time=0 */
 void smjo_forward(const smjo_model* m, smjo_data* d);        /* mj_forward */
+/* tests: the next forward pass takes these contacts instead of running its collision stage (one-shot) */
+void smjo_set_contacts(smjo_data* d, int n, const double* con /* n x (dist, pos[3], normal[3], geom1, geom2) */);
 void smjo_step(const smjo_model* m, smjo_data* d);           /* mj_step (implicitfast + PGS) */
 void smjo_step_n(const smjo_model* m, smjo_data* d, int n);
 void smjo_sensors(const smjo_model* m, smjo_data* d, int with_lidar); /* gyro, accel, lidar into d */

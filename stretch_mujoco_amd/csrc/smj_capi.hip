@@ -26,7 +26,16 @@ struct smj_ctx {
   std::vector<void*> allocs;
   std::string err;
   float* qpos0_dev = nullptr;
-  float* stage = nullptr;      // env-major staging copy of the state, [num_envs][SMJ_ST_STRIDE] (DevState::stage)
+  float* stage = nullptr;      // env-major staging copy of the state, [num_envs][layout.stride] (DevState::stage)
+  int variant = 0;             // 0: standard step kernel, 1: big (smj_model.h)
+  // capacity escalation (standard variant): the model once more with the big variant's records, and the list of parked envs
+  DevModel model_big{};
+  bool has_big = false;
+  int* redo = nullptr;
+  int escalate = 1;
+  SmjCaps caps{};              // capacities of the variant in use
+  SmjStageLayout layout{};     // staging-row layout of the variant in use
+  int debug_floats = 0;
   DevRender render{};
   bool has_render = false;
   float* pose_ws = nullptr;
@@ -207,15 +216,32 @@ int smj_create(const void* blob, size_t nbytes, int num_envs, int device, smj_ct
   c->num_envs = num_envs;
   HIPCHK(c, hipSetDevice(device));
   DeviceUploader up{c};
-  int rc = smj_load_model(blob, nbytes, c->model, up, c->err);
+  SmjCaps caps[2] = {{NVP, NBP, NENT, NEFC, NCON}, {}};
+  int big_debug = 0;
+  smj_big_caps(&caps[1].nvp, &caps[1].nbp, &caps[1].nent, &caps[1].nefc, &caps[1].ncon, &big_debug);
+  int rc = smj_load_model(blob, nbytes, c->model, up, c->err, caps, 2, &c->variant);
   if (rc) return rc;
+  c->caps = caps[c->variant];
+  c->layout = smj_stage_layout(c->caps.nvp, c->caps.nbp);
+  if (c->variant == 0) {   // escalation target: the same model loaded for the big variant (its own per-lane records)
+    int dummy = 0;
+    rc = smj_load_model(blob, nbytes, c->model_big, up, c->err, caps + 1, 1, &dummy);
+    if (rc) return rc;
+    c->has_big = true;
+    void* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, sizeof(int) * (1 + 2 * (size_t)num_envs)));
+    c->allocs.push_back(d);
+    HIPCHK(c, hipMemset(d, 0, sizeof(int)));
+    c->redo = (int*)d;
+  }
+  c->debug_floats = c->variant ? big_debug : SMJ_DEBUG_FLOATS;
   DevModel& m = c->model;
   c->qpos0_dev = const_cast<float*>(m.qpos0);
   c->state.B = num_envs;
   c->state.ld = num_envs;
   {
     void* d = nullptr;
-    const size_t bytes = sizeof(float) * (size_t)SMJ_ST_STRIDE * (size_t)num_envs;
+    const size_t bytes = sizeof(float) * (size_t)c->layout.stride * (size_t)num_envs;
     HIPCHK(c, hipMalloc(&d, bytes));
     c->allocs.push_back(d);
     HIPCHK(c, hipMemset(d, 0, bytes));
@@ -308,8 +334,8 @@ int smj_dims(const smj_ctx* c, int* out) {
   if (!c || !out) return -1;
   out[SMJ_DIM_NQ] = c->model.nq; out[SMJ_DIM_NV] = c->model.nv; out[SMJ_DIM_NU] = c->model.nu;
   out[SMJ_DIM_NBODY] = c->model.nbody; out[SMJ_DIM_NLIDAR] = c->model.nlidar; out[SMJ_DIM_NKEY] = c->model.nkey;
-  out[SMJ_DIM_NUM_ENVS] = c->num_envs; out[SMJ_DIM_DEBUG_FLOATS] = SMJ_DEBUG_FLOATS; out[SMJ_DIM_NEFC_MAX] = NEFC;
-  out[SMJ_DIM_NCON_MAX] = NCON; out[SMJ_DIM_NCAM] = c->has_render ? c->render.ncam : 0;
+  out[SMJ_DIM_NUM_ENVS] = c->num_envs; out[SMJ_DIM_DEBUG_FLOATS] = c->debug_floats; out[SMJ_DIM_NEFC_MAX] = c->caps.nefc;
+  out[SMJ_DIM_NCON_MAX] = c->caps.ncon; out[SMJ_DIM_NV_MAX] = c->caps.nvp; out[SMJ_DIM_NCAM] = c->has_render ? c->render.ncam : 0;
   return 0;
 }
 
@@ -398,17 +424,36 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
   // batch-major slots -> env-major staging rows, the step kernel on contiguous rows, and back (smj_model.h, DevState::stage)
   const DevModel& m = c->model;
   StagePlan in, out;
-  in.add(st.qpos, m.nq, SMJ_ST_QPOS); in.add(st.qvel, m.nv, SMJ_ST_QVEL); in.add(st.warm, m.nv, SMJ_ST_WARM);
-  in.add(st.ctrl, m.nu, SMJ_ST_CTRL); in.add(st.bctl, SMJ_BC_ROWS, SMJ_ST_BCTL); in.add(st.nstep, 1, SMJ_ST_NSTEP);
-  in.add(st.info, 4, SMJ_ST_INFO);
+  const SmjStageLayout& Y = c->layout;
+  in.add(st.qpos, m.nq, Y.qpos); in.add(st.qvel, m.nv, Y.qvel); in.add(st.warm, m.nv, Y.warm);
+  in.add(st.ctrl, m.nu, Y.ctrl); in.add(st.bctl, SMJ_BC_ROWS, Y.bctl); in.add(st.nstep, 1, Y.nstep);
+  in.add(st.info, 4, Y.info);
   out = in;
-  out.add(st.act_len, m.nu, SMJ_ST_ACTLEN); out.add(st.act_vel, m.nu, SMJ_ST_ACTVEL); out.add(st.base, 3, SMJ_ST_BASE);
-  if (read_flags & SMJ_READ_IMU) { out.add(st.gyro, 3, SMJ_ST_GYRO); out.add(st.accel, 3, SMJ_ST_ACCEL); }
-  if (read_flags & SMJ_READ_POSES) out.add(st.xpose, 12 * m.nbody, SMJ_ST_XPOSE);
+  out.add(st.act_len, m.nu, Y.actlen); out.add(st.act_vel, m.nu, Y.actvel); out.add(st.base, 3, Y.base);
+  if (read_flags & SMJ_READ_IMU) { out.add(st.gyro, 3, Y.gyro); out.add(st.accel, 3, Y.accel); }
+  if (read_flags & SMJ_READ_POSES) out.add(st.xpose, 12 * m.nbody, Y.xpose);
   st.stage = c->stage;
-  smj_launch_stage(in, c->stage, c->num_envs, st.ld, false, (hipStream_t)stream);
-  smj_launch_step(c->model, st, nsteps, read_flags, (hipStream_t)stream);
-  smj_launch_stage(out, c->stage, c->num_envs, st.ld, true, (hipStream_t)stream);
+  st.lay = Y;
+  const bool esc = c->variant == 0 && c->has_big && c->escalate && c->model.solver == 2;
+  st.redo = esc ? c->redo : nullptr;
+  st.redo_worker = 0;
+  if (esc) HIPCHK(c, hipMemsetAsync(c->redo, 0, sizeof(int), (hipStream_t)stream));
+  smj_launch_stage(in, c->stage, Y.stride, c->num_envs, st.ld, false, (hipStream_t)stream);
+  int lrc = c->variant ? smj_launch_step_big(c->model, st, nsteps, read_flags, (hipStream_t)stream)
+                       : smj_launch_step(c->model, st, nsteps, read_flags, (hipStream_t)stream);
+  if (!lrc && esc) {
+    // envs that ran out of constraint rows / contact slots were parked at the start of the offending step: the big variant
+    // (64 dofs / 160 rows / 48 contacts) finishes their steps; a launch without such envs finds the list empty and returns
+    DevModel& mb = c->model_big;
+    const DevModel& ms = c->model;
+    mb.iterations = ms.iterations; mb.warmstart = ms.warmstart; mb.pgs_fixed_iter = ms.pgs_fixed_iter; mb.max_con_pair = ms.max_con_pair;
+    mb.solver = ms.solver; mb.ls_iterations = ms.ls_iterations; mb.convex_pairs = ms.convex_pairs; mb.multiccd = ms.multiccd;
+    mb.ls_tolerance = ms.ls_tolerance; mb.tolerance = ms.tolerance;
+    st.redo_worker = 1;
+    lrc = smj_launch_step_big(mb, st, nsteps, read_flags, (hipStream_t)stream);
+  }
+  if (lrc) return fail(c, -2, "step kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  smj_launch_stage(out, c->stage, Y.stride, c->num_envs, st.ld, true, (hipStream_t)stream);
   HIPCHK(c, hipGetLastError());
   if (read_flags & SMJ_READ_LIDAR) {
     smj_launch_lidar(c->render, st.xpose, pose_ld, c->num_envs, st.lidar, st.ld, (hipStream_t)stream);
@@ -474,6 +519,8 @@ int smj_set_option(smj_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "max_contacts_per_pair")) m.max_con_pair = (int)v;
   else if (!strcmp(name, "solver")) m.solver = (int)v;
   else if (!strcmp(name, "convex_pairs")) m.convex_pairs = (int)v;
+  else if (!strcmp(name, "multiccd")) m.multiccd = (int)v;
+  else if (!strcmp(name, "escalate")) c->escalate = (int)v;
   else return fail(c, -1, "unknown option '%s'", name);
   return 0;
 }

@@ -20,10 +20,13 @@ struct StagePlan {
   }
 };
 
-void smj_launch_step(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);
+// the two capacity variants of the step kernel (smj_model.h); return 0 or a hipError_t
+int smj_launch_step(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);
+int smj_launch_step_big(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);
+void smj_big_caps(int* nvp, int* nbp, int* nent, int* nefc, int* ncon, int* debug_floats);
 void smj_launch_reset(const DevModel& m, const DevState& s, const uint8_t* mask, hipStream_t stream);
 // batch-major -> env-major staging rows (import) and back (export); tiles of 64 envs transposed through LDS
-void smj_launch_stage(const StagePlan& plan, float* stage, int B, long ld, bool is_export, hipStream_t stream);
+void smj_launch_stage(const StagePlan& plan, float* stage, int stride, int B, long ld, bool is_export, hipStream_t stream);
 // one BaseController.update() on the bound BASE_POSE / BASECTL / CTRL arrays (lane = env); the same device function the
 // step kernel runs after every step
 void smj_launch_base_tick(const DevState& s, hipStream_t stream);

@@ -2,17 +2,7 @@
 // workgroup per wavefront; the per-environment working set (body tree, mass-matrix factor, constraint
 // Jacobian, A = J M^-1 J' + R) lives in LDS for the whole launch, model constants stream from L2.
 #include "smj_kernels.h"
-#include "smj_step_impl.h"
-
-__global__ __launch_bounds__(64) void smj_step_kernel(const DevModel M, const DevState S, int nsteps, unsigned read_flags) {
-  // dynamic LDS: a Newton launch asks for sizeof(Smem), a PGS launch for the extra tail that holds A (smj_lds_bytes)
-  extern __shared__ __align__(16) unsigned char smj_lds[];
-  Smem& smem = *reinterpret_cast<Smem*>(smj_lds);
-  const int env = blockIdx.x;
-  if (env >= S.B) return;
-  StepKernel k(M, S, smem, env);
-  k.run(nsteps, read_flags);
-}
+#include "smj_step_tu.h"   // the standard variant of the step kernel (smj_kernels_big.hip compiles the big one)
 
 // mj_resetData for masked envs: batch-major, lanes = envs (coalesced)
 __global__ __launch_bounds__(256) void smj_reset_kernel(const DevModel M, const DevState S, const uint8_t* mask) {
@@ -31,7 +21,7 @@ __global__ __launch_bounds__(256) void smj_reset_kernel(const DevModel M, const 
 // Staging transposes.  A block moves one tile: 64 envs x up to 128 rows of one batch-major array (blockIdx.y = tile).  Rows of
 // the batch-major array are read / written with lanes = envs (256-byte coalesced runs), the env-major rows with lanes =
 // consecutive words; the tile turns in LDS (row stride 65: conflict-free).
-__global__ __launch_bounds__(256) void smj_stage_kernel(const StagePlan P, float* stage, int B, long ld, int is_export) {
+__global__ __launch_bounds__(256) void smj_stage_kernel(const StagePlan P, float* stage, int stride, int B, long ld, int is_export) {
   __shared__ float tile[128][65];
   const int t = threadIdx.x, w = t >> 6, l = t & 63, env0 = blockIdx.x * 64, sg = blockIdx.y;
   float* arr = static_cast<float*>(P.seg[sg].ptr) + (long)P.row0[sg] * ld;
@@ -41,12 +31,12 @@ __global__ __launch_bounds__(256) void smj_stage_kernel(const StagePlan P, float
     __syncthreads();
     for (int idx = t; idx < 64 * nr; idx += 256) {
       const int e = idx / nr, k = idx - e * nr;
-      if (env0 + e < B) stage[(size_t)(env0 + e) * SMJ_ST_STRIDE + off + k] = tile[k][e];
+      if (env0 + e < B) stage[(size_t)(env0 + e) * stride + off + k] = tile[k][e];
     }
   } else {
     for (int idx = t; idx < 64 * nr; idx += 256) {
       const int e = idx / nr, k = idx - e * nr;
-      if (env0 + e < B) tile[k][e] = stage[(size_t)(env0 + e) * SMJ_ST_STRIDE + off + k];
+      if (env0 + e < B) tile[k][e] = stage[(size_t)(env0 + e) * stride + off + k];
     }
     __syncthreads();
     for (int k = w; k < nr; k += 4)
@@ -76,15 +66,12 @@ __global__ __launch_bounds__(256) void smj_base_tick_kernel(const DevState S) {
   S.bctl[SMJ_BC_MODE * ld + e] = (float)next;
 }
 
-void smj_launch_stage(const StagePlan& plan, float* stage, int B, long ld, bool is_export, hipStream_t stream) {
+void smj_launch_stage(const StagePlan& plan, float* stage, int stride, int B, long ld, bool is_export, hipStream_t stream) {
   if (plan.nseg == 0) return;
-  hipLaunchKernelGGL(smj_stage_kernel, dim3((B + 63) / 64, plan.nseg), dim3(256), 0, stream, plan, stage, B, ld, is_export ? 1 : 0);
+  hipLaunchKernelGGL(smj_stage_kernel, dim3((B + 63) / 64, plan.nseg), dim3(256), 0, stream, plan, stage, stride, B, ld, is_export ? 1 : 0);
 }
 void smj_launch_base_tick(const DevState& s, hipStream_t stream) {
   hipLaunchKernelGGL(smj_base_tick_kernel, dim3((s.B + 255) / 256), dim3(256), 0, stream, s);
-}
-void smj_launch_step(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream) {
-  hipLaunchKernelGGL(smj_step_kernel, dim3(s.B), dim3(64), smj_lds_bytes(m.solver != 2), stream, m, s, nsteps, read_flags);
 }
 void smj_launch_reset(const DevModel& m, const DevState& s, const uint8_t* mask, hipStream_t stream) {
   hipLaunchKernelGGL(smj_reset_kernel, dim3((s.B + 255) / 256), dim3(256), 0, stream, m, s, mask);

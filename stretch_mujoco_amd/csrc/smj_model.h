@@ -4,10 +4,24 @@
 #pragma once
 #include <stdint.h>
 
-#define NVP 32   // dof capacity (model nv <= NVP)
+// Two capacity variants of the step kernel are compiled from the same source (smj_kernels.hip / smj_kernels_big.hip):
+//   standard -- the robot alone or with ONE free object: 32 dofs, 80 constraint rows, 16 contacts; 40 KB of LDS per env,
+//               four envs per CU;
+//   big (SMJ_BIG) -- scenes with several free objects (the reference's own scene.xml: table + 2 objects; kitchens):
+//               64 dofs, 160 rows, 48 contacts; ~130 KB of LDS per env, one env per CU.
+// smj_create picks the variant from the model's dimensions.
+#ifdef SMJ_BIG
+#define NVP 64    // dof capacity (model nv <= NVP)
+#define NEFC 160  // constraint-row capacity of the Newton path: rows 64.. take further passes on lanes 0..63 (PGS: 64)
+#define NCON 48   // contact capacity (<= 64: contact stages are lane = contact)
+#define NENT 8    // mass-matrix pattern entries per lane (64 lanes)
+#else
+#define NVP 32
+#define NEFC 80
+#define NCON 16
+#define NENT 5
+#endif
 #define NBP 32   // fused-body capacity
-#define NEFC 80  // constraint-row capacity of the Newton path: rows 64..79 take a second pass on lanes 0..15 (PGS: 64)
-#define NCON 16  // contact capacity
 #define NCG 128  // geoms that take part in non-plane collision pairs (world-frame cache of the broadphase)
 
 #define SMJ_MODEL_I32(X)                                                                                          \
@@ -39,6 +53,7 @@ struct DevModel {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, neq, npair, nlevel, nfric, nlimit, nplanepair, nldl, nlidar, imu_site,
       ngc, nroot, nkey, ncgeom, nconvpair, njump, maxsubtree;
   int iterations, warmstart, pgs_fixed_iter, max_con_pair, solver /* 0 PGS, 2 Newton */, ls_iterations, convex_pairs;
+  int multiccd;   // stretch.xml:8 <flag multiccd="enable"/>: multi-point contacts for convex pairs (box-box polygon, counter-rotated queries)
   float ls_tolerance;
   float timestep, gravity[3], impratio, tolerance, meaninertia, lidar_cutoff;
 #define X(n) const int* n;
@@ -61,12 +76,15 @@ struct DevModel {
   const int* k_cprec;     // [nconvpair][SMJ_CP_STRIDE]
 };
 enum { SMJ_CP_PAIR = 0, SMJ_CP_G1, SMJ_CP_G2, SMJ_CP_S1, SMJ_CP_S2, SMJ_CP_MARGIN, SMJ_CP_MG, SMJ_CP_CONDIM, SMJ_CP_FRIC = 8, SMJ_CP_SOLIMP = 13,
-       SMJ_CP_SOLREF = 18, SMJ_CP_STRIDE = 20 };
+       SMJ_CP_SOLREF = 18, SMJ_CP_RBMIN = 20 /* min bounding radius of the two geoms (multiccd duplicate tolerance) */, SMJ_CP_STRIDE = 24 };
 // row record: type, id (equality / dof / joint), dofs (limit: dof, side), qpos addresses, reference values (equality: qpos0 of
 // both joints; limit: range bound of the side, margin), equality polynomial, diagonal approximation, friction loss, solref, solimp
 enum { SMJ_RR_TYPE = 0, SMJ_RR_ID, SMJ_RR_D1, SMJ_RR_D2, SMJ_RR_Q1, SMJ_RR_Q2, SMJ_RR_V1, SMJ_RR_V2, SMJ_RR_DATA = 8, SMJ_RR_DIAG = 13,
        SMJ_RR_FLOSS = 14, SMJ_RR_SOLREF = 15, SMJ_RR_SOLIMP = 17, SMJ_RR_USED = 22, SMJ_RR_STRIDE = 24 };
-enum { SMJ_LR_KIN = 0, SMJ_LR_BODY = 36, SMJ_LR_DOF = 60, SMJ_LR_ENT = 76, SMJ_LR_ACT = 112, SMJ_LR_STRIDE = 140 };
+// per-lane stage record: KinTab 36 words, BodyTab 24, DofTab 16, EntryTab 7 arrays of `nent` slots (padded to 4 words), ActTab 28
+constexpr int smj_lr_act(int nent) { return 76 + ((7 * nent + 3) & ~3); }
+constexpr int smj_lr_stride(int nent) { return smj_lr_act(nent) + 28; }
+enum { SMJ_LR_KIN = 0, SMJ_LR_BODY = 36, SMJ_LR_DOF = 60, SMJ_LR_ENT = 76, SMJ_LR_ACT = smj_lr_act(NENT), SMJ_LR_STRIDE = smj_lr_stride(NENT) };
 // plane-pair record: pair, geom1 (the plane), geom2, their bodies, geom2 type, margin, geom2 bounding radius / centre,
 // local frames of both geoms, geom2 size, then the contact parameters of the pair
 enum { SMJ_PP_PAIR = 0, SMJ_PP_G1, SMJ_PP_G2, SMJ_PP_B1, SMJ_PP_B2, SMJ_PP_T2, SMJ_PP_MARGIN, SMJ_PP_RBOUND2, SMJ_PP_BCEN2 = 8,
@@ -78,6 +96,18 @@ enum { SMJ_PP_PAIR = 0, SMJ_PP_G1, SMJ_PP_G2, SMJ_PP_B1, SMJ_PP_B2, SMJ_PP_T2, S
 enum { SMJ_CG_GEOM = 0, SMJ_CG_BODY, SMJ_CG_META, SMJ_CG_POS = 3, SMJ_CG_MAT = 6, SMJ_CG_LCEN = 15, SMJ_CG_HALF = 18, SMJ_CG_CCEN = 21,
        SMJ_CG_SIZE = 24, SMJ_CG_STRIDE = 28 };
 
+// layout of one env's staging row (4-byte words); a function of the variant's capacities, so that host code compiled once
+// (smj_capi.hip) can address the rows of either kernel variant
+struct SmjStageLayout {
+  int qpos, qvel, warm, ctrl, bctl, nstep, info, actlen, actvel, base, gyro, accel, xpose, stride;
+};
+constexpr SmjStageLayout smj_stage_layout(int nvp, int nbp) {
+  SmjStageLayout L{};
+  L.qpos = 0; L.qvel = L.qpos + nvp + 8; L.warm = L.qvel + nvp; L.ctrl = L.warm + nvp; L.bctl = L.ctrl + 16; L.nstep = L.bctl + 8;
+  L.info = L.nstep + 4; L.actlen = L.info + 4; L.actvel = L.actlen + 16; L.base = L.actvel + 16; L.gyro = L.base + 4;
+  L.accel = L.gyro + 4; L.xpose = L.accel + 4; L.stride = L.xpose + 12 * nbp;
+  return L;
+}
 // Batch-major simulator state bound through smj_bind() (include/smj.h).  ld = row stride in elements (>= B).
 struct DevState {
   int B;           // environments in this context
@@ -103,17 +133,15 @@ struct DevState {
   // arrays every lane of a load / store touches its own 64-byte sector.  smj_step therefore runs import (batch-major ->
   // env-major, tiles transposed through LDS, both sides coalesced), the step kernel on contiguous 512-byte rows, export.
   float* stage;
+  SmjStageLayout lay;   // word offsets inside a staging row (those of the context's primary kernel variant)
+  // Capacity escalation (standard variant only; null = off): an env whose step needs more than the variant's constraint rows /
+  // contacts stops BEFORE that step, leaves its state as of the start of the step in the staging row and appends
+  // (env, steps done) to this list -- [0] = count, then pairs; the big variant then finishes the env's steps (smj_step).
+  int* redo;
+  int redo_worker;      // the launch is the big variant working the list off: env = redo[1 + 2 i], steps already done redo[2 + 2 i]
 };
 // BaseController state rows (floats; mode: 0 none, 1 translate-by, 2 rotate-by, 3 velocity)
 enum { SMJ_BC_MODE = 0, SMJ_BC_X0, SMJ_BC_Y0, SMJ_BC_TH0, SMJ_BC_INC, SMJ_BC_V, SMJ_BC_W, SMJ_BC_ROWS = 8 };
-// layout of one env's staging row (4-byte words)
-enum {
-  SMJ_ST_QPOS = 0, SMJ_ST_QVEL = SMJ_ST_QPOS + NVP + 8, SMJ_ST_WARM = SMJ_ST_QVEL + NVP, SMJ_ST_CTRL = SMJ_ST_WARM + NVP,
-  SMJ_ST_BCTL = SMJ_ST_CTRL + 16, SMJ_ST_NSTEP = SMJ_ST_BCTL + 8, SMJ_ST_INFO = SMJ_ST_NSTEP + 4, SMJ_ST_ACTLEN = SMJ_ST_INFO + 4,
-  SMJ_ST_ACTVEL = SMJ_ST_ACTLEN + 16, SMJ_ST_BASE = SMJ_ST_ACTVEL + 16, SMJ_ST_GYRO = SMJ_ST_BASE + 4, SMJ_ST_ACCEL = SMJ_ST_GYRO + 4,
-  SMJ_ST_XPOSE = SMJ_ST_ACCEL + 4, SMJ_ST_STRIDE = SMJ_ST_XPOSE + 12 * NBP
-};
-static_assert(SMJ_ST_STRIDE % 4 == 0, "staging rows are whole 16-byte words");
 // wheel geometry and default speeds of the relative base moves (stretch_mujoco/config.py:2-3,11)
 #define SMJ_WHEEL_RADIUS 0.0508f
 #define SMJ_WHEEL_SEPARATION 0.3153f
@@ -127,21 +155,27 @@ enum { SMJ_PROF_KIN = 0, SMJ_PROF_COMCRB, SMJ_PROF_SMOOTH, SMJ_PROF_FACTOR, SMJ_
 enum { SMJ_INFO_NEFC = 0, SMJ_INFO_NCON = 1, SMJ_INFO_NITER = 2, SMJ_INFO_FLAGS = 3 };
 enum { SMJ_FLAG_EFC_OVERFLOW = 1, SMJ_FLAG_CON_OVERFLOW = 2, SMJ_FLAG_BAD_STATE = 4 };
 
-// layout of the optional debug dump (floats), one column per env
+// layout of the optional debug dump (floats), one column per env; a function of the variant's capacities (smj_dims reports
+// the offsets of the running variant, lib.py: debug_layout)
+struct SmjDebugLayout { int qm, g, qacc, efc_force, efc_b, efc_r, efc_aref, ar_diag, xpos, qfrc_bias, qfrc_passive, qfrc_act, con, ar, floats; };
+constexpr SmjDebugLayout smj_debug_layout(int nvp, int ncon) {
+  SmjDebugLayout L{};
+  L.qm = 0; L.g = nvp * nvp; L.qacc = L.g + nvp; L.efc_force = L.qacc + nvp; L.efc_b = L.efc_force + 64; L.efc_r = L.efc_b + 64;
+  L.efc_aref = L.efc_r + 64; L.ar_diag = L.efc_aref + 64; L.xpos = L.ar_diag + 64; L.qfrc_bias = L.xpos + 96; L.qfrc_passive = L.qfrc_bias + nvp;
+  L.qfrc_act = L.qfrc_passive + nvp; L.con = L.qfrc_act + nvp; L.ar = L.con + 8 * ncon; L.floats = L.ar + 64 * 64;
+  return L;
+}
+constexpr SmjDebugLayout SMJ_DBG = smj_debug_layout(NVP, NCON);
 enum {
-  SMJ_DBG_QM = 0,             // 32*32 dense mass matrix (row-major, stride 32)
-  SMJ_DBG_G = 1024,           // 32 qfrc_smooth
-  SMJ_DBG_QACC = 1056,        // 32 qacc (forward dynamics)
-  SMJ_DBG_EFC_FORCE = 1088,   // 64
-  SMJ_DBG_EFC_B = 1152,       // 64
-  SMJ_DBG_EFC_R = 1216,       // 64
-  SMJ_DBG_EFC_AREF = 1280,    // 64
-  SMJ_DBG_AR_DIAG = 1344,     // 64
-  SMJ_DBG_XPOS = 1408,        // 32*3
-  SMJ_DBG_QFRC_BIAS = 1504,   // 32
-  SMJ_DBG_QFRC_PASSIVE = 1536,// 32
-  SMJ_DBG_QFRC_ACT = 1568,    // 32
-  SMJ_DBG_CON = 1600,         // 16 contacts x (dist, pos3, normal3, condim | geom1 << 4 | geom2 << 14) = 8 floats
-  SMJ_DBG_AR = 1728,          // 64*64 AR
-  SMJ_DEBUG_FLOATS = 1728 + 4096
+  SMJ_DBG_QM = SMJ_DBG.qm,                     // NVP*NVP dense mass matrix (row-major, stride NVP)
+  SMJ_DBG_G = SMJ_DBG.g,                       // NVP qfrc_smooth
+  SMJ_DBG_QACC = SMJ_DBG.qacc,                 // NVP qacc (forward dynamics)
+  SMJ_DBG_EFC_FORCE = SMJ_DBG.efc_force,       // the first 64 rows of each efc array
+  SMJ_DBG_EFC_B = SMJ_DBG.efc_b, SMJ_DBG_EFC_R = SMJ_DBG.efc_r, SMJ_DBG_EFC_AREF = SMJ_DBG.efc_aref, SMJ_DBG_AR_DIAG = SMJ_DBG.ar_diag,
+  SMJ_DBG_XPOS = SMJ_DBG.xpos,                 // 32*3
+  SMJ_DBG_QFRC_BIAS = SMJ_DBG.qfrc_bias, SMJ_DBG_QFRC_PASSIVE = SMJ_DBG.qfrc_passive, SMJ_DBG_QFRC_ACT = SMJ_DBG.qfrc_act,   // NVP each
+  SMJ_DBG_CON = SMJ_DBG.con,                   // NCON contacts x (dist, pos3, normal3, condim | geom1 << 4 | geom2 << 14) = 8 floats
+  SMJ_DBG_AR = SMJ_DBG.ar,                     // 64*64 AR (PGS)
+  SMJ_DEBUG_FLOATS = SMJ_DBG.floats
 };
+static_assert(NVP != 32 || (SMJ_DBG_QACC == 1056 && SMJ_DBG_CON == 1600 && SMJ_DBG_AR == 1728), "standard variant: the layout the tests index");

@@ -43,15 +43,18 @@ struct SmjBlob {
 
 // Host restatement of what the kernel's stage-table loaders (smj_step_impl.h: KinTab, BodyTab, DofTab, EntryTab, ActTab)
 // used to gather per lane from the individual tables, one record per lane.
+// capacities of a kernel variant (smj_model.h): the loader builds its records for the variant that will run
+struct SmjCaps { int nvp, nbp, nent, nefc, ncon; };
 static inline std::vector<int> smj_build_lanerec(const DevModel& m, std::map<std::string, std::vector<int>>& I,
-                                                 std::map<std::string, std::vector<float>>& F) {
-  std::vector<int> rec(64 * SMJ_LR_STRIDE, 0);
+                                                 std::map<std::string, std::vector<float>>& F, int nent) {
+  const int LR_ACT = smj_lr_act(nent), LR_STRIDE = smj_lr_stride(nent);
+  std::vector<int> rec(64 * LR_STRIDE, 0);
   auto fb = [](float v) { int b; memcpy(&b, &v, 4); return b; };
   auto gi = [&](const char* n, size_t k) { const std::vector<int>& v = I[n]; return k < v.size() ? v[k] : 0; };
   auto gf = [&](const char* n, size_t k) { const std::vector<float>& v = F[n]; return k < v.size() ? v[k] : 0.f; };
   const int nb = m.nbody, nv = m.nv, nu = m.nu;
   for (int L = 0; L < 64; L++) {
-    int* r = rec.data() + L * SMJ_LR_STRIDE;
+    int* r = rec.data() + L * LR_STRIDE;
     {  // KinTab: parent, level, jump[6], pos[3], quat[4], jtype[2], jqadr[2], jdadr[2], jq0[2], jaxis[6], jpos[6]
       int* k = r + SMJ_LR_KIN;
       const int b = L < nb ? L : 0;
@@ -85,17 +88,17 @@ static inline std::vector<int> smj_build_lanerec(const DevModel& m, std::map<std
       k[9] = fb(jt == 0 ? 0.f : gf("qpos_spring", gi("jnt_qposadr", j)));
       for (int u = 0; u < 2; u++) { k[10 + u] = gi("k_dof_act", 2 * d + u); k[12 + u] = fb(gf("k_dof_actmom", 2 * d + u)); }
     }
-    {  // EntryTab, 5 mass-matrix pattern slots: i[5], j[5], arm[5] | lact[5], damp[5], dcoef[5], lcoef[5] (implicit only)
+    {  // EntryTab, `nent` mass-matrix pattern slots: i[], j[], arm[] | lact[], damp[], dcoef[], lcoef[] (implicit only)
       int* k = r + SMJ_LR_ENT;
-      for (int u = 0; u < 5; u++) {
+      for (int u = 0; u < nent; u++) {
         const int e = L + 64 * u, ok = e < m.nldl, ex = ok ? e : 0, i = gi("k_ldl_i", ex), j = gi("k_ldl_j", ex);
-        k[u] = ok ? i : -1; k[5 + u] = ok ? j : 0; k[10 + u] = fb((ok && i == j) ? gf("dof_armature", i) : 0.f);
-        k[15 + u] = ok ? gi("k_ldl_lact", ex) : -1;
-        k[20 + u] = fb(ok ? gf("k_ldl_damp", ex) : 0.f); k[25 + u] = fb(ok ? gf("k_ldl_dcoef", ex) : 0.f); k[30 + u] = fb(ok ? gf("k_ldl_lcoef", ex) : 0.f);
+        k[u] = ok ? i : -1; k[nent + u] = ok ? j : 0; k[2 * nent + u] = fb((ok && i == j) ? gf("dof_armature", i) : 0.f);
+        k[3 * nent + u] = ok ? gi("k_ldl_lact", ex) : -1;
+        k[4 * nent + u] = fb(ok ? gf("k_ldl_damp", ex) : 0.f); k[5 * nent + u] = fb(ok ? gf("k_ldl_dcoef", ex) : 0.f); k[6 * nent + u] = fb(ok ? gf("k_ldl_lcoef", ex) : 0.f);
       }
     }
     {  // ActTab: dof[4], qadr[4], mom[4], prm[8], flags, gc_body, gc_mlo, gc_mhi, gc_mass, gc_x, gc_y, gc_z
-      int* k = r + SMJ_LR_ACT;
+      int* k = r + LR_ACT;
       const int a = L < nu ? L : 0;
       for (int u = 0; u < 4; u++) {
         const int dd = gi("k_act_dof", 4 * a + u);
@@ -215,12 +218,15 @@ static inline std::vector<int> smj_build_cprec(const DevModel& m, std::map<std::
     k[SMJ_CP_MARGIN] = fb(gf("pair_margin", p)); k[SMJ_CP_MG] = fb(gf("pair_margin", p) - gf("pair_gap", p)); k[SMJ_CP_CONDIM] = gi("pair_condim", p);
     for (int q = 0; q < 5; q++) { k[SMJ_CP_FRIC + q] = fb(gf("pair_friction", 5 * p + q)); k[SMJ_CP_SOLIMP + q] = fb(gf("pair_solimp", 5 * p + q)); }
     k[SMJ_CP_SOLREF] = fb(gf("pair_solref", 2 * p)); k[SMJ_CP_SOLREF + 1] = fb(gf("pair_solref", 2 * p + 1));
+    const float r1 = gf("geom_rbound", k[SMJ_CP_G1]), r2 = gf("geom_rbound", k[SMJ_CP_G2]);
+    k[SMJ_CP_RBMIN] = fb(r1 < r2 ? r1 : r2);
   }
   return rec;
 }
 
+// `caps`: the kernel variants available to the caller, smallest first; the first one the model fits is chosen (*chosen).
 template <class Up>
-int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::string& err) {
+int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::string& err, const SmjCaps* caps, int ncaps, int* chosen) {
   if (!blob || nbytes < 16 || memcmp(blob, "SMJB0001", 8) != 0) { err = "not an SMJB model blob"; return -1; }
   SmjBlob b{static_cast<const uint8_t*>(blob), nbytes};
   if (!b.valid()) { err = "model blob: truncated or corrupt entry table"; return -3; }
@@ -254,14 +260,26 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
     const SmjBlobEntry* e = b.find("sensor_lidar_site");
     m.nlidar = e ? (int)(e->nbytes / 4) : 0;
   }
-  m.warmstart = 1; m.pgs_fixed_iter = 0; m.max_con_pair = 4; m.solver = 0; m.convex_pairs = 1; m.ls_iterations = 50; m.ls_tolerance = 0.01f;
+  m.warmstart = 1; m.pgs_fixed_iter = 0; m.max_con_pair = 4; m.solver = 0; m.convex_pairs = 1; m.multiccd = 1; m.ls_iterations = 50; m.ls_tolerance = 0.01f;
   char buf[256];
-  if (m.nv > NVP || m.nbody > NBP || m.nq > NVP + 8 || m.nu > 16) {
-    snprintf(buf, sizeof buf, "model exceeds kernel capacity (nv %d<=%d, nbody %d<=%d, nu %d<=16)", m.nv, NVP, m.nbody, NBP, m.nu);
+  int pick = -1, first = 0;
+  {   // optional hint of the model compiler: contact-rich scene, start at the big variant (model_fuse.prepare_for_kernels)
+    const SmjBlobEntry* e = b.find("k_capacity_hint");
+    int hint = 0;
+    if (e && e->dtype == 1 && e->nbytes >= 4) memcpy(&hint, b.p + e->offset, 4);
+    if (hint > 0 && ncaps > 1) first = ncaps - 1;
+  }
+  for (int v = first; v < ncaps && pick < 0; v++)
+    if (m.nv <= caps[v].nvp && m.nbody <= caps[v].nbp && m.nq <= caps[v].nvp + 8 && m.nldl <= caps[v].nent * 64) pick = v;
+  if (pick < 0 || m.nu > 16) {
+    const SmjCaps& c = caps[ncaps - 1];
+    snprintf(buf, sizeof buf, "model exceeds kernel capacity (nv %d<=%d, nbody %d<=%d, nq %d<=%d, nu %d<=16, mass-matrix entries %d<=%d)",
+             m.nv, c.nvp, m.nbody, c.nbp, m.nq, c.nvp + 8, m.nu, m.nldl, c.nent * 64);
     err = buf;
     return -4;
   }
-  if (m.nldl > 5 * 64) { err = "mass-matrix sparsity pattern too large"; return -4; }
+  if (chosen) *chosen = pick;
+  const int nent = caps[pick].nent;
   if (m.neq + m.nfric > 64) { err = "too many static constraint rows"; return -4; }
   if (2 * m.nlimit > 64) { err = "too many limited joints"; return -4; }
   if (m.ngc > 16) { err = "more than 16 gravity-compensated bodies"; return -4; }
@@ -297,7 +315,7 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
   SMJ_MODEL_F32(X)
 #undef X
   {
-    std::vector<int> rec = smj_build_lanerec(m, hosti, hostf);
+    std::vector<int> rec = smj_build_lanerec(m, hosti, hostf, nent);
     m.k_lanerec = up.i32(rec);
     if (!m.k_lanerec) { err = "device allocation failed for k_lanerec"; return -2; }
     std::vector<int> pp = smj_build_pprec(m, hosti, hostf), cg = smj_build_cgrec(m, hosti, hostf);

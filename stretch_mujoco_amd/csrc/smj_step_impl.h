@@ -51,6 +51,7 @@ struct Smem {
       float ccen[NCG][3], size[NCG][3];   // world centre used as MPR's interior point, geom size
       int meta[NCG];                      // geom type (bits 0-3) | hull vertex count (4-15) | hull address (16-31)
       unsigned short list[1024];   // bounding-sphere survivors of the convex pair list, table order
+      float mc[5][3];              // multiccd: contact points found so far for the pair in hand
     } c;
     struct {                // plane narrowphase staging: contacts of the pair owned by each lane, emitted in pair order
       int cnt[64], pair[64];
@@ -68,7 +69,7 @@ struct Smem {
       float cH[NCON][36];   // cone Hessians of contacts in the middle zone
       // per-row solver registers (NRow) of rows 64..NEFC-1: the second row pass loads them at the start of a stage and
       // stores them back at its end, so that the (rare) second pass holds no registers across the Newton loop
-      int rxi[3][NEFC > 64 ? NEFC - 64 : 1];
+      int rxi[3][NEFC > 64 ? NEFC - 64 : 1];      // indexed by row - 64
       float rxf[17][NEFC > 64 ? NEFC - 64 : 1];
     } n;
   } u;
@@ -77,12 +78,12 @@ struct Smem {
 #define NEFP 64   // PGS row capacity (rows = lanes in the PGS sweeps)
 // Row passes of the Newton path: rows 0..63 on lanes 0..63 (rb = 0), then rows 64..NEFC-1 on lanes 0..NEFC-65 (rb = 64), the
 // second pass only for an env that has that many rows (wave-uniform test).
-#define ROWPASS(rb, ne) _Pragma("unroll") for (int rb = 0; rb < NEFC; rb += 64) if (rb == 0 || __builtin_expect((ne) > 64, 0))
+#define ROWPASS(rb, ne) _Pragma("unroll") for (int rb = 0; rb < NEFC; rb += 64) if (rb == 0 || __builtin_expect((ne) > rb, 0))
 #define ROWPASS_ALL(rb) _Pragma("unroll") for (int rb = 0; rb < NEFC; rb += 64)
 // A solver stage over all rows: `nr` names the per-row registers of the pass -- nr0 (registers, live across the Newton loop)
 // in the first pass, a stage-local copy of the LDS-resident state (rx_load / rx_store) in the second.
-#define ROWS_BEGIN(rb, ne) ROWPASS(rb, ne) { NRow nrx_; if (rb != 0) rx_load(nrx_); NRow& nr = (rb != 0) ? nrx_ : nr0; (void)nr;
-#define ROWS_END_RW(rb) if (rb != 0) rx_store(nrx_); }
+#define ROWS_BEGIN(rb, ne) ROWPASS(rb, ne) { NRow nrx_; if (rb != 0) rx_load(nrx_, rb); NRow& nr = (rb != 0) ? nrx_ : nr0; (void)nr;
+#define ROWS_END_RW(rb) if (rb != 0) rx_store(nrx_, rb); }
 #define ROWS_END_RO() }
 static inline size_t smj_lds_bytes(bool pgs) {
   const size_t a_end = offsetof(Smem, u) + sizeof(float) * NEFP * NEFP;
@@ -289,17 +290,18 @@ struct StepKernel {
       for (int u = 0; u < 2; u++) { t.act[lane][u] = v[10 + u]; t.actmom[lane][u] = asf(v[12 + u]); }
     }
   }
-  struct EntryTab { // lane = mass-matrix pattern slots (5 per lane)
-    PL<int[5]> i, j, lact;
-    PL<float[5]> arm, damp, dcoef, lcoef;
+  struct EntryTab { // lane = mass-matrix pattern slots (NENT per lane)
+    PL<int[NENT]> i, j, lact;
+    PL<float[NENT]> arm, damp, dcoef, lcoef;
   };
   SMJ_DEV void load(EntryTab& t, bool implicit) {
     LANES {
       const int* r = lanerec(opaque(lane), SMJ_LR_ENT);
-      for (int u = 0; u < 5; u++) { t.i[lane][u] = r[u]; t.j[lane][u] = r[5 + u]; t.arm[lane][u] = asf(r[10 + u]); }
+      for (int u = 0; u < NENT; u++) { t.i[lane][u] = r[u]; t.j[lane][u] = r[NENT + u]; t.arm[lane][u] = asf(r[2 * NENT + u]); }
       if (implicit)
-        for (int u = 0; u < 5; u++) {
-          t.lact[lane][u] = r[15 + u]; t.damp[lane][u] = asf(r[20 + u]); t.dcoef[lane][u] = asf(r[25 + u]); t.lcoef[lane][u] = asf(r[30 + u]);
+        for (int u = 0; u < NENT; u++) {
+          t.lact[lane][u] = r[3 * NENT + u]; t.damp[lane][u] = asf(r[4 * NENT + u]); t.dcoef[lane][u] = asf(r[5 * NENT + u]);
+          t.lcoef[lane][u] = asf(r[6 * NENT + u]);
         }
     }
   }
@@ -343,16 +345,38 @@ struct StepKernel {
   }
 
   // One env's row of the env-major staging copy (DevState::stage): contiguous words, lanes = consecutive words
-  SMJ_DEV float* stage_row() const { return S.stage + (size_t)env * SMJ_ST_STRIDE; }
+  SMJ_DEV float* stage_row() const { return S.stage + (size_t)env * S.lay.stride; }
+  // Capacity escalation: park the env at the START of step `st` (nothing of this step has been written to the state yet:
+  // qpos / qvel / qacc_warmstart / ctrl / the base controller change in solve / integrate / base_controller only) and queue
+  // it for the big kernel variant, which finishes the launch's remaining steps on it.
+  SMJ_DEV void escalate(int st) {
+    float* row = stage_row();
+    int* rowi = reinterpret_cast<int*>(row);
+    LANES {
+      for (int k = lane; k < M.nq; k += 64) row[S.lay.qpos + k] = s.qpos[k];
+      if (lane < M.nv) { row[S.lay.qvel + lane] = s.qvel[lane]; row[S.lay.warm + lane] = s.warm[lane]; }
+      if (lane < M.nu) row[S.lay.ctrl + lane] = s.ctrl[lane];
+      if (lane < SMJ_BC_ROWS) row[S.lay.bctl + lane] = s.bctl[lane];
+      if (lane == 0) {
+        rowi[S.lay.nstep] += st;
+#ifndef SMJ_EMUL
+        const int at = atomicAdd(&S.redo[0], 1);
+#else
+        const int at = S.redo[0]++;
+#endif
+        S.redo[1 + 2 * at] = env; S.redo[2 + 2 * at] = st;
+      }
+    }
+  }
   SMJ_DEV void load_state() {
     const long ld = S.ld;
     if (S.stage) {
       const float* st = stage_row();
       LANES {
-        for (int k = lane; k < M.nq; k += 64) s.qpos[k] = st[SMJ_ST_QPOS + k];
-        if (lane < M.nv) { s.qvel[lane] = st[SMJ_ST_QVEL + lane]; s.warm[lane] = st[SMJ_ST_WARM + lane]; }
-        if (lane < M.nu) s.ctrl[lane] = st[SMJ_ST_CTRL + lane];
-        if (lane < SMJ_BC_ROWS) s.bctl[lane] = st[SMJ_ST_BCTL + lane];
+        for (int k = lane; k < M.nq; k += 64) s.qpos[k] = st[S.lay.qpos + k];
+        if (lane < M.nv) { s.qvel[lane] = st[S.lay.qvel + lane]; s.warm[lane] = st[S.lay.warm + lane]; }
+        if (lane < M.nu) s.ctrl[lane] = st[S.lay.ctrl + lane];
+        if (lane < SMJ_BC_ROWS) s.bctl[lane] = st[S.lay.bctl + lane];
       }
     } else {
       LANES {
@@ -375,15 +399,15 @@ struct StepKernel {
       float* st = stage_row();
       int* sti = reinterpret_cast<int*>(st);
       LANES {
-        for (int k = lane; k < M.nq; k += 64) st[SMJ_ST_QPOS + k] = s.qpos[k];
-        if (lane < M.nv) { st[SMJ_ST_QVEL + lane] = s.qvel[lane]; st[SMJ_ST_WARM + lane] = s.warm[lane]; }
-        if (lane < M.nu) { st[SMJ_ST_CTRL + lane] = s.ctrl[lane]; st[SMJ_ST_ACTLEN + lane] = s.act_len[lane]; st[SMJ_ST_ACTVEL + lane] = s.act_vel[lane]; }
-        if (lane < SMJ_BC_ROWS) st[SMJ_ST_BCTL + lane] = s.bctl[lane];
+        for (int k = lane; k < M.nq; k += 64) st[S.lay.qpos + k] = s.qpos[k];
+        if (lane < M.nv) { st[S.lay.qvel + lane] = s.qvel[lane]; st[S.lay.warm + lane] = s.warm[lane]; }
+        if (lane < M.nu) { st[S.lay.ctrl + lane] = s.ctrl[lane]; st[S.lay.actlen + lane] = s.act_len[lane]; st[S.lay.actvel + lane] = s.act_vel[lane]; }
+        if (lane < SMJ_BC_ROWS) st[S.lay.bctl + lane] = s.bctl[lane];
         if (lane == 0) {
-          sti[SMJ_ST_NSTEP] += nsteps;
-          sti[SMJ_ST_INFO + SMJ_INFO_NEFC] = nefc; sti[SMJ_ST_INFO + SMJ_INFO_NCON] = ncon;
-          sti[SMJ_ST_INFO + SMJ_INFO_NITER] = niter; sti[SMJ_ST_INFO + SMJ_INFO_FLAGS] |= flags;
-          st[SMJ_ST_BASE] = bx; st[SMJ_ST_BASE + 1] = by; st[SMJ_ST_BASE + 2] = bth;
+          sti[S.lay.nstep] += nsteps;
+          sti[S.lay.info + SMJ_INFO_NEFC] = nefc; sti[S.lay.info + SMJ_INFO_NCON] = ncon;
+          sti[S.lay.info + SMJ_INFO_NITER] = niter; sti[S.lay.info + SMJ_INFO_FLAGS] |= flags;
+          st[S.lay.base] = bx; st[S.lay.base + 1] = by; st[S.lay.base + 2] = bth;
         }
       }
     } else {
@@ -712,7 +736,7 @@ struct StepKernel {
     SYNC();
     // M entries on the static sparsity pattern: lower (working copy), upper (kept), Mdiag
     LANES {
-      for (int t = 0; t < 5; t++) {
+      for (int t = 0; t < NENT; t++) {
         const int i = et.i[lane][t], j = et.j[lane][t];
         if (i < 0) continue;
         float v = 0;
@@ -735,7 +759,7 @@ struct StepKernel {
     for (int k = nv - 1; k >= 0; k--) {
       const float dkk = s.MM[k][k], dinv = 1.0f / dkk;
       LANES {
-        for (int t = 0; t < 5; t++) {
+        for (int t = 0; t < NENT; t++) {
           const int i = et.i[lane][t], j = et.j[lane][t];
           if (i < 0 || i >= k) continue;
           const float a = s.MM[k][i];
@@ -1588,6 +1612,250 @@ struct StepKernel {
     }
   }
 
+
+  // ------------------------------------------------------------------ box-box, multi-point convex contacts
+  // [MJ] mjc_BoxBox and the multiccd branch of mjc_Convex, in the formulation of oracle/smj_oracle.c box_box / convex_pair
+  // (see there: behaviour restated, not MuJoCo's arithmetic).  The separating-axis test is wave-uniform; the polygon of a
+  // face contact is enumerated lane-parallel -- lane = candidate: 4 incident corners inside the reference face, 4 reference
+  // corners inside the incident face, 16 edge crossings -- and emitted in candidate order by ballot prefix.
+  SMJ_DEV static void col3(float* o, const float* R, int i) {   // column i of a row-major 3x3, static selects only
+    o[0] = i == 0 ? R[0] : (i == 1 ? R[1] : R[2]); o[1] = i == 0 ? R[3] : (i == 1 ? R[4] : R[5]); o[2] = i == 0 ? R[6] : (i == 1 ? R[7] : R[8]);
+  }
+  SMJ_DEV static float sel3(const float* v, int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : v[2]); }
+  SMJ_DEV void box_box(const int* rec, const Shape& S1, const Shape& S2, float margin) {
+    const float* p1 = S1.pos; const float* R1 = S1.mat; const float* A = S1.size;
+    const float* p2 = S2.pos; const float* R2 = S2.mat; const float* B = S2.size;
+    const float p[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+    float R[3][3], Q[3][3], pp[3], pq[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const float ai[3] = {R1[i], R1[3 + i], R1[6 + i]}, bi[3] = {R2[i], R2[3 + i], R2[6 + i]};
+      pp[i] = dot3(p, ai); pq[i] = dot3(p, bi);
+#pragma unroll
+      for (int j = 0; j < 3; j++) { const float bj[3] = {R2[j], R2[3 + j], R2[6 + j]}; R[i][j] = dot3(ai, bj); Q[i][j] = fabsf(R[i][j]); }
+    }
+    float best = -3.0e38f, en[3] = {0, 0, 0};
+    int code = -1;
+    bool sep = false;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const float sv = fabsf(pp[i]) - (A[i] + B[0] * Q[i][0] + B[1] * Q[i][1] + B[2] * Q[i][2]);
+      sep = sep || sv > margin;
+      if (sv > best) { best = sv; code = i; }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const float sv = fabsf(pq[j]) - (B[j] + A[0] * Q[0][j] + A[1] * Q[1][j] + A[2] * Q[2][j]);
+      sep = sep || sv > margin;
+      if (sv > best) { best = sv; code = 3 + j; }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+        const float l = sqrtf(fmaxf(0.f, 1.f - R[i][j] * R[i][j]));
+        if (l >= 1e-6f) {
+          const float e = pp[i2] * R[i1][j] - pp[i1] * R[i2][j];
+          const float sv = (fabsf(e) - (A[i1] * Q[i2][j] + A[i2] * Q[i1][j] + B[j1] * Q[i][j2] + B[j2] * Q[i][j1])) / l;
+          sep = sep || sv > margin;
+          if (sv * 1.05f > best && sv > best) {
+            best = sv; code = 6 + 3 * i + j;
+            const float ai[3] = {R1[i], R1[3 + i], R1[6 + i]}, bj[3] = {R2[j], R2[3 + j], R2[6 + j]};
+            cross3(en, ai, bj);
+            for (int k = 0; k < 3; k++) en[k] /= l;
+          }
+        }
+      }
+    if (sep) return;
+    if (code >= 6) {   // edge-edge: one point, midway between the closest points of the two edges
+      float n[3] = {en[0], en[1], en[2]};
+      if (dot3(n, p) < 0) for (int k = 0; k < 3; k++) n[k] = -n[k];
+      const int i = (code - 6) / 3, j = (code - 6) % 3;
+      float pa[3] = {p1[0], p1[1], p1[2]}, pb[3] = {p2[0], p2[1], p2[2]};
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const float ak[3] = {R1[k], R1[3 + k], R1[6 + k]}, bk[3] = {R2[k], R2[3 + k], R2[6 + k]};
+        const float sa = dot3(n, ak) > 0 ? 1.f : -1.f, sb = dot3(n, bk) > 0 ? -1.f : 1.f;
+        for (int x = 0; x < 3; x++) { pa[x] += sa * A[k] * ak[x]; pb[x] += sb * B[k] * bk[x]; }
+      }
+      float ua[3], ub[3];
+      col3(ua, R1, i); col3(ub, R2, j);
+      const float dd[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+      const float uaub = dot3(ua, ub), q1 = dot3(ua, dd), q2 = -dot3(ub, dd), den = 1.f - uaub * uaub;
+      float al = 0, be = 0;
+      if (den > 1e-12f) { al = (q1 + uaub * q2) / den; be = (uaub * q1 + q2) / den; }
+      float pos[3];
+      for (int x = 0; x < 3; x++) pos[x] = 0.5f * ((pa[x] + al * ua[x]) + (pb[x] + be * ub[x]));
+      add_contact(rec, best, pos, n);
+      return;
+    }
+    // face contact.  Reference box a (the one owning the axis), incident box b; n from a to b
+    const bool swap = code >= 3;
+    const int ia = swap ? code - 3 : code;
+    float pa[3], Ra[9], ha[3], pb[3], Rb[9], hb[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { pa[k] = swap ? p2[k] : p1[k]; pb[k] = swap ? p1[k] : p2[k]; ha[k] = swap ? B[k] : A[k]; hb[k] = swap ? A[k] : B[k]; }
+#pragma unroll
+    for (int k = 0; k < 9; k++) { Ra[k] = swap ? R2[k] : R1[k]; Rb[k] = swap ? R1[k] : R2[k]; }
+    float n[3], u[3], v[3];
+    col3(n, Ra, ia);
+    const float ab[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+    if (dot3(n, ab) < 0) for (int k = 0; k < 3; k++) n[k] = -n[k];
+    const int ja = (ia + 1) % 3, ka = (ia + 2) % 3;
+    col3(u, Ra, ja); col3(v, Ra, ka);
+    const float hu = sel3(ha, ja), hv = sel3(ha, ka), hn = sel3(ha, ia);
+    float cA[3];
+    for (int k = 0; k < 3; k++) cA[k] = pa[k] + n[k] * hn;
+    int ib = 0;
+    float bd = -1.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const float bk[3] = {Rb[k], Rb[3 + k], Rb[6 + k]}; const float t = fabsf(dot3(bk, n)); if (t > bd) { bd = t; ib = k; } }
+    float nb[3], pv[3], qv[3];
+    col3(nb, Rb, ib);
+    if (dot3(nb, n) > 0) for (int k = 0; k < 3; k++) nb[k] = -nb[k];
+    const int jb = (ib + 1) % 3, kb = (ib + 2) % 3;
+    col3(pv, Rb, jb); col3(qv, Rb, kb);
+    const float hp = sel3(hb, jb), hq = sel3(hb, kb), hbn = sel3(hb, ib);
+    float cB[3];
+    for (int k = 0; k < 3; k++) cB[k] = pb[k] + nb[k] * hbn;
+    const float nnb = dot3(n, nb);
+    PL<int> okv;
+    PL<float> dv, px, py, pz;
+    LANES {
+      const int cand = lane;
+      int ok = 0;
+      float x[3] = {0, 0, 0};
+      // corner c of a face, counter-clockwise: (-,-) (+,-) (+,+) (-,+)
+#define SG0(c) (((c) == 1 || (c) == 2) ? 1.f : -1.f)
+#define SG1(c) ((c) >= 2 ? 1.f : -1.f)
+      if (cand < 4) {
+        float d[3];
+        for (int k = 0; k < 3; k++) { x[k] = cB[k] + SG0(cand) * hp * pv[k] + SG1(cand) * hq * qv[k]; d[k] = x[k] - cA[k]; }
+        ok = fabsf(dot3(d, u)) <= hu && fabsf(dot3(d, v)) <= hv;
+      } else if (cand < 8) {
+        const int c = cand - 4;
+        float r[3], d[3];
+        for (int k = 0; k < 3; k++) { r[k] = cA[k] + SG0(c) * hu * u[k] + SG1(c) * hv * v[k]; d[k] = cB[k] - r[k]; }
+        const float t = dot3(d, nb) / nnb;
+        for (int k = 0; k < 3; k++) { x[k] = r[k] + t * n[k]; d[k] = x[k] - cB[k]; }
+        ok = fabsf(dot3(d, pv)) < hp && fabsf(dot3(d, qv)) < hq;
+      } else if (cand < 24) {
+        const int e = (cand - 8) >> 2, r = (cand - 8) & 3, c0 = e, c1 = (e + 1) & 3;
+        float w0[3], w1[3], d0[3], d1[3];
+        for (int k = 0; k < 3; k++) {
+          w0[k] = cB[k] + SG0(c0) * hp * pv[k] + SG1(c0) * hq * qv[k]; w1[k] = cB[k] + SG0(c1) * hp * pv[k] + SG1(c1) * hq * qv[k];
+          d0[k] = w0[k] - cA[k]; d1[k] = w1[k] - cA[k];
+        }
+        const float u0 = dot3(d0, u), v0 = dot3(d0, v), u1 = dot3(d1, u), v1 = dot3(d1, v);
+        const bool along_u = r < 2;
+        const float lim = ((r & 1) ? 1.f : -1.f) * (along_u ? hu : hv);
+        const float a0 = along_u ? u0 : v0, a1 = along_u ? u1 : v1, b0 = along_u ? v0 : u0, b1 = along_u ? v1 : u1;
+        const float den = a1 - a0;
+        if (fabsf(den) > 1e-12f) {
+          const float t = (lim - a0) / den, o = b0 + t * (b1 - b0);
+          ok = t > 0 && t < 1 && fabsf(o) < (along_u ? hv : hu);
+          for (int k = 0; k < 3; k++) x[k] = w0[k] + t * (w1[k] - w0[k]);
+        }
+      }
+#undef SG0
+#undef SG1
+      const float d[3] = {x[0] - cA[0], x[1] - cA[1], x[2] - cA[2]};
+      const float depth = -dot3(d, n);
+      if (-depth > margin) ok = 0;
+      okv[lane] = ok; dv[lane] = -depth;
+      px[lane] = x[0] + 0.5f * depth * n[0]; py[lane] = x[1] + 0.5f * depth * n[1]; pz[lane] = x[2] + 0.5f * depth * n[2];
+    }
+    uint64_t mask = wave_ballot(okv);
+    if (mask == 0) return;
+    const int maxcon = M.max_con_pair < 4 ? 4 : M.max_con_pair;
+    if (popc64(mask) > maxcon) {
+      // more points than max_contacts_per_pair: keep the extreme ones along the two axes of the reference face (ties: lowest
+      // candidate), a support polygon as wide as the full one
+      PL<float> ku, kv, kk;
+      PL<int> li;
+      LANES {
+        const float pos[3] = {px[lane], py[lane], pz[lane]};
+        const float d[3] = {pos[0] - cA[0], pos[1] - cA[1], pos[2] - cA[2]};   // (the midpoint shift is along n: same u, v)
+        ku[lane] = okv[lane] ? dot3(d, u) : 3.0e38f; kv[lane] = okv[lane] ? dot3(d, v) : 3.0e38f; li[lane] = okv[lane] ? lane : -1;
+      }
+      uint64_t keep = 0;
+      keep |= 1ull << pick_index(ku, li, wave_min(ku));
+      keep |= 1ull << pick_index(kv, li, wave_min(kv));
+      LANES { kk[lane] = okv[lane] ? -ku[lane] : 3.0e38f; }
+      keep |= 1ull << pick_index(kk, li, wave_min(kk));
+      LANES { kk[lane] = okv[lane] ? -kv[lane] : 3.0e38f; }
+      keep |= 1ull << pick_index(kk, li, wave_min(kk));
+      mask &= keep;
+      LANES { okv[lane] = (int)((mask >> lane) & 1); }
+    }
+    const int total = popc64(mask) < 8 ? popc64(mask) : 8;
+    const float cn[3] = {swap ? -n[0] : n[0], swap ? -n[1] : n[1], swap ? -n[2] : n[2]};
+    LANES {
+      if (okv[lane]) {
+        const int k = popc64(mask & ((1ull << lane) - 1));
+        if (k < 8 && ncon + k < NCON) {
+          const float pos[3] = {px[lane], py[lane], pz[lane]};
+          write_contact(ncon + k, rec, dv[lane], pos, cn);
+        }
+      }
+    }
+    if (ncon + total > NCON) { flags |= SMJ_FLAG_CON_OVERFLOW; ncon = NCON; }
+    else ncon += total;
+  }
+
+  SMJ_DEV static void axis_angle_mat(float* Rm, const float* ax, float ang) {
+    const float c = cosf(ang), sn = sinf(ang), t = 1 - c, x = ax[0], y = ax[1], z = ax[2];
+    Rm[0] = t * x * x + c; Rm[1] = t * x * y - sn * z; Rm[2] = t * x * z + sn * y;
+    Rm[3] = t * x * y + sn * z; Rm[4] = t * y * y + c; Rm[5] = t * y * z - sn * x;
+    Rm[6] = t * x * z - sn * y; Rm[7] = t * y * z + sn * x; Rm[8] = t * z * z + c;
+  }
+  SMJ_DEV static void rotate_point(float* q, const float* c, const float* Rm) {
+    const float d[3] = {q[0] - c[0], q[1] - c[1], q[2] - c[2]};
+    float r[3];
+    mulmat3vec(r, Rm, d);
+    for (int k = 0; k < 3; k++) q[k] = c[k] + r[k];
+  }
+  // multiccd: the two geoms counter-rotated by +-1e-3 rad about the two tangent axes through the first contact point, the
+  // penetration query repeated; new points farther than 1e-3 x min(rbound) from the earlier ones join the manifold, which
+  // shares the first normal.  A, Bs are modified in place (the pair is done afterwards).
+  SMJ_DEV void convex_multi(const int* rec, Shape& A, Shape& Bs, const float* c0, const float* c1, const float* pos0, const float* dir0,
+                            float margin, float tol) {
+    float fr[9] = {dir0[0], dir0[1], dir0[2], 0, 0, 0, 0, 0, 0};
+    make_frame(fr);
+    float pA[3], mA[9], pB[3], mB[9];
+    for (int k = 0; k < 3; k++) { pA[k] = A.pos[k]; pB[k] = Bs.pos[k]; }
+    for (int k = 0; k < 9; k++) { mA[k] = A.mat[k]; mB[k] = Bs.mat[k]; }
+    LANES { if (lane == 0) for (int k = 0; k < 3; k++) s.u.c.mc[0][k] = pos0[k]; }
+    SYNC();
+    int n = 1;
+#pragma nounroll
+    for (int q = 0; q < 4; q++) {
+      const float* ax = fr + 3 * (1 + (q >> 1));
+      const float axv[3] = {uni(ax[0]), uni(ax[1]), uni(ax[2])};
+      const float ang = (q & 1) ? -1e-3f : 1e-3f;
+      float Rp[9], Rn[9], ca[3] = {c0[0], c0[1], c0[2]}, cb[3] = {c1[0], c1[1], c1[2]};
+      axis_angle_mat(Rp, axv, ang); axis_angle_mat(Rn, axv, -ang);
+      for (int k = 0; k < 3; k++) { A.pos[k] = pA[k]; Bs.pos[k] = pB[k]; }
+      rotate_point(A.pos, pos0, Rp); rotate_point(Bs.pos, pos0, Rn); rotate_point(ca, pos0, Rp); rotate_point(cb, pos0, Rn);
+      mulmat3(A.mat, Rp, mA); mulmat3(Bs.mat, Rn, mB);
+      float dp, dr[3], ps[3];
+      if (!mpr_penetration(A, Bs, ca, cb, dp, dr, ps)) continue;
+      if (-dp > margin || dot3(dr, dr) < 0.5f) continue;
+      bool dup = false;
+#pragma nounroll
+      for (int k = 0; k < n; k++) {
+        const float e[3] = {ps[0] - uni(s.u.c.mc[k][0]), ps[1] - uni(s.u.c.mc[k][1]), ps[2] - uni(s.u.c.mc[k][2])};
+        dup = dup || dot3(e, e) < tol * tol;
+      }
+      if (dup) continue;
+      LANES { if (lane == 0) for (int k = 0; k < 3; k++) s.u.c.mc[n][k] = ps[k]; }
+      SYNC();
+      n++;
+      add_contact(rec, -dp, ps, dir0);
+    }
+  }
+
   // non-plane pairs: cache world frames of the participating geoms, sphere + oriented-box broadphase with lane = pair,
   // MPR on the survivors in pair-table order
   SMJ_DEV void collision_convex() {
@@ -1713,9 +1981,12 @@ struct StepKernel {
           }
           continue;
         }
+        if (A.type == GT_BOX && Bs.type == GT_BOX && M.multiccd) { box_box(r, A, Bs, margin); continue; }
         if (!mpr_penetration(A, Bs, c0, c1, depth, dir, pos)) continue;
         if (-depth > margin || dot3(dir, dir) < 0.5f) continue;
         add_contact(r, -depth, pos, dir);
+        if (M.multiccd && A.type != GT_SPHERE && Bs.type != GT_SPHERE)
+          convex_multi(r, A, Bs, c0, c1, pos, dir, margin, 1e-3f * asf(uni(r[SMJ_CP_RBMIN])));
       }
     }
     SYNC();
@@ -1730,9 +2001,8 @@ struct StepKernel {
     ROWPASS(rb, nefc) LANES {
       const int row = lane + rb;
       // J rows rb .. rb+63 (or up to NEFC-1) cleared as one 16-byte-aligned block: 9 wide stores per lane instead of 33
-      constexpr int NROW = 64, NF4 = NROW * JS / 4;   // 64 rows x 33 floats = 528 float4
-      static_assert((NROW * JS) % 4 == 0 && ((NEFC - 64) * JS) % 4 == 0, "row blocks are whole float4s");
-      const int nf4 = rb == 0 ? NF4 : (NEFC - 64) * JS / 4;
+      static_assert((64 * JS) % 4 == 0 && ((NEFC % 64) * JS) % 4 == 0, "row blocks are whole float4s");
+      const int nrow = NEFC - rb < 64 ? NEFC - rb : 64, nf4 = nrow * JS / 4;
       Vec4* jz = reinterpret_cast<Vec4*>(&s.J[rb][0]);
       for (int k = lane; k < nf4; k += 64) jz[k] = Vec4{0.f, 0.f, 0.f, 0.f};
       if (row < NEFC) {
@@ -1858,20 +2128,23 @@ struct StepKernel {
       }
     }
     SYNC();
-    // Phase 2, lanes = dofs fill the Jacobian columns; per contact only LDS is read.  Two contacts per pass: lanes 0-31
-    // take contact c0, lanes 32-63 contact c0 + 1.
-    for (int c0 = 0; c0 < ncon; c0 += 2) {
+    // Phase 2, lanes = dofs fill the Jacobian columns; per contact only LDS is read.  64 / NVP contacts per pass: with 32 dof
+    // lanes, lanes 0-31 take contact c0 and lanes 32-63 contact c0 + 1.
+    constexpr int CPP = 64 / NVP;
+    for (int c0 = 0; c0 < ncon; c0 += CPP) {
       LANES {
-        const int c = c0 + (lane >> 5), d = lane & 31;
+        const int c = c0 + lane / NVP, d = lane % NVP;
         if (c < ncon && d < nv) {
           const int r0 = s.cefc[c];
           if (r0 >= 0) {
             const int dim = s.cdim[c], b1 = s.u.k.b1[c], b2 = s.u.k.b2[c];
             const uint64_t m1 = mk64(s.u.k.m1lo[c], s.u.k.m1hi[c]), m2 = mk64(s.u.k.m2lo[c], s.u.k.m2hi[c]);
-            const float sg = (float)((int)((m2 >> d) & 1) - (int)((m1 >> d) & 1));
+            const int in1 = (int)((m1 >> d) & 1), in2 = (int)((m2 >> d) & 1);
+            const float sg = (float)(in2 - in1);
             if (sg != 0.f) {
-              // both bodies hang off the same tree root here (or one is the world): offsets relative to that root's com
-              const int bb = ((m2 >> d) & 1) ? b2 : b1;
+              // a dof moves at most one of the two bodies differently (same tree: the common ancestors cancel; different
+              // trees: disjoint dof sets): offsets relative to the subtree com of the body it moves
+              const int bb = in2 ? b2 : b1;
               const float off[3] = {s.cpos[c][0] - s.com[bb][0], s.cpos[c][1] - s.com[bb][1], s.cpos[c][2] - s.com[bb][2]};
               float cd[6], tv[3];
               for (int x = 0; x < 6; x++) cd[x] = s.u.k.cd[d][x];
@@ -2263,10 +2536,10 @@ struct StepKernel {
   };
 
   enum { RX_AREF = 0, RX_D, RX_R, RX_FL, RX_JAR, RX_JV, RX_FORCE, RX_Q0, RX_Q1, RX_Q2, RX_CQ };
-  SMJ_DEV void rx_load(NRow& t) {
+  SMJ_DEV void rx_load(NRow& t, int rb) {
     LANES {
-      const bool on = lane < NEFC - 64;
-      const int l = on ? lane : 0;
+      const bool on = lane + rb < NEFC;
+      const int l = on ? lane + rb - 64 : 0;
       t.type[lane] = on ? s.u.n.rxi[0][l] : CT_NONE; t.state[lane] = on ? s.u.n.rxi[1][l] : 0; t.c0[lane] = on ? s.u.n.rxi[2][l] : -1;
       t.aref[lane] = on ? s.u.n.rxf[RX_AREF][l] : 0.f; t.D[lane] = on ? s.u.n.rxf[RX_D][l] : 0.f; t.R[lane] = on ? s.u.n.rxf[RX_R][l] : 1.f;
       t.fl[lane] = on ? s.u.n.rxf[RX_FL][l] : 0.f; t.jar[lane] = on ? s.u.n.rxf[RX_JAR][l] : 0.f; t.jv[lane] = on ? s.u.n.rxf[RX_JV][l] : 0.f;
@@ -2275,15 +2548,16 @@ struct StepKernel {
       for (int k = 0; k < 7; k++) t.cq[lane][k] = on ? s.u.n.rxf[RX_CQ + k][l] : 0.f;
     }
   }
-  SMJ_DEV void rx_store(const NRow& t) {
+  SMJ_DEV void rx_store(const NRow& t, int rb) {
     LANES {
-      if (lane < NEFC - 64) {
-        s.u.n.rxi[0][lane] = t.type[lane]; s.u.n.rxi[1][lane] = t.state[lane]; s.u.n.rxi[2][lane] = t.c0[lane];
-        s.u.n.rxf[RX_AREF][lane] = t.aref[lane]; s.u.n.rxf[RX_D][lane] = t.D[lane]; s.u.n.rxf[RX_R][lane] = t.R[lane];
-        s.u.n.rxf[RX_FL][lane] = t.fl[lane]; s.u.n.rxf[RX_JAR][lane] = t.jar[lane]; s.u.n.rxf[RX_JV][lane] = t.jv[lane];
-        s.u.n.rxf[RX_FORCE][lane] = t.force[lane];
-        s.u.n.rxf[RX_Q0][lane] = t.q0[lane]; s.u.n.rxf[RX_Q1][lane] = t.q1[lane]; s.u.n.rxf[RX_Q2][lane] = t.q2[lane];
-        for (int k = 0; k < 7; k++) s.u.n.rxf[RX_CQ + k][lane] = t.cq[lane][k];
+      if (lane + rb < NEFC) {
+        const int l = lane + rb - 64;
+        s.u.n.rxi[0][l] = t.type[lane]; s.u.n.rxi[1][l] = t.state[lane]; s.u.n.rxi[2][l] = t.c0[lane];
+        s.u.n.rxf[RX_AREF][l] = t.aref[lane]; s.u.n.rxf[RX_D][l] = t.D[lane]; s.u.n.rxf[RX_R][l] = t.R[lane];
+        s.u.n.rxf[RX_FL][l] = t.fl[lane]; s.u.n.rxf[RX_JAR][l] = t.jar[lane]; s.u.n.rxf[RX_JV][l] = t.jv[lane];
+        s.u.n.rxf[RX_FORCE][l] = t.force[lane];
+        s.u.n.rxf[RX_Q0][l] = t.q0[lane]; s.u.n.rxf[RX_Q1][l] = t.q1[lane]; s.u.n.rxf[RX_Q2][l] = t.q2[lane];
+        for (int k = 0; k < 7; k++) s.u.n.rxf[RX_CQ + k][l] = t.cq[lane][k];
       }
     }
   }
@@ -2471,8 +2745,8 @@ struct StepKernel {
         LANES { acc[lane] = F2{0.f, 0.f}; }
 #pragma unroll
         for (int u = 0; u < 16; u += 2) {
-          const float f0 = r0 < 64 ? wave_read(nr0.force, (r0 & 63) + u) : s.u.n.rxf[RX_FORCE][(r0 & 63) + u];   // rows >= 64: LDS
-          const float f1 = r0 < 64 ? wave_read(nr0.force, (r0 & 63) + u + 1) : s.u.n.rxf[RX_FORCE][(r0 & 63) + u + 1];
+          const float f0 = r0 < 64 ? wave_read(nr0.force, (r0 & 63) + u) : s.u.n.rxf[RX_FORCE][(r0 >= 64 ? r0 - 64 : 0) + u];   // rows >= 64: LDS
+          const float f1 = r0 < 64 ? wave_read(nr0.force, (r0 & 63) + u + 1) : s.u.n.rxf[RX_FORCE][(r0 >= 64 ? r0 - 64 : 0) + u + 1];
           LANES { pk_fma(acc[lane], a[lane][u], a[lane][u + 1], f0, f1); }
         }
         LANES { out[lane] += acc[lane].x + acc[lane].y; }
@@ -2589,8 +2863,14 @@ struct StepKernel {
     LANES { x[lane] *= pinv[lane]; }
   }
   SMJ_DEV void solve_H(PL<float>& x) {
+#if NVP == 32
     if (M.nv <= 26) gj_solve<26>(x);   // Stretch: 26 dofs; a third fewer column pairs than the full 32
     else gj_solve<NVP>(x);
+#else
+    if (M.nv <= 38) gj_solve<38>(x);        // Stretch + two free objects (the reference's scene.xml)
+    else if (M.nv <= 50) gj_solve<50>(x);   // Stretch + four free objects (kitchen)
+    else gj_solve<NVP>(x);
+#endif
   }
 
   // cost and derivatives along the search line  ([MJ] CGeval); lanes = rows, three wave reductions
@@ -2646,7 +2926,7 @@ struct StepKernel {
   template <int D>
   SMJ_DEV void xa_cone_pass(int ca, int cb) {
     LANES {
-      const int c = lane < 32 ? ca : cb, k = lane & 31;
+      const int c = lane < NVP ? ca : cb, k = lane % NVP;   // NVP = 64: one contact per pass (cb unused)
       if (c >= 0) {
         const int r0 = s.cefc[c], dim = s.cdim[c];
         float j[D], h[D * D];
@@ -2768,7 +3048,7 @@ struct StepKernel {
           const int ca = ffs64(cm);
           cm &= cm - 1;
           int cb = -1;
-          if (cm) { cb = ffs64(cm); cm &= cm - 1; }
+          if (NVP < 64 && cm) { cb = ffs64(cm); cm &= cm - 1; }
           const int da = wave_read(cdl, ca), db = cb >= 0 ? wave_read(cdl, cb) : 0;
           if (da <= 3 && db <= 3) xa_cone_pass<3>(ca, cb);
           else xa_cone_pass<6>(ca, cb);
@@ -2776,59 +3056,64 @@ struct StepKernel {
       }
       SYNC();
       TICK(SMJ_PROF_N_XA)
-      // H = M + XA' J on the matrix cores: the three lower 16x16 tiles over dofs, K = constraint rows.  The operands of all
-      // tiles are fetched first (XA and J column halves, shared between tiles) and the three accumulation chains are
+      // H = M + XA' J on the matrix cores: the lower 16x16 tiles over dofs (3 for 32 dofs, 10 for 64), K = constraint rows.  The
+      // operands of all tiles are fetched first (XA and J column blocks, shared between tiles) and the accumulation chains are
       // interleaved, so that neither the LDS latency nor the MFMA latency of one tile serialises the others.
       {
+        constexpr int NT = NVP / 16, NTRI = NT * (NT + 1) / 2, KB = NVP == 32 ? 16 : 8;
         const int ksteps = (ne + 3) >> 2;
-        PL<F4v> acc00, acc10, acc11;
+        PL<F4v> acc[NTRI];
         LANES {
-          for (int r = 0; r < 4; r++) { acc00[lane].r[r] = 0.f; acc10[lane].r[r] = 0.f; acc11[lane].r[r] = 0.f; }
-        }
-        // rows 0..63 in one batch of 16 k-steps, rows 64..NEFC-1 (rare) in a second short one
 #pragma unroll
-        for (int kb = 0; kb < NEFC / 4; kb += 16) {
-          if (kb == 0 || __builtin_expect(kb < ksteps, 0)) {
-            constexpr int KB = 16;
-            PL<float[KB]> a0, a1, b0, b1;
+          for (int t = 0; t < NTRI; t++)
+            for (int r = 0; r < 4; r++) acc[t][lane].r[r] = 0.f;
+        }
+        // rows 0..63 in batches of KB k-steps, rows 64..NEFC-1 (rare) in further ones, entered only by an env that has them
+#pragma unroll
+        for (int kb = 0; kb < NEFC / 4; kb += KB) {
+          if (kb < 16 ? kb < ksteps : __builtin_expect(kb < ksteps, 0)) {
+            PL<float[KB]> a[NT], b[NT];
             LANES {
 #pragma unroll
               for (int ks = 0; ks < KB; ks++) {
                 const int k = 4 * (kb + ks) + (lane >> 4), c = lane & 15;
                 if (kb + ks < NEFC / 4) {                      // compile-time: k stays inside XA / J
                   // unconditional: rows >= ne of XA / J are zero, and the k-steps beyond ne are skipped below anyway
-                  a0[lane][ks] = s.u.n.XA[k][c];
-                  a1[lane][ks] = s.u.n.XA[k][16 + c];
-                  b0[lane][ks] = s.J[k][c];
-                  b1[lane][ks] = s.J[k][16 + c];
+#pragma unroll
+                  for (int t = 0; t < NT; t++) { a[t][lane][ks] = s.u.n.XA[k][16 * t + c]; b[t][lane][ks] = s.J[k][16 * t + c]; }
                 }
               }
             }
 #pragma unroll
             for (int ks = 0; ks < KB; ks++) {
               if (kb + ks < ksteps && kb + ks < NEFC / 4) {
-                PL<float> pa0, pa1, pb0, pb1;
-                LANES { pa0[lane] = a0[lane][ks]; pa1[lane] = a1[lane][ks]; pb0[lane] = b0[lane][ks]; pb1[lane] = b1[lane][ks]; }
-                mfma16x16x4(acc00, pa0, pb0);
-                mfma16x16x4(acc10, pa1, pb0);
-                mfma16x16x4(acc11, pa1, pb1);
+                PL<float> pa[NT], pb[NT];
+                LANES {
+#pragma unroll
+                  for (int t = 0; t < NT; t++) { pa[t][lane] = a[t][lane][ks]; pb[t][lane] = b[t][lane][ks]; }
+                }
+#pragma unroll
+                for (int ta = 0; ta < NT; ta++)
+#pragma unroll
+                  for (int tb = 0; tb <= ta; tb++) mfma16x16x4(acc[ta * (ta + 1) / 2 + tb], pa[ta], pb[tb]);
               }
             }
           }
         }
         LANES {
 #pragma unroll
-          for (int t = 0; t < 3; t++) {
-            const int ta = t > 0, tb = t > 1;
+          for (int ta = 0; ta < NT; ta++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-              const int row = 16 * ta + (lane >> 4) * 4 + r, col = 16 * tb + (lane & 15);
-              float v = t == 0 ? acc00[lane].r[r] : (t == 1 ? acc10[lane].r[r] : acc11[lane].r[r]);
-              v += s.MM[row][col];   // the full symmetric M, identity beyond nv (setup); acc is zero there (J, XA columns >= nv are zero)
-              s.u.n.H[row][col] = v;
-              if (ta != tb) s.u.n.H[col][row] = v;
+            for (int tb = 0; tb <= ta; tb++) {
+#pragma unroll
+              for (int r = 0; r < 4; r++) {
+                const int row = 16 * ta + (lane >> 4) * 4 + r, col = 16 * tb + (lane & 15);
+                float v = acc[ta * (ta + 1) / 2 + tb][lane].r[r];
+                v += s.MM[row][col];   // the full symmetric M, identity beyond nv (setup); acc is zero there (J, XA columns >= nv are zero)
+                s.u.n.H[row][col] = v;
+                if (ta != tb) s.u.n.H[col][row] = v;
+              }
             }
-          }
         }
       }
       SYNC();
@@ -2910,7 +3195,17 @@ struct StepKernel {
       iter++;
       if (alpha == 0.f) break;
       LANES { qacc[lane] += alpha * search[lane]; Ma[lane] += alpha * Mv[lane]; }
-      ROWS_BEGIN(rb, ne) LANES { nr.jar[lane] += alpha * nr.jv[lane]; } ROWS_END_RW(rb)
+      if (M.nroot > 1) {
+        // scenes with free objects: the residual is re-evaluated from the new qacc with error-free transformations instead
+        // of being advanced by alpha * jv.  jv = J search is a plain fp32 product (error ~1e-5 of terms that cancel to 1e-2),
+        // and with D = 1/R up to 1e4 that is 0.1 N of force noise per iteration -- invisible on the 20 kg robot, 5 % of the
+        // acceleration of a 0.5 kg object (inertia 3e-4).  The line search keeps using jv (it only sets the step length).
+        PL<float> qn;
+        LANES { qn[lane] = qacc[lane]; }
+        ROWS_BEGIN(rb, ne) mat_J_exact(nr.jar, qn, nr.aref, rb); ROWS_END_RW(rb)
+      } else {
+        ROWS_BEGIN(rb, ne) LANES { nr.jar[lane] += alpha * nr.jv[lane]; } ROWS_END_RW(rb)
+      }
       // decrease of the cost along the accepted step, from the slope at 0 (exact for the quadratic pieces)
       if (scale * (-0.5f * alpha * d10) < M.tolerance) break;
     }
@@ -2949,7 +3244,7 @@ struct StepKernel {
     }
     SYNC();
     LANES {
-      for (int t = 0; t < 5; t++) {
+      for (int t = 0; t < NENT; t++) {
         const int i = et.i[lane][t], j = et.j[lane][t];
         if (i < 0) continue;
         float v = (i == j) ? s.Mdiag[i] : s.MM[j][i];
@@ -3001,14 +3296,14 @@ struct StepKernel {
     PL<int> bad;
     LANES {
       int b = 0;
-      if (lane < M.nq) { const float q = s.qpos[lane]; b |= !(fabsf(q) < 1e10f); }
+      for (int k = lane; k < M.nq; k += 64) { const float q = s.qpos[k]; b |= !(fabsf(q) < 1e10f); }
       if (lane < nv) { const float v = s.qvel[lane]; b |= !(fabsf(v) < 1e10f); }
       bad[lane] = b;
     }
     if (wave_ballot(bad) != 0) {
       flags |= SMJ_FLAG_BAD_STATE;
       LANES {
-        if (lane < M.nq) s.qpos[lane] = M.qpos0[lane];
+        for (int k = lane; k < M.nq; k += 64) s.qpos[k] = M.qpos0[k];
         if (lane < nv) { s.qvel[lane] = 0.f; s.warm[lane] = 0.f; }
       }
       SYNC();
@@ -3047,7 +3342,7 @@ struct StepKernel {
     mulmat3Tvec(ac, R, alin);
     if (S.stage) {
       float* st = stage_row();
-      LANES { if (lane < 3) { st[SMJ_ST_GYRO + lane] = gy[lane]; st[SMJ_ST_ACCEL + lane] = ac[lane]; } }
+      LANES { if (lane < 3) { st[S.lay.gyro + lane] = gy[lane]; st[S.lay.accel + lane] = ac[lane]; } }
     } else {
       LANES { if (lane < 3) { S.gyro[lane * S.ld + env] = gy[lane]; S.accel[lane * S.ld + env] = ac[lane]; } }
     }
@@ -3057,7 +3352,7 @@ struct StepKernel {
   // mjv_updateScene read from mjData
   SMJ_DEV void dump_poses() {
     if (S.stage) {   // contiguous: 12 words per body
-      float* st = stage_row() + SMJ_ST_XPOSE;
+      float* st = stage_row() + S.lay.xpose;
       LANES {
         for (int k = lane; k < 12 * M.nbody; k += 64) {
           const int b = k / 12, c = k - 12 * b;
@@ -3133,6 +3428,7 @@ struct StepKernel {
       TICK(SMJ_PROF_COLLISION)
       make_constraint();
       TICK(SMJ_PROF_MAKECON)
+      if (S.redo && !S.redo_worker && M.solver == 2 && (flags & (SMJ_FLAG_EFC_OVERFLOW | SMJ_FLAG_CON_OVERFLOW))) { escalate(st); return; }
       if (M.solver == 2) solve_newton(last, pc, t0, prof);
       else solve(last, pc, t0, prof);
       if (last && want_imu) imu();

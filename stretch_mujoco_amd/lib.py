@@ -12,13 +12,26 @@ LIB_PATH = os.path.join(_HERE, "libsmj.so")
 
 SLOT = dict(QPOS=0, QVEL=1, CTRL=2, WARMSTART=3, NSTEP=4, ACT_LENGTH=5, ACT_VELOCITY=6, BASE_POSE=7, GYRO=8, ACCEL=9,
             LIDAR=10, INFO=11, DEBUG=12, PROF=13, XPOSE=14, BASECTL=15)
-DIM = dict(NQ=0, NV=1, NU=2, NBODY=3, NLIDAR=4, NKEY=5, NUM_ENVS=6, DEBUG_FLOATS=7, NEFC_MAX=8, NCON_MAX=9, NCAM=10)
+DIM = dict(NQ=0, NV=1, NU=2, NBODY=3, NLIDAR=4, NKEY=5, NUM_ENVS=6, DEBUG_FLOATS=7, NEFC_MAX=8, NCON_MAX=9, NCAM=10, NV_MAX=11)
 READ_IMU, READ_LIDAR, READ_POSES = 1, 2, 4
 EXPORTS = ("smj_create", "smj_destroy", "smj_bind", "smj_dims", "smj_reset", "smj_step", "smj_set_option",
            "smj_last_error", "smj_version", "smj_render_depth", "smj_comm_init", "smj_allgather_returns", "smj_comm_destroy",
            "smj_base_controller_tick")
 
 _lib = None
+
+
+def debug_layout(nvp: int = 32, ncon: int = 16) -> dict:
+    """Offsets of the optional debug dump (SMJ_SLOT_DEBUG) for a kernel variant with `nvp` dof lanes and `ncon` contact slots
+    (csrc/smj_model.h, smj_debug_layout): standard variant 32 / 16, big variant 64 / 48."""
+    L, o = {}, 0
+    for name, n in (("qm", nvp * nvp), ("g", nvp), ("qacc", nvp), ("efc_force", 64), ("efc_b", 64), ("efc_r", 64), ("efc_aref", 64),
+                    ("ar_diag", 64), ("xpos", 96), ("qfrc_bias", nvp), ("qfrc_passive", nvp), ("qfrc_act", nvp), ("con", 8 * ncon),
+                    ("ar", 64 * 64)):
+        L[name] = o
+        o += n
+    L["floats"] = o
+    return L
 
 
 class SmjError(RuntimeError):

@@ -1242,7 +1242,7 @@ def empty_scene_xml(stretch_xml_path: str) -> str:
             '<worldbody><geom name="floor" type="plane" size="0 0 0.05"/></worldbody></mujoco>')
 
 
-def kitchen_standin_xml(stretch_xml_path: str, free_ball: bool = False) -> str:
+def kitchen_standin_xml(stretch_xml_path: str, free_ball: bool = False, free_objects: bool = False) -> str:
     """Synthetic kitchen stand-in (Robocasa itself is unavailable here): the robot at
     the origin in a 5 m x 5 m room with a counter run on its arm side (-y), wall cabinets above it, an island in front, a
     fridge, a table and a few fixtures -- 24 STATIC boxes on the world body, all colliding with the robot ([MJ] default
@@ -1277,6 +1277,25 @@ def kitchen_standin_xml(stretch_xml_path: str, free_ball: bool = False) -> str:
     # exactly the kernel's 32-dof capacity; sphere contacts are single-point exact, no multi-contact manifold needed)
     ball = ('<body name="ball" pos="-0.3 -0.95 0.9597"><freejoint name="ball_free"/>'
             '<geom name="ball" type="sphere" size="0.04" mass="0.1" rgba="0.9 0.3 0.2 1" condim="4" friction="1 0.01 0.001"/></body>') if free_ball else ""
+    if free_objects:
+        # config 4 as SURVEY.md 8(d) specifies it: 4 free objects (2 boxes, 2 cylinders), two on the countertop within reach of
+        # the gripper and two on the table.  Box / cylinder resting contacts are the multi-point cases (box-box, multiccd).
+        ball = ('<body name="box_a" pos="-0.45 -0.95 0.96"><freejoint/><geom name="box_a" type="box" size="0.03 0.03 0.04" mass="0.2" rgba="0.2 0.2 0.8 1"/></body>'
+                '<body name="cyl_a" pos="-0.15 -0.95 0.96"><freejoint/><geom name="cyl_a" type="cylinder" size="0.03 0.04" mass="0.2" rgba="0.8 0.2 0.2 1"/></body>'
+                '<body name="box_b" pos="-0.2 1.45 0.80"><freejoint/><geom name="box_b" type="box" size="0.04 0.03 0.04" mass="0.3" rgba="0.2 0.7 0.3 1"/></body>'
+                '<body name="cyl_b" pos="0.2 1.45 0.80"><freejoint/><geom name="cyl_b" type="cylinder" size="0.03 0.04" mass="0.3" rgba="0.8 0.7 0.2 1"/></body>')
     return (f'<mujoco model="stretch_kitchen_standin"><include file="{stretch_xml_path}"/>'
             '<worldbody><geom name="floor" type="plane" size="0 0 0.05"/>' + "".join(boxes) + ball + '</worldbody></mujoco>')
+
+
+def scene_table_xml(stretch_xml_path: str) -> str:
+    """The reference's own default scene (stretch_mujoco/models/scene.xml:21-35): floor, a table (a jointless body: welded to the
+    world) and two free objects on it, a box and a cylinder.  The docking station of scene.xml is left out: its mesh
+    link_docking_base.obj is absent from the checkout (.MISSING_LARGE_BLOBS:2)."""
+    return (f'<mujoco model="stretch scene"><include file="{stretch_xml_path}"/>'
+            '<worldbody><geom name="floor" size="0 0 0.05" type="plane"/>'
+            '<body name="table" pos="0 -1 .24"><geom type="box" size=".6 .5 .24" mass="1"/></body>'
+            '<body name="object1" pos="-.02 -0.55 .6"><freejoint/><geom type="box" size=".02 .04 .04" mass=".5" rgba=".2 .2 .5 1"/></body>'
+            '<body name="object2" pos=".08 -0.55 .6"><freejoint/><geom type="cylinder" size=".02 .04 .04" mass=".5" rgba=".8 .2 .2 1"/></body>'
+            '</worldbody></mujoco>')
 

@@ -328,5 +328,10 @@ def _is_desc(par, x, b):
     return x == b
 
 
-def prepare_for_kernels(m: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
-    return kernel_tables(fuse_static_bodies(m))
+def prepare_for_kernels(m: Dict[str, np.ndarray], capacity: str = "auto") -> Dict[str, np.ndarray]:
+    """Fused model + kernel tables.  capacity: "auto" lets smj_create pick the step-kernel variant by the model's size (standard:
+    32 dofs / 80 constraint rows / 16 contacts; big: 64 / 160 / 48); "big" asks for the big variant regardless -- for
+    contact-rich scenes (fixtures all around the robot) whose steps would keep escalating out of the standard one."""
+    f = kernel_tables(fuse_static_bodies(m))
+    f["k_capacity_hint"] = np.array([1 if capacity == "big" else 0], np.int32)
+    return f

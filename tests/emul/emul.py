@@ -8,29 +8,33 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = None
+_LIB = {}
 
 SLOTS = dict(qpos=0, qvel=1, ctrl=2, warm=3, nstep=4, act_len=5, act_vel=6, base=7, gyro=8, accel=9, lidar=10, info=11, debug=12, bctl=15)
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
+def lib(big: bool = False):
+    if big not in _LIB:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
-        L = ctypes.CDLL(os.path.join(_HERE, "libsmj_emul.so"))
+        L = ctypes.CDLL(os.path.join(_HERE, "libsmj_emul_big.so" if big else "libsmj_emul.so"))
         L.emul_create.restype = ctypes.c_void_p
         L.emul_create.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
         L.emul_bind.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_long]
         L.emul_step.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint]
         L.emul_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double]
         L.emul_destroy.argtypes = [ctypes.c_void_p]
-        _LIB = L
-    return _LIB
+        _LIB[big] = L
+    return _LIB[big]
 
 
 class Emul:
-    def __init__(self, blob: bytes, dims: dict, num_envs: int = 1, debug: bool = True):
-        self.L = lib()
+    def __init__(self, blob: bytes, dims: dict, num_envs: int = 1, debug: bool = True, big: bool | None = None):
+        """big: the 64-dof / 160-row / 48-contact kernel variant (default: chosen like smj_create does, by the model's size)."""
+        if big is None:
+            big = dims["nv"] > 32
+        self.big = big
+        self.L = lib(big)
+        self.nvp, self.ncon_max = self.L.emul_nvp(), self.L.emul_ncon_max()
         self.B = B = num_envs
         self.c = self.L.emul_create(blob, len(blob), B)
         if not self.c:

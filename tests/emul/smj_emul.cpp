@@ -40,13 +40,16 @@ extern "C" {
 emul_ctx* emul_create(const void* blob, size_t nbytes, int num_envs) {
   emul_ctx* c = new emul_ctx();
   HostUploader up{&c->keep};
-  if (smj_load_model(blob, nbytes, c->m, up, c->err)) {
+  const SmjCaps caps{NVP, NBP, NENT, NEFC, NCON};   // this build's variant (Makefile: -DSMJ_BIG for libsmj_emul_big.so)
+  int chosen = 0;
+  if (smj_load_model(blob, nbytes, c->m, up, c->err, &caps, 1, &chosen)) {
     fprintf(stderr, "emul_create: %s\n", c->err.c_str());
     delete c;
     return nullptr;
   }
   c->s.B = num_envs;
   c->s.ld = num_envs;
+  c->s.lay = smj_stage_layout(NVP, NBP);
   return c;
 }
 void emul_destroy(emul_ctx* c) {
@@ -87,6 +90,7 @@ int emul_set_option(emul_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "max_contacts_per_pair")) m.max_con_pair = (int)v;
   else if (!strcmp(name, "solver")) m.solver = (int)v;
   else if (!strcmp(name, "convex_pairs")) m.convex_pairs = (int)v;
+  else if (!strcmp(name, "multiccd")) m.multiccd = (int)v;
   else return -1;
   return 0;
 }
@@ -103,4 +107,7 @@ int emul_step(emul_ctx* c, int nsteps, unsigned read_flags) {
   return 0;
 }
 int emul_debug_floats() { return SMJ_DEBUG_FLOATS; }
+int emul_nvp() { return NVP; }
+int emul_ncon_max() { return NCON; }
+int emul_nefc_max() { return NEFC; }
 }

@@ -77,26 +77,45 @@ def free_running(backend, blob, model, B, windows, seed, solver=2):
     return dict(base=mx(0), arm=mx(1), obj=mx(2), hist=hist, flags=backend.download()["info"][3], oracles=oracles)
 
 
-def _bifurcation_explains(blob, solver, state, ctrl, qacc_kernel, trials=24, eps=1e-7, tol=EVENT_TOL):
-    """Does the oracle reproduce the kernel's acceleration at an input within `eps` of the shared state?"""
+def _bifurcation_explains(blob, solver, state, ctrl, qacc_kernel, trials=12, tol=EVENT_TOL):
+    """Does the oracle reproduce the kernel's acceleration at an input near the shared state?  Perturbations of 1e-7 (fp32
+    round-off of the poses), then 1e-6 and 1e-5: MPR's answer on curved or faceted pairs (cylinder rim against a mesh hull) is
+    the normal of the portal facet it happens to stop on, and which facet that is moves with perturbations far below the
+    algorithm's own 1e-6 m tolerance.  Returns (explained, best residual, eps that explained it)."""
     qpos, qvel, warm = state
     rng = np.random.default_rng(12345)
     scale = max(1.0, np.abs(qacc_kernel).max())
     best = np.inf
-    for t in range(trials):
-        o = Oracle(blob)
-        o.set_option("solver", solver)
-        q = qpos.copy()
-        if t:
-            q += rng.normal(size=q.shape) * eps
-        o.arr("qpos")[:] = q; o.arr("qvel")[:] = qvel; o.arr("qacc_warmstart")[:] = warm
-        o.arr("ctrl")[: len(ctrl)] = ctrl
-        o.forward()
-        err = np.abs(o.arr("qacc") - qacc_kernel).max() / scale
-        best = min(best, err)
-        if err < tol:
-            return True, err
-    return False, best
+    for eps in (1e-7, 1e-6, 1e-5):
+        for t in range(trials):
+            o = Oracle(blob)
+            o.set_option("solver", solver)
+            q = qpos.copy()
+            if t:
+                q += rng.normal(size=q.shape) * eps
+            o.arr("qpos")[:] = q; o.arr("qvel")[:] = qvel; o.arr("qacc_warmstart")[:] = warm
+            o.arr("ctrl")[: len(ctrl)] = ctrl
+            o.forward()
+            err = np.abs(o.arr("qacc") - qacc_kernel).max() / scale
+            best = min(best, err)
+            if err < tol:
+                return True, err, eps
+    return False, best, None
+
+
+def _same_contacts_same_dynamics(blob, solver, state, ctrl, qacc_kernel, dump, ncon_k, tol=EVENT_TOL):
+    qpos, qvel, warm = state
+    ck = dump.reshape(-1, 8)[:ncon_k].astype(np.float64)
+    code = ck[:, 7].astype(np.int64)
+    con = np.concatenate([ck[:, :7], ((code >> 4) & 1023)[:, None].astype(np.float64), (code >> 14)[:, None].astype(np.float64)], 1)
+    o = Oracle(blob)
+    o.set_option("solver", solver)
+    o.arr("qpos")[:] = qpos; o.arr("qvel")[:] = qvel; o.arr("qacc_warmstart")[:] = warm
+    o.arr("ctrl")[: len(ctrl)] = ctrl
+    o.set_contacts(con)
+    o.forward()
+    err = np.abs(o.arr("qacc") - qacc_kernel).max() / max(1.0, np.abs(qacc_kernel).max())
+    return bool(err < tol), float(err)
 
 
 def state_synchronised(backend, blob, model, B, windows, seed, solver=2):
@@ -106,6 +125,7 @@ def state_synchronised(backend, blob, model, B, windows, seed, solver=2):
     nu, nv = oracles[0].dim("nu"), oracles[0].dim("nv")
     sched = ctrl_schedule(model, nu, B, windows, seed)
     rel, events = [], []
+    clean = []    # env-steps whose contact lists agree (same pairs, normals within 0.5 degree): the dynamics-only error sample
     cstat = dict(n=0, depth=[], pos=[], cosn=[], mismatched_steps=0)   # contact geometry on identical states
     for w in range(windows):
         backend.set_ctrl(sched[w])
@@ -122,12 +142,21 @@ def state_synchronised(backend, blob, model, B, windows, seed, solver=2):
                 qk = out["qacc"][:nv, b]
                 r = np.abs(qk - qa).max() / max(1.0, np.abs(qa).max())
                 rel.append(r)
-                _compare_contacts(cstat, out["contacts"][:, b], int(out["info"][1, b]), o)
+                if _compare_contacts(cstat, out["contacts"][:, b], int(out["info"][1, b]), o):
+                    clean.append(r)
                 if r > EVENT_TOL or int(out["info"][1, b]) != o.ncon:
-                    ok, err = _bifurcation_explains(blob, solver, (st[0][:, b], st[1][:, b], st[2][:, b]), sched[w][:, b], qk)
+                    ok, err, eps = _bifurcation_explains(blob, solver, (st[0][:, b], st[1][:, b], st[2][:, b]), sched[w][:, b], qk)
+                    if not ok:
+                        # same state, the KERNEL's contact list handed to the oracle: isolates the dynamics from MPR's portal
+                        # noise on curved rims / faceted hulls (its normal is the facet the refinement stops on: degrees of
+                        # scatter under the algorithm's own 1e-6 m tolerance, tools/parity_probe.py)
+                        ok, err = _same_contacts_same_dynamics(blob, solver, (st[0][:, b], st[1][:, b], st[2][:, b]), sched[w][:, b], qk,
+                                                               out["contacts"][:, b], int(out["info"][1, b]))
+                        eps = "kernel contacts" if ok else None
                     events.append(dict(env=b, window=w, step=s, rel=float(r), ncon_kernel=int(out["info"][1, b]), ncon_oracle=o.ncon,
-                                       explained=bool(ok), residual=float(err), flags=int(out["info"][3, b])))
+                                       explained=bool(ok), residual=float(err), eps=eps, flags=int(out["info"][3, b])))
     state_synchronised.contacts = cstat
+    state_synchronised.clean = np.array(clean)
     return np.array(rel), events
 
 
@@ -135,19 +164,22 @@ def _compare_contacts(cstat, dump, ncon_k, o):
     """Contact list of the kernel (debug slot: dist, pos, normal, condim | geom1 << 4 | geom2 << 14 per contact) against the
     oracle's on the same state, contact by contact in list order (both emit in pair-table order)."""
     n = o.ncon
-    ck = dump.reshape(16, 8)[:ncon_k]
+    ck = dump.reshape(-1, 8)[:ncon_k]
     co = o.arr("contact").reshape(n, -1) if n else np.zeros((0, 29))
     code = ck[:, 7].astype(np.int64)
     gk = [(int((c >> 4) & 1023), int(c >> 14)) for c in code]
     go = [tuple(int(v) for v in co[k, -2:].copy().view(np.int32)[1:3]) for k in range(n)]
     if gk != go:
         cstat["mismatched_steps"] += 1
-        return
+        return False
+    same = True
     for k in range(n):
+        same = same and float(np.dot(ck[k, 4:7], co[k, 4:7])) > 0.99996 and abs(ck[k, 0] - co[k, 0]) < 1e-5
         cstat["n"] += 1
         cstat["depth"].append(abs(ck[k, 0] - co[k, 0]))
         cstat["pos"].append(np.abs(ck[k, 1:4] - co[k, 1:4]).max())
         cstat["cosn"].append(float(np.dot(ck[k, 4:7], co[k, 4:7])))
+    return same
 
 
 class EmulBackend:
@@ -157,8 +189,16 @@ class EmulBackend:
         from emul.emul import Emul
 
         o = Oracle(blob)
-        self.e = Emul(blob, dict(nq=o.dim("nq"), nv=o.dim("nv"), nu=o.dim("nu"), nlidar=360), num_envs=B, debug=True)
+        import stretch_mujoco_amd.model_blob as mb
+
+        hint = mb.loads(blob).get("k_capacity_hint")
+        big = o.dim("nv") > 32 or (hint is not None and int(np.asarray(hint).ravel()[0]) > 0)   # as smj_create chooses
+        self.e = Emul(blob, dict(nq=o.dim("nq"), nv=o.dim("nv"), nu=o.dim("nu"), nlidar=360), num_envs=B, debug=True, big=big)
         self.e.set_option("solver", solver)
+        from stretch_mujoco_amd.lib import debug_layout
+
+        self.D = debug_layout(self.e.nvp, self.e.ncon_max)
+        self.ncon_max, self.nvp = self.e.ncon_max, self.e.nvp
 
     def upload(self, qpos, qvel, warm):
         self.e.qpos[:] = qpos; self.e.qvel[:] = qvel; self.e.warm[:] = warm
@@ -172,7 +212,8 @@ class EmulBackend:
     def download(self):
         e = self.e
         return dict(qpos=e.qpos.astype(np.float64), qvel=e.qvel.astype(np.float64), info=e.info.copy(),
-                    qacc=e.debug[1056:1056 + 32].astype(np.float64), contacts=e.debug[1600:1728].copy())
+                    qacc=e.debug[self.D["qacc"]:self.D["qacc"] + self.nvp].astype(np.float64),
+                    contacts=e.debug[self.D["con"]:self.D["con"] + 8 * self.ncon_max].copy())
 
 
 class HipBackend:
@@ -186,6 +227,7 @@ class HipBackend:
         self.torch = torch
         self.sim = StretchBatchSimulator(num_envs=B, device="cuda:0", scene=scene, solver={0: "pgs", 2: "newton"}[solver], debug=True)
         self.sim.start(home=False)
+        self.D, self.nvp, self.ncon_max = self.sim.debug_layout, self.sim.nv_max, self.sim.ncon_max
 
     def _put(self, dst, a):
         dst.copy_(self.torch.as_tensor(np.ascontiguousarray(a), dtype=self.torch.float32).to(dst.device))
@@ -203,8 +245,8 @@ class HipBackend:
         s = self.sim
         self.torch.cuda.synchronize()
         return dict(qpos=s.qpos.cpu().numpy().astype(np.float64), qvel=s.qvel.cpu().numpy().astype(np.float64),
-                    info=s.info.cpu().numpy(), qacc=s.debug[1056:1056 + 32].cpu().numpy().astype(np.float64),
-                    contacts=s.debug[1600:1728].cpu().numpy())
+                    info=s.info.cpu().numpy(), qacc=s.debug[self.D["qacc"]:self.D["qacc"] + self.nvp].cpu().numpy().astype(np.float64),
+                    contacts=s.debug[self.D["con"]:self.D["con"] + 8 * self.ncon_max].cpu().numpy())
 
     def close(self):
         self.sim.stop()

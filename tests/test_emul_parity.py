@@ -242,6 +242,7 @@ def test_rows_beyond_one_wavefront(blob_fused):
     ctrl = [0, 0, 0.0, 0.3, 0, -1.57, 0, 0, 0, 0]
     o.arr("ctrl")[:10] = ctrl
     e = Emul(blob_fused, DIMS, num_envs=1); e.set_option("solver", 2)
+    o.set_option("multiccd", 0); e.set_option("multiccd", 0)   # the scripted row counts are those of single-point convex contacts
     e.ctrl[:, 0] = np.asarray(ctrl, np.float32)
     o.step(22)
     for want in (77, 80, None):
@@ -261,14 +262,14 @@ def test_rows_beyond_one_wavefront(blob_fused):
 def test_second_row_pass_reads_no_stale_lds(blob_fused):
     """Same 77- and 80-row steps with the LDS pre-filled with zeros / large values / NaNs before every launch: the rows of
     the second pass (their registers live in LDS between stages) must not depend on what was there."""
-    o = Oracle(blob_fused); o.set_option("solver", 2); o.reset()
+    o = Oracle(blob_fused); o.set_option("solver", 2); o.set_option("multiccd", 0); o.reset()   # single-point convex contacts: the scripted row counts
     ctrl = [0, 0, 0.0, 0.3, 0, -1.57, 0, 0, 0, 0]
     o.arr("ctrl")[:10] = ctrl
     o.step(22)
     q, v, w = o.arr("qpos").copy(), o.arr("qvel").copy(), o.arr("qacc_warmstart").copy()
     ref = None
     for poison in (0x00, 0x7F, 0xFF):
-        e = Emul(blob_fused, DIMS, num_envs=1); e.set_option("solver", 2); e.set_poison(poison)
+        e = Emul(blob_fused, DIMS, num_envs=1); e.set_option("solver", 2); e.set_option("multiccd", 0); e.set_poison(poison)
         e.ctrl[:, 0] = np.asarray(ctrl, np.float32)
         e.qpos[:, 0] = q; e.qvel[:, 0] = v; e.warm[:, 0] = w
         e.step(1); a = np.concatenate([e.qpos[:, 0], e.qvel[:, 0]]).copy(); n1 = int(e.info[0, 0])

@@ -150,6 +150,7 @@ def test_mpr_penetration_against_closed_forms():
 
     def first_contact(xml):
         o = make(xml)
+        o.set_option("multiccd", 0)    # the single-point query itself; the multi-point manifolds are tested below
         o.forward()
         assert o.ncon == 1
         c = o.arr("contact").reshape(1, -1)[0]
@@ -168,6 +169,50 @@ def test_mpr_penetration_against_closed_forms():
              '<body pos="0 0 0.25"><freejoint/><geom type="box" size="0.1 0.1 0.1"/></body></worldbody></mujoco>')
     o.forward()
     assert o.ncon == 0
+
+
+def test_box_box_polygon_and_multiccd_manifolds():
+    """Multi-point contacts (stretch.xml:8 enables multiccd): a box on a box gets the clipped face polygon -- here the four
+    bottom corners of the small box, all 2 cm deep, midway between the two faces; partially overlapping faces give the
+    intersection polygon; an edge-edge crossing gives one point.  A cylinder lying on a box gets a line of points from the
+    counter-rotated queries, all sharing the first normal.  A box resting on a box does not rock."""
+    opt = '<option integrator="implicitfast" cone="elliptic" impratio="20" gravity="0 0 0"/>'
+    o = make(f'<mujoco><compiler angle="radian"/>{opt}<worldbody><body><freejoint/><geom type="box" size="0.2 0.2 0.1"/></body>'
+             '<body pos="0.05 0.03 0.18"><freejoint/><geom type="box" size="0.1 0.1 0.1"/></body></worldbody></mujoco>')
+    o.forward()
+    c = o.arr("contact").reshape(o.ncon, -1)
+    assert o.ncon == 4 and np.allclose(c[:, 0], -0.02, atol=1e-12) and np.allclose(c[:, 4:7], [0, 0, 1], atol=1e-12)
+    assert np.allclose(c[:, 3], 0.09, atol=1e-12)
+    corners = sorted((round(x, 6), round(y, 6)) for x, y in c[:, 1:3])
+    assert corners == [(-0.05, -0.07), (-0.05, 0.13), (0.15, -0.07), (0.15, 0.13)]
+    # faces overlapping partially: the small box hangs over the edge x = 0.2 of the big one -> polygon [0.15, 0.2] x [-0.1, 0.1]
+    o = make(f'<mujoco><compiler angle="radian"/>{opt}<worldbody><body><freejoint/><geom type="box" size="0.2 0.2 0.1"/></body>'
+             '<body pos="0.25 0 0.19"><freejoint/><geom type="box" size="0.1 0.1 0.1"/></body></worldbody></mujoco>')
+    o.forward()
+    c = o.arr("contact").reshape(o.ncon, -1)
+    pts = sorted((round(x, 6), round(y, 6)) for x, y in c[:, 1:3])
+    assert o.ncon == 4 and pts == [(0.15, -0.1), (0.15, 0.1), (0.2, -0.1), (0.2, 0.1)] and np.allclose(c[:, 0], -0.01, atol=1e-12)
+    # edge against edge: the upper box turned 45 deg about x and about z, its lowest edge crossing the top edge region
+    o = make(f'<mujoco><compiler angle="radian"/>{opt}<worldbody><body><freejoint/><geom type="box" size="0.2 0.2 0.1"/></body>'
+             '<body pos="0.2 0 0.235" euler="0.7853981634 0 0.7853981634"><freejoint/><geom type="box" size="0.1 0.1 0.1"/></body></worldbody></mujoco>')
+    o.forward()
+    assert 1 <= o.ncon <= 2
+    # cylinder lying on the box (axis along y): the first contact plus the counter-rotated queries spread along the line
+    o = make(f'<mujoco><compiler angle="radian"/>{opt}<worldbody><body><freejoint/><geom type="box" size="0.2 0.2 0.1"/></body>'
+             '<body pos="0 0 0.19" euler="1.5708 0 0"><freejoint/><geom type="cylinder" size="0.1 0.15"/></body></worldbody></mujoco>')
+    o.forward()
+    c = o.arr("contact").reshape(o.ncon, -1)
+    assert 2 <= o.ncon <= 5 and np.allclose(c[:, 4:7], c[0, 4:7], atol=1e-12) and np.ptp(c[:, 2]) > 0.2   # spread along y
+    assert np.all(np.abs(c[:, 0] + 0.01) < 1e-3)    # depths are those of the counter-rotated (1e-3 rad) configurations
+    # a box put on a box stays put (a single contact point would let it rock)
+    o = make(f'<mujoco><compiler angle="radian"/>{OPT}<worldbody><geom type="plane" size="0 0 1"/>'
+             '<body pos="0 0 0.1"><freejoint/><geom type="box" size="0.2 0.2 0.1" mass="2"/></body>'
+             '<body pos="0.05 0.03 0.2995"><freejoint/><geom type="box" size="0.05 0.04 0.1" mass="0.5"/></body></worldbody></mujoco>')
+    o.set_option("solver", 2)
+    o.step(1000)
+    q = o.arr("qpos")
+    assert np.abs(o.arr("qvel")).max() < 1e-6 and abs(q[9] - 0.2995) < 2e-3 and np.allclose(q[10:14], [1, 0, 0, 0], atol=1e-3)
+    assert abs(q[7] - 0.05) < 1e-3 and abs(q[8] - 0.03) < 1e-3
 
 
 def test_sphere_rests_on_a_free_box():

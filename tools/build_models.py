@@ -26,7 +26,15 @@ def main():
     B.save(os.path.join(out, "stretch_empty_full.smjb"), full)
     B.save(os.path.join(out, "stretch_empty.smjb"), F.prepare_for_kernels(m))        # fused + kernel tables (product)
     k = C.compile_string(C.kitchen_standin_xml(stretch, free_ball=True))
-    B.save(os.path.join(out, "stretch_kitchen_standin.smjb"), F.prepare_for_kernels(k))  # config 4 stand-in (static fixtures + one free ball)
+    # config 4 stand-in (static fixtures + one free ball); contact-rich: the big kernel variant (box-box polygons of the rubber
+    # tips on counters need more than 80 rows)
+    B.save(os.path.join(out, "stretch_kitchen_standin.smjb"), F.prepare_for_kernels(k, capacity="big"))
+    # the reference's own default scene (models/scene.xml: table + 2 free objects) and config 4 as SURVEY.md 8(d) has it
+    # (24 static boxes + 2 free boxes + 2 free cylinders): 38 / 50 dofs -> the big variant by size
+    for name, xml in (("stretch_scene", C.scene_table_xml(stretch)), ("stretch_kitchen4", C.kitchen_standin_xml(stretch, free_objects=True))):
+        mm = C.compile_string(xml)
+        B.save(os.path.join(out, name + ".smjb"), F.prepare_for_kernels(mm))
+        print(name + ":", dict(zip("nq nv nu nbody njnt ngeom".split(), [int(x) for x in mm["dims"][:6]])), "npair", int(mm["dims"][12]))
     print("stretch_kitchen_standin:", dict(zip("nq nv nu nbody njnt ngeom".split(), [int(x) for x in k["dims"][:6]])),
           "npair", int(k["dims"][12]))
     print("stretch_empty:", dict(zip("nq nv nu nbody njnt ngeom nsite ncam neq ntendon nwrap nkey npair nhullvert".split(),
