@@ -27,10 +27,10 @@ struct smj_ctx {
   std::string err;
   float* qpos0_dev = nullptr;
   float* stage = nullptr;      // env-major staging copy of the state, [num_envs][layout.stride] (DevState::stage)
-  int variant = 0;             // 0: standard step kernel, 1: big (smj_model.h)
-  // capacity escalation (standard variant): the model once more with the big variant's records, and the list of parked envs
-  DevModel model_big{};
-  bool has_big = false;
+  int variant = 0;             // 0: standard step kernel, 1: tall, 2: big (smj_model.h)
+  // capacity escalation (standard variant): the model once more with the tall variant's records, and the list of parked envs
+  DevModel model_esc{};
+  bool has_esc = false;
   int* redo = nullptr;
   int escalate = 1;
   SmjCaps caps{};              // capacities of the variant in use
@@ -223,11 +223,11 @@ int smj_create(const void* blob, size_t nbytes, int num_envs, int device, smj_ct
   if (rc) return rc;
   c->caps = caps[c->variant];
   c->layout = smj_stage_layout(c->caps.nvp, c->caps.nbp);
-  if (c->variant == 0) {   // escalation target: the same model loaded for the big variant (its own per-lane records)
+  if (c->variant == 0) {   // escalation target: the same model loaded for the tall variant
     int dummy = 0;
-    rc = smj_load_model(blob, nbytes, c->model_big, up, c->err, caps + 1, 1, &dummy);
+    rc = smj_load_model(blob, nbytes, c->model_esc, up, c->err, caps + 1, 1, &dummy);
     if (rc) return rc;
-    c->has_big = true;
+    c->has_esc = true;
     void* d = nullptr;
     HIPCHK(c, hipMalloc(&d, sizeof(int) * (1 + 2 * (size_t)num_envs)));
     c->allocs.push_back(d);
@@ -434,23 +434,24 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
   if (read_flags & SMJ_READ_POSES) out.add(st.xpose, 12 * m.nbody, Y.xpose);
   st.stage = c->stage;
   st.lay = Y;
-  const bool esc = c->variant == 0 && c->has_big && c->escalate && c->model.solver == 2;
+  const bool esc = c->variant == 0 && c->has_esc && c->escalate && c->model.solver == 2;
   st.redo = esc ? c->redo : nullptr;
   st.redo_worker = 0;
   if (esc) HIPCHK(c, hipMemsetAsync(c->redo, 0, sizeof(int), (hipStream_t)stream));
   smj_launch_stage(in, c->stage, Y.stride, c->num_envs, st.ld, false, (hipStream_t)stream);
-  int lrc = c->variant ? smj_launch_step_big(c->model, st, nsteps, read_flags, (hipStream_t)stream)
-                       : smj_launch_step(c->model, st, nsteps, read_flags, (hipStream_t)stream);
+  int lrc = c->variant == 2   ? smj_launch_step_big(c->model, st, nsteps, read_flags, (hipStream_t)stream)
+            : c->variant == 1 ? smj_launch_step_tall(c->model, st, nsteps, read_flags, (hipStream_t)stream)
+                              : smj_launch_step(c->model, st, nsteps, read_flags, (hipStream_t)stream);
   if (!lrc && esc) {
-    // envs that ran out of constraint rows / contact slots were parked at the start of the offending step: the big variant
-    // (64 dofs / 160 rows / 48 contacts) finishes their steps; a launch without such envs finds the list empty and returns
-    DevModel& mb = c->model_big;
+    // envs that ran out of constraint rows / contact slots were parked at the start of the offending step: the tall variant
+    // (160 rows / 48 contacts) finishes their steps; a launch without such envs finds the list empty and returns
+    DevModel& mb = c->model_esc;
     const DevModel& ms = c->model;
     mb.iterations = ms.iterations; mb.warmstart = ms.warmstart; mb.pgs_fixed_iter = ms.pgs_fixed_iter; mb.max_con_pair = ms.max_con_pair;
     mb.solver = ms.solver; mb.ls_iterations = ms.ls_iterations; mb.convex_pairs = ms.convex_pairs; mb.multiccd = ms.multiccd;
     mb.ls_tolerance = ms.ls_tolerance; mb.tolerance = ms.tolerance;
     st.redo_worker = 1;
-    lrc = smj_launch_step_big(mb, st, nsteps, read_flags, (hipStream_t)stream);
+    lrc = smj_launch_step_tall(mb, st, nsteps, read_flags, (hipStream_t)stream);
   }
   if (lrc) return fail(c, -2, "step kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
   smj_launch_stage(out, c->stage, Y.stride, c->num_envs, st.ld, true, (hipStream_t)stream);

@@ -20,9 +20,11 @@ struct StagePlan {
   }
 };
 
-// the two capacity variants of the step kernel (smj_model.h); return 0 or a hipError_t
+// the capacity variants of the step kernel (smj_model.h); return 0 or a hipError_t
 int smj_launch_step(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);
+int smj_launch_step_tall(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);
 int smj_launch_step_big(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);
+void smj_tall_caps(int* nvp, int* nbp, int* nent, int* nefc, int* ncon, int* debug_floats);
 void smj_big_caps(int* nvp, int* nbp, int* nent, int* nefc, int* ncon, int* debug_floats);
 void smj_launch_reset(const DevModel& m, const DevState& s, const uint8_t* mask, hipStream_t stream);
 // batch-major -> env-major staging rows (import) and back (export); tiles of 64 envs transposed through LDS

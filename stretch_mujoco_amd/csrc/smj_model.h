@@ -4,17 +4,26 @@
 #pragma once
 #include <stdint.h>
 
-// Two capacity variants of the step kernel are compiled from the same source (smj_kernels.hip / smj_kernels_big.hip):
+// Three capacity variants of the step kernel are compiled from the same source (smj_kernels.hip, smj_kernels_tall.hip,
+// smj_kernels_big.hip):
 //   standard -- the robot alone or with ONE free object: 32 dofs, 80 constraint rows, 16 contacts; 40 KB of LDS per env,
 //               four envs per CU;
+//   tall (SMJ_TALL) -- the same 32 dofs with 160 rows and 48 contacts (~80 KB of LDS, two envs per CU): contact-rich scenes
+//               (kitchen fixtures all around the robot), and the escalation target of the standard variant -- an env whose
+//               step needs more rows / contacts than the standard kernel holds is finished by this one (DevState::redo);
 //   big (SMJ_BIG) -- scenes with several free objects (the reference's own scene.xml: table + 2 objects; kitchens):
 //               64 dofs, 160 rows, 48 contacts; ~130 KB of LDS per env, one env per CU.
-// smj_create picks the variant from the model's dimensions.
-#ifdef SMJ_BIG
+// smj_create picks the variant from the model's dimensions (and the model compiler's capacity hint).
+#if defined(SMJ_BIG)
 #define NVP 64    // dof capacity (model nv <= NVP)
 #define NEFC 160  // constraint-row capacity of the Newton path: rows 64.. take further passes on lanes 0..63 (PGS: 64)
 #define NCON 48   // contact capacity (<= 64: contact stages are lane = contact)
 #define NENT 8    // mass-matrix pattern entries per lane (64 lanes)
+#elif defined(SMJ_TALL)
+#define NVP 32
+#define NEFC 160
+#define NCON 48
+#define NENT 5
 #else
 #define NVP 32
 #define NEFC 80
@@ -178,4 +187,4 @@ enum {
   SMJ_DBG_AR = SMJ_DBG.ar,                     // 64*64 AR (PGS)
   SMJ_DEBUG_FLOATS = SMJ_DBG.floats
 };
-static_assert(NVP != 32 || (SMJ_DBG_QACC == 1056 && SMJ_DBG_CON == 1600 && SMJ_DBG_AR == 1728), "standard variant: the layout the tests index");
+static_assert(NVP != 32 || NCON != 16 || (SMJ_DBG_QACC == 1056 && SMJ_DBG_CON == 1600 && SMJ_DBG_AR == 1728), "standard variant: the layout the tests index");

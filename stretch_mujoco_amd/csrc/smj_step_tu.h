@@ -1,13 +1,16 @@
 // The step kernel and its launcher for ONE capacity variant (smj_model.h): included by smj_kernels.hip (standard) and by
-// smj_kernels_big.hip (SMJ_BIG).  Device code is compiled per translation unit, so the two instantiations of StepKernel / Smem
+// smj_kernels_tall.hip (SMJ_TALL) and smj_kernels_big.hip (SMJ_BIG).  Device code is compiled per translation unit, so the two instantiations of StepKernel / Smem
 // never meet.
 #pragma once
 #include "smj_kernels.h"
 #include "smj_step_impl.h"
 
-#ifdef SMJ_BIG
+#if defined(SMJ_BIG)
 #define SMJ_STEP_KERNEL smj_step_kernel_big
 #define SMJ_LAUNCH_STEP smj_launch_step_big
+#elif defined(SMJ_TALL)
+#define SMJ_STEP_KERNEL smj_step_kernel_tall
+#define SMJ_LAUNCH_STEP smj_launch_step_tall
 #else
 #define SMJ_STEP_KERNEL smj_step_kernel
 #define SMJ_LAUNCH_STEP smj_launch_step

@@ -13,10 +13,11 @@ _LIB = {}
 SLOTS = dict(qpos=0, qvel=1, ctrl=2, warm=3, nstep=4, act_len=5, act_vel=6, base=7, gyro=8, accel=9, lidar=10, info=11, debug=12, bctl=15)
 
 
-def lib(big: bool = False):
+def lib(variant: str = "standard"):
+    big = variant   # cache key
     if big not in _LIB:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
-        L = ctypes.CDLL(os.path.join(_HERE, "libsmj_emul_big.so" if big else "libsmj_emul.so"))
+        L = ctypes.CDLL(os.path.join(_HERE, {"standard": "libsmj_emul.so", "tall": "libsmj_emul_tall.so", "big": "libsmj_emul_big.so"}[variant]))
         L.emul_create.restype = ctypes.c_void_p
         L.emul_create.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
         L.emul_bind.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_long]
@@ -28,12 +29,20 @@ def lib(big: bool = False):
 
 
 class Emul:
-    def __init__(self, blob: bytes, dims: dict, num_envs: int = 1, debug: bool = True, big: bool | None = None):
-        """big: the 64-dof / 160-row / 48-contact kernel variant (default: chosen like smj_create does, by the model's size)."""
-        if big is None:
-            big = dims["nv"] > 32
-        self.big = big
-        self.L = lib(big)
+    def __init__(self, blob: bytes, dims: dict, num_envs: int = 1, debug: bool = True, big: bool | None = None, variant: str | None = None):
+        """variant: "standard" (32 dofs / 80 rows / 16 contacts), "tall" (32 / 160 / 48) or "big" (64 / 160 / 48); default: chosen
+        like smj_create does, by the model's size and the blob's capacity hint.  `big=True` is shorthand for variant="big"."""
+        if variant is None:
+            if big or dims["nv"] > 32:
+                variant = "big"
+            else:
+                import stretch_mujoco_amd.model_blob as mb
+
+                hint = mb.loads(blob).get("k_capacity_hint")
+                variant = "tall" if hint is not None and int(np.asarray(hint).ravel()[0]) > 0 else "standard"
+        self.variant = variant
+        self.big = variant == "big"
+        self.L = lib(variant)
         self.nvp, self.ncon_max = self.L.emul_nvp(), self.L.emul_ncon_max()
         self.B = B = num_envs
         self.c = self.L.emul_create(blob, len(blob), B)

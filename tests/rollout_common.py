@@ -189,11 +189,7 @@ class EmulBackend:
         from emul.emul import Emul
 
         o = Oracle(blob)
-        import stretch_mujoco_amd.model_blob as mb
-
-        hint = mb.loads(blob).get("k_capacity_hint")
-        big = o.dim("nv") > 32 or (hint is not None and int(np.asarray(hint).ravel()[0]) > 0)   # as smj_create chooses
-        self.e = Emul(blob, dict(nq=o.dim("nq"), nv=o.dim("nv"), nu=o.dim("nu"), nlidar=360), num_envs=B, debug=True, big=big)
+        self.e = Emul(blob, dict(nq=o.dim("nq"), nv=o.dim("nv"), nu=o.dim("nu"), nlidar=360), num_envs=B, debug=True)   # variant as smj_create picks it
         self.e.set_option("solver", solver)
         from stretch_mujoco_amd.lib import debug_layout
 
