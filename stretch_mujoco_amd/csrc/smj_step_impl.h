@@ -1618,13 +1618,17 @@ struct StepKernel {
   // (see there: behaviour restated, not MuJoCo's arithmetic).  The separating-axis test is wave-uniform; the polygon of a
   // face contact is enumerated lane-parallel -- lane = candidate: 4 incident corners inside the reference face, 4 reference
   // corners inside the incident face, 16 edge crossings -- and emitted in candidate order by ballot prefix.
-  SMJ_DEV static void col3(float* o, const float* R, int i) {   // column i of a row-major 3x3, static selects only
-    o[0] = i == 0 ? R[0] : (i == 1 ? R[1] : R[2]); o[1] = i == 0 ? R[3] : (i == 1 ? R[4] : R[5]); o[2] = i == 0 ? R[6] : (i == 1 ? R[7] : R[8]);
+  // Geom frames come from the collision stage's LDS cache (s.u.c, slot = cache index): dynamically chosen boxes / axes are
+  // LDS addresses, not register selects.
+  SMJ_DEV void ccol(float* o, int slot, int i) const {   // axis i of the cached frame of `slot`
+    o[0] = uni(s.u.c.mat[slot][i]); o[1] = uni(s.u.c.mat[slot][3 + i]); o[2] = uni(s.u.c.mat[slot][6 + i]);
   }
-  SMJ_DEV static float sel3(const float* v, int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : v[2]); }
-  SMJ_DEV void box_box(const int* rec, const Shape& S1, const Shape& S2, float margin) {
-    const float* p1 = S1.pos; const float* R1 = S1.mat; const float* A = S1.size;
-    const float* p2 = S2.pos; const float* R2 = S2.mat; const float* B = S2.size;
+  SMJ_DEV void box_box(const int* rec, int slot1, int slot2, float margin) {
+    float p1[3], p2[3], A[3], B[3], R1[9], R2[9];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { p1[k] = uni(s.u.c.pos[slot1][k]); p2[k] = uni(s.u.c.pos[slot2][k]); A[k] = uni(s.u.c.size[slot1][k]); B[k] = uni(s.u.c.size[slot2][k]); }
+#pragma unroll
+    for (int k = 0; k < 9; k++) { R1[k] = uni(s.u.c.mat[slot1][k]); R2[k] = uni(s.u.c.mat[slot2][k]); }
     const float p[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
     float R[3][3], Q[3][3], pp[3], pq[3];
 #pragma unroll
@@ -1680,7 +1684,7 @@ struct StepKernel {
         for (int x = 0; x < 3; x++) { pa[x] += sa * A[k] * ak[x]; pb[x] += sb * B[k] * bk[x]; }
       }
       float ua[3], ub[3];
-      col3(ua, R1, i); col3(ub, R2, j);
+      ccol(ua, slot1, i); ccol(ub, slot2, j);
       const float dd[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
       const float uaub = dot3(ua, ub), q1 = dot3(ua, dd), q2 = -dot3(ub, dd), den = 1.f - uaub * uaub;
       float al = 0, be = 0;
@@ -1692,31 +1696,27 @@ struct StepKernel {
     }
     // face contact.  Reference box a (the one owning the axis), incident box b; n from a to b
     const bool swap = code >= 3;
-    const int ia = swap ? code - 3 : code;
-    float pa[3], Ra[9], ha[3], pb[3], Rb[9], hb[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { pa[k] = swap ? p2[k] : p1[k]; pb[k] = swap ? p1[k] : p2[k]; ha[k] = swap ? B[k] : A[k]; hb[k] = swap ? A[k] : B[k]; }
-#pragma unroll
-    for (int k = 0; k < 9; k++) { Ra[k] = swap ? R2[k] : R1[k]; Rb[k] = swap ? R1[k] : R2[k]; }
-    float n[3], u[3], v[3];
-    col3(n, Ra, ia);
+    const int ia = swap ? code - 3 : code, sa = swap ? slot2 : slot1, sb = swap ? slot1 : slot2;
+    float pa[3], pb[3], n[3], u[3], v[3];
+    for (int k = 0; k < 3; k++) { pa[k] = uni(s.u.c.pos[sa][k]); pb[k] = uni(s.u.c.pos[sb][k]); }
+    ccol(n, sa, ia);
     const float ab[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
     if (dot3(n, ab) < 0) for (int k = 0; k < 3; k++) n[k] = -n[k];
     const int ja = (ia + 1) % 3, ka = (ia + 2) % 3;
-    col3(u, Ra, ja); col3(v, Ra, ka);
-    const float hu = sel3(ha, ja), hv = sel3(ha, ka), hn = sel3(ha, ia);
+    ccol(u, sa, ja); ccol(v, sa, ka);
+    const float hu = uni(s.u.c.size[sa][ja]), hv = uni(s.u.c.size[sa][ka]), hn = uni(s.u.c.size[sa][ia]);
     float cA[3];
     for (int k = 0; k < 3; k++) cA[k] = pa[k] + n[k] * hn;
     int ib = 0;
     float bd = -1.f;
 #pragma unroll
-    for (int k = 0; k < 3; k++) { const float bk[3] = {Rb[k], Rb[3 + k], Rb[6 + k]}; const float t = fabsf(dot3(bk, n)); if (t > bd) { bd = t; ib = k; } }
+    for (int k = 0; k < 3; k++) { float bk[3]; ccol(bk, sb, k); const float t = fabsf(dot3(bk, n)); if (t > bd) { bd = t; ib = k; } }
     float nb[3], pv[3], qv[3];
-    col3(nb, Rb, ib);
+    ccol(nb, sb, ib);
     if (dot3(nb, n) > 0) for (int k = 0; k < 3; k++) nb[k] = -nb[k];
     const int jb = (ib + 1) % 3, kb = (ib + 2) % 3;
-    col3(pv, Rb, jb); col3(qv, Rb, kb);
-    const float hp = sel3(hb, jb), hq = sel3(hb, kb), hbn = sel3(hb, ib);
+    ccol(pv, sb, jb); ccol(qv, sb, kb);
+    const float hp = uni(s.u.c.size[sb][jb]), hq = uni(s.u.c.size[sb][kb]), hbn = uni(s.u.c.size[sb][ib]);
     float cB[3];
     for (int k = 0; k < 3; k++) cB[k] = pb[k] + nb[k] * hbn;
     const float nnb = dot3(n, nb);
@@ -1819,13 +1819,10 @@ struct StepKernel {
   // multiccd: the two geoms counter-rotated by +-1e-3 rad about the two tangent axes through the first contact point, the
   // penetration query repeated; new points farther than 1e-3 x min(rbound) from the earlier ones join the manifold, which
   // shares the first normal.  A, Bs are modified in place (the pair is done afterwards).
-  SMJ_DEV void convex_multi(const int* rec, Shape& A, Shape& Bs, const float* c0, const float* c1, const float* pos0, const float* dir0,
+  SMJ_DEV void convex_multi(const int* rec, Shape& A, Shape& Bs, int slotA, int slotB, const float* pos0, const float* dir0,
                             float margin, float tol) {
     float fr[9] = {dir0[0], dir0[1], dir0[2], 0, 0, 0, 0, 0, 0};
     make_frame(fr);
-    float pA[3], mA[9], pB[3], mB[9];
-    for (int k = 0; k < 3; k++) { pA[k] = A.pos[k]; pB[k] = Bs.pos[k]; }
-    for (int k = 0; k < 9; k++) { mA[k] = A.mat[k]; mB[k] = Bs.mat[k]; }
     LANES { if (lane == 0) for (int k = 0; k < 3; k++) s.u.c.mc[0][k] = pos0[k]; }
     SYNC();
     int n = 1;
@@ -1834,9 +1831,13 @@ struct StepKernel {
       const float* ax = fr + 3 * (1 + (q >> 1));
       const float axv[3] = {uni(ax[0]), uni(ax[1]), uni(ax[2])};
       const float ang = (q & 1) ? -1e-3f : 1e-3f;
-      float Rp[9], Rn[9], ca[3] = {c0[0], c0[1], c0[2]}, cb[3] = {c1[0], c1[1], c1[2]};
+      // the unrotated poses and MPR interior points come from the LDS geom cache every round (no register copies kept)
+      float Rp[9], Rn[9], ca[3], cb[3], mA[9], mB[9];
       axis_angle_mat(Rp, axv, ang); axis_angle_mat(Rn, axv, -ang);
-      for (int k = 0; k < 3; k++) { A.pos[k] = pA[k]; Bs.pos[k] = pB[k]; }
+      for (int k = 0; k < 3; k++) {
+        A.pos[k] = uni(s.u.c.pos[slotA][k]); Bs.pos[k] = uni(s.u.c.pos[slotB][k]); ca[k] = uni(s.u.c.ccen[slotA][k]); cb[k] = uni(s.u.c.ccen[slotB][k]);
+      }
+      for (int k = 0; k < 9; k++) { mA[k] = uni(s.u.c.mat[slotA][k]); mB[k] = uni(s.u.c.mat[slotB][k]); }
       rotate_point(A.pos, pos0, Rp); rotate_point(Bs.pos, pos0, Rn); rotate_point(ca, pos0, Rp); rotate_point(cb, pos0, Rn);
       mulmat3(A.mat, Rp, mA); mulmat3(Bs.mat, Rn, mB);
       float dp, dr[3], ps[3];
@@ -1981,12 +1982,16 @@ struct StepKernel {
           }
           continue;
         }
-        if (A.type == GT_BOX && Bs.type == GT_BOX && M.multiccd) { box_box(r, A, Bs, margin); continue; }
+#ifndef SMJ_NO_BOXBOX
+        if (A.type == GT_BOX && Bs.type == GT_BOX && M.multiccd) { box_box(r, uni(r[SMJ_CP_S1]), uni(r[SMJ_CP_S2]), margin); continue; }
+#endif
         if (!mpr_penetration(A, Bs, c0, c1, depth, dir, pos)) continue;
         if (-depth > margin || dot3(dir, dir) < 0.5f) continue;
         add_contact(r, -depth, pos, dir);
+#ifndef SMJ_NO_MULTI
         if (M.multiccd && A.type != GT_SPHERE && Bs.type != GT_SPHERE)
-          convex_multi(r, A, Bs, c0, c1, pos, dir, margin, 1e-3f * asf(uni(r[SMJ_CP_RBMIN])));
+          convex_multi(r, A, Bs, uni(r[SMJ_CP_S1]), uni(r[SMJ_CP_S2]), pos, dir, margin, 1e-3f * asf(uni(r[SMJ_CP_RBMIN])));
+#endif
       }
     }
     SYNC();

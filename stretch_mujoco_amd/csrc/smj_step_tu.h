@@ -20,19 +20,25 @@ __global__ __launch_bounds__(64) void SMJ_STEP_KERNEL(const DevModel M, const De
   // dynamic LDS: a Newton launch asks for sizeof(Smem), a PGS launch for the extra tail that holds A (smj_lds_bytes)
   extern __shared__ __align__(16) unsigned char smj_lds[];
   Smem& smem = *reinterpret_cast<Smem*>(smj_lds);
-  if (S.redo_worker) {   // escalation: finish the envs the standard variant parked (DevState::redo)
-    const int count = S.redo[0];
-    for (int i = blockIdx.x; i < count; i += gridDim.x) {
-      StepKernel k(M, S, smem, S.redo[1 + 2 * i]);
-      k.run(nsteps - S.redo[2 + 2 * i], read_flags);
-      __syncthreads();
-    }
-    return;
+#if defined(SMJ_TALL) || defined(SMJ_BIG)
+  // One call site of run() (the whole step pipeline is inlined into it): a normal launch takes env = blockIdx.x, steps = nsteps;
+  // an escalation launch works the list of envs the standard variant parked (DevState::redo).
+  int i = blockIdx.x, last = blockIdx.x;
+  if (S.redo_worker) last = S.redo[0] - 1;
+  for (; i <= last; i += gridDim.x) {
+    int env = i, steps = nsteps;
+    if (S.redo_worker) { env = S.redo[1 + 2 * i]; steps = nsteps - S.redo[2 + 2 * i]; }
+    if (env >= S.B) return;
+    StepKernel k(M, S, smem, env);
+    k.run(steps, read_flags);
+    __syncthreads();
   }
+#else
   const int env = blockIdx.x;
   if (env >= S.B) return;
   StepKernel k(M, S, smem, env);
   k.run(nsteps, read_flags);
+#endif
 }
 
 int SMJ_LAUNCH_STEP(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream) {
