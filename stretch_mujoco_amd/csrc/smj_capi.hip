@@ -216,13 +216,15 @@ int smj_create(const void* blob, size_t nbytes, int num_envs, int device, smj_ct
   c->num_envs = num_envs;
   HIPCHK(c, hipSetDevice(device));
   DeviceUploader up{c};
-  SmjCaps caps[2] = {{NVP, NBP, NENT, NEFC, NCON}, {}};
-  int big_debug = 0;
-  smj_big_caps(&caps[1].nvp, &caps[1].nbp, &caps[1].nent, &caps[1].nefc, &caps[1].ncon, &big_debug);
-  int rc = smj_load_model(blob, nbytes, c->model, up, c->err, caps, 2, &c->variant);
+  SmjCaps caps[3] = {{NVP, NBP, NENT, NEFC, NCON}, {}, {}};   // standard, tall, big (smj_model.h)
+  int dbg[3] = {SMJ_DEBUG_FLOATS, 0, 0};
+  smj_tall_caps(&caps[1].nvp, &caps[1].nbp, &caps[1].nent, &caps[1].nefc, &caps[1].ncon, &dbg[1]);
+  smj_big_caps(&caps[2].nvp, &caps[2].nbp, &caps[2].nent, &caps[2].nefc, &caps[2].ncon, &dbg[2]);
+  int rc = smj_load_model(blob, nbytes, c->model, up, c->err, caps, 3, &c->variant);
   if (rc) return rc;
   c->caps = caps[c->variant];
   c->layout = smj_stage_layout(c->caps.nvp, c->caps.nbp);
+  c->debug_floats = dbg[c->variant];
   if (c->variant == 0) {   // escalation target: the same model loaded for the tall variant
     int dummy = 0;
     rc = smj_load_model(blob, nbytes, c->model_esc, up, c->err, caps + 1, 1, &dummy);
@@ -234,7 +236,6 @@ int smj_create(const void* blob, size_t nbytes, int num_envs, int device, smj_ct
     HIPCHK(c, hipMemset(d, 0, sizeof(int)));
     c->redo = (int*)d;
   }
-  c->debug_floats = c->variant ? big_debug : SMJ_DEBUG_FLOATS;
   DevModel& m = c->model;
   c->qpos0_dev = const_cast<float*>(m.qpos0);
   c->state.B = num_envs;

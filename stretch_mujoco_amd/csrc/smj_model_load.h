@@ -267,7 +267,7 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
     const SmjBlobEntry* e = b.find("k_capacity_hint");
     int hint = 0;
     if (e && e->dtype == 1 && e->nbytes >= 4) memcpy(&hint, b.p + e->offset, 4);
-    if (hint > 0 && ncaps > 1) first = ncaps - 1;
+    if (hint > 0 && ncaps > 1) first = 1;   // skip the standard variant: tall if the model fits it, else big
   }
   for (int v = first; v < ncaps && pick < 0; v++)
     if (m.nv <= caps[v].nvp && m.nbody <= caps[v].nbp && m.nq <= caps[v].nvp + 8 && m.nldl <= caps[v].nent * 64) pick = v;
