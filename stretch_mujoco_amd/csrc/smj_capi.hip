@@ -33,6 +33,10 @@ struct smj_ctx {
   bool has_esc = false;
   int* redo = nullptr;
   int escalate = 1;
+  // launch order: per-env shader time of the last launch and the permutation sorted by it (DevState::order / cost)
+  int* cost = nullptr;
+  int* order = nullptr;
+  int balance = 1;
   SmjCaps caps{};              // capacities of the variant in use
   SmjStageLayout layout{};     // staging-row layout of the variant in use
   int debug_floats = 0;
@@ -242,6 +246,14 @@ int smj_create(const void* blob, size_t nbytes, int num_envs, int device, smj_ct
   c->state.ld = num_envs;
   {
     void* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, sizeof(int) * 2 * (size_t)num_envs));
+    c->allocs.push_back(d);
+    HIPCHK(c, hipMemset(d, 0, sizeof(int) * 2 * (size_t)num_envs));
+    c->cost = (int*)d;
+    c->order = c->cost + num_envs;
+  }
+  {
+    void* d = nullptr;
     const size_t bytes = sizeof(float) * (size_t)c->layout.stride * (size_t)num_envs;
     HIPCHK(c, hipMalloc(&d, bytes));
     c->allocs.push_back(d);
@@ -439,6 +451,13 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
   st.redo = esc ? c->redo : nullptr;
   st.redo_worker = 0;
   if (esc) HIPCHK(c, hipMemsetAsync(c->redo, 0, sizeof(int), (hipStream_t)stream));
+  // launch order: the envs that took longest last time go first (a launch of one or two steps is not worth the sort)
+  st.cost = c->cost;
+  st.order = nullptr;
+  if (c->balance && nsteps >= 4 && c->num_envs > 1024) {
+    smj_launch_order(c->cost, c->order, c->num_envs, (hipStream_t)stream);
+    st.order = c->order;
+  }
   smj_launch_stage(in, c->stage, Y.stride, c->num_envs, st.ld, false, (hipStream_t)stream);
   int lrc = c->variant == 2   ? smj_launch_step_big(c->model, st, nsteps, read_flags, (hipStream_t)stream)
             : c->variant == 1 ? smj_launch_step_tall(c->model, st, nsteps, read_flags, (hipStream_t)stream)
@@ -523,6 +542,7 @@ int smj_set_option(smj_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "convex_pairs")) m.convex_pairs = (int)v;
   else if (!strcmp(name, "multiccd")) m.multiccd = (int)v;
   else if (!strcmp(name, "escalate")) c->escalate = (int)v;
+  else if (!strcmp(name, "balance")) c->balance = (int)v;
   else return fail(c, -1, "unknown option '%s'", name);
   return 0;
 }

@@ -29,6 +29,8 @@ void smj_big_caps(int* nvp, int* nbp, int* nent, int* nefc, int* ncon, int* debu
 void smj_launch_reset(const DevModel& m, const DevState& s, const uint8_t* mask, hipStream_t stream);
 // batch-major -> env-major staging rows (import) and back (export); tiles of 64 envs transposed through LDS
 void smj_launch_stage(const StagePlan& plan, float* stage, int stride, int B, long ld, bool is_export, hipStream_t stream);
+// launch order for the next step launch: envs by descending cost (256 buckets relative to the maximum), one workgroup
+void smj_launch_order(const int* cost, int* order, int B, hipStream_t stream);
 // one BaseController.update() on the bound BASE_POSE / BASECTL / CTRL arrays (lane = env); the same device function the
 // step kernel runs after every step
 void smj_launch_base_tick(const DevState& s, hipStream_t stream);

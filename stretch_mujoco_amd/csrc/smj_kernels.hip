@@ -66,6 +66,31 @@ __global__ __launch_bounds__(256) void smj_base_tick_kernel(const DevState S) {
   S.bctl[SMJ_BC_MODE * ld + e] = (float)next;
 }
 
+// Envs sorted by the shader time of their last launch, longest first: a counting sort on 256 cost buckets relative to the
+// maximum (order inside a bucket does not matter: envs are independent, only the dispatch order changes).
+__global__ __launch_bounds__(1024) void smj_order_kernel(const int* cost, int* order, int B) {
+  __shared__ int hist[256], mx;
+  const int t = threadIdx.x;
+  if (t < 256) hist[t] = 0;
+  if (t == 0) mx = 1;
+  __syncthreads();
+  int m = 1;
+  for (int e = t; e < B; e += 1024) m = cost[e] > m ? cost[e] : m;
+  atomicMax(&mx, m);
+  __syncthreads();
+  const float sc = 255.f / (float)mx;
+  for (int e = t; e < B; e += 1024) atomicAdd(&hist[255 - (int)((float)(cost[e] > 0 ? cost[e] : 0) * sc)], 1);
+  __syncthreads();
+  if (t == 0) {
+    int acc = 0;
+    for (int k = 0; k < 256; k++) { const int n = hist[k]; hist[k] = acc; acc += n; }
+  }
+  __syncthreads();
+  for (int e = t; e < B; e += 1024) order[atomicAdd(&hist[255 - (int)((float)(cost[e] > 0 ? cost[e] : 0) * sc)], 1)] = e;
+}
+void smj_launch_order(const int* cost, int* order, int B, hipStream_t stream) {
+  hipLaunchKernelGGL(smj_order_kernel, dim3(1), dim3(1024), 0, stream, cost, order, B);
+}
 void smj_launch_stage(const StagePlan& plan, float* stage, int stride, int B, long ld, bool is_export, hipStream_t stream) {
   if (plan.nseg == 0) return;
   hipLaunchKernelGGL(smj_stage_kernel, dim3((B + 63) / 64, plan.nseg), dim3(256), 0, stream, plan, stage, stride, B, ld, is_export ? 1 : 0);

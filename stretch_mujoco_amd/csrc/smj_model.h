@@ -146,6 +146,11 @@ struct DevState {
   // Capacity escalation (standard variant only; null = off): an env whose step needs more than the variant's constraint rows /
   // contacts stops BEFORE that step, leaves its state as of the start of the step in the staging row and appends
   // (env, steps done) to this list -- [0] = count, then pairs; the big variant then finishes the env's steps (smj_step).
+  // Launch order (null = env id order): workgroup w takes env order[w].  smj_step sorts the envs by the shader time their last
+  // launch took, longest first (`cost`, written by the kernel): the hardware dispatches workgroups in index order, so the
+  // expensive envs (many convex contacts, Newton iterations) start in the first round and the cheap ones fill the tail.
+  const int* order;
+  int* cost;
   int* redo;
   int redo_worker;      // the launch is the big variant working the list off: env = redo[1 + 2 i], steps already done redo[2 + 2 i]
 };

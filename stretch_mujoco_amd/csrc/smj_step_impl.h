@@ -1365,7 +1365,12 @@ struct StepKernel {
         best[lane] = bd; bidx[lane] = bi; bx[lane] = b[0]; by[lane] = b[1]; bz[lane] = b[2];
       }
       const float mx = wave_max(best);
-      const int idx = pick_index(best, bidx, mx);
+      // the lane(s) holding the maximum: almost always one -- then it is the owner; exact ties (symmetric hulls along an axis)
+      // take the lowest vertex index, like the oracle's first-maximum scan
+      PL<int> ism;
+      LANES { ism[lane] = best[lane] == mx && bidx[lane] >= 0; }
+      const uint64_t mm = wave_ballot(ism);
+      const int idx = popc64(mm) == 1 ? wave_read(bidx, ffs64(mm)) : pick_index(best, bidx, mx);
       const int owner = idx & 63;   // vertex i is scanned by lane i mod 64: the winner's coordinates come by v_readlane
       pl[0] = wave_read(bx, owner); pl[1] = wave_read(by, owner); pl[2] = wave_read(bz, owner);
     }
@@ -2867,14 +2872,44 @@ struct StepKernel {
     gj_cols<0, N>(hrow, x, pinv, ol);
     LANES { x[lane] *= pinv[lane]; }
   }
+  // The same Gauss-Jordan elimination with the matrix left in LDS (s.u.n.H, destroyed): lane i updates row i in place, the
+  // pivot row is read as a broadcast, x rides along as column NVP.  For the 64-dof variant: 50 x 50 rows in registers plus the
+  // solver's per-row state do not fit the register file (the unrolled version spilled to scratch and took 30x longer).
+  SMJ_DEV void gj_solve_lds(PL<float>& x) {
+    const int n = M.nv;
+    LANES { if (lane < NVP) s.u.n.H[lane][NVP] = lane < n ? x[lane] : 0.f; }
+    SYNC();
+    for (int k = 0; k < n; k++) {
+      const float rp = fast_rcp(fmaxf(uni(s.u.n.H[k][k]), 1e-30f));
+      LANES {
+        if (lane < n && lane != k) {
+          float* row = s.u.n.H[lane];
+          const float* piv = s.u.n.H[k];
+          const float mult = row[k] * rp;
+          // eight columns per round: the sixteen LDS reads issue back to back (one latency per round, not per column)
+          int j = k + 1;
+          for (; j + 8 <= n; j += 8) {
+            float a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { a[u] = row[j + u]; b[u] = piv[j + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) row[j + u] = a[u] - mult * b[u];
+          }
+          for (; j < n; j++) row[j] -= mult * piv[j];
+          row[NVP] -= mult * piv[NVP];
+        }
+      }
+      SYNC();
+    }
+    LANES { x[lane] = lane < n ? s.u.n.H[lane][NVP] * fast_rcp(fmaxf(s.u.n.H[lane][lane], 1e-30f)) : 0.f; }
+    SYNC();
+  }
   SMJ_DEV void solve_H(PL<float>& x) {
 #if NVP == 32
     if (M.nv <= 26) gj_solve<26>(x);   // Stretch: 26 dofs; a third fewer column pairs than the full 32
     else gj_solve<NVP>(x);
 #else
-    if (M.nv <= 38) gj_solve<38>(x);        // Stretch + two free objects (the reference's scene.xml)
-    else if (M.nv <= 50) gj_solve<50>(x);   // Stretch + four free objects (kitchen)
-    else gj_solve<NVP>(x);
+    gj_solve_lds(x);
 #endif
   }
 
@@ -3185,7 +3220,10 @@ struct StepKernel {
             ls_eval(nr0, qg, a, d1, d2);
             if (prof) pc[SMJ_PROF_N_LSEVALS] += 1.f;
             if (fabsf(d1) < bestd) { bestd = fabsf(d1); alpha = a; }
-            if (fabsf(d1) < gtol) break;
+            // fp32: besides the absolute tolerance, stop once the slope has dropped to 1e-4 of its value at 0 -- along a
+            // (piecewise) quadratic the cost still to be gained is then 1e-8 of what this step gained, below the rounding of
+            // the next gradient; chasing gtol = 1e-10 * |search| through fp32 noise cost ~7 evaluations per Newton iteration
+            if (fabsf(d1) < gtol || fabsf(d1) < 1e-4f * fabsf(d10)) break;
             if (d1 < 0) lo = a; else hi = a;
             float an = (d2 > 0) ? a - d1 / d2 : -1.f;
             if (hi < 0) { if (an <= lo) an = 2 * a + 1e-12f; }
@@ -3410,6 +3448,7 @@ struct StepKernel {
     float pc[SMJ_PROF_SLOTS];
     for (int k = 0; k < SMJ_PROF_SLOTS; k++) pc[k] = 0.f;
     const bool prof = S.prof != nullptr;
+    const long long tlaunch = S.cost ? smj_clock() : 0;
     long long t0 = prof ? smj_clock() : 0, tstart = t0;
 #define TICK(slot) if (prof) { const long long t1 = smj_clock(); pc[slot] += (float)(t1 - t0); t0 = t1; }
     setup();
@@ -3433,7 +3472,11 @@ struct StepKernel {
       TICK(SMJ_PROF_COLLISION)
       make_constraint();
       TICK(SMJ_PROF_MAKECON)
-      if (S.redo && !S.redo_worker && M.solver == 2 && (flags & (SMJ_FLAG_EFC_OVERFLOW | SMJ_FLAG_CON_OVERFLOW))) { escalate(st); return; }
+      if (S.redo && !S.redo_worker && M.solver == 2 && (flags & (SMJ_FLAG_EFC_OVERFLOW | SMJ_FLAG_CON_OVERFLOW))) {
+        escalate(st);
+        if (S.cost) { const int cst = (int)((smj_clock() - tlaunch) >> 6); LANES { if (lane == 0) S.cost[env] = cst; } }
+        return;
+      }
       if (M.solver == 2) solve_newton(last, pc, t0, prof);
       else solve(last, pc, t0, prof);
       if (last && want_imu) imu();
@@ -3444,6 +3487,10 @@ struct StepKernel {
       pc[SMJ_PROF_PGS_SWEEPS] += (float)niter;
     }
     store_state(nsteps);
+    if (S.cost) {   // shader time of this env's launch (units of 64 clocks): the key of the next launch's order (DevState::order)
+      const int cst = (int)((smj_clock() - tlaunch) >> 6);
+      LANES { if (lane == 0) S.cost[env] = S.redo_worker ? S.cost[env] + cst : cst; }
+    }
     if (prof) {
       pc[SMJ_PROF_TOTAL] = (float)(smj_clock() - tstart);
       LANES { if (lane < SMJ_PROF_SLOTS) S.prof[lane * S.ld + env] = pc[lane]; }

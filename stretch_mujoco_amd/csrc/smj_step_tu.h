@@ -26,16 +26,16 @@ __global__ __launch_bounds__(64) void SMJ_STEP_KERNEL(const DevModel M, const De
   int i = blockIdx.x, last = blockIdx.x;
   if (S.redo_worker) last = S.redo[0] - 1;
   for (; i <= last; i += gridDim.x) {
-    int env = i, steps = nsteps;
+    if (i >= S.B) return;
+    int env = S.order ? S.order[i] : i, steps = nsteps;
     if (S.redo_worker) { env = S.redo[1 + 2 * i]; steps = nsteps - S.redo[2 + 2 * i]; }
-    if (env >= S.B) return;
     StepKernel k(M, S, smem, env);
     k.run(steps, read_flags);
     __syncthreads();
   }
 #else
-  const int env = blockIdx.x;
-  if (env >= S.B) return;
+  if ((int)blockIdx.x >= S.B) return;
+  const int env = S.order ? S.order[blockIdx.x] : (int)blockIdx.x;
   StepKernel k(M, S, smem, env);
   k.run(nsteps, read_flags);
 #endif
