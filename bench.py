@@ -65,6 +65,20 @@ def _cpu_worker(args):
     return n, time.perf_counter() - t0
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box shows 256 CPUs to
+    os.cpu_count() while its container is limited to a fraction of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(hold: int, seconds: float, solver: str):
     """BASELINE.md section 3, C1-C4 on the fp64 CPU restatement ('port'; MuJoCo itself is not installable here).
     `value` is C4, the whole-host aggregate (one independent oracle process per core)."""
@@ -73,22 +87,25 @@ def cpu_baseline(hold: int, seconds: float, solver: str):
     scene = os.path.join(models, "stretch_scene.smjb")          # scene.xml equivalent: table + 2 free objects
     if not os.path.exists(scene):
         scene = os.path.join(models, "stretch_kitchen_standin.smjb")
-    ncpu = os.cpu_count() or 1
-    ctx = mp.get_context("fork")
+    ncpu = usable_cores()
+    from oracle import oracle as _o
+
+    _o.lib()                      # make sure the oracle library is built before the workers start
+    ctx = mp.get_context("spawn")   # the parent holds a HIP context: no fork
     single = {}
     with ctx.Pool(3) as pool:   # C1-C3 single-thread rates, measured side by side on three otherwise idle cores
-        r = pool.map(_cpu_worker, [(empty, 1, hold, seconds / 2, solver, False), (empty, 2, hold, seconds / 2, solver, True),
-                                   (scene, 3, hold, seconds / 2, solver, False)])
+        r = pool.map_async(_cpu_worker, [(empty, 1, hold, seconds / 2, solver, False), (empty, 2, hold, seconds / 2, solver, True),
+                                         (scene, 3, hold, seconds / 2, solver, False)]).get(timeout=4 * seconds + 120)
     for key, (n, dt) in zip(("C1_empty_sensors_off", "C2_empty_lidar_imu_every_step", "C3_" + os.path.basename(scene)[:-5]), r):
         single[key] = {"value": n / dt, "unit": "env-steps/s", "steps": n}
     with ctx.Pool(ncpu) as pool:
-        r = pool.map(_cpu_worker, [(empty, 100 + i, hold, seconds, solver, False) for i in range(ncpu)])
+        r = pool.map_async(_cpu_worker, [(empty, 100 + i, hold, seconds, solver, False) for i in range(ncpu)]).get(timeout=4 * seconds + 120)
     total = sum(n / dt for n, dt in r)
     return dict(value=total, unit="env-steps/s", cores=ncpu, kind="port",
-                sample=f"C4 whole-host aggregate: {ncpu} independent oracle processes (one per core), {seconds:.0f} s each of the bench "
+                sample=f"C4 whole-host aggregate: {ncpu} independent oracle processes, one per usable core ({os.cpu_count()} visible, cgroup quota / affinity allow {ncpu}), {seconds:.0f} s each of the bench "
                        f"workload (1 env, empty scene, random ctrl every {hold} steps, {solver}); {sum(n for n, _ in r)} steps in total. "
                        f"Stand-in fp64 CPU restatement, NOT MuJoCo.",
-                single_thread=single, host_cpus=ncpu,
+                single_thread=single, host_cpus=os.cpu_count(), usable_cpus=ncpu,
                 reference_as_shipped="<= 500 steps/s by construction (realtime sleep, mujoco_server.py:381-384); not measured")
 
 

@@ -47,6 +47,8 @@ def lib():
         L.smjo_get_int.restype = ctypes.POINTER(ctypes.c_int)
         L.smjo_get_int.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
         L.smjo_dim.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+        L.smjo_flops.argtypes = [ctypes.c_int]
+        L.smjo_flops.restype = ctypes.c_longlong
         L.smjo_set_contacts.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.smjo_set_contacts.restype = None
         _LIB = L

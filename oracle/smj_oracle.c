@@ -296,29 +296,35 @@ int* smjo_get_int(smjo_data* d, const char* name, int* n) {
 }
 
 /* ------------------------------------------------------------------ small math */
-static inline double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-static inline void cross3(double* r, const double* a, const double* b) {
+/* Floating-point operation counter (multiplies, adds, divides, square roots each count 1; an FMA counts 2): incremented in the
+ * vector primitives and at the dense loops of every stage, so that a rollout yields the flops MuJoCo's algorithm spends per
+ * step on this model (tools/flop_count.py -> profiles/flops_per_env_step.json, the constant bench.py's fp32 roofline uses). */
+static long long g_flop = 0;
+#define FL(n) (g_flop += (long long)(n))
+long long smjo_flops(int reset) { long long v = g_flop; if (reset) g_flop = 0; return v; }
+static inline double dot3(const double* a, const double* b) { FL(5); return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void cross3(double* r, const double* a, const double* b) { FL(9);
   double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
   r[0] = x; r[1] = y; r[2] = z;
 }
 static inline double norm3(const double* a) { return sqrt(dot3(a, a)); }
-static inline double normalize3(double* a) {
+static inline double normalize3(double* a) { FL(4);
   double n = norm3(a);
   if (n < MINVAL) { a[0] = 1; a[1] = 0; a[2] = 0; return 0; }
   a[0] /= n; a[1] /= n; a[2] /= n;
   return n;
 }
-static void quat_mul(double* r, const double* a, const double* b) {
+static void quat_mul(double* r, const double* a, const double* b) { FL(28);
   double t[4] = {a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
                  a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]};
   memcpy(r, t, 32);
 }
-static void quat_normalize(double* q) {
+static void quat_normalize(double* q) { FL(12);
   double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   if (n < MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
   for (int i = 0; i < 4; i++) q[i] /= n;
 }
-static void quat2mat(double* R, const double* q) {
+static void quat2mat(double* R, const double* q) { FL(27);
   double w = q[0], x = q[1], y = q[2], z = q[3];
   R[0] = w * w + x * x - y * y - z * z; R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
   R[3] = 2 * (x * y + w * z); R[4] = w * w - x * x + y * y - z * z; R[5] = 2 * (y * z - w * x);
@@ -328,17 +334,17 @@ static void axisangle2quat(double* q, const double* axis, double ang) {
   double s = sin(0.5 * ang);
   q[0] = cos(0.5 * ang); q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
 }
-static inline void mulmat3vec(double* r, const double* R, const double* v) {
+static inline void mulmat3vec(double* r, const double* R, const double* v) { FL(15);
   double x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2], y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2],
          z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
   r[0] = x; r[1] = y; r[2] = z;
 }
-static inline void mulmat3Tvec(double* r, const double* R, const double* v) {
+static inline void mulmat3Tvec(double* r, const double* R, const double* v) { FL(15);
   double x = R[0] * v[0] + R[3] * v[1] + R[6] * v[2], y = R[1] * v[0] + R[4] * v[1] + R[7] * v[2],
          z = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
   r[0] = x; r[1] = y; r[2] = z;
 }
-static void mulmat3(double* r, const double* A, const double* B) {
+static void mulmat3(double* r, const double* A, const double* B) { FL(45);
   double t[9];
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
@@ -346,7 +352,7 @@ static void mulmat3(double* r, const double* A, const double* B) {
 }
 
 /* spatial algebra on [angular(3); linear(3)] about the tree-root subtree COM.  [MJ] mju_mulInertVec etc. */
-static void mul_inert_vec(double* r, const double* i, const double* v) {
+static void mul_inert_vec(double* r, const double* i, const double* v) { FL(33);
   r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
   r[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
   r[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
@@ -354,19 +360,19 @@ static void mul_inert_vec(double* r, const double* i, const double* v) {
   r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
   r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
 }
-static void cross_motion(double* r, const double* vel, const double* v) {
+static void cross_motion(double* r, const double* vel, const double* v) { FL(6);
   double a[3], b[3], c[3];
   cross3(a, vel, v); cross3(b, vel, v + 3); cross3(c, vel + 3, v);
   r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = b[0] + c[0]; r[4] = b[1] + c[1]; r[5] = b[2] + c[2];
 }
-static void cross_force(double* r, const double* vel, const double* f) {
+static void cross_force(double* r, const double* vel, const double* f) { FL(6);
   double a[3], b[3], c[3];
   cross3(a, vel, f); cross3(b, vel + 3, f + 3); cross3(c, vel, f + 3);
   r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2]; r[3] = c[0]; r[4] = c[1]; r[5] = c[2];
 }
 
 /* dense Cholesky A = L L^T (lower, row-major n x n); returns rank */
-static int chol_factor(double* A, int n, double mindiag) {
+static int chol_factor(double* A, int n, double mindiag) { FL((long long)n * n * n / 3 + 2LL * n * n);
   int rank = n;
   for (int j = 0; j < n; j++) {
     double s = A[j * n + j];
@@ -382,7 +388,7 @@ static int chol_factor(double* A, int n, double mindiag) {
   }
   return rank;
 }
-static void chol_solve(double* x, const double* L, const double* b, int n) {
+static void chol_solve(double* x, const double* L, const double* b, int n) { FL(2LL * n * n + 2 * n);
   if (x != b) memcpy(x, b, sizeof(double) * n);
   for (int i = 0; i < n; i++) {
     double s = x[i];
@@ -559,7 +565,7 @@ static void crb_factor(const smjo_model* m, smjo_data* d) {
   memcpy(d->crb, d->cinert, sizeof(double) * 10 * nb);
   for (int b = nb - 1; b > 0; b--) {
     int p = m->body_parentid[b];
-    if (p > 0) for (int k = 0; k < 10; k++) d->crb[10 * p + k] += d->crb[10 * b + k];
+    if (p > 0) { FL(10); for (int k = 0; k < 10; k++) d->crb[10 * p + k] += d->crb[10 * b + k]; }
   }
   memset(d->qM, 0, sizeof(double) * nv * nv);
   for (int i = 0; i < nv; i++) {
@@ -567,6 +573,7 @@ static void crb_factor(const smjo_model* m, smjo_data* d) {
     mul_inert_vec(buf, d->crb + 10 * m->dof_bodyid[i], d->cdof + 6 * i);
     for (int j = i; j >= 0; j = m->dof_parentid[j]) {
       double v = 0;
+      FL(12);
       for (int k = 0; k < 6; k++) v += d->cdof[6 * j + k] * buf[k];
       d->qM[i * nv + j] = d->qM[j * nv + i] = v;
     }
@@ -591,6 +598,7 @@ static void jac_point(const smjo_model* m, const smjo_data* d, double* jacp, dou
     if (jacp) {
       double t[3];
       cross3(t, c, off);
+      FL(3);
       jacp[i] = c[3] + t[0]; jacp[nv + i] = c[4] + t[1]; jacp[2 * nv + i] = c[5] + t[2];
     }
   }
@@ -1716,7 +1724,7 @@ typedef struct {
 } nctx;
 
 /* forces, cost and (optionally) per-contact cone Hessians at residual jar.  coneH: ncon x 36 or NULL */
-static double newton_update(const smjo_model* m, smjo_data* d, const double* jar, double* force, int* state, double* coneH) {
+static double newton_update(const smjo_model* m, smjo_data* d, const double* jar, double* force, int* state, double* coneH) { FL(8LL * d->nefc + 60LL * d->ncon);
   double cost = 0;
   for (int i = 0; i < d->nefc; i++) {
     int t = d->efc_type[i];
@@ -1770,7 +1778,7 @@ static double newton_update(const smjo_model* m, smjo_data* d, const double* jar
 }
 
 /* cost and first/second derivative along the search line at step alpha  ([MJ] CGeval) */
-static double ls_eval(const nctx* c, double a, double* d1, double* d2) {
+static double ls_eval(const nctx* c, double a, double* d1, double* d2) { FL(10LL * c->d->nefc + 40LL * c->d->ncon + 12);
   const smjo_data* d = c->d;
   double q0 = c->quadGauss[0], q1 = c->quadGauss[1], q2 = c->quadGauss[2], cost = 0, e1 = 0, e2 = 0;
   for (int i = 0; i < d->nefc; i++) {
@@ -1849,9 +1857,9 @@ static void fwd_constraint_newton(const smjo_model* m, smjo_data* d) {
   int* state2 = state + ne;
   nctx ctx = {m, d, Jaref, Jv, quad, cq, {0, 0, 0}};
   double scale = 1.0 / (m->meaninertia * (nv > 1 ? nv : 1));
-#define MATVEC_M(out, x) for (int i_ = 0; i_ < nv; i_++) { double s_ = 0; for (int k_ = 0; k_ < nv; k_++) s_ += d->qM[i_ * nv + k_] * (x)[k_]; (out)[i_] = s_; }
-#define JAREF(out, x) for (int i_ = 0; i_ < ne; i_++) { double s_ = 0; for (int k_ = 0; k_ < nv; k_++) s_ += d->efc_J[(size_t)i_ * nv + k_] * (x)[k_]; (out)[i_] = s_ - d->efc_aref[i_]; }
-#define GAUSS(x, Mx) ({ double g_ = 0; for (int k_ = 0; k_ < nv; k_++) g_ += 0.5 * ((Mx)[k_] - d->qfrc_smooth[k_]) * ((x)[k_] - d->qacc_smooth[k_]); g_; })
+#define MATVEC_M(out, x) FL(2LL * nv * nv); for (int i_ = 0; i_ < nv; i_++) { double s_ = 0; for (int k_ = 0; k_ < nv; k_++) s_ += d->qM[i_ * nv + k_] * (x)[k_]; (out)[i_] = s_; }
+#define JAREF(out, x) FL(2LL * ne * nv + ne); for (int i_ = 0; i_ < ne; i_++) { double s_ = 0; for (int k_ = 0; k_ < nv; k_++) s_ += d->efc_J[(size_t)i_ * nv + k_] * (x)[k_]; (out)[i_] = s_ - d->efc_aref[i_]; }
+#define GAUSS(x, Mx) ({ double g_ = 0; FL(5 * nv); for (int k_ = 0; k_ < nv; k_++) g_ += 0.5 * ((Mx)[k_] - d->qfrc_smooth[k_]) * ((x)[k_] - d->qacc_smooth[k_]); g_; })
   /* warm start ([MJ] mj_warmstart, primal branch): the cheaper of qacc_warmstart and qacc_smooth */
   memcpy(qacc, m->warmstart ? d->qacc_warmstart : d->qacc_smooth, sizeof(double) * nv);
   MATVEC_M(Ma, qacc);
@@ -1866,6 +1874,7 @@ static void fwd_constraint_newton(const smjo_model* m, smjo_data* d) {
   for (; iter < m->iterations;) {
     cost = newton_update(m, d, Jaref, force, state, coneH) + GAUSS(qacc, Ma);
     /* gradient */
+    FL(2LL * ne * nv + 4 * nv);
     for (int k = 0; k < nv; k++) {
       double s = 0;
       for (int i = 0; i < ne; i++) s += d->efc_J[(size_t)i * nv + k] * force[i];
@@ -1886,16 +1895,20 @@ static void fwd_constraint_newton(const smjo_model* m, smjo_data* d) {
             if (h == 0) continue;
             const double *Jr = d->efc_J + (size_t)(i + r) * nv, *Jq = d->efc_J + (size_t)(i + q) * nv;
             for (int a = 0; a < nv; a++)
-              if (Jr[a] != 0)
+              if (Jr[a] != 0) {
+                FL(3 * nv);
                 for (int b = 0; b < nv; b++) H[a * nv + b] += h * Jr[a] * Jq[b];
+              }
           }
         i += dim - 1;
       } else if (state[i] == 1) {
         const double* Jr = d->efc_J + (size_t)i * nv;
         double D = d->efc_D[i];
         for (int a = 0; a < nv; a++)
-          if (Jr[a] != 0)
+          if (Jr[a] != 0) {
+            FL(3 * nv);
             for (int b = 0; b < nv; b++) H[a * nv + b] += D * Jr[a] * Jr[b];
+          }
       }
     }
     memcpy(Hf, H, sizeof(double) * nv * nv);
@@ -1905,6 +1918,7 @@ static void fwd_constraint_newton(const smjo_model* m, smjo_data* d) {
     for (int k = 0; k < nv; k++) { search[k] = -search[k]; sn += search[k] * search[k]; }
     sn = sqrt(sn);
     /* line-search preparation ([MJ] CGprepare) */
+    FL(2LL * ne * nv + 9 * ne + 6 * nv);
     MATVEC_M(Mv, search);
     for (int i = 0; i < ne; i++) {
       double s = 0;
@@ -1936,6 +1950,7 @@ static void fwd_constraint_newton(const smjo_model* m, smjo_data* d) {
     nls_total += nls;
     iter++;
     if (alpha == 0) break;
+    FL(4 * nv + 2 * ne);
     for (int k = 0; k < nv; k++) { qacc[k] += alpha * search[k]; Ma[k] += alpha * Mv[k]; }
     for (int i = 0; i < ne; i++) Jaref[i] += alpha * Jv[i];
     double newcost = newton_update(m, d, Jaref, ftmp, state2, NULL) + GAUSS(qacc, Ma);
@@ -2029,13 +2044,16 @@ void smjo_step(const smjo_model* m, smjo_data* d) {
       continue;
     const double* mo = d->actuator_moment + a * nv;
     for (int i = 0; i < nv; i++)
-      if (mo[i] != 0)
+      if (mo[i] != 0) {
+        FL(3 * nv);
         for (int j = 0; j < nv; j++) d->qH[i * nv + j] -= h * bv * mo[i] * mo[j];
+      }
   }
   chol_factor(d->qH, nv, MINVAL);
   double* rhs = d->scratch;
   for (int k = 0; k < nv; k++) rhs[k] = d->qfrc_smooth[k] + d->qfrc_constraint[k];
   chol_solve(rhs, d->qH, rhs, nv);
+  FL(4 * nv);
   for (int k = 0; k < nv; k++) d->qvel[k] += h * rhs[k];
   integrate_pos(m, d->qpos, d->qvel, h);
   d->time += h;

@@ -40,6 +40,8 @@ int smjo_set_option(smjo_model* m, const char* name, double value);
 double* smjo_get(smjo_data* d, const char* name, int* n);
 int* smjo_get_int(smjo_data* d, const char* name, int* n);
 int smjo_dim(const smjo_model* m, const char* name);
+/* floating-point operations counted since the last reset (vector primitives + the dense loops of every stage) */
+long long smjo_flops(int reset);
 
 /* depth image float[H][W] of camera `cam` from the poses of the last smjo_forward / smjo_step; -1 if the blob has no
  * render tables.  max_depth <= 0: raw render (far plane where nothing is hit). */
