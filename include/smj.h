@@ -87,7 +87,8 @@ int smj_base_controller_tick(smj_ctx* ctx, void* stream);
 /* Solver / collision options (mjOption fields): "iterations", "tolerance", "warmstart", "pgs_fixed_iter",
  * "max_contacts_per_pair", "solver" (0 PGS, 2 Newton), "convex_pairs", "multiccd" (mjENBL_MULTICCD, stretch.xml:8; default on), "escalate" (default on: an env whose step needs more constraint rows / contacts
  * than the standard kernel variant holds is finished by the tall variant instead of being flagged), "balance" (default on:
- * workgroups are dispatched in the order of the envs' shader time in the previous launch, longest first). */
+ * workgroups are dispatched in the order of the envs' shader time in the previous dispatch, longest first), "chunk" (default 0 = one dispatch; k > 0:
+ * smj_step sends its n steps out as dispatches of this many steps on the staged state, each with a fresh order; 0 = one dispatch). */
 int smj_set_option(smj_ctx* ctx, const char* name, double value);
 
 /* Depth image of camera `camera_id` (index into the model's cameras, stretch.xml order: d405_rgb, d405_depth,

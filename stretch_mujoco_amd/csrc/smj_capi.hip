@@ -37,6 +37,7 @@ struct smj_ctx {
   int* cost = nullptr;
   int* order = nullptr;
   int balance = 1;
+  int chunk = 0;               // steps per dispatch inside one smj_step (0: the whole launch at once; measured: no gain)
   SmjCaps caps{};              // capacities of the variant in use
   SmjStageLayout layout{};     // staging-row layout of the variant in use
   int debug_floats = 0;
@@ -449,29 +450,41 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
   st.lay = Y;
   const bool esc = c->variant == 0 && c->has_esc && c->escalate && c->model.solver == 2;
   st.redo = esc ? c->redo : nullptr;
-  st.redo_worker = 0;
-  if (esc) HIPCHK(c, hipMemsetAsync(c->redo, 0, sizeof(int), (hipStream_t)stream));
-  // launch order: the envs that took longest last time go first (a launch of one or two steps is not worth the sort)
   st.cost = c->cost;
-  st.order = nullptr;
-  if (c->balance && nsteps >= 4 && c->num_envs > 1024) {
-    smj_launch_order(c->cost, c->order, c->num_envs, (hipStream_t)stream);
-    st.order = c->order;
-  }
-  smj_launch_stage(in, c->stage, Y.stride, c->num_envs, st.ld, false, (hipStream_t)stream);
-  int lrc = c->variant == 2   ? smj_launch_step_big(c->model, st, nsteps, read_flags, (hipStream_t)stream)
-            : c->variant == 1 ? smj_launch_step_tall(c->model, st, nsteps, read_flags, (hipStream_t)stream)
-                              : smj_launch_step(c->model, st, nsteps, read_flags, (hipStream_t)stream);
-  if (!lrc && esc) {
-    // envs that ran out of constraint rows / contact slots were parked at the start of the offending step: the tall variant
-    // (160 rows / 48 contacts) finishes their steps; a launch without such envs finds the list empty and returns
+  if (esc) {   // the escalation target runs with the same options
     DevModel& mb = c->model_esc;
     const DevModel& ms = c->model;
     mb.iterations = ms.iterations; mb.warmstart = ms.warmstart; mb.pgs_fixed_iter = ms.pgs_fixed_iter; mb.max_con_pair = ms.max_con_pair;
     mb.solver = ms.solver; mb.ls_iterations = ms.ls_iterations; mb.convex_pairs = ms.convex_pairs; mb.multiccd = ms.multiccd;
     mb.ls_tolerance = ms.ls_tolerance; mb.tolerance = ms.tolerance;
-    st.redo_worker = 1;
-    lrc = smj_launch_step_tall(mb, st, nsteps, read_flags, (hipStream_t)stream);
+  }
+  smj_launch_stage(in, c->stage, Y.stride, c->num_envs, st.ld, false, (hipStream_t)stream);
+  // The n steps go out as chunks of `chunk` steps (default 10) on the staged rows.  Per-env cost is uneven and changes over
+  // tens of steps (contacts come and go): the cost of the previous chunk predicts the next one far better than the previous
+  // 50-step window predicts the next window, so each chunk is dispatched longest-env-first with a fresh order; and an env
+  // that runs out of rows is handed to the tall variant for the rest of a 10-step chunk, not of the whole launch.  Readout
+  // flags go with the last chunk only.  (Debug / profiling slots bound: one chunk, their dumps describe the whole launch.)
+  const int chunk = (c->chunk > 0 && !st.debug && !st.prof && c->num_envs > 1024) ? c->chunk : nsteps;
+  int lrc = 0;
+  for (int done = 0; done < nsteps && !lrc; done += chunk) {
+    const int k = nsteps - done < chunk ? nsteps - done : chunk;
+    const unsigned fl = done + k >= nsteps ? read_flags : 0u;
+    st.redo_worker = 0;
+    st.order = nullptr;
+    if (esc) HIPCHK(c, hipMemsetAsync(c->redo, 0, sizeof(int), (hipStream_t)stream));
+    if (c->balance && k >= 4 && c->num_envs > 1024) {   // a launch of one or two steps is not worth the sort
+      smj_launch_order(c->cost, c->order, c->num_envs, (hipStream_t)stream);
+      st.order = c->order;
+    }
+    lrc = c->variant == 2   ? smj_launch_step_big(c->model, st, k, fl, (hipStream_t)stream)
+          : c->variant == 1 ? smj_launch_step_tall(c->model, st, k, fl, (hipStream_t)stream)
+                            : smj_launch_step(c->model, st, k, fl, (hipStream_t)stream);
+    if (!lrc && esc) {
+      // envs that ran out of constraint rows / contact slots were parked at the start of the offending step: the tall variant
+      // (160 rows / 48 contacts) finishes the chunk's steps for them; an empty list returns at once
+      st.redo_worker = 1;
+      lrc = smj_launch_step_tall(c->model_esc, st, k, fl, (hipStream_t)stream);
+    }
   }
   if (lrc) return fail(c, -2, "step kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
   smj_launch_stage(out, c->stage, Y.stride, c->num_envs, st.ld, true, (hipStream_t)stream);
@@ -543,6 +556,7 @@ int smj_set_option(smj_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "multiccd")) m.multiccd = (int)v;
   else if (!strcmp(name, "escalate")) c->escalate = (int)v;
   else if (!strcmp(name, "balance")) c->balance = (int)v;
+  else if (!strcmp(name, "chunk")) c->chunk = (int)v;
   else return fail(c, -1, "unknown option '%s'", name);
   return 0;
 }
