@@ -303,27 +303,88 @@ class StretchBatchSimulator:
 
     # ------------------------------------------------------------------ wait helpers as batched predicates
     @_require_connection
-    def get_link_pose(self, link_name: str) -> torch.Tensor:
-        """World pose [B, 4, 4] of a link (a body name of stretch.xml, e.g. "link_grasp_center"), from the body poses of the
-        last physics step.  The reference (stretch_mujoco_simulator.py:468-486) evaluates the URDF at the joint positions and
-        places it at the planar base pose; here the simulated pose itself is returned, base roll / pitch / height included."""
+    def get_link_pose(self, link_name: str, simulated: bool = False) -> torch.Tensor:
+        """World pose [B, 4, 4] of a link (a body name of stretch.xml, e.g. "link_grasp_center").
+
+        Default = the reference's semantics (stretch_mujoco_simulator.py:468-486): forward kinematics of the link relative to
+        `base_link` at the STATUS joint positions -- lift, arm (a quarter of the extension on each of the four telescope
+        joints, utils.py:209-212), wrist yaw / pitch / roll, head pan / tilt; every other joint (gripper, fingers) at zero --
+        placed at the planar base pose Rz(theta), (x, y, 0).  The reference evaluates its URDF for this; the URDF is not in
+        the checkout, the same kinematic chain is read from the compiled MJCF model (stretch.xml carries the URDF's link
+        names and frames).  simulated=True returns the simulated body pose of the last physics step instead, base roll /
+        pitch / height, finger and rubber-tip joints included."""
         names = self.names["body"]
         if link_name not in names:
             raise KeyError(link_name)
         i = names.index(link_name)
         fb = int(self.model["link_fused"][i])
         rp = torch.tensor(np.asarray(self.model["link_relpos"][i], np.float32), device=self.device)
-        w, x, y, z = [float(v) for v in self.model["link_relquat"][i]]
-        Rl = torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
-                           [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
-                           [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]], dtype=torch.float32, device=self.device)
-        P = self.xpose[12 * fb: 12 * fb + 3].t()                       # [B, 3]
-        Rb = self.xpose[12 * fb + 3: 12 * fb + 12].t().reshape(-1, 3, 3)
-        T = torch.zeros(self.num_envs, 4, 4, dtype=torch.float32, device=self.device)
-        T[:, :3, :3] = Rb @ Rl
-        T[:, :3, 3] = P + (Rb @ rp)
+        Rl = self._quat_mat(torch.tensor(np.asarray(self.model["link_relquat"][i], np.float32), device=self.device))
+        B = self.num_envs
+        T = torch.zeros(B, 4, 4, dtype=torch.float32, device=self.device)
         T[:, 3, 3] = 1.0
+        if simulated:
+            P = self.xpose[12 * fb: 12 * fb + 3].t()                       # [B, 3]
+            Rb = self.xpose[12 * fb + 3: 12 * fb + 12].t().reshape(-1, 3, 3)
+            T[:, :3, :3] = Rb @ Rl
+            T[:, :3, 3] = P + (Rb @ rp)
+            return T
+        st = self.pull_status()
+        q = {"joint_lift": st.lift.pos, "joint_wrist_yaw": st.wrist_yaw.pos, "joint_wrist_pitch": st.wrist_pitch.pos,
+             "joint_wrist_roll": st.wrist_roll.pos, "joint_head_pan": st.head_pan.pos, "joint_head_tilt": st.head_tilt.pos}
+        for k in range(4):
+            q[f"joint_arm_l{k}"] = st.arm.pos / 4
+        m = self.model
+        base = self.names["body"].index("base_link")
+        base = int(m["link_fused"][base])
+        path, b = [], fb
+        while b != base and b > 0:
+            path.append(b)
+            b = int(m["body_parentid"][b])
+        if b != base:
+            raise KeyError(f"{link_name} is not part of the robot")
+        R = torch.eye(3, device=self.device).expand(B, 3, 3).clone()
+        p = torch.zeros(B, 3, device=self.device)
+        f32 = lambda a: torch.tensor(np.asarray(a, np.float32), device=self.device)
+        for b in reversed(path):     # [MJ] mj_kinematics: body frame in the parent, then the body's joints about their anchors
+            p = p + (R @ f32(m["body_pos"][b]))
+            R = R @ self._quat_mat(f32(m["body_quat"][b]))
+            for j in range(int(m["body_jntadr"][b]), int(m["body_jntadr"][b]) + int(m["body_jntnum"][b])):
+                val = q.get(self.names["joint"][j])
+                if val is None:
+                    continue
+                val = val.float() - float(m["qpos0"][int(m["jnt_qposadr"][j])])
+                axis, jpos = f32(m["jnt_axis"][j]), f32(m["jnt_pos"][j])
+                if int(m["jnt_type"][j]) == 2:       # slide
+                    p = p + (R @ axis) * val.unsqueeze(1)
+                else:                                 # hinge: rotate about the anchor
+                    anchor = p + (R @ jpos)
+                    R = R @ self._axis_angle_mat(axis, val)
+                    p = anchor - (R @ jpos)
+        x, y, th = st.base.x.float(), st.base.y.float(), st.base.theta.float()
+        Rz = torch.zeros(B, 3, 3, device=self.device)
+        Rz[:, 0, 0] = torch.cos(th); Rz[:, 0, 1] = -torch.sin(th); Rz[:, 1, 0] = torch.sin(th); Rz[:, 1, 1] = torch.cos(th); Rz[:, 2, 2] = 1.0
+        Rw = Rz @ R
+        pw = (Rz @ p.unsqueeze(2)).squeeze(2)
+        pw[:, 0] += x; pw[:, 1] += y
+        T[:, :3, :3] = Rw @ Rl
+        T[:, :3, 3] = pw + (Rw @ rp)
         return T
+
+    @staticmethod
+    def _quat_mat(qt: torch.Tensor) -> torch.Tensor:
+        w, x, y, z = [float(v) for v in qt]
+        return torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                             [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                             [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]], dtype=torch.float32, device=qt.device)
+
+    @staticmethod
+    def _axis_angle_mat(axis: torch.Tensor, ang: torch.Tensor) -> torch.Tensor:
+        """Rotation matrices [B, 3, 3] about a fixed axis by per-env angles (Rodrigues)."""
+        a = axis / axis.norm()
+        K = torch.tensor([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]], dtype=torch.float32, device=axis.device)
+        s, c = torch.sin(ang).view(-1, 1, 1), torch.cos(ang).view(-1, 1, 1)
+        return torch.eye(3, device=axis.device) + s * K + (1 - c) * (K @ K)
 
     @_require_connection
     def get_ee_pose(self) -> torch.Tensor:
