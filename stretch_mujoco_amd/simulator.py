@@ -319,7 +319,7 @@ class StretchBatchSimulator:
         i = names.index(link_name)
         fb = int(self.model["link_fused"][i])
         rp = torch.tensor(np.asarray(self.model["link_relpos"][i], np.float32), device=self.device)
-        Rl = self._quat_mat(torch.tensor(np.asarray(self.model["link_relquat"][i], np.float32), device=self.device))
+        Rl = self._quat_mat(self.model["link_relquat"][i], self.device)
         B = self.num_envs
         T = torch.zeros(B, 4, 4, dtype=torch.float32, device=self.device)
         T[:, 3, 3] = 1.0
@@ -348,7 +348,7 @@ class StretchBatchSimulator:
         f32 = lambda a: torch.tensor(np.asarray(a, np.float32), device=self.device)
         for b in reversed(path):     # [MJ] mj_kinematics: body frame in the parent, then the body's joints about their anchors
             p = p + (R @ f32(m["body_pos"][b]))
-            R = R @ self._quat_mat(f32(m["body_quat"][b]))
+            R = R @ self._quat_mat(m["body_quat"][b], self.device)
             for j in range(int(m["body_jntadr"][b]), int(m["body_jntadr"][b]) + int(m["body_jntnum"][b])):
                 val = q.get(self.names["joint"][j])
                 if val is None:
@@ -372,16 +372,16 @@ class StretchBatchSimulator:
         return T
 
     @staticmethod
-    def _quat_mat(qt: torch.Tensor) -> torch.Tensor:
-        w, x, y, z = [float(v) for v in qt]
+    def _quat_mat(qt, device) -> torch.Tensor:
+        w, x, y, z = [float(v) for v in np.asarray(qt)]
         return torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
                              [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
-                             [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]], dtype=torch.float32, device=qt.device)
+                             [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]], dtype=torch.float32, device=device)
 
     @staticmethod
     def _axis_angle_mat(axis: torch.Tensor, ang: torch.Tensor) -> torch.Tensor:
         """Rotation matrices [B, 3, 3] about a fixed axis by per-env angles (Rodrigues)."""
-        a = axis / axis.norm()
+        a = (axis / axis.norm()).tolist()
         K = torch.tensor([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]], dtype=torch.float32, device=axis.device)
         s, c = torch.sin(ang).view(-1, 1, 1), torch.cos(ang).view(-1, 1, 1)
         return torch.eye(3, device=axis.device) + s * K + (1 - c) * (K @ K)

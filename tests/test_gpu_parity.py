@@ -177,6 +177,8 @@ def test_api_flow_home_move_to_move_by_base():
     assert ee.shape == (16, 4, 4) and torch.allclose(ee[:, 3], torch.tensor([0, 0, 0, 1.0], device=sim.device).expand(16, 4))
     assert float((ee[:4, 2, 3] - ee[4:8, 2, 3]).mean()) == pytest.approx(1.0 - 0.589, abs=0.02)
     assert float(ee[4, 1, 3]) < -0.3 and torch.allclose(ee[:, :3, :3] @ ee[:, :3, :3].transpose(1, 2), torch.eye(3, device=sim.device).expand(16, 3, 3), atol=1e-5)
+    ee_sim = sim.get_link_pose("link_grasp_center", simulated=True)      # settled robot: the reference's value ~ the simulated pose
+    assert float((ee[:, :3, 3] - ee_sim[:, :3, 3]).abs().max()) < 0.02 and float((ee[:, :3, :3] - ee_sim[:, :3, :3]).abs().max()) < 0.05
     base = sim.get_link_pose("base_link")
     assert torch.allclose(base[:, 0, 3], sim.pull_status().base.x.float(), atol=1e-5)
     with pytest.raises(KeyError):
