@@ -142,3 +142,31 @@ def test_culling_does_not_change_the_image():
     lines = [l for l in out.stdout.splitlines() if "differing" in l]
     assert out.returncode == 0 and len(lines) == 2, out.stdout + out.stderr
     assert all(l.rstrip().endswith("differing 0") for l in lines), out.stdout
+
+
+def test_notebook_corner_values_through_the_raw_entry():
+    """docs/getting_started.ipynb cell 14 (640 x 480, f = 399.427): the last three columns of cam_d435i_depth read 1.649 /
+    1.643 / 1.638 m in the top rows, 1.647 / 1.641 / 1.636 m in the bottom rows, the first columns 0 -- 3.2 s after start().
+    Same tolerances as the oracle's twin (tests/test_depth_oracle.py: 1.5 % absolute for the model revision, 1.1 mm on the
+    pixel-to-pixel steps)."""
+    import ctypes
+    import math
+
+    from stretch_mujoco_amd import lib
+    from stretch_mujoco_amd.enums import StretchCameras
+
+    from stretch_mujoco_amd import StretchBatchSimulator
+    sim = StretchBatchSimulator(num_envs=2, device="cuda:0", cameras_to_use=[StretchCameras.cam_d435i_depth], solver="newton")
+    sim.start()                       # the reference's start: home keyframe targets
+    sim.step(1601)
+    L = lib.load()
+    img = torch.zeros(2, 480, 640, dtype=torch.float32, device=sim.device)
+    fovy = 2 * math.degrees(math.atan(240 / 399.427))
+    assert L.smj_render_depth(sim._ctx, 3, 640, 480, fovy, 10.0, ctypes.c_void_p(img.data_ptr()), sim._stream()) == 0
+    torch.cuda.synchronize()
+    d = img[0].cpu().numpy()
+    top, bot = np.array([1.649, 1.643, 1.638]), np.array([1.647, 1.641, 1.636])
+    assert np.all(d[:3, :3] == 0) and np.all(d[-3:, :3] == 0)
+    assert np.allclose(d[0, -3:], top, rtol=0.015) and np.allclose(d[-1, -3:], bot, rtol=0.015)
+    assert np.allclose(np.diff(d[0, -3:]), np.diff(top), atol=1.1e-3)
+    assert np.allclose(d[0, -3:] - d[-1, -3:], top - bot, atol=1.1e-3)
