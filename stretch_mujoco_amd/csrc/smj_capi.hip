@@ -38,6 +38,8 @@ struct smj_ctx {
   int* order = nullptr;
   int balance = 1;
   int chunk = 0;               // steps per dispatch inside one smj_step (0: the whole launch at once; measured: no gain)
+  int pipeline = 10;           // chunk length of the pipelined dispatch (DevState::pipe_len; 0 = one workgroup per env for the whole launch)
+  int* progress = nullptr;
   SmjCaps caps{};              // capacities of the variant in use
   SmjStageLayout layout{};     // staging-row layout of the variant in use
   int debug_floats = 0;
@@ -255,6 +257,12 @@ int smj_create(const void* blob, size_t nbytes, int num_envs, int device, smj_ct
   }
   {
     void* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, sizeof(int) * (size_t)num_envs));
+    c->allocs.push_back(d);
+    c->progress = (int*)d;
+  }
+  {
+    void* d = nullptr;
     const size_t bytes = sizeof(float) * (size_t)c->layout.stride * (size_t)num_envs;
     HIPCHK(c, hipMalloc(&d, bytes));
     c->allocs.push_back(d);
@@ -465,6 +473,13 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
   // that runs out of rows is handed to the tall variant for the rest of a 10-step chunk, not of the whole launch.  Readout
   // flags go with the last chunk only.  (Debug / profiling slots bound: one chunk, their dumps describe the whole launch.)
   const int chunk = (c->chunk > 0 && !st.debug && !st.prof && c->num_envs > 1024) ? c->chunk : nsteps;
+  // Pipelined chunks (standard variant, batches that need more than one round of workgroups): see DevState::pipe_len
+  st.progress = c->progress;
+  st.pipe_len = 0;
+  if (c->variant == 0 && c->pipeline > 0 && chunk == nsteps && nsteps > c->pipeline && !st.debug && !st.prof && c->num_envs > 1024) {
+    st.pipe_len = c->pipeline;
+    HIPCHK(c, hipMemsetAsync(c->progress, 0, sizeof(int) * (size_t)c->num_envs, (hipStream_t)stream));
+  }
   int lrc = 0;
   for (int done = 0; done < nsteps && !lrc; done += chunk) {
     const int k = nsteps - done < chunk ? nsteps - done : chunk;
@@ -483,6 +498,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
       // envs that ran out of constraint rows / contact slots were parked at the start of the offending step: the tall variant
       // (160 rows / 48 contacts) finishes the chunk's steps for them; an empty list returns at once
       st.redo_worker = 1;
+      st.pipe_len = 0;
       lrc = smj_launch_step_tall(c->model_esc, st, k, fl, (hipStream_t)stream);
     }
   }
@@ -557,6 +573,7 @@ int smj_set_option(smj_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "escalate")) c->escalate = (int)v;
   else if (!strcmp(name, "balance")) c->balance = (int)v;
   else if (!strcmp(name, "chunk")) c->chunk = (int)v;
+  else if (!strcmp(name, "pipeline")) c->pipeline = (int)v;
   else return fail(c, -1, "unknown option '%s'", name);
   return 0;
 }

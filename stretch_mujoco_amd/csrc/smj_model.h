@@ -153,7 +153,15 @@ struct DevState {
   int* cost;
   int* redo;
   int redo_worker;      // the launch is the big variant working the list off: env = redo[1 + 2 i], steps already done redo[2 + 2 i]
+  // Pipelined chunks (standard variant; pipe_len 0 = off): the launch's n steps are cut into chunks of pipe_len steps and the
+  // grid holds one workgroup per (chunk, env), chunk-major -- workgroup w = chunk * B + slot.  Chunk c of an env starts when
+  // progress[env] >= c (published by the workgroup that ran chunk c - 1, which has a lower index and was therefore dispatched
+  // earlier); SMJ_PIPE_PARKED = the env was handed to the escalation list, later chunks return at once.  No barrier between
+  // chunks: the tail of a launch is the longest CHUNK of one env instead of the longest env (smj_step_tu.h).
+  int* progress;
+  int pipe_len;
 };
+enum { SMJ_PIPE_PARKED = 1 << 30 };
 // BaseController state rows (floats; mode: 0 none, 1 translate-by, 2 rotate-by, 3 velocity)
 enum { SMJ_BC_MODE = 0, SMJ_BC_X0, SMJ_BC_Y0, SMJ_BC_TH0, SMJ_BC_INC, SMJ_BC_V, SMJ_BC_W, SMJ_BC_ROWS = 8 };
 // wheel geometry and default speeds of the relative base moves (stretch_mujoco/config.py:2-3,11)
@@ -167,7 +175,7 @@ enum { SMJ_PROF_KIN = 0, SMJ_PROF_COMCRB, SMJ_PROF_SMOOTH, SMJ_PROF_FACTOR, SMJ_
        SMJ_PROF_SETUP, SMJ_PROF_N_UPDATE, SMJ_PROF_N_GRAD, SMJ_PROF_N_XA, SMJ_PROF_N_HMFMA, SMJ_PROF_N_FACTSOLVE, SMJ_PROF_N_SOLVE,
        SMJ_PROF_N_PREP, SMJ_PROF_N_LS, SMJ_PROF_N_LSEVALS, SMJ_PROF_SLOTS = 24 };
 enum { SMJ_INFO_NEFC = 0, SMJ_INFO_NCON = 1, SMJ_INFO_NITER = 2, SMJ_INFO_FLAGS = 3 };
-enum { SMJ_FLAG_EFC_OVERFLOW = 1, SMJ_FLAG_CON_OVERFLOW = 2, SMJ_FLAG_BAD_STATE = 4 };
+enum { SMJ_FLAG_EFC_OVERFLOW = 1, SMJ_FLAG_CON_OVERFLOW = 2, SMJ_FLAG_BAD_STATE = 4, SMJ_FLAG_PIPE_TIMEOUT = 8 };
 
 // layout of the optional debug dump (floats), one column per env; a function of the variant's capacities (smj_dims reports
 // the offsets of the running variant, lib.py: debug_layout)

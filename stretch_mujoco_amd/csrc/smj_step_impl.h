@@ -220,6 +220,8 @@ struct StepKernel {
   PL<float> qvel_r, g_r, qacc_r;
   PL<float> f_r, r_r, ARinv_r;          // lane = row (PGS)
   int nefc, ncon, niter, flags;
+  int step_base = 0;     // steps of this launch that earlier chunks of the env already ran (pipelined chunks, DevState::pipe_len)
+  bool parked = false;   // run() handed the env to the escalation list
 
   SMJ_DEV StepKernel(const DevModel& M_, const DevState& S_, Smem& s_, int env_) : M(M_), S(S_), s(s_), env(env_) {}
 
@@ -364,9 +366,10 @@ struct StepKernel {
 #else
         const int at = S.redo[0]++;
 #endif
-        S.redo[1 + 2 * at] = env; S.redo[2 + 2 * at] = st;
+        S.redo[1 + 2 * at] = env; S.redo[2 + 2 * at] = step_base + st;
       }
     }
+    parked = true;
   }
   SMJ_DEV void load_state() {
     const long ld = S.ld;
@@ -3474,7 +3477,7 @@ struct StepKernel {
       TICK(SMJ_PROF_MAKECON)
       if (S.redo && !S.redo_worker && M.solver == 2 && (flags & (SMJ_FLAG_EFC_OVERFLOW | SMJ_FLAG_CON_OVERFLOW))) {
         escalate(st);
-        if (S.cost) { const int cst = (int)((smj_clock() - tlaunch) >> 6); LANES { if (lane == 0) S.cost[env] = cst; } }
+        if (S.cost) { const int cst = (int)((smj_clock() - tlaunch) >> 6); LANES { if (lane == 0) S.cost[env] = step_base ? S.cost[env] + cst : cst; } }
         return;
       }
       if (M.solver == 2) solve_newton(last, pc, t0, prof);
@@ -3489,7 +3492,7 @@ struct StepKernel {
     store_state(nsteps);
     if (S.cost) {   // shader time of this env's launch (units of 64 clocks): the key of the next launch's order (DevState::order)
       const int cst = (int)((smj_clock() - tlaunch) >> 6);
-      LANES { if (lane == 0) S.cost[env] = S.redo_worker ? S.cost[env] + cst : cst; }
+      LANES { if (lane == 0) S.cost[env] = (S.redo_worker || step_base) ? S.cost[env] + cst : cst; }
     }
     if (prof) {
       pc[SMJ_PROF_TOTAL] = (float)(smj_clock() - tstart);

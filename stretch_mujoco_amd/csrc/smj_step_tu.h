@@ -34,10 +34,38 @@ __global__ __launch_bounds__(64) void SMJ_STEP_KERNEL(const DevModel M, const De
     __syncthreads();
   }
 #else
-  if ((int)blockIdx.x >= S.B) return;
-  const int env = S.order ? S.order[blockIdx.x] : (int)blockIdx.x;
+  int slot = blockIdx.x, chunk = 0, steps = nsteps;
+  if (S.pipe_len) {   // pipelined chunks: workgroup = (chunk, slot), chunk-major (DevState::pipe_len)
+    chunk = (int)blockIdx.x / S.B;
+    slot = (int)blockIdx.x - chunk * S.B;
+    const int base = chunk * S.pipe_len;
+    steps = nsteps - base < S.pipe_len ? nsteps - base : S.pipe_len;
+    if (base + steps < nsteps) read_flags = 0;   // readouts go with the env's last chunk
+  }
+  if (slot >= S.B) return;
+  const int env = S.order ? S.order[slot] : slot;
+  if (chunk > 0) {
+    // wait for the env's previous chunk (normally long finished: it was dispatched B workgroups earlier).  Bounded: a wait of
+    // seconds means the in-order dispatch this scheme leans on did not hold -- flag the env instead of hanging the device.
+    const long long t0 = wall_clock64();
+    int seen;
+    while ((seen = __hip_atomic_load(&S.progress[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < chunk) {
+      __builtin_amdgcn_s_sleep(32);
+      if (wall_clock64() - t0 > 300000000LL) {   // 3 s of the 100 MHz constant clock
+        if (threadIdx.x == 0) atomicOr(&reinterpret_cast<int*>(S.stage + (size_t)env * S.lay.stride)[S.lay.info + SMJ_INFO_FLAGS], SMJ_FLAG_PIPE_TIMEOUT);
+        return;
+      }
+    }
+    if (seen >= SMJ_PIPE_PARKED) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
   StepKernel k(M, S, smem, env);
-  k.run(nsteps, read_flags);
+  k.step_base = chunk * S.pipe_len;
+  k.run(steps, read_flags);
+  if (S.pipe_len) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (threadIdx.x == 0) __hip_atomic_store(&S.progress[env], k.parked ? (int)SMJ_PIPE_PARKED : chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 #endif
 }
 
@@ -49,6 +77,10 @@ int SMJ_LAUNCH_STEP(const DevModel& m, const DevState& s, int nsteps, unsigned r
     if (e != hipSuccess) return (int)e;
     lds_allowed = lds;
   }
-  hipLaunchKernelGGL(SMJ_STEP_KERNEL, dim3(s.redo_worker ? (s.B < 128 ? s.B : 128) : s.B), dim3(64), lds, stream, m, s, nsteps, read_flags);
+  unsigned grid = s.redo_worker ? (s.B < 128 ? s.B : 128) : s.B;
+#if !defined(SMJ_TALL) && !defined(SMJ_BIG)
+  if (s.pipe_len) grid = (unsigned)s.B * (unsigned)((nsteps + s.pipe_len - 1) / s.pipe_len);
+#endif
+  hipLaunchKernelGGL(SMJ_STEP_KERNEL, dim3(grid), dim3(64), lds, stream, m, s, nsteps, read_flags);
   return 0;
 }

@@ -428,3 +428,31 @@ def test_per_env_start_pose():
     assert abs(float(back[0][3]) - float(moved[0][3])) < 2e-3      # the other envs were not touched (one more step)
     sim.stop()
 
+
+
+def test_pipelined_chunks_are_bit_identical_to_one_workgroup_per_env():
+    """smj_step cuts a launch into chunks of `pipeline` steps, one workgroup per (chunk, env) with a per-env progress counter
+    instead of a barrier (DevState::pipe_len): scheduling only -- every env must go through exactly the arithmetic of the
+    unpipelined launch.  Random actions (contacts, Newton iterations and escalations differ per env), 2048 envs, 2 x 37
+    steps with chunk lengths that do and do not divide the launch."""
+    B, final = 2048, {}
+    for pipe in (0, 10, 4, 36):
+        sim = _sim(B, solver="newton")
+        sim.set_option("pipeline", pipe)
+        g = torch.Generator(device=sim.device).manual_seed(7)
+        lo = torch.tensor(sim.model["actuator_ctrlrange"][:, 0], dtype=torch.float32, device=sim.device).unsqueeze(1)
+        hi = torch.tensor(sim.model["actuator_ctrlrange"][:, 1], dtype=torch.float32, device=sim.device).unsqueeze(1)
+        _set_ctrl(sim, HOME_CTRL)
+        sim.step(200)
+        for _ in range(2):
+            sim.ctrl.copy_(lo + (hi - lo) * torch.rand(10, B, generator=g, device=sim.device))
+            sim.step(37)
+        torch.cuda.synchronize()
+        got = [t.clone() for t in (sim.qpos, sim.qvel, sim.qacc_warmstart, sim.actuator_length, sim.actuator_velocity, sim.base_pose, sim.info, sim.nstep)]
+        assert int(sim.info[3].max()) == 0 and int(sim.nstep.min()) == int(sim.nstep.max()) == 274
+        if pipe == 0:
+            final = got
+        else:
+            for a, b in zip(final, got):
+                assert torch.equal(a, b), pipe
+        sim.stop()
