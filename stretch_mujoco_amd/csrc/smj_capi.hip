@@ -38,8 +38,12 @@ struct smj_ctx {
   int* order = nullptr;
   int balance = 1;
   int chunk = 0;               // steps per dispatch inside one smj_step (0: the whole launch at once; measured: no gain)
-  int pipeline = 10;           // chunk length of the pipelined dispatch (DevState::pipe_len; 0 = one workgroup per env for the whole launch)
-  int* progress = nullptr;
+  int pipeline = 5;            // chunk length of the pipelined dispatch (DevState::pipe_len; 0 = one workgroup per env for the whole launch)
+  int pollers = 8;             // tall-variant workgroups that finish parked envs beside the standard kernel (0: the sweep does it all)
+  int* progress = nullptr;     // [B] progress, [B] done_steps, [SMJ_SCHED_WORDS] sched (DevState)
+  size_t redo_cap = 0;         // entries the escalation list holds
+  hipStream_t aux = nullptr;   // the pollers' stream
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   SmjCaps caps{};              // capacities of the variant in use
   SmjStageLayout layout{};     // staging-row layout of the variant in use
   int debug_floats = 0;
@@ -238,10 +242,12 @@ int smj_create(const void* blob, size_t nbytes, int num_envs, int device, smj_ct
     if (rc) return rc;
     c->has_esc = true;
     void* d = nullptr;
-    HIPCHK(c, hipMalloc(&d, sizeof(int) * (1 + 2 * (size_t)num_envs)));
-    c->allocs.push_back(d);
-    HIPCHK(c, hipMemset(d, 0, sizeof(int)));
-    c->redo = (int*)d;
+    c->redo_cap = 8 * (size_t)num_envs;
+    HIPCHK(c, hipMalloc(&d, sizeof(int) * c->redo_cap));
+    c->redo = (int*)d;   // freed in smj_destroy (it can be re-allocated by smj_step)
+    HIPCHK(c, hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   }
   DevModel& m = c->model;
   c->qpos0_dev = const_cast<float*>(m.qpos0);
@@ -257,7 +263,7 @@ int smj_create(const void* blob, size_t nbytes, int num_envs, int device, smj_ct
   }
   {
     void* d = nullptr;
-    HIPCHK(c, hipMalloc(&d, sizeof(int) * (size_t)num_envs));
+    HIPCHK(c, hipMalloc(&d, sizeof(int) * (2 * (size_t)num_envs + SMJ_SCHED_WORDS)));
     c->allocs.push_back(d);
     c->progress = (int*)d;
   }
@@ -347,6 +353,10 @@ int smj_comm_destroy(smj_ctx* c) {
 int smj_destroy(smj_ctx* c) {
   if (!c) return -1;
   smj_comm_destroy(c);
+  if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->redo) (void)hipFree(c->redo);
   for (void* p : c->allocs) (void)hipFree(p);
   delete c;
   return 0;
@@ -474,32 +484,66 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
   // flags go with the last chunk only.  (Debug / profiling slots bound: one chunk, their dumps describe the whole launch.)
   const int chunk = (c->chunk > 0 && !st.debug && !st.prof && c->num_envs > 1024) ? c->chunk : nsteps;
   // Pipelined chunks (standard variant, batches that need more than one round of workgroups): see DevState::pipe_len
-  st.progress = c->progress;
-  st.pipe_len = 0;
-  if (c->variant == 0 && c->pipeline > 0 && chunk == nsteps && nsteps > c->pipeline && !st.debug && !st.prof && c->num_envs > 1024) {
-    st.pipe_len = c->pipeline;
-    HIPCHK(c, hipMemsetAsync(c->progress, 0, sizeof(int) * (size_t)c->num_envs, (hipStream_t)stream));
+  hipStream_t sm = (hipStream_t)stream;
+  const bool pipe = c->variant == 0 && c->pipeline > 0 && chunk == nsteps && nsteps > c->pipeline && !st.debug && !st.prof && c->num_envs > 1024;
+  st.progress = st.done_steps = st.sched = nullptr;
+  if (esc || pipe) {
+    st.progress = c->progress;
+    st.done_steps = c->progress + c->num_envs;
+    st.sched = c->progress + 2 * (size_t)c->num_envs;
   }
+  st.pipe_len = 0;
+  st.pollers = 0;
   int lrc = 0;
   for (int done = 0; done < nsteps && !lrc; done += chunk) {
     const int k = nsteps - done < chunk ? nsteps - done : chunk;
     const unsigned fl = done + k >= nsteps ? read_flags : 0u;
     st.redo_worker = 0;
     st.order = nullptr;
-    if (esc) HIPCHK(c, hipMemsetAsync(c->redo, 0, sizeof(int), (hipStream_t)stream));
+    st.pipe_len = pipe ? c->pipeline : 0;
+    st.pipe_total = c->num_envs * (pipe ? (k + c->pipeline - 1) / c->pipeline : 1);
+    if (esc || pipe) HIPCHK(c, hipMemsetAsync(c->progress, 0, sizeof(int) * (2 * (size_t)c->num_envs + SMJ_SCHED_WORDS), sm));
+    if (esc) {
+      if ((size_t)st.pipe_total > c->redo_cap) {   // every workgroup of the standard launch can park its env once
+        HIPCHK(c, hipDeviceSynchronize());
+        (void)hipFree(c->redo);
+        c->redo = nullptr;
+        c->redo_cap = (size_t)st.pipe_total;
+        void* d = nullptr;
+        HIPCHK(c, hipMalloc(&d, sizeof(int) * c->redo_cap));
+        c->redo = (int*)d;
+        st.redo = c->redo;
+      }
+      HIPCHK(c, hipMemsetAsync(c->redo, 0xff, sizeof(int) * (size_t)st.pipe_total, sm));   // -1 = entry not published yet
+    }
     if (c->balance && k >= 4 && c->num_envs > 1024) {   // a launch of one or two steps is not worth the sort
-      smj_launch_order(c->cost, c->order, c->num_envs, (hipStream_t)stream);
+      smj_launch_order(c->cost, c->order, c->num_envs, sm);
       st.order = c->order;
     }
-    lrc = c->variant == 2   ? smj_launch_step_big(c->model, st, k, fl, (hipStream_t)stream)
-          : c->variant == 1 ? smj_launch_step_tall(c->model, st, k, fl, (hipStream_t)stream)
-                            : smj_launch_step(c->model, st, k, fl, (hipStream_t)stream);
+    const bool poll = esc && pipe && c->pollers > 0;
+    if (poll) {
+      // pollers first, on their own stream, so that they are resident when the standard kernel fills the device; should they
+      // not be (nothing guarantees it), parked envs are given up to the sweep, as without pollers
+      DevState sp = st;
+      sp.redo_worker = 2;
+      sp.pollers = c->pollers;
+      sp.order = nullptr;
+      HIPCHK(c, hipEventRecord(c->ev_fork, sm));
+      HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+      lrc = smj_launch_step_tall(c->model_esc, sp, k, fl, c->aux);
+      HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
+    }
+    if (!lrc)
+      lrc = c->variant == 2   ? smj_launch_step_big(c->model, st, k, fl, sm)
+            : c->variant == 1 ? smj_launch_step_tall(c->model, st, k, fl, sm)
+                              : smj_launch_step(c->model, st, k, fl, sm);
+    if (poll) HIPCHK(c, hipStreamWaitEvent(sm, c->ev_join, 0));
     if (!lrc && esc) {
-      // envs that ran out of constraint rows / contact slots were parked at the start of the offending step: the tall variant
-      // (160 rows / 48 contacts) finishes the chunk's steps for them; an empty list returns at once
+      // the sweep: whatever is left of the envs that ran out of constraint rows / contact slots (parked at the start of the
+      // offending step) is finished by the tall variant (160 rows / 48 contacts); an empty list returns at once
       st.redo_worker = 1;
       st.pipe_len = 0;
-      lrc = smj_launch_step_tall(c->model_esc, st, k, fl, (hipStream_t)stream);
+      lrc = smj_launch_step_tall(c->model_esc, st, k, fl, sm);
     }
   }
   if (lrc) return fail(c, -2, "step kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
@@ -574,6 +618,7 @@ int smj_set_option(smj_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "balance")) c->balance = (int)v;
   else if (!strcmp(name, "chunk")) c->chunk = (int)v;
   else if (!strcmp(name, "pipeline")) c->pipeline = (int)v;
+  else if (!strcmp(name, "pollers")) c->pollers = (int)v < 0 ? 0 : (int)v > 256 ? 256 : (int)v;
   else return fail(c, -1, "unknown option '%s'", name);
   return 0;
 }

@@ -152,16 +152,30 @@ struct DevState {
   const int* order;
   int* cost;
   int* redo;
-  int redo_worker;      // the launch is the big variant working the list off: env = redo[1 + 2 i], steps already done redo[2 + 2 i]
+  int redo_worker;      // the launch is the tall variant working the list (redo[i] = env, -1 until published) off: 1 sweep, 2 poller
   // Pipelined chunks (standard variant; pipe_len 0 = off): the launch's n steps are cut into chunks of pipe_len steps and the
   // grid holds one workgroup per (chunk, env), chunk-major -- workgroup w = chunk * B + slot.  Chunk c of an env starts when
   // progress[env] >= c (published by the workgroup that ran chunk c - 1, which has a lower index and was therefore dispatched
-  // earlier); SMJ_PIPE_PARKED = the env was handed to the escalation list, later chunks return at once.  No barrier between
-  // chunks: the tail of a launch is the longest CHUNK of one env instead of the longest env (smj_step_tu.h).
+  // earlier).  No barrier between chunks: the tail of a launch is the longest CHUNK of one env instead of the longest env
+  // (smj_step_tu.h).
+  // progress[env]: chunks finished (0..C) | -(c + 1): parked during chunk c, on the escalation list | SMJ_PIPE_ABANDONED: a
+  // later chunk found the env parked with no poller alive and gave it up to the sweep | SMJ_PIPE_SWEPT: claimed by the sweep.
+  // done_steps[env]: steps of this launch the env has completed (whoever ran them).
+  // sched: [0] escalation entries claimed by pollers, [1] workgroups of the standard kernel that have exited, [2] pollers
+  // alive, [3] escalation entries published (the list's count).
+  // Escalation with pollers (redo_worker == 2): a few workgroups of the tall variant run CONCURRENTLY with the standard kernel
+  // (second stream), take parked envs off the list as they appear, finish the env's current chunk and hand it back
+  // (progress: -(c+1) -> c+1); they exit when every standard workgroup has exited and the list is drained.  The sweep
+  // (redo_worker == 1, after both) finishes whatever is left of every env on the list -- all of it when there are no pollers.
   int* progress;
+  int* done_steps;
+  int* sched;
   int pipe_len;
+  int pipe_total;   // workgroups of the standard launch
+  int pollers;      // workgroups of the poller launch
 };
-enum { SMJ_PIPE_PARKED = 1 << 30 };
+enum { SMJ_PIPE_ABANDONED = 0x7fffffff, SMJ_PIPE_SWEPT = 0x7ffffffe };
+enum { SMJ_SCHED_CLAIMED = 0, SMJ_SCHED_EXITED = 1, SMJ_SCHED_POLLERS = 2, SMJ_SCHED_COUNT = 3, SMJ_SCHED_WORDS = 4 };
 // BaseController state rows (floats; mode: 0 none, 1 translate-by, 2 rotate-by, 3 velocity)
 enum { SMJ_BC_MODE = 0, SMJ_BC_X0, SMJ_BC_Y0, SMJ_BC_TH0, SMJ_BC_INC, SMJ_BC_V, SMJ_BC_W, SMJ_BC_ROWS = 8 };
 // wheel geometry and default speeds of the relative base moves (stretch_mujoco/config.py:2-3,11)

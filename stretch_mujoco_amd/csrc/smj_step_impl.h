@@ -221,6 +221,7 @@ struct StepKernel {
   PL<float> f_r, r_r, ARinv_r;          // lane = row (PGS)
   int nefc, ncon, niter, flags;
   int step_base = 0;     // steps of this launch that earlier chunks of the env already ran (pipelined chunks, DevState::pipe_len)
+  int pipe_chunk = 0;    // the chunk this workgroup runs
   bool parked = false;   // run() handed the env to the escalation list
 
   SMJ_DEV StepKernel(const DevModel& M_, const DevState& S_, Smem& s_, int env_) : M(M_), S(S_), s(s_), env(env_) {}
@@ -352,6 +353,7 @@ struct StepKernel {
   // qpos / qvel / qacc_warmstart / ctrl / the base controller change in solve / integrate / base_controller only) and queue
   // it for the big kernel variant, which finishes the launch's remaining steps on it.
   SMJ_DEV void escalate(int st) {
+#ifndef SMJ_EMUL
     float* row = stage_row();
     int* rowi = reinterpret_cast<int*>(row);
     LANES {
@@ -361,14 +363,19 @@ struct StepKernel {
       if (lane < SMJ_BC_ROWS) row[S.lay.bctl + lane] = s.bctl[lane];
       if (lane == 0) {
         rowi[S.lay.nstep] += st;
-#ifndef SMJ_EMUL
-        const int at = atomicAdd(&S.redo[0], 1);
-#else
-        const int at = S.redo[0]++;
-#endif
-        S.redo[1 + 2 * at] = env; S.redo[2 + 2 * at] = step_base + st;
+        S.done_steps[env] += st;
+        // parked state first, then the list entry (a poller that takes the entry swaps exactly this value back)
+        __hip_atomic_store(&S.progress[env], -(pipe_chunk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    LANES {
+      if (lane == 0) {
+        const int at = atomicAdd(&S.sched[SMJ_SCHED_COUNT], 1);
+        __hip_atomic_store(&S.redo[at], env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+#endif
     parked = true;
   }
   SMJ_DEV void load_state() {
@@ -408,6 +415,7 @@ struct StepKernel {
         if (lane < SMJ_BC_ROWS) st[S.lay.bctl + lane] = s.bctl[lane];
         if (lane == 0) {
           sti[S.lay.nstep] += nsteps;
+          if (S.done_steps) S.done_steps[env] += nsteps;
           sti[S.lay.info + SMJ_INFO_NEFC] = nefc; sti[S.lay.info + SMJ_INFO_NCON] = ncon;
           sti[S.lay.info + SMJ_INFO_NITER] = niter; sti[S.lay.info + SMJ_INFO_FLAGS] |= flags;
           st[S.lay.base] = bx; st[S.lay.base + 1] = by; st[S.lay.base + 2] = bth;

@@ -16,22 +16,76 @@
 #define SMJ_LAUNCH_STEP smj_launch_step
 #endif
 
+// agent-scope relaxed atomics on the scheduling words (coherent across the XCDs' L2s); data handed over with them is fenced
+#define SMJ_ALOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define SMJ_ASTORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define SMJ_WAIT_TICKS 300000000LL   // 3 s of the 100 MHz constant clock: the bound of every wait loop below
+
 __global__ __launch_bounds__(64) void SMJ_STEP_KERNEL(const DevModel M, const DevState S, int nsteps, unsigned read_flags) {
   // dynamic LDS: a Newton launch asks for sizeof(Smem), a PGS launch for the extra tail that holds A (smj_lds_bytes)
   extern __shared__ __align__(16) unsigned char smj_lds[];
   Smem& smem = *reinterpret_cast<Smem*>(smj_lds);
 #if defined(SMJ_TALL) || defined(SMJ_BIG)
-  // One call site of run() (the whole step pipeline is inlined into it): a normal launch takes env = blockIdx.x, steps = nsteps;
-  // an escalation launch works the list of envs the standard variant parked (DevState::redo).
-  int i = blockIdx.x, last = blockIdx.x;
-  if (S.redo_worker) last = S.redo[0] - 1;
-  for (; i <= last; i += gridDim.x) {
-    if (i >= S.B) return;
-    int env = S.order ? S.order[i] : i, steps = nsteps;
-    if (S.redo_worker) { env = S.redo[1 + 2 * i]; steps = nsteps - S.redo[2 + 2 * i]; }
+  // One call site of run() (the whole step pipeline is inlined into it): a normal launch takes env = order[blockIdx.x], steps =
+  // nsteps; an escalation launch works the list of envs the standard variant parked (DevState::redo) -- as the sweep after
+  // the standard kernel (redo_worker 1) or as a poller beside it (redo_worker 2, DevState::sched).
+  const int mode = S.redo_worker;
+  long long t0 = mode == 2 ? wall_clock64() : 0;   // of the last sign of life of the standard kernel
+  int exited_seen = -1;
+  if (mode == 2 && threadIdx.x == 0) atomicAdd(&S.sched[SMJ_SCHED_POLLERS], 1);
+  for (int i = blockIdx.x;; i += gridDim.x) {
+    int env, steps = nsteps, chunk = 0;
+    unsigned fl = read_flags;
+    if (mode == 0) {
+      if (i != (int)blockIdx.x || i >= S.B) return;
+      env = S.order ? S.order[i] : i;
+    } else if (mode == 1) {
+      if (i >= SMJ_ALOAD(&S.sched[SMJ_SCHED_COUNT])) return;
+      env = S.redo[i];
+      int old = 0;
+      if (threadIdx.x == 0) old = atomicExch(&S.progress[env], (int)SMJ_PIPE_SWEPT);   // an env can be on the list more than once
+      old = __builtin_amdgcn_readfirstlane(old);
+      steps = nsteps - S.done_steps[env];
+      if (old == SMJ_PIPE_SWEPT || steps <= 0) continue;
+    } else {
+      // poller: claim the next published entry; leave when the standard kernel is through and the list is drained
+      int at = -1;
+      for (;;) {
+        const int exited = SMJ_ALOAD(&S.sched[SMJ_SCHED_EXITED]);   // read BEFORE the count: exited == total => the count is final
+        const int cnt = SMJ_ALOAD(&S.sched[SMJ_SCHED_COUNT]), cl = SMJ_ALOAD(&S.sched[SMJ_SCHED_CLAIMED]);
+        if (cl < cnt) {
+          int got = 0;
+          if (threadIdx.x == 0) got = atomicCAS(&S.sched[SMJ_SCHED_CLAIMED], cl, cl + 1);
+          if (__builtin_amdgcn_readfirstlane(got) == cl) { at = cl; break; }
+          continue;
+        }
+        if (exited != exited_seen) { exited_seen = exited; t0 = wall_clock64(); }
+        if (exited >= S.pipe_total || wall_clock64() - t0 > SMJ_WAIT_TICKS) {
+          if (threadIdx.x == 0) atomicSub(&S.sched[SMJ_SCHED_POLLERS], 1);   // waiters stop counting on pollers
+          return;
+        }
+        __builtin_amdgcn_s_sleep(64);
+      }
+      t0 = wall_clock64();
+      while ((env = SMJ_ALOAD(&S.redo[at])) < 0)   // the count is bumped before the entry is written
+        if (wall_clock64() - t0 > SMJ_WAIT_TICKS) {
+          if (threadIdx.x == 0) atomicSub(&S.sched[SMJ_SCHED_POLLERS], 1);
+          return;
+        }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const int done = S.done_steps[env];
+      chunk = done / S.pipe_len;
+      const int end = (chunk + 1) * S.pipe_len < nsteps ? (chunk + 1) * S.pipe_len : nsteps;
+      steps = end - done;
+      if (end < nsteps) fl = 0;
+    }
     StepKernel k(M, S, smem, env);
-    k.run(steps, read_flags);
+    k.run(steps, fl);
     __syncthreads();
+    if (mode == 2) {   // hand the env back to the standard kernel's next chunk (unless that one has given the env up)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (threadIdx.x == 0) atomicCAS(&S.progress[env], -(chunk + 1), chunk + 1);
+    }
   }
 #else
   int slot = blockIdx.x, chunk = 0, steps = nsteps;
@@ -44,28 +98,41 @@ __global__ __launch_bounds__(64) void SMJ_STEP_KERNEL(const DevModel M, const De
   }
   if (slot >= S.B) return;
   const int env = S.order ? S.order[slot] : slot;
+  bool go = true;
   if (chunk > 0) {
     // wait for the env's previous chunk (normally long finished: it was dispatched B workgroups earlier).  Bounded: a wait of
     // seconds means the in-order dispatch this scheme leans on did not hold -- flag the env instead of hanging the device.
     const long long t0 = wall_clock64();
-    int seen;
-    while ((seen = __hip_atomic_load(&S.progress[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < chunk) {
-      __builtin_amdgcn_s_sleep(32);
-      if (wall_clock64() - t0 > 300000000LL) {   // 3 s of the 100 MHz constant clock
-        if (threadIdx.x == 0) atomicOr(&reinterpret_cast<int*>(S.stage + (size_t)env * S.lay.stride)[S.lay.info + SMJ_INFO_FLAGS], SMJ_FLAG_PIPE_TIMEOUT);
-        return;
+    for (;;) {
+      const int seen = SMJ_ALOAD(&S.progress[env]);
+      if (seen >= chunk) { go = seen < SMJ_PIPE_SWEPT; break; }
+      const bool late = wall_clock64() - t0 > SMJ_WAIT_TICKS;
+      if (seen < 0 && (late || SMJ_ALOAD(&S.sched[SMJ_SCHED_POLLERS]) == 0)) {
+        // parked and nobody to finish the chunk now: the sweep after this kernel takes the env from where it stands
+        if (threadIdx.x == 0) atomicCAS(&S.progress[env], seen, (int)SMJ_PIPE_ABANDONED);
+        go = false;
+        break;
       }
+      if (late) {
+        if (threadIdx.x == 0) atomicOr(&reinterpret_cast<int*>(S.stage + (size_t)env * S.lay.stride)[S.lay.info + SMJ_INFO_FLAGS], SMJ_FLAG_PIPE_TIMEOUT);
+        go = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(32);
     }
-    if (seen >= SMJ_PIPE_PARKED) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
-  StepKernel k(M, S, smem, env);
-  k.step_base = chunk * S.pipe_len;
-  k.run(steps, read_flags);
-  if (S.pipe_len) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    if (threadIdx.x == 0) __hip_atomic_store(&S.progress[env], k.parked ? (int)SMJ_PIPE_PARKED : chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (go) {
+    StepKernel k(M, S, smem, env);
+    k.step_base = chunk * S.pipe_len;
+    k.pipe_chunk = chunk;
+    k.run(steps, read_flags);
+    if (S.pipe_len && !k.parked) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (threadIdx.x == 0) SMJ_ASTORE(&S.progress[env], chunk + 1);
+    }
   }
+  if (S.sched && threadIdx.x == 0) atomicAdd(&S.sched[SMJ_SCHED_EXITED], 1);
 #endif
 }
 
@@ -77,7 +144,7 @@ int SMJ_LAUNCH_STEP(const DevModel& m, const DevState& s, int nsteps, unsigned r
     if (e != hipSuccess) return (int)e;
     lds_allowed = lds;
   }
-  unsigned grid = s.redo_worker ? (s.B < 128 ? s.B : 128) : s.B;
+  unsigned grid = s.redo_worker == 2 ? (unsigned)s.pollers : s.redo_worker ? (s.B < 128 ? s.B : 128) : s.B;
 #if !defined(SMJ_TALL) && !defined(SMJ_BIG)
   if (s.pipe_len) grid = (unsigned)s.B * (unsigned)((nsteps + s.pipe_len - 1) / s.pipe_len);
 #endif

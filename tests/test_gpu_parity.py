@@ -434,11 +434,14 @@ def test_pipelined_chunks_are_bit_identical_to_one_workgroup_per_env():
     """smj_step cuts a launch into chunks of `pipeline` steps, one workgroup per (chunk, env) with a per-env progress counter
     instead of a barrier (DevState::pipe_len): scheduling only -- every env must go through exactly the arithmetic of the
     unpipelined launch.  Random actions (contacts, Newton iterations and escalations differ per env), 2048 envs, 2 x 37
-    steps with chunk lengths that do and do not divide the launch."""
+    steps with chunk lengths that do and do not divide the launch.  pollers = 0: escalated envs are finished by the sweep in
+    every case (with pollers an escalated env returns to the standard variant after its chunk -- same physics, other
+    rounding; next test)."""
     B, final = 2048, {}
     for pipe in (0, 10, 4, 36):
         sim = _sim(B, solver="newton")
         sim.set_option("pipeline", pipe)
+        sim.set_option("pollers", 0)
         g = torch.Generator(device=sim.device).manual_seed(7)
         lo = torch.tensor(sim.model["actuator_ctrlrange"][:, 0], dtype=torch.float32, device=sim.device).unsqueeze(1)
         hi = torch.tensor(sim.model["actuator_ctrlrange"][:, 1], dtype=torch.float32, device=sim.device).unsqueeze(1)
@@ -456,3 +459,44 @@ def test_pipelined_chunks_are_bit_identical_to_one_workgroup_per_env():
             for a, b in zip(final, got):
                 assert torch.equal(a, b), pipe
         sim.stop()
+
+
+def test_pollers_finish_the_parked_chunk_and_hand_the_env_back():
+    """Escalation beside the standard kernel (DevState::sched): a few workgroups of the tall variant take parked envs off the
+    list while the standard kernel runs, finish the env's chunk and publish it for the standard variant's next chunk.  The
+    scripted overflow (83 rows on steps 19-20 of this window; start = the oracle's state after the drop's first 8 steps) on
+    every 7th of 1100 envs, free-running for 32 steps in ONE launch: all copies bit-identical, no flags, every env 32 steps,
+    the result within fp32 free-running drift of the capacity-free oracle and of the sweep-only schedule (whose steps after
+    the overflow run in the tall variant: other MFMA tiling, last-bit differences)."""
+    blob = open(__import__("os").path.join(__import__("conftest").MODELS, "stretch_empty.smjb"), "rb").read()
+    o = Oracle(blob)
+    o.set_option("solver", 2); o.reset()
+    ctrl = [0, 0, 0.0, 0.3, 0, -1.57, 0, 0, 0, 0]
+    o.arr("ctrl")[:10] = ctrl
+    o.step(8)
+    start = [o.arr(n).copy() for n in ("qpos", "qvel", "qacc_warmstart")]
+    over = 0
+    for _ in range(32):
+        o.step(1)
+        over += o.nefc > 80
+    assert over >= 2
+    B, res = 1100, {}
+    for name, opts in (("sweep", dict(pipeline=0)), ("pollers", dict(pipeline=5, pollers=8)), ("pollers10", dict(pipeline=10, pollers=3))):
+        sim = _sim(B, solver="newton")
+        for k, v in opts.items():
+            sim.set_option(k, v)
+        _set_ctrl(sim, HOME_CTRL)
+        idx = torch.arange(0, B, 7, device=sim.device)
+        sim.ctrl[:, idx] = torch.tensor(ctrl, dtype=torch.float32, device=sim.device).unsqueeze(1)
+        for t, a in zip((sim.qpos, sim.qvel, sim.qacc_warmstart), start):
+            t[:, idx] = torch.tensor(a, dtype=torch.float32, device=sim.device).unsqueeze(1)
+        sim.step(32)
+        torch.cuda.synchronize()
+        assert int(sim.info[3].max()) == 0 and int(sim.nstep.min()) == int(sim.nstep.max()) == 32
+        qp, qv = sim.qpos[:, idx].cpu().numpy(), sim.qvel[:, idx].cpu().numpy()
+        assert np.abs(qv - qv[:, :1]).max() == 0 and np.abs(qp - qp[:, :1]).max() == 0
+        assert np.abs(qp[:, 0] - o.arr("qpos")).max() < 1e-4 and np.abs(qv[:, 0] - o.arr("qvel")).max() < 3e-3
+        res[name] = (qp[:, 0], qv[:, 0])
+        sim.stop()
+    for name in ("pollers", "pollers10"):
+        assert np.abs(res[name][0] - res["sweep"][0]).max() < 1e-5 and np.abs(res[name][1] - res["sweep"][1]).max() < 1e-3
