@@ -21,7 +21,10 @@
 #define SMJ_ASTORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define SMJ_WAIT_TICKS 300000000LL   // 3 s of the 100 MHz constant clock: the bound of every wait loop below
 
-__global__ __launch_bounds__(64) void SMJ_STEP_KERNEL(const DevModel M, const DevState S, int nsteps, unsigned read_flags) {
+#ifndef SMJ_KERNEL_ATTR
+#define SMJ_KERNEL_ATTR
+#endif
+__global__ __launch_bounds__(64) SMJ_KERNEL_ATTR void SMJ_STEP_KERNEL(const DevModel M, const DevState S, int nsteps, unsigned read_flags) {
   // dynamic LDS: a Newton launch asks for sizeof(Smem), a PGS launch for the extra tail that holds A (smj_lds_bytes)
   extern __shared__ __align__(16) unsigned char smj_lds[];
   Smem& smem = *reinterpret_cast<Smem*>(smj_lds);

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsmj.so")
+LIB_PATH = os.environ.get("SMJ_LIB_PATH") or os.path.join(_HERE, "libsmj.so")   # SMJ_LIB_PATH: another build of the same library (compiler-flag experiments)
 
 SLOT = dict(QPOS=0, QVEL=1, CTRL=2, WARMSTART=3, NSTEP=4, ACT_LENGTH=5, ACT_VELOCITY=6, BASE_POSE=7, GYRO=8, ACCEL=9,
             LIDAR=10, INFO=11, DEBUG=12, PROF=13, XPOSE=14, BASECTL=15)
