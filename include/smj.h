@@ -91,9 +91,10 @@ int smj_base_controller_tick(smj_ctx* ctx, void* stream);
  * smj_step sends its n steps out as dispatches of this many steps on the staged state, each with a fresh order; 0 = one dispatch),
  * "pipeline" (default 5; batches of more than 1024 envs: the n steps of a call are cut into chunks of this many steps and the
  * grid holds one workgroup per (chunk, env) that waits on the env's progress counter instead of a barrier between chunks --
- * scheduling only, results are bit-identical; 0 = one workgroup per env per call), "pollers" (default 8: workgroups of the
+ * scheduling only, results are bit-identical; 0 = one workgroup per env per call), "pollers" (default 2: workgroups of the
  * tall variant that run beside the standard kernel on a second stream, finish the current chunk of an env that ran out of
- * rows and hand it back; 0 = such envs are finished after the standard kernel). */
+ * rows and hand it back -- they leave at once unless one of the last 8 calls had such envs; -n: n pollers that always stay; 0 = such envs are
+ * finished after the standard kernel). */
 int smj_set_option(smj_ctx* ctx, const char* name, double value);
 
 /* Depth image of camera `camera_id` (index into the model's cameras, stretch.xml order: d405_rgb, d405_depth,

@@ -39,7 +39,8 @@ struct smj_ctx {
   int balance = 1;
   int chunk = 0;               // steps per dispatch inside one smj_step (0: the whole launch at once; measured: no gain)
   int pipeline = 5;            // chunk length of the pipelined dispatch (DevState::pipe_len; 0 = one workgroup per env for the whole launch)
-  int pollers = 8;             // tall-variant workgroups that finish parked envs beside the standard kernel (0: the sweep does it all)
+  bool pollers_always = false; // option "pollers" < 0: send the pollers with every launch (tests)
+  int pollers = 2;             // tall-variant workgroups that finish parked envs beside the standard kernel (0: the sweep does it all)
   int* progress = nullptr;     // [B] progress, [B] done_steps, [SMJ_SCHED_WORDS] sched (DevState)
   size_t redo_cap = 0;         // entries the escalation list holds
   hipStream_t aux = nullptr;   // the pollers' stream
@@ -263,9 +264,10 @@ int smj_create(const void* blob, size_t nbytes, int num_envs, int device, smj_ct
   }
   {
     void* d = nullptr;
-    HIPCHK(c, hipMalloc(&d, sizeof(int) * (2 * (size_t)num_envs + SMJ_SCHED_WORDS)));
+    HIPCHK(c, hipMalloc(&d, sizeof(int) * (2 * (size_t)num_envs + SMJ_SCHED_WORDS + 1)));
     c->allocs.push_back(d);
-    c->progress = (int*)d;
+    HIPCHK(c, hipMemset(d, 0, sizeof(int) * (2 * (size_t)num_envs + SMJ_SCHED_WORDS + 1)));
+    c->progress = (int*)d;   // + the `hot` word behind sched, which the per-launch memset leaves alone
   }
   {
     void* d = nullptr;
@@ -486,11 +488,12 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
   // Pipelined chunks (standard variant, batches that need more than one round of workgroups): see DevState::pipe_len
   hipStream_t sm = (hipStream_t)stream;
   const bool pipe = c->variant == 0 && c->pipeline > 0 && chunk == nsteps && nsteps > c->pipeline && !st.debug && !st.prof && c->num_envs > 1024;
-  st.progress = st.done_steps = st.sched = nullptr;
+  st.progress = st.done_steps = st.sched = st.hot = nullptr;
   if (esc || pipe) {
     st.progress = c->progress;
     st.done_steps = c->progress + c->num_envs;
     st.sched = c->progress + 2 * (size_t)c->num_envs;
+    st.hot = st.sched + SMJ_SCHED_WORDS;
   }
   st.pipe_len = 0;
   st.pollers = 0;
@@ -520,13 +523,17 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
       smj_launch_order(c->cost, c->order, c->num_envs, sm);
       st.order = c->order;
     }
+    // A second kernel resident beside the standard one costs a launch in which nobody escalates 5 % (measured: one poller or
+    // sixteen, any poll interval, any stream priority), and escalations are rare events (0-2 envs per 50-step launch of 4096
+    // under random actions, each worth milliseconds when left to the sweep): the pollers leave at once unless one of the last
+    // SMJ_HOT_LAUNCHES launches had an escalation (DevState::hot, kept on the device -- the host runs many launches ahead)
     const bool poll = esc && pipe && c->pollers > 0;
     if (poll) {
       // pollers first, on their own stream, so that they are resident when the standard kernel fills the device; should they
       // not be (nothing guarantees it), parked envs are given up to the sweep, as without pollers
       DevState sp = st;
       sp.redo_worker = 2;
-      sp.pollers = c->pollers;
+      sp.pollers = c->pollers_always ? -c->pollers : c->pollers;
       sp.order = nullptr;
       HIPCHK(c, hipEventRecord(c->ev_fork, sm));
       HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
@@ -618,7 +625,11 @@ int smj_set_option(smj_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "balance")) c->balance = (int)v;
   else if (!strcmp(name, "chunk")) c->chunk = (int)v;
   else if (!strcmp(name, "pipeline")) c->pipeline = (int)v;
-  else if (!strcmp(name, "pollers")) c->pollers = (int)v < 0 ? 0 : (int)v > 256 ? 256 : (int)v;
+  else if (!strcmp(name, "pollers")) {   // n > 0: n pollers when a recent launch escalated; -n: n pollers with every launch; 0: none
+    c->pollers_always = v < 0;
+    const int n = (int)(v < 0 ? -v : v);
+    c->pollers = n > 256 ? 256 : n;
+  }
   else return fail(c, -1, "unknown option '%s'", name);
   return 0;
 }

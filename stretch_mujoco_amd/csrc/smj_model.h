@@ -172,9 +172,10 @@ struct DevState {
   int* sched;
   int pipe_len;
   int pipe_total;   // workgroups of the standard launch
-  int pollers;      // workgroups of the poller launch
+  int pollers;      // workgroups of the poller launch; negative: they stay even if the previous launch had no escalation
+  int* hot;         // > 0: one of the last SMJ_HOT_LAUNCHES launches had escalations (kept by the sweep)
 };
-enum { SMJ_PIPE_ABANDONED = 0x7fffffff, SMJ_PIPE_SWEPT = 0x7ffffffe };
+enum { SMJ_PIPE_ABANDONED = 0x7fffffff, SMJ_PIPE_SWEPT = 0x7ffffffe, SMJ_HOT_LAUNCHES = 8 };
 enum { SMJ_SCHED_CLAIMED = 0, SMJ_SCHED_EXITED = 1, SMJ_SCHED_POLLERS = 2, SMJ_SCHED_COUNT = 3, SMJ_SCHED_WORDS = 4 };
 // BaseController state rows (floats; mode: 0 none, 1 translate-by, 2 rotate-by, 3 velocity)
 enum { SMJ_BC_MODE = 0, SMJ_BC_X0, SMJ_BC_Y0, SMJ_BC_TH0, SMJ_BC_INC, SMJ_BC_V, SMJ_BC_W, SMJ_BC_ROWS = 8 };

@@ -35,7 +35,10 @@ __global__ __launch_bounds__(64) SMJ_KERNEL_ATTR void SMJ_STEP_KERNEL(const DevM
   const int mode = S.redo_worker;
   long long t0 = mode == 2 ? wall_clock64() : 0;   // of the last sign of life of the standard kernel
   int exited_seen = -1;
-  if (mode == 2 && threadIdx.x == 0) atomicAdd(&S.sched[SMJ_SCHED_POLLERS], 1);
+  if (mode == 2) {
+    if (S.pollers > 0 && *S.hot == 0) return;   // a quiet run: no second queue beside the standard kernel
+    if (threadIdx.x == 0) atomicAdd(&S.sched[SMJ_SCHED_POLLERS], 1);
+  }
   for (int i = blockIdx.x;; i += gridDim.x) {
     int env, steps = nsteps, chunk = 0;
     unsigned fl = read_flags;
@@ -43,7 +46,9 @@ __global__ __launch_bounds__(64) SMJ_KERNEL_ATTR void SMJ_STEP_KERNEL(const DevM
       if (i != (int)blockIdx.x || i >= S.B) return;
       env = S.order ? S.order[i] : i;
     } else if (mode == 1) {
-      if (i >= SMJ_ALOAD(&S.sched[SMJ_SCHED_COUNT])) return;
+      const int cnt = SMJ_ALOAD(&S.sched[SMJ_SCHED_COUNT]);
+      if (i == 0 && threadIdx.x == 0) *S.hot = cnt > 0 ? (int)SMJ_HOT_LAUNCHES : *S.hot > 0 ? *S.hot - 1 : 0;
+      if (i >= cnt) return;
       env = S.redo[i];
       int old = 0;
       if (threadIdx.x == 0) old = atomicExch(&S.progress[env], (int)SMJ_PIPE_SWEPT);   // an env can be on the list more than once
@@ -147,7 +152,7 @@ int SMJ_LAUNCH_STEP(const DevModel& m, const DevState& s, int nsteps, unsigned r
     if (e != hipSuccess) return (int)e;
     lds_allowed = lds;
   }
-  unsigned grid = s.redo_worker == 2 ? (unsigned)s.pollers : s.redo_worker ? (s.B < 128 ? s.B : 128) : s.B;
+  unsigned grid = s.redo_worker == 2 ? (unsigned)(s.pollers < 0 ? -s.pollers : s.pollers) : s.redo_worker ? (s.B < 128 ? s.B : 128) : s.B;
 #if !defined(SMJ_TALL) && !defined(SMJ_BIG)
   if (s.pipe_len) grid = (unsigned)s.B * (unsigned)((nsteps + s.pipe_len - 1) / s.pipe_len);
 #endif

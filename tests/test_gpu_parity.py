@@ -481,7 +481,7 @@ def test_pollers_finish_the_parked_chunk_and_hand_the_env_back():
         over += o.nefc > 80
     assert over >= 2
     B, res = 1100, {}
-    for name, opts in (("sweep", dict(pipeline=0)), ("pollers", dict(pipeline=5, pollers=8)), ("pollers10", dict(pipeline=10, pollers=3))):
+    for name, opts in (("sweep", dict(pipeline=0)), ("pollers", dict(pipeline=5, pollers=-8)), ("pollers10", dict(pipeline=10, pollers=-3))):
         sim = _sim(B, solver="newton")
         for k, v in opts.items():
             sim.set_option(k, v)
