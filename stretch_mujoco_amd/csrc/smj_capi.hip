@@ -487,7 +487,9 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
   const int chunk = (c->chunk > 0 && !st.debug && !st.prof && c->num_envs > 1024) ? c->chunk : nsteps;
   // Pipelined chunks (standard variant, batches that need more than one round of workgroups): see DevState::pipe_len
   hipStream_t sm = (hipStream_t)stream;
-  const bool pipe = c->variant == 0 && c->pipeline > 0 && chunk == nsteps && nsteps > c->pipeline && !st.debug && !st.prof && c->num_envs > 1024;
+  // measured: standard +19 % at chunks of 5, tall (2 envs per CU) +7 % at 10, big (1 env per CU, 16 rounds of workgroups) nothing
+  const int pipe_len = c->variant == 1 ? 2 * c->pipeline : c->pipeline;
+  const bool pipe = c->variant != 2 && c->pipeline > 0 && chunk == nsteps && nsteps > pipe_len && !st.debug && !st.prof && c->num_envs > 1024;
   st.progress = st.done_steps = st.sched = st.hot = nullptr;
   if (esc || pipe) {
     st.progress = c->progress;
@@ -503,8 +505,8 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
     const unsigned fl = done + k >= nsteps ? read_flags : 0u;
     st.redo_worker = 0;
     st.order = nullptr;
-    st.pipe_len = pipe ? c->pipeline : 0;
-    st.pipe_total = c->num_envs * (pipe ? (k + c->pipeline - 1) / c->pipeline : 1);
+    st.pipe_len = pipe ? pipe_len : 0;
+    st.pipe_total = c->num_envs * (pipe ? (k + pipe_len - 1) / pipe_len : 1);
     if (esc || pipe) HIPCHK(c, hipMemsetAsync(c->progress, 0, sizeof(int) * (2 * (size_t)c->num_envs + SMJ_SCHED_WORDS), sm));
     if (esc) {
       if ((size_t)st.pipe_total > c->redo_cap) {   // every workgroup of the standard launch can park its env once

@@ -21,6 +21,48 @@
 #define SMJ_ASTORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define SMJ_WAIT_TICKS 300000000LL   // 3 s of the 100 MHz constant clock: the bound of every wait loop below
 
+// Pipelined chunks (DevState::pipe_len): what workgroup blockIdx.x of a normal launch runs.  go = false: nothing (the env
+// is on the escalation list and nobody finishes its chunk now, or the wait ran out).
+struct SmjTicket { int env, steps, chunk; unsigned read_flags; bool go; };
+static __device__ __forceinline__ SmjTicket smj_take_ticket(const DevState& S, int nsteps, unsigned read_flags) {
+  SmjTicket t;
+  int slot = blockIdx.x;
+  t.chunk = 0; t.steps = nsteps; t.read_flags = read_flags; t.go = true; t.env = 0;
+  if (S.pipe_len) {   // workgroup = (chunk, slot), chunk-major
+    t.chunk = (int)blockIdx.x / S.B;
+    slot = (int)blockIdx.x - t.chunk * S.B;
+    const int base = t.chunk * S.pipe_len;
+    t.steps = nsteps - base < S.pipe_len ? nsteps - base : S.pipe_len;
+    if (base + t.steps < nsteps) t.read_flags = 0;   // readouts go with the env's last chunk
+  }
+  if (slot >= S.B) { t.go = false; return t; }
+  t.env = S.order ? S.order[slot] : slot;
+  if (t.chunk > 0) {
+    // wait for the env's previous chunk (normally long finished: it was dispatched B workgroups earlier).  Bounded: a wait of
+    // seconds means the in-order dispatch this scheme leans on did not hold -- flag the env instead of hanging the device.
+    const long long t0 = wall_clock64();
+    for (;;) {
+      const int seen = SMJ_ALOAD(&S.progress[t.env]);
+      if (seen >= t.chunk) { t.go = seen < SMJ_PIPE_SWEPT; break; }
+      const bool late = wall_clock64() - t0 > SMJ_WAIT_TICKS;
+      if (seen < 0 && (late || SMJ_ALOAD(&S.sched[SMJ_SCHED_POLLERS]) == 0)) {
+        // parked and nobody to finish the chunk now: the sweep after this kernel takes the env from where it stands
+        if (threadIdx.x == 0) atomicCAS(&S.progress[t.env], seen, (int)SMJ_PIPE_ABANDONED);
+        t.go = false;
+        break;
+      }
+      if (late) {
+        if (threadIdx.x == 0) atomicOr(&reinterpret_cast<int*>(S.stage + (size_t)t.env * S.lay.stride)[S.lay.info + SMJ_INFO_FLAGS], SMJ_FLAG_PIPE_TIMEOUT);
+        t.go = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(32);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  return t;
+}
+
 #ifndef SMJ_KERNEL_ATTR
 #define SMJ_KERNEL_ATTR
 #endif
@@ -43,8 +85,10 @@ __global__ __launch_bounds__(64) SMJ_KERNEL_ATTR void SMJ_STEP_KERNEL(const DevM
     int env, steps = nsteps, chunk = 0;
     unsigned fl = read_flags;
     if (mode == 0) {
-      if (i != (int)blockIdx.x || i >= S.B) return;
-      env = S.order ? S.order[i] : i;
+      if (i != (int)blockIdx.x) return;
+      const SmjTicket t = smj_take_ticket(S, nsteps, read_flags);
+      if (!t.go) return;
+      env = t.env; steps = t.steps; chunk = t.chunk; fl = t.read_flags;
     } else if (mode == 1) {
       const int cnt = SMJ_ALOAD(&S.sched[SMJ_SCHED_COUNT]);
       if (i == 0 && threadIdx.x == 0) *S.hot = cnt > 0 ? (int)SMJ_HOT_LAUNCHES : *S.hot > 0 ? *S.hot - 1 : 0;
@@ -88,56 +132,28 @@ __global__ __launch_bounds__(64) SMJ_KERNEL_ATTR void SMJ_STEP_KERNEL(const DevM
       if (end < nsteps) fl = 0;
     }
     StepKernel k(M, S, smem, env);
+    if (mode == 0) k.step_base = chunk * S.pipe_len;
     k.run(steps, fl);
     __syncthreads();
+    if (mode == 0 && S.pipe_len) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (threadIdx.x == 0) SMJ_ASTORE(&S.progress[env], chunk + 1);
+    }
     if (mode == 2) {   // hand the env back to the standard kernel's next chunk (unless that one has given the env up)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       if (threadIdx.x == 0) atomicCAS(&S.progress[env], -(chunk + 1), chunk + 1);
     }
   }
 #else
-  int slot = blockIdx.x, chunk = 0, steps = nsteps;
-  if (S.pipe_len) {   // pipelined chunks: workgroup = (chunk, slot), chunk-major (DevState::pipe_len)
-    chunk = (int)blockIdx.x / S.B;
-    slot = (int)blockIdx.x - chunk * S.B;
-    const int base = chunk * S.pipe_len;
-    steps = nsteps - base < S.pipe_len ? nsteps - base : S.pipe_len;
-    if (base + steps < nsteps) read_flags = 0;   // readouts go with the env's last chunk
-  }
-  if (slot >= S.B) return;
-  const int env = S.order ? S.order[slot] : slot;
-  bool go = true;
-  if (chunk > 0) {
-    // wait for the env's previous chunk (normally long finished: it was dispatched B workgroups earlier).  Bounded: a wait of
-    // seconds means the in-order dispatch this scheme leans on did not hold -- flag the env instead of hanging the device.
-    const long long t0 = wall_clock64();
-    for (;;) {
-      const int seen = SMJ_ALOAD(&S.progress[env]);
-      if (seen >= chunk) { go = seen < SMJ_PIPE_SWEPT; break; }
-      const bool late = wall_clock64() - t0 > SMJ_WAIT_TICKS;
-      if (seen < 0 && (late || SMJ_ALOAD(&S.sched[SMJ_SCHED_POLLERS]) == 0)) {
-        // parked and nobody to finish the chunk now: the sweep after this kernel takes the env from where it stands
-        if (threadIdx.x == 0) atomicCAS(&S.progress[env], seen, (int)SMJ_PIPE_ABANDONED);
-        go = false;
-        break;
-      }
-      if (late) {
-        if (threadIdx.x == 0) atomicOr(&reinterpret_cast<int*>(S.stage + (size_t)env * S.lay.stride)[S.lay.info + SMJ_INFO_FLAGS], SMJ_FLAG_PIPE_TIMEOUT);
-        go = false;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(32);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  if (go) {
-    StepKernel k(M, S, smem, env);
-    k.step_base = chunk * S.pipe_len;
-    k.pipe_chunk = chunk;
-    k.run(steps, read_flags);
+  const SmjTicket t = smj_take_ticket(S, nsteps, read_flags);
+  if (t.go) {
+    StepKernel k(M, S, smem, t.env);
+    k.step_base = t.chunk * S.pipe_len;
+    k.pipe_chunk = t.chunk;
+    k.run(t.steps, t.read_flags);
     if (S.pipe_len && !k.parked) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      if (threadIdx.x == 0) SMJ_ASTORE(&S.progress[env], chunk + 1);
+      if (threadIdx.x == 0) SMJ_ASTORE(&S.progress[t.env], t.chunk + 1);
     }
   }
   if (S.sched && threadIdx.x == 0) atomicAdd(&S.sched[SMJ_SCHED_EXITED], 1);
@@ -153,9 +169,7 @@ int SMJ_LAUNCH_STEP(const DevModel& m, const DevState& s, int nsteps, unsigned r
     lds_allowed = lds;
   }
   unsigned grid = s.redo_worker == 2 ? (unsigned)(s.pollers < 0 ? -s.pollers : s.pollers) : s.redo_worker ? (s.B < 128 ? s.B : 128) : s.B;
-#if !defined(SMJ_TALL) && !defined(SMJ_BIG)
-  if (s.pipe_len) grid = (unsigned)s.B * (unsigned)((nsteps + s.pipe_len - 1) / s.pipe_len);
-#endif
+  if (s.pipe_len && !s.redo_worker) grid = (unsigned)s.B * (unsigned)((nsteps + s.pipe_len - 1) / s.pipe_len);
   hipLaunchKernelGGL(SMJ_STEP_KERNEL, dim3(grid), dim3(64), lds, stream, m, s, nsteps, read_flags);
   return 0;
 }

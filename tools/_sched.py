@@ -3,8 +3,10 @@ import sys, time, torch
 sys.path.insert(0, ".")
 from stretch_mujoco_amd import StretchBatchSimulator
 B = 4096
-opts = {a.split("=")[0]: float(a.split("=")[1]) for a in sys.argv[1:]}
-sim = StretchBatchSimulator(num_envs=B, device='cuda:0'); sim.start(home=False)
+opts = {a.split("=")[0]: a.split("=")[1] for a in sys.argv[1:]}
+scene = opts.pop("scene", None)
+opts = {k: float(v) for k, v in opts.items()}
+sim = StretchBatchSimulator(num_envs=B, device='cuda:0', **({"scene": scene} if scene else {})); sim.start(home=False)
 for k, v in opts.items(): sim.set_option(k, v)
 dev = sim.device
 lo = torch.tensor(sim.model["actuator_ctrlrange"][:, 0], dtype=torch.float32, device=dev).unsqueeze(1); hi = torch.tensor(sim.model["actuator_ctrlrange"][:, 1], dtype=torch.float32, device=dev).unsqueeze(1)
@@ -18,4 +20,4 @@ torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(10): sim.ctrl.copy_(lo + (hi - lo) * torch.rand(10, B, generator=g, device=dev)); sim.step(50)
 torch.cuda.synchronize(); dt = time.perf_counter() - t
 import os
-print(os.environ.get("SMJ_LIB_PATH", "default")[-24:], opts, 'settled %.2f M, random %.2f M env-steps/s' % (settled, B * 500 / dt / 1e6), 'flagged', float((sim.info[3] != 0).float().mean()), flush=True)
+print(os.environ.get("SMJ_LIB_PATH", "default")[-24:], scene, opts, 'settled %.2f M, random %.2f M env-steps/s' % (settled, B * 500 / dt / 1e6), 'flagged', float((sim.info[3] != 0).float().mean()), flush=True)
