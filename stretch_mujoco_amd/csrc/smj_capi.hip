@@ -475,7 +475,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
     DevModel& mb = c->model_esc;
     const DevModel& ms = c->model;
     mb.iterations = ms.iterations; mb.warmstart = ms.warmstart; mb.pgs_fixed_iter = ms.pgs_fixed_iter; mb.max_con_pair = ms.max_con_pair;
-    mb.solver = ms.solver; mb.ls_iterations = ms.ls_iterations; mb.convex_pairs = ms.convex_pairs; mb.multiccd = ms.multiccd;
+    mb.solver = ms.solver; mb.ls_iterations = ms.ls_iterations; mb.convex_pairs = ms.convex_pairs; mb.multiccd = ms.multiccd; mb.multi_serial = ms.multi_serial;
     mb.ls_tolerance = ms.ls_tolerance; mb.tolerance = ms.tolerance;
   }
   smj_launch_stage(in, c->stage, Y.stride, c->num_envs, st.ld, false, (hipStream_t)stream);
@@ -545,6 +545,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
     if (!lrc)
       lrc = c->variant == 2   ? smj_launch_step_big(c->model, st, k, fl, sm)
             : c->variant == 1 ? smj_launch_step_tall(c->model, st, k, fl, sm)
+            : st.prof         ? smj_launch_step_prof(c->model, st, k, fl, sm)
                               : smj_launch_step(c->model, st, k, fl, sm);
     if (poll) HIPCHK(c, hipStreamWaitEvent(sm, c->ev_join, 0));
     if (!lrc && esc) {
@@ -626,6 +627,7 @@ int smj_set_option(smj_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "escalate")) c->escalate = (int)v;
   else if (!strcmp(name, "balance")) c->balance = (int)v;
   else if (!strcmp(name, "chunk")) c->chunk = (int)v;
+  else if (!strcmp(name, "multi_serial")) m.multi_serial = (int)v;
   else if (!strcmp(name, "pipeline")) c->pipeline = (int)v;
   else if (!strcmp(name, "pollers")) {   // n > 0: n pollers when a recent launch escalated; -n: n pollers with every launch; 0: none
     c->pollers_always = v < 0;

@@ -22,6 +22,7 @@ struct StagePlan {
 
 // the capacity variants of the step kernel (smj_model.h); return 0 or a hipError_t
 int smj_launch_step(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);
+int smj_launch_step_prof(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);   // standard + cycle counters
 int smj_launch_step_tall(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);
 int smj_launch_step_big(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);
 void smj_tall_caps(int* nvp, int* nbp, int* nent, int* nefc, int* ncon, int* debug_floats);

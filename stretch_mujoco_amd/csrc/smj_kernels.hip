@@ -2,7 +2,10 @@
 // workgroup per wavefront; the per-environment working set (body tree, mass-matrix factor, constraint
 // Jacobian, A = J M^-1 J' + R) lives in LDS for the whole launch, model constants stream from L2.
 #include "smj_kernels.h"
-#include "smj_step_tu.h"   // the standard variant of the step kernel (smj_kernels_big.hip compiles the big one)
+// the standard variant of the step kernel, without the per-stage cycle counters: they are runtime-optional but cost the
+// kernel registers it does not have (scratch 144 -> 48 B per lane); smj_kernels_prof.hip compiles the same kernel with them
+#define SMJ_PROFILING 0
+#include "smj_step_tu.h"
 
 // mj_resetData for masked envs: batch-major, lanes = envs (coalesced)
 __global__ __launch_bounds__(256) void smj_reset_kernel(const DevModel M, const DevState S, const uint8_t* mask) {

@@ -62,6 +62,7 @@ struct DevModel {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, neq, npair, nlevel, nfric, nlimit, nplanepair, nldl, nlidar, imu_site,
       ngc, nroot, nkey, ncgeom, nconvpair, njump, maxsubtree;
   int iterations, warmstart, pgs_fixed_iter, max_con_pair, solver /* 0 PGS, 2 Newton */, ls_iterations, convex_pairs;
+  int multi_serial;   // 1: the four multiccd queries of a pair one after the other (convex_multi) instead of side by side (convex_multi4)
   int multiccd;   // stretch.xml:8 <flag multiccd="enable"/>: multi-point contacts for convex pairs (box-box polygon, counter-rotated queries)
   float ls_tolerance;
   float timestep, gravity[3], impratio, tolerance, meaninertia, lidar_cutoff;
@@ -188,7 +189,10 @@ enum { SMJ_BC_MODE = 0, SMJ_BC_X0, SMJ_BC_Y0, SMJ_BC_TH0, SMJ_BC_INC, SMJ_BC_V, 
 enum { SMJ_PROF_KIN = 0, SMJ_PROF_COMCRB, SMJ_PROF_SMOOTH, SMJ_PROF_FACTOR, SMJ_PROF_COLLISION, SMJ_PROF_MAKECON,
        SMJ_PROF_PROJECT, SMJ_PROF_WARM, SMJ_PROF_PGS, SMJ_PROF_POST, SMJ_PROF_INTEGRATE, SMJ_PROF_TOTAL, SMJ_PROF_PGS_SWEEPS,
        SMJ_PROF_SETUP, SMJ_PROF_N_UPDATE, SMJ_PROF_N_GRAD, SMJ_PROF_N_XA, SMJ_PROF_N_HMFMA, SMJ_PROF_N_FACTSOLVE, SMJ_PROF_N_SOLVE,
-       SMJ_PROF_N_PREP, SMJ_PROF_N_LS, SMJ_PROF_N_LSEVALS, SMJ_PROF_SLOTS = 24 };
+       SMJ_PROF_N_PREP, SMJ_PROF_N_LS, SMJ_PROF_N_LSEVALS,
+       // convex collision: cycles of the pose / bounding-sphere / oriented-box / narrowphase parts, and counts per step
+       SMJ_PROF_C_POSE, SMJ_PROF_C_SPHERE, SMJ_PROF_C_OBB, SMJ_PROF_C_NARROW, SMJ_PROF_C_NSPHERE, SMJ_PROF_C_NOBB, SMJ_PROF_C_NHIT,
+       SMJ_PROF_C_NMULTI, SMJ_PROF_SLOTS = 32 };
 enum { SMJ_INFO_NEFC = 0, SMJ_INFO_NCON = 1, SMJ_INFO_NITER = 2, SMJ_INFO_FLAGS = 3 };
 enum { SMJ_FLAG_EFC_OVERFLOW = 1, SMJ_FLAG_CON_OVERFLOW = 2, SMJ_FLAG_BAD_STATE = 4, SMJ_FLAG_PIPE_TIMEOUT = 8 };
 

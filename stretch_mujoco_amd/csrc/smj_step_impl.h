@@ -8,6 +8,9 @@
 // projectConstraint (Y = J L^-1, A = Y D^-1 Y' + R on MFMA) -> PGS (dual, elliptic cones, QCQP blocks) ->
 // implicitfast integrate.
 #pragma once
+#ifndef SMJ_PROFILING
+#define SMJ_PROFILING 1   // per-stage shader-cycle counters (DevState::prof) compiled in; the product build of the standard variant drops them
+#endif
 #include <cstddef>
 #include "smj_model.h"
 #include "smj_wave.h"
@@ -1873,10 +1876,298 @@ struct StepKernel {
     }
   }
 
+  // ---- multiccd, four queries at once.  The four counter-rotated penetration queries of a pair are independent MPR runs on
+  // the same two shapes: run serially they are four times ~30 k cycles of wave-uniform scalar code with the vector lanes idle
+  // (measured: 0.38 hits per env-step under random actions, 5 MPR runs per hit = most of the collision stage).  Here each
+  // 16-lane row of the wave owns one query: the MPR state is per lane (identical within a row), the control flow of
+  // mpr_penetration becomes a small state machine that advances one support point per round, and the hull support scan
+  // evaluates every lane's four register-resident vertices against the four rows' directions at once (four arg-max
+  // reductions per shape and round instead of sixteen dependent ones per query).  Same arithmetic per query as
+  // mpr_penetration / shape_support, same tie-breaks: the contacts are those of the serial code.
+  struct MprLane {
+    MprPt P[4], v4;
+    float dir[3], apos[3], amat[9], bpos[3], bmat[9];
+    int phase, it, ok;
+    float depth, pdir[3], pos[3];
+  };
+  enum { MQ_W1 = 0, MQ_W2, MQ_W3, MQ_R1, MQ_R2, MQ_DONE };
+  // support points of `sh` for every lane's own frame (pos, mat: per lane, equal within a row) and direction
+  SMJ_DEV void shape_support4(const Shape& sh, PL<MprLane>& st, bool second, PL<float[3]>& out) {
+    if (sh.type != GT_MESH) {
+      LANES {
+        MprLane& m = st[lane];
+        const float* mat = second ? m.bmat : m.amat;
+        const float* ps = second ? m.bpos : m.apos;
+        const float dir[3] = {second ? -m.dir[0] : m.dir[0], second ? -m.dir[1] : m.dir[1], second ? -m.dir[2] : m.dir[2]};
+        float dl[3], pl[3] = {0, 0, 0};
+        mulmat3Tvec(dl, mat, dir);
+        if (sh.type == GT_SPHERE) {
+          const float n = sqrtf(dot3(dl, dl));
+          if (n > SMJ_MINVAL) for (int i = 0; i < 3; i++) pl[i] = sh.size[0] * dl[i] / n;
+        } else if (sh.type == GT_BOX) {
+          for (int i = 0; i < 3; i++) pl[i] = dl[i] >= 0 ? sh.size[i] : -sh.size[i];
+        } else {   // cylinder
+          const float n = sqrtf(dl[0] * dl[0] + dl[1] * dl[1]);
+          if (n > SMJ_MINVAL) { pl[0] = sh.size[0] * dl[0] / n; pl[1] = sh.size[0] * dl[1] / n; }
+          pl[2] = dl[2] >= 0 ? sh.size[1] : -sh.size[1];
+        }
+        float o[3];
+        mulmat3vec(o, mat, pl);
+        for (int i = 0; i < 3; i++) out[lane][i] = o[i] + ps[i];
+      }
+      return;
+    }
+    // the four rows' directions in the hull frame, broadcast to the wave
+    PL<float> dlx, dly, dlz;
+    LANES {
+      const MprLane& m = st[lane];
+      const float dir[3] = {second ? -m.dir[0] : m.dir[0], second ? -m.dir[1] : m.dir[1], second ? -m.dir[2] : m.dir[2]};
+      float dl[3];
+      mulmat3Tvec(dl, second ? m.bmat : m.amat, dir);
+      dlx[lane] = dl[0]; dly[lane] = dl[1]; dlz[lane] = dl[2];
+    }
+    float dq[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { dq[q][0] = wave_read(dlx, 16 * q); dq[q][1] = wave_read(dly, 16 * q); dq[q][2] = wave_read(dlz, 16 * q); }
+    PL<float> best[4], bx[4], by[4], bz[4];
+    PL<int> bidx[4];
+    const Vec4* verts = reinterpret_cast<const Vec4*>(sh.verts);
+    const int nvert = sh.nvert;
+    LANES {
+      float bd[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f}, b[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+      int bi[4] = {-1, -1, -1, -1};
+#pragma unroll
+      for (int u = 0; u < 4; u++) {   // register-resident vertices
+        const int id = lane + 64 * u;
+        const float x = sh.vc[lane][3 * u], y = sh.vc[lane][3 * u + 1], z = sh.vc[lane][3 * u + 2];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float d = x * dq[q][0] + y * dq[q][1] + z * dq[q][2];
+          if (id < nvert && d > bd[q]) { bd[q] = d; bi[q] = id; b[q][0] = x; b[q][1] = y; b[q][2] = z; }
+        }
+      }
+      for (int i0 = 256 + lane; i0 < nvert; i0 += 256) {   // larger hulls: the rest from memory
+        Vec4 v[4];
+        int id[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { id[u] = i0 + 64 * u < nvert ? i0 + 64 * u : nvert - 1; v[u] = verts[id[u]]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const float d = v[u].x * dq[q][0] + v[u].y * dq[q][1] + v[u].z * dq[q][2];
+            if (d > bd[q]) { bd[q] = d; bi[q] = id[u]; b[q][0] = v[u].x; b[q][1] = v[u].y; b[q][2] = v[u].z; }
+          }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) { best[q][lane] = bd[q]; bidx[q][lane] = bi[q]; bx[q][lane] = b[q][0]; by[q][lane] = b[q][1]; bz[q][lane] = b[q][2]; }
+    }
+    float plq[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const float mx = wave_max(best[q]);
+      PL<int> ism;
+      LANES { ism[lane] = best[q][lane] == mx && bidx[q][lane] >= 0; }
+      const uint64_t mm = wave_ballot(ism);
+      const int idx = popc64(mm) == 1 ? wave_read(bidx[q], ffs64(mm)) : pick_index(best[q], bidx[q], mx);
+      const int owner = idx & 63;
+      plq[q][0] = wave_read(bx[q], owner); plq[q][1] = wave_read(by[q], owner); plq[q][2] = wave_read(bz[q], owner);
+    }
+    LANES {
+      const MprLane& m = st[lane];
+      const int q = lane >> 4;
+      const float pl[3] = {q == 0 ? plq[0][0] : q == 1 ? plq[1][0] : q == 2 ? plq[2][0] : plq[3][0],
+                           q == 0 ? plq[0][1] : q == 1 ? plq[1][1] : q == 2 ? plq[2][1] : plq[3][1],
+                           q == 0 ? plq[0][2] : q == 1 ? plq[1][2] : q == 2 ? plq[2][2] : plq[3][2]};
+      float o[3];
+      mulmat3vec(o, second ? m.bmat : m.amat, pl);
+      const float* ps = second ? m.bpos : m.apos;
+      for (int i = 0; i < 3; i++) out[lane][i] = o[i] + ps[i];
+    }
+  }
+  // the end of mpr_penetration: depth, direction and position from the final portal (per lane)
+  SMJ_DEV static void mpr_finish(MprLane& m) {
+    m.depth = sqrtf(fmaxf(0.f, origin_tri_dist2(m.P[1].v, m.P[2].v, m.P[3].v, m.pdir)));
+    if (ccd_zero(m.pdir[0]) && ccd_zero(m.pdir[1]) && ccd_zero(m.pdir[2])) { m.pdir[0] = m.dir[0]; m.pdir[1] = m.dir[1]; m.pdir[2] = m.dir[2]; }
+    normalize3(m.pdir);
+    float b[4], vec[3], sum;
+    const MprPt* P = m.P;
+    cross3(vec, P[1].v, P[2].v); b[0] = dot3(vec, P[3].v);
+    cross3(vec, P[3].v, P[2].v); b[1] = dot3(vec, P[0].v);
+    cross3(vec, P[0].v, P[1].v); b[2] = dot3(vec, P[3].v);
+    cross3(vec, P[2].v, P[1].v); b[3] = dot3(vec, P[0].v);
+    sum = b[0] + b[1] + b[2] + b[3];
+    if (ccd_zero(sum) || sum < 0) {
+      b[0] = 0;
+      cross3(vec, P[2].v, P[3].v); b[1] = dot3(vec, m.dir);
+      cross3(vec, P[3].v, P[1].v); b[2] = dot3(vec, m.dir);
+      cross3(vec, P[1].v, P[2].v); b[3] = dot3(vec, m.dir);
+      sum = b[1] + b[2] + b[3];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const float p1 = b[0] * P[0].a[i] + b[1] * P[1].a[i] + b[2] * P[2].a[i] + b[3] * P[3].a[i];
+      const float p2 = b[0] * P[0].b[i] + b[1] * P[1].b[i] + b[2] * P[2].b[i] + b[3] * P[3].b[i];
+      m.pos[i] = 0.5f * (p1 + p2) / sum;
+    }
+  }
+  SMJ_DEV void convex_multi4(const int* rec, const Shape& A, const Shape& Bs, int slotA, int slotB, const float* pos0, const float* dir0,
+                             float margin, float tol) {
+    float fr[9] = {dir0[0], dir0[1], dir0[2], 0, 0, 0, 0, 0, 0};
+    make_frame(fr);
+    const float tolm = 1e-6f;
+    const int maxit = 50;
+    PL<MprLane> st;
+    LANES {
+      MprLane& m = st[lane];
+      const int q = lane >> 4;
+      const float* ax = fr + 3 * (1 + (q >> 1));
+      const float axv[3] = {ax[0], ax[1], ax[2]};
+      const float ang = (q & 1) ? -1e-3f : 1e-3f;
+      float Rp[9], Rn[9], ca[3], cb[3], mA[9], mB[9];
+      axis_angle_mat(Rp, axv, ang); axis_angle_mat(Rn, axv, -ang);
+      for (int k = 0; k < 3; k++) { m.apos[k] = s.u.c.pos[slotA][k]; m.bpos[k] = s.u.c.pos[slotB][k]; ca[k] = s.u.c.ccen[slotA][k]; cb[k] = s.u.c.ccen[slotB][k]; }
+      for (int k = 0; k < 9; k++) { mA[k] = s.u.c.mat[slotA][k]; mB[k] = s.u.c.mat[slotB][k]; }
+      rotate_point(m.apos, pos0, Rp); rotate_point(m.bpos, pos0, Rn); rotate_point(ca, pos0, Rp); rotate_point(cb, pos0, Rn);
+      mulmat3(m.amat, Rp, mA); mulmat3(m.bmat, Rn, mB);
+      // mpr_penetration up to its first support query
+      for (int i = 0; i < 3; i++) { m.P[0].a[i] = ca[i]; m.P[0].b[i] = cb[i]; m.P[0].v[i] = ca[i] - cb[i]; }
+      if (ccd_zero(m.P[0].v[0]) && ccd_zero(m.P[0].v[1]) && ccd_zero(m.P[0].v[2])) m.P[0].v[0] += 10.f * CCD_EPS;
+      for (int i = 0; i < 3; i++) m.dir[i] = -m.P[0].v[i];
+      normalize3(m.dir);
+      m.phase = MQ_W1; m.it = 0; m.ok = 0; m.depth = 0;
+      for (int i = 0; i < 3; i++) { m.pdir[i] = 0; m.pos[i] = 0; }
+    }
+    for (int round = 0; round < 256; round++) {
+      // what each query needs before its next support point (loop heads of mpr_penetration)
+      PL<int> need;
+      LANES {
+        MprLane& m = st[lane];
+        if (m.phase == MQ_W3 && m.it > 100) m.phase = MQ_DONE;
+        if (m.phase == MQ_R1) {
+          portal_dir(m.P, m.dir);
+          const float dot = dot3(m.dir, m.P[1].v);
+          if (ccd_zero(dot) || dot > 0) { m.phase = MQ_R2; m.it = 0; }
+        }
+        if (m.phase == MQ_R2) portal_dir(m.P, m.dir);
+        need[lane] = m.phase != MQ_DONE;
+      }
+      if (wave_ballot(need) == 0) break;
+      PL<float[3]> sa, sb;
+      shape_support4(A, st, false, sa);
+      shape_support4(Bs, st, true, sb);
+      LANES {
+        MprLane& m = st[lane];
+        MprPt np;
+        for (int i = 0; i < 3; i++) { np.a[i] = sa[lane][i]; np.b[i] = sb[lane][i]; np.v[i] = np.a[i] - np.b[i]; }
+        float va[3], vb[3];
+        if (m.phase == MQ_W1) {
+          m.P[1] = np;
+          float dot = dot3(m.P[1].v, m.dir);
+          if (ccd_zero(dot) || dot < 0) m.phase = MQ_DONE;
+          else {
+            cross3(m.dir, m.P[0].v, m.P[1].v);
+            if (ccd_zero(dot3(m.dir, m.dir))) {
+              if (ccd_zero(m.P[1].v[0]) && ccd_zero(m.P[1].v[1]) && ccd_zero(m.P[1].v[2])) { m.depth = 0; m.pdir[0] = m.pdir[1] = m.pdir[2] = 0; }
+              else {
+                m.depth = sqrtf(dot3(m.P[1].v, m.P[1].v));
+                for (int i = 0; i < 3; i++) m.pdir[i] = m.P[1].v[i];
+                normalize3(m.pdir);
+              }
+              for (int i = 0; i < 3; i++) m.pos[i] = 0.5f * (m.P[1].a[i] + m.P[1].b[i]);
+              m.ok = 1; m.phase = MQ_DONE;
+            } else { normalize3(m.dir); m.phase = MQ_W2; }
+          }
+        } else if (m.phase == MQ_W2) {
+          m.P[2] = np;
+          const float dot = dot3(m.P[2].v, m.dir);
+          if (ccd_zero(dot) || dot < 0) m.phase = MQ_DONE;
+          else {
+            for (int i = 0; i < 3; i++) { va[i] = m.P[1].v[i] - m.P[0].v[i]; vb[i] = m.P[2].v[i] - m.P[0].v[i]; }
+            cross3(m.dir, va, vb);
+            normalize3(m.dir);
+            const bool sw = dot3(m.dir, m.P[0].v) > 0;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+              const float v1 = m.P[1].v[i], v2 = m.P[2].v[i], a1 = m.P[1].a[i], a2 = m.P[2].a[i], b1 = m.P[1].b[i], b2 = m.P[2].b[i];
+              m.P[1].v[i] = sw ? v2 : v1; m.P[2].v[i] = sw ? v1 : v2;
+              m.P[1].a[i] = sw ? a2 : a1; m.P[2].a[i] = sw ? a1 : a2;
+              m.P[1].b[i] = sw ? b2 : b1; m.P[2].b[i] = sw ? b1 : b2;
+              m.dir[i] = sw ? -m.dir[i] : m.dir[i];
+            }
+            m.phase = MQ_W3; m.it = 0;
+          }
+        } else if (m.phase == MQ_W3) {
+          m.P[3] = np;
+          float dot = dot3(m.P[3].v, m.dir);
+          if (ccd_zero(dot) || dot < 0) m.phase = MQ_DONE;
+          else {
+            bool cont = false;
+            cross3(va, m.P[1].v, m.P[3].v);
+            dot = dot3(va, m.P[0].v);
+            if (dot < 0 && !ccd_zero(dot)) { const MprPt q = m.P[3]; portal_set<2>(m.P, q, true); cont = true; }
+            if (!cont) {
+              cross3(va, m.P[3].v, m.P[2].v);
+              dot = dot3(va, m.P[0].v);
+              if (dot < 0 && !ccd_zero(dot)) { const MprPt q = m.P[3]; portal_set<1>(m.P, q, true); cont = true; }
+            }
+            if (cont) {
+              for (int i = 0; i < 3; i++) { va[i] = m.P[1].v[i] - m.P[0].v[i]; vb[i] = m.P[2].v[i] - m.P[0].v[i]; }
+              cross3(m.dir, va, vb);
+              normalize3(m.dir);
+              m.it++;
+            } else { m.phase = MQ_R1; m.it = 0; }
+          }
+        } else if (m.phase == MQ_R1) {
+          m.v4 = np;
+          const float dot = dot3(m.v4.v, m.dir);
+          if (!(ccd_zero(dot) || dot > 0) || reach_tolerance(m.P, m.v4, m.dir, tolm) || m.it > maxit) m.phase = MQ_DONE;
+          else { expand_portal(m.P, m.v4); m.it++; }
+        } else if (m.phase == MQ_R2) {
+          m.v4 = np;
+          if (reach_tolerance(m.P, m.v4, m.dir, tolm) || m.it > maxit) { mpr_finish(m); m.ok = 1; m.phase = MQ_DONE; }
+          else { expand_portal(m.P, m.v4); m.it++; }
+        }
+      }
+    }
+    // the results in query order: the manifold's duplicate test is sequential (convex_multi)
+    PL<int> okp;
+    PL<float> dpp, drx, dry, drz, psx, psy, psz;
+    LANES {
+      const MprLane& m = st[lane];
+      okp[lane] = m.ok; dpp[lane] = m.depth; drx[lane] = m.pdir[0]; dry[lane] = m.pdir[1]; drz[lane] = m.pdir[2];
+      psx[lane] = m.pos[0]; psy[lane] = m.pos[1]; psz[lane] = m.pos[2];
+    }
+    LANES { if (lane == 0) for (int k = 0; k < 3; k++) s.u.c.mc[0][k] = pos0[k]; }
+    SYNC();
+    int n = 1;
+#pragma nounroll
+    for (int q = 0; q < 4; q++) {
+      const int l = 16 * q;
+      if (!wave_read(okp, l)) continue;
+      const float dp = wave_read(dpp, l);
+      const float dr[3] = {wave_read(drx, l), wave_read(dry, l), wave_read(drz, l)}, ps[3] = {wave_read(psx, l), wave_read(psy, l), wave_read(psz, l)};
+      if (-dp > margin || dot3(dr, dr) < 0.5f) continue;
+      bool dup = false;
+#pragma nounroll
+      for (int k = 0; k < n; k++) {
+        const float e[3] = {ps[0] - uni(s.u.c.mc[k][0]), ps[1] - uni(s.u.c.mc[k][1]), ps[2] - uni(s.u.c.mc[k][2])};
+        dup = dup || dot3(e, e) < tol * tol;
+      }
+      if (dup) continue;
+      LANES { if (lane == 0) for (int k = 0; k < 3; k++) s.u.c.mc[n][k] = ps[k]; }
+      SYNC();
+      n++;
+      add_contact(rec, -dp, ps, dir0);
+    }
+  }
+
   // non-plane pairs: cache world frames of the participating geoms, sphere + oriented-box broadphase with lane = pair,
   // MPR on the survivors in pair-table order
-  SMJ_DEV void collision_convex() {
+  SMJ_DEV void collision_convex(float* pc, bool prof) {
     if (!M.convex_pairs || M.nconvpair == 0) return;
+    long long tc = prof ? smj_clock() : 0;
+#define CTICK(slot) if (prof) { const long long t1 = smj_clock(); pc[slot] += (float)(t1 - tc); tc = t1; }
     for (int c0 = 0; c0 < M.ncgeom; c0 += 64) {
       LANES {
         const int c = c0 + lane;
@@ -1902,6 +2193,7 @@ struct StepKernel {
       }
     }
     SYNC();
+    CTICK(SMJ_PROF_C_POSE)
     // pass 1: bounding spheres of all pairs (lane = pair), survivors compacted in table order.  The pair words of eight
     // chunks are fetched up front so that their load latency is paid once per group, not once per chunk.
     int nsurv = 0;
@@ -1944,6 +2236,8 @@ struct StepKernel {
     }
     if (nsurv > 1024) { nsurv = 1024; flags |= SMJ_FLAG_CON_OVERFLOW; }   // pairs beyond the survivor list are lost: flagged
     SYNC();
+    CTICK(SMJ_PROF_C_SPHERE)
+    if (prof) pc[SMJ_PROF_C_NSPHERE] += (float)nsurv;
     // pass 2: oriented boxes on the survivors, then MPR in table order
     for (int base = 0; base < nsurv; base += 64) {
       PL<int> hit;
@@ -1971,6 +2265,8 @@ struct StepKernel {
         tt[lane] = t;
       }
       uint64_t mask = wave_ballot(hit);
+      CTICK(SMJ_PROF_C_OBB)
+      if (prof) pc[SMJ_PROF_C_NOBB] += (float)popc64(mask);
       while (mask) {
         const int l = ffs64(mask);
         mask &= mask - 1;
@@ -2004,13 +2300,19 @@ struct StepKernel {
         if (!mpr_penetration(A, Bs, c0, c1, depth, dir, pos)) continue;
         if (-depth > margin || dot3(dir, dir) < 0.5f) continue;
         add_contact(r, -depth, pos, dir);
+        if (prof) pc[SMJ_PROF_C_NHIT] += 1.f;
 #ifndef SMJ_NO_MULTI
-        if (M.multiccd && A.type != GT_SPHERE && Bs.type != GT_SPHERE)
-          convex_multi(r, A, Bs, uni(r[SMJ_CP_S1]), uni(r[SMJ_CP_S2]), pos, dir, margin, 1e-3f * asf(uni(r[SMJ_CP_RBMIN])));
+        if (prof && M.multiccd && A.type != GT_SPHERE && Bs.type != GT_SPHERE) pc[SMJ_PROF_C_NMULTI] += 1.f;
+        if (M.multiccd && A.type != GT_SPHERE && Bs.type != GT_SPHERE) {
+          if (M.multi_serial) convex_multi(r, A, Bs, uni(r[SMJ_CP_S1]), uni(r[SMJ_CP_S2]), pos, dir, margin, 1e-3f * asf(uni(r[SMJ_CP_RBMIN])));
+          else convex_multi4(r, A, Bs, uni(r[SMJ_CP_S1]), uni(r[SMJ_CP_S2]), pos, dir, margin, 1e-3f * asf(uni(r[SMJ_CP_RBMIN])));
+        }
 #endif
       }
+      CTICK(SMJ_PROF_C_NARROW)
     }
     SYNC();
+#undef CTICK
   }
 
   // ------------------------------------------------------------------ B.4 constraint rows
@@ -3458,7 +3760,7 @@ struct StepKernel {
     flags = 0; nefc = NEFC; ncon = 0; niter = 0;   // nefc = NEFC: the first make_constraint clears every row
     float pc[SMJ_PROF_SLOTS];
     for (int k = 0; k < SMJ_PROF_SLOTS; k++) pc[k] = 0.f;
-    const bool prof = S.prof != nullptr;
+    const bool prof = SMJ_PROFILING && S.prof != nullptr;
     const long long tlaunch = S.cost ? smj_clock() : 0;
     long long t0 = prof ? smj_clock() : 0, tstart = t0;
 #define TICK(slot) if (prof) { const long long t1 = smj_clock(); pc[slot] += (float)(t1 - t0); t0 = t1; }
@@ -3478,7 +3780,7 @@ struct StepKernel {
       if (M.solver != 2) factor();   // the sparse L'DL of M is only needed by the PGS path (Y = J L^-1)
       TICK(SMJ_PROF_FACTOR)
       collision();
-      collision_convex();
+      collision_convex(pc, prof);
       if (last) dump_contacts();
       TICK(SMJ_PROF_COLLISION)
       make_constraint();

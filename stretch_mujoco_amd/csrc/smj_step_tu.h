@@ -11,6 +11,9 @@
 #elif defined(SMJ_TALL)
 #define SMJ_STEP_KERNEL smj_step_kernel_tall
 #define SMJ_LAUNCH_STEP smj_launch_step_tall
+#elif defined(SMJ_PROF_TU)
+#define SMJ_STEP_KERNEL smj_step_kernel_prof
+#define SMJ_LAUNCH_STEP smj_launch_step_prof
 #else
 #define SMJ_STEP_KERNEL smj_step_kernel
 #define SMJ_LAUNCH_STEP smj_launch_step

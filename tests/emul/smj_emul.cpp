@@ -91,6 +91,7 @@ int emul_set_option(emul_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "solver")) m.solver = (int)v;
   else if (!strcmp(name, "convex_pairs")) m.convex_pairs = (int)v;
   else if (!strcmp(name, "multiccd")) m.multiccd = (int)v;
+  else if (!strcmp(name, "multi_serial")) m.multi_serial = (int)v;
   else return -1;
   return 0;
 }

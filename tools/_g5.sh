@@ -1,5 +1,2 @@
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-{
-for sc in stretch_kitchen_standin stretch_scene stretch_kitchen4; do for o in "pipeline=0" "pipeline=5" "pipeline=10"; do timeout 600 python tools/_sched.py scene=$sc $o; done; done
-timeout 300 python tools/_sched.py
-} > gpurun_out/sched.log 2>&1; grep -v amdgpu.ids gpurun_out/sched.log | tail -60
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log

@@ -19,5 +19,6 @@ for _ in range(4): sim.ctrl.copy_(lo + (hi - lo) * torch.rand(10, B, generator=g
 torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(10): sim.ctrl.copy_(lo + (hi - lo) * torch.rand(10, B, generator=g, device=dev)); sim.step(50)
 torch.cuda.synchronize(); dt = time.perf_counter() - t
-import os
-print(os.environ.get("SMJ_LIB_PATH", "default")[-24:], scene, opts, 'settled %.2f M, random %.2f M env-steps/s' % (settled, B * 500 / dt / 1e6), 'flagged', float((sim.info[3] != 0).float().mean()), flush=True)
+import os, hashlib
+h = hashlib.md5(torch.cat([sim.qpos.flatten(), sim.qvel.flatten()]).cpu().numpy().tobytes()).hexdigest()[:10]
+print(h, os.environ.get("SMJ_LIB_PATH", "default")[-24:], scene, opts, 'settled %.2f M, random %.2f M env-steps/s' % (settled, B * 500 / dt / 1e6), 'flagged', float((sim.info[3] != 0).float().mean()), flush=True)
