@@ -360,22 +360,23 @@ struct StepKernel {
     float* row = stage_row();
     int* rowi = reinterpret_cast<int*>(row);
     LANES {
-      for (int k = lane; k < M.nq; k += 64) row[S.lay.qpos + k] = s.qpos[k];
-      if (lane < M.nv) { row[S.lay.qvel + lane] = s.qvel[lane]; row[S.lay.warm + lane] = s.warm[lane]; }
-      if (lane < M.nu) row[S.lay.ctrl + lane] = s.ctrl[lane];
-      if (lane < SMJ_BC_ROWS) row[S.lay.bctl + lane] = s.bctl[lane];
+      for (int k = lane; k < M.nq; k += 64) st_coh(&row[S.lay.qpos + k], s.qpos[k]);
+      if (lane < M.nv) { st_coh(&row[S.lay.qvel + lane], s.qvel[lane]); st_coh(&row[S.lay.warm + lane], s.warm[lane]); }
+      if (lane < M.nu) st_coh(&row[S.lay.ctrl + lane], s.ctrl[lane]);
+      if (lane < SMJ_BC_ROWS) st_coh(&row[S.lay.bctl + lane], s.bctl[lane]);
       if (lane == 0) {
-        rowi[S.lay.nstep] += st;
-        S.done_steps[env] += st;
-        // parked state first, then the list entry (a poller that takes the entry swaps exactly this value back)
-        __hip_atomic_store(&S.progress[env], -(pipe_chunk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st_coh(&rowi[S.lay.nstep], ld_coh(&rowi[S.lay.nstep]) + st);
+        st_coh(&S.done_steps[env], ld_coh(&S.done_steps[env]) + st);
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    coh_release();
     LANES {
       if (lane == 0) {
+        // parked state first, then the list entry (a poller that takes the entry swaps exactly this value back)
+        st_coh(&S.progress[env], -(pipe_chunk + 1));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int at = atomicAdd(&S.sched[SMJ_SCHED_COUNT], 1);
-        __hip_atomic_store(&S.redo[at], env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st_coh(&S.redo[at], env);
       }
     }
 #endif
@@ -386,10 +387,10 @@ struct StepKernel {
     if (S.stage) {
       const float* st = stage_row();
       LANES {
-        for (int k = lane; k < M.nq; k += 64) s.qpos[k] = st[S.lay.qpos + k];
-        if (lane < M.nv) { s.qvel[lane] = st[S.lay.qvel + lane]; s.warm[lane] = st[S.lay.warm + lane]; }
-        if (lane < M.nu) s.ctrl[lane] = st[S.lay.ctrl + lane];
-        if (lane < SMJ_BC_ROWS) s.bctl[lane] = st[S.lay.bctl + lane];
+        for (int k = lane; k < M.nq; k += 64) s.qpos[k] = ld_coh(&st[S.lay.qpos + k]);
+        if (lane < M.nv) { s.qvel[lane] = ld_coh(&st[S.lay.qvel + lane]); s.warm[lane] = ld_coh(&st[S.lay.warm + lane]); }
+        if (lane < M.nu) s.ctrl[lane] = ld_coh(&st[S.lay.ctrl + lane]);
+        if (lane < SMJ_BC_ROWS) s.bctl[lane] = ld_coh(&st[S.lay.bctl + lane]);
       }
     } else {
       LANES {
@@ -412,15 +413,16 @@ struct StepKernel {
       float* st = stage_row();
       int* sti = reinterpret_cast<int*>(st);
       LANES {
-        for (int k = lane; k < M.nq; k += 64) st[S.lay.qpos + k] = s.qpos[k];
-        if (lane < M.nv) { st[S.lay.qvel + lane] = s.qvel[lane]; st[S.lay.warm + lane] = s.warm[lane]; }
-        if (lane < M.nu) { st[S.lay.ctrl + lane] = s.ctrl[lane]; st[S.lay.actlen + lane] = s.act_len[lane]; st[S.lay.actvel + lane] = s.act_vel[lane]; }
-        if (lane < SMJ_BC_ROWS) st[S.lay.bctl + lane] = s.bctl[lane];
+        // the state words go out device-coherent (st_coh): the env's next chunk may run on another XCD (DevState::pipe_len)
+        for (int k = lane; k < M.nq; k += 64) st_coh(&st[S.lay.qpos + k], s.qpos[k]);
+        if (lane < M.nv) { st_coh(&st[S.lay.qvel + lane], s.qvel[lane]); st_coh(&st[S.lay.warm + lane], s.warm[lane]); }
+        if (lane < M.nu) { st_coh(&st[S.lay.ctrl + lane], s.ctrl[lane]); st[S.lay.actlen + lane] = s.act_len[lane]; st[S.lay.actvel + lane] = s.act_vel[lane]; }
+        if (lane < SMJ_BC_ROWS) st_coh(&st[S.lay.bctl + lane], s.bctl[lane]);
         if (lane == 0) {
-          sti[S.lay.nstep] += nsteps;
-          if (S.done_steps) S.done_steps[env] += nsteps;
+          st_coh(&sti[S.lay.nstep], ld_coh(&sti[S.lay.nstep]) + nsteps);
+          if (S.done_steps) st_coh(&S.done_steps[env], ld_coh(&S.done_steps[env]) + nsteps);
           sti[S.lay.info + SMJ_INFO_NEFC] = nefc; sti[S.lay.info + SMJ_INFO_NCON] = ncon;
-          sti[S.lay.info + SMJ_INFO_NITER] = niter; sti[S.lay.info + SMJ_INFO_FLAGS] |= flags;
+          sti[S.lay.info + SMJ_INFO_NITER] = niter; st_coh(&sti[S.lay.info + SMJ_INFO_FLAGS], ld_coh(&sti[S.lay.info + SMJ_INFO_FLAGS]) | flags);
           st[S.lay.base] = bx; st[S.lay.base + 1] = by; st[S.lay.base + 2] = bth;
         }
       }
@@ -3787,7 +3789,7 @@ struct StepKernel {
       TICK(SMJ_PROF_MAKECON)
       if (S.redo && !S.redo_worker && M.solver == 2 && (flags & (SMJ_FLAG_EFC_OVERFLOW | SMJ_FLAG_CON_OVERFLOW))) {
         escalate(st);
-        if (S.cost) { const int cst = (int)((smj_clock() - tlaunch) >> 6); LANES { if (lane == 0) S.cost[env] = step_base ? S.cost[env] + cst : cst; } }
+        if (S.cost) { const int cst = (int)((smj_clock() - tlaunch) >> 6); LANES { if (lane == 0) st_coh(&S.cost[env], step_base ? ld_coh(&S.cost[env]) + cst : cst); } }
         return;
       }
       if (M.solver == 2) solve_newton(last, pc, t0, prof);
@@ -3802,7 +3804,7 @@ struct StepKernel {
     store_state(nsteps);
     if (S.cost) {   // shader time of this env's launch (units of 64 clocks): the key of the next launch's order (DevState::order)
       const int cst = (int)((smj_clock() - tlaunch) >> 6);
-      LANES { if (lane == 0) S.cost[env] = (S.redo_worker || step_base) ? S.cost[env] + cst : cst; }
+      LANES { if (lane == 0) st_coh(&S.cost[env], (S.redo_worker || step_base) ? ld_coh(&S.cost[env]) + cst : cst); }
     }
     if (prof) {
       pc[SMJ_PROF_TOTAL] = (float)(smj_clock() - tstart);

@@ -61,7 +61,7 @@ static __device__ __forceinline__ SmjTicket smj_take_ticket(const DevState& S, i
       }
       __builtin_amdgcn_s_sleep(32);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    coh_acquire();
   }
   return t;
 }
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64) SMJ_KERNEL_ATTR void SMJ_STEP_KERNEL(const DevM
       int old = 0;
       if (threadIdx.x == 0) old = atomicExch(&S.progress[env], (int)SMJ_PIPE_SWEPT);   // an env can be on the list more than once
       old = __builtin_amdgcn_readfirstlane(old);
-      steps = nsteps - S.done_steps[env];
+      steps = nsteps - ld_coh(&S.done_steps[env]);
       if (old == SMJ_PIPE_SWEPT || steps <= 0) continue;
     } else {
       // poller: claim the next published entry; leave when the standard kernel is through and the list is drained
@@ -127,8 +127,8 @@ __global__ __launch_bounds__(64) SMJ_KERNEL_ATTR void SMJ_STEP_KERNEL(const DevM
           if (threadIdx.x == 0) atomicSub(&S.sched[SMJ_SCHED_POLLERS], 1);
           return;
         }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      const int done = S.done_steps[env];
+      coh_acquire();
+      const int done = ld_coh(&S.done_steps[env]);
       chunk = done / S.pipe_len;
       const int end = (chunk + 1) * S.pipe_len < nsteps ? (chunk + 1) * S.pipe_len : nsteps;
       steps = end - done;
@@ -139,11 +139,11 @@ __global__ __launch_bounds__(64) SMJ_KERNEL_ATTR void SMJ_STEP_KERNEL(const DevM
     k.run(steps, fl);
     __syncthreads();
     if (mode == 0 && S.pipe_len) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      coh_release();
       if (threadIdx.x == 0) SMJ_ASTORE(&S.progress[env], chunk + 1);
     }
     if (mode == 2) {   // hand the env back to the standard kernel's next chunk (unless that one has given the env up)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      coh_release();
       if (threadIdx.x == 0) atomicCAS(&S.progress[env], -(chunk + 1), chunk + 1);
     }
   }
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64) SMJ_KERNEL_ATTR void SMJ_STEP_KERNEL(const DevM
     k.pipe_chunk = t.chunk;
     k.run(t.steps, t.read_flags);
     if (S.pipe_len && !k.parked) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      coh_release();
       if (threadIdx.x == 0) SMJ_ASTORE(&S.progress[t.env], t.chunk + 1);
     }
   }

@@ -63,6 +63,10 @@ static inline float wave_bcast16(const PL<float>& x, int lane) { return x.v[(lan
 static inline int ffs64(uint64_t x) { return __builtin_ffsll((long long)x) - 1; }
 static inline long long smj_clock() { return 0; }
 static inline int opaque(int x) { return x; }
+static inline float ld_coh(const float* p) { return *p; }
+static inline int ld_coh(const int* p) { return *p; }
+static inline void st_coh(float* p, float v) { *p = v; }
+static inline void st_coh(int* p, int v) { *p = v; }
 static inline int uni(int x) { return x; }
 static inline float uni(float x) { return x; }
 static inline float fast_rcp(float x) { return 1.0f / x; }
@@ -123,6 +127,17 @@ __device__ __forceinline__ int wave_read(const PL<int>& x, int l) { return __bui
 __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
 __device__ __forceinline__ int ffs64(uint64_t x) { return __ffsll((long long)x) - 1; }
 __device__ __forceinline__ long long smj_clock() { return (long long)__builtin_readcyclecounter(); }
+// Device-coherent accesses (agent scope, relaxed: sc1 loads / write-through stores that do not live in an XCD's L2) for the
+// words one workgroup hands to another inside a launch -- the staged state between the chunks of an env, scheduling words.
+// With them the hand-over needs no L2 write-back / invalidate (an agent-scope release fence writes back EVERY dirty line of
+// the XCD's L2, scratch spills of the other resident waves included: measured 193 MB of HBM writes per launch).
+__device__ __forceinline__ float ld_coh(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_coh(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_coh(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_coh(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// all of this wave's stores have reached the coherent level (then the flag that publishes them may be stored)
+__device__ __forceinline__ void coh_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void coh_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 // hides a value from the optimiser: table loads indexed through it are not loop invariant, so the stage-local constant
 // tables are re-fetched from L2 in every step instead of being hoisted out of the step loop and kept alive (spilled)
 __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
