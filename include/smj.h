@@ -33,7 +33,8 @@ enum smj_slot {
   SMJ_SLOT_LIDAR = 10,    /* [nlidar][B] sensors base_lidar000.. (mujoco_server_sensor_manager.py:77-83)   */
   SMJ_SLOT_INFO = 11,     /* int32 [4][B] nefc, ncon, solver iterations, flags                             */
   SMJ_SLOT_DEBUG = 12,    /* [SMJ_DEBUG_FLOATS][B] optional stage dumps for parity tests (may stay unbound) */
-  SMJ_SLOT_PROF = 13,     /* [32][B] optional per-stage shader-cycle counters and event counts of a launch       */
+  SMJ_SLOT_PROF = 13,     /* [32][B] optional per-stage shader-cycle counters and event counts of a launch (filled by the
+                             standard kernel variant only: binding it selects that variant's profiling build)           */
   SMJ_SLOT_XPOSE = 14,    /* [nbody*12][B] world pose (xpos 3 + xmat 9, row major) of every fused body at the last step:
                              what Renderer.update_scene reads from MjData (mujoco_server_camera_manager.py:135); input of
                              smj_render_depth                                                                            */

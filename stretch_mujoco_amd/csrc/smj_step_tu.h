@@ -69,14 +69,32 @@ static __device__ __forceinline__ SmjTicket smj_take_ticket(const DevState& S, i
 #ifndef SMJ_KERNEL_ATTR
 #define SMJ_KERNEL_ATTR
 #endif
+// The primary kernel of a variant: workgroup = one env (or one chunk of one env), no loop around run() -- a loop at this level
+// keeps the whole step pipeline's live ranges alive across its back edge and costs hundreds of bytes of scratch per lane.
 __global__ __launch_bounds__(64) SMJ_KERNEL_ATTR void SMJ_STEP_KERNEL(const DevModel M, const DevState S, int nsteps, unsigned read_flags) {
   // dynamic LDS: a Newton launch asks for sizeof(Smem), a PGS launch for the extra tail that holds A (smj_lds_bytes)
   extern __shared__ __align__(16) unsigned char smj_lds[];
   Smem& smem = *reinterpret_cast<Smem*>(smj_lds);
-#if defined(SMJ_TALL) || defined(SMJ_BIG)
-  // One call site of run() (the whole step pipeline is inlined into it): a normal launch takes env = order[blockIdx.x], steps =
-  // nsteps; an escalation launch works the list of envs the standard variant parked (DevState::redo) -- as the sweep after
-  // the standard kernel (redo_worker 1) or as a poller beside it (redo_worker 2, DevState::sched).
+  const SmjTicket t = smj_take_ticket(S, nsteps, read_flags);
+  if (t.go) {
+    StepKernel k(M, S, smem, t.env);
+    k.step_base = t.chunk * S.pipe_len;
+    k.pipe_chunk = t.chunk;
+    k.run(t.steps, t.read_flags);
+    if (S.pipe_len && !k.parked) {
+      coh_release();
+      if (threadIdx.x == 0) SMJ_ASTORE(&S.progress[t.env], t.chunk + 1);
+    }
+  }
+  if (S.sched && threadIdx.x == 0) atomicAdd(&S.sched[SMJ_SCHED_EXITED], 1);
+}
+
+#if defined(SMJ_TALL)
+// The escalation worker (tall variant only): works the list of envs the standard variant parked (DevState::redo) -- as the sweep
+// after the standard kernel (redo_worker 1) or as a poller beside it (redo_worker 2, DevState::sched).  One call site of run().
+__global__ __launch_bounds__(64) void smj_step_kernel_tall_worker(const DevModel M, const DevState S, int nsteps, unsigned read_flags) {
+  extern __shared__ __align__(16) unsigned char smj_lds[];
+  Smem& smem = *reinterpret_cast<Smem*>(smj_lds);
   const int mode = S.redo_worker;
   long long t0 = mode == 2 ? wall_clock64() : 0;   // of the last sign of life of the standard kernel
   int exited_seen = -1;
@@ -87,12 +105,7 @@ __global__ __launch_bounds__(64) SMJ_KERNEL_ATTR void SMJ_STEP_KERNEL(const DevM
   for (int i = blockIdx.x;; i += gridDim.x) {
     int env, steps = nsteps, chunk = 0;
     unsigned fl = read_flags;
-    if (mode == 0) {
-      if (i != (int)blockIdx.x) return;
-      const SmjTicket t = smj_take_ticket(S, nsteps, read_flags);
-      if (!t.go) return;
-      env = t.env; steps = t.steps; chunk = t.chunk; fl = t.read_flags;
-    } else if (mode == 1) {
+    if (mode == 1) {
       const int cnt = SMJ_ALOAD(&S.sched[SMJ_SCHED_COUNT]);
       if (i == 0 && threadIdx.x == 0) *S.hot = cnt > 0 ? (int)SMJ_HOT_LAUNCHES : *S.hot > 0 ? *S.hot - 1 : 0;
       if (i >= cnt) return;
@@ -135,44 +148,36 @@ __global__ __launch_bounds__(64) SMJ_KERNEL_ATTR void SMJ_STEP_KERNEL(const DevM
       if (end < nsteps) fl = 0;
     }
     StepKernel k(M, S, smem, env);
-    if (mode == 0) k.step_base = chunk * S.pipe_len;
     k.run(steps, fl);
     __syncthreads();
-    if (mode == 0 && S.pipe_len) {
-      coh_release();
-      if (threadIdx.x == 0) SMJ_ASTORE(&S.progress[env], chunk + 1);
-    }
     if (mode == 2) {   // hand the env back to the standard kernel's next chunk (unless that one has given the env up)
       coh_release();
       if (threadIdx.x == 0) atomicCAS(&S.progress[env], -(chunk + 1), chunk + 1);
     }
   }
-#else
-  const SmjTicket t = smj_take_ticket(S, nsteps, read_flags);
-  if (t.go) {
-    StepKernel k(M, S, smem, t.env);
-    k.step_base = t.chunk * S.pipe_len;
-    k.pipe_chunk = t.chunk;
-    k.run(t.steps, t.read_flags);
-    if (S.pipe_len && !k.parked) {
-      coh_release();
-      if (threadIdx.x == 0) SMJ_ASTORE(&S.progress[t.env], t.chunk + 1);
-    }
-  }
-  if (S.sched && threadIdx.x == 0) atomicAdd(&S.sched[SMJ_SCHED_EXITED], 1);
-#endif
 }
+#endif
 
 int SMJ_LAUNCH_STEP(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream) {
   const size_t lds = smj_lds_bytes(m.solver != 2);
   static size_t lds_allowed = 64 * 1024;
-  if (lds > lds_allowed) {   // beyond the default 64 KB per workgroup: raise the kernel's dynamic-LDS limit once (gfx950: 160 KB per CU)
+  if (lds > lds_allowed) {   // beyond the default 64 KB per workgroup: raise the kernels' dynamic-LDS limit once (gfx950: 160 KB per CU)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(SMJ_STEP_KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#if defined(SMJ_TALL)
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(smj_step_kernel_tall_worker), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#endif
     if (e != hipSuccess) return (int)e;
     lds_allowed = lds;
   }
-  unsigned grid = s.redo_worker == 2 ? (unsigned)(s.pollers < 0 ? -s.pollers : s.pollers) : s.redo_worker ? (s.B < 128 ? s.B : 128) : s.B;
-  if (s.pipe_len && !s.redo_worker) grid = (unsigned)s.B * (unsigned)((nsteps + s.pipe_len - 1) / s.pipe_len);
+#if defined(SMJ_TALL)
+  if (s.redo_worker) {
+    const unsigned wg = s.redo_worker == 2 ? (unsigned)(s.pollers < 0 ? -s.pollers : s.pollers) : (unsigned)(s.B < 128 ? s.B : 128);
+    hipLaunchKernelGGL(smj_step_kernel_tall_worker, dim3(wg), dim3(64), lds, stream, m, s, nsteps, read_flags);
+    return 0;
+  }
+#endif
+  unsigned grid = s.B;
+  if (s.pipe_len) grid = (unsigned)s.B * (unsigned)((nsteps + s.pipe_len - 1) / s.pipe_len);
   hipLaunchKernelGGL(SMJ_STEP_KERNEL, dim3(grid), dim3(64), lds, stream, m, s, nsteps, read_flags);
   return 0;
 }
