@@ -1,4 +1,5 @@
-"""Throughput of the settled and the random-action regime for a set of smj_set_option values: python tools/_sched.py k=v ..."""
+"""Throughput of the settled and the random-action regime (and an md5 of the final state) for a set of smj_set_option values and a scene:
+   python tools/gpu_options_probe.py [scene=stretch_kitchen_standin] [pipeline=0] [pollers=-2] [multi_serial=1] ...  (SMJ_LIB_PATH selects another build)"""
 import sys, time, torch
 sys.path.insert(0, ".")
 from stretch_mujoco_amd import StretchBatchSimulator
