@@ -627,7 +627,6 @@ int smj_set_option(smj_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "escalate")) c->escalate = (int)v;
   else if (!strcmp(name, "balance")) c->balance = (int)v;
   else if (!strcmp(name, "chunk")) c->chunk = (int)v;
-  else if (!strcmp(name, "multi_serial")) m.multi_serial = (int)v;
   else if (!strcmp(name, "pipeline")) c->pipeline = (int)v;
   else if (!strcmp(name, "pollers")) {   // n > 0: n pollers when a recent launch escalated; -n: n pollers with every launch; 0: none
     c->pollers_always = v < 0;

@@ -2296,20 +2296,18 @@ struct StepKernel {
           }
           continue;
         }
-#ifndef SMJ_NO_BOXBOX
         if (A.type == GT_BOX && Bs.type == GT_BOX && M.multiccd) { box_box(r, uni(r[SMJ_CP_S1]), uni(r[SMJ_CP_S2]), margin); continue; }
-#endif
         if (!mpr_penetration(A, Bs, c0, c1, depth, dir, pos)) continue;
         if (-depth > margin || dot3(dir, dir) < 0.5f) continue;
         add_contact(r, -depth, pos, dir);
         if (prof) pc[SMJ_PROF_C_NHIT] += 1.f;
-#ifndef SMJ_NO_MULTI
         if (prof && M.multiccd && A.type != GT_SPHERE && Bs.type != GT_SPHERE) pc[SMJ_PROF_C_NMULTI] += 1.f;
         if (M.multiccd && A.type != GT_SPHERE && Bs.type != GT_SPHERE) {
-          if (M.multi_serial) convex_multi(r, A, Bs, uni(r[SMJ_CP_S1]), uni(r[SMJ_CP_S2]), pos, dir, margin, 1e-3f * asf(uni(r[SMJ_CP_RBMIN])));
-          else convex_multi4(r, A, Bs, uni(r[SMJ_CP_S1]), uni(r[SMJ_CP_S2]), pos, dir, margin, 1e-3f * asf(uni(r[SMJ_CP_RBMIN])));
-        }
+#ifdef SMJ_EMUL   // the serial formulation stays in the lane emulator as the comparator of the four-wide one (tests/test_emul_parity.py)
+          if (M.multi_serial) { convex_multi(r, A, Bs, uni(r[SMJ_CP_S1]), uni(r[SMJ_CP_S2]), pos, dir, margin, 1e-3f * asf(uni(r[SMJ_CP_RBMIN]))); continue; }
 #endif
+          convex_multi4(r, A, Bs, uni(r[SMJ_CP_S1]), uni(r[SMJ_CP_S2]), pos, dir, margin, 1e-3f * asf(uni(r[SMJ_CP_RBMIN])));
+        }
       }
       CTICK(SMJ_PROF_C_NARROW)
     }

@@ -317,3 +317,31 @@ def test_no_read_of_uninitialised_lds(blob_fused):
         else:
             assert np.array_equal(out, ref), hex(poison)
 
+
+
+def test_four_wide_multiccd_equals_the_serial_formulation(blob_fused):
+    """convex_multi4 (the four counter-rotated MPR queries of a pair side by side, one per 16-lane row, hull support against
+    four directions at once) against convex_multi (one query after the other; kept in the emulator build as the comparator):
+    16 envs under random actions for 150 steps, the regime in which fingers, wrist and arm hulls touch -- every state word
+    and every contact / row count identical, and multiccd does matter on this workload (switching it off changes the states)."""
+    from stretch_mujoco_amd import model_blob
+
+    m = model_blob.loads(blob_fused)
+    lo, hi = np.asarray(m["actuator_ctrlrange"])[:, 0], np.asarray(m["actuator_ctrlrange"])[:, 1]
+    B, res = 16, {}
+    for name, serial, multi in (("serial", 1, 1), ("four", 0, 1), ("off", 0, 0)):
+        rng = np.random.default_rng(5)
+        e = Emul(blob_fused, DIMS, num_envs=B, variant="standard")
+        e.set_option("solver", 2); e.set_option("multi_serial", serial); e.set_option("multiccd", multi)
+        e.qpos[:] = np.asarray(m["qpos0"], np.float32)[:, None]
+        extra = 0
+        for _ in range(6):
+            e.ctrl[:] = (lo[:, None] + (hi - lo)[:, None] * rng.random((10, B))).astype(np.float32)
+            for _ in range(25):
+                e.step(1)
+                extra += int((e.info[1] > 5).sum())
+        res[name] = (e.qpos.copy(), e.qvel.copy(), e.info.copy(), extra)
+    assert res["serial"][3] > 50                                      # env-steps with contacts beyond the wheels and the caster
+    for k in range(3):
+        assert np.array_equal(res["serial"][k], res["four"][k])
+    assert not np.array_equal(res["off"][0], res["four"][0])
