@@ -1,11 +1,12 @@
 """Throughput of the settled and the random-action regime (and an md5 of the final state) for a set of smj_set_option values and a scene:
-   python tools/gpu_options_probe.py [scene=stretch_kitchen_standin] [pipeline=0] [pollers=-2] [multi_serial=1] ...  (SMJ_LIB_PATH selects another build)"""
+   python tools/gpu_options_probe.py [scene=stretch_kitchen_standin] [envs=16384] [pipeline=0] [pollers=-2] [multi_serial=1] ...  (SMJ_LIB_PATH selects another build)"""
 import sys, time, torch
 sys.path.insert(0, ".")
 from stretch_mujoco_amd import StretchBatchSimulator
 B = 4096
 opts = {a.split("=")[0]: a.split("=")[1] for a in sys.argv[1:]}
 scene = opts.pop("scene", None)
+B = int(opts.pop("envs", B))
 opts = {k: float(v) for k, v in opts.items()}
 sim = StretchBatchSimulator(num_envs=B, device='cuda:0', **({"scene": scene} if scene else {})); sim.start(home=False)
 for k, v in opts.items(): sim.set_option(k, v)

@@ -146,6 +146,10 @@ def main():
     render_summary(out)
     with open(os.path.join(DST, f"{TAG}_rocprof_summary.md"), "w") as f:
         f.write("\n".join(out) + "\n")
+    sc = os.path.join(ROOT, "gpurun_out", "stage_cycles.txt")
+    if os.path.exists(sc):   # tools/gpu_diag.py: per-stage shader cycles and event counts per env-step (profiling build of the standard kernel)
+        with open(sc) as fi, open(os.path.join(DST, f"{TAG}_stage_cycles.txt"), "w") as fo:
+            fo.write(fi.read())
     for name in ("smj_kernel_stats.csv", "smj_domain_stats.csv"):
         src = os.path.join(SRC, "trace", name)
         if os.path.exists(src):
