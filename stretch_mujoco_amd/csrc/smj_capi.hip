@@ -243,7 +243,7 @@ int smj_create(const void* blob, size_t nbytes, int num_envs, int device, smj_ct
     if (rc) return rc;
     c->has_esc = true;
     void* d = nullptr;
-    c->redo_cap = 8 * (size_t)num_envs;
+    c->redo_cap = 16 * (size_t)num_envs;   // a 50-step call is 10 chunks per env; longer calls re-allocate (smj_step)
     HIPCHK(c, hipMalloc(&d, sizeof(int) * c->redo_cap));
     c->redo = (int*)d;   // freed in smj_destroy (it can be re-allocated by smj_step)
     HIPCHK(c, hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));

@@ -437,9 +437,11 @@ def test_pipelined_chunks_are_bit_identical_to_one_workgroup_per_env():
     steps with chunk lengths that do and do not divide the launch.  pollers = 0: escalated envs are finished by the sweep in
     every case (with pollers an escalated env returns to the standard variant after its chunk -- same physics, other
     rounding; next test)."""
+    from stretch_mujoco_amd.enums import StretchSensors
+
     B, final = 2048, {}
     for pipe in (0, 10, 4, 36):
-        sim = _sim(B, solver="newton")
+        sim = _sim(B, solver="newton", sensors_to_use=StretchSensors.all())   # readouts go with an env's last chunk only
         sim.set_option("pipeline", pipe)
         sim.set_option("pollers", 0)
         g = torch.Generator(device=sim.device).manual_seed(7)
@@ -451,8 +453,10 @@ def test_pipelined_chunks_are_bit_identical_to_one_workgroup_per_env():
             sim.ctrl.copy_(lo + (hi - lo) * torch.rand(10, B, generator=g, device=sim.device))
             sim.step(37)
         torch.cuda.synchronize()
-        got = [t.clone() for t in (sim.qpos, sim.qvel, sim.qacc_warmstart, sim.actuator_length, sim.actuator_velocity, sim.base_pose, sim.info, sim.nstep)]
+        got = [t.clone() for t in (sim.qpos, sim.qvel, sim.qacc_warmstart, sim.actuator_length, sim.actuator_velocity, sim.base_pose, sim.info, sim.nstep,
+                                    sim.gyro, sim.accel, sim.lidar, sim.xpose)]
         assert int(sim.info[3].max()) == 0 and int(sim.nstep.min()) == int(sim.nstep.max()) == 274
+        assert float(sim.lidar.abs().max()) > 0 and float(sim.accel.abs().max()) > 1.0
         if pipe == 0:
             final = got
         else:
