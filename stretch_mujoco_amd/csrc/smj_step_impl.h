@@ -2214,20 +2214,24 @@ struct StepKernel {
           rrv[j][lane] = pair_rr[t];
         }
       }
+      // the eight chunks' tests first (independent: their LDS gathers overlap), then the eight compactions (a chain through nsurv)
+      PL<int> hit[8];
+      LANES {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int ss = ssv[j][lane], s1 = ss & 255, s2 = ss >> 8;
+          const float rr = rrv[j][lane];
+          const float dv[3] = {s.u.c.cen[s2][0] - s.u.c.cen[s1][0], s.u.c.cen[s2][1] - s.u.c.cen[s1][1], s.u.c.cen[s2][2] - s.u.c.cen[s1][2]};
+          hit[j][lane] = rr >= 0.f && dot3(dv, dv) <= rr * rr;
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         const int base = g0 + 64 * j;
         if (base < ncp) {
-          PL<int> hit;
+          const uint64_t mask = wave_ballot(hit[j]);
           LANES {
-            const int ss = ssv[j][lane], s1 = ss & 255, s2 = ss >> 8;
-            const float rr = rrv[j][lane];
-            const float dv[3] = {s.u.c.cen[s2][0] - s.u.c.cen[s1][0], s.u.c.cen[s2][1] - s.u.c.cen[s1][1], s.u.c.cen[s2][2] - s.u.c.cen[s1][2]};
-            hit[lane] = rr >= 0.f && dot3(dv, dv) <= rr * rr;
-          }
-          const uint64_t mask = wave_ballot(hit);
-          LANES {
-            if (hit[lane]) {
+            if (hit[j][lane]) {
               const int at = nsurv + popc64(mask & ((1ull << lane) - 1));
               if (at < 1024) s.u.c.list[at] = (unsigned short)(base + lane);
             }
@@ -2250,17 +2254,25 @@ struct StepKernel {
           t = s.u.c.list[base + lane];
           const int ss = M.k_convpair_ss[t], s1 = ss & 255, s2 = ss >> 8;
           const float dv[3] = {s.u.c.cen[s2][0] - s.u.c.cen[s1][0], s.u.c.cen[s2][1] - s.u.c.cen[s1][1], s.u.c.cen[s2][2] - s.u.c.cen[s1][2]};
+          // the six face axes of the two boxes, straight-line: frames and half extents are fetched once (their LDS reads issue
+          // back to back), no early exit (a chain of dependent LDS gathers per axis cost more than the arithmetic it spared)
+          float Ra[9], Rb[9], ha[3], hb[3], Rm[3][3], ta[3], tb[3];
+#pragma unroll
+          for (int k = 0; k < 9; k++) { Ra[k] = s.u.c.mat[s1][k]; Rb[k] = s.u.c.mat[s2][k]; }
+#pragma unroll
+          for (int k = 0; k < 3; k++) { ha[k] = s.u.c.half[s1][k]; hb[k] = s.u.c.half[s2][k]; }
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            ta[i] = Ra[i] * dv[0] + Ra[3 + i] * dv[1] + Ra[6 + i] * dv[2];
+            tb[i] = Rb[i] * dv[0] + Rb[3 + i] * dv[1] + Rb[6 + i] * dv[2];
+#pragma unroll
+            for (int j = 0; j < 3; j++) Rm[i][j] = fabsf(Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j]);
+          }
           h = 1;
-          for (int sd = 0; sd < 2 && h; sd++) {
-            const int sa = sd ? s2 : s1, sb = sd ? s1 : s2;
-            const float* Ra = s.u.c.mat[sa];
-            const float* Rb = s.u.c.mat[sb];
-            for (int k = 0; k < 3 && h; k++) {
-              const float ax[3] = {Ra[k], Ra[3 + k], Ra[6 + k]};
-              float r = 0;
-              for (int j = 0; j < 3; j++) r += fabsf(ax[0] * Rb[j] + ax[1] * Rb[3 + j] + ax[2] * Rb[6 + j]) * s.u.c.half[sb][j];
-              if (fabsf(dot3(ax, dv)) > s.u.c.half[sa][k] + r) h = 0;
-            }
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            if (fabsf(ta[k]) > ha[k] + (Rm[k][0] * hb[0] + Rm[k][1] * hb[1] + Rm[k][2] * hb[2])) h = 0;   // axis k of box 1
+            if (fabsf(tb[k]) > hb[k] + (Rm[0][k] * ha[0] + Rm[1][k] * ha[1] + Rm[2][k] * ha[2])) h = 0;   // axis k of box 2
           }
         }
         hit[lane] = h;

@@ -16,6 +16,7 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #ifdef SMJ_EMUL
 #define SMJ_DEV
@@ -24,6 +25,9 @@
 template <class T>
 struct PL {
   T v[64];
+#ifdef SMJ_EMUL_POISON   // debug build of the emulator: lane-private values start as this byte pattern (0xFF = NaN / -1), so a
+  PL() { memset(v, SMJ_EMUL_POISON, sizeof v); }   // read of a lane that was never written changes the results
+#endif
   T& operator[](int l) { return v[l]; }
   const T& operator[](int l) const { return v[l]; }
 };

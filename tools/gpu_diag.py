@@ -37,8 +37,8 @@ def stage_parity(nsteps=1):
     print("env-to-env max diff (identical inputs):", ident)
     sim.stop()
 
-def profile(B, random_ctrl, steps=50, solver="pgs"):
-    sim = StretchBatchSimulator(num_envs=B, device="cuda:0", debug=True, solver=solver)
+def profile(B, random_ctrl, steps=50, solver="pgs", scene=None):
+    sim = StretchBatchSimulator(num_envs=B, device="cuda:0", debug=True, solver=solver, **({"scene": scene} if scene else {}))
     sim.start(home=False)
     import os
     if os.environ.get("SMJ_REP"): sim.set_option("pgs_fixed_iter", int(os.environ["SMJ_REP"]))
@@ -66,6 +66,10 @@ def profile(B, random_ctrl, steps=50, solver="pgs"):
     sim.stop()
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:   # python tools/gpu_diag.py <scene>: the cycle table of another scene (a build whose variant has the counters)
+        profile(1024, False, solver="newton", scene=sys.argv[1])
+        profile(1024, True, solver="newton", scene=sys.argv[1])
+        sys.exit(0)
     for solver in ("newton",):
         profile(1024, False, solver=solver)
         profile(1024, True, solver=solver)
