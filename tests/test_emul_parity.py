@@ -345,3 +345,27 @@ def test_four_wide_multiccd_equals_the_serial_formulation(blob_fused):
     for k in range(3):
         assert np.array_equal(res["serial"][k], res["four"][k])
     assert not np.array_equal(res["off"][0], res["four"][0])
+
+
+@pytest.mark.parametrize("solver", [2, 0])
+def test_no_lane_private_value_is_read_before_it_is_written(blob_fused, solver):
+    """On the GPU a lane-private value (PL<T>) is a register: whatever the previous code left there.  The emulator's `poison`
+    build starts every such value as NaN / -1 (tests/emul/Makefile); a rollout that reads one before writing it -- e.g. a wave
+    reduction over lanes that were never set -- would differ from the plain build.  32 envs under random actions, 200 steps."""
+    from stretch_mujoco_amd import model_blob
+
+    m = model_blob.loads(blob_fused)
+    lo, hi = np.asarray(m["actuator_ctrlrange"])[:, 0], np.asarray(m["actuator_ctrlrange"])[:, 1]
+    B, res = 32, {}
+    for variant in ("standard", "poison"):
+        rng = np.random.default_rng(11)
+        e = Emul(blob_fused, DIMS, num_envs=B, variant=variant)
+        e.set_option("solver", solver)
+        e.qpos[:] = np.asarray(m["qpos0"], np.float32)[:, None]
+        for _ in range(8 if solver == 2 else 3):
+            e.ctrl[:] = (lo[:, None] + (hi - lo)[:, None] * rng.random((10, B))).astype(np.float32)
+            e.step(25)
+        res[variant] = (e.qpos.copy(), e.qvel.copy(), e.info.copy(), e.act_len.copy(), e.base.copy())
+    assert np.isfinite(res["poison"][0]).all()
+    for a, b in zip(res["standard"], res["poison"]):
+        assert np.array_equal(a, b)
