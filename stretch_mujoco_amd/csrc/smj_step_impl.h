@@ -29,8 +29,8 @@ struct TreeTmp {  // lives in the A region until A is built
   float cinert[NBP][10], crb[NBP][10], cvel[NBP][6], cfrc[NBP][6], buf[NVP][6], cdof[NVP][6], cdof_dot[NVP][6];
 };
 
+#define NEFP 64   // PGS row capacity (rows = lanes in the PGS sweeps)
 struct Smem {
-  float J[NEFC][JS];    // constraint Jacobian, transformed in place to Y = J L^-1
   float MM[NVP][MS];    // strict upper: M; lower + diag: working copy -> L (unit, strictly lower), D on diag
   float Mdiag[NVP], Dinv[NVP];
   float xpos[NBP][3], xquat[NBP][4], xmat[NBP][9], com[NBP][3];
@@ -44,9 +44,11 @@ struct Smem {
       eb[NEFC], ef[NEFC];
   float cpos[NCON][3], cframe[NCON][9], cdist[NCON], cfric[NCON][5], csolref[NCON][2], csolimp[NCON][5], cmargin[NCON];
   int cdim[NCON], cgeom1[NCON], cgeom2[NCON], cefc[NCON];
-  // Stage-local storage, LAST on purpose: the PGS matrix A = J M^-1 J' + R (NEFP x NEFP floats, see A()) starts here too and
-  // runs past the end of the struct into the extra dynamic LDS that only a PGS launch asks for (smj_lds_bytes).  A Newton
-  // launch stays at sizeof(Smem) <= 40 KB = four resident workgroups per CU.
+  // The Jacobian and the stage-local union come LAST, in this order, on purpose: the PGS path has NEFP = 64 rows, so its matrix
+  // A = J M^-1 J' + R (NEFP x NEFP floats, see A()) starts at J's row 64 and runs on through the union -- in the standard
+  // variant it ends inside the struct, and a PGS launch needs no more LDS than a Newton launch (four workgroups per CU; with A
+  // starting at the union it needed 1.5 KB more and only three fitted).  smj_lds_bytes covers the variants where it does not.
+  float J[NEFC][JS];    // constraint Jacobian, transformed in place to Y = J L^-1
   union {
     TreeTmp t;
     struct {                // collision: world frames of the geoms taking part in convex pairs (tree temporaries are dead)
@@ -76,9 +78,8 @@ struct Smem {
       float rxf[17][NEFC > 64 ? NEFC - 64 : 1];
     } n;
   } u;
-  SMJ_DEV float* A() { return reinterpret_cast<float*>(&u); }
+  SMJ_DEV float* A() { return &J[NEFP][0]; }
 };
-#define NEFP 64   // PGS row capacity (rows = lanes in the PGS sweeps)
 // Row passes of the Newton path: rows 0..63 on lanes 0..63 (rb = 0), then rows 64..NEFC-1 on lanes 0..NEFC-65 (rb = 64), the
 // second pass only for an env that has that many rows (wave-uniform test).
 #define ROWPASS(rb, ne) _Pragma("unroll") for (int rb = 0; rb < NEFC; rb += 64) if (rb == 0 || __builtin_expect((ne) > rb, 0))
@@ -89,7 +90,7 @@ struct Smem {
 #define ROWS_END_RW(rb) if (rb != 0) rx_store(nrx_, rb); }
 #define ROWS_END_RO() }
 static inline size_t smj_lds_bytes(bool pgs) {
-  const size_t a_end = offsetof(Smem, u) + sizeof(float) * NEFP * NEFP;
+  const size_t a_end = offsetof(Smem, J) + sizeof(float) * (NEFP * JS + NEFP * NEFP);
   return (pgs && a_end > sizeof(Smem)) ? a_end : sizeof(Smem);
 }
 

@@ -103,7 +103,7 @@ def main():
     r0 = tr[0]
     out.append(f"\nResources: VGPR {r0['VGPR_Count']} (+AGPR {r0['Accum_VGPR_Count']}), SGPR {r0['SGPR_Count']}, LDS {r0['LDS_Block_Size']} B, "
                f"scratch {r0['Scratch_Size']} B, workgroup {r0['Workgroup_Size_X']}, grid {r0['Grid_Size_X']}.  (The trace lists static LDS only: "
-               f"the step kernel's LDS is dynamic, 40 864 B per workgroup for a Newton launch, 42 400 B for PGS -- smj_lds_bytes(); the code "
+               f"the step kernel's LDS is dynamic, 40 956 B per workgroup, Newton and PGS alike -- smj_lds_bytes(); the code "
                f"object's metadata gives 256 VGPR + 256 AGPR.)\n")
     out.append("## PMC counters (each group collected in its own `rocprofv3 --pmc ... --kernel-trace` run), per launch, timed region\n")
     out.append("| counter | mean | min | max |\n|---|---|---|---|")
