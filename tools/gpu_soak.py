@@ -39,7 +39,8 @@ def main(B=4096, steps=20000, scene="stretch_empty"):
     print(f"{scene}: {B} envs x {steps} steps in {dt:.1f} s = {B*steps/dt/1e6:.2f} M env-steps/s; "
           f"flags: rows {float(((fl & 1) != 0).float().mean()):.3f} contacts {float(((fl & 2) != 0).float().mean()):.3f} "
           f"(per 50-step launch: mean {np.mean(per_launch):.4f}, max {np.max(per_launch):.4f}) "
-          f"bad-state resets {float(((fl & 4) != 0).float().mean()):.4f}; |quat|-1 max {worst_q:.1e}; "
+          f"bad-state resets {float(((fl & 4) != 0).float().mean()):.4f}; pipeline timeouts {int(((fl & 8) != 0).sum())}; "
+          f"steps per env min {int(sim.nstep.min())} max {int(sim.nstep.max())}; |quat|-1 max {worst_q:.1e}; "
           f"base z in [{float(z.min()):.3f}, {float(z.max()):.3f}], upright (R22>0.9) {float((up > 0.9).float().mean()):.3f}, "
           f"|x|,|y| max {float(sim.qpos[0:2].abs().max()):.1f} m")
 
