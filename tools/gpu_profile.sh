@@ -19,4 +19,7 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/prof/rpmc_$tag -o smj -- $RCMD > gpurun_out/prof/rpmc_$tag.log 2>&1
   echo "render pmc $tag rc=$?"
 done
+# the kitchen stand-in (tall variant as the primary kernel) and the PGS path: kernel-trace stats only
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/ktrace -o smj -- python tools/gpu_options_probe.py scene=stretch_kitchen_standin > gpurun_out/prof/kitchen_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/ptrace -o smj -- python tools/gpu_options_probe.py solver=0 > gpurun_out/prof/pgs_trace.log 2>&1
 find gpurun_out/prof -name "*.csv" | wc -l

@@ -144,6 +144,22 @@ def main():
                    "source": f"profiles/{TAG}_rocprof_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                              f"timed-region launches; read side x2 per MI355X_MICROARCH.md section HBM)"}, f, indent=1)
     render_summary(out)
+    for sub, title in (("ktrace", "kitchen stand-in (`tools/gpu_options_probe.py scene=stretch_kitchen_standin`: 300 settle steps, 14 random-action launches of 50 steps; the tall variant is the primary kernel)"),
+                       ("ptrace", "PGS (`tools/gpu_options_probe.py solver=0`, empty scene, same schedule)")):
+        path = os.path.join(SRC, sub, "smj_kernel_stats.csv")
+        if not os.path.exists(path):
+            continue
+        out.append(f"\n## `rocprofv3 --kernel-trace --stats`: {title}\n")
+        out.append("| kernel | calls | total ms | avg ms | % | min ms | max ms |\n|---|---|---|---|---|---|---|")
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                if float(r["Percentage"]) > 0.05:
+                    out.append(f"| `{r['Name'][:60]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e6:.3f} | {float(r['Percentage']):.2f} | {float(r['MinNs'])/1e6:.3f} | {float(r['MaxNs'])/1e6:.3f} |")
+        log = os.path.join(SRC, {"ktrace": "kitchen_trace.log", "ptrace": "pgs_trace.log"}[sub])
+        if os.path.exists(log):
+            last = [l for l in open(log) if "env-steps/s" in l]
+            if last:
+                out.append("\nProbe output under the profiler: `" + last[-1].strip()[:200] + "`")
     with open(os.path.join(DST, f"{TAG}_rocprof_summary.md"), "w") as f:
         f.write("\n".join(out) + "\n")
     sc = os.path.join(ROOT, "gpurun_out", "stage_cycles.txt")
