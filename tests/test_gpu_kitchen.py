@@ -84,3 +84,32 @@ def test_depth_sees_the_fixtures():
     d435 = imgs.cam_d435i_depth[1].cpu().numpy()
     assert ((d435 > 0.5) & (d435 < 3.0)).mean() > 0.3      # cabinets / counter fill the head camera's view
     sim.stop()
+
+
+def test_pipelined_chunks_on_the_tall_variant_are_bit_identical():
+    """The kitchen stand-in runs the tall variant as its primary kernel; its launches are pipelined in chunks of 10 steps
+    (smj_step, DevState::pipe_len).  Scheduling only: 2048 envs under random actions, 2 x 37 steps -- every state word and the
+    sensor readouts equal those of the one-workgroup-per-env launch."""
+    from stretch_mujoco_amd import StretchSensors
+
+    B, ref = 2048, None
+    for pipe in (0, 5, 3):
+        sim = _sim(B, sensors_to_use=StretchSensors.all())
+        sim.set_option("pipeline", pipe)
+        g = torch.Generator(device=sim.device).manual_seed(11)
+        lo = torch.tensor(sim.model["actuator_ctrlrange"][:, 0], dtype=torch.float32, device=sim.device).unsqueeze(1)
+        hi = torch.tensor(sim.model["actuator_ctrlrange"][:, 1], dtype=torch.float32, device=sim.device).unsqueeze(1)
+        sim.ctrl[:] = torch.tensor([0, 0, 0.6, 0.1, 0, 0, 0, 0, 0, 0], dtype=torch.float32, device=sim.device).unsqueeze(1)
+        sim.step(200)
+        for _ in range(2):
+            sim.ctrl.copy_(lo + (hi - lo) * torch.rand(10, B, generator=g, device=sim.device))
+            sim.step(37)
+        torch.cuda.synchronize()
+        got = [t.clone() for t in (sim.qpos, sim.qvel, sim.qacc_warmstart, sim.actuator_length, sim.base_pose, sim.info, sim.nstep, sim.gyro, sim.accel, sim.lidar, sim.xpose)]
+        assert int(sim.nstep.min()) == int(sim.nstep.max()) == 274 and (int(sim.info[3].max()) & 8) == 0
+        if ref is None:
+            ref = got
+        else:
+            for a, b in zip(ref, got):
+                assert torch.equal(a, b), pipe
+        sim.stop()
