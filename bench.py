@@ -317,7 +317,11 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    all_returns, gather_path = parallel.gather_returns_native(sim, returns)   # RCCL all-gather of per-env returns (the only collective)
+    try:   # RCCL all-gather of per-env returns inside libsmj.so (the only collective of the path); after the timed region
+        all_returns, gather_path = parallel.gather_returns_native(sim, returns)
+    except Exception as e:   # never lose the measured line to the gather: fall back to torch.distributed's and say so
+        all_returns = parallel.gather_returns(returns)
+        gather_path = f"torch.distributed all_gather_into_tensor (the library's RCCL path failed: {type(e).__name__}: {e})"
     f = sim.info[3]
     flags = int(((f & 1).max() | (f & 2).max() | (f & 4).max()).item())   # union of the sticky overflow / bad-state bits
     flagged = float((f != 0).float().mean().item())
