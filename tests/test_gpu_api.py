@@ -147,3 +147,24 @@ def test_stow_and_home_replace_the_command():
     assert float(st.lift.pos[0]) == pytest.approx(key[2], abs=0.02)
     assert float(st.wrist_pitch.pos[0]) == pytest.approx(key[5], abs=0.05)
     sim.stop()
+
+
+def test_status_at_t_8_26_against_the_notebook_through_the_api():
+    """docs/getting_started.ipynb cell 20: `sim.start()` ... `sim.pull_status()` at time = 8.26 s.  The same two calls here
+    (start() sends the home keyframe like the reference's, stretch_mujoco_simulator.py:136), 4130 steps in between, every
+    printed joint against pull_status() of the HIP path.  fp32 tolerances: 5e-5 on lift / arm (the notebook's MuJoCo and this
+    build's oracle differ by 1.4e-5 there, tests/test_oracle_physics.py), 2e-5 on the wrist and head joints, 1e-4 on the still
+    creeping wrist_yaw and on the gripper (printed in the real gripper's range: the sim -> real map is part of the check)."""
+    sim = _sim(4)
+    sim.home(settle=False)          # start()'s home(): the keyframe's targets; the 8.26 s include whatever the client waited
+    sim.step(4130)
+    st = sim.pull_status()
+    torch.cuda.synchronize()
+    assert float(st.time[0]) == pytest.approx(8.26, abs=1e-6)
+    nb = dict(lift=(0.5905520090306994, 5e-5), arm=(0.09999622635034094, 5e-5), head_pan=(-5.005046374741913e-06, 2e-5),
+              head_tilt=(-0.004519272499335126, 2e-5), wrist_yaw=(9.232975816659571e-05, 1e-4), wrist_pitch=(-0.005324523093874352, 2e-5),
+              wrist_roll=(-9.586627571896982e-05, 2e-5), gripper=(-0.06399746756801022, 1e-4))
+    for name, (val, tol) in nb.items():
+        got = getattr(st, name).pos
+        assert float((got - val).abs().max()) < tol, (name, got.tolist(), val)
+    sim.stop()

@@ -227,3 +227,24 @@ def test_sphere_rests_on_a_free_box():
     assert abs(q[2] - 0.1) < 3e-3 and abs(q[9] - 0.3) < 6e-3 and np.abs(o.arr("qvel")).max() < 0.2   # the ball may roll slowly
     c = o.arr("contact").reshape(o.ncon, -1)
     assert o.ncon == 5 and -3e-3 < c[4][0] < 0 and np.allclose(c[4][4:7], [0, 0, -1], atol=1e-3)   # sphere (geom1) -> box: down
+
+
+def test_status_at_t_8_26_against_the_notebook(blob_full):
+    """docs/getting_started.ipynb cell 20 prints pull_status() at time = 8.26 s of a robot that was started (qpos0, home
+    keyframe targets) and left alone.  Joint by joint, the oracle at step 4130 against the printed values (the reference's own
+    MuJoCo, fp64): lift and arm to 2e-5, the wrist and head joints to 1e-6 -- tighter than any band, and at a stated time.
+    wrist_yaw is still creeping there (printed velocity -3.3e-05 rad/s): 1e-4.  The base pose is not compared: x, y, theta of
+    the settled base are what is left of the first contact transient of the drop from qpos0 (1 cm, 4 degrees in the notebook)."""
+    o = Oracle(blob_full)
+    o.arr("ctrl")[:] = HOME_CTRL
+    o.step(4130)
+    o.forward()
+    assert o.time == pytest.approx(8.26, abs=1e-9)
+    L = o.arr("actuator_length")
+    nb = {2: (0.5905520090306994, 2e-5), 3: (0.09999622635034094, 2e-5), 8: (-5.005046374741913e-06, 1e-6), 9: (-0.004519272499335126, 1e-6),
+          4: (9.232975816659571e-05, 1e-4), 5: (-0.005324523093874352, 1e-6), 6: (-9.586627571896982e-05, 1e-6)}
+    for a, (val, tol) in nb.items():
+        assert abs(L[a] - val) < tol, (a, L[a], val)
+    # gripper: printed -0.06399746756801022 = the reference's sim -> real range map of the simulated 2.5e-6
+    from stretch_mujoco_amd.utils import to_real_gripper_range
+    assert float(to_real_gripper_range(np.array([L[7]]))[0]) == pytest.approx(-0.06399746756801022, abs=2e-5)
