@@ -479,11 +479,9 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
     mb.ls_tolerance = ms.ls_tolerance; mb.tolerance = ms.tolerance;
   }
   smj_launch_stage(in, c->stage, Y.stride, c->num_envs, st.ld, false, (hipStream_t)stream);
-  // The n steps go out as chunks of `chunk` steps (default 10) on the staged rows.  Per-env cost is uneven and changes over
-  // tens of steps (contacts come and go): the cost of the previous chunk predicts the next one far better than the previous
-  // 50-step window predicts the next window, so each chunk is dispatched longest-env-first with a fresh order; and an env
-  // that runs out of rows is handed to the tall variant for the rest of a 10-step chunk, not of the whole launch.  Readout
-  // flags go with the last chunk only.  (Debug / profiling slots bound: one chunk, their dumps describe the whole launch.)
+  // Option `chunk` (default 0 = off; kept for experiments): the n steps go out as separate dispatches of `chunk` steps on the
+  // staged rows, each with a fresh longest-first order.  Measured: no gain -- a barrier per chunk keeps the tail's share of a
+  // dispatch what it was; the pipelined chunks below have no barrier.  Readout flags go with the last chunk only.
   const int chunk = (c->chunk > 0 && !st.debug && !st.prof && c->num_envs > 1024) ? c->chunk : nsteps;
   // Pipelined chunks (standard variant, batches that need more than one round of workgroups): see DevState::pipe_len
   hipStream_t sm = (hipStream_t)stream;

@@ -1,6 +1,7 @@
-// The step kernel and its launcher for ONE capacity variant (smj_model.h): included by smj_kernels.hip (standard) and by
-// smj_kernels_tall.hip (SMJ_TALL) and smj_kernels_big.hip (SMJ_BIG).  Device code is compiled per translation unit, so the two instantiations of StepKernel / Smem
-// never meet.
+// The step kernel and its launcher for ONE build of ONE capacity variant (smj_model.h): included by smj_kernels.hip (standard),
+// smj_kernels_prof.hip (standard with the per-stage cycle counters), smj_kernels_tall.hip (SMJ_TALL, which also gets the
+// escalation worker kernel) and smj_kernels_big.hip (SMJ_BIG).  Device code is compiled per translation unit, so the
+// instantiations of StepKernel / Smem never meet.
 #pragma once
 #include "smj_kernels.h"
 #include "smj_step_impl.h"
