@@ -1394,8 +1394,59 @@ struct StepKernel {
     mulmat3vec(out, sh.mat, pl);
     for (int i = 0; i < 3; i++) out[i] += sh.pos[i];
   }
+  // per-lane part of a hull support query: the lane's best vertex for direction dl (hull frame)
+  SMJ_DEV void hull_scan(const Shape& sh, const float* dl, int lane, float& bd, int& bi, float* b) {
+    const Vec4* verts = reinterpret_cast<const Vec4*>(sh.verts);
+    const int nvert = sh.nvert;
+    bd = -3.0e38f; bi = -1; b[0] = b[1] = b[2] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {   // register-resident vertices
+      const int id = lane + 64 * u;
+      const float x = sh.vc[lane][3 * u], y = sh.vc[lane][3 * u + 1], z = sh.vc[lane][3 * u + 2];
+      const float d = x * dl[0] + y * dl[1] + z * dl[2];
+      if (id < nvert && d > bd) { bd = d; bi = id; b[0] = x; b[1] = y; b[2] = z; }
+    }
+    for (int i0 = 256 + lane; i0 < nvert; i0 += 256) {   // larger hulls: the rest from memory, four 16-byte loads in flight
+      Vec4 v[4];
+      int id[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { id[u] = i0 + 64 * u < nvert ? i0 + 64 * u : nvert - 1; v[u] = verts[id[u]]; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const float d = v[u].x * dl[0] + v[u].y * dl[1] + v[u].z * dl[2];
+        if (d > bd) { bd = d; bi = id[u]; b[0] = v[u].x; b[1] = v[u].y; b[2] = v[u].z; }
+      }
+    }
+  }
   SMJ_DEV void mpr_support(const Shape& A, const Shape& Bs, const float* dir, MprPt& p) {
     const float nd[3] = {-dir[0], -dir[1], -dir[2]};
+    if (A.type == GT_MESH && Bs.type == GT_MESH) {
+      // hull against hull (most convex pairs of the robot): the two queries side by side -- one lane region scans both hulls and
+      // the two arg-max reductions are independent chains the scheduler interleaves.  Same arithmetic as shape_support.
+      float dla[3], dlb[3];
+      mulmat3Tvec(dla, A.mat, dir);
+      mulmat3Tvec(dlb, Bs.mat, nd);
+      PL<float> besta, ax, ay, az, bestb, bx, by, bz;
+      PL<int> ia, ib;
+      LANES {
+        float ba[3], bb[3];
+        hull_scan(A, dla, lane, besta[lane], ia[lane], ba);
+        hull_scan(Bs, dlb, lane, bestb[lane], ib[lane], bb);
+        ax[lane] = ba[0]; ay[lane] = ba[1]; az[lane] = ba[2]; bx[lane] = bb[0]; by[lane] = bb[1]; bz[lane] = bb[2];
+      }
+      const float mxa = wave_max(besta), mxb = wave_max(bestb);
+      PL<int> isa, isb;
+      LANES { isa[lane] = besta[lane] == mxa && ia[lane] >= 0; isb[lane] = bestb[lane] == mxb && ib[lane] >= 0; }
+      const uint64_t ma = wave_ballot(isa), mb = wave_ballot(isb);
+      const int idxa = popc64(ma) == 1 ? wave_read(ia, ffs64(ma)) : pick_index(besta, ia, mxa);
+      const int idxb = popc64(mb) == 1 ? wave_read(ib, ffs64(mb)) : pick_index(bestb, ib, mxb);
+      const int oa = idxa & 63, ob = idxb & 63;
+      const float pla[3] = {wave_read(ax, oa), wave_read(ay, oa), wave_read(az, oa)}, plb[3] = {wave_read(bx, ob), wave_read(by, ob), wave_read(bz, ob)};
+      mulmat3vec(p.a, A.mat, pla);
+      mulmat3vec(p.b, Bs.mat, plb);
+      for (int i = 0; i < 3; i++) { p.a[i] += A.pos[i]; p.b[i] += Bs.pos[i]; p.v[i] = p.a[i] - p.b[i]; }
+      return;
+    }
     shape_support(A, dir, p.a);
     shape_support(Bs, nd, p.b);
     for (int i = 0; i < 3; i++) p.v[i] = p.a[i] - p.b[i];
