@@ -1387,8 +1387,8 @@ struct StepKernel {
       PL<int> ism;
       LANES { ism[lane] = best[lane] == mx && bidx[lane] >= 0; }
       const uint64_t mm = wave_ballot(ism);
-      const int idx = popc64(mm) == 1 ? wave_read(bidx, ffs64(mm)) : pick_index(best, bidx, mx);
-      const int owner = idx & 63;   // vertex i is scanned by lane i mod 64: the winner's coordinates come by v_readlane
+      // vertex i is scanned by lane i mod 64: the lane holding the maximum is the owner, its coordinates come by v_readlane
+      const int owner = popc64(mm) == 1 ? ffs64(mm) : (pick_index(best, bidx, mx) & 63);
       pl[0] = wave_read(bx, owner); pl[1] = wave_read(by, owner); pl[2] = wave_read(bz, owner);
     }
     mulmat3vec(out, sh.mat, pl);
@@ -1438,9 +1438,8 @@ struct StepKernel {
       PL<int> isa, isb;
       LANES { isa[lane] = besta[lane] == mxa && ia[lane] >= 0; isb[lane] = bestb[lane] == mxb && ib[lane] >= 0; }
       const uint64_t ma = wave_ballot(isa), mb = wave_ballot(isb);
-      const int idxa = popc64(ma) == 1 ? wave_read(ia, ffs64(ma)) : pick_index(besta, ia, mxa);
-      const int idxb = popc64(mb) == 1 ? wave_read(ib, ffs64(mb)) : pick_index(bestb, ib, mxb);
-      const int oa = idxa & 63, ob = idxb & 63;
+      const int oa = popc64(ma) == 1 ? ffs64(ma) : (pick_index(besta, ia, mxa) & 63);
+      const int ob = popc64(mb) == 1 ? ffs64(mb) : (pick_index(bestb, ib, mxb) & 63);
       const float pla[3] = {wave_read(ax, oa), wave_read(ay, oa), wave_read(az, oa)}, plb[3] = {wave_read(bx, ob), wave_read(by, ob), wave_read(bz, ob)};
       mulmat3vec(p.a, A.mat, pla);
       mulmat3vec(p.b, Bs.mat, plb);
@@ -2023,8 +2022,7 @@ struct StepKernel {
       PL<int> ism;
       LANES { ism[lane] = best[q][lane] == mx && bidx[q][lane] >= 0; }
       const uint64_t mm = wave_ballot(ism);
-      const int idx = popc64(mm) == 1 ? wave_read(bidx[q], ffs64(mm)) : pick_index(best[q], bidx[q], mx);
-      const int owner = idx & 63;
+      const int owner = popc64(mm) == 1 ? ffs64(mm) : (pick_index(best[q], bidx[q], mx) & 63);
       plq[q][0] = wave_read(bx[q], owner); plq[q][1] = wave_read(by[q], owner); plq[q][2] = wave_read(bz[q], owner);
     }
     LANES {
