@@ -31,7 +31,11 @@ enum smj_slot {
   SMJ_SLOT_GYRO = 8,      /* [3][B]    sensor base_gyro   (mujoco_server_sensor_manager.py:85)             */
   SMJ_SLOT_ACCEL = 9,     /* [3][B]    sensor base_accel                                                   */
   SMJ_SLOT_LIDAR = 10,    /* [nlidar][B] sensors base_lidar000.. (mujoco_server_sensor_manager.py:77-83)   */
-  SMJ_SLOT_INFO = 11,     /* int32 [4][B] nefc, ncon, solver iterations, flags                             */
+  SMJ_SLOT_INFO = 11,     /* int32 [4][B] nefc, ncon, solver iterations, flags (sticky, OR-ed by every step until the caller
+                             clears them: bit 0 = constraint rows beyond the kernel variant's capacity were degraded / dropped,
+                             bit 1 = contacts beyond capacity dropped, bit 2 = non-finite state reset to qpos0, bit 3 = the
+                             pipelined dispatch gave up waiting for the env's previous chunk: the env ran fewer steps than
+                             asked for (NSTEP tells how many) -- never observed, it bounds a wait that would otherwise hang)  */
   SMJ_SLOT_DEBUG = 12,    /* [SMJ_DEBUG_FLOATS][B] optional stage dumps for parity tests (may stay unbound) */
   SMJ_SLOT_PROF = 13,     /* [32][B] optional per-stage shader-cycle counters and event counts of a launch (filled by the
                              standard kernel variant only: binding it selects that variant's profiling build)           */
