@@ -113,6 +113,14 @@ int smj_set_option(smj_ctx* ctx, const char* name, double value);
 int smj_render_depth(smj_ctx* ctx, int camera_id, int width, int height, float fovy_deg, float max_depth, void* out_dev,
                      void* stream);
 
+/* RGB stand-in for the reference's colour cameras (cam_d405_rgb, cam_d435i_rgb, cam_nav_rgb; Renderer.render without depth,
+ * mujoco_server_camera_manager.py:127-143): per pixel the 8-bit albedo -- the geom's rgba, its material's where the MJCF names
+ * one -- of the first geom the pixel ray meets (same rays, geoms and front-face rule as smj_render_depth), (169, 224, 255)
+ * where it meets none.  No lighting, no textures, no shadows: NOT MuJoCo's OpenGL image, a placeholder with the reference's
+ * shapes, resolutions and intrinsics.  rgb_dev: uint8 [num_envs][height][width][3]; gid_dev (optional, may be null): int32
+ * [num_envs][height][width], the geom ids (-1 = none). */
+int smj_render_rgb(smj_ctx* ctx, int camera_id, int width, int height, float fovy_deg, void* rgb_dev, void* gid_dev, void* stream);
+
 /* Multi-GPU: envs shard across one process per GPU with no exchange while stepping -- the reference itself is
  * one env per process with no coupling (stretch_mujoco_simulator.py:102-118).  The only collective of the path gathers the
  * per-env returns of all ranks, rank-major, with RCCL (ncclAllGather over xGMI), issued on the caller's stream.

@@ -41,6 +41,9 @@ def lib():
         L.smjo_render_depth.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
         L.smjo_render_depth.restype = ctypes.c_int
+        L.smjo_render_geomid.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                         ctypes.c_void_p, ctypes.c_void_p]
+        L.smjo_render_geomid.restype = ctypes.c_int
         L.smjo_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double]
         L.smjo_get.restype = ctypes.POINTER(ctypes.c_double)
         L.smjo_get.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
@@ -143,6 +146,16 @@ class Oracle:
         if rc != 0:
             raise ValueError("model blob has no render tables, or bad camera id")
         return out
+
+    def render_geomid(self, cam: int, width: int, height: int, fovy_deg: float):
+        """(geom id image [H, W] int32 with -1 = nothing hit, albedo image [H, W, 3] uint8) of camera `cam`: the RGB stand-in."""
+        gid = np.zeros((height, width), np.int32)
+        rgb = np.zeros((height, width, 3), np.uint8)
+        rc = self.L.smjo_render_geomid(self.m, self.d, int(cam), int(width), int(height), float(fovy_deg),
+                                       gid.ctypes.data_as(ctypes.c_void_p), rgb.ctypes.data_as(ctypes.c_void_p))
+        if rc != 0:
+            raise ValueError("model blob has no render tables, or bad camera id")
+        return gid, rgb
 
     def sensors(self, with_lidar: bool = True):
         self.L.smjo_sensors(self.m, self.d, int(with_lidar))

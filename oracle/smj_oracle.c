@@ -2341,7 +2341,7 @@ static double ray_prim_front(int type, const double* size, const double* lp, con
   return -1;
 }
 /* out: float[H][W]; returns 0, or -1 when the blob has no render tables */
-int smjo_render_depth(smjo_model* m, const smjo_data* d, int cam, int W, int H, double fovy_deg, double max_depth, float* out) {
+static int render_rays(smjo_model* m, const smjo_data* d, int cam, int W, int H, double fovy_deg, double max_depth, float* out, int* gid) {
   if (!m->rmesh_vert || cam < 0 || cam >= m->ncam) return -1;
   rb_ensure(m);
   const double* cp = d->cam_xpos + 3 * cam;
@@ -2353,6 +2353,7 @@ int smjo_render_depth(smjo_model* m, const smjo_data* d, int cam, int W, int H, 
       double dc[3] = {((u + 0.5) / W * 2 - 1) * th * aspect, (1 - (v + 0.5) / H * 2) * th, -1.0}, dv[3];
       mulmat3vec(dv, cm, dc);
       double best = tfar * (1 + 1e-6);
+      int hit = -1;
       for (int g = 0; g < m->ngeom; g++) {
         if (m->geom_group[g] > 2 || m->geom_rgba[4 * g + 3] == 0) continue;
         int type = m->geom_type[g];
@@ -2375,16 +2376,42 @@ int smjo_render_depth(smjo_model* m, const smjo_data* d, int cam, int W, int H, 
             if (b < t1) t1 = b;
             if (t0 > t1) miss = 1;
           }
-          if (!miss) best = rb_ray(m, m->geom_rmeshid[g], lp, lv, tnear, best, 1);
+          if (!miss) {
+            const double nb = rb_ray(m, m->geom_rmeshid[g], lp, lv, tnear, best, 1);
+            if (nb < best) { best = nb; hit = g; }
+          }
         } else {
           double x = ray_prim_front(type, m->geom_size + 3 * g, lp, lv, tnear);
-          if (x >= 0 && x < best) best = x;
+          if (x >= 0 && x < best) { best = x; hit = g; }
         }
       }
       double z = best;
       if (z > tfar) z = max_depth > 0 ? 0 : m->zfar;
       if (max_depth > 0 && z > max_depth) z = 0;
-      out[(size_t)v * W + u] = (float)z;
+      if (out) out[(size_t)v * W + u] = (float)z;
+      if (gid) gid[(size_t)v * W + u] = best <= tfar ? hit : -1;
+    }
+  return 0;
+}
+int smjo_render_depth(smjo_model* m, const smjo_data* d, int cam, int W, int H, double fovy_deg, double max_depth, float* out) {
+  return render_rays(m, d, cam, W, H, fovy_deg, max_depth, out, NULL);
+}
+/* The geom each pixel ray hits first (front faces, the geoms a camera draws), -1 = nothing up to the far plane; and its colour
+ * as the build's RGB cameras define it: the geom's rgba (material rgba where the MJCF names one) as 8-bit albedo, no lighting,
+ * no textures; sky = (169, 224, 255), the colour docs/getting_started.ipynb cell 14 prints for empty pixels.  NOT MuJoCo's
+ * OpenGL image: a stand-in with the reference's shapes, resolutions and intrinsics. */
+int smjo_render_geomid(smjo_model* m, const smjo_data* d, int cam, int W, int H, double fovy_deg, int* gid, unsigned char* rgb) {
+  const int rc = render_rays(m, d, cam, W, H, fovy_deg, 0.0, NULL, gid);
+  if (rc) return rc;
+  if (rgb)
+    for (size_t i = 0; i < (size_t)W * H; i++) {
+      const int g = gid[i];
+      const unsigned char sky[3] = {169, 224, 255};
+      for (int k = 0; k < 3; k++) {
+        double c = g >= 0 ? m->geom_rgba[4 * g + k] : 0;
+        c = c < 0 ? 0 : (c > 1 ? 1 : c);
+        rgb[3 * i + k] = g >= 0 ? (unsigned char)(c * 255.0 + 0.5) : sky[k];
+      }
     }
   return 0;
 }

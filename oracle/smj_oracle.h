@@ -46,6 +46,7 @@ long long smjo_flops(int reset);
 /* depth image float[H][W] of camera `cam` from the poses of the last smjo_forward / smjo_step; -1 if the blob has no
  * render tables.  max_depth <= 0: raw render (far plane where nothing is hit). */
 int smjo_render_depth(smjo_model* m, const smjo_data* d, int cam, int W, int H, double fovy_deg, double max_depth, float* out);
+int smjo_render_geomid(smjo_model* m, const smjo_data* d, int cam, int W, int H, double fovy_deg, int* gid, unsigned char* rgb);
 
 #ifdef __cplusplus
 }

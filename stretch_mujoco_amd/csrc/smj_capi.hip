@@ -185,6 +185,10 @@ static int setup_render(smj_ctx* c, const void* blob, size_t nbytes) {
   r.geom_type = c->model.geom_type; r.geom_bodyid = c->model.geom_bodyid; r.geom_pos = c->model.geom_pos;
   r.geom_mat = c->model.k_geom_mat; r.geom_size = c->model.geom_size; r.geom_rbound = c->model.geom_rbound;
   r.geom_bcenter = c->model.k_geom_bcenter; r.geom_aabb = c->model.geom_aabb;
+  {
+    const SmjBlobEntry* gc = b.find("geom_rgba");   // colours of the RGB stand-in (smj_render_rgb); older blobs may lack them
+    r.geom_rgba = (gc && gc->dtype == 0) ? up.f32(getd(gc)) : nullptr;
+  }
   // BVHs
   const std::vector<int> vadr = geti(va), vnum = geti(vn), fadr = geti(fa), fnum = geti(fn);
   const float* verts = reinterpret_cast<const float*>(b.p + rv->offset);
@@ -607,6 +611,27 @@ int smj_render_depth(smj_ctx* c, int cam, int width, int height, float fovy_deg,
   }
   smj_launch_depth(c->render, c->state.xpose, c->slot_ld[SMJ_SLOT_XPOSE], c->num_envs, cam, width, height, fovy_deg, max_depth,
                    (float*)out_dev, L->buf, 2, c->depth_ws, (hipStream_t)stream);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+int smj_render_rgb(smj_ctx* c, int cam, int width, int height, float fovy_deg, void* rgb_dev, void* gid_dev, void* stream) {
+  if (!c) return -1;
+  if (!c->has_render) return fail(c, -6, "the model blob carries no render tables (k_rgeom / rmesh_*)");
+  if (!c->render.geom_rgba) return fail(c, -6, "the model blob carries no geom colours (geom_rgba)");
+  if (cam < 0 || cam >= c->render.ncam) return fail(c, -1, "camera id %d out of range (ncam %d)", cam, c->render.ncam);
+  if (width <= 0 || height <= 0 || !(fovy_deg > 0.f && fovy_deg < 180.f)) return fail(c, -1, "bad image size / field of view");
+  if (!rgb_dev) return fail(c, -1, "null output image");
+  if (!c->state.xpose) return fail(c, -5, "XPOSE slot is not bound (step with SMJ_READ_POSES first)");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->depth_ws) {
+    void* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, smj_depth_workspace_bytes(c->num_envs)));
+    c->allocs.push_back(d);
+    c->depth_ws = (float*)d;
+  }
+  smj_launch_rgb(c->render, c->state.xpose, c->slot_ld[SMJ_SLOT_XPOSE], c->num_envs, cam, width, height, fovy_deg,
+                 (unsigned char*)rgb_dev, (int*)gid_dev, c->depth_ws, (hipStream_t)stream);
   HIPCHK(c, hipGetLastError());
   return 0;
 }

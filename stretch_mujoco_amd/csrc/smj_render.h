@@ -18,6 +18,7 @@ struct DevRender {
   const float* geom_rbound;        // [ngeom]
   const float* geom_bcenter;       // [ngeom][3]  bounding-sphere centre, body frame
   const float* geom_aabb;          // [ngeom][6]  box in the geom frame: centre, half sizes
+  const float* geom_rgba;          // [ngeom][4]  colour of the RGB stand-in (geom / material rgba), or null
   const int* cam_bodyid;           // [ncam]
   const float* cam_pos;            // [ncam][3]
   const float* cam_mat;            // [ncam][9]
@@ -43,5 +44,9 @@ void smj_launch_lidar(const DevRender& r, const float* xpose, long ld, int num_e
 // ray from layer[height][width].
 // workspace: smj_depth_workspace_bytes(num_envs) of device memory, scratch of the per-env staging pass (smj_render.hip).
 size_t smj_depth_workspace_bytes(int num_envs);
+// RGB stand-in: per pixel the albedo (geom rgba, 8 bit, unlit) of the first geom the ray meets, sky (169, 224, 255) where it meets
+// none; rgb [num_envs][height][width][3] bytes, gid (optional) [num_envs][height][width] the geom ids (-1 = none).
+void smj_launch_rgb(const DevRender& r, const float* xpose, long ld, int num_envs, int cam, int width, int height, float fovy_deg,
+                    unsigned char* rgb, int* gid, float* workspace, hipStream_t stream);
 void smj_launch_depth(const DevRender& r, const float* xpose, long ld, int num_envs, int cam, int width, int height,
                       float fovy_deg, float max_depth, float* out, const float* layer, int mode, float* workspace, hipStream_t stream);

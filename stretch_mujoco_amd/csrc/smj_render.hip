@@ -21,7 +21,7 @@ constexpr int TILE = 16;   // pixels per side of a workgroup's tile (32 was meas
 
 struct RGeom {
   float pos[3], mat[9], cen[3], rbound, size[3];
-  int type, rmesh;
+  int type, rmesh, gid;
 };
 
 enum { RT_PLANE = 0, RT_SPHERE = 2, RT_CAPSULE = 3, RT_ELLIPSOID = 4, RT_CYLINDER = 5, RT_BOX = 6, RT_MESH = 7 };
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(384) void smj_lidar_kernel(const DevRender R, const
 // Everything here is a superset test: the image does not depend on it.
 //
 // Workspace per env (floats): header cpos[3], cmat[9], count; then one 32-float slot per surviving geom in front-to-back
-// order: RGeom (pos 3, mat 9, cen 3, rbound, size 3, type, rmesh = 23 words), rect x0 x1 y0 y1.
+// order: RGeom (pos 3, mat 9, cen 3, rbound, size 3, type, rmesh, geom id = 22 words), rect x0 x1 y0 y1.
 constexpr int WS_HDR = 16, WS_SLOT = 32, WS_RECT = 24;
 constexpr int WS_STRIDE = WS_HDR + SMJ_RGEOM_MAX * WS_SLOT;
 
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(128) void smj_depth_prepass(const DevRender R, cons
       for (int k = 0; k < 3; k++) { S[k] = G.pos[k]; S[12 + k] = G.cen[k]; S[16 + k] = G.size[k]; }
       for (int k = 0; k < 9; k++) S[3 + k] = G.mat[k];
       S[15] = G.rbound;
-      S[19] = __int_as_float(G.type); S[20] = __int_as_float(G.rmesh);
+      S[19] = __int_as_float(G.type); S[20] = __int_as_float(G.rmesh); S[21] = __int_as_float(R.rgeom[tid]);
       for (int k = 0; k < 4; k++) S[WS_RECT + k] = rect[k];
     }
     if (tid == 0) {
@@ -466,9 +466,13 @@ __global__ __launch_bounds__(128) void smj_depth_prepass(const DevRender R, cons
   }
 }
 
+// COLOR: the RGB stand-in -- besides the nearest depth the ray keeps WHICH geom gave it; writes that geom's 8-bit albedo
+// (rgb_out) and, if asked, its id (gid_out) instead of the depth.  A second instantiation: the depth cameras' loop stays as it is.
+template <bool COLOR>
 __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const float* __restrict__ ws, int width, int height,
                                                         float tan_half_fovy, float max_depth, float* __restrict__ out,
-                                                        const float* __restrict__ layer, int mode) {
+                                                        const float* __restrict__ layer, int mode,
+                                                        unsigned char* __restrict__ rgb_out, int* __restrict__ gid_out) {
   __shared__ RGeom geoms[SMJ_RGEOM_MAX];
   __shared__ float cpos[3], cmat[9];
   __shared__ int wcount[2];
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
     for (int k = 0; k < 3; k++) { G.pos[k] = S[k]; G.cen[k] = S[12 + k]; G.size[k] = S[16 + k]; }
     for (int k = 0; k < 9; k++) G.mat[k] = S[3 + k];
     G.rbound = S[15];
-    G.type = __float_as_int(S[19]); G.rmesh = __float_as_int(S[20]);
+    G.type = __float_as_int(S[19]); G.rmesh = __float_as_int(S[20]); G.gid = __float_as_int(S[21]);
   }
   const int nkeep_total = wcount[0] + wcount[1];
   __syncthreads();
@@ -525,6 +529,7 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
     mul(d, cmat, dc);
     const float dd = dot3(d, d), dl = sqrtf(dd);
     float best = tfar * (1.f + 1e-6f);
+    int hit = -1;
     if (mode == 2) best = fminf(best, layer[(long)v * width + u]);
     for (int i = 0; i < ng; i++) {
       const RGeom& G = geoms[i];
@@ -539,11 +544,24 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
       mulT(lp, G.mat, dif);
       mulT(lv, G.mat, d);
       if (G.type == RT_MESH) {
-        if (G.rmesh >= 0) best = ray_mesh<true>(R, G.rmesh, lp, lv, tnear, best);
+        if (G.rmesh >= 0) {
+          const float nb = ray_mesh<true>(R, G.rmesh, lp, lv, tnear, best);
+          if (COLOR && nb < best) hit = G.gid;
+          best = nb;
+        }
       } else {
         const float x = ray_prim(G.type, G.size, lp, lv, tnear);
-        if (x >= 0 && x < best) best = x;
+        if (x >= 0 && x < best) { best = x; if (COLOR) hit = G.gid; }
       }
+    }
+    if (COLOR) {
+      const long px = ((long)env * height + v) * width + u;
+      if (best > tfar) hit = -1;
+      if (gid_out) gid_out[px] = hit;
+      float c[3] = {169.f / 255.f, 224.f / 255.f, 1.f};   // nothing up to the far plane: the sky of docs/getting_started.ipynb cell 14
+      if (hit >= 0) for (int k = 0; k < 3; k++) c[k] = fminf(1.f, fmaxf(0.f, R.geom_rgba[4 * hit + k]));
+      for (int k = 0; k < 3; k++) rgb_out[3 * px + k] = (unsigned char)(c[k] * 255.f + 0.5f);
+      continue;
     }
     float z = best;
     if (mode == 1) { out[(long)v * width + u] = z; continue; }   // raw nearest depth (or just beyond the far plane)
@@ -568,5 +586,14 @@ void smj_launch_depth(const DevRender& r, const float* xpose, long ld, int num_e
   const float md = mode == 1 ? 0.f : max_depth;
   static const int nocull = getenv("SMJ_DEPTH_NOCULL") ? 1 : 0;   // debug: every geom in every tile (the image must not change)
   hipLaunchKernelGGL(smj_depth_prepass, dim3(nenv), dim3(128), 0, stream, r, xpose, ld, cam, md, ws, mode, nocull);
-  hipLaunchKernelGGL(smj_depth_kernel, dim3(tiles, nenv), dim3(256), 0, stream, r, ws, width, height, th, md, out, layer, mode);
+  hipLaunchKernelGGL(smj_depth_kernel<false>, dim3(tiles, nenv), dim3(256), 0, stream, r, ws, width, height, th, md, out, layer, mode,
+                     (unsigned char*)nullptr, (int*)nullptr);
+}
+void smj_launch_rgb(const DevRender& r, const float* xpose, long ld, int num_envs, int cam, int width, int height, float fovy_deg,
+                    unsigned char* rgb, int* gid, float* workspace, hipStream_t stream) {
+  const int tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+  const float th = tanf(fovy_deg * 3.14159265358979323846f / 360.f);
+  hipLaunchKernelGGL(smj_depth_prepass, dim3(num_envs), dim3(128), 0, stream, r, xpose, ld, cam, 0.f, workspace, 0, 0);
+  hipLaunchKernelGGL(smj_depth_kernel<true>, dim3(tiles, num_envs), dim3(256), 0, stream, r, workspace, width, height, th, 0.f,
+                     (float*)nullptr, (const float*)nullptr, 0, rgb, gid);
 }

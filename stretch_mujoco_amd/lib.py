@@ -15,7 +15,7 @@ SLOT = dict(QPOS=0, QVEL=1, CTRL=2, WARMSTART=3, NSTEP=4, ACT_LENGTH=5, ACT_VELO
 DIM = dict(NQ=0, NV=1, NU=2, NBODY=3, NLIDAR=4, NKEY=5, NUM_ENVS=6, DEBUG_FLOATS=7, NEFC_MAX=8, NCON_MAX=9, NCAM=10, NV_MAX=11)
 READ_IMU, READ_LIDAR, READ_POSES = 1, 2, 4
 EXPORTS = ("smj_create", "smj_destroy", "smj_bind", "smj_dims", "smj_reset", "smj_step", "smj_set_option",
-           "smj_last_error", "smj_version", "smj_render_depth", "smj_comm_init", "smj_allgather_returns", "smj_comm_destroy",
+           "smj_last_error", "smj_version", "smj_render_depth", "smj_render_rgb", "smj_comm_init", "smj_allgather_returns", "smj_comm_destroy",
            "smj_base_controller_tick")
 
 _lib = None
@@ -54,6 +54,7 @@ def load() -> ctypes.CDLL:
     L.smj_reset.argtypes = [vp, vp, vp]
     L.smj_step.argtypes = [vp, ci, cu, vp]
     L.smj_render_depth.argtypes = [vp, ci, ci, ci, ctypes.c_float, ctypes.c_float, vp, vp]
+    L.smj_render_rgb.argtypes = [vp, ci, ci, ci, ctypes.c_float, vp, vp, vp]
     L.smj_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_double]
     L.smj_base_controller_tick.argtypes = [vp, vp]
     L.smj_comm_init.argtypes = [vp, ci, ci, ctypes.c_char_p, ctypes.c_double]

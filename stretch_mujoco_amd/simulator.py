@@ -61,10 +61,9 @@ class StretchBatchSimulator:
         self.names = json.loads(model_blob.get_str(self.model, "names_json"))
         self._sensors = list(sensors_to_use)
         self._cameras = list(cameras_to_use)
-        for cam in self._cameras:
-            if not cam.is_depth:
-                raise NotImplementedError(f"{cam}: only the depth cameras are on the HIP path (RGB needs textures and "
-                                          "materials; DESIGN.md, scope)")
+        # depth cameras: metric depth (smj_render_depth).  RGB cameras: an unlit-albedo STAND-IN (smj_render_rgb: geom / material
+        # rgba of the first geom each pixel ray meets, uint8 [B, H, W, 3]) -- MuJoCo's lighting, textures and shadows are not on
+        # this path (scope)
         self._start_translation = start_translation
         self._start_rotation_quat = start_rotation_quat
         self._debug = debug
@@ -143,7 +142,10 @@ class StretchBatchSimulator:
                 raise _lib.SmjError("the model blob carries no render tables: depth cameras are unavailable for this scene")
             for cam in self._cameras:
                 st = cam.initial_camera_settings
-                self._depth[cam] = torch.zeros(B, st.height, st.width, **f)
+                if cam.is_depth:
+                    self._depth[cam] = torch.zeros(B, st.height, st.width, **f)
+                else:
+                    self._depth[cam] = torch.zeros(B, st.height, st.width, 3, dtype=torch.uint8, device=self.device)
         self.reset()
         if home:
             self.home()
@@ -261,7 +263,8 @@ class StretchBatchSimulator:
 
     @_require_connection
     def pull_camera_data(self) -> StatusStretchCameras:
-        """Depth images [B, H, W] of the cameras in cameras_to_use, rendered from the body poses of the last physics step
+        """Depth images [B, H, W] (fp32 metres) and RGB stand-in images [B, H, W, 3] (uint8 unlit albedo, see __init__) of the
+        cameras in cameras_to_use, rendered from the body poses of the last physics step
         (what Renderer.update_scene sees, mujoco_server_camera_manager.py:127-143), limited like
         StretchCameras.post_processing_callback; K as get_camera_params (:168-183: fovy with the SENSOR resolution).
         The reference renders at 30 Hz wall clock (mujoco_server.py:272); here the cadence is the caller's.
@@ -273,10 +276,16 @@ class StretchBatchSimulator:
         for cam in self._cameras:
             st = cam.initial_camera_settings
             img = self._depth[cam]
-            rc = self._L.smj_render_depth(self._ctx, names.index(cam.camera_name_in_mjcf), st.width, st.height,
-                                          float(st.field_of_view_vertical_in_degrees), cam.depth_limit,
-                                          ctypes.c_void_p(img.data_ptr()), self._stream())
-            _lib.check(self._L, self._ctx, rc, "smj_render_depth")
+            if cam.is_depth:
+                rc = self._L.smj_render_depth(self._ctx, names.index(cam.camera_name_in_mjcf), st.width, st.height,
+                                              float(st.field_of_view_vertical_in_degrees), cam.depth_limit,
+                                              ctypes.c_void_p(img.data_ptr()), self._stream())
+                _lib.check(self._L, self._ctx, rc, "smj_render_depth")
+            else:
+                rc = self._L.smj_render_rgb(self._ctx, names.index(cam.camera_name_in_mjcf), st.width, st.height,
+                                            float(st.field_of_view_vertical_in_degrees), ctypes.c_void_p(img.data_ptr()), None,
+                                            self._stream())
+                _lib.check(self._L, self._ctx, rc, "smj_render_rgb")
             out.set_camera_data(cam, img)
         for attr, cam in (("cam_d405_K", StretchCameras.cam_d405_rgb), ("cam_d435i_K", StretchCameras.cam_d435i_rgb)):
             st = cam.initial_camera_settings

@@ -205,3 +205,24 @@ def test_d405_notebook_rows_are_floor_seen_from_the_wrist(blob_fused):
     bl, br = d[-1, 0], d[-1, -1]
     assert 0.2 < bl < 0.5 and 0.002 < br - bl < 0.008
     assert 0.0005 < d[-2, 0] - d[-1, 0] < 0.0025 and 0.0005 < d[-3, 0] - d[-2, 0] < 0.0025
+
+
+def test_rgb_stand_in_is_the_albedo_of_the_nearest_geom(posed):
+    """smjo_render_geomid / smj_render_rgb: the id image agrees with the depth image about what is sky, the floor is the plane
+    geom in its own colour, the colour image is the rgba table entry of the id, and the ids seen are camera-visible geoms."""
+    m, o = posed
+    fovy = 100.0     # the wrist camera: gripper, floor and sky
+    depth = o.render_depth(D405, 53, 30, fovy, 0.0)
+    gid, rgb = o.render_geomid(D405, 53, 30, fovy)
+    zfar = float(m["vis_znear_zfar_extent"][1] * m["vis_znear_zfar_extent"][2])
+    assert np.array_equal(gid < 0, depth >= zfar * (1 - 1e-9))
+    rgba = np.asarray(m["geom_rgba"], float).reshape(-1, 4)
+    seen = np.unique(gid[gid >= 0])
+    assert len(seen) >= 2 and (rgba[seen, 3] > 0).all()
+    plane = int(np.where(np.asarray(m["geom_type"]) == 0)[0][0])
+    assert plane in seen
+    want = np.where(gid[..., None] >= 0, (np.clip(rgba[np.maximum(gid, 0), :3], 0, 1) * 255 + 0.5).astype(np.uint8), np.array([169, 224, 255], np.uint8))
+    assert np.array_equal(rgb, want)
+    # the colour twin of the wrist depth camera sits at the same place (stretch.xml:383-384): the same image
+    gid2, _ = o.render_geomid(D405 - 1, 53, 30, fovy)
+    assert np.array_equal(gid2, gid)
