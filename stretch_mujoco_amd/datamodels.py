@@ -76,18 +76,28 @@ class StatusStretchCameras:  # status_stretch_camera.py:10-125 (depth only on th
     cam_d435i_K: Optional[Any] = None
     cam_nav_rgb: Optional[Any] = None
 
-    def get_camera_data(self, camera, *, auto_rotate: bool = True, **_ignored):
+    def get_camera_data(self, camera, *, auto_rotate: bool = True, auto_correct_rgb: bool = True, **_ignored):
         """status_stretch_camera.py:48-86: the d435i frames come out of the (physically rotated) optical frame and are
-        turned upright with rot90(-1) when auto_rotate is set; ValueError when the image is empty."""
+        turned upright with rot90(-1) when auto_rotate is set, the nav camera's with rot90(+1); colour images [..., H, W, 3]
+        come back in BGR channel order when auto_correct_rgb is set (the reference's cv2.COLOR_RGB2BGR); ValueError when the
+        image is empty."""
         from .enums import StretchCameras
         import torch
 
         data = None
+        turn = 0
         if camera == StretchCameras.cam_d405_depth and self.cam_d405_depth is not None:
             data = self.cam_d405_depth
         elif camera == StretchCameras.cam_d435i_depth and self.cam_d435i_depth is not None:
             data = self.cam_d435i_depth
             data = torch.rot90(data, -1, dims=(-2, -1)) if auto_rotate else data
+        elif camera in (StretchCameras.cam_d405_rgb, StretchCameras.cam_d435i_rgb, StretchCameras.cam_nav_rgb) and getattr(self, camera.name) is not None:
+            data = getattr(self, camera.name)
+            turn = {StretchCameras.cam_d405_rgb: 0, StretchCameras.cam_d435i_rgb: -1, StretchCameras.cam_nav_rgb: 1}[camera]
+            if auto_rotate and turn:
+                data = torch.rot90(data, turn, dims=(-3, -2))
+            if auto_correct_rgb:
+                data = data.flip(-1)
         if data is None:
             raise ValueError(f"Tried to get {camera} data, but it is empty or not implemented.")
         return data

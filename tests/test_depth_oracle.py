@@ -149,6 +149,17 @@ def test_camera_intrinsics_and_rotation():
     assert set(s.get_all()) == {StretchCameras.cam_d405_depth, StretchCameras.cam_d435i_depth}
     with pytest.raises(ValueError):
         s.get_camera_data(StretchCameras.cam_nav_rgb)
+    # colour images [B, H, W, 3]: status_stretch_camera.py:60-80 -- d405 as is, d435i turned by rot90(-1), nav by rot90(+1), each
+    # in BGR order unless auto_correct_rgb is off
+    import torch
+    rgb = torch.arange(2 * 3 * 4 * 3, dtype=torch.uint8).reshape(2, 3, 4, 3)
+    for cam, k in ((StretchCameras.cam_d405_rgb, 0), (StretchCameras.cam_d435i_rgb, -1), (StretchCameras.cam_nav_rgb, 1)):
+        s.set_camera_data(cam, rgb)
+        got = s.get_camera_data(cam)
+        assert np.array_equal(got[1].numpy(), np.rot90(rgb[1].numpy(), k)[..., ::-1])
+        assert np.array_equal(s.get_camera_data(cam, auto_correct_rgb=False)[0].numpy(), np.rot90(rgb[0].numpy(), k))
+        assert s.get_camera_data(cam, auto_rotate=False, auto_correct_rgb=False) is rgb
+    assert set(s.get_all()) == set(StretchCameras.all())
 
 
 NOTEBOOK_D435I_F = 399.427   # docs/getting_started.ipynb cell 14: cam_d435i_K at 640 x 480
