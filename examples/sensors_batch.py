@@ -1,4 +1,4 @@
-"""Lidar sectors (as in the reference's examples/laser_scan.py) and depth images for a batch of robots in the kitchen stand-in.
+"""Lidar sectors (as in the reference's examples/laser_scan.py), depth images and the colour cameras' stand-in images for a batch of robots in the kitchen stand-in.
 
     python examples/sensors_batch.py [num_envs]
 """
@@ -11,7 +11,7 @@ from stretch_mujoco_amd import StretchBatchSimulator, StretchCameras, StretchSen
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 sim = StretchBatchSimulator(num_envs=B, device="cuda:0", scene="stretch_kitchen_standin",
-                            sensors_to_use=StretchSensors.all(), cameras_to_use=StretchCameras.depth())
+                            sensors_to_use=StretchSensors.all(), cameras_to_use=StretchCameras.all())
 sim.start()
 sim.step(33)                                          # 15 Hz lidar cadence in sim time
 scan = sim.pull_sensor_data().lidar                   # [B, 360]; index = degrees, 0 = rear, 180 = front (laser_scan.py:32-39)
@@ -29,5 +29,8 @@ for cam in StretchCameras.depth():
     valid = img[img > 0]
     print(cam.name, tuple(img.shape), "valid pixels", f"{float((img > 0).float().mean()):.2f}",
           "median depth", round(float(valid.median()), 3) if valid.numel() else None)
+for cam in StretchCameras.rgb():                      # unlit-albedo stand-in for the colour cameras: uint8 [B, H, W, 3], BGR like the reference
+    img = cams.get_camera_data(cam)
+    print(cam.name, tuple(img.shape), str(img.dtype), "sky pixels", f"{float((img == torch.tensor([255, 224, 169], dtype=torch.uint8, device=img.device)).all(-1).float().mean()):.2f}")
 print("K (d435i):", cams.cam_d435i_K.tolist())
 sim.stop()
