@@ -167,6 +167,7 @@ def test_status_at_t_8_26_against_the_notebook_through_the_api():
     for name, (val, tol) in nb.items():
         got = getattr(st, name).pos
         assert float((got - val).abs().max()) < tol, (name, got.tolist(), val)
+    assert float((st.lift.vel - 0.00022063552289719744).abs().max()) < 0.05 * 0.00022063552289719744   # the lift's creep rate at that time
     # cell 23: move_to('head_tilt', -2.0) "did not reach -2.0. Actual: -1.522573472981672" -- the limit stop minus the gravity sag,
     # a steady state the fp64 oracle reproduces to 1e-9 (tests/test_oracle_physics.py); fp32 on the device: 5e-6
     sim.move_to("head_tilt", -2.0)

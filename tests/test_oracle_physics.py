@@ -247,6 +247,8 @@ def test_status_at_t_8_26_against_the_notebook(blob_full):
           4: (9.232975816659571e-05, 1e-4), 5: (-0.005324523093874352, 1e-6), 6: (-9.586627571896982e-05, 1e-6)}
     for a, (val, tol) in nb.items():
         assert abs(L[a] - val) < tol, (a, L[a], val)
+    # the lift is still creeping towards its target at that time: printed velocity 2.2064e-4 m/s, here 2.193e-4
+    assert o.arr("actuator_velocity")[2] == pytest.approx(0.00022063552289719744, rel=0.02)
     # gripper: printed -0.06399746756801022 = the reference's sim -> real range map of the simulated 2.5e-6
     from stretch_mujoco_amd.utils import to_real_gripper_range
     assert float(to_real_gripper_range(np.array([L[7]]))[0]) == pytest.approx(-0.06399746756801022, abs=2e-5)
