@@ -142,31 +142,35 @@ def test_culling_does_not_change_the_image():
 
 
 def test_notebook_corner_values_through_the_raw_entry():
-    """docs/getting_started.ipynb cell 14 (640 x 480, f = 399.427): the last three columns of cam_d435i_depth read 1.649 /
-    1.643 / 1.638 m in the top rows, 1.647 / 1.641 / 1.636 m in the bottom rows, the first columns 0 -- 3.2 s after start().
-    Same tolerances as the oracle's twin (tests/test_depth_oracle.py: 1.5 % absolute for the model revision, 1.1 mm on the
-    pixel-to-pixel steps)."""
+    """docs/getting_started.ipynb cell 14, 3.2 s after start() in the default scene (640 x 480): cam_d405_depth reads 0.445 / 0.444
+    / 0.442 m in the first and 0.449 / 0.448 / 0.447 m in the last columns of its last three rows (the table), 0 in its top rows;
+    cam_d435i_depth reads 1.649 / 1.643 / 1.638 m (top rows) and 1.647 / 1.641 / 1.636 m (bottom rows) in its last three columns
+    from the colour camera's position (tests/test_depth_oracle.py has the story of the 15 mm).  MuJoCo's printed numbers through
+    start() / step / smj_render_depth(width, height, fovy): +- 2 in the third decimal."""
     import ctypes
     import math
 
-    from stretch_mujoco_amd import lib
+    from stretch_mujoco_amd import StretchBatchSimulator, lib
     from stretch_mujoco_amd.enums import StretchCameras
 
-    from stretch_mujoco_amd import StretchBatchSimulator
-    sim = StretchBatchSimulator(num_envs=2, device="cuda:0", cameras_to_use=[StretchCameras.cam_d435i_depth], solver="newton")
-    sim.start()                       # the reference's start: home keyframe targets
+    sim = StretchBatchSimulator(num_envs=2, device="cuda:0", cameras_to_use=StretchCameras.depth(), solver="newton", scene="stretch_scene")
+    sim.start(home=False)
+    sim.home(settle=False)            # the reference's start(): home keyframe targets
     sim.step(1601)
     L = lib.load()
     img = torch.zeros(2, 480, 640, dtype=torch.float32, device=sim.device)
-    fovy = 2 * math.degrees(math.atan(240 / 399.427))
-    assert L.smj_render_depth(sim._ctx, 3, 640, 480, fovy, 10.0, ctypes.c_void_p(img.data_ptr()), sim._stream()) == 0
+    cols = [0, 1, 2, -3, -2, -1]
+    assert L.smj_render_depth(sim._ctx, 1, 640, 480, 2 * math.degrees(math.atan(240 / 514.682)), 1.0, ctypes.c_void_p(img.data_ptr()), sim._stream()) == 0
     torch.cuda.synchronize()
     d = img[0].cpu().numpy()
-    top, bot = np.array([1.649, 1.643, 1.638]), np.array([1.647, 1.641, 1.636])
+    want = np.array([[0.445, 0.445, 0.445, 0.449, 0.449, 0.449], [0.444, 0.444, 0.444, 0.448, 0.448, 0.448], [0.442, 0.442, 0.442, 0.447, 0.447, 0.447]])
+    assert np.all(d[:3][:, cols] == 0) and np.abs(d[-3:][:, cols] - want).max() < 2.1e-3
+    assert L.smj_render_depth(sim._ctx, 2, 640, 480, 2 * math.degrees(math.atan(240 / 399.427)), 10.0, ctypes.c_void_p(img.data_ptr()), sim._stream()) == 0
+    torch.cuda.synchronize()
+    d = img[0].cpu().numpy()
     assert np.all(d[:3, :3] == 0) and np.all(d[-3:, :3] == 0)
-    assert np.allclose(d[0, -3:], top, rtol=0.015) and np.allclose(d[-1, -3:], bot, rtol=0.015)
-    assert np.allclose(np.diff(d[0, -3:]), np.diff(top), atol=1.1e-3)
-    assert np.allclose(d[0, -3:] - d[-1, -3:], top - bot, atol=1.1e-3)
+    assert np.abs(d[:3, -3:] - np.array([1.649, 1.643, 1.638])).max() < 2.1e-3 and np.abs(d[-3:, -3:] - np.array([1.647, 1.641, 1.636])).max() < 2.1e-3
+    sim.stop()
 
 
 def test_rgb_stand_in_matches_the_oracle_ray_caster():
