@@ -7,7 +7,13 @@
  * (reference pyproject.toml:12), which is absent from /root/reference and from this
  * image.  The one reference call site is stretch_mujoco/mujoco_server.py:378
  * (`mj_step(self.mjmodel, self.mjdata)`).  Each function below names the MuJoCo stage
- * it restates; none of it could be checked against MuJoCo here.
+ * it restates; no MuJoCo could be run against it here.
+ * What does pin it are the MuJoCo outputs the reference itself holds in print (docs/getting_started.ipynb): the joint
+ * status at t = 8.26 s (cell 20: lift / arm to 1.4e-5, wrist and head joints to 5e-7, the lift's creep rate to 1 %), the
+ * head_tilt limit stop (cell 23, to 2e-9) and 30 depth pixels of both depth cameras in the default scene (cell 14, to the
+ * printed 1e-3) -- tests/test_oracle_physics.py, tests/test_depth_oracle.py.  They cover the quasi-static chain (kinematics,
+ * gravity compensation, actuators, equality constraints, friction loss, limits, wheel contacts, implicitfast) and the camera
+ * model; fast contact dynamics, multiccd and box-box manifolds stay unpinned.
  */
 #ifndef SMJ_ORACLE_H
 #define SMJ_ORACLE_H
