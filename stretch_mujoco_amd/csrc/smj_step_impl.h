@@ -66,11 +66,8 @@ struct Smem {
       int m1lo[NCON], m1hi[NCON], m2lo[NCON], m2hi[NCON], b1[NCON], b2[NCON];
       float cd[NVP][6];     // cdof, so that both half-waves of the Jacobian fill can read any dof's motion axis
     } k;
-    struct {                // Newton: XA = W J (row-weighted Jacobian), then the Hessian H = M + J' W J / M - h*D in its place
-      union {
-        float XA[NEFC][JS];
-        float H[NVP][NVP + 1];   // written once the matrix cores have consumed XA (operands are fetched to registers first)
-      };
+    struct {                // Newton: the Hessian H = M + J' W J (or M - h*D of the integrator)
+      float H[NVP][NVP + 1];
       float cH[NCON][36];   // cone Hessians of contacts in the middle zone
       // per-row solver registers (NRow) of rows 64..NEFC-1: the second row pass loads them at the start of a stage and
       // stores them back at its end, so that the (rare) second pass holds no registers across the Newton loop
@@ -3279,12 +3276,16 @@ struct StepKernel {
     LANES { x[lane] = lane < n ? s.u.n.H[lane][NVP] * fast_rcp(fmaxf(s.u.n.H[lane][lane], 1e-30f)) : 0.f; }
     SYNC();
   }
-  SMJ_DEV void solve_H(PL<float>& x) {
+  SMJ_DEV void solve_H(PL<float>& x, bool rare = false) {
 #if NVP == 32
     if (M.nv <= 26) gj_solve<26>(x);   // Stretch: 26 dofs; a third fewer column pairs than the full 32
     else gj_solve<NVP>(x);
 #else
-    gj_solve_lds(x);
+    // the 64-dof variant: the robot with two free objects (the reference's scene.xml: 38 dofs) or four (50 dofs) in registers,
+    // anything larger -- and the call sites that hardly ever run -- with the matrix left in LDS
+    if (rare || M.nv > 50) gj_solve_lds(x);
+    else if (M.nv <= 38) gj_solve<38>(x);
+    else gj_solve<50>(x);
 #endif
   }
 
@@ -3335,33 +3336,6 @@ struct StepKernel {
     return a * a * q2 + a * q1 + q0;
   }
 
-  // XA rows of (up to) two cone-zone contacts: (Hc Jc), lanes 0..31 = dofs of contact ca, lanes 32..63 = dofs of contact cb.
-  // D = block size the pass is compiled for (3: both contacts condim 3; 6: zero-padded up to condim 6); fixed trip counts so
-  // that the LDS reads issue back to back.
-  template <int D>
-  SMJ_DEV void xa_cone_pass(int ca, int cb) {
-    LANES {
-      const int c = lane < NVP ? ca : cb, k = lane % NVP;   // NVP = 64: one contact per pass (cb unused)
-      if (c >= 0) {
-        const int r0 = s.cefc[c], dim = s.cdim[c];
-        float j[D], h[D * D];
-#pragma unroll
-        for (int q = 0; q < D; q++) j[q] = s.J[r0 + q < NEFC ? r0 + q : NEFC - 1][k];   // rows past the block meet zero padding of cH
-#pragma unroll
-        for (int rr = 0; rr < D; rr++)
-#pragma unroll
-          for (int q = 0; q < D; q++) h[D * rr + q] = s.u.n.cH[c][6 * rr + q];
-#pragma unroll
-        for (int rr = 0; rr < D; rr++) {
-          float v = 0;
-#pragma unroll
-          for (int q = 0; q < D; q++) v += h[D * rr + q] * j[q];
-          if (rr < dim) s.u.n.XA[r0 + rr][k] = v;
-        }
-      }
-    }
-  }
-
   SMJ_DEV void solve_newton(bool dbg, float* pc, long long& t0, bool prof) {
 #define TICK(slot) if (prof) { const long long t1 = smj_clock(); pc[slot] += (float)(t1 - t0); t0 = t1; }
     const int nv = M.nv, ne = nefc;
@@ -3372,7 +3346,7 @@ struct StepKernel {
     if (ne == 0) {   // unconstrained: qacc = M^-1 g
       build_dense(false);
       LANES { qacc[lane] = lane < nv ? g_r[lane] : 0.f; }
-      solve_H(qacc);
+      solve_H(qacc, true);
       LANES {
         qacc_r[lane] = lane < nv ? qacc[lane] : 0.f;
         if (lane < nv) { s.qacc[lane] = qacc[lane]; s.warm[lane] = qacc[lane]; s.tmp[lane] = g_r[lane]; }
@@ -3433,47 +3407,33 @@ struct StepKernel {
       const float gnorm = sqrtf(wave_sum(g2));
       if (iter > 0 && scale * gnorm < M.tolerance) break;
       TICK(SMJ_PROF_N_GRAD)
-      // XA = W J.  Quadratic rows D*J, satisfied / linear rows 0 (lane = row).  Rows of a contact in the cone (middle) zone:
-      // (Hc Jc) with lanes = dofs, two contacts per pass (half-waves), the 6x6 block zero-padded so that every loop has a
-      // fixed trip count and the LDS reads issue back to back.
+      // H = M + J' W J on the matrix cores, without a weighted copy of J.  W is diagonal (D for rows in the quadratic zone, 0 for
+      // satisfied / linear rows) except for the contacts whose block sits in the cone (middle) zone, which carry a dense
+      // dim x dim Hessian Hc.  Diagonal part: the operand pair of a k-step is (w_k J[k][:], J[k][:]) -- one LDS read and one
+      // multiply per element, the row weights staged in s.ediag (dead since the per-row constants were taken).  Cone part:
+      // further k-steps per contact, operands (Hc Jc, Jc) built in registers from the contact's rows.
       ROWS_BEGIN(rb, ne) LANES {
         const int row = lane + rb;
-        const bool cone = row < ne && nr.state[lane] == 4;
-        if (!cone && row < NEFC) {
-          const float w = (row < ne && nr.state[lane] == 1) ? nr.D[lane] : 0.f;
-#pragma unroll
-          for (int k = 0; k < NVP; k++) s.u.n.XA[row][k] = w * s.J[row][k];
-        }
+        if (row < NEFC) s.ediag[row] = (row < ne && nr.state[lane] == 1) ? nr.D[lane] : 0.f;
       } ROWS_END_RO()
-      // Rows of the contacts whose block is in the cone (middle) zone: only those contacts are visited, two per pass (half-waves),
-      // and a pass whose contacts are both condim 3 runs the 3x3 instead of the zero-padded 6x6 block product.
+      uint64_t conemask;
       {
-        PL<int> cz, cdl;
+        PL<int> cz;
         LANES {
-          int z = 0, d = 0;
+          int z = 0;
           if (lane < ncon) {
             const int r0 = s.cefc[lane];
-            d = s.cdim[lane];
-            z = r0 >= 0 && d >= 3 && s.estate[r0 >= 0 ? r0 : 0] == 4;   // row states as left by newton_update
+            z = r0 >= 0 && s.cdim[lane] >= 3 && s.estate[r0 >= 0 ? r0 : 0] == 4;   // row states as left by newton_update
           }
-          cz[lane] = z; cdl[lane] = d;
+          cz[lane] = z;
         }
-        uint64_t cm = wave_ballot(cz);
-        while (cm) {
-          const int ca = ffs64(cm);
-          cm &= cm - 1;
-          int cb = -1;
-          if (NVP < 64 && cm) { cb = ffs64(cm); cm &= cm - 1; }
-          const int da = wave_read(cdl, ca), db = cb >= 0 ? wave_read(cdl, cb) : 0;
-          if (da <= 3 && db <= 3) xa_cone_pass<3>(ca, cb);
-          else xa_cone_pass<6>(ca, cb);
-        }
+        conemask = wave_ballot(cz);
       }
       SYNC();
       TICK(SMJ_PROF_N_XA)
-      // H = M + XA' J on the matrix cores: the lower 16x16 tiles over dofs (3 for 32 dofs, 10 for 64), K = constraint rows.  The
-      // operands of all tiles are fetched first (XA and J column blocks, shared between tiles) and the accumulation chains are
-      // interleaved, so that neither the LDS latency nor the MFMA latency of one tile serialises the others.
+      // The lower 16x16 tiles over dofs (3 for 32 dofs, 10 for 64), K = constraint rows.  The operands of all tiles are fetched
+      // first (J column blocks, shared between tiles) and the accumulation chains are interleaved, so that neither the LDS
+      // latency nor the MFMA latency of one tile serialises the others.
       {
         constexpr int NT = NVP / 16, NTRI = NT * (NT + 1) / 2, KB = NVP == 32 ? 16 : 8;
         const int ksteps = (ne + 3) >> 2;
@@ -3487,15 +3447,16 @@ struct StepKernel {
 #pragma unroll
         for (int kb = 0; kb < NEFC / 4; kb += KB) {
           if (kb < 16 ? kb < ksteps : __builtin_expect(kb < ksteps, 0)) {
-            PL<float[KB]> a[NT], b[NT];
+            PL<float[KB]> b[NT], wk;
             LANES {
 #pragma unroll
               for (int ks = 0; ks < KB; ks++) {
                 const int k = 4 * (kb + ks) + (lane >> 4), c = lane & 15;
-                if (kb + ks < NEFC / 4) {                      // compile-time: k stays inside XA / J
-                  // unconditional: rows >= ne of XA / J are zero, and the k-steps beyond ne are skipped below anyway
+                if (kb + ks < NEFC / 4) {                      // compile-time: k stays inside J
+                  // unconditional: rows >= ne of J are zero, and the k-steps beyond ne are skipped below anyway
+                  wk[lane][ks] = s.ediag[k];
 #pragma unroll
-                  for (int t = 0; t < NT; t++) { a[t][lane][ks] = s.u.n.XA[k][16 * t + c]; b[t][lane][ks] = s.J[k][16 * t + c]; }
+                  for (int t = 0; t < NT; t++) b[t][lane][ks] = s.J[k][16 * t + c];
                 }
               }
             }
@@ -3505,7 +3466,7 @@ struct StepKernel {
                 PL<float> pa[NT], pb[NT];
                 LANES {
 #pragma unroll
-                  for (int t = 0; t < NT; t++) { pa[t][lane] = a[t][lane][ks]; pb[t][lane] = b[t][lane][ks]; }
+                  for (int t = 0; t < NT; t++) { pb[t][lane] = b[t][lane][ks]; pa[t][lane] = wk[lane][ks] * pb[t][lane]; }
                 }
 #pragma unroll
                 for (int ta = 0; ta < NT; ta++)
@@ -3513,6 +3474,37 @@ struct StepKernel {
                   for (int tb = 0; tb <= ta; tb++) mfma16x16x4(acc[ta * (ta + 1) / 2 + tb], pa[ta], pb[tb]);
               }
             }
+          }
+        }
+        // contacts in the cone zone: k = the contact's rows q = 0..dim-1 (zero-padded to 4 or 8), A = (Hc Jc)[q][:], B = Jc[q][:].
+        // cH is stored 6 x 6 with zero padding beyond the contact's condim (newton_update), rows past the block meet those zeros.
+        for (uint64_t cm = conemask; cm;) {
+          const int c = ffs64(cm);
+          cm &= cm - 1;
+          const int r0 = uni(s.cefc[c]), dim = uni(s.cdim[c]);
+          for (int q0 = 0; q0 < dim; q0 += 4) {
+            PL<float> pa[NT], pb[NT];
+            LANES {
+              const int q = q0 + (lane >> 4), col = lane & 15, qc = q < 6 ? q : 5;
+              const float on = q < dim ? 1.f : 0.f;
+              float hq[6];
+#pragma unroll
+              for (int p = 0; p < 6; p++) hq[p] = on * s.u.n.cH[c][6 * qc + p];
+#pragma unroll
+              for (int t = 0; t < NT; t++) {
+                float jv[6], av = 0.f;
+#pragma unroll
+                for (int p = 0; p < 6; p++) jv[p] = s.J[r0 + p < NEFC ? r0 + p : NEFC - 1][16 * t + col];
+#pragma unroll
+                for (int p = 0; p < 6; p++) av += hq[p] * jv[p];
+                pa[t][lane] = av;
+                pb[t][lane] = on * s.J[r0 + qc < NEFC ? r0 + qc : NEFC - 1][16 * t + col];
+              }
+            }
+#pragma unroll
+            for (int ta = 0; ta < NT; ta++)
+#pragma unroll
+              for (int tb = 0; tb <= ta; tb++) mfma16x16x4(acc[ta * (ta + 1) / 2 + tb], pa[ta], pb[tb]);
           }
         }
         LANES {
@@ -3524,7 +3516,7 @@ struct StepKernel {
               for (int r = 0; r < 4; r++) {
                 const int row = 16 * ta + (lane >> 4) * 4 + r, col = 16 * tb + (lane & 15);
                 float v = acc[ta * (ta + 1) / 2 + tb][lane].r[r];
-                v += s.MM[row][col];   // the full symmetric M, identity beyond nv (setup); acc is zero there (J, XA columns >= nv are zero)
+                v += s.MM[row][col];   // the full symmetric M, identity beyond nv (setup); acc is zero there (J columns >= nv are zero)
                 s.u.n.H[row][col] = v;
                 if (ta != tb) s.u.n.H[col][row] = v;
               }
