@@ -27,7 +27,7 @@ struct smj_ctx {
   std::string err;
   float* qpos0_dev = nullptr;
   float* stage = nullptr;      // env-major staging copy of the state, [num_envs][layout.stride] (DevState::stage)
-  int variant = 0;             // 0: standard step kernel, 1: tall, 2: big (smj_model.h)
+  int variant = 0;             // 0: standard step kernel, 1: tall, 2 / 3 / 4: big with 38 / 50 / 64 dof columns (smj_model.h)
   // capacity escalation (standard variant): the model once more with the tall variant's records, and the list of parked envs
   DevModel model_esc{};
   bool has_esc = false;
@@ -38,6 +38,7 @@ struct smj_ctx {
   int* order = nullptr;
   int balance = 1;
   int chunk = 0;               // steps per dispatch inside one smj_step (0: the whole launch at once; measured: no gain)
+  int pipeline_big = 1;        // pipelined dispatch for the two-envs-per-CU builds of the big variant too (option "pipeline_big")
   int pipeline = 5;            // chunk length of the pipelined dispatch (DevState::pipe_len; 0 = one workgroup per env for the whole launch)
   bool pollers_always = false; // option "pollers" < 0: send the pollers with every launch (tests)
   int pollers = 2;             // tall-variant workgroups that finish parked envs beside the standard kernel (0: the sweep does it all)
@@ -232,11 +233,13 @@ int smj_create(const void* blob, size_t nbytes, int num_envs, int device, smj_ct
   c->num_envs = num_envs;
   HIPCHK(c, hipSetDevice(device));
   DeviceUploader up{c};
-  SmjCaps caps[3] = {{NVP, NBP, NENT, NEFC, NCON}, {}, {}};   // standard, tall, big (smj_model.h)
-  int dbg[3] = {SMJ_DEBUG_FLOATS, 0, 0};
+  SmjCaps caps[5] = {{NVP, NBP, NENT, NEFC, NCON, 0}, {}, {}, {}, {}};   // standard, tall, big38, big50, big (smj_model.h)
+  int dbg[5] = {SMJ_DEBUG_FLOATS, 0, 0, 0, 0};
   smj_tall_caps(&caps[1].nvp, &caps[1].nbp, &caps[1].nent, &caps[1].nefc, &caps[1].ncon, &dbg[1]);
-  smj_big_caps(&caps[2].nvp, &caps[2].nbp, &caps[2].nent, &caps[2].nefc, &caps[2].ncon, &dbg[2]);
-  int rc = smj_load_model(blob, nbytes, c->model, up, c->err, caps, 3, &c->variant);
+  smj_big38_caps(&caps[2].nvp, &caps[2].nbp, &caps[2].nent, &caps[2].nefc, &caps[2].ncon, &dbg[2], &caps[2].nvs);
+  smj_big50_caps(&caps[3].nvp, &caps[3].nbp, &caps[3].nent, &caps[3].nefc, &caps[3].ncon, &dbg[3], &caps[3].nvs);
+  smj_big_caps(&caps[4].nvp, &caps[4].nbp, &caps[4].nent, &caps[4].nefc, &caps[4].ncon, &dbg[4], &caps[4].nvs);
+  int rc = smj_load_model(blob, nbytes, c->model, up, c->err, caps, 5, &c->variant);
   if (rc) return rc;
   c->caps = caps[c->variant];
   c->layout = smj_stage_layout(c->caps.nvp, c->caps.nbp);
@@ -489,9 +492,9 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
   const int chunk = (c->chunk > 0 && !st.debug && !st.prof && c->num_envs > 1024) ? c->chunk : nsteps;
   // Pipelined chunks (standard variant, batches that need more than one round of workgroups): see DevState::pipe_len
   hipStream_t sm = (hipStream_t)stream;
-  // measured: standard +19 % at chunks of 5, tall (2 envs per CU) +7 % at 10, big (1 env per CU, 16 rounds of workgroups) nothing
-  const int pipe_len = c->variant == 1 ? 2 * c->pipeline : c->pipeline;
-  const bool pipe = c->variant != 2 && c->pipeline > 0 && chunk == nsteps && nsteps > pipe_len && !st.debug && !st.prof && c->num_envs > 1024;
+  // measured: standard +19 % at chunks of 5, tall (2 envs per CU) +7 % at 10, big with 64 columns (1 env per CU, 16 rounds of workgroups) nothing
+  const int pipe_len = c->variant >= 1 ? 2 * c->pipeline : c->pipeline;
+  const bool pipe = c->variant != 4 && (c->variant < 2 || c->pipeline_big) && c->pipeline > 0 && chunk == nsteps && nsteps > pipe_len && !st.debug && !st.prof && c->num_envs > 1024;
   st.progress = st.done_steps = st.sched = st.hot = nullptr;
   if (esc || pipe) {
     st.progress = c->progress;
@@ -545,7 +548,9 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
       HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
     }
     if (!lrc)
-      lrc = c->variant == 2   ? smj_launch_step_big(c->model, st, k, fl, sm)
+      lrc = c->variant == 4   ? smj_launch_step_big(c->model, st, k, fl, sm)
+            : c->variant == 3 ? smj_launch_step_big50(c->model, st, k, fl, sm)
+            : c->variant == 2 ? smj_launch_step_big38(c->model, st, k, fl, sm)
             : c->variant == 1 ? smj_launch_step_tall(c->model, st, k, fl, sm)
             : st.prof         ? smj_launch_step_prof(c->model, st, k, fl, sm)
                               : smj_launch_step(c->model, st, k, fl, sm);
@@ -651,6 +656,7 @@ int smj_set_option(smj_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "balance")) c->balance = (int)v;
   else if (!strcmp(name, "chunk")) c->chunk = (int)v;
   else if (!strcmp(name, "pipeline")) c->pipeline = (int)v;
+  else if (!strcmp(name, "pipeline_big")) c->pipeline_big = (int)v;
   else if (!strcmp(name, "pollers")) {   // n > 0: n pollers when a recent launch escalated; -n: n pollers with every launch; 0: none
     c->pollers_always = v < 0;
     const int n = (int)(v < 0 ? -v : v);

@@ -24,9 +24,13 @@ struct StagePlan {
 int smj_launch_step(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);
 int smj_launch_step_prof(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);   // standard + cycle counters
 int smj_launch_step_tall(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);
-int smj_launch_step_big(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);
+int smj_launch_step_big(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);     // 64 dof columns
+int smj_launch_step_big38(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);   // 38
+int smj_launch_step_big50(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);   // 50
 void smj_tall_caps(int* nvp, int* nbp, int* nent, int* nefc, int* ncon, int* debug_floats);
-void smj_big_caps(int* nvp, int* nbp, int* nent, int* nefc, int* ncon, int* debug_floats);
+void smj_big_caps(int* nvp, int* nbp, int* nent, int* nefc, int* ncon, int* debug_floats, int* nvs);
+void smj_big38_caps(int* nvp, int* nbp, int* nent, int* nefc, int* ncon, int* debug_floats, int* nvs);
+void smj_big50_caps(int* nvp, int* nbp, int* nent, int* nefc, int* ncon, int* debug_floats, int* nvs);
 void smj_launch_reset(const DevModel& m, const DevState& s, const uint8_t* mask, hipStream_t stream);
 // batch-major -> env-major staging rows (import) and back (export); tiles of 64 envs transposed through LDS
 void smj_launch_stage(const StagePlan& plan, float* stage, int stride, int B, long ld, bool is_export, hipStream_t stream);

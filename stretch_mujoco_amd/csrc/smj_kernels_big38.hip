@@ -1,9 +1,9 @@
 // The big capacity variant of the step kernel (64 dof lanes, 160 constraint rows, 48 contacts; smj_model.h): scenes with several
-// free objects -- the reference's own scene.xml (table + 2 objects, models/scene.xml:21-35) and the kitchens.  This build: the full 64 dof columns
-// (136 KB of LDS per env, one env per CU) -- the fallback for models beyond 50 dofs.
+// free objects -- the reference's own scene.xml (table + 2 objects, models/scene.xml:21-35) and the kitchens.  This build: 38 dof columns
+// (the robot + two free objects: scene.xml), under 80 KB of LDS per env: two envs per CU.
 #define SMJ_BIG 1
-#define SMJ_NVS 64
-#define SMJ_VARIANT_TAG big
+#define SMJ_NVS 38
+#define SMJ_VARIANT_TAG big38
 #ifndef SMJ_PROFILING
 #define SMJ_PROFILING 0   // the per-stage cycle counters cost registers; tools build a profiling copy with -DSMJ_PROFILING=1
 #endif

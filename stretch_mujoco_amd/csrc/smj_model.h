@@ -15,7 +15,13 @@
 //               64 dofs, 160 rows, 48 contacts; ~130 KB of LDS per env, one env per CU.
 // smj_create picks the variant from the model's dimensions (and the model compiler's capacity hint).
 #if defined(SMJ_BIG)
-#define NVP 64    // dof capacity (model nv <= NVP)
+#define NVP 64    // dof LANES (lane = dof stages run on 64 lanes)
+#ifndef SMJ_NVS
+#define SMJ_NVS 64
+#endif
+#define NVS SMJ_NVS   // dof COLUMNS of the LDS-resident matrices J / M / H (model nv <= NVS): the big variant is built three times,
+                      // for 38 (the reference's scene.xml: robot + 2 free objects), 50 (robot + 4) and 64 dofs -- with 38 / 50
+                      // columns an env's working set stays under 80 KB of LDS and two envs share a CU
 #define NEFC 160  // constraint-row capacity of the Newton path: rows 64.. take further passes on lanes 0..63 (PGS: 64)
 #define NCON 48   // contact capacity (<= 64: contact stages are lane = contact)
 #define NENT 8    // mass-matrix pattern entries per lane (64 lanes)
@@ -30,6 +36,10 @@
 #define NCON 16
 #define NENT 5
 #endif
+#ifndef NVS
+#define NVS NVP
+#endif
+static_assert(NVS % 2 == 0 && NVS <= NVP && (NVP == 64 ? NVS >= 38 : NVS == NVP), "column capacity: even (packed pairs), odd row stride NVS + 1");
 #define NBP 32   // fused-body capacity
 #define NCG 128  // geoms that take part in non-plane collision pairs (world-frame cache of the broadphase)
 

@@ -44,7 +44,7 @@ struct SmjBlob {
 // Host restatement of what the kernel's stage-table loaders (smj_step_impl.h: KinTab, BodyTab, DofTab, EntryTab, ActTab)
 // used to gather per lane from the individual tables, one record per lane.
 // capacities of a kernel variant (smj_model.h): the loader builds its records for the variant that will run
-struct SmjCaps { int nvp, nbp, nent, nefc, ncon; };
+struct SmjCaps { int nvp, nbp, nent, nefc, ncon, nvs; };   // nvs: dof columns of the variant's matrices (0: nvp)
 static inline std::vector<int> smj_build_lanerec(const DevModel& m, std::map<std::string, std::vector<int>>& I,
                                                  std::map<std::string, std::vector<float>>& F, int nent) {
   const int LR_ACT = smj_lr_act(nent), LR_STRIDE = smj_lr_stride(nent);
@@ -270,7 +270,7 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
     if (hint > 0 && ncaps > 1) first = 1;   // skip the standard variant: tall if the model fits it, else big
   }
   for (int v = first; v < ncaps && pick < 0; v++)
-    if (m.nv <= caps[v].nvp && m.nbody <= caps[v].nbp && m.nq <= caps[v].nvp + 8 && m.nldl <= caps[v].nent * 64) pick = v;
+    if (m.nv <= (caps[v].nvs ? caps[v].nvs : caps[v].nvp) && m.nbody <= caps[v].nbp && m.nq <= caps[v].nvp + 8 && m.nldl <= caps[v].nent * 64) pick = v;
   if (pick < 0 || m.nu > 16) {
     const SmjCaps& c = caps[ncaps - 1];
     snprintf(buf, sizeof buf, "model exceeds kernel capacity (nv %d<=%d, nbody %d<=%d, nq %d<=%d, nu %d<=16, mass-matrix entries %d<=%d)",

@@ -15,8 +15,9 @@
 #include "smj_model.h"
 #include "smj_wave.h"
 
-#define JS (NVP + 1)
-#define MS (NVP + 1)
+// NVS: columns the dof-indexed matrices (J, M, H) hold -- the 64-lane variant is built for 40, 52 or 64 dofs (smj_model.h)
+#define JS (NVS + 1)
+#define MS (NVS + 1)
 #define SMJ_MINVAL 1e-15f
 #define SMJ_MINIMP 0.0001f
 #define SMJ_MAXIMP 0.9999f
@@ -31,7 +32,7 @@ struct TreeTmp {  // lives in the A region until A is built
 
 #define NEFP 64   // PGS row capacity (rows = lanes in the PGS sweeps)
 struct Smem {
-  float MM[NVP][MS];    // strict upper: M; lower + diag: working copy -> L (unit, strictly lower), D on diag
+  float MM[NVS][MS];    // strict upper: M; lower + diag: working copy -> L (unit, strictly lower), D on diag
   float Mdiag[NVP], Dinv[NVP];
   float xpos[NBP][3], xquat[NBP][4], xmat[NBP][9], com[NBP][3];
   float xaxis[NVP][3], xanchor[NVP][3];
@@ -67,12 +68,14 @@ struct Smem {
       float cd[NVP][6];     // cdof, so that both half-waves of the Jacobian fill can read any dof's motion axis
     } k;
     struct {                // Newton: the Hessian H = M + J' W J (or M - h*D of the integrator)
-      float H[NVP][NVP + 1];
-      float cH[NCON][36];   // cone Hessians of contacts in the middle zone
+      union {               // the cone Hessians are consumed (as MFMA operands) before the Hessian of the same iteration is written
+        float H[NVS][NVS + 1];
+        float cH[NCON][36];   // cone Hessians of contacts in the middle zone
+      };
       // per-row solver registers (NRow) of rows 64..NEFC-1: the second row pass loads them at the start of a stage and
       // stores them back at its end, so that the (rare) second pass holds no registers across the Newton loop
       int rxi[3][NEFC > 64 ? NEFC - 64 : 1];      // indexed by row - 64
-      float rxf[17][NEFC > 64 ? NEFC - 64 : 1];
+      float rxf[15][NEFC > 64 ? NEFC - 64 : 1];
     } n;
   } u;
   SMJ_DEV float* A() { return &J[NEFP][0]; }
@@ -333,7 +336,7 @@ struct StepKernel {
   SMJ_DEV void setup() {
     LANES {
       // zero the factor storage once: the sparsity pattern is static, non-pattern entries stay zero
-      for (int k = lane; k < NVP * MS; k += 64) (&s.MM[0][0])[k] = 0.f;
+      for (int k = lane; k < NVS * MS; k += 64) (&s.MM[0][0])[k] = 0.f;
       // world body
       if (lane == 0) {
         s.xpos[0][0] = s.xpos[0][1] = s.xpos[0][2] = 0;
@@ -344,7 +347,7 @@ struct StepKernel {
     SYNC();
     // identity padding of the dof block nv..NVP-1, written once: the per-step mass-matrix entries never touch it, and the
     // Newton Hessian H = M + J'WJ / the dense M x products can then take MM as it is, with no `< nv` select per element
-    LANES { if (lane >= M.nv && lane < NVP) s.MM[lane][lane] = 1.f; }
+    LANES { if (lane >= M.nv && lane < NVS) s.MM[lane][lane] = 1.f; }
     SYNC();
   }
 
@@ -2917,14 +2920,14 @@ struct StepKernel {
     PL<float[7]> cq;                  // u0 v0 uu uv vv Dm mu   (first row of an elliptic contact)
   };
 
-  enum { RX_AREF = 0, RX_D, RX_R, RX_FL, RX_JAR, RX_JV, RX_FORCE, RX_Q0, RX_Q1, RX_Q2, RX_CQ };
+  enum { RX_AREF = 0, RX_D, RX_JAR, RX_JV, RX_FORCE, RX_Q0, RX_Q1, RX_Q2, RX_CQ };   // R and the friction loss stay where make_constraint left them (s.eR, s.efloss)
   SMJ_DEV void rx_load(NRow& t, int rb) {
     LANES {
       const bool on = lane + rb < NEFC;
       const int l = on ? lane + rb - 64 : 0;
       t.type[lane] = on ? s.u.n.rxi[0][l] : CT_NONE; t.state[lane] = on ? s.u.n.rxi[1][l] : 0; t.c0[lane] = on ? s.u.n.rxi[2][l] : -1;
-      t.aref[lane] = on ? s.u.n.rxf[RX_AREF][l] : 0.f; t.D[lane] = on ? s.u.n.rxf[RX_D][l] : 0.f; t.R[lane] = on ? s.u.n.rxf[RX_R][l] : 1.f;
-      t.fl[lane] = on ? s.u.n.rxf[RX_FL][l] : 0.f; t.jar[lane] = on ? s.u.n.rxf[RX_JAR][l] : 0.f; t.jv[lane] = on ? s.u.n.rxf[RX_JV][l] : 0.f;
+      t.aref[lane] = on ? s.u.n.rxf[RX_AREF][l] : 0.f; t.D[lane] = on ? s.u.n.rxf[RX_D][l] : 0.f; t.R[lane] = on ? s.eR[l + 64] : 1.f;
+      t.fl[lane] = on ? s.efloss[l + 64] : 0.f; t.jar[lane] = on ? s.u.n.rxf[RX_JAR][l] : 0.f; t.jv[lane] = on ? s.u.n.rxf[RX_JV][l] : 0.f;
       t.force[lane] = on ? s.u.n.rxf[RX_FORCE][l] : 0.f;
       t.q0[lane] = on ? s.u.n.rxf[RX_Q0][l] : 0.f; t.q1[lane] = on ? s.u.n.rxf[RX_Q1][l] : 0.f; t.q2[lane] = on ? s.u.n.rxf[RX_Q2][l] : 0.f;
       for (int k = 0; k < 7; k++) t.cq[lane][k] = on ? s.u.n.rxf[RX_CQ + k][l] : 0.f;
@@ -2935,8 +2938,8 @@ struct StepKernel {
       if (lane + rb < NEFC) {
         const int l = lane + rb - 64;
         s.u.n.rxi[0][l] = t.type[lane]; s.u.n.rxi[1][l] = t.state[lane]; s.u.n.rxi[2][l] = t.c0[lane];
-        s.u.n.rxf[RX_AREF][l] = t.aref[lane]; s.u.n.rxf[RX_D][l] = t.D[lane]; s.u.n.rxf[RX_R][l] = t.R[lane];
-        s.u.n.rxf[RX_FL][l] = t.fl[lane]; s.u.n.rxf[RX_JAR][l] = t.jar[lane]; s.u.n.rxf[RX_JV][l] = t.jv[lane];
+        s.u.n.rxf[RX_AREF][l] = t.aref[lane]; s.u.n.rxf[RX_D][l] = t.D[lane];
+        s.u.n.rxf[RX_JAR][l] = t.jar[lane]; s.u.n.rxf[RX_JV][l] = t.jv[lane];
         s.u.n.rxf[RX_FORCE][l] = t.force[lane];
         s.u.n.rxf[RX_Q0][l] = t.q0[lane]; s.u.n.rxf[RX_Q1][l] = t.q1[lane]; s.u.n.rxf[RX_Q2][l] = t.q2[lane];
         for (int k = 0; k < 7; k++) s.u.n.rxf[RX_CQ + k][l] = t.cq[lane][k];
@@ -3054,15 +3057,16 @@ struct StepKernel {
   // full symmetric M (both triangles + diagonal, identity beyond nv) and lane i reads its row as it is -- no select per element.
   // Lanes 32..63 mirror lanes 0..31; their y is never used.
   SMJ_DEV void mat_M(PL<float>& y, const PL<float>& x) {
-    PL<float[NVP]> m;   // row `lane` of M: all LDS reads are issued before the first use (fixed trip count)
+    PL<float[NVS]> m;   // row `lane` of M: all LDS reads are issued before the first use (fixed trip count)
     LANES {
+      const int i = NVS == 32 ? (lane & 31) : (lane < NVS ? lane : NVS - 1);   // lanes beyond the matrix: any row, y unused
 #pragma unroll
-      for (int j = 0; j < NVP; j++) m[lane][j] = s.MM[lane & (NVP - 1)][j];
+      for (int j = 0; j < NVS; j++) m[lane][j] = s.MM[i][j];
     }
     PL<F2> acc;
     LANES { acc[lane] = F2{0.f, 0.f}; }
 #pragma unroll
-    for (int j = 0; j < NVP; j += 2) {
+    for (int j = 0; j < NVS; j += 2) {
       const float x0 = wave_read(x, j), x1 = wave_read(x, j + 1);
       LANES { pk_fma(acc[lane], m[lane][j], m[lane][j + 1], x0, x1); }
     }
@@ -3075,16 +3079,16 @@ struct StepKernel {
   SMJ_DEV void mat_J_exact(PL<float>& out, const PL<float>& x, const PL<float>& sub, int rb) {
     // the row is fetched up front (fixed trip count: columns >= nv of J and entries >= nv of x are zero) and the compensated
     // sum runs as two independent chains (even / odd columns), merged by a last TwoSum
-    PL<float[NVP]> a;
+    PL<float[NVS]> a;
     PL<float> hi0, lo0, hi1, lo1;
     LANES {
       const int row = lane + rb < NEFC ? lane + rb : 0;
 #pragma unroll
-      for (int k = 0; k < NVP; k++) a[lane][k] = s.J[row][k];
+      for (int k = 0; k < NVS; k++) a[lane][k] = s.J[row][k];
       hi0[lane] = -sub[lane]; lo0[lane] = 0.f; hi1[lane] = 0.f; lo1[lane] = 0.f;
     }
 #pragma unroll
-    for (int k = 0; k < NVP; k += 2) {
+    for (int k = 0; k < NVS; k += 2) {
       const float x0 = wave_read(x, k), x1 = wave_read(x, k + 1);
       LANES {
         {
@@ -3121,7 +3125,7 @@ struct StepKernel {
 #pragma unroll
           // rows >= ne of J are zero.  Lanes 32..63 mirror lanes 0..31 (their `out` is never used): no `lane < NVP` select --
           // that mask, hoisted and spilled, was reloaded with two v_readlane per use
-          for (int u = 0; u < 16; u++) a[lane][u] = s.J[r0 + u][lane & (NVP - 1)];
+          for (int u = 0; u < 16; u++) a[lane][u] = s.J[r0 + u][NVS == 32 ? (lane & 31) : (lane < NVS ? lane : 0)];
         }
         PL<F2> acc;
         LANES { acc[lane] = F2{0.f, 0.f}; }
@@ -3137,16 +3141,16 @@ struct StepKernel {
   }
   // out[row] = J[row] . x   (lane = row - rb, x lane-resident over dofs; columns nv..NVP of J are zero)
   SMJ_DEV void mat_J(PL<float>& out, const PL<float>& x, int rb) {
-    PL<float[NVP]> a;
+    PL<float[NVS]> a;
     LANES {
       const int row = lane + rb < NEFC ? lane + rb : 0;
 #pragma unroll
-      for (int k = 0; k < NVP; k++) a[lane][k] = s.J[row][k];
+      for (int k = 0; k < NVS; k++) a[lane][k] = s.J[row][k];
     }
     PL<F2> acc;
     LANES { acc[lane] = F2{0.f, 0.f}; }
 #pragma unroll
-    for (int k = 0; k < NVP; k += 2) {
+    for (int k = 0; k < NVS; k += 2) {
       const float x0 = wave_read(x, k), x1 = wave_read(x, k + 1);
       LANES { pk_fma(acc[lane], a[lane][k], a[lane][k + 1], x0, x1); }
     }
@@ -3164,7 +3168,7 @@ struct StepKernel {
   // FMAs (v_pk_fma_f32) apply them -- two columns per FMA, and enough distance between a v_readlane and the FMA that consumes
   // its SGPR that no hazard s_nop is needed (they were 15 % of the solve's instructions with one column pair per step).
   template <int K, int J, int N>
-  SMJ_DEV void gj_pair(PL<float[NVP]>& hrow, const PL<float>& mult) {
+  SMJ_DEV void gj_pair(PL<float[NVS]>& hrow, const PL<float>& mult) {
     if constexpr (J + 3 < N) {
       PL<float> c0, c1, c2, c3;
       LANES { c0[lane] = hrow[lane][J]; c1[lane] = hrow[lane][J + 1]; c2[lane] = hrow[lane][J + 2]; c3[lane] = hrow[lane][J + 3]; }
@@ -3208,7 +3212,7 @@ struct StepKernel {
     }
   }
   template <int K, int N>
-  SMJ_DEV void gj_cols(PL<float[NVP]>& hrow, PL<float>& x, PL<float>& pinv, const PL<int>& ol) {
+  SMJ_DEV void gj_cols(PL<float[NVS]>& hrow, PL<float>& x, PL<float>& pinv, const PL<int>& ol) {
     if constexpr (K < N) {
       PL<float> col, mult;
       LANES { col[lane] = hrow[lane][K]; }
@@ -3228,14 +3232,14 @@ struct StepKernel {
   // N = matrix order actually eliminated (rows / columns >= nv are identity padding and never touched)
   template <int N>
   SMJ_DEV void gj_solve(PL<float>& x) {
-    PL<float[NVP]> hrow;
+    PL<float[NVS]> hrow;
     PL<float> pinv;
     PL<int> ol;
     LANES { ol[lane] = opaque(lane); }
     LANES {
       // lanes >= N: rows N..31 are identity padding (never touched by the elimination), lanes 32..63 mirror lanes 0..31;
       // their x is zeroed below and scaled by pinv = 0 at the end, so they need no `lane < N` select per element
-      const int i = lane & (NVP - 1);
+      const int i = NVS == 32 ? (lane & 31) : (lane < NVS ? lane : NVS - 1);
 #pragma unroll
       for (int k = 0; k < N; k++) hrow[lane][k] = s.u.n.H[i][k];
       pinv[lane] = 0.f;
@@ -3249,7 +3253,7 @@ struct StepKernel {
   // solver's per-row state do not fit the register file (the unrolled version spilled to scratch and took 30x longer).
   SMJ_DEV void gj_solve_lds(PL<float>& x) {
     const int n = M.nv;
-    LANES { if (lane < NVP) s.u.n.H[lane][NVP] = lane < n ? x[lane] : 0.f; }
+    LANES { if (lane < NVS) s.u.n.H[lane][NVS] = lane < n ? x[lane] : 0.f; }
     SYNC();
     for (int k = 0; k < n; k++) {
       const float rp = fast_rcp(fmaxf(uni(s.u.n.H[k][k]), 1e-30f));
@@ -3268,12 +3272,12 @@ struct StepKernel {
             for (int u = 0; u < 8; u++) row[j + u] = a[u] - mult * b[u];
           }
           for (; j < n; j++) row[j] -= mult * piv[j];
-          row[NVP] -= mult * piv[NVP];
+          row[NVS] -= mult * piv[NVS];
         }
       }
       SYNC();
     }
-    LANES { x[lane] = lane < n ? s.u.n.H[lane][NVP] * fast_rcp(fmaxf(s.u.n.H[lane][lane], 1e-30f)) : 0.f; }
+    LANES { x[lane] = lane < n ? s.u.n.H[lane][NVS] * fast_rcp(fmaxf(s.u.n.H[lane][lane], 1e-30f)) : 0.f; }
     SYNC();
   }
   SMJ_DEV void solve_H(PL<float>& x, bool rare = false) {
@@ -3281,11 +3285,13 @@ struct StepKernel {
     if (M.nv <= 26) gj_solve<26>(x);   // Stretch: 26 dofs; a third fewer column pairs than the full 32
     else gj_solve<NVP>(x);
 #else
-    // the 64-dof variant: the robot with two free objects (the reference's scene.xml: 38 dofs) or four (50 dofs) in registers,
+    // the 64-lane variants: the robot with two free objects (the reference's scene.xml: 38 dofs) or four (50 dofs) in registers,
     // anything larger -- and the call sites that hardly ever run -- with the matrix left in LDS
     if (rare || M.nv > 50) gj_solve_lds(x);
-    else if (M.nv <= 38) gj_solve<38>(x);
-    else gj_solve<50>(x);
+#if NVS >= 50
+    else if (M.nv > 38) gj_solve<50>(x);
+#endif
+    else gj_solve<38>(x);
 #endif
   }
 
@@ -3435,7 +3441,7 @@ struct StepKernel {
       // first (J column blocks, shared between tiles) and the accumulation chains are interleaved, so that neither the LDS
       // latency nor the MFMA latency of one tile serialises the others.
       {
-        constexpr int NT = NVP / 16, NTRI = NT * (NT + 1) / 2, KB = NVP == 32 ? 16 : 8;
+        constexpr int NT = (NVS + 15) / 16, NTRI = NT * (NT + 1) / 2, KB = NVP == 32 ? 16 : 8;   // (the last tile may read past column NVS: those products land in rows / columns >= NVS of H, which are not stored)
         const int ksteps = (ne + 3) >> 2;
         PL<F4v> acc[NTRI];
         LANES {
@@ -3515,10 +3521,12 @@ struct StepKernel {
 #pragma unroll
               for (int r = 0; r < 4; r++) {
                 const int row = 16 * ta + (lane >> 4) * 4 + r, col = 16 * tb + (lane & 15);
-                float v = acc[ta * (ta + 1) / 2 + tb][lane].r[r];
-                v += s.MM[row][col];   // the full symmetric M, identity beyond nv (setup); acc is zero there (J columns >= nv are zero)
-                s.u.n.H[row][col] = v;
-                if (ta != tb) s.u.n.H[col][row] = v;
+                if (NVS % 16 == 0 || (row < NVS && col < NVS)) {
+                  float v = acc[ta * (ta + 1) / 2 + tb][lane].r[r];
+                  v += s.MM[row][col];   // the full symmetric M, identity beyond nv (setup); acc is zero there (J columns >= nv are zero)
+                  s.u.n.H[row][col] = v;
+                  if (ta != tb) s.u.n.H[col][row] = v;
+                }
               }
             }
         }
@@ -3647,8 +3655,8 @@ struct StepKernel {
     EntryTab et;
     load(et, implicit);
     LANES {
-      for (int k = lane; k < NVP * (NVP + 1); k += 64) {
-        const int r = k / (NVP + 1), c = k - r * (NVP + 1);
+      for (int k = lane; k < NVS * (NVS + 1); k += 64) {
+        const int r = k / (NVS + 1), c = k - r * (NVS + 1);
         (&s.u.n.H[0][0])[k] = (r == c && r >= M.nv) ? 1.f : 0.f;
       }
     }

@@ -6,9 +6,11 @@
 #include "smj_kernels.h"
 #include "smj_step_impl.h"
 
-#if defined(SMJ_BIG)
-#define SMJ_STEP_KERNEL smj_step_kernel_big
-#define SMJ_LAUNCH_STEP smj_launch_step_big
+#define SMJ_CAT2(a, b) a##b
+#define SMJ_CAT(a, b) SMJ_CAT2(a, b)
+#if defined(SMJ_BIG)   // three builds: SMJ_VARIANT_TAG = big38 / big50 / big (column capacity SMJ_NVS, smj_model.h)
+#define SMJ_STEP_KERNEL SMJ_CAT(smj_step_kernel_, SMJ_VARIANT_TAG)
+#define SMJ_LAUNCH_STEP SMJ_CAT(smj_launch_step_, SMJ_VARIANT_TAG)
 #elif defined(SMJ_TALL)
 #define SMJ_STEP_KERNEL smj_step_kernel_tall
 #define SMJ_LAUNCH_STEP smj_launch_step_tall
@@ -161,7 +163,11 @@ __global__ __launch_bounds__(64) void smj_step_kernel_tall_worker(const DevModel
 
 int SMJ_LAUNCH_STEP(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream) {
   const size_t lds = smj_lds_bytes(m.solver != 2);
-  static size_t lds_allowed = 64 * 1024;
+  static size_t lds_allowed_dev[64] = {};   // per device: the attribute belongs to the device's copy of the kernel
+  int dev_now = 0;
+  (void)hipGetDevice(&dev_now);
+  size_t& lds_allowed = lds_allowed_dev[dev_now & 63];
+  if (lds_allowed == 0) lds_allowed = 64 * 1024;
   if (lds > lds_allowed) {   // beyond the default 64 KB per workgroup: raise the kernels' dynamic-LDS limit once (gfx950: 160 KB per CU)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(SMJ_STEP_KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #if defined(SMJ_TALL)
@@ -182,3 +188,10 @@ int SMJ_LAUNCH_STEP(const DevModel& m, const DevState& s, int nsteps, unsigned r
   hipLaunchKernelGGL(SMJ_STEP_KERNEL, dim3(grid), dim3(64), lds, stream, m, s, nsteps, read_flags);
   return 0;
 }
+
+#if defined(SMJ_BIG)
+// capacities and layouts of this build for the host side (smj_capi.hip is compiled for the standard variant)
+void SMJ_CAT(SMJ_CAT(smj_, SMJ_VARIANT_TAG), _caps)(int* nvp, int* nbp, int* nent, int* nefc, int* ncon, int* debug_floats, int* nvs) {
+  *nvp = NVP; *nbp = NBP; *nent = NENT; *nefc = NEFC; *ncon = NCON; *debug_floats = SMJ_DEBUG_FLOATS; *nvs = NVS;
+}
+#endif

@@ -17,7 +17,7 @@ def lib(variant: str = "standard"):
     big = variant   # cache key
     if big not in _LIB:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
-        L = ctypes.CDLL(os.path.join(_HERE, {"standard": "libsmj_emul.so", "tall": "libsmj_emul_tall.so", "big": "libsmj_emul_big.so", "poison": "libsmj_emul_poison.so"}[variant]))
+        L = ctypes.CDLL(os.path.join(_HERE, {"standard": "libsmj_emul.so", "tall": "libsmj_emul_tall.so", "big": "libsmj_emul_big.so", "big38": "libsmj_emul_big38.so", "big50": "libsmj_emul_big50.so", "poison": "libsmj_emul_poison.so"}[variant]))
         L.emul_create.restype = ctypes.c_void_p
         L.emul_create.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
         L.emul_bind.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_long]
@@ -33,15 +33,15 @@ class Emul:
         """variant: "standard" (32 dofs / 80 rows / 16 contacts), "tall" (32 / 160 / 48) or "big" (64 / 160 / 48); default: chosen
         like smj_create does, by the model's size and the blob's capacity hint.  `big=True` is shorthand for variant="big"."""
         if variant is None:
-            if big or dims["nv"] > 32:
-                variant = "big"
+            if big or dims["nv"] > 32:   # the big variant is built for 38 / 50 / 64 dof columns (smj_model.h); big=True with a small model: 64
+                variant = "big38" if 32 < dims["nv"] <= 38 else "big50" if 38 < dims["nv"] <= 50 else "big"
             else:
                 import stretch_mujoco_amd.model_blob as mb
 
                 hint = mb.loads(blob).get("k_capacity_hint")
                 variant = "tall" if hint is not None and int(np.asarray(hint).ravel()[0]) > 0 else "standard"
         self.variant = variant
-        self.big = variant == "big"
+        self.big = variant.startswith("big")
         self.L = lib(variant)
         self.nvp, self.ncon_max = self.L.emul_nvp(), self.L.emul_ncon_max()
         self.B = B = num_envs

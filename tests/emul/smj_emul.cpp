@@ -40,7 +40,7 @@ extern "C" {
 emul_ctx* emul_create(const void* blob, size_t nbytes, int num_envs) {
   emul_ctx* c = new emul_ctx();
   HostUploader up{&c->keep};
-  const SmjCaps caps{NVP, NBP, NENT, NEFC, NCON};   // this build's variant (Makefile: -DSMJ_BIG for libsmj_emul_big.so)
+  const SmjCaps caps{NVP, NBP, NENT, NEFC, NCON, NVS};   // this build's variant (Makefile: -DSMJ_BIG for libsmj_emul_big.so)
   int chosen = 0;
   if (smj_load_model(blob, nbytes, c->m, up, c->err, &caps, 1, &chosen)) {
     fprintf(stderr, "emul_create: %s\n", c->err.c_str());
