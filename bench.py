@@ -141,14 +141,22 @@ def other_configs(B, dev, hold, solver):
 
     def flags_of(sim):
         f = sim.info[3]
-        return {"overflow_flags": int(torch.bitwise_or(torch.bitwise_or((f & 1).max(), (f & 2).max()), (f & 4).max()).item()),
-                "envs_flagged": float((f != 0).float().mean().item())}
+        # bits: 1 row overflow, 2 contact overflow, 4 bad-state reset, 8 pipeline time-out (the env ran fewer steps than asked)
+        return {"overflow_flags": int(torch.bitwise_or(torch.bitwise_or((f & 1).max(), (f & 2).max()), torch.bitwise_or((f & 4).max(), (f & 8).max())).item()),
+                "envs_flagged": float((f != 0).float().mean().item()),
+                "steps_min_max": [int(sim.nstep.min().item()), int(sim.nstep.max().item())]}
 
-    # config 2: 1024 envs, physics only
-    sim = StretchBatchSimulator(num_envs=1024, device=str(dev), solver=solver)
-    sim.start(home=False)
-    res["config2_1024_envs_physics"] = {"value": rollout(sim, 200, hold), "unit": "env-steps/s"}
-    sim.stop()
+    # config 2: 1024 envs, physics only -- and the per-rank shares of BASELINE.json's metric (4096 envs IN TOTAL at 2 / 4 / 8 GPUs =
+    # 2048 / 1024 / 512 envs per rank), measured on this one GPU: what a strong-scaling run can reach per rank.  At <= 1024 envs
+    # every env has a wave slot of its own (256 CUs x 4), so a launch lasts as long as its slowest env.
+    share = {}
+    for nb in (2048, 1024, 512):
+        sim = StretchBatchSimulator(num_envs=nb, device=str(dev), solver=solver)
+        sim.start(home=False)
+        share[str(nb)] = {"value": rollout(sim, 200, hold), "unit": "env-steps/s", **flags_of(sim)}
+        sim.stop()
+    res["config2_1024_envs_physics"] = {"value": share["1024"]["value"], "unit": "env-steps/s"}
+    res["strong_scaling_rank_share"] = {"envs_per_rank": share, "note": "empty scene, physics only, one GPU: the per-rank batch of 4096 envs in total at 2 / 4 / 8 GPUs"}
     # config 3: + joint readout, IMU, 2-D lidar; at 15 Hz sim-time (every 33 steps) and every step
     sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver=solver, sensors_to_use=StretchSensors.all())
     sim.start(home=False)
@@ -323,8 +331,11 @@ def main():
         all_returns = parallel.gather_returns(returns)
         gather_path = f"torch.distributed all_gather_into_tensor (the library's RCCL path failed: {type(e).__name__}: {e})"
     f = sim.info[3]
-    flags = int(((f & 1).max() | (f & 2).max() | (f & 4).max()).item())   # union of the sticky overflow / bad-state bits
+    flags = int(((f & 1).max() | (f & 2).max() | (f & 4).max() | (f & 8).max()).item())   # union of the sticky overflow / bad-state / time-out bits
     flagged = float((f != 0).float().mean().item())
+    # bit 8 = a pipelined chunk gave up waiting: that env ran fewer steps than asked and the env-step count below would be wrong
+    if flags & 8 or int(sim.nstep.min().item()) != int(sim.nstep.max().item()):
+        raise SystemExit(f"bench.py: envs ran different step counts ({int(sim.nstep.min())}..{int(sim.nstep.max())}, flags {flags}): pipeline time-out, the measurement is void")
     kern_ms = sum(a.elapsed_time(b) for a, b, _ in events)
     kern_steps = sum(k for _, _, k in events)
     total_env_steps = float(B_total) * args.steps
@@ -384,8 +395,12 @@ def main():
                 k = min(hold, n2 - d2)
                 random_action(); sim.step(k); d2 += k
             torch.cuda.synchronize(dev)
+            f2 = sim.info[3]
             out["other_solver"] = {"solver": other, "value": B * n2 / (time.perf_counter() - t1), "unit": "env-steps/s",
-                                   "n_gpus": 1, "steps": n2, "note": "rank 0 only, same workload, measured after the timed region"}
+                                   "n_gpus": 1, "steps": n2, "envs_flagged": float((f2 != 0).float().mean().item()),
+                                   "flags_union": int(((f2 & 1).max() | (f2 & 2).max() | (f2 & 4).max() | (f2 & 8).max()).item()),
+                                   "note": "rank 0 only, same workload, measured after the timed region; envs_flagged counts envs that ran out of "
+                                           "constraint rows / contacts since the reset (flags are sticky: the Newton phase before contributes none)"}
         import __graft_entry__ as _ge
         out["parity_oracle"] = _ge.mujoco_status()
         if not args.no_extra and world == 1:

@@ -417,14 +417,16 @@ struct StepKernel {
         // the state words go out device-coherent (st_coh): the env's next chunk may run on another XCD (DevState::pipe_len)
         for (int k = lane; k < M.nq; k += 64) st_coh(&st[S.lay.qpos + k], s.qpos[k]);
         if (lane < M.nv) { st_coh(&st[S.lay.qvel + lane], s.qvel[lane]); st_coh(&st[S.lay.warm + lane], s.warm[lane]); }
-        if (lane < M.nu) { st_coh(&st[S.lay.ctrl + lane], s.ctrl[lane]); st[S.lay.actlen + lane] = s.act_len[lane]; st[S.lay.actvel + lane] = s.act_vel[lane]; }
+        // (the readout words too: with pipelined chunks every chunk of an env stores them, possibly from different XCDs -- plain
+        // stores would leave dirty copies of the same words in two L2s, written back in no defined order at kernel end)
+        if (lane < M.nu) { st_coh(&st[S.lay.ctrl + lane], s.ctrl[lane]); st_coh(&st[S.lay.actlen + lane], s.act_len[lane]); st_coh(&st[S.lay.actvel + lane], s.act_vel[lane]); }
         if (lane < SMJ_BC_ROWS) st_coh(&st[S.lay.bctl + lane], s.bctl[lane]);
         if (lane == 0) {
           st_coh(&sti[S.lay.nstep], ld_coh(&sti[S.lay.nstep]) + nsteps);
           if (S.done_steps) st_coh(&S.done_steps[env], ld_coh(&S.done_steps[env]) + nsteps);
-          sti[S.lay.info + SMJ_INFO_NEFC] = nefc; sti[S.lay.info + SMJ_INFO_NCON] = ncon;
-          sti[S.lay.info + SMJ_INFO_NITER] = niter; st_coh(&sti[S.lay.info + SMJ_INFO_FLAGS], ld_coh(&sti[S.lay.info + SMJ_INFO_FLAGS]) | flags);
-          st[S.lay.base] = bx; st[S.lay.base + 1] = by; st[S.lay.base + 2] = bth;
+          st_coh(&sti[S.lay.info + SMJ_INFO_NEFC], nefc); st_coh(&sti[S.lay.info + SMJ_INFO_NCON], ncon);
+          st_coh(&sti[S.lay.info + SMJ_INFO_NITER], niter); st_coh(&sti[S.lay.info + SMJ_INFO_FLAGS], ld_coh(&sti[S.lay.info + SMJ_INFO_FLAGS]) | flags);
+          st_coh(&st[S.lay.base], bx); st_coh(&st[S.lay.base + 1], by); st_coh(&st[S.lay.base + 2], bth);
         }
       }
     } else {
