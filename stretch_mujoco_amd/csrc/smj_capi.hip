@@ -475,7 +475,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
   if (read_flags & SMJ_READ_POSES) out.add(st.xpose, 12 * m.nbody, Y.xpose);
   st.stage = c->stage;
   st.lay = Y;
-  const bool esc = c->variant == 0 && c->has_esc && c->escalate && c->model.solver == 2;
+  const bool esc = c->variant == 0 && c->has_esc && c->escalate;
   st.redo = esc ? c->redo : nullptr;
   st.cost = c->cost;
   if (esc) {   // the escalation target runs with the same options

@@ -30,7 +30,8 @@ struct TreeTmp {  // lives in the A region until A is built
   float cinert[NBP][10], crb[NBP][10], cvel[NBP][6], cfrc[NBP][6], buf[NVP][6], cdof[NVP][6], cdof_dot[NVP][6];
 };
 
-#define NEFP 64   // PGS row capacity (rows = lanes in the PGS sweeps)
+#define NEFP 64   // rows per register set of the PGS path (set p: rows 64 p .. 64 p + 63)
+#define NPS ((NEFC + 63) / 64)   // register sets of the PGS path: every row of the variant
 struct Smem {
   float MM[NVS][MS];    // strict upper: M; lower + diag: working copy -> L (unit, strictly lower), D on diag
   float Mdiag[NVP], Dinv[NVP];
@@ -45,10 +46,10 @@ struct Smem {
       eb[NEFC], ef[NEFC];
   float cpos[NCON][3], cframe[NCON][9], cdist[NCON], cfric[NCON][5], csolref[NCON][2], csolimp[NCON][5], cmargin[NCON];
   int cdim[NCON], cgeom1[NCON], cgeom2[NCON], cefc[NCON];
-  // The Jacobian and the stage-local union come LAST, in this order, on purpose: the PGS path has NEFP = 64 rows, so its matrix
-  // A = J M^-1 J' + R (NEFP x NEFP floats, see A()) starts at J's row 64 and runs on through the union -- in the standard
-  // variant it ends inside the struct, and a PGS launch needs no more LDS than a Newton launch (four workgroups per CU; with A
-  // starting at the union it needed 1.5 KB more and only three fitted).  smj_lds_bytes covers the variants where it does not.
+  // The stage-local union comes LAST on purpose: the PGS path keeps its matrix A = J M^-1 J' + R there (packed lower triangle,
+  // NEFC (NEFC + 1) / 2 floats, see A()).  In the standard variant the 80-row triangle (13 KB) ends inside the struct, so a PGS
+  // launch needs no more LDS than a Newton launch (four workgroups per CU); the 160-row variants ask for the tail as dynamic
+  // LDS (smj_lds_bytes).
   float J[NEFC][JS];    // constraint Jacobian, transformed in place to Y = J L^-1
   union {
     TreeTmp t;
@@ -78,7 +79,7 @@ struct Smem {
       float rxf[15][NEFC > 64 ? NEFC - 64 : 1];
     } n;
   } u;
-  SMJ_DEV float* A() { return &J[NEFP][0]; }
+  SMJ_DEV float* A() { return reinterpret_cast<float*>(&u); }   // PGS: A = Y D^-1 Y' + R as a packed lower triangle, NEFC (NEFC + 1) / 2 floats
 };
 // Row passes of the Newton path: rows 0..63 on lanes 0..63 (rb = 0), then rows 64..NEFC-1 on lanes 0..NEFC-65 (rb = 64), the
 // second pass only for an env that has that many rows (wave-uniform test).
@@ -90,7 +91,9 @@ struct Smem {
 #define ROWS_END_RW(rb) if (rb != 0) rx_store(nrx_, rb); }
 #define ROWS_END_RO() }
 static inline size_t smj_lds_bytes(bool pgs) {
-  const size_t a_end = offsetof(Smem, J) + sizeof(float) * (NEFP * JS + NEFP * NEFP);
+  const size_t a_wide = offsetof(Smem, u) + sizeof(float) * (NEFC * (NEFC + 1) / 2);          // packed triangle in the union
+  const size_t a_sq = offsetof(Smem, J) + sizeof(float) * (NEFP * JS + NEFP * NEFP);           // 64 x 64 square from row 64 of J
+  const size_t a_end = a_wide > a_sq ? a_wide : a_sq;
   return (pgs && a_end > sizeof(Smem)) ? a_end : sizeof(Smem);
 }
 
@@ -222,7 +225,7 @@ struct StepKernel {
   // issued back to back cost one L2 round trip per stage -- instead of living in registers for the whole launch.
   PL<float[6]> cdof, cdof_dot;          // lane = dof
   PL<float> qvel_r, g_r, qacc_r;
-  PL<float> f_r, r_r, ARinv_r;          // lane = row (PGS)
+  PL<float> f_r[NPS], r_r[NPS], ARinv_r[NPS];   // lane = row (PGS), one register set per 64 rows
   int nefc, ncon, niter, flags;
   int step_base = 0;     // steps of this launch that earlier chunks of the env already ran (pipelined chunks, DevState::pipe_len)
   int pipe_chunk = 0;    // the chunk this workgroup runs
@@ -2397,7 +2400,7 @@ struct StepKernel {
       }
     }
     SYNC();
-    const int cap = M.solver == 2 ? NEFC : NEFP;   // the PGS sweeps are lane = row: 64 rows
+    const int cap = NEFC;
     // static rows (equalities -- all active, an inactive one gets an empty row with R large -> force 0 -- then friction-loss
     // dofs) and the limit slots, each from its row record (DevModel::k_rowrec): one level of loads
     const int nstat = neq + nfric;
@@ -2601,18 +2604,44 @@ struct StepKernel {
   }
 
   // ------------------------------------------------------------------ projectConstraint + PGS
+  // The sweeps are lane = row.  Two builds of the same code (template WIDE), chosen per step by the env's row count:
+  //   WIDE = false -- at most 64 rows (99 % of the steps): one register set, A = Y D^-1 Y' + R a 64 x 64 square that starts at
+  //     row 64 of J (free when there are no more rows) and runs on through the union; row i = column i is a conflict-free read;
+  //   WIDE = true -- every row the variant holds: the per-row state (force, residual, type ...) lives in NPS register sets --
+  //     set p holds rows 64 p .. 64 p + 63 -- and A is a packed lower triangle in the union (row i doubles as column i), which
+  //     is what lets the standard variant's 80 x 80 matrix fit with nothing added to the launch's LDS.
+  SMJ_DEV static int tri(int r, int c) { return r >= c ? ((r * (r + 1)) >> 1) + c : ((c * (c + 1)) >> 1) + r; }
+#define PSETS(p, ne) _Pragma("unroll") for (int p = 0; p < NP; p++) if (p == 0 || (ne) > 64 * p)
+#define PSETS_ALL(p) _Pragma("unroll") for (int p = 0; p < NP; p++)
+  // value of row i (wave-uniform) from the register sets
+  template <int NP, class T>
+  SMJ_DEV T prow(const PL<T>* a, int i) const {
+    T v = wave_read(a[0], i & 63);
+#pragma unroll
+    for (int p = 1; p < NP; p++)
+      if (i >= 64 * p) v = wave_read(a[p], i & 63);
+    return v;
+  }
+  template <bool WIDE>
+  SMJ_DEV float* Amat() { return WIDE ? s.A() : &s.J[NEFP][0]; }
+  template <bool WIDE>
+  SMJ_DEV static int ai(int r, int c) { return WIDE ? tri(r, c) : r * NEFP + c; }
+  template <bool WIDE>
   SMJ_DEV void solve(bool dbg, float* pc, long long& t0, bool prof) {
 #define TICK(slot) if (prof) { const long long t1 = smj_clock(); pc[slot] += (float)(t1 - t0); t0 = t1; }
+    constexpr int NP = WIDE ? NPS : 1;
     const int nv = M.nv, ne = nefc;
+    float* const A = Amat<WIDE>();
     // efc_vel, aref, warm-start residual jar (rows = lanes), all from J before it is transformed
-    PL<float> aref, jar, Rr, bb;
-    LANES {
+    PL<float> aref[NP], jar[NP], Rr[NP], bb[NP];
+    PSETS(p, ne) LANES {
+      const int row = lane + 64 * p;
       float vel = 0, jw = 0;
-      if (lane < ne)
-        for (int k = 0; k < nv; k++) { const float jv = s.J[lane][k]; vel += jv * s.qvel[k]; jw += jv * s.warm[k]; }
-      const float ar = lane < ne ? -s.eBv[lane] * vel - s.eK[lane] * s.eimp[lane] * (s.epos[lane] - s.emargin[lane]) : 0.f;
-      aref[lane] = ar; jar[lane] = jw - ar; Rr[lane] = lane < ne ? s.eR[lane] : 1.f;
-      s.earef[lane] = ar;
+      if (row < ne)
+        for (int k = 0; k < nv; k++) { const float jv = s.J[row][k]; vel += jv * s.qvel[k]; jw += jv * s.warm[k]; }
+      const float ar = row < ne ? -s.eBv[row] * vel - s.eK[row] * s.eimp[row] * (s.epos[row] - s.emargin[row]) : 0.f;
+      aref[p][lane] = ar; jar[p][lane] = jw - ar; Rr[p][lane] = row < ne ? s.eR[row] : 1.f;
+      if (row < NEFC) s.earef[row] = ar;
     }
     // u = L^-T phase of g (dof lanes)
     PL<float> u;
@@ -2623,26 +2652,28 @@ struct StepKernel {
     for (int i = nv - 1; i > 0; i--) {
       const int na = uni(M.k_dof_anc_num[i]), adr = uni(M.k_dof_anc_adr[i]);
       if (na == 0) continue;
-      LANES {
-        const float xi = s.J[lane][i];
+      PSETS(p, ne) LANES {
+        const int row = lane + 64 * p < NEFC ? lane + 64 * p : NEFC - 1;
+        const float xi = lane + 64 * p < NEFC ? s.J[row][i] : 0.f;
         if (xi != 0.f)
           for (int a = 0; a < na; a++) {
             const int j = uni(M.k_dof_anc[adr + a]);
-            s.J[lane][j] -= s.MM[i][j] * xi;
+            s.J[row][j] -= s.MM[i][j] * xi;
           }
       }
     }
     SYNC();
     // b = Y Dinv u - aref
-    LANES {
+    PSETS(p, ne) LANES {
+      const int row = lane + 64 * p;
       float v = 0;
-      if (lane < ne)
-        for (int k = 0; k < nv; k++) v += s.J[lane][k] * s.Dinv[k] * s.uu[k];
-      bb[lane] = v - aref[lane];
-      s.eb[lane] = bb[lane];
+      if (row < ne)
+        for (int k = 0; k < nv; k++) v += s.J[row][k] * s.Dinv[k] * s.uu[k];
+      bb[p][lane] = v - aref[p][lane];
+      if (row < NEFC) s.eb[row] = bb[p][lane];
     }
     SYNC();  // all reads of the tree temporaries that alias A are done (cdof etc. live in registers from here on)
-    // A = Y Dinv Y' (+R on the diagonal) on the matrix cores, 16x16 tiles, K = nv padded to 4
+    // A = Y Dinv Y' (+R on the diagonal) on the matrix cores, 16x16 tiles of the lower triangle, K = nv padded to 4
     {
       const int ntile = (ne + 15) >> 4, ksteps = (nv + 3) >> 2;
       for (int tr = 0; tr < ntile; tr++)
@@ -2654,8 +2685,9 @@ struct StepKernel {
             LANES {
               const int k = 4 * ks + (lane >> 4);
               const float dk = k < nv ? s.Dinv[k] : 0.f;
-              a[lane] = k < nv ? s.J[16 * tr + (lane & 15)][k] * dk : 0.f;
-              b[lane] = k < nv ? s.J[16 * tc + (lane & 15)][k] : 0.f;
+              const int ra = 16 * tr + (lane & 15), rb = 16 * tc + (lane & 15);
+              a[lane] = (k < nv && ra < NEFC) ? s.J[ra][k] * dk : 0.f;
+              b[lane] = (k < nv && rb < NEFC) ? s.J[rb][k] : 0.f;
             }
             mfma16x16x4(acc, a, b);
           }
@@ -2664,8 +2696,8 @@ struct StepKernel {
               const int row = 16 * tr + (lane >> 4) * 4 + r, col = 16 * tc + (lane & 15);
               float v = acc[lane].r[r];
               if (row == col) v += row < ne ? s.eR[row] : 1.f;
-              s.A()[row * NEFP + col] = v;
-              if (tr != tc) s.A()[col * NEFP + row] = v;
+              if (WIDE) { if (col <= row && row < NEFC) A[tri(row, col)] = v; }
+              else { A[row * NEFP + col] = v; if (tr != tc) A[col * NEFP + row] = v; }
             }
           }
         }
@@ -2673,21 +2705,21 @@ struct StepKernel {
     SYNC();
     TICK(SMJ_PROF_PROJECT)
     // warm start  [MJ] mj_warmstart (PGS branch): forces from the primal residual at qacc_warmstart
-    LANES { s.earef[lane] = jar[lane]; }  // stash jar in LDS so a contact's first row can see its block
+    PSETS(p, ne) LANES { if (lane + 64 * p < NEFC) s.earef[lane + 64 * p] = jar[p][lane]; }  // stash jar in LDS so a contact's first row can see its block
     SYNC();
-    LANES {
+    PSETS(p, ne) LANES {
       float f = 0;
-      const int i = lane;
+      const int i = lane + 64 * p;
       if (i < ne && M.warmstart) {
         const int t = s.etype[i];
-        const float D = 1.0f / Rr[lane], jr = jar[lane];
+        const float D = 1.0f / Rr[p][lane], jr = jar[p][lane];
         if (t == CT_EQUALITY) f = -D * jr;
         else if (t == CT_FRICTION) {
           const float fl = s.efloss[i];
-          f = (jr <= -Rr[lane] * fl) ? fl : (jr >= Rr[lane] * fl) ? -fl : -D * jr;
+          f = (jr <= -Rr[p][lane] * fl) ? fl : (jr >= Rr[p][lane] * fl) ? -fl : -D * jr;
         } else if (t == CT_LIMIT || t == CT_CONTACT_FRICTIONLESS) f = jr < 0 ? -D * jr : 0.f;
       }
-      s.ef[lane] = f;  // elliptic rows: overwritten below by the contact's lane
+      if (i < NEFC) s.ef[i] = f;  // elliptic rows: overwritten below by the contact's lane
     }
     SYNC();
     LANES {
@@ -2714,60 +2746,64 @@ struct StepKernel {
     SYNC();
     // residual r = A f + b (lanes = rows; column reads via symmetry), dual cost of the warm start
     PL<float> cost;
-    LANES {
-      f_r[lane] = lane < ne ? s.ef[lane] : 0.f;
-      s.earef[lane] = aref[lane];
+    LANES { cost[lane] = 0.f; }
+    PSETS_ALL(p) LANES {
+      const int row = lane + 64 * p;
+      f_r[p][lane] = row < ne ? s.ef[row] : 0.f;
+      r_r[p][lane] = 0.f;
+      if (row < NEFC) s.earef[row] = row < ne ? aref[p][lane] : 0.f;
     }
-    residual_refresh(bb);
-    LANES { cost[lane] = lane < ne ? f_r[lane] * 0.5f * (r_r[lane] + bb[lane]) : 0.f; }
+    residual_refresh<WIDE>(bb);
+    PSETS(p, ne) LANES { cost[lane] += lane + 64 * p < ne ? f_r[p][lane] * 0.5f * (r_r[p][lane] + bb[p][lane]) : 0.f; }
     const float wcost = wave_sum(cost);
-    if (wcost > 0) { LANES { f_r[lane] = 0.f; r_r[lane] = bb[lane]; } }
-    LANES { ARinv_r[lane] = 1.0f / s.A()[lane * NEFP + lane]; }
+    if (wcost > 0) { PSETS(p, ne) LANES { f_r[p][lane] = 0.f; r_r[p][lane] = bb[p][lane]; } }
 
     TICK(SMJ_PROF_WARM)
     // ---- PGS sweeps  [MJ] mj_solPGS
     // Row metadata lives in the registers of the row's lane and is fetched with v_readlane (no LDS round trip on the
     // serial path); the A row needed for the residual update is loaded first so its latency overlaps the scalar math.
-    PL<int> type_r, dimc_r;   // row type; for the first row of an elliptic block: dim | contact << 8
-    PL<float> aii_r, fl_r;
-    LANES {
-      const int t = lane < ne ? s.etype[lane] : CT_NONE;
-      type_r[lane] = t;
+    PL<int> type_r[NP], dimc_r[NP];   // row type; for the first row of an elliptic block: dim | contact << 8
+    PL<float> aii_r[NP], fl_r[NP];
+    PSETS_ALL(p) LANES {
+      const int row = lane + 64 * p;
+      const int t = row < ne ? s.etype[row] : CT_NONE;
+      type_r[p][lane] = t;
       int dc = 0;
-      if (t == CT_CONTACT_ELLIPTIC) { const int c = s.eid[lane]; dc = s.cdim[c] | (c << 8); }
-      dimc_r[lane] = dc;
-      aii_r[lane] = s.A()[lane * NEFP + lane];
-      fl_r[lane] = s.efloss[lane];
+      if (t == CT_CONTACT_ELLIPTIC) { const int c = s.eid[row]; dc = s.cdim[c] | (c << 8); }
+      dimc_r[p][lane] = dc;
+      const float aii = row < ne ? A[ai<WIDE>(row, row)] : 1.f;
+      aii_r[p][lane] = aii; ARinv_r[p][lane] = 1.0f / aii;
+      fl_r[p][lane] = row < ne ? s.efloss[row] : 0.f;
     }
     const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
     int iter = 0;
     for (; iter < M.iterations; iter++) {
       float improvement = 0;
-      if (iter > 0 && (iter & 7) == 0) residual_refresh(bb);
+      if (iter > 0 && (iter & 7) == 0) residual_refresh<WIDE>(bb);
       for (int i = 0; i < ne;) {
-        const int t = wave_read(type_r, i);
+        const int t = prow<NP>(type_r, i);
         if (t != CT_CONTACT_ELLIPTIC) {
-          PL<float> arow;
-          LANES { arow[lane] = s.A()[i * NEFP + lane]; }
-          const float res = wave_read(r_r, i), old = wave_read(f_r, i), ainv = wave_read(ARinv_r, i);
-          const float aii = wave_read(aii_r, i);
+          PL<float> arow[NP];
+          PSETS(p, ne) LANES { const int col = lane + 64 * p; arow[p][lane] = (!WIDE || col < ne) ? A[ai<WIDE>(i, col)] : 0.f; }
+          const float res = prow<NP>(r_r, i), old = prow<NP>(f_r, i), ainv = prow<NP>(ARinv_r, i);
+          const float aii = prow<NP>(aii_r, i);
           float fn = old - res * ainv;
-          if (t == CT_FRICTION) { const float fl = wave_read(fl_r, i); fn = fminf(fl, fmaxf(-fl, fn)); }
+          if (t == CT_FRICTION) { const float fl = prow<NP>(fl_r, i); fn = fminf(fl, fmaxf(-fl, fn)); }
           else if (t != CT_EQUALITY) fn = fmaxf(0.f, fn);
           float delta = fn - old;
           float change = delta * (0.5f * aii * delta + res);
           if (change > 1e-10f) { delta = 0; change = 0; }
           improvement -= change;
-          LANES {
-            r_r[lane] += arow[lane] * delta;
-            if (lane == i) f_r[lane] += delta;
+          PSETS(p, ne) LANES {
+            r_r[p][lane] += arow[p][lane] * delta;
+            if (lane + 64 * p == i) f_r[p][lane] += delta;
           }
           i += 1;
         } else {
-          const int dc = wave_read(dimc_r, i), dim = dc & 255, c = dc >> 8;
-          if (dim == 3) improvement += pgs_block<3>(i, c);
-          else if (dim == 4) improvement += pgs_block<4>(i, c);
-          else improvement += pgs_block<6>(i, c);
+          const int dc = prow<NP>(dimc_r, i), dim = dc & 255, c = dc >> 8;
+          if (dim == 3) improvement += pgs_block<3, WIDE>(i, c);
+          else if (dim == 4) improvement += pgs_block<4, WIDE>(i, c);
+          else improvement += pgs_block<6, WIDE>(i, c);
           i += dim;
         }
       }
@@ -2777,7 +2813,7 @@ struct StepKernel {
     niter = iter;
     TICK(SMJ_PROF_PGS)
 #undef TICK
-    LANES { s.ef[lane] = lane < ne ? f_r[lane] : 0.f; }
+    PSETS_ALL(p) LANES { if (lane + 64 * p < NEFC) s.ef[lane + 64 * p] = lane + 64 * p < ne ? f_r[p][lane] : 0.f; }
     SYNC();
     // w = Y' f (dof lanes); qfrc_constraint = L' w ; qacc = L^-1 ( Dinv (u + w) )
     PL<float> w, qc;
@@ -2801,45 +2837,54 @@ struct StepKernel {
       if (lane < nv) { s.qacc[lane] = qacc_r[lane]; s.warm[lane] = qacc_r[lane]; s.tmp[lane] = g_r[lane] + qc[lane]; }
     }
     SYNC();
-    if (dbg && S.debug) {
+    if (dbg && S.debug) {   // the debug layout holds the first 64 rows
       LANES {
         if (lane < nv) S.debug[(SMJ_DBG_QACC + lane) * S.ld + env] = qacc_r[lane];
-        S.debug[(SMJ_DBG_EFC_FORCE + lane) * S.ld + env] = lane < ne ? f_r[lane] : 0.f;
-        S.debug[(SMJ_DBG_EFC_B + lane) * S.ld + env] = lane < ne ? bb[lane] : 0.f;
+        S.debug[(SMJ_DBG_EFC_FORCE + lane) * S.ld + env] = lane < ne ? f_r[0][lane] : 0.f;
+        S.debug[(SMJ_DBG_EFC_B + lane) * S.ld + env] = lane < ne ? bb[0][lane] : 0.f;
         S.debug[(SMJ_DBG_EFC_R + lane) * S.ld + env] = lane < ne ? s.eR[lane] : 0.f;
-        S.debug[(SMJ_DBG_EFC_AREF + lane) * S.ld + env] = lane < ne ? aref[lane] : 0.f;
-        S.debug[(SMJ_DBG_AR_DIAG + lane) * S.ld + env] = lane < ne ? s.A()[lane * NEFP + lane] : 0.f;
-        for (int k = 0; k < NEFP; k++) S.debug[(SMJ_DBG_AR + k * NEFP + lane) * S.ld + env] = (k < ne && lane < ne) ? s.A()[k * NEFP + lane] : 0.f;
+        S.debug[(SMJ_DBG_EFC_AREF + lane) * S.ld + env] = lane < ne ? aref[0][lane] : 0.f;
+        S.debug[(SMJ_DBG_AR_DIAG + lane) * S.ld + env] = lane < ne ? A[ai<WIDE>(lane, lane)] : 0.f;
+        for (int k = 0; k < 64; k++) S.debug[(SMJ_DBG_AR + k * 64 + lane) * S.ld + env] = (k < ne && lane < ne) ? A[ai<WIDE>(k, lane)] : 0.f;
       }
     }
   }
 
-  SMJ_DEV void residual_refresh(const PL<float>& bb) {
-    LANES { s.ef[lane] = f_r[lane]; }
+  template <bool WIDE>
+  SMJ_DEV void residual_refresh(const PL<float>* bb) {
+    constexpr int NP = WIDE ? NPS : 1;
+    const int ne = nefc;
+    const float* const A = Amat<WIDE>();
+    PSETS_ALL(p) LANES { if (lane + 64 * p < NEFC) s.ef[lane + 64 * p] = f_r[p][lane]; }
     SYNC();
-    LANES {
-      float v = bb[lane];
-      if (lane < nefc)
-        for (int k = 0; k < nefc; k++) v += s.A()[k * NEFP + lane] * s.ef[k];
-      r_r[lane] = v;
+    PSETS(p, ne) LANES {
+      const int row = lane + 64 * p;
+      float v = bb[p][lane];
+      if (row < ne)
+        for (int k = 0; k < ne; k++) v += A[ai<WIDE>(k, row)] * s.ef[k];
+      r_r[p][lane] = v;
     }
     SYNC();
   }
 
   // one elliptic contact block of the PGS sweep  [MJ] mj_solPGS elliptic branch (ray update + QCQP); uniform math
-  template <int DIM>
+  template <int DIM, bool WIDE>
   SMJ_DEV float pgs_block(int i, int c) {
+    constexpr int NP = WIDE ? NPS : 1;
+    const int ne = nefc;
+    const float* const A = Amat<WIDE>();
     float res[DIM], old[DIM], f[DIM], At[DIM * DIM], v1[DIM], mu[DIM - 1];
-    PL<float[DIM]> arow;  // rows i..i+DIM of A for the residual update, issued up front
-    LANES {
+    PL<float[DIM]> arow[NP];  // rows i..i+DIM of A for the residual update, issued up front
+    PSETS(p, ne) LANES {
+      const int col = lane + 64 * p;
 #pragma unroll
-      for (int r = 0; r < DIM; r++) arow[lane][r] = s.A()[(i + r) * NEFP + lane];
+      for (int r = 0; r < DIM; r++) arow[p][lane][r] = (!WIDE || col < ne) ? A[ai<WIDE>(i + r, col)] : 0.f;
     }
 #pragma unroll
     for (int r = 0; r < DIM; r++) {
-      res[r] = wave_read(r_r, i + r); old[r] = wave_read(f_r, i + r); f[r] = old[r];
+      res[r] = prow<NP>(r_r, i + r); old[r] = prow<NP>(f_r, i + r); f[r] = old[r];
 #pragma unroll
-      for (int q = 0; q < DIM; q++) At[r * DIM + q] = s.A()[(i + r) * NEFP + i + q];
+      for (int q = 0; q < DIM; q++) At[r * DIM + q] = A[ai<WIDE>(i + r, i + q)];
     }
 #pragma unroll
     for (int j = 0; j < DIM - 1; j++) mu[j] = s.cfric[c][j];
@@ -2854,7 +2899,7 @@ struct StepKernel {
       denom += old[r] * a; num += old[r] * res[r];
     }
     if (f[0] < SMJ_MINVAL) {  // normal update
-      f[0] -= res[0] * wave_read(ARinv_r, i);
+      f[0] -= res[0] * prow<NP>(ARinv_r, i);
       if (f[0] < 0) f[0] = 0;
 #pragma unroll
       for (int j = 1; j < DIM; j++) f[j] = 0;
@@ -2899,17 +2944,19 @@ struct StepKernel {
       change += delta[r] * (0.5f * sv + res[r]);
     }
     if (change > 1e-10f) return 0.f;
-    LANES {
-      float acc = r_r[lane];
+    PSETS(p, ne) LANES {
+      float acc = r_r[p][lane];
 #pragma unroll
       for (int r = 0; r < DIM; r++) {
-        acc += arow[lane][r] * delta[r];
-        if (lane == i + r) f_r[lane] += delta[r];
+        acc += arow[p][lane][r] * delta[r];
+        if (lane + 64 * p == i + r) f_r[p][lane] += delta[r];
       }
-      r_r[lane] = acc;
+      r_r[p][lane] = acc;
     }
     return -change;
   }
+#undef PSETS
+#undef PSETS_ALL
 
 
   // ------------------------------------------------------------------ B.7' Newton solver (primal)
@@ -3847,15 +3894,17 @@ struct StepKernel {
       collision_convex(pc, prof);
       if (last) dump_contacts();
       TICK(SMJ_PROF_COLLISION)
+      if (M.solver != 2) nefc = NEFC;   // PGS: the A of a step with at most 64 rows sits in rows 64.. of J (solve<false>) -- have them cleared
       make_constraint();
       TICK(SMJ_PROF_MAKECON)
-      if (S.redo && !S.redo_worker && M.solver == 2 && (flags & (SMJ_FLAG_EFC_OVERFLOW | SMJ_FLAG_CON_OVERFLOW))) {
+      if (S.redo && !S.redo_worker && (flags & (SMJ_FLAG_EFC_OVERFLOW | SMJ_FLAG_CON_OVERFLOW))) {
         escalate(st);
         if (S.cost) { const int cst = (int)((smj_clock() - tlaunch) >> 6); LANES { if (lane == 0) st_coh(&S.cost[env], step_base ? ld_coh(&S.cost[env]) + cst : cst); } }
         return;
       }
       if (M.solver == 2) solve_newton(last, pc, t0, prof);
-      else solve(last, pc, t0, prof);
+      else if (nefc > NEFP) solve<true>(last, pc, t0, prof);
+      else solve<false>(last, pc, t0, prof);
       if (last && want_imu) imu();
       TICK(SMJ_PROF_POST)
       integrate();

@@ -32,7 +32,7 @@ struct emul_ctx {
   DevState s{};
   std::vector<void*> keep;
   std::string err;
-  struct { Smem s; unsigned char pgs_tail[sizeof(float) * NEFP * NEFP]; } lds;   // PGS: A runs past the end of Smem
+  struct { Smem s; unsigned char pgs_tail[sizeof(float) * (NEFC * (NEFC + 1) / 2 + NEFP * NEFP)]; } lds;   // PGS: A runs past the end of Smem
 };
 
 extern "C" {

@@ -369,3 +369,44 @@ def test_no_lane_private_value_is_read_before_it_is_written(blob_fused, solver):
     assert np.isfinite(res["poison"][0]).all()
     for a, b in zip(res["standard"], res["poison"]):
         assert np.array_equal(a, b)
+
+
+def test_pgs_rows_beyond_one_wavefront(blob_fused):
+    """The PGS sweeps are lane = row; rows beyond 64 live in further register sets and A is a packed triangle.  The scripted
+    worst case (lift to the floor with the wrist pitched down, from mj_resetData) reaches 101-113 rows / 20-22 contacts from
+    step 32 on: the tall variant (160 rows) must carry all of them -- same row / contact counts as the capacity-free fp64
+    oracle, no flag -- and its PGS (both capped at 100 sweeps there) must land on the oracle's velocities, state-synchronised."""
+    ctrl = [0, 0, 0.0, 0.3, 0, -1.57, 0, 0, 0, 0]
+    o = Oracle(blob_fused)
+    o.set_option("solver", 0); o.reset()
+    o.arr("ctrl")[:10] = ctrl
+    e = Emul(blob_fused, DIMS, num_envs=1, variant="tall")
+    e.set_option("solver", 0)
+    e.ctrl[:, 0] = np.asarray(ctrl, np.float32)
+    wide = 0
+    for k in range(40):
+        e.qpos[:, 0] = o.arr("qpos"); e.qvel[:, 0] = o.arr("qvel"); e.warm[:, 0] = o.arr("qacc_warmstart")
+        o.step(1); e.step(1)
+        assert int(e.info[3, 0]) == 0, k
+        if o.nefc > 64:
+            assert (int(e.info[0, 0]), int(e.info[1, 0])) == (o.nefc, o.ncon), k
+            assert np.abs(e.qvel[:, 0] - o.arr("qvel")).max() < 5e-3, k
+            wide += 1
+    assert wide >= 6
+
+
+def test_pgs_launch_crossing_64_rows(blob_fused):
+    """One launch of 8 steps that starts with 53 rows and ends with 107 (the scenario above, from the oracle's state at step 29):
+    a step with at most 64 rows keeps its PGS matrix in rows 64.. of J, the next step may need those rows for constraints."""
+    ctrl = [0, 0, 0.0, 0.3, 0, -1.57, 0, 0, 0, 0]
+    o = Oracle(blob_fused)
+    o.set_option("solver", 0); o.reset()
+    o.arr("ctrl")[:10] = ctrl
+    o.step(29)
+    e = Emul(blob_fused, DIMS, num_envs=1, variant="tall")
+    e.set_option("solver", 0)
+    e.ctrl[:, 0] = np.asarray(ctrl, np.float32)
+    e.qpos[:, 0] = o.arr("qpos"); e.qvel[:, 0] = o.arr("qvel"); e.warm[:, 0] = o.arr("qacc_warmstart")
+    o.step(8); e.step(8)
+    assert int(e.info[3, 0]) == 0 and int(e.info[0, 0]) == o.nefc > 64
+    assert np.abs(e.qvel[:, 0] - o.arr("qvel")).max() < 5e-2 and np.abs(e.qpos[:, 0] - o.arr("qpos")).max() < 1e-3
