@@ -244,9 +244,10 @@ int smj_create(const void* blob, size_t nbytes, int num_envs, int device, smj_ct
   c->caps = caps[c->variant];
   c->layout = smj_stage_layout(c->caps.nvp, c->caps.nbp);
   c->debug_floats = dbg[c->variant];
-  if (c->variant == 0) {   // escalation target: the same model loaded for the tall variant
+  if (c->variant == 0 || c->variant == 2 || c->variant == 3) {
+    // escalation target: the same model loaded for the tall variant (standard) / the 64-column big build (38 / 50 columns)
     int dummy = 0;
-    rc = smj_load_model(blob, nbytes, c->model_esc, up, c->err, caps + 1, 1, &dummy);
+    rc = smj_load_model(blob, nbytes, c->model_esc, up, c->err, caps + (c->variant == 0 ? 1 : 4), 1, &dummy);
     if (rc) return rc;
     c->has_esc = true;
     void* d = nullptr;
@@ -475,7 +476,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
   if (read_flags & SMJ_READ_POSES) out.add(st.xpose, 12 * m.nbody, Y.xpose);
   st.stage = c->stage;
   st.lay = Y;
-  const bool esc = c->variant == 0 && c->has_esc && c->escalate;
+  const bool esc = c->has_esc && c->escalate;   // standard -> tall, big38 / big50 -> big (has_esc: smj_create)
   st.redo = esc ? c->redo : nullptr;
   st.cost = c->cost;
   if (esc) {   // the escalation target runs with the same options
@@ -534,7 +535,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
     // sixteen, any poll interval, any stream priority), and escalations are rare events (0-2 envs per 50-step launch of 4096
     // under random actions, each worth milliseconds when left to the sweep): the pollers leave at once unless one of the last
     // SMJ_HOT_LAUNCHES launches had an escalation (DevState::hot, kept on the device -- the host runs many launches ahead)
-    const bool poll = esc && pipe && c->pollers > 0;
+    const bool poll = esc && pipe && c->pollers > 0 && c->variant == 0;
     if (poll) {
       // pollers first, on their own stream, so that they are resident when the standard kernel fills the device; should they
       // not be (nothing guarantees it), parked envs are given up to the sweep, as without pollers
@@ -560,7 +561,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
       // offending step) is finished by the tall variant (160 rows / 48 contacts); an empty list returns at once
       st.redo_worker = 1;
       st.pipe_len = 0;
-      lrc = smj_launch_step_tall(c->model_esc, st, k, fl, sm);
+      lrc = c->variant == 0 ? smj_launch_step_tall(c->model_esc, st, k, fl, sm) : smj_launch_step_big(c->model_esc, st, k, fl, sm);
     }
   }
   if (lrc) return fail(c, -2, "step kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
@@ -652,6 +653,7 @@ int smj_set_option(smj_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "solver")) m.solver = (int)v;
   else if (!strcmp(name, "convex_pairs")) m.convex_pairs = (int)v;
   else if (!strcmp(name, "multiccd")) m.multiccd = (int)v;
+  else if (!strcmp(name, "primary_rows")) m.row_limit = (int)v;   // the escalation variant keeps its full capacity (model_esc is not touched)
   else if (!strcmp(name, "escalate")) c->escalate = (int)v;
   else if (!strcmp(name, "balance")) c->balance = (int)v;
   else if (!strcmp(name, "chunk")) c->chunk = (int)v;

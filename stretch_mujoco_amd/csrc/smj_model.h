@@ -22,8 +22,13 @@
 #define NVS SMJ_NVS   // dof COLUMNS of the LDS-resident matrices J / M / H (model nv <= NVS): the big variant is built three times,
                       // for 38 (the reference's scene.xml: robot + 2 free objects), 50 (robot + 4) and 64 dofs -- with 38 / 50
                       // columns an env's working set stays under 80 KB of LDS and two envs share a CU
-#define NEFC 160  // constraint-row capacity of the Newton path: rows 64.. take further passes on lanes 0..63 (PGS: 64)
+#if SMJ_NVS == 64   // one env per CU anyway: the build that takes over when a 38- / 50-column env runs out of rows / contacts
+#define NEFC 224
+#define NCON 64
+#else
+#define NEFC 160  // constraint-row capacity: rows 64.. take further passes on lanes 0..63
 #define NCON 48   // contact capacity (<= 64: contact stages are lane = contact)
+#endif
 #define NENT 8    // mass-matrix pattern entries per lane (64 lanes)
 #elif defined(SMJ_TALL)
 #define NVP 32
@@ -73,6 +78,7 @@ struct DevModel {
       ngc, nroot, nkey, ncgeom, nconvpair, njump, maxsubtree;
   int iterations, warmstart, pgs_fixed_iter, max_con_pair, solver /* 0 PGS, 2 Newton */, ls_iterations, convex_pairs;
   int multi_serial;   // lane emulator only: 1 = the four multiccd queries of a pair one after the other (convex_multi), the comparator of convex_multi4
+  int row_limit;  // > 0: the primary variant hands an env over to the escalation variant beyond this many constraint rows (tests; option "primary_rows")
   int multiccd;   // stretch.xml:8 <flag multiccd="enable"/>: multi-point contacts for convex pairs (box-box polygon, counter-rotated queries)
   float ls_tolerance;
   float timestep, gravity[3], impratio, tolerance, meaninertia, lidar_cutoff;

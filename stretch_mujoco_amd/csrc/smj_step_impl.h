@@ -31,7 +31,8 @@ struct TreeTmp {  // lives in the A region until A is built
 };
 
 #define NEFP 64   // rows per register set of the PGS path (set p: rows 64 p .. 64 p + 63)
-#define NPS ((NEFC + 63) / 64)   // register sets of the PGS path: every row of the variant
+#define NEFC_P (NEFC > 160 ? 160 : NEFC)   // rows of the PGS path: every row of the variant up to 160 (the packed A of the 224-row build would not fit the CU's LDS)
+#define NPS ((NEFC_P + 63) / 64)   // register sets of the PGS path
 struct Smem {
   float MM[NVS][MS];    // strict upper: M; lower + diag: working copy -> L (unit, strictly lower), D on diag
   float Mdiag[NVP], Dinv[NVP];
@@ -47,7 +48,7 @@ struct Smem {
   float cpos[NCON][3], cframe[NCON][9], cdist[NCON], cfric[NCON][5], csolref[NCON][2], csolimp[NCON][5], cmargin[NCON];
   int cdim[NCON], cgeom1[NCON], cgeom2[NCON], cefc[NCON];
   // The stage-local union comes LAST on purpose: the PGS path keeps its matrix A = J M^-1 J' + R there (packed lower triangle,
-  // NEFC (NEFC + 1) / 2 floats, see A()).  In the standard variant the 80-row triangle (13 KB) ends inside the struct, so a PGS
+  // NEFC_P (NEFC_P + 1) / 2 floats, see A()).  In the standard variant the 80-row triangle (13 KB) ends inside the struct, so a PGS
   // launch needs no more LDS than a Newton launch (four workgroups per CU); the 160-row variants ask for the tail as dynamic
   // LDS (smj_lds_bytes).
   float J[NEFC][JS];    // constraint Jacobian, transformed in place to Y = J L^-1
@@ -79,7 +80,7 @@ struct Smem {
       float rxf[15][NEFC > 64 ? NEFC - 64 : 1];
     } n;
   } u;
-  SMJ_DEV float* A() { return reinterpret_cast<float*>(&u); }   // PGS: A = Y D^-1 Y' + R as a packed lower triangle, NEFC (NEFC + 1) / 2 floats
+  SMJ_DEV float* A() { return reinterpret_cast<float*>(&u); }   // PGS: A = Y D^-1 Y' + R as a packed lower triangle, NEFC_P (NEFC_P + 1) / 2 floats
 };
 // Row passes of the Newton path: rows 0..63 on lanes 0..63 (rb = 0), then rows 64..NEFC-1 on lanes 0..NEFC-65 (rb = 64), the
 // second pass only for an env that has that many rows (wave-uniform test).
@@ -91,7 +92,7 @@ struct Smem {
 #define ROWS_END_RW(rb) if (rb != 0) rx_store(nrx_, rb); }
 #define ROWS_END_RO() }
 static inline size_t smj_lds_bytes(bool pgs) {
-  const size_t a_wide = offsetof(Smem, u) + sizeof(float) * (NEFC * (NEFC + 1) / 2);          // packed triangle in the union
+  const size_t a_wide = offsetof(Smem, u) + sizeof(float) * (NEFC_P * (NEFC_P + 1) / 2);      // packed triangle in the union
   const size_t a_sq = offsetof(Smem, J) + sizeof(float) * (NEFP * JS + NEFP * NEFP);           // 64 x 64 square from row 64 of J
   const size_t a_end = a_wide > a_sq ? a_wide : a_sq;
   return (pgs && a_end > sizeof(Smem)) ? a_end : sizeof(Smem);
@@ -2400,7 +2401,8 @@ struct StepKernel {
       }
     }
     SYNC();
-    const int cap = NEFC;
+    int cap = M.solver == 2 ? NEFC : NEFC_P;
+    if (M.row_limit > 0 && M.row_limit < cap) cap = M.row_limit;
     // static rows (equalities -- all active, an inactive one gets an empty row with R large -> force 0 -- then friction-loss
     // dofs) and the limit slots, each from its row record (DevModel::k_rowrec): one level of loads
     const int nstat = neq + nfric;

@@ -11,9 +11,13 @@
 #if defined(SMJ_BIG)   // three builds: SMJ_VARIANT_TAG = big38 / big50 / big (column capacity SMJ_NVS, smj_model.h)
 #define SMJ_STEP_KERNEL SMJ_CAT(smj_step_kernel_, SMJ_VARIANT_TAG)
 #define SMJ_LAUNCH_STEP SMJ_CAT(smj_launch_step_, SMJ_VARIANT_TAG)
+#if SMJ_NVS == 64   // the escalation target of the 38- / 50-column builds
+#define SMJ_WORKER_KERNEL smj_step_kernel_big_worker
+#endif
 #elif defined(SMJ_TALL)
 #define SMJ_STEP_KERNEL smj_step_kernel_tall
 #define SMJ_LAUNCH_STEP smj_launch_step_tall
+#define SMJ_WORKER_KERNEL smj_step_kernel_tall_worker   // the escalation target of the standard variant
 #elif defined(SMJ_PROF_TU)
 #define SMJ_STEP_KERNEL smj_step_kernel_prof
 #define SMJ_LAUNCH_STEP smj_launch_step_prof
@@ -92,10 +96,11 @@ __global__ __launch_bounds__(64) SMJ_KERNEL_ATTR void SMJ_STEP_KERNEL(const DevM
   if (S.sched && threadIdx.x == 0) atomicAdd(&S.sched[SMJ_SCHED_EXITED], 1);
 }
 
-#if defined(SMJ_TALL)
-// The escalation worker (tall variant only): works the list of envs the standard variant parked (DevState::redo) -- as the sweep
-// after the standard kernel (redo_worker 1) or as a poller beside it (redo_worker 2, DevState::sched).  One call site of run().
-__global__ __launch_bounds__(64) void smj_step_kernel_tall_worker(const DevModel M, const DevState S, int nsteps, unsigned read_flags) {
+#if defined(SMJ_WORKER_KERNEL)
+// The escalation worker (the tall variant for the standard one, the 64-column big build for the 38- / 50-column ones): works the
+// list of envs the smaller variant parked (DevState::redo) -- as the sweep after its kernel (redo_worker 1) or as a poller beside
+// it (redo_worker 2, DevState::sched; standard variant only).  One call site of run().
+__global__ __launch_bounds__(64) void SMJ_WORKER_KERNEL(const DevModel M, const DevState S, int nsteps, unsigned read_flags) {
   extern __shared__ __align__(16) unsigned char smj_lds[];
   Smem& smem = *reinterpret_cast<Smem*>(smj_lds);
   const int mode = S.redo_worker;
@@ -170,16 +175,16 @@ int SMJ_LAUNCH_STEP(const DevModel& m, const DevState& s, int nsteps, unsigned r
   if (lds_allowed == 0) lds_allowed = 64 * 1024;
   if (lds > lds_allowed) {   // beyond the default 64 KB per workgroup: raise the kernels' dynamic-LDS limit once (gfx950: 160 KB per CU)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(SMJ_STEP_KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-#if defined(SMJ_TALL)
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(smj_step_kernel_tall_worker), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#if defined(SMJ_WORKER_KERNEL)
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(SMJ_WORKER_KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #endif
     if (e != hipSuccess) return (int)e;
     lds_allowed = lds;
   }
-#if defined(SMJ_TALL)
+#if defined(SMJ_WORKER_KERNEL)
   if (s.redo_worker) {
     const unsigned wg = s.redo_worker == 2 ? (unsigned)(s.pollers < 0 ? -s.pollers : s.pollers) : (unsigned)(s.B < 128 ? s.B : 128);
-    hipLaunchKernelGGL(smj_step_kernel_tall_worker, dim3(wg), dim3(64), lds, stream, m, s, nsteps, read_flags);
+    hipLaunchKernelGGL(SMJ_WORKER_KERNEL, dim3(wg), dim3(64), lds, stream, m, s, nsteps, read_flags);
     return 0;
   }
 #endif

@@ -113,3 +113,48 @@ def test_pipelined_chunks_on_the_tall_variant_are_bit_identical():
             for a, b in zip(ref, got):
                 assert torch.equal(a, b), pipe
         sim.stop()
+
+
+@pytest.mark.parametrize("scene", ["stretch_scene", "stretch_kitchen4"])
+def test_big_builds_hand_over_to_the_224_row_build(scene):
+    """The two-envs-per-CU builds of the big variant (38 / 50 dof columns, 160 rows / 48 contacts) park an env whose step needs
+    more and the 64-column build (224 rows / 64 contacts, one env per CU) finishes the launch's remaining steps on it -- the
+    standard -> tall mechanism one size up.  Forced here with the `primary_rows` option: the primary kernel hands over beyond
+    90 rows (kitchen4 settles at 96), the escalation build keeps its full capacity.  State-synchronised against the fp64 oracle
+    like every contact-rich check: no flag, the oracle's row / contact counts, its velocities."""
+    from stretch_mujoco_amd import StretchBatchSimulator
+
+    sim = StretchBatchSimulator(num_envs=3, device="cuda:0", scene=scene, solver="newton")
+    sim.start(home=False)
+    assert sim.nefc_max == 160
+    o = Oracle(sim._blob); o.set_option("solver", 2)
+    ctrl = [1.5, -1.5, 0.3, 0.4, 0, -1.2, 0, 0, 0.5, -0.5]   # driving, arm out and down towards the table / counter
+    o.arr("ctrl")[:10] = ctrl
+    sim.ctrl[:] = torch.tensor(ctrl, dtype=torch.float32, device=sim.device).unsqueeze(1)
+    o.step(150)     # past the start transient, objects settled on their supports
+    limit = max(40, o.nefc - 6)
+    sim.set_option("primary_rows", limit)
+    over, errs = 0, []
+    for k in range(40):
+        for e in range(3):
+            sim.qpos[:, e] = torch.tensor(o.arr("qpos"), dtype=torch.float32, device=sim.device)
+            sim.qvel[:, e] = torch.tensor(o.arr("qvel"), dtype=torch.float32, device=sim.device)
+            sim.qacc_warmstart[:, e] = torch.tensor(o.arr("qacc_warmstart"), dtype=torch.float32, device=sim.device)
+        o.step(1); sim.step(1)
+        torch.cuda.synchronize()
+        assert int(sim.info[3].max()) == 0, k
+        assert torch.equal(sim.qpos[:, 0], sim.qpos[:, 2])
+        if o.nefc > limit:
+            over += 1
+        if (int(sim.info[0, 0]), int(sim.info[1, 0])) == (o.nefc, o.ncon):
+            errs.append(np.abs(sim.qvel[:, 0].cpu().numpy() - o.arr("qvel")).max() / max(1.0, np.abs(o.arr("qvel")).max()))
+    assert over >= 30     # the hand-over was exercised on nearly every step
+    # same statistics as the state-synchronised rollout tests: the bulk of the steps at fp32 rounding, the odd step at an MPR
+    # facet bifurcation (a free object resting on a face: the contact normal of two equally close facets) well above it
+    errs = np.sort(np.array(errs))
+    assert len(errs) >= 30 and errs[int(0.8 * len(errs))] < 2e-3 and errs[-1] < 0.3, errs[-8:]
+    sim.set_option("escalate", 0)
+    sim.step(1)
+    torch.cuda.synchronize()
+    assert int(sim.info[3].max()) & 1   # without it the same step is flagged
+    sim.stop()
