@@ -769,6 +769,13 @@ static void shape_support(const mprctx* c, int k, const double* dir, double* out
     double n = sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
     if (n > MINVAL) { pl[0] = sz[0] * dl[0] / n; pl[1] = sz[0] * dl[1] / n; }
     pl[2] = dl[2] >= 0 ? sz[1] : -sz[1];
+  } else if (t == G_CAPSULE) {      /* [MJ] mjc_support: the sphere's support point, moved to the end the direction points to */
+    double n = norm3(dl);
+    if (n > MINVAL) for (int i = 0; i < 3; i++) pl[i] = sz[0] * dl[i] / n;
+    pl[2] += dl[2] > 0 ? sz[1] : (dl[2] < 0 ? -sz[1] : 0);
+  } else if (t == G_ELLIPSOID) {    /* [MJ] mjc_support: unit-sphere support of the scaled direction, scaled back */
+    double tv[3] = {dl[0] * sz[0], dl[1] * sz[1], dl[2] * sz[2]}, n = norm3(tv);
+    if (n > MINVAL) for (int i = 0; i < 3; i++) pl[i] = sz[i] * tv[i] / n;
   } else if (t == G_MESH) {
     int best = 0;
     double bd = -1e300;
@@ -1266,7 +1273,25 @@ static void collision(const smjo_model* m, smjo_data* d) {
       if (t2 == G_SPHERE) n = plane_sphere(p1, R1, p2, s2[0], margin, rc);
       else if (t2 == G_CYLINDER) n = plane_cylinder(p1, R1, p2, R2, s2, margin, rc);
       else if (t2 == G_BOX) n = plane_box(p1, R1, p2, R2, s2, margin, rc);
-      else if (t2 == G_MESH)
+      else if (t2 == G_CAPSULE) {     /* [MJ] mjc_PlaneCapsule: the two end spheres, +axis end first */
+        for (int e = 0; e < 2; e++) {
+          double sg = e ? -1 : 1, c[3] = {p2[0] + sg * s2[1] * R2[2], p2[1] + sg * s2[1] * R2[5], p2[2] + sg * s2[1] * R2[8]};
+          n += plane_sphere(p1, R1, c, s2[0], margin, rc + n);
+        }
+      } else if (t2 == G_ELLIPSOID) { /* [MJ] mjc_PlaneEllipsoid: the surface point whose outward normal is -n */
+        double nl[3], sv[3], loc[3], wv[3];
+        mulmat3Tvec(nl, R2, nrm);
+        for (int k = 0; k < 3; k++) sv[k] = -nl[k] * s2[k];
+        double len = norm3(sv);
+        for (int k = 0; k < 3; k++) loc[k] = len > MINVAL ? s2[k] * sv[k] / len : 0;
+        mulmat3vec(wv, R2, loc);
+        double df[3] = {p2[0] + wv[0] - p1[0], p2[1] + wv[1] - p1[1], p2[2] + wv[2] - p1[2]}, dist = dot3(df, nrm);
+        if (dist <= margin) {
+          rc[0].dist = dist; memcpy(rc[0].normal, nrm, 24);
+          for (int k = 0; k < 3; k++) rc[0].pos[k] = p2[k] + wv[k] - nrm[k] * dist * 0.5;
+          n = 1;
+        }
+      } else if (t2 == G_MESH)
         n = plane_hull(p1, R1, p2, R2, m->hull_vert + 3 * m->geom_hulladr[g2], m->geom_hullnum[g2], margin, m->max_con_pair, rc);
       else continue;
     } else {
@@ -2184,6 +2209,36 @@ static double ray_geom(const smjo_model* m, const smjo_data* d, int g, const dou
     }
     return best;
   }
+  if (t == G_CAPSULE) {   /* [MJ] mj_rayGeom capsule: the cylinder's side between the caps, then the two end spheres beyond them */
+    double best = -1;
+    double a = lv[0] * lv[0] + lv[1] * lv[1], b = lv[0] * lp[0] + lv[1] * lp[1], c = lp[0] * lp[0] + lp[1] * lp[1] - size[0] * size[0];
+    if (a > MINVAL) {
+      double det = b * b - a * c;
+      if (det >= MINVAL) {
+        det = sqrt(det);
+        for (int sgn = -1; sgn <= 1; sgn += 2) {
+          double x = (-b + sgn * det) / a;
+          if (x >= 0 && fabs(lp[2] + x * lv[2]) <= size[1] && (best < 0 || x < best)) best = x;
+        }
+      }
+    }
+    for (int sg = -1; sg <= 1; sg += 2) {
+      double q[3] = {lp[0], lp[1], lp[2] - sg * size[1]};
+      double aa = dot3(lv, lv), bb = dot3(lv, q), cc = dot3(q, q) - size[0] * size[0], dd = bb * bb - aa * cc;
+      if (dd < MINVAL) continue;
+      dd = sqrt(dd);
+      for (int sgn = -1; sgn <= 1; sgn += 2) {
+        double x = (-bb + sgn * dd) / aa;
+        if (x >= 0 && sg * (lp[2] + x * lv[2]) >= size[1] && (best < 0 || x < best)) best = x;
+      }
+    }
+    return best;
+  }
+  if (t == G_ELLIPSOID) {
+    double sc[3] = {1 / size[0], 1 / size[1], 1 / size[2]};
+    double v[3] = {lv[0] * sc[0], lv[1] * sc[1], lv[2] * sc[2]}, q[3] = {lp[0] * sc[0], lp[1] * sc[1], lp[2] * sc[2]};
+    return ray_quad(dot3(v, v), dot3(v, q), dot3(q, q) - 1);
+  }
   return -1;
 }
 
@@ -2337,6 +2392,31 @@ static double ray_prim_front(int type, const double* size, const double* lp, con
       if (fabs(lp[a1] + x * lv[a1]) <= size[a1] && fabs(lp[a2] + x * lv[a2]) <= size[a2] && (best < 0 || x < best)) best = x;
     }
     return best;
+  }
+  if (type == G_CAPSULE) {
+    double best = -1;
+    double a = lv[0] * lv[0] + lv[1] * lv[1], b = lv[0] * lp[0] + lv[1] * lp[1], c = lp[0] * lp[0] + lp[1] * lp[1] - size[0] * size[0];
+    double det = b * b - a * c;
+    if (a > MINVAL && det >= MINVAL) {
+      double x = (-b - sqrt(det)) / a;
+      if (x >= tnear && fabs(lp[2] + x * lv[2]) <= size[1]) best = x;
+    }
+    for (int sg = -1; sg <= 1; sg += 2) {
+      double q[3] = {lp[0], lp[1], lp[2] - sg * size[1]};
+      double aa = dot3(lv, lv), bb = dot3(lv, q), cc = dot3(q, q) - size[0] * size[0], dd = bb * bb - aa * cc;
+      if (dd < MINVAL) continue;
+      double x = (-bb - sqrt(dd)) / aa;
+      if (x >= tnear && sg * (lp[2] + x * lv[2]) >= size[1] && (best < 0 || x < best)) best = x;
+    }
+    return best;
+  }
+  if (type == G_ELLIPSOID) {
+    double sc[3] = {1 / size[0], 1 / size[1], 1 / size[2]};
+    double v[3] = {lv[0] * sc[0], lv[1] * sc[1], lv[2] * sc[2]}, q[3] = {lp[0] * sc[0], lp[1] * sc[1], lp[2] * sc[2]};
+    double a = dot3(v, v), b = dot3(v, q), c = dot3(q, q) - 1, det = b * b - a * c;
+    if (det < MINVAL) return -1;
+    double x = (-b - sqrt(det)) / a;
+    return x >= tnear ? x : -1;
   }
   return -1;
 }

@@ -251,6 +251,37 @@ __device__ float ray_prim_any(int type, const float* size, const float* lp, cons
     }
     return best;
   }
+  if (type == RT_CAPSULE) {   // the cylinder's side between the caps, then the two end spheres beyond them
+    float best = -1.f;
+    const float a = lv[0] * lv[0] + lv[1] * lv[1], b = lv[0] * lp[0] + lv[1] * lp[1], c = lp[0] * lp[0] + lp[1] * lp[1] - size[0] * size[0];
+    if (a > 1e-15f) {
+      float det = b * b - a * c;
+      if (det >= 1e-15f) {
+        det = sqrtf(det);
+        for (int sgn = -1; sgn <= 1; sgn += 2) {
+          const float x = (-b + sgn * det) / a;
+          if (x >= 0 && fabsf(lp[2] + x * lv[2]) <= size[1] && (best < 0 || x < best)) best = x;
+        }
+      }
+    }
+    for (int sg = -1; sg <= 1; sg += 2) {
+      const float q[3] = {lp[0], lp[1], lp[2] - sg * size[1]};
+      const float aa = dot3(lv, lv), bb = dot3(lv, q), cc = dot3(q, q) - size[0] * size[0];
+      float dd = bb * bb - aa * cc;
+      if (dd < 1e-15f) continue;
+      dd = sqrtf(dd);
+      for (int sgn = -1; sgn <= 1; sgn += 2) {
+        const float x = (-bb + sgn * dd) / aa;
+        if (x >= 0 && sg * (lp[2] + x * lv[2]) >= size[1] && (best < 0 || x < best)) best = x;
+      }
+    }
+    return best;
+  }
+  if (type == RT_ELLIPSOID) {
+    const float sc[3] = {1.f / size[0], 1.f / size[1], 1.f / size[2]};
+    const float v[3] = {lv[0] * sc[0], lv[1] * sc[1], lv[2] * sc[2]}, q[3] = {lp[0] * sc[0], lp[1] * sc[1], lp[2] * sc[2]};
+    return ray_quad(dot3(v, v), dot3(v, q), dot3(q, q) - 1.f);
+  }
   return -1.f;
 }
 

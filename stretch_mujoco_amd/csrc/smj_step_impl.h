@@ -23,7 +23,7 @@
 #define SMJ_MAXIMP 0.9999f
 
 enum { JT_FREE = 0, JT_BALL = 1, JT_SLIDE = 2, JT_HINGE = 3 };
-enum { GT_PLANE = 0, GT_SPHERE = 2, GT_CYLINDER = 5, GT_BOX = 6, GT_MESH = 7 };
+enum { GT_PLANE = 0, GT_SPHERE = 2, GT_CAPSULE = 3, GT_ELLIPSOID = 4, GT_CYLINDER = 5, GT_BOX = 6, GT_MESH = 7 };
 enum { CT_EQUALITY = 0, CT_FRICTION = 1, CT_LIMIT = 3, CT_CONTACT_FRICTIONLESS = 5, CT_CONTACT_ELLIPTIC = 7, CT_NONE = -1 };
 
 struct TreeTmp {  // lives in the A region until A is built
@@ -1193,6 +1193,33 @@ struct StepKernel {
           }
         }
       }
+    } else if (t2 == GT_CAPSULE) {  // [MJ] mjc_PlaneCapsule: the two end spheres, +axis end first
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const float sg = e ? -1.f : 1.f;
+        const float c[3] = {gp[0] + sg * size[1] * gm[2], gp[1] + sg * size[1] * gm[5], gp[2] + sg * size[1] * gm[8]};
+        const float dif[3] = {c[0] - pp[0], c[1] - pp[1], c[2] - pp[2]};
+        const float dist = dot3(dif, n) - size[0];
+        if (dist <= margin) {
+          float pos[3];
+          for (int k = 0; k < 3; k++) pos[k] = c[k] - n[k] * (size[0] + 0.5f * dist);
+          put(dist, pos);
+        }
+      }
+    } else if (t2 == GT_ELLIPSOID) {  // [MJ] mjc_PlaneEllipsoid: the surface point whose outward normal is -n
+      float nl[3], sv[3], loc[3], wv[3];
+      mulmat3Tvec(nl, gm, n);
+      for (int k = 0; k < 3; k++) sv[k] = -nl[k] * size[k];
+      const float len = sqrtf(dot3(sv, sv));
+      for (int k = 0; k < 3; k++) loc[k] = len > SMJ_MINVAL ? size[k] * sv[k] / len : 0.f;
+      mulmat3vec(wv, gm, loc);
+      const float dif[3] = {gp[0] + wv[0] - pp[0], gp[1] + wv[1] - pp[1], gp[2] + wv[2] - pp[2]};
+      const float dist = dot3(dif, n);
+      if (dist <= margin) {
+        float pos[3];
+        for (int k = 0; k < 3; k++) pos[k] = gp[k] + wv[k] - n[k] * dist * 0.5f;
+        put(dist, pos);
+      }
     } else if (t2 == GT_BOX) {  // [MJ] mjc_PlaneBox
       const float dif[3] = {gp[0] - pp[0], gp[1] - pp[1], gp[2] - pp[2]};
       const float dist = dot3(dif, n);
@@ -1347,18 +1374,33 @@ struct StepKernel {
   struct Shape { int type, nvert; const float* verts; float pos[3], mat[9], size[3]; PL<float[12]> vc; };
   struct MprPt { float v[3], a[3], b[3]; };
 
+  // support point of a primitive in its own frame for the direction dl ([MJ] mjc_support)
+  SMJ_DEV static void prim_support(int type, const float* size, const float* dl, float* pl) {
+    pl[0] = pl[1] = pl[2] = 0.f;
+    if (type == GT_SPHERE) {
+      const float n = sqrtf(dot3(dl, dl));
+      if (n > SMJ_MINVAL) for (int i = 0; i < 3; i++) pl[i] = size[0] * dl[i] / n;
+    } else if (type == GT_BOX) {
+      for (int i = 0; i < 3; i++) pl[i] = dl[i] >= 0 ? size[i] : -size[i];
+    } else if (type == GT_CYLINDER) {
+      const float n = sqrtf(dl[0] * dl[0] + dl[1] * dl[1]);
+      if (n > SMJ_MINVAL) { pl[0] = size[0] * dl[0] / n; pl[1] = size[0] * dl[1] / n; }
+      pl[2] = dl[2] >= 0 ? size[1] : -size[1];
+    } else if (type == GT_CAPSULE) {     // a sphere swept along z: the sphere's support point, moved to the end the direction points to
+      const float n = sqrtf(dot3(dl, dl));
+      if (n > SMJ_MINVAL) for (int i = 0; i < 3; i++) pl[i] = size[0] * dl[i] / n;
+      pl[2] += dl[2] > 0 ? size[1] : (dl[2] < 0 ? -size[1] : 0.f);
+    } else if (type == GT_ELLIPSOID) {   // the unit sphere's support point for the scaled direction, scaled back
+      const float t[3] = {dl[0] * size[0], dl[1] * size[1], dl[2] * size[2]};
+      const float n = sqrtf(dot3(t, t));
+      if (n > SMJ_MINVAL) for (int i = 0; i < 3; i++) pl[i] = size[i] * t[i] / n;
+    }
+  }
   SMJ_DEV void shape_support(const Shape& sh, const float* dir, float* out) {
     float dl[3], pl[3] = {0, 0, 0};
     mulmat3Tvec(dl, sh.mat, dir);
-    if (sh.type == GT_SPHERE) {
-      const float n = sqrtf(dot3(dl, dl));
-      if (n > SMJ_MINVAL) for (int i = 0; i < 3; i++) pl[i] = sh.size[0] * dl[i] / n;
-    } else if (sh.type == GT_BOX) {
-      for (int i = 0; i < 3; i++) pl[i] = dl[i] >= 0 ? sh.size[i] : -sh.size[i];
-    } else if (sh.type == GT_CYLINDER) {
-      const float n = sqrtf(dl[0] * dl[0] + dl[1] * dl[1]);
-      if (n > SMJ_MINVAL) { pl[0] = sh.size[0] * dl[0] / n; pl[1] = sh.size[0] * dl[1] / n; }
-      pl[2] = dl[2] >= 0 ? sh.size[1] : -sh.size[1];
+    if (sh.type != GT_MESH) {
+      prim_support(sh.type, sh.size, dl, pl);
     } else {
       PL<float> best, bx, by, bz;
       PL<int> bidx;
@@ -1958,18 +2000,9 @@ struct StepKernel {
         const float* mat = second ? m.bmat : m.amat;
         const float* ps = second ? m.bpos : m.apos;
         const float dir[3] = {second ? -m.dir[0] : m.dir[0], second ? -m.dir[1] : m.dir[1], second ? -m.dir[2] : m.dir[2]};
-        float dl[3], pl[3] = {0, 0, 0};
+        float dl[3], pl[3];
         mulmat3Tvec(dl, mat, dir);
-        if (sh.type == GT_SPHERE) {
-          const float n = sqrtf(dot3(dl, dl));
-          if (n > SMJ_MINVAL) for (int i = 0; i < 3; i++) pl[i] = sh.size[0] * dl[i] / n;
-        } else if (sh.type == GT_BOX) {
-          for (int i = 0; i < 3; i++) pl[i] = dl[i] >= 0 ? sh.size[i] : -sh.size[i];
-        } else {   // cylinder
-          const float n = sqrtf(dl[0] * dl[0] + dl[1] * dl[1]);
-          if (n > SMJ_MINVAL) { pl[0] = sh.size[0] * dl[0] / n; pl[1] = sh.size[0] * dl[1] / n; }
-          pl[2] = dl[2] >= 0 ? sh.size[1] : -sh.size[1];
-        }
+        prim_support(sh.type, sh.size, dl, pl);
         float o[3];
         mulmat3vec(o, mat, pl);
         for (int i = 0; i < 3; i++) out[lane][i] = o[i] + ps[i];

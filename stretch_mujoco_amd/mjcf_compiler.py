@@ -379,19 +379,30 @@ class _Body:
         self.geoms: List[dict] = []
         self.sites: List[dict] = []
         self.cams: List[dict] = []
+        self.inertial: Optional[dict] = None
         self.id = -1
+
+
+_ANGLE_SCALE = [1.0]   # radians per angle unit of the document being parsed ([MJ] <compiler angle>: global, default degree)
+_EULER_SEQ = ["xyz"]
 
 
 def _orient(attrib: Dict[str, str]) -> np.ndarray:
     if "quat" in attrib:
         return quat_norm(_floats(attrib["quat"]))
     if "euler" in attrib:
-        return euler2quat(_floats(attrib["euler"]))
+        return euler2quat([a * _ANGLE_SCALE[0] for a in _floats(attrib["euler"])], _EULER_SEQ[0])
     if "zaxis" in attrib:
         return zaxis2quat(_floats(attrib["zaxis"]))
     if "axisangle" in attrib:
         v = _floats(attrib["axisangle"])
-        return axisangle2quat(v[:3], v[3])
+        return axisangle2quat(v[:3], v[3] * _ANGLE_SCALE[0])
+    if "xyaxes" in attrib:
+        v = np.array(_floats(attrib["xyaxes"]))
+        x = v[:3] / np.linalg.norm(v[:3])
+        y = v[3:] - np.dot(v[3:], x) * x
+        y = y / np.linalg.norm(y)
+        return mat2quat(np.stack([x, y, np.cross(x, y)], axis=1))
     return np.array([1.0, 0, 0, 0])
 
 
@@ -434,6 +445,9 @@ class MjcfCompiler:
         self.stat_extent: Optional[float] = None
         self.znear, self.zfar = 0.01, 50.0
         self.meshes_missing: List[str] = []
+        self.angle_scale = math.pi / 180.0   # [MJ] <compiler angle> defaults to degree
+        self.eulerseq = "xyz"
+        self.inertia_groups = (0, 5)
         self._geom_mesh_names: List[Optional[str]] = []
 
     # ---- parsing
@@ -452,13 +466,19 @@ class MjcfCompiler:
             assetdir = d
             for ch in part:
                 if ch.tag == "compiler":
-                    if ch.get("angle", "degree") != "radian":
-                        raise ValueError("only angle=radian is supported")
+                    # [MJ] compiler settings are global (includes are textual): the last `angle` / `eulerseq` given wins
+                    if "angle" in ch.attrib:
+                        self.angle_scale = 1.0 if ch.get("angle") == "radian" else math.pi / 180.0
+                    if "eulerseq" in ch.attrib:
+                        self.eulerseq = ch.get("eulerseq")
+                    if "inertiagrouprange" in ch.attrib:   # [MJ] only geoms of these groups give their bodies mass (robosuite: "0 0")
+                        self.inertia_groups = tuple(int(v) for v in ch.get("inertiagrouprange").split())
                     assetdir = os.path.join(d, ch.get("assetdir", ch.get("meshdir", "")))
             part.set("_assetdir", assetdir)
             for ch in part:
                 if ch.tag == "default":
                     self.defaults.parse(ch)
+        _ANGLE_SCALE[0], _EULER_SEQ[0] = self.angle_scale, self.eulerseq
         for part, d in parts:
             for ch in part:
                 if ch.tag == "asset":
@@ -498,7 +518,8 @@ class MjcfCompiler:
                 elif ch.tag == "equality":
                     for e in ch:
                         if e.tag != "joint":
-                            raise ValueError(f"unsupported equality type {e.tag}")
+                            raise ValueError(f"equality <{e.tag}> is not supported: this build restates <joint> equalities only "
+                                             f"(connect / weld / tendon / flex rows are not on the Stretch path)")
                         a = dict(_EQ_DEF)
                         a.update(self.defaults.get(e.get("class"), "equality"))
                         a.update(e.attrib)
@@ -554,7 +575,19 @@ class MjcfCompiler:
                 a = dict(_GEOM_DEF)
                 a.update(self.defaults.get(cls, "geom"))
                 a.update(ch.attrib)
-                a["_pos"], a["_quat"] = place({k: a[k] for k in ("pos", "quat", "euler", "zaxis", "axisangle") if k in a})
+                if "fromto" in a:   # [MJ] capsule / cylinder / box / ellipsoid between two points: centre, z axis and half length from them
+                    ft = np.array(_floats(a["fromto"]))
+                    vec = ft[0:3] - ft[3:6]
+                    sz = _floats(a["size"])
+                    half = 0.5 * float(np.linalg.norm(vec))
+                    if a["type"] in ("capsule", "cylinder"):
+                        a["size"] = f"{sz[0]} {half} 0"
+                    else:
+                        a["size"] = f"{sz[0]} {sz[1] if len(sz) > 1 else sz[0]} {half}"
+                    a = {k: v for k, v in a.items() if k not in ("quat", "euler", "axisangle", "xyaxes")}
+                    a["pos"] = " ".join(repr(float(x)) for x in 0.5 * (ft[0:3] + ft[3:6]))
+                    a["zaxis"] = " ".join(repr(float(x)) for x in vec)
+                a["_pos"], a["_quat"] = place({k: a[k] for k in ("pos", "quat", "euler", "zaxis", "axisangle", "xyaxes") if k in a})
                 body.geoms.append(a)
             elif ch.tag == "site":
                 a = dict(_SITE_DEF)
@@ -581,9 +614,13 @@ class MjcfCompiler:
                     self._parse_body_children(ch, body, childclass, frame=(p.copy(), q.copy()))
                     p = p + quat2mat(q) @ dp
                     q = quat_norm(quat_mul(q, dq))
-            elif ch.tag in ("light", "inertial"):
-                if ch.tag == "inertial":
-                    raise ValueError("<inertial> not supported")
+            elif ch.tag == "inertial":
+                # [MJ] explicit body inertia: replaces what the geoms would give (compiler inertiafromgeom="auto")
+                body.inertial = dict(pos=np.array(_floats(ch.get("pos", "0 0 0"))), quat=_orient(ch.attrib), mass=float(ch.get("mass")),
+                                     diag=_floats(ch.get("diaginertia")) if "diaginertia" in ch.attrib else None,
+                                     full=_floats(ch.get("fullinertia")) if "fullinertia" in ch.attrib else None)
+            elif ch.tag == "light":
+                pass
             else:
                 raise ValueError(f"unsupported element <{ch.tag}> in body")
 
@@ -644,7 +681,8 @@ class MjcfCompiler:
                 ax = np.array(_floats(j["axis"], 3))
                 jnt_axis.append(ax / max(np.linalg.norm(ax), MINVAL))
                 jnt_stiffness.append(float(j["stiffness"]))
-                rng = _floats(j["range"], 2) if "range" in j else [0.0, 0.0]
+                asc = self.angle_scale if t == JNT_HINGE else 1.0   # [MJ] hinge range / ref / springref are in the compiler's angle unit
+                rng = [asc * x for x in _floats(j["range"], 2)] if "range" in j else [0.0, 0.0]
                 lim = j.get("limited", "auto")
                 jnt_limited.append(int((lim == "true") or (lim == "auto" and "range" in j)))
                 jnt_range.append(rng)
@@ -666,8 +704,8 @@ class MjcfCompiler:
                     qpos0.extend(list(b.pos) + list(b.quat))
                     qpos_spring.extend(list(b.pos) + list(b.quat))
                 else:
-                    qpos0.append(float(j["ref"]))
-                    qpos_spring.append(float(j["springref"]))
+                    qpos0.append(asc * float(j["ref"]))
+                    qpos_spring.append(asc * float(j["springref"]))
             body_dofnum.append(len(dof_bodyid) - nd0)
             body_lastdof[b.id] = last
         nq, nv, njnt = len(qpos0), len(dof_bodyid), len(jnt_type)
@@ -739,7 +777,7 @@ class MjcfCompiler:
                     vol = 4.0 / 3 * math.pi * size[0] * size[1] * size[2]
                     I = np.diag([vol / 5 * (size[1] ** 2 + size[2] ** 2), vol / 5 * (size[0] ** 2 + size[2] ** 2),
                                  vol / 5 * (size[0] ** 2 + size[1] ** 2)])
-                if t != GEOM_PLANE and vol > 0:
+                if t != GEOM_PLANE and vol > 0 and self.inertia_groups[0] <= int(g["group"]) <= self.inertia_groups[1]:
                     m = mass_attr if mass_attr is not None else dens * vol
                     if m > 0:
                         sc = m / vol
@@ -798,7 +836,21 @@ class MjcfCompiler:
                 G["ccenter"].append(hull_verts[mesh_names.index(g["mesh"])].mean(0) if (t == GEOM_MESH and num > 0) else np.zeros(3))
                 G["name"].append(g.get("name", ""))
                 self._geom_mesh_names.append(g.get("mesh") if t == GEOM_MESH else None)
-            if parts:
+            if b.inertial is not None:
+                it = b.inertial
+                if it["full"] is not None:   # xx yy zz xy xz yz in the body frame: principal axes by eigen-decomposition
+                    f = it["full"]
+                    I = np.array([[f[0], f[3], f[4]], [f[3], f[1], f[5]], [f[4], f[5], f[2]]])
+                    w, V = np.linalg.eigh(I)
+                    order = np.argsort(-w)
+                    w, V = w[order], V[:, order]
+                    if np.linalg.det(V) < 0:
+                        V[:, 2] = -V[:, 2]
+                    iq = mat2quat(V)
+                else:
+                    w, iq = np.array(it["diag"], float), it["quat"]
+                body_mass[b.id], body_ipos[b.id], body_iquat[b.id], body_inertia[b.id] = it["mass"], it["pos"], iq, w
+            elif parts:
                 M = sum(p[0] for p in parts)
                 c = sum(p[0] * p[1] for p in parts) / M
                 I = np.zeros((3, 3))

@@ -158,3 +158,37 @@ def test_big_builds_hand_over_to_the_224_row_build(scene):
     torch.cuda.synchronize()
     assert int(sim.info[3].max()) & 1   # without it the same step is flagged
     sim.stop()
+
+
+def test_kitchen_export_on_the_device():
+    """The converted robosuite-style export (tests/test_compiler_generality.py has the CPU side) through StretchBatchSimulator on
+    the device, the robot started at the removed robosuite robot's pose (`start_translation`, like the reference's
+    change_start_pose): state-synchronised against the fp64 oracle for 600 steps of the reach / press / sweep script."""
+    from stretch_mujoco_amd import StretchBatchSimulator
+    from test_compiler_generality import KX_SCRIPT, kx_start
+
+    sim = StretchBatchSimulator(num_envs=2, device="cuda:0", scene="stretch_kitchen_export", solver="newton",
+                                start_translation=[0.0, -0.2, 0.0], start_rotation_quat=[1.0, 0.0, 0.0, 0.0])
+    sim.start(home=False)
+    assert sim.nv == 46 and sim.nefc_max == 160 and float(sim.qpos[1, 0]) == pytest.approx(-0.2)
+    o = Oracle(sim._blob); o.set_option("solver", 2)
+    kx_start(o)
+    errs, same = [], 0
+    for k in range(600):
+        for k0, c in KX_SCRIPT:
+            if k == k0:
+                o.arr("ctrl")[:] = c
+                sim.ctrl[:] = torch.tensor(c, dtype=torch.float32, device=sim.device).unsqueeze(1)
+        for e in range(2):
+            sim.qpos[:, e] = torch.tensor(o.arr("qpos"), dtype=torch.float32, device=sim.device)
+            sim.qvel[:, e] = torch.tensor(o.arr("qvel"), dtype=torch.float32, device=sim.device)
+            sim.qacc_warmstart[:, e] = torch.tensor(o.arr("qacc_warmstart"), dtype=torch.float32, device=sim.device)
+        o.step(1); sim.step(1)
+        torch.cuda.synchronize()
+        assert int(sim.info[3].max()) == 0, k
+        if (int(sim.info[0, 0]), int(sim.info[1, 0])) == (o.nefc, o.ncon):
+            same += 1
+            errs.append(np.abs(sim.qvel[:, 0].cpu().numpy() - o.arr("qvel")).max() / max(1.0, np.abs(o.arr("qvel")).max()))
+    errs = np.sort(np.array(errs))
+    assert same >= 570 and errs[int(0.9 * len(errs))] < 5e-4 and torch.equal(sim.qpos[:, 0], sim.qpos[:, 1]), (same, errs[-5:])
+    sim.stop()

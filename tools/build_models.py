@@ -35,6 +35,15 @@ def main():
         mm = C.compile_string(xml)
         B.save(os.path.join(out, name + ".smjb"), F.prepare_for_kernels(mm))
         print(name + ":", dict(zip("nq nv nu nbody njnt ngeom".split(), [int(x) for x in mm["dims"][:6]])), "npair", int(mm["dims"][12]))
+    # a robosuite-style kitchen export (hand-written test fixture: articulated fixtures, <inertial>, capsule / ellipsoid objects)
+    # through the converter for pre-exported Robocasa kitchens (robocasa_import.py; robocasa_gen.py:242-280)
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    from kitchen_export_fixture import KITCHEN_EXPORT
+    from stretch_mujoco_amd.robocasa_import import convert_kitchen_xml
+    kx, pose = convert_kitchen_xml(KITCHEN_EXPORT, stretch)
+    ke = C.compile_string(kx)
+    B.save(os.path.join(out, "stretch_kitchen_export.smjb"), F.prepare_for_kernels(ke))
+    print("stretch_kitchen_export:", dict(zip("nq nv nu nbody njnt ngeom".split(), [int(x) for x in ke["dims"][:6]])), "npair", int(ke["dims"][12]), "spawn pose", pose)
     print("stretch_kitchen_standin:", dict(zip("nq nv nu nbody njnt ngeom".split(), [int(x) for x in k["dims"][:6]])),
           "npair", int(k["dims"][12]))
     print("stretch_empty:", dict(zip("nq nv nu nbody njnt ngeom nsite ncam neq ntendon nwrap nkey npair nhullvert".split(),
