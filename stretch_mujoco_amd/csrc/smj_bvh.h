@@ -27,6 +27,7 @@ struct SmjBvhSet {
   std::vector<float> node;  // [inner node][16]: child 2n lo.xyz,0 hi.xyz,0, child 2n+1 lo.xyz,0 hi.xyz,0  (empty child: lo = +big, hi = -big)
   std::vector<float> tri;   // [ntri][12]: v0.xyz, 0, e1.xyz, 0, e2.xyz, 0  (padding triangles are all zero)
   std::vector<SmjBvhMesh> mesh;
+  std::vector<std::vector<int>> order;   // per mesh: its faces in leaf order (spatially coherent runs: the rasteriser's meshlets)
 };
 
 // verts: float[nv][3]; faces: int[nf][3] (indices into verts)
@@ -170,4 +171,8 @@ static inline void smj_bvh_add_mesh(SmjBvhSet& set, const float* verts, int nv, 
     for (int k = 0; k < 8; k++) { P[16 * n + k] = N[8 * (2 * n) + k]; P[16 * n + 8 + k] = N[8 * (2 * n + 1) + k]; }
   for (int k = 0; k < 8; k++) P[k] = N[8 + k];   // slot 0 (no heap node 0): the root's own box, for hosts that want it
   set.mesh.push_back(m);
+  std::vector<int> ord(nf);
+  for (int f = 0; f < nf; f++) ord[f] = f;
+  std::sort(ord.begin(), ord.end(), [&](int a, int b) { return slot[a] < slot[b]; });
+  set.order.push_back(std::move(ord));
 }

@@ -16,6 +16,7 @@
 #include "smj_kernels.h"
 #include "smj_model_load.h"
 #include "smj_bvh.h"
+#include "smj_meshlet.h"
 #include "smj_render.h"
 
 struct smj_ctx {
@@ -212,6 +213,37 @@ static int setup_render(smj_ctx* c, const void* blob, size_t nbytes) {
   r.mesh = reinterpret_cast<const int4*>(up.i32(meshtab));
   if (!r.rgeom || !r.geom_rmeshid || !r.cam_bodyid || !r.cam_pos || !r.cam_mat || !r.node || !r.tri || !r.mesh)
     return fail(c, -2, "device allocation failed for the render tables");
+  {   // the mesh rasteriser's tables: meshlets of every render mesh and the work list over the mesh geoms a camera can see
+    const SmjBlobEntry* gt = b.find("geom_type");
+    std::vector<int> rgh = geti(rg), gmh = geti(gm), gth = gt ? geti(gt) : std::vector<int>();
+    SmjMeshletSet ml;
+    for (size_t i = 0; i < nmesh; i++) smj_meshlets_add_mesh(ml, verts + 3 * (size_t)vadr[i], faces + 3 * (size_t)fadr[i], set.order[i]);
+    std::vector<int> rec(12 * (ml.let.size() ? ml.let.size() : 1), 0), work;
+    for (size_t i = 0; i < ml.let.size(); i++) {
+      const SmjMeshlet& m = ml.let[i];
+      int* q = rec.data() + 12 * i;
+      q[0] = m.vbase; q[1] = m.nvert; q[2] = m.tbase; q[3] = m.ntri;
+      const float f[8] = {m.cen[0], m.cen[1], m.cen[2], m.rad, m.axis[0], m.axis[1], m.axis[2], m.cosc};
+      memcpy(q + 4, f, sizeof f);
+    }
+    for (int i = 0; i < nrgeom && gt; i++) {
+      const int g = rgh[i];
+      if (gth[g] != 7 || gmh[g] < 0) continue;
+      for (int k = 0; k < ml.mesh_count[gmh[g]]; k++) { work.push_back(i); work.push_back(ml.mesh_first[gmh[g]] + k); }
+    }
+    r.nmlist = (int)(work.size() / 2);
+    if (work.empty()) work.assign(2, 0);
+    if (ml.vert.empty()) ml.vert.assign(4, 0.f);
+    std::vector<int> tri(ml.tri.begin(), ml.tri.end());
+    if (tri.empty()) tri.assign(1, 0);
+    r.mlvert = reinterpret_cast<const float4*>(up.f32(ml.vert));
+    r.mltri = reinterpret_cast<const unsigned*>(up.i32(tri));
+    r.mlrec = reinterpret_cast<const int4*>(up.i32(rec));
+    r.mlist = reinterpret_cast<const int2*>(up.i32(work));
+    if (!r.mlvert || !r.mltri || !r.mlrec || !r.mlist) return fail(c, -2, "device allocation failed for the meshlet tables");
+    r.raster = 1;
+    r.raster_splits = 8;
+  }
   c->has_render = true;
   return 0;
 }
@@ -653,6 +685,8 @@ int smj_set_option(smj_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "solver")) m.solver = (int)v;
   else if (!strcmp(name, "convex_pairs")) m.convex_pairs = (int)v;
   else if (!strcmp(name, "multiccd")) m.multiccd = (int)v;
+  else if (!strcmp(name, "depth_raster")) c->render.raster = (int)v;            // 0: ray cast the meshes through their BVHs (the round-2 path)
+  else if (!strcmp(name, "depth_raster_splits")) c->render.raster_splits = (int)(v < 1 ? 1 : v > 256 ? 256 : v);
   else if (!strcmp(name, "primary_rows")) m.row_limit = (int)v;   // the escalation variant keeps its full capacity (model_esc is not touched)
   else if (!strcmp(name, "escalate")) c->escalate = (int)v;
   else if (!strcmp(name, "balance")) c->balance = (int)v;

@@ -12,10 +12,26 @@
 // bounding-sphere reject and, for meshes, a stack-free walk of the mesh BVH (heap layout, see smj_bvh.h) in the mesh frame.
 #include "smj_render.h"
 #include "smj_bvh.h"   // SMJ_BVH_LEAF
+#include "smj_meshlet.h"   // SMJ_MESHLET_TRIS / _VERTS
 
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace {
+
+// Work counters of the depth kernel (a tools-only build, -DSMJ_DEPTH_STATS: the image then holds a per-ray count instead of the
+// depth -- 0: geoms in the tile's list, 1: geoms past the bounding-sphere reject, 2: mesh walks, 3: inner-node visits, 4: leaves)
+#ifdef SMJ_DEPTH_STATS
+#define STAT(k) (stat_cnt[k] += 1.f)
+#define STAT_DECL float stat_cnt[5] = {0, 0, 0, 0, 0};
+#define STAT_ARG , float* stat_cnt
+#define STAT_PASS , stat_cnt
+#else
+#define STAT(k) ((void)0)
+#define STAT_DECL
+#define STAT_ARG
+#define STAT_PASS
+#endif
 
 constexpr int TILE = 16;   // pixels per side of a workgroup's tile (32 was measured slower: coarser culling outweighs the shared staging)
 
@@ -80,7 +96,7 @@ __device__ __forceinline__ float ray_box(const float4 lo, const float4 hi, const
   return (t0 <= t1 && lo.x <= hi.x) ? t0 : -1.f;   // padding boxes are stored inverted: the slab test alone would accept them
 }
 template <bool CULL>
-__device__ float ray_mesh(const DevRender& R, int rmesh, const float* o, const float* d, float tnear, float best) {
+__device__ float ray_mesh(const DevRender& R, int rmesh, const float* o, const float* d, float tnear, float best STAT_ARG) {
   const int4 mi = R.mesh[rmesh];
   const float4* node = R.node + 4 * (long)mi.x;
   const float4* tri = R.tri + 3 * (long)mi.y;
@@ -94,6 +110,7 @@ __device__ float ray_mesh(const DevRender& R, int rmesh, const float* o, const f
   unsigned trail = 0;
   while (true) {
     // n is an inner node
+    STAT(3);
     const float4 l0 = node[4 * n], h0 = node[4 * n + 1], l1 = node[4 * n + 2], h1 = node[4 * n + 3];
     const float e0 = ray_box(l0, h0, o, inv, tnear, best), e1 = ray_box(l1, h1, o, inv, tnear, best);
     bool down = false;
@@ -108,6 +125,7 @@ __device__ float ray_mesh(const DevRender& R, int rmesh, const float* o, const f
     while (true) {
       if (down) {
         if (n < leaf0) break;   // an inner node: test its children next
+        STAT(4);
         best = ray_leaf<CULL>(tri + 3 * SMJ_BVH_LEAF * (long)(n - leaf0), o, d, tnear, best);
         down = false;
       }
@@ -344,7 +362,8 @@ __global__ __launch_bounds__(384) void smj_lidar_kernel(const DevRender R, const
       mulT(lv, G.mat, vec);
       if (G.type == RT_MESH) {
         if (G.rmesh >= 0) {
-          const float x = ray_mesh<false>(R, G.rmesh, lp, lv, 0.f, lim);
+          STAT_DECL
+          const float x = ray_mesh<false>(R, G.rmesh, lp, lv, 0.f, lim STAT_PASS);
           if (x < lim) best = x;
         }
       } else {
@@ -370,8 +389,13 @@ __global__ __launch_bounds__(384) void smj_lidar_kernel(const DevRender R, const
 //
 // Workspace per env (floats): header cpos[3], cmat[9], count; then one 32-float slot per surviving geom in front-to-back
 // order: RGeom (pos 3, mat 9, cen 3, rbound, size 3, type, rmesh, geom id = 22 words), rect x0 x1 y0 y1.
-constexpr int WS_HDR = 16, WS_SLOT = 32, WS_RECT = 24;
-constexpr int WS_STRIDE = WS_HDR + SMJ_RGEOM_MAX * WS_SLOT;
+constexpr int WS_HDR = 16, WS_SLOT = 48, WS_RECT = 24, WS_RCG = 28, WS_TCG = 37, WS_LP = 40;   // slot: RGeom words 0..21, rect, geom -> camera rotation / translation, camera position in the geom frame
+constexpr int WS_IDX = WS_HDR + SMJ_RGEOM_MAX * WS_SLOT;   // [SMJ_RGEOM_MAX] slot of visible-geom table entry i, or -1 (the rasteriser's look-up)
+// Triangles the rasteriser hands to the per-pixel kernel (boxes beyond 16384 pixels, triangles cut by the near plane): per env a
+// count and up to HLCAP entries of HLW words -- v0, e1, e2 in the camera frame, the pixel box u0 | u1 << 16, w0 | w1 << 16
+constexpr int HLCAP = 256, HLW = 12;   // (one per thread of the per-pixel kernel's list builder)
+constexpr int WS_HL = WS_IDX + SMJ_RGEOM_MAX;
+constexpr int WS_STRIDE = WS_HL + 4 + HLCAP * HLW;
 
 // mode 0: all visible geoms.  mode 1: only the geoms rigidly attached to the camera's body, with that body at the
 // identity (no state is read) -- the camera-static layer.  mode 2: all other geoms.
@@ -440,8 +464,8 @@ __global__ __launch_bounds__(128) void smj_depth_prepass(const DevRender R, cons
           const float e = 1e-5f * (1.f + fabsf(lo) + fabsf(hi));
           rect[2 * a] = lo - e; rect[2 * a + 1] = hi + e;
         }
-        if (G.type == RT_MESH) {
-          // a mesh's box (geom frame): long thin parts have large bounding spheres but small projections
+        {
+          // the geom's box (geom frame): long thin parts and big flat fixtures have large bounding spheres but small projections
           const float* bb = R.geom_aabb + 6 * R.rgeom[tid];
           float lo[2] = {BIG, BIG}, hi[2] = {-BIG, -BIG}, dmin = BIG;
           bool ok = true;
@@ -488,18 +512,26 @@ __global__ __launch_bounds__(128) void smj_depth_prepass(const DevRender R, cons
       S[15] = G.rbound;
       S[19] = __int_as_float(G.type); S[20] = __int_as_float(G.rmesh); S[21] = __int_as_float(R.rgeom[tid]);
       for (int k = 0; k < 4; k++) S[WS_RECT + k] = rect[k];
+      // for the rasteriser: geom frame -> camera frame (x right, y up, looking down -z), and the camera in the geom frame
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) S[WS_RCG + 3 * i + j] = cmat[i] * G.mat[j] + cmat[3 + i] * G.mat[3 + j] + cmat[6 + i] * G.mat[6 + j];
+      const float gc[3] = {G.pos[0] - cpos[0], G.pos[1] - cpos[1], G.pos[2] - cpos[2]}, cg[3] = {-gc[0], -gc[1], -gc[2]};
+      mulT(S + WS_TCG, cmat, gc);
+      mulT(S + WS_LP, G.mat, cg);
     }
+    reinterpret_cast<int*>(W + WS_IDX)[tid] = key < 1.0e38f ? rank : -1;
     if (tid == 0) {
       for (int k = 0; k < 3; k++) W[k] = cpos[k];
       for (int k = 0; k < 9; k++) W[3 + k] = cmat[k];
       W[12] = __int_as_float(kept);
+      reinterpret_cast<int*>(W + WS_HL)[0] = 0;
     }
   }
 }
 
 // COLOR: the RGB stand-in -- besides the nearest depth the ray keeps WHICH geom gave it; writes that geom's 8-bit albedo
 // (rgb_out) and, if asked, its id (gid_out) instead of the depth.  A second instantiation: the depth cameras' loop stays as it is.
-template <bool COLOR>
+template <bool COLOR, bool RASTER>
 __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const float* __restrict__ ws, int width, int height,
                                                         float tan_half_fovy, float max_depth, float* __restrict__ out,
                                                         const float* __restrict__ layer, int mode,
@@ -507,6 +539,8 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
   __shared__ RGeom geoms[SMJ_RGEOM_MAX];
   __shared__ float cpos[3], cmat[9];
   __shared__ int wcount[2];
+  __shared__ float htri[RASTER ? HLCAP : 1][9];   // the rasteriser's handed-over triangles that meet this tile (camera frame)
+  __shared__ int hcount[4];
   const int env = blockIdx.y;
   const int tiles_x = (width + TILE - 1) / TILE;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
@@ -527,6 +561,7 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
     const float y1 = (1.f - (float)(ty * TILE) / height * 2.f) * tan_half_fovy;
     const float y0 = (1.f - (float)(ty * TILE + TILE) / height * 2.f) * tan_half_fovy;
     keep = S[1] >= x0 && S[0] <= x1 && S[3] >= y0 && S[2] <= y1;
+    if (RASTER && __float_as_int(S[19 - WS_RECT]) == RT_MESH) keep = 0;   // meshes are in the z-buffer already (smj_raster_kernel)
   }
   const unsigned long long bal = __ballot(keep);
   const int wv0 = tid >> 6, ln0 = tid & 63;
@@ -542,6 +577,25 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
     G.type = __float_as_int(S[19]); G.rmesh = __float_as_int(S[20]); G.gid = __float_as_int(S[21]);
   }
   const int nkeep_total = wcount[0] + wcount[1];
+  int nhuge = 0;
+  if (RASTER) {
+    const int* H = reinterpret_cast<const int*>(W + WS_HL);
+    const int nh = min(H[0], HLCAP);
+    int hk = 0;
+    if (tid < nh) {
+      const int bu = H[4 + tid * HLW + 9], bw = H[4 + tid * HLW + 10];
+      hk = (bu >> 16) >= tx * TILE && (bu & 0xffff) < tx * TILE + TILE && (bw >> 16) >= ty * TILE && (bw & 0xffff) < ty * TILE + TILE;
+    }
+    const unsigned long long hb = __ballot(hk);
+    if (ln0 == 0) hcount[wv0] = __popcll(hb);
+    __syncthreads();
+    if (hk) {
+      int at = __popcll(hb & ((1ull << ln0) - 1ull));
+      for (int q = 0; q < wv0; q++) at += hcount[q];
+      for (int k = 0; k < 9; k++) htri[at][k] = W[WS_HL + 4 + tid * HLW + k];
+    }
+    nhuge = hcount[0] + hcount[1] + hcount[2] + hcount[3];
+  }
   __syncthreads();
   // A workgroup renders a TILE x TILE pixel tile with its 256 threads in (TILE/16)^2 rounds; each wavefront covers an 8x8
   // pixel square (not a 16x4 strip): neighbouring rays share more of their walk.  The staging and culling above are paid
@@ -561,28 +615,51 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
     const float dd = dot3(d, d), dl = sqrtf(dd);
     float best = tfar * (1.f + 1e-6f);
     int hit = -1;
+    STAT_DECL
     if (mode == 2) best = fminf(best, layer[(long)v * width + u]);
+    if (RASTER) best = fminf(best, out[mode == 1 ? (long)v * width + u : ((long)env * height + v) * width + u]);   // nearest mesh hit of this pixel
     for (int i = 0; i < ng; i++) {
       const RGeom& G = geoms[i];
+      STAT(0);
       if (G.type != RT_PLANE) {   // bounding sphere
         const float oc[3] = {G.cen[0] - o[0], G.cen[1] - o[1], G.cen[2] - o[2]};
         const float b = dot3(oc, d), r = G.rbound;
         if (dot3(oc, oc) * dd - b * b > r * r * dd) continue;
         if (b + r * dl < tnear * dd || b - r * dl > best * dd) continue;
       }
+      STAT(1);
       const float dif[3] = {o[0] - G.pos[0], o[1] - G.pos[1], o[2] - G.pos[2]};
       float lp[3], lv[3];
       mulT(lp, G.mat, dif);
       mulT(lv, G.mat, d);
       if (G.type == RT_MESH) {
         if (G.rmesh >= 0) {
-          const float nb = ray_mesh<true>(R, G.rmesh, lp, lv, tnear, best);
+          STAT(2);
+          const float nb = ray_mesh<true>(R, G.rmesh, lp, lv, tnear, best STAT_PASS);
           if (COLOR && nb < best) hit = G.gid;
           best = nb;
         }
       } else {
         const float x = ray_prim(G.type, G.size, lp, lv, tnear);
         if (x >= 0 && x < best) { best = x; if (COLOR) hit = G.gid; }
+      }
+    }
+    if (RASTER) {   // the large / near-plane-cut triangles of the meshes: the ray (origin 0, direction dc) in the camera frame
+      for (int i = 0; i < nhuge; i++) {
+        const float* t = htri[i];
+        const float p[3] = {dc[1] * t[8] - dc[2] * t[7], dc[2] * t[6] - dc[0] * t[8], dc[0] * t[7] - dc[1] * t[6]};
+        const float det = t[3] * p[0] + t[4] * p[1] + t[5] * p[2];
+        if (det > 1e-30f) {
+          const float id = 1.f / det;
+          const float tv[3] = {-t[0], -t[1], -t[2]};
+          const float uu = (tv[0] * p[0] + tv[1] * p[1] + tv[2] * p[2]) * id;
+          const float q[3] = {tv[1] * t[5] - tv[2] * t[4], tv[2] * t[3] - tv[0] * t[5], tv[0] * t[4] - tv[1] * t[3]};
+          const float vv = (dc[0] * q[0] + dc[1] * q[1] + dc[2] * q[2]) * id;
+          if (uu >= 0.f && vv >= 0.f && uu + vv <= 1.f) {
+            const float tt = (t[6] * q[0] + t[7] * q[1] + t[8] * q[2]) * id;   // dc[2] = -1: the ray parameter is the depth
+            if (tt >= tnear && tt < best) best = tt;
+          }
+        }
       }
     }
     if (COLOR) {
@@ -596,10 +673,300 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
     }
     float z = best;
     if (mode == 1) { out[(long)v * width + u] = z; continue; }   // raw nearest depth (or just beyond the far plane)
+#ifdef SMJ_DEPTH_STATS
+    if (R.stat_select >= 0) { out[((long)env * height + v) * width + u] = stat_cnt[R.stat_select]; continue; }
+#endif
     if (z > tfar) z = (max_depth > 0.f) ? 0.f : R.zfar;   // nothing in range: the far plane, which limit_depth_distance zeroes
     if (max_depth > 0.f && z > max_depth) z = 0.f;
     out[((long)env * height + v) * width + u] = z;
   }
+}
+
+// ------------------------------------------------------------------------------------------------ mesh rasteriser
+// The robot's visual meshes are 196 k triangles: casting a ray per pixel walks ~8 BVH nodes per ray for ~1 triangle test (and a
+// wave pays for its slowest ray).  Here the meshes are RASTERISED into the depth image with atomicMin, and the per-pixel kernel
+// only resolves the primitives (floor, fixtures) against that z-buffer:
+//  * one WAVEFRONT per meshlet (smj_meshlet.h: <= 128 triangles in BVH leaf order, <= 256 own vertices, bounding sphere, normal
+//    cone).  A meshlet that is out of the depth range, off screen or turned away from the camera is dropped whole;
+//  * lane = vertex: each vertex goes to the camera frame and the screen ONCE, into the wave's LDS slice;
+//  * lane = triangle: screen box from the projected vertices, back faces out by the sign of the screen area.  Only a few per cent
+//    of the triangles have a pixel centre in their box; those are compacted into the wave's LDS queue as barycentric edge
+//    functions (relative to the box corner) + 1 / depth at the vertices (perspective-correct: 1 / depth is affine on screen);
+//  * lane = candidate pixel: the queue's candidate counts are prefix-summed and every lane takes one candidate at a time (binary
+//    search of the prefix for its triangle), so small and medium triangles fill the lanes whatever the mix;
+//  * a triangle cut by the near plane has no projection as a whole (the shell of the head around the head camera): its part beyond
+//    the plane is one or two triangles, whose screen box is what the per-pixel kernel gets together with the uncut triangle
+//    (camera frame, the env's workspace) -- it tests such triangles like primitives, per tile; so it does the handful of
+//    triangles with more than 16384 candidate pixels.  (List full: the cut triangles are rasterised here after all.)
+// Same image as the ray caster (pixel centres, front faces only, depth along the optical axis, t >= znear) up to fp32 rounding
+// and the tie-break at shared edges: tests/test_gpu_depth.py compares the two.
+__device__ __forceinline__ float rl(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+constexpr int RASTER_MAX_BOX = 16384;   // candidate pixels a wave still takes itself (256 rounds of 64); larger boxes go to the per-pixel kernel
+struct MlEntry { float la[3], lb[3], lc[3], w[3]; int u0, w0, nu, npx; };   // lambda_k(col, row) = la[k] col + lb[k] row + lc[k]
+
+__global__ __launch_bounds__(256) void smj_meshlet_kernel(const DevRender R, float* __restrict__ ws, int width, int height,
+                                                          float tan_half_fovy, float tfar_eps, float* __restrict__ zbuf, int single_image) {
+  __shared__ float vx[4][SMJ_MESHLET_VERTS], vy[4][SMJ_MESHLET_VERTS], vd[4][SMJ_MESHLET_VERTS];
+  __shared__ MlEntry queue[4][64];
+  __shared__ int prefix[4][65];
+  const int env = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float* W = ws + (long)env * WS_STRIDE;
+  const int* slot_of = reinterpret_cast<const int*>(W + WS_IDX);
+  int* HL = reinterpret_cast<int*>(W + WS_HL);
+  float* zimg = zbuf + (single_image ? 0 : (long)env * height * width);
+  const float aspect = (float)width / (float)height, tnear = R.znear, tx = tan_half_fovy * aspect, ty = tan_half_fovy;
+  const float sx = 0.5f * width / tx, sy = 0.5f * height / ty;
+  const float dn = tnear * (1.f - 1e-3f);
+  float* X = vx[wv]; float* Y = vy[wv]; float* Dp = vd[wv];
+  MlEntry* Q = queue[wv];
+  int* pre = prefix[wv];
+  for (int m = blockIdx.x * 4 + wv; m < R.nmlist; m += gridDim.x * 4) {
+    const int2 pr = R.mlist[m];                       // (visible-geom table entry, meshlet)
+    const int sl = __builtin_amdgcn_readfirstlane(slot_of[pr.x]);
+    if (sl < 0) continue;                             // dropped by the staging pass for this env (out of range, other layer)
+    const float* S = W + WS_HDR + (long)sl * WS_SLOT;
+    float rcg[9], tcg[3], lp[3];
+    for (int k = 0; k < 9; k++) rcg[k] = S[WS_RCG + k];
+    for (int k = 0; k < 3; k++) { tcg[k] = S[WS_TCG + k]; lp[k] = S[WS_LP + k]; }
+    const int4 r0 = R.mlrec[3 * pr.y];
+    const float4 r1 = reinterpret_cast<const float4*>(R.mlrec)[3 * pr.y + 1], r2 = reinterpret_cast<const float4*>(R.mlrec)[3 * pr.y + 2];
+    const int vbase = r0.x, nvert = r0.y, tbase = r0.z, ntri = r0.w;
+    {   // the meshlet's bounding sphere against depth range and frustum, its normal cone against the camera
+      const float cen[3] = {r1.x, r1.y, r1.z}, rad = r1.w;
+      float cc[3];
+      mul(cc, rcg, cen);
+      const float ccx = cc[0] + tcg[0], ccy = cc[1] + tcg[1], D = -(cc[2] + tcg[2]);
+      if (D + rad < tnear || D - rad > tfar_eps) continue;
+      // (a point at depth d is on screen iff |x| <= d tx, |y| <= d ty; the sphere's points have depth <= D + rad)
+      if (ccx - rad > (D + rad) * tx || -ccx - rad > (D + rad) * tx || ccy - rad > (D + rad) * ty || -ccy - rad > (D + rad) * ty) continue;
+      if (r2.w > 0.f) {
+        // every face normal within theta of the axis; u = direction camera -> centre, phi its angle to the axis.  A face at x is
+        // turned away iff n . (x - camera) >= 0; n . (x - camera) >= dist cos(phi + theta) - rad when phi + theta < 90 deg
+        const float uv[3] = {cen[0] - lp[0], cen[1] - lp[1], cen[2] - lp[2]};
+        const float dist = sqrtf(uv[0] * uv[0] + uv[1] * uv[1] + uv[2] * uv[2]);
+        const float cf = (r2.x * uv[0] + r2.y * uv[1] + r2.z * uv[2]) / fmaxf(dist, 1e-20f);
+        const float sf = sqrtf(fmaxf(0.f, 1.f - cf * cf)), sc = sqrtf(fmaxf(0.f, 1.f - r2.w * r2.w));
+        const float val = cf * r2.w - sf * sc;
+        if (cf > 0.f && val > 0.f && val * dist >= rad) continue;
+      }
+    }
+    // lane = vertex: camera frame, then the screen (pixel coordinates); a vertex nearer than the near plane keeps its camera x, y
+    for (int j = lane; j < nvert; j += 64) {
+      const float4 v = R.mlvert[vbase + j];
+      const float pv[3] = {v.x, v.y, v.z};
+      float cv[3];
+      mul(cv, rcg, pv);
+      const float cxx = cv[0] + tcg[0], cyy = cv[1] + tcg[1], D = -(cv[2] + tcg[2]);
+      if (D >= dn) {
+        const float inv = 1.f / D;
+        X[j] = cxx * inv * sx + 0.5f * width; Y[j] = 0.5f * height - cyy * inv * sy;
+      } else { X[j] = cxx; Y[j] = cyy; }
+      Dp[j] = D;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int round = 0; round < SMJ_MESHLET_TRIS / 64; round++) {
+      if (round * 64 >= ntri) break;                  // uniform
+      const int k = round * 64 + lane;
+      // the lane's triangle as up to two SCREEN triangles (pixel coordinates + depth): itself, or -- cut by the near plane, where it
+      // has no projection as a whole -- the one or two triangles of its part beyond the plane
+      float qx[4] = {0, 0, 0, 0}, qy[4] = {0, 0, 0, 0}, qd[4] = {1, 1, 1, 1};
+      int nsub = 0;
+      if (k < ntri) {
+        const unsigned t = R.mltri[tbase + k];
+        const int ia = t & 255, ib = (t >> 8) & 255, ic = (t >> 16) & 255;
+        float px[3] = {X[ia], X[ib], X[ic]}, py[3] = {Y[ia], Y[ib], Y[ic]}, pd[3] = {Dp[ia], Dp[ib], Dp[ic]};
+        const float dmin = fminf(pd[0], fminf(pd[1], pd[2])), dmax = fmaxf(pd[0], fmaxf(pd[1], pd[2]));
+        if (!(dmax < tnear * (1.f - 1e-4f) || dmin > tfar_eps * (1.f + 1e-4f))) {   // else: every hit fails t >= znear / loses to the initial depth
+          if (dmin < dn) {
+            // back to the camera frame (vertices nearer than the plane were left there); front faces only
+            float cx[3], cy[3];
+            for (int q = 0; q < 3; q++) {
+              if (pd[q] >= dn) { cx[q] = (px[q] - 0.5f * width) / sx * pd[q]; cy[q] = (0.5f * height - py[q]) / sy * pd[q]; }
+              else { cx[q] = px[q]; cy[q] = py[q]; }
+            }
+            const float e1[3] = {cx[1] - cx[0], cy[1] - cy[0], -(pd[1] - pd[0])}, e2[3] = {cx[2] - cx[0], cy[2] - cy[0], -(pd[2] - pd[0])};
+            const float n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+            if (-(cx[0] * n[0] + cy[0] * n[1] - pd[0] * n[2]) > 0.f) {
+              // Sutherland-Hodgman against depth >= dn, by cases: rotate the vertices so that vertex 0 is the lone one on its side
+              const int in0 = pd[0] >= dn, in1 = pd[1] >= dn, in2 = pd[2] >= dn, nin = in0 + in1 + in2;
+              const int lone = nin == 1 ? (in0 ? 0 : in1 ? 1 : 2) : (!in0 ? 0 : !in1 ? 1 : 2);
+              float rx[3], ry[3], rd[3];
+#pragma unroll
+              for (int q = 0; q < 3; q++) {
+                const int src = (q + lone) % 3;
+                rx[q] = src == 0 ? cx[0] : src == 1 ? cx[1] : cx[2]; ry[q] = src == 0 ? cy[0] : src == 1 ? cy[1] : cy[2]; rd[q] = src == 0 ? pd[0] : src == 1 ? pd[1] : pd[2];
+              }
+              // the plane's crossings of the two edges at the lone vertex: 0 -> 1 and 2 -> 0
+              const float s01 = (dn - rd[0]) / (rd[1] - rd[0]), s20 = (dn - rd[2]) / (rd[0] - rd[2]);
+              const float ax = rx[0] + s01 * (rx[1] - rx[0]), ay = ry[0] + s01 * (ry[1] - ry[0]);
+              const float bx = rx[2] + s20 * (rx[0] - rx[2]), by = ry[2] + s20 * (ry[0] - ry[2]);
+              float vx4[4], vy4[4], vd4[4];
+              if (nin == 1) {   // the lone vertex is beyond the plane: (V0, A, B)
+                vx4[0] = rx[0]; vy4[0] = ry[0]; vd4[0] = rd[0]; vx4[1] = ax; vy4[1] = ay; vd4[1] = dn; vx4[2] = bx; vy4[2] = by; vd4[2] = dn;
+                vx4[3] = 0; vy4[3] = 0; vd4[3] = 1;
+                nsub = 1;
+              } else {          // the lone vertex is cut off: (A, V1, V2, B)
+                vx4[0] = ax; vy4[0] = ay; vd4[0] = dn; vx4[1] = rx[1]; vy4[1] = ry[1]; vd4[1] = rd[1]; vx4[2] = rx[2]; vy4[2] = ry[2]; vd4[2] = rd[2];
+                vx4[3] = bx; vy4[3] = by; vd4[3] = dn;
+                nsub = 2;
+              }
+#pragma unroll
+              for (int q = 0; q < 4; q++) {
+                const float inv = 1.f / vd4[q];
+                qx[q] = vx4[q] * inv * sx + 0.5f * width; qy[q] = 0.5f * height - vy4[q] * inv * sy; qd[q] = vd4[q];
+              }
+              // These are few but large on screen (a few centimetres from the camera): the per-pixel kernel takes the uncut triangle,
+              // tile by tile inside the cut part's box (its t >= znear test does the cutting) -- measured 7 ms per render cheaper
+              // than shading them here, where one wave would sit on each for hundreds of rounds.  Only if the env's list is full do
+              // the cut triangles stay in this wave (nsub).
+              const float eps = 0.05f;
+              const float bx0 = fminf(fminf(qx[0], qx[1]), nsub == 2 ? fminf(qx[2], qx[3]) : qx[2]), bx1 = fmaxf(fmaxf(qx[0], qx[1]), nsub == 2 ? fmaxf(qx[2], qx[3]) : qx[2]);
+              const float by0 = fminf(fminf(qy[0], qy[1]), nsub == 2 ? fminf(qy[2], qy[3]) : qy[2]), by1 = fmaxf(fmaxf(qy[0], qy[1]), nsub == 2 ? fmaxf(qy[2], qy[3]) : qy[2]);
+              const int hu0 = (int)ceilf(fmaxf(bx0 - 0.5f - eps, 0.f)), hu1 = (int)floorf(fminf(bx1 - 0.5f + eps, (float)(width - 1)));
+              const int hw0 = (int)ceilf(fmaxf(by0 - 0.5f - eps, 0.f)), hw1 = (int)floorf(fminf(by1 - 0.5f + eps, (float)(height - 1)));
+              if (hu0 > hu1 || hw0 > hw1) nsub = 0;
+              else {
+                const int at = atomicAdd(HL, 1);
+                if (at < HLCAP) {
+                  float* E = W + WS_HL + 4 + at * HLW;
+                  E[0] = cx[0]; E[1] = cy[0]; E[2] = -pd[0];
+                  E[3] = e1[0]; E[4] = e1[1]; E[5] = e1[2];
+                  E[6] = e2[0]; E[7] = e2[1]; E[8] = e2[2];
+                  reinterpret_cast<int*>(E)[9] = hu0 | (hu1 << 16); reinterpret_cast<int*>(E)[10] = hw0 | (hw1 << 16);
+                  nsub = 0;
+                }
+              }
+            }
+          } else {
+            // twice the screen area, y up: positive = counter-clockwise = facing the camera
+            const float area = (px[1] - px[0]) * (py[0] - py[2]) - (px[2] - px[0]) * (py[0] - py[1]);
+            if (area > 0.f) {
+              nsub = 1;
+              for (int q = 0; q < 3; q++) { qx[q] = px[q]; qy[q] = py[q]; qd[q] = pd[q]; }
+            }
+          }
+        }
+      }
+      for (int sub = 0; sub < 2; sub++) {
+      if (__ballot(nsub > sub) == 0) break;            // uniform (the second pass: only waves that hold a quadrilateral)
+      int u0 = 0, w0 = 0, nu = 0, npx = 0, lost = 0, npx_lost = 0;
+      float px[3] = {qx[0], sub ? qx[2] : qx[1], sub ? qx[3] : qx[2]}, py[3] = {qy[0], sub ? qy[2] : qy[1], sub ? qy[3] : qy[2]};
+      float pd[3] = {qd[0], sub ? qd[2] : qd[1], sub ? qd[3] : qd[2]};
+      if (nsub > sub) {
+        const float eps = 0.02f;   // projection rounding is ~1e-4 of a pixel
+        u0 = (int)ceilf(fmaxf(fminf(px[0], fminf(px[1], px[2])) - 0.5f - eps, 0.f));
+        const int u1 = (int)floorf(fminf(fmaxf(px[0], fmaxf(px[1], px[2])) - 0.5f + eps, (float)(width - 1)));
+        w0 = (int)ceilf(fmaxf(fminf(py[0], fminf(py[1], py[2])) - 0.5f - eps, 0.f));
+        const int w1 = (int)floorf(fminf(fmaxf(py[0], fmaxf(py[1], py[2])) - 0.5f + eps, (float)(height - 1)));
+        if (u0 <= u1 && w0 <= w1) {
+          nu = u1 - u0 + 1;
+          npx = nu * (w1 - w0 + 1);
+          if (npx > RASTER_MAX_BOX) {
+            // too many candidates for one wave: the per-pixel kernel takes the triangle (camera frame), tile by tile
+            float cx[3], cy[3];
+            for (int q = 0; q < 3; q++) { cx[q] = (px[q] - 0.5f * width) / sx * pd[q]; cy[q] = (0.5f * height - py[q]) / sy * pd[q]; }
+            const int at = atomicAdd(HL, 1);
+            if (at < HLCAP) {
+              float* E = W + WS_HL + 4 + at * HLW;
+              E[0] = cx[0]; E[1] = cy[0]; E[2] = -pd[0];
+              E[3] = cx[1] - cx[0]; E[4] = cy[1] - cy[0]; E[5] = -(pd[1] - pd[0]);
+              E[6] = cx[2] - cx[0]; E[7] = cy[2] - cy[0]; E[8] = -(pd[2] - pd[0]);
+              reinterpret_cast<int*>(E)[9] = u0 | (u1 << 16); reinterpret_cast<int*>(E)[10] = w0 | (w1 << 16);
+            } else {   // the list is full: this wave shades the triangle itself, below (keep what that needs in the lane)
+              lost = 1;
+              for (int q = 0; q < 3; q++) { px[q] = cx[q]; py[q] = cy[q]; }
+              npx_lost = npx;
+            }
+            npx = 0;
+          }
+        }
+      }
+      // hand-over list full (not seen with the Stretch meshes: boxes beyond 16384 pixels are a handful per image): one such
+      // triangle at a time, lanes = the pixels of its box, the per-pixel kernel's ray / triangle test in the camera frame
+      for (unsigned long long lm = __ballot(lost); lm;) {
+        const int l = __ffsll((long long)lm) - 1;
+        lm &= lm - 1;
+        float tv0[3], te1[3], te2[3];
+        tv0[0] = rl(px[0], l); tv0[1] = rl(py[0], l); tv0[2] = -rl(pd[0], l);
+        te1[0] = rl(px[1], l) - tv0[0]; te1[1] = rl(py[1], l) - tv0[1]; te1[2] = -rl(pd[1], l) - tv0[2];
+        te2[0] = rl(px[2], l) - tv0[0]; te2[1] = rl(py[2], l) - tv0[1]; te2[2] = -rl(pd[2], l) - tv0[2];
+        const int bu0 = __builtin_amdgcn_readlane(u0, l), bw0 = __builtin_amdgcn_readlane(w0, l), bnu = __builtin_amdgcn_readlane(nu, l);
+        const int bn = __builtin_amdgcn_readlane(npx_lost, l);
+        for (int i = lane; i < bn; i += 64) {
+          const int row = (int)(((float)i + 0.5f) / (float)bnu), col = i - row * bnu;
+          const float dc[3] = {(((float)(bu0 + col) + 0.5f) / width * 2.f - 1.f) * tx, (1.f - ((float)(bw0 + row) + 0.5f) / height * 2.f) * ty, -1.f};
+          const float p[3] = {dc[1] * te2[2] - dc[2] * te2[1], dc[2] * te2[0] - dc[0] * te2[2], dc[0] * te2[1] - dc[1] * te2[0]};
+          const float det = te1[0] * p[0] + te1[1] * p[1] + te1[2] * p[2];
+          if (det > 1e-30f) {
+            const float id = 1.f / det;
+            const float tv[3] = {-tv0[0], -tv0[1], -tv0[2]};
+            const float uu = (tv[0] * p[0] + tv[1] * p[1] + tv[2] * p[2]) * id;
+            const float q[3] = {tv[1] * te1[2] - tv[2] * te1[1], tv[2] * te1[0] - tv[0] * te1[2], tv[0] * te1[1] - tv[1] * te1[0]};
+            const float vv = (dc[0] * q[0] + dc[1] * q[1] + dc[2] * q[2]) * id;
+            if (uu >= 0.f && vv >= 0.f && uu + vv <= 1.f) {
+              const float tt = (te2[0] * q[0] + te2[1] * q[1] + te2[2] * q[2]) * id;
+              if (tt >= tnear) atomicMin(reinterpret_cast<unsigned*>(zimg + (long)(bw0 + row) * width + bu0 + col), __float_as_uint(tt));
+            }
+          }
+        }
+      }
+      const unsigned long long have = __ballot(npx > 0);
+      if (have == 0) continue;       // wave-uniform
+      const int n = __popcll(have);
+      if (npx > 0) {
+        // barycentric coordinates as affine functions of (col, row) relative to the box corner's pixel centre (y down); 1 / depth
+        MlEntry& E = Q[__popcll(have & ((1ull << lane) - 1ull))];
+        const float ox = (float)u0 + 0.5f, oy = (float)w0 + 0.5f;
+        const float x0 = px[0] - ox, y0 = py[0] - oy, x1 = px[1] - ox, y1 = py[1] - oy, x2 = px[2] - ox, y2 = py[2] - oy;
+        const float A = (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0), ia = 1.f / A;
+        // lambda_0 = E_12 / A, lambda_1 = E_20 / A, lambda_2 = E_01 / A;  E_ij(p) = (xj - xi)(py - yi) - (yj - yi)(px - xi)
+        E.la[0] = -(y2 - y1) * ia; E.lb[0] = (x2 - x1) * ia; E.lc[0] = ((y2 - y1) * x1 - (x2 - x1) * y1) * ia;
+        E.la[1] = -(y0 - y2) * ia; E.lb[1] = (x0 - x2) * ia; E.lc[1] = ((y0 - y2) * x2 - (x0 - x2) * y2) * ia;
+        E.la[2] = -(y1 - y0) * ia; E.lb[2] = (x1 - x0) * ia; E.lc[2] = ((y1 - y0) * x0 - (x1 - x0) * y0) * ia;
+        E.w[0] = 1.f / pd[0]; E.w[1] = 1.f / pd[1]; E.w[2] = 1.f / pd[2];
+        E.u0 = u0; E.w0 = w0; E.nu = nu; E.npx = npx;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      int incl = lane < n ? Q[lane].npx : 0;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+      }
+      if (lane == 0) pre[0] = 0;     // pre[j] = candidate pixels of entries 0..j-1
+      pre[lane + 1] = incl;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int total = pre[n];
+      for (int pidx = lane; pidx < total; pidx += 64) {
+        int lo = 0, hi = n;          // the entry j with pre[j] <= pidx < pre[j + 1]
+#pragma unroll
+        for (int st = 0; st < 6; st++) {
+          const int mid = (lo + hi) >> 1;
+          if (hi - lo > 1) { if (pre[mid] <= pidx) lo = mid; else hi = mid; }
+        }
+        const MlEntry& E = Q[lo];
+        const int i = pidx - pre[lo];
+        const int row = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)E.nu));   // i / nu (the half keeps the product away from an integer)
+        const int col = i - row * E.nu;
+        const float fc = (float)col, fr = (float)row;
+        const float l0 = E.la[0] * fc + E.lb[0] * fr + E.lc[0], l1 = E.la[1] * fc + E.lb[1] * fr + E.lc[1], l2 = E.la[2] * fc + E.lb[2] * fr + E.lc[2];
+        if (l0 >= -2e-5f && l1 >= -2e-5f && l2 >= -2e-5f) {
+          const float t = 1.f / (l0 * E.w[0] + l1 * E.w[1] + l2 * E.w[2]);
+          if (t >= tnear) atomicMin(reinterpret_cast<unsigned*>(zimg + (long)(E.w0 + row) * width + E.u0 + col), __float_as_uint(t));   // t > 0: the bit patterns order like the values
+        }
+      }
+      __builtin_amdgcn_wave_barrier();   // the queue is rewritten by the next pass
+      }
+    }
+    __builtin_amdgcn_wave_barrier();     // ... and the vertices by the next meshlet
+  }
+}
+
+__global__ void smj_fill_kernel(float* __restrict__ p, long n, float v) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
 }
 
 }  // namespace
@@ -616,8 +983,23 @@ void smj_launch_depth(const DevRender& r, const float* xpose, long ld, int num_e
   float* ws = mode == 1 ? workspace + (size_t)WS_STRIDE * num_envs : workspace;   // the static layer stages into the last block
   const float md = mode == 1 ? 0.f : max_depth;
   static const int nocull = getenv("SMJ_DEPTH_NOCULL") ? 1 : 0;   // debug: every geom in every tile (the image must not change)
-  hipLaunchKernelGGL(smj_depth_prepass, dim3(nenv), dim3(128), 0, stream, r, xpose, ld, cam, md, ws, mode, nocull);
-  hipLaunchKernelGGL(smj_depth_kernel<false>, dim3(tiles, nenv), dim3(256), 0, stream, r, ws, width, height, th, md, out, layer, mode,
+  DevRender rr = r;
+  rr.stat_select = -1;
+#ifdef SMJ_DEPTH_STATS
+  if (getenv("SMJ_DEPTH_STAT")) rr.stat_select = atoi(getenv("SMJ_DEPTH_STAT"));
+#endif
+  hipLaunchKernelGGL(smj_depth_prepass, dim3(nenv), dim3(128), 0, stream, rr, xpose, ld, cam, md, ws, mode, nocull);
+  if (r.raster && r.nmlist > 0 && rr.stat_select < 0) {
+    // meshes by rasterisation into the image (z-buffer, atomicMin), then the per-pixel kernel resolves the primitives against it
+    const float tfar = (md > 0.f && md < r.zfar) ? md : r.zfar;
+    const long npx = (long)nenv * width * height;
+    hipLaunchKernelGGL(smj_fill_kernel, dim3(2048), dim3(256), 0, stream, out, npx, tfar * (1.f + 1e-6f));
+    hipLaunchKernelGGL(smj_meshlet_kernel, dim3(r.raster_splits, nenv), dim3(256), 0, stream, rr, ws, width, height, th, tfar * (1.f + 1e-6f), out, mode == 1 ? 1 : 0);
+    hipLaunchKernelGGL((smj_depth_kernel<false, true>), dim3(tiles, nenv), dim3(256), 0, stream, rr, ws, width, height, th, md, out, layer, mode,
+                       (unsigned char*)nullptr, (int*)nullptr);
+    return;
+  }
+  hipLaunchKernelGGL((smj_depth_kernel<false, false>), dim3(tiles, nenv), dim3(256), 0, stream, rr, ws, width, height, th, md, out, layer, mode,
                      (unsigned char*)nullptr, (int*)nullptr);
 }
 void smj_launch_rgb(const DevRender& r, const float* xpose, long ld, int num_envs, int cam, int width, int height, float fovy_deg,
@@ -625,6 +1007,6 @@ void smj_launch_rgb(const DevRender& r, const float* xpose, long ld, int num_env
   const int tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
   const float th = tanf(fovy_deg * 3.14159265358979323846f / 360.f);
   hipLaunchKernelGGL(smj_depth_prepass, dim3(num_envs), dim3(128), 0, stream, r, xpose, ld, cam, 0.f, workspace, 0, 0);
-  hipLaunchKernelGGL(smj_depth_kernel<true>, dim3(tiles, num_envs), dim3(256), 0, stream, r, workspace, width, height, th, 0.f,
+  hipLaunchKernelGGL((smj_depth_kernel<true, false>), dim3(tiles, num_envs), dim3(256), 0, stream, r, workspace, width, height, th, 0.f,
                      (float*)nullptr, (const float*)nullptr, 0, rgb, gid);
 }

@@ -141,6 +141,36 @@ def test_culling_does_not_change_the_image():
     assert all(l.rstrip().endswith("differing 0") for l in lines), out.stdout
 
 
+def test_rasterised_meshes_equal_the_ray_cast_meshes():
+    """The meshes go into the depth image by rasterisation (smj_raster_kernel: lanes = triangles, atomicMin) and the per-pixel
+    kernel resolves the primitives against it; option depth_raster = 0 casts a ray per pixel through the mesh BVHs instead (the
+    round-2 path).  Every candidate pixel of a triangle runs the ray caster's own ray / triangle arithmetic, so the two images
+    agree pixel for pixel up to fp32 rounding (the rasteriser folds the two rotations of the ray into one matrix): bit-identical
+    on > 90 % of the pixels, within 1e-4 relative on all but the odd silhouette pixel (< 2 in 10^5).  64 envs at random poses,
+    kitchen stand-in, both cameras."""
+    from stretch_mujoco_amd import StretchBatchSimulator
+    from stretch_mujoco_amd.enums import StretchCameras
+
+    B = 64
+    sim = StretchBatchSimulator(num_envs=B, device="cuda:0", cameras_to_use=StretchCameras.depth(), scene="stretch_kitchen_standin")
+    sim.start(home=True)
+    g = torch.Generator(device=sim.device).manual_seed(99)
+    lo = torch.tensor(np.asarray(sim.model["actuator_ctrlrange"], np.float32)[:, 0], device=sim.device)
+    hi = torch.tensor(np.asarray(sim.model["actuator_ctrlrange"], np.float32)[:, 1], device=sim.device)
+    sim.ctrl[:] = lo[:, None] + (hi - lo)[:, None] * torch.rand(sim.nu, B, generator=g, device=sim.device)
+    sim.step(300)
+    a = {c.name: getattr(sim.pull_camera_data(), c.name).clone() for c in StretchCameras.depth()}
+    sim.set_option("depth_raster", 0)
+    b = {c.name: getattr(sim.pull_camera_data(), c.name).clone() for c in StretchCameras.depth()}
+    torch.cuda.synchronize()
+    for k in a:
+        same = (a[k] == b[k]).float().mean().item()
+        close = ((a[k] - b[k]).abs() <= 1e-4 * b[k].abs()).float().mean().item()
+        assert same > 0.9 and close > 0.99998, (k, same, close)
+        assert float((a[k] > 0).float().mean()) > 0.3
+    sim.stop()
+
+
 def test_notebook_corner_values_through_the_raw_entry():
     """docs/getting_started.ipynb cell 14, 3.2 s after start() in the default scene (640 x 480): cam_d405_depth reads 0.445 / 0.444
     / 0.442 m in the first and 0.449 / 0.448 / 0.447 m in the last columns of its last three rows (the table), 0 in its top rows;
