@@ -218,6 +218,11 @@ static int setup_render(smj_ctx* c, const void* blob, size_t nbytes) {
     std::vector<int> rgh = geti(rg), gmh = geti(gm), gth = gt ? geti(gt) : std::vector<int>();
     SmjMeshletSet ml;
     for (size_t i = 0; i < nmesh; i++) smj_meshlets_add_mesh(ml, verts + 3 * (size_t)vadr[i], faces + 3 * (size_t)fadr[i], set.order[i]);
+    const SmjBlobEntry* gs = b.find("geom_size");
+    std::vector<float> gsh = (gs && gs->dtype == 0) ? getd(gs) : std::vector<float>();
+    std::vector<int> boxlet(nrgeom > 0 ? nrgeom : 1, -1);
+    for (int i = 0; i < nrgeom && gt && !gsh.empty(); i++)   // box geoms: one meshlet each, appended after the meshes'
+      if (gth[rgh[i]] == 6) boxlet[i] = smj_meshlets_add_box(ml, gsh.data() + 3 * (size_t)rgh[i]);
     std::vector<int> rec(12 * (ml.let.size() ? ml.let.size() : 1), 0), work;
     for (size_t i = 0; i < ml.let.size(); i++) {
       const SmjMeshlet& m = ml.let[i];
@@ -228,9 +233,11 @@ static int setup_render(smj_ctx* c, const void* blob, size_t nbytes) {
     }
     for (int i = 0; i < nrgeom && gt; i++) {
       const int g = rgh[i];
+      if (boxlet[i] >= 0) { work.push_back(i); work.push_back(boxlet[i]); continue; }
       if (gth[g] != 7 || gmh[g] < 0) continue;
       for (int k = 0; k < ml.mesh_count[gmh[g]]; k++) { work.push_back(i); work.push_back(ml.mesh_first[gmh[g]] + k); }
     }
+    r.raster_boxes = gsh.empty() ? 0 : 1;
     r.nmlist = (int)(work.size() / 2);
     if (work.empty()) work.assign(2, 0);
     if (ml.vert.empty()) ml.vert.assign(4, 0.f);

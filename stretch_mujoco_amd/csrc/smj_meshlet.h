@@ -84,3 +84,24 @@ static inline void smj_meshlets_add_mesh(SmjMeshletSet& set, const float* verts,
   }
   set.mesh_count.push_back((int)set.let.size() - set.mesh_first.back());
 }
+
+// A box geom as one meshlet (8 vertices, 12 outward-facing triangles, geom frame): the fixtures of a kitchen are boxes, and a box
+// that is rasterised with the meshes costs the per-pixel kernel nothing.  Returns the meshlet's index.
+static inline int smj_meshlets_add_box(SmjMeshletSet& set, const float* half) {
+  SmjMeshlet m{};
+  m.vbase = (int)(set.vert.size() / 4);
+  m.tbase = (int)set.tri.size();
+  m.nvert = 8; m.ntri = 12;
+  for (int i = 0; i < 8; i++) {
+    set.vert.push_back((i & 1) ? half[0] : -half[0]); set.vert.push_back((i & 2) ? half[1] : -half[1]);
+    set.vert.push_back((i & 4) ? half[2] : -half[2]); set.vert.push_back(0.f);
+  }
+  // faces -x +x -y +y -z +z, counter-clockwise seen from outside
+  static const int F[12][3] = {{0, 4, 6}, {0, 6, 2}, {1, 3, 7}, {1, 7, 5}, {0, 1, 5}, {0, 5, 4}, {2, 6, 7}, {2, 7, 3}, {0, 2, 3}, {0, 3, 1}, {4, 5, 7}, {4, 7, 6}};
+  for (int f = 0; f < 12; f++) set.tri.push_back((uint32_t)F[f][0] | ((uint32_t)F[f][1] << 8) | ((uint32_t)F[f][2] << 16));
+  m.cen[0] = m.cen[1] = m.cen[2] = 0.f;
+  m.rad = sqrtf(half[0] * half[0] + half[1] * half[1] + half[2] * half[2]) * (1.f + 1e-5f) + 1e-7f;
+  m.cosc = -1.f;   // faces point everywhere: no cone
+  set.let.push_back(m);
+  return (int)set.let.size() - 1;
+}

@@ -41,7 +41,7 @@ struct DevRender {
   const unsigned* mltri;
   const int4* mlrec;
   const int2* mlist;
-  int nmlist, raster, raster_splits;
+  int nmlist, raster, raster_splits, raster_boxes;   // raster_boxes: box geoms are in the work list too (one meshlet each)
   int stat_select;                 // tools-only build (-DSMJ_DEPTH_STATS): >= 0 writes that work counter instead of the depth
 };
 

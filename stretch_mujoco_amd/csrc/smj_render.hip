@@ -392,8 +392,9 @@ __global__ __launch_bounds__(384) void smj_lidar_kernel(const DevRender R, const
 constexpr int WS_HDR = 16, WS_SLOT = 48, WS_RECT = 24, WS_RCG = 28, WS_TCG = 37, WS_LP = 40;   // slot: RGeom words 0..21, rect, geom -> camera rotation / translation, camera position in the geom frame
 constexpr int WS_IDX = WS_HDR + SMJ_RGEOM_MAX * WS_SLOT;   // [SMJ_RGEOM_MAX] slot of visible-geom table entry i, or -1 (the rasteriser's look-up)
 // Triangles the rasteriser hands to the per-pixel kernel (boxes beyond 16384 pixels, triangles cut by the near plane): per env a
-// count and up to HLCAP entries of HLW words -- v0, e1, e2 in the camera frame, the pixel box u0 | u1 << 16, w0 | w1 << 16
-constexpr int HLCAP = 256, HLW = 12;   // (one per thread of the per-pixel kernel's list builder)
+// count and up to HLCAP entries of HLW words -- v0, e1, e2 in the camera frame, the pixel box u0 | u1 << 16, w0 | w1 << 16, and the
+// screen polygon of the visible part (vertex count, then x y pairs in pixels) for the per-tile cull
+constexpr int HLCAP = 256, HLW = 20;   // (one per thread of the per-pixel kernel's list builder)
 constexpr int WS_HL = WS_IDX + SMJ_RGEOM_MAX;
 constexpr int WS_STRIDE = WS_HL + 4 + HLCAP * HLW;
 
@@ -561,7 +562,10 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
     const float y1 = (1.f - (float)(ty * TILE) / height * 2.f) * tan_half_fovy;
     const float y0 = (1.f - (float)(ty * TILE + TILE) / height * 2.f) * tan_half_fovy;
     keep = S[1] >= x0 && S[0] <= x1 && S[3] >= y0 && S[2] <= y1;
-    if (RASTER && __float_as_int(S[19 - WS_RECT]) == RT_MESH) keep = 0;   // meshes are in the z-buffer already (smj_raster_kernel)
+    if (RASTER) {   // meshes -- and boxes, one meshlet each -- are in the z-buffer already (smj_meshlet_kernel)
+      const int gt = __float_as_int(S[19 - WS_RECT]);
+      if (gt == RT_MESH || (gt == RT_BOX && R.raster_boxes)) keep = 0;
+    }
   }
   const unsigned long long bal = __ballot(keep);
   const int wv0 = tid >> 6, ln0 = tid & 63;
@@ -585,6 +589,23 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
     if (tid < nh) {
       const int bu = H[4 + tid * HLW + 9], bw = H[4 + tid * HLW + 10];
       hk = (bu >> 16) >= tx * TILE && (bu & 0xffff) < tx * TILE + TILE && (bw >> 16) >= ty * TILE && (bw & 0xffff) < ty * TILE + TILE;
+      if (hk) {
+        // the tile's pixel centres against the convex screen polygon: out if they are all beyond one of its edges (a long thin
+        // triangle meets few of the tiles of its box)
+        const float* P = W + WS_HL + 4 + tid * HLW + 12;
+        const int nvp = H[4 + tid * HLW + 11];
+        const float rx0 = (float)(tx * TILE) + 0.5f, rx1 = (float)(tx * TILE + TILE) - 0.5f, ry0 = (float)(ty * TILE) + 0.5f, ry1 = (float)(ty * TILE + TILE) - 0.5f;
+        float area = 0.f;
+        for (int q = 0; q < nvp; q++) { const int q2 = q + 1 < nvp ? q + 1 : 0; area += P[2 * q] * P[2 * q2 + 1] - P[2 * q2] * P[2 * q + 1]; }
+        const float sg = area >= 0.f ? 1.f : -1.f;
+        for (int q = 0; q < nvp; q++) {
+          const int q2 = q + 1 < nvp ? q + 1 : 0;
+          const float ex = P[2 * q2] - P[2 * q], ey = P[2 * q2 + 1] - P[2 * q + 1], lim = -0.05f * (fabsf(ex) + fabsf(ey));
+          const float e00 = sg * (ex * (ry0 - P[2 * q + 1]) - ey * (rx0 - P[2 * q])), e10 = sg * (ex * (ry0 - P[2 * q + 1]) - ey * (rx1 - P[2 * q]));
+          const float e01 = sg * (ex * (ry1 - P[2 * q + 1]) - ey * (rx0 - P[2 * q])), e11 = sg * (ex * (ry1 - P[2 * q + 1]) - ey * (rx1 - P[2 * q]));
+          if (e00 < lim && e10 < lim && e01 < lim && e11 < lim) hk = 0;
+        }
+      }
     }
     const unsigned long long hb = __ballot(hk);
     if (ln0 == 0) hcount[wv0] = __popcll(hb);
@@ -834,6 +855,8 @@ __global__ __launch_bounds__(256) void smj_meshlet_kernel(const DevRender R, flo
                   E[3] = e1[0]; E[4] = e1[1]; E[5] = e1[2];
                   E[6] = e2[0]; E[7] = e2[1]; E[8] = e2[2];
                   reinterpret_cast<int*>(E)[9] = hu0 | (hu1 << 16); reinterpret_cast<int*>(E)[10] = hw0 | (hw1 << 16);
+                  reinterpret_cast<int*>(E)[11] = nsub + 2;
+                  for (int q = 0; q < 4; q++) { E[12 + 2 * q] = qx[q]; E[13 + 2 * q] = qy[q]; }
                   nsub = 0;
                 }
               }
@@ -873,6 +896,8 @@ __global__ __launch_bounds__(256) void smj_meshlet_kernel(const DevRender R, flo
               E[3] = cx[1] - cx[0]; E[4] = cy[1] - cy[0]; E[5] = -(pd[1] - pd[0]);
               E[6] = cx[2] - cx[0]; E[7] = cy[2] - cy[0]; E[8] = -(pd[2] - pd[0]);
               reinterpret_cast<int*>(E)[9] = u0 | (u1 << 16); reinterpret_cast<int*>(E)[10] = w0 | (w1 << 16);
+              reinterpret_cast<int*>(E)[11] = 3;
+              for (int q = 0; q < 3; q++) { E[12 + 2 * q] = px[q]; E[13 + 2 * q] = py[q]; }
             } else {   // the list is full: this wave shades the triangle itself, below (keep what that needs in the lane)
               lost = 1;
               for (int q = 0; q < 3; q++) { px[q] = cx[q]; py[q] = cy[q]; }
@@ -997,6 +1022,12 @@ void smj_launch_depth(const DevRender& r, const float* xpose, long ld, int num_e
     hipLaunchKernelGGL(smj_meshlet_kernel, dim3(r.raster_splits, nenv), dim3(256), 0, stream, rr, ws, width, height, th, tfar * (1.f + 1e-6f), out, mode == 1 ? 1 : 0);
     hipLaunchKernelGGL((smj_depth_kernel<false, true>), dim3(tiles, nenv), dim3(256), 0, stream, rr, ws, width, height, th, md, out, layer, mode,
                        (unsigned char*)nullptr, (int*)nullptr);
+    if (getenv("SMJ_DEPTH_DEBUG")) {   // tools: how many triangles the rasteriser handed over, per env
+      (void)hipStreamSynchronize(stream);
+      int cnt[64]; double sum = 0; int mx = 0; const int ne = nenv < 64 ? nenv : 64;
+      for (int e = 0; e < ne; e++) { (void)hipMemcpy(&cnt[e], ws + (size_t)e * WS_STRIDE + WS_HL, 4, hipMemcpyDeviceToHost); sum += cnt[e]; mx = cnt[e] > mx ? cnt[e] : mx; }
+      fprintf(stderr, "depth cam %d mode %d: handed-over triangles per env: mean %.1f max %d (first %d envs)\n", cam, mode, sum / ne, mx, ne);
+    }
     return;
   }
   hipLaunchKernelGGL((smj_depth_kernel<false, false>), dim3(tiles, nenv), dim3(256), 0, stream, rr, ws, width, height, th, md, out, layer, mode,
