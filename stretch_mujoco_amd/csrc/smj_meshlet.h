@@ -1,5 +1,5 @@
 // Host-side builder of the MESHLETS the depth rasteriser works on (smj_render.hip, smj_meshlet_kernel): runs of up to 128
-// triangles of a mesh in BVH leaf order (spatially coherent, smj_bvh.h) with their own list of up to 256 vertices, a bounding
+// triangles of a mesh in BVH leaf order (spatially coherent, smj_bvh.h) with their own list of up to 192 vertices, a bounding
 // sphere and a normal cone.  One wavefront takes one meshlet: it transforms each vertex ONCE (lane = vertex), then sets up its
 // triangles from the projected vertices in LDS (lane = triangle) -- against three vertex transforms per triangle when
 // triangles are streamed on their own -- and a meshlet that is off screen, out of range or turned away is dropped whole.
@@ -11,7 +11,7 @@
 #include <vector>
 
 #define SMJ_MESHLET_TRIS 128
-#define SMJ_MESHLET_VERTS 256
+#define SMJ_MESHLET_VERTS 192   // (128 triangles of a closed surface share ~70-100 vertices; 192 keeps the wave's LDS slice at 2.3 KB)
 
 struct SmjMeshlet {     // 12 words
   int vbase, nvert, tbase, ntri;

@@ -36,11 +36,11 @@ struct DevRender {
   const float* lidar_static;       // [nlidar] distance to the geoms welded to the laser (ray-cast by the model compiler), -1 none
   // mesh rasteriser (smj_meshlet_kernel; tables built at smj_create from smj_meshlet.h): meshlet vertices (float4), triangles (three
   // local vertex indices packed in 32 bits), records (three 16-byte words per meshlet: vbase nvert tbase ntri | sphere | cone) and
-  // the work list over the mesh geoms of the visible-geom table: (table entry, meshlet).  raster = 0: ray cast the meshes (BVHs)
+  // the work list over the mesh / box geoms of the visible-geom table: (table entry, first meshlet, count <= 32, 0).  raster = 0: ray cast the meshes (BVHs)
   const float4* mlvert;
   const unsigned* mltri;
   const int4* mlrec;
-  const int2* mlist;
+  const int4* mlist;
   int nmlist, raster, raster_splits, raster_boxes;   // raster_boxes: box geoms are in the work list too (one meshlet each)
   int stat_select;                 // tools-only build (-DSMJ_DEPTH_STATS): >= 0 writes that work counter instead of the depth
 };

@@ -707,8 +707,9 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
 // The robot's visual meshes are 196 k triangles: casting a ray per pixel walks ~8 BVH nodes per ray for ~1 triangle test (and a
 // wave pays for its slowest ray).  Here the meshes are RASTERISED into the depth image with atomicMin, and the per-pixel kernel
 // only resolves the primitives (floor, fixtures) against that z-buffer:
-//  * one WAVEFRONT per meshlet (smj_meshlet.h: <= 128 triangles in BVH leaf order, <= 256 own vertices, bounding sphere, normal
-//    cone).  A meshlet that is out of the depth range, off screen or turned away from the camera is dropped whole;
+//  * one WAVEFRONT per meshlet (smj_meshlet.h: <= 128 triangles in BVH leaf order, <= 192 own vertices, bounding sphere, normal
+//    cone).  A meshlet that is out of the depth range, off screen or turned away from the camera is dropped whole -- tested 32
+//    meshlets at a time, lane = meshlet;
 //  * lane = vertex: each vertex goes to the camera frame and the screen ONCE, into the wave's LDS slice;
 //  * lane = triangle: screen box from the projected vertices, back faces out by the sign of the screen area.  Only a few per cent
 //    of the triangles have a pixel centre in their box; those are compacted into the wave's LDS queue as barycentric edge
@@ -723,14 +724,21 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
 // and the tie-break at shared edges: tests/test_gpu_depth.py compares the two.
 __device__ __forceinline__ float rl(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
 constexpr int RASTER_MAX_BOX = 16384;   // candidate pixels a wave still takes itself (256 rounds of 64); larger boxes go to the per-pixel kernel
+#ifdef SMJ_ZMIN_XCD
+#define ZMIN(p, t) __hip_atomic_fetch_min(reinterpret_cast<unsigned*>(p), __float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#else
+#define ZMIN(p, t) atomicMin(reinterpret_cast<unsigned*>(p), __float_as_uint(t))
+#endif
 struct MlEntry { float la[3], lb[3], lc[3], w[3]; int u0, w0, nu, npx; };   // lambda_k(col, row) = la[k] col + lb[k] row + lc[k]
 
-__global__ __launch_bounds__(256) void smj_meshlet_kernel(const DevRender R, float* __restrict__ ws, int width, int height,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void smj_meshlet_kernel(const DevRender R, float* __restrict__ ws, int width, int height,
                                                           float tan_half_fovy, float tfar_eps, float* __restrict__ zbuf, int single_image) {
   __shared__ float vx[4][SMJ_MESHLET_VERTS], vy[4][SMJ_MESHLET_VERTS], vd[4][SMJ_MESHLET_VERTS];
   __shared__ MlEntry queue[4][64];
   __shared__ int prefix[4][65];
-  const int env = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // grid = (env, split): the workgroups of one env have linear ids env + nenv * split -- with nenv a multiple of 8 they land on the
+  // same XCD (round-robin dispatch), so that env's image and workspace stay in one L2
+  const int env = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   float* W = ws + (long)env * WS_STRIDE;
   const int* slot_of = reinterpret_cast<const int*>(W + WS_IDX);
   int* HL = reinterpret_cast<int*>(W + WS_HL);
@@ -741,25 +749,29 @@ __global__ __launch_bounds__(256) void smj_meshlet_kernel(const DevRender R, flo
   float* X = vx[wv]; float* Y = vy[wv]; float* Dp = vd[wv];
   MlEntry* Q = queue[wv];
   int* pre = prefix[wv];
-  for (int m = blockIdx.x * 4 + wv; m < R.nmlist; m += gridDim.x * 4) {
-    const int2 pr = R.mlist[m];                       // (visible-geom table entry, meshlet)
-    const int sl = __builtin_amdgcn_readfirstlane(slot_of[pr.x]);
+  for (int m = blockIdx.y * 4 + wv; m < R.nmlist; m += gridDim.y * 4) {
+    const int4 grp = R.mlist[m];                      // (visible-geom table entry, first meshlet, meshlets <= 32, 0)
+    const int sl = __builtin_amdgcn_readfirstlane(slot_of[grp.x]);
     if (sl < 0) continue;                             // dropped by the staging pass for this env (out of range, other layer)
     const float* S = W + WS_HDR + (long)sl * WS_SLOT;
     float rcg[9], tcg[3], lp[3];
     for (int k = 0; k < 9; k++) rcg[k] = S[WS_RCG + k];
     for (int k = 0; k < 3; k++) { tcg[k] = S[WS_TCG + k]; lp[k] = S[WS_LP + k]; }
-    const int4 r0 = R.mlrec[3 * pr.y];
-    const float4 r1 = reinterpret_cast<const float4*>(R.mlrec)[3 * pr.y + 1], r2 = reinterpret_cast<const float4*>(R.mlrec)[3 * pr.y + 2];
-    const int vbase = r0.x, nvert = r0.y, tbase = r0.z, ntri = r0.w;
-    {   // the meshlet's bounding sphere against depth range and frustum, its normal cone against the camera
+    // lane = meshlet of the group: bounding sphere against depth range and frustum, normal cone against the camera -- one pass of
+    // coalesced record loads and lane-parallel tests instead of a chain of dependent loads per meshlet; the survivors are then
+    // taken one after the other by the whole wave
+    int4 r0 = make_int4(0, 0, 0, 0);
+    int alive_l = 0;
+    if (lane < grp.z) {
+      r0 = R.mlrec[3 * (grp.y + lane)];
+      const float4 r1 = reinterpret_cast<const float4*>(R.mlrec)[3 * (grp.y + lane) + 1], r2 = reinterpret_cast<const float4*>(R.mlrec)[3 * (grp.y + lane) + 2];
       const float cen[3] = {r1.x, r1.y, r1.z}, rad = r1.w;
       float cc[3];
       mul(cc, rcg, cen);
       const float ccx = cc[0] + tcg[0], ccy = cc[1] + tcg[1], D = -(cc[2] + tcg[2]);
-      if (D + rad < tnear || D - rad > tfar_eps) continue;
+      alive_l = !(D + rad < tnear || D - rad > tfar_eps);
       // (a point at depth d is on screen iff |x| <= d tx, |y| <= d ty; the sphere's points have depth <= D + rad)
-      if (ccx - rad > (D + rad) * tx || -ccx - rad > (D + rad) * tx || ccy - rad > (D + rad) * ty || -ccy - rad > (D + rad) * ty) continue;
+      if (ccx - rad > (D + rad) * tx || -ccx - rad > (D + rad) * tx || ccy - rad > (D + rad) * ty || -ccy - rad > (D + rad) * ty) alive_l = 0;
       if (r2.w > 0.f) {
         // every face normal within theta of the axis; u = direction camera -> centre, phi its angle to the axis.  A face at x is
         // turned away iff n . (x - camera) >= 0; n . (x - camera) >= dist cos(phi + theta) - rad when phi + theta < 90 deg
@@ -768,9 +780,14 @@ __global__ __launch_bounds__(256) void smj_meshlet_kernel(const DevRender R, flo
         const float cf = (r2.x * uv[0] + r2.y * uv[1] + r2.z * uv[2]) / fmaxf(dist, 1e-20f);
         const float sf = sqrtf(fmaxf(0.f, 1.f - cf * cf)), sc = sqrtf(fmaxf(0.f, 1.f - r2.w * r2.w));
         const float val = cf * r2.w - sf * sc;
-        if (cf > 0.f && val > 0.f && val * dist >= rad) continue;
+        if (cf > 0.f && val > 0.f && val * dist >= rad) alive_l = 0;
       }
     }
+    for (unsigned long long alive = __ballot(alive_l); alive;) {
+    const int ml = __ffsll((long long)alive) - 1;
+    alive &= alive - 1;
+    const int vbase = __builtin_amdgcn_readlane(r0.x, ml), nvert = __builtin_amdgcn_readlane(r0.y, ml);
+    const int tbase = __builtin_amdgcn_readlane(r0.z, ml), ntri = __builtin_amdgcn_readlane(r0.w, ml);
     // lane = vertex: camera frame, then the screen (pixel coordinates); a vertex nearer than the near plane keeps its camera x, y
     for (int j = lane; j < nvert; j += 64) {
       const float4 v = R.mlvert[vbase + j];
@@ -931,7 +948,7 @@ __global__ __launch_bounds__(256) void smj_meshlet_kernel(const DevRender R, flo
             const float vv = (dc[0] * q[0] + dc[1] * q[1] + dc[2] * q[2]) * id;
             if (uu >= 0.f && vv >= 0.f && uu + vv <= 1.f) {
               const float tt = (te2[0] * q[0] + te2[1] * q[1] + te2[2] * q[2]) * id;
-              if (tt >= tnear) atomicMin(reinterpret_cast<unsigned*>(zimg + (long)(bw0 + row) * width + bu0 + col), __float_as_uint(tt));
+              if (tt >= tnear) ZMIN(zimg + (long)(bw0 + row) * width + bu0 + col, tt);
             }
           }
         }
@@ -955,11 +972,14 @@ __global__ __launch_bounds__(256) void smj_meshlet_kernel(const DevRender R, flo
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       int incl = lane < n ? Q[lane].npx : 0;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off);
-        if (lane >= off) incl += t;
-      }
+      // inclusive prefix sum over the wave on the DPP data path: within the 16-lane rows (row_shr 1, 2, 4, 8; lanes without a source add
+      // 0), then the row totals across (row_bcast 15 into rows 1 and 3, row_bcast 31 into rows 2 and 3)
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);
       if (lane == 0) pre[0] = 0;     // pre[j] = candidate pixels of entries 0..j-1
       pre[lane + 1] = incl;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -980,13 +1000,14 @@ __global__ __launch_bounds__(256) void smj_meshlet_kernel(const DevRender R, flo
         const float l0 = E.la[0] * fc + E.lb[0] * fr + E.lc[0], l1 = E.la[1] * fc + E.lb[1] * fr + E.lc[1], l2 = E.la[2] * fc + E.lb[2] * fr + E.lc[2];
         if (l0 >= -2e-5f && l1 >= -2e-5f && l2 >= -2e-5f) {
           const float t = 1.f / (l0 * E.w[0] + l1 * E.w[1] + l2 * E.w[2]);
-          if (t >= tnear) atomicMin(reinterpret_cast<unsigned*>(zimg + (long)(E.w0 + row) * width + E.u0 + col), __float_as_uint(t));   // t > 0: the bit patterns order like the values
+          if (t >= tnear) ZMIN(zimg + (long)(E.w0 + row) * width + E.u0 + col, t);   // t > 0: the bit patterns order like the values
         }
       }
       __builtin_amdgcn_wave_barrier();   // the queue is rewritten by the next pass
       }
     }
     __builtin_amdgcn_wave_barrier();     // ... and the vertices by the next meshlet
+    }
   }
 }
 
@@ -1019,7 +1040,7 @@ void smj_launch_depth(const DevRender& r, const float* xpose, long ld, int num_e
     const float tfar = (md > 0.f && md < r.zfar) ? md : r.zfar;
     const long npx = (long)nenv * width * height;
     hipLaunchKernelGGL(smj_fill_kernel, dim3(2048), dim3(256), 0, stream, out, npx, tfar * (1.f + 1e-6f));
-    hipLaunchKernelGGL(smj_meshlet_kernel, dim3(r.raster_splits, nenv), dim3(256), 0, stream, rr, ws, width, height, th, tfar * (1.f + 1e-6f), out, mode == 1 ? 1 : 0);
+    hipLaunchKernelGGL(smj_meshlet_kernel, dim3(nenv, r.raster_splits), dim3(256), 0, stream, rr, ws, width, height, th, tfar * (1.f + 1e-6f), out, mode == 1 ? 1 : 0);
     hipLaunchKernelGGL((smj_depth_kernel<false, true>), dim3(tiles, nenv), dim3(256), 0, stream, rr, ws, width, height, th, md, out, layer, mode,
                        (unsigned char*)nullptr, (int*)nullptr);
     if (getenv("SMJ_DEPTH_DEBUG")) {   // tools: how many triangles the rasteriser handed over, per env
