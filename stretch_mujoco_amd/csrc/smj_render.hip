@@ -33,7 +33,9 @@ namespace {
 #define STAT_PASS
 #endif
 
-constexpr int TILE = 16;   // pixels per side of a workgroup's tile (32 was measured slower: coarser culling outweighs the shared staging)
+constexpr int TILE_RAY = 16;    // pixels per side of a workgroup's tile when every mesh is ray cast (32 was measured slower: coarser culling outweighs the shared staging)
+constexpr int TILE_RASTER = 64; // ... when the meshes and boxes are in the z-buffer already: the few primitives left make the tile's set-up (a chain of
+                                // dependent global loads) the cost of the per-pixel kernel, so it is shared by 16 times as many pixels
 
 struct RGeom {
   float pos[3], mat[9], cen[3], rbound, size[3];
@@ -43,6 +45,7 @@ struct RGeom {
 enum { RT_PLANE = 0, RT_SPHERE = 2, RT_CAPSULE = 3, RT_ELLIPSOID = 4, RT_CYLINDER = 5, RT_BOX = 6, RT_MESH = 7 };
 
 __device__ __forceinline__ float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }   // 1-ulp reciprocal (the rasteriser's paths: depths are compared at 1e-4)
 __device__ __forceinline__ void mulT(float* r, const float* m, const float* v) {   // r = m' v
   r[0] = m[0] * v[0] + m[3] * v[1] + m[6] * v[2];
   r[1] = m[1] * v[0] + m[4] * v[1] + m[7] * v[2];
@@ -542,6 +545,7 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
   __shared__ int wcount[2];
   __shared__ float htri[RASTER ? HLCAP : 1][9];   // the rasteriser's handed-over triangles that meet this tile (camera frame)
   __shared__ int hcount[4];
+  constexpr int TILE = RASTER ? TILE_RASTER : TILE_RAY;
   const int env = blockIdx.y;
   const int tiles_x = (width + TILE - 1) / TILE;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
@@ -628,8 +632,8 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
     const int u = tx * TILE + (rd % (TILE / 16)) * 16 + (wv & 1) * 8 + (ln & 7), v = ty * TILE + (rd / (TILE / 16)) * 16 + (wv >> 1) * 8 + (ln >> 3);
     if (u >= width || v >= height) continue;
     // pixel centre -> ray in the camera frame (x right, y up, looking down -z); parameter t = distance along the optical axis
-    const float xn = ((u + 0.5f) / width * 2.f - 1.f) * tan_half_fovy * aspect;
-    const float yn = (1.f - (v + 0.5f) / height * 2.f) * tan_half_fovy;
+    const float xn = RASTER ? ((u + 0.5f) * (2.f * frcp((float)width)) - 1.f) * tan_half_fovy * aspect : ((u + 0.5f) / width * 2.f - 1.f) * tan_half_fovy * aspect;
+    const float yn = RASTER ? (1.f - (v + 0.5f) * (2.f * frcp((float)height))) * tan_half_fovy : (1.f - (v + 0.5f) / height * 2.f) * tan_half_fovy;
     const float dc[3] = {xn, yn, -1.f};
     float d[3], o[3] = {cpos[0], cpos[1], cpos[2]};
     mul(d, cmat, dc);
@@ -650,10 +654,20 @@ __global__ __launch_bounds__(256) void smj_depth_kernel(const DevRender R, const
       }
       STAT(1);
       const float dif[3] = {o[0] - G.pos[0], o[1] - G.pos[1], o[2] - G.pos[2]};
+      if (RASTER && G.type == RT_PLANE && G.size[0] <= 0.f && G.size[1] <= 0.f) {
+        // the floor: an unbounded plane needs only the third row of the ray in its frame (normal = the frame's z axis)
+        const float nz[3] = {G.mat[2], G.mat[5], G.mat[8]};
+        const float den = dot3(nz, d);
+        if (den < -1e-15f) {
+          const float x = -dot3(nz, dif) * frcp(den);
+          if (x >= tnear && x < best) best = x;
+        }
+        continue;
+      }
       float lp[3], lv[3];
       mulT(lp, G.mat, dif);
       mulT(lv, G.mat, d);
-      if (G.type == RT_MESH) {
+      if (!RASTER && G.type == RT_MESH) {
         if (G.rmesh >= 0) {
           STAT(2);
           const float nb = ray_mesh<true>(R, G.rmesh, lp, lv, tnear, best STAT_PASS);
@@ -744,7 +758,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   int* HL = reinterpret_cast<int*>(W + WS_HL);
   float* zimg = zbuf + (single_image ? 0 : (long)env * height * width);
   const float aspect = (float)width / (float)height, tnear = R.znear, tx = tan_half_fovy * aspect, ty = tan_half_fovy;
-  const float sx = 0.5f * width / tx, sy = 0.5f * height / ty;
+  const float sx = 0.5f * width / tx, sy = 0.5f * height / ty, isx = 1.f / sx, isy = 1.f / sy;
+  // (1-ulp reciprocals throughout: screen boxes carry their own margin, depths are compared at 1e-4)
   const float dn = tnear * (1.f - 1e-3f);
   float* X = vx[wv]; float* Y = vy[wv]; float* Dp = vd[wv];
   MlEntry* Q = queue[wv];
@@ -777,7 +792,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         // turned away iff n . (x - camera) >= 0; n . (x - camera) >= dist cos(phi + theta) - rad when phi + theta < 90 deg
         const float uv[3] = {cen[0] - lp[0], cen[1] - lp[1], cen[2] - lp[2]};
         const float dist = sqrtf(uv[0] * uv[0] + uv[1] * uv[1] + uv[2] * uv[2]);
-        const float cf = (r2.x * uv[0] + r2.y * uv[1] + r2.z * uv[2]) / fmaxf(dist, 1e-20f);
+        const float cf = (r2.x * uv[0] + r2.y * uv[1] + r2.z * uv[2]) * frcp(fmaxf(dist, 1e-20f));
         const float sf = sqrtf(fmaxf(0.f, 1.f - cf * cf)), sc = sqrtf(fmaxf(0.f, 1.f - r2.w * r2.w));
         const float val = cf * r2.w - sf * sc;
         if (cf > 0.f && val > 0.f && val * dist >= rad) alive_l = 0;
@@ -796,7 +811,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       mul(cv, rcg, pv);
       const float cxx = cv[0] + tcg[0], cyy = cv[1] + tcg[1], D = -(cv[2] + tcg[2]);
       if (D >= dn) {
-        const float inv = 1.f / D;
+        const float inv = frcp(D);
         X[j] = cxx * inv * sx + 0.5f * width; Y[j] = 0.5f * height - cyy * inv * sy;
       } else { X[j] = cxx; Y[j] = cyy; }
       Dp[j] = D;
@@ -820,7 +835,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
             // back to the camera frame (vertices nearer than the plane were left there); front faces only
             float cx[3], cy[3];
             for (int q = 0; q < 3; q++) {
-              if (pd[q] >= dn) { cx[q] = (px[q] - 0.5f * width) / sx * pd[q]; cy[q] = (0.5f * height - py[q]) / sy * pd[q]; }
+              if (pd[q] >= dn) { cx[q] = (px[q] - 0.5f * width) * isx * pd[q]; cy[q] = (0.5f * height - py[q]) * isy * pd[q]; }
               else { cx[q] = px[q]; cy[q] = py[q]; }
             }
             const float e1[3] = {cx[1] - cx[0], cy[1] - cy[0], -(pd[1] - pd[0])}, e2[3] = {cx[2] - cx[0], cy[2] - cy[0], -(pd[2] - pd[0])};
@@ -836,7 +851,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                 rx[q] = src == 0 ? cx[0] : src == 1 ? cx[1] : cx[2]; ry[q] = src == 0 ? cy[0] : src == 1 ? cy[1] : cy[2]; rd[q] = src == 0 ? pd[0] : src == 1 ? pd[1] : pd[2];
               }
               // the plane's crossings of the two edges at the lone vertex: 0 -> 1 and 2 -> 0
-              const float s01 = (dn - rd[0]) / (rd[1] - rd[0]), s20 = (dn - rd[2]) / (rd[0] - rd[2]);
+              const float s01 = (dn - rd[0]) * frcp(rd[1] - rd[0]), s20 = (dn - rd[2]) * frcp(rd[0] - rd[2]);
               const float ax = rx[0] + s01 * (rx[1] - rx[0]), ay = ry[0] + s01 * (ry[1] - ry[0]);
               const float bx = rx[2] + s20 * (rx[0] - rx[2]), by = ry[2] + s20 * (ry[0] - ry[2]);
               float vx4[4], vy4[4], vd4[4];
@@ -851,7 +866,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
               }
 #pragma unroll
               for (int q = 0; q < 4; q++) {
-                const float inv = 1.f / vd4[q];
+                const float inv = frcp(vd4[q]);
                 qx[q] = vx4[q] * inv * sx + 0.5f * width; qy[q] = 0.5f * height - vy4[q] * inv * sy; qd[q] = vd4[q];
               }
               // These are few but large on screen (a few centimetres from the camera): the per-pixel kernel takes the uncut triangle,
@@ -905,7 +920,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
           if (npx > RASTER_MAX_BOX) {
             // too many candidates for one wave: the per-pixel kernel takes the triangle (camera frame), tile by tile
             float cx[3], cy[3];
-            for (int q = 0; q < 3; q++) { cx[q] = (px[q] - 0.5f * width) / sx * pd[q]; cy[q] = (0.5f * height - py[q]) / sy * pd[q]; }
+            for (int q = 0; q < 3; q++) { cx[q] = (px[q] - 0.5f * width) * isx * pd[q]; cy[q] = (0.5f * height - py[q]) * isy * pd[q]; }
             const int at = atomicAdd(HL, 1);
             if (at < HLCAP) {
               float* E = W + WS_HL + 4 + at * HLW;
@@ -961,12 +976,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         MlEntry& E = Q[__popcll(have & ((1ull << lane) - 1ull))];
         const float ox = (float)u0 + 0.5f, oy = (float)w0 + 0.5f;
         const float x0 = px[0] - ox, y0 = py[0] - oy, x1 = px[1] - ox, y1 = py[1] - oy, x2 = px[2] - ox, y2 = py[2] - oy;
-        const float A = (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0), ia = 1.f / A;
+        const float A = (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0), ia = frcp(A);
         // lambda_0 = E_12 / A, lambda_1 = E_20 / A, lambda_2 = E_01 / A;  E_ij(p) = (xj - xi)(py - yi) - (yj - yi)(px - xi)
         E.la[0] = -(y2 - y1) * ia; E.lb[0] = (x2 - x1) * ia; E.lc[0] = ((y2 - y1) * x1 - (x2 - x1) * y1) * ia;
         E.la[1] = -(y0 - y2) * ia; E.lb[1] = (x0 - x2) * ia; E.lc[1] = ((y0 - y2) * x2 - (x0 - x2) * y2) * ia;
         E.la[2] = -(y1 - y0) * ia; E.lb[2] = (x1 - x0) * ia; E.lc[2] = ((y1 - y0) * x0 - (x1 - x0) * y0) * ia;
-        E.w[0] = 1.f / pd[0]; E.w[1] = 1.f / pd[1]; E.w[2] = 1.f / pd[2];
+        E.w[0] = frcp(pd[0]); E.w[1] = frcp(pd[1]); E.w[2] = frcp(pd[2]);
         E.u0 = u0; E.w0 = w0; E.nu = nu; E.npx = npx;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -999,7 +1014,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         const float fc = (float)col, fr = (float)row;
         const float l0 = E.la[0] * fc + E.lb[0] * fr + E.lc[0], l1 = E.la[1] * fc + E.lb[1] * fr + E.lc[1], l2 = E.la[2] * fc + E.lb[2] * fr + E.lc[2];
         if (l0 >= -2e-5f && l1 >= -2e-5f && l2 >= -2e-5f) {
-          const float t = 1.f / (l0 * E.w[0] + l1 * E.w[1] + l2 * E.w[2]);
+          const float t = frcp(l0 * E.w[0] + l1 * E.w[1] + l2 * E.w[2]);
           if (t >= tnear) ZMIN(zimg + (long)(E.w0 + row) * width + E.u0 + col, t);   // t > 0: the bit patterns order like the values
         }
       }
@@ -1023,7 +1038,8 @@ void smj_launch_lidar(const DevRender& r, const float* xpose, long ld, int num_e
 size_t smj_depth_workspace_bytes(int num_envs) { return sizeof(float) * (size_t)WS_STRIDE * (size_t)(num_envs + 1); }
 void smj_launch_depth(const DevRender& r, const float* xpose, long ld, int num_envs, int cam, int width, int height,
                       float fovy_deg, float max_depth, float* out, const float* layer, int mode, float* workspace, hipStream_t stream) {
-  const int tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+  const int tiles = ((width + TILE_RAY - 1) / TILE_RAY) * ((height + TILE_RAY - 1) / TILE_RAY);
+  const int tiles_r = ((width + TILE_RASTER - 1) / TILE_RASTER) * ((height + TILE_RASTER - 1) / TILE_RASTER);
   const float th = tanf(fovy_deg * 3.14159265358979323846f / 360.f);
   const int nenv = mode == 1 ? 1 : num_envs;
   float* ws = mode == 1 ? workspace + (size_t)WS_STRIDE * num_envs : workspace;   // the static layer stages into the last block
@@ -1041,7 +1057,7 @@ void smj_launch_depth(const DevRender& r, const float* xpose, long ld, int num_e
     const long npx = (long)nenv * width * height;
     hipLaunchKernelGGL(smj_fill_kernel, dim3(2048), dim3(256), 0, stream, out, npx, tfar * (1.f + 1e-6f));
     hipLaunchKernelGGL(smj_meshlet_kernel, dim3(nenv, r.raster_splits), dim3(256), 0, stream, rr, ws, width, height, th, tfar * (1.f + 1e-6f), out, mode == 1 ? 1 : 0);
-    hipLaunchKernelGGL((smj_depth_kernel<false, true>), dim3(tiles, nenv), dim3(256), 0, stream, rr, ws, width, height, th, md, out, layer, mode,
+    hipLaunchKernelGGL((smj_depth_kernel<false, true>), dim3(tiles_r, nenv), dim3(256), 0, stream, rr, ws, width, height, th, md, out, layer, mode,
                        (unsigned char*)nullptr, (int*)nullptr);
     if (getenv("SMJ_DEPTH_DEBUG")) {   // tools: how many triangles the rasteriser handed over, per env
       (void)hipStreamSynchronize(stream);
@@ -1056,7 +1072,7 @@ void smj_launch_depth(const DevRender& r, const float* xpose, long ld, int num_e
 }
 void smj_launch_rgb(const DevRender& r, const float* xpose, long ld, int num_envs, int cam, int width, int height, float fovy_deg,
                     unsigned char* rgb, int* gid, float* workspace, hipStream_t stream) {
-  const int tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+  const int tiles = ((width + TILE_RAY - 1) / TILE_RAY) * ((height + TILE_RAY - 1) / TILE_RAY);
   const float th = tanf(fovy_deg * 3.14159265358979323846f / 360.f);
   hipLaunchKernelGGL(smj_depth_prepass, dim3(num_envs), dim3(128), 0, stream, r, xpose, ld, cam, 0.f, workspace, 0, 0);
   hipLaunchKernelGGL((smj_depth_kernel<true, false>), dim3(tiles, num_envs), dim3(256), 0, stream, r, workspace, width, height, th, 0.f,

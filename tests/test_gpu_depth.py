@@ -146,8 +146,8 @@ def test_rasterised_meshes_equal_the_ray_cast_meshes():
     and the per-pixel kernel resolves the other primitives against it; option depth_raster = 0 casts a ray per pixel through the
     mesh BVHs instead (the round-2 path).  Same pixel-centre sampling, front faces only, depth along the optical axis: the two
     images agree up to fp32 rounding (the rasteriser interpolates 1 / depth over the screen triangle, and takes a box as twelve
-    triangles instead of the ray / box closed form) -- within 1e-4 relative on all but the odd silhouette pixel (< 2 in 10^5),
-    bit-identical on more than half.  64 envs at random poses, kitchen stand-in, both cameras."""
+    triangles instead of the ray / box closed form, 1-ulp reciprocals) -- within 1e-4 relative on all but the odd silhouette pixel
+    (< 2 in 10^5).  64 envs at random poses, kitchen stand-in, both cameras."""
     from stretch_mujoco_amd import StretchBatchSimulator
     from stretch_mujoco_amd.enums import StretchCameras
 
@@ -166,7 +166,7 @@ def test_rasterised_meshes_equal_the_ray_cast_meshes():
     for k in a:
         same = (a[k] == b[k]).float().mean().item()
         close = ((a[k] - b[k]).abs() <= 1e-4 * b[k].abs()).float().mean().item()
-        assert same > 0.5 and close > 0.99998, (k, same, close)
+        assert close > 0.99998, (k, same, close)
         assert float((a[k] > 0).float().mean()) > 0.3
     sim.stop()
 
