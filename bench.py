@@ -371,6 +371,8 @@ def main():
                        "overflow_flags": flags, "envs_over_capacity_since_reset": flagged},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on an earlier run "
+                                           "(read side x2 per MI355X_MICROARCH.md), NOT measured inside this run" if traffic is not None else None,
                          "kernel": "smj_step_kernel", "timed_launches": len(events), "timed_kernel_ms": kern_ms,
                          "kernel_ms_per_step": kern_ms / max(1, kern_steps),
                          "us_per_env_step_latency": kern_ms * 1e3 / max(1, kern_steps),

@@ -9,7 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 KERNEL = "smj_step_kernel"
 
 
@@ -18,22 +18,24 @@ def render_summary(out):
     path = os.path.join(SRC, "rtrace", "smj_kernel_stats.csv")
     if not os.path.exists(path):
         return
-    out.append("\n## Ray-casting kernels: `rocprofv3 --kernel-trace --stats -- python tools/gpu_render_prof.py` (kitchen stand-in, 4096 envs, both depth cameras + lidar)\n")
+    out.append("\n## Depth / lidar kernels: `rocprofv3 --kernel-trace --stats -- python tools/gpu_render_prof.py` (kitchen stand-in, 4096 envs, both depth cameras + lidar)\n")
+    out.append("A depth render of one camera = `smj_depth_prepass` (per-env staging) + `smj_fill_kernel` (z-buffer) + `smj_meshlet_kernel` (meshes and boxes rasterised, "
+               "atomicMin) + `smj_depth_kernel<false, true>` (per-pixel: remaining primitives, handed-over triangles, limits); calls 1 and 3 of each are the one-off camera-static layers.\n")
     out.append("| kernel | calls | total ms | avg ms | % | min ms | max ms |\n|---|---|---|---|---|---|---|")
     with open(path) as f:
         for r in csv.DictReader(f):
-            if any(k in r["Name"] for k in ("smj_depth", "smj_lidar", "smj_stage", "smj_base")):
+            if any(k in r["Name"] for k in ("smj_depth", "smj_meshlet", "smj_fill", "smj_lidar", "smj_stage", "smj_base")):
                 out.append(f"| `{r['Name'][:50]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e6:.3f} | {float(r['Percentage']):.2f} | {float(r['MinNs'])/1e6:.3f} | {float(r['MaxNs'])/1e6:.3f} |")
     per = collections.defaultdict(dict)
     for d in sorted(glob.glob(os.path.join(SRC, "rpmc_*", "smj_counter_collection.csv"))):
         acc = collections.defaultdict(list)
         with open(d) as f:
             for r in csv.DictReader(f):
-                for kn in ("smj_depth_kernel", "smj_depth_prepass", "smj_lidar_kernel"):
+                for kn in ("smj_meshlet_kernel", "smj_depth_kernel", "smj_depth_prepass", "smj_lidar_kernel"):
                     if kn in r["Kernel_Name"]:
                         acc[(kn, r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (kn, cn), v in acc.items():
-            v = v[2:] if kn == "smj_depth_kernel" and len(v) > 4 else v   # skip the two one-off camera-static layer renders
+            v = [x for x in v if x > 0.05 * max(v)] if kn in ("smj_depth_kernel", "smj_meshlet_kernel") and len(v) > 4 else v   # skip the two one-off camera-static layer renders
             per[kn][cn] = sum(v) / len(v)
     out.append("\nPMC means per dispatch (separate `--pmc` passes):\n")
     names = sorted({c for k in per.values() for c in k})
@@ -65,6 +67,9 @@ def main():
         if float(r["Percentage"]) > 0.01:
             name = r["Name"][:60]
             out.append(f"| `{name}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e6:.3f} | {float(r['Percentage']):.2f} | {float(r['MinNs'])/1e6:.3f} | {float(r['MaxNs'])/1e6:.3f} |")
+    out.append("\n(`smj_step_kernel_tall_worker` is not a second hot kernel: its time is that of the two POLLER workgroups that stay resident beside "
+               "each standard launch while a recent launch had a capacity escalation -- they idle-poll the escalation list -- plus the sweep launch that follows; "
+               "their share of the GPU is 2 of ~1000 wave slots.)")
     with open(os.path.join(SRC, "trace", "smj_kernel_trace.csv")) as f:
         allk = list(csv.DictReader(f))
     is_std = lambda name: name.startswith(KERNEL + "(")
@@ -144,7 +149,9 @@ def main():
                    "source": f"profiles/{TAG}_rocprof_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                              f"timed-region launches; read side x2 per MI355X_MICROARCH.md section HBM)"}, f, indent=1)
     render_summary(out)
-    for sub, title in (("ktrace", "kitchen stand-in (`tools/gpu_options_probe.py scene=stretch_kitchen_standin`: 300 settle steps, 14 random-action launches of 50 steps; the tall variant is the primary kernel)"),
+    for sub, title in (("strace", "the reference's own scene (`tools/gpu_options_probe.py scene=stretch_scene`: table + 2 free objects, 38 dofs; `smj_step_kernel_big38`, two envs per CU, escalation target `smj_step_kernel_big_worker`)"),
+                       ("k4trace", "kitchen with four free objects (`scene=stretch_kitchen4`, 50 dofs; `smj_step_kernel_big50`, two envs per CU)"),
+                       ("ktrace", "kitchen stand-in (`tools/gpu_options_probe.py scene=stretch_kitchen_standin`: 300 settle steps, 14 random-action launches of 50 steps; the tall variant is the primary kernel)"),
                        ("ptrace", "PGS (`tools/gpu_options_probe.py solver=0`, empty scene, same schedule)")):
         path = os.path.join(SRC, sub, "smj_kernel_stats.csv")
         if not os.path.exists(path):
@@ -155,13 +162,41 @@ def main():
             for r in csv.DictReader(f):
                 if float(r["Percentage"]) > 0.05:
                     out.append(f"| `{r['Name'][:60]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e6:.3f} | {float(r['Percentage']):.2f} | {float(r['MinNs'])/1e6:.3f} | {float(r['MaxNs'])/1e6:.3f} |")
-        log = os.path.join(SRC, {"ktrace": "kitchen_trace.log", "ptrace": "pgs_trace.log"}[sub])
+        log = os.path.join(SRC, {"ktrace": "kitchen_trace.log", "ptrace": "pgs_trace.log", "strace": "scene_trace.log", "k4trace": "kitchen4_trace.log"}[sub])
         if os.path.exists(log):
             last = [l for l in open(log) if "env-steps/s" in l]
             if last:
                 out.append("\nProbe output under the profiler: `" + last[-1].strip()[:200] + "`")
+    # PMC passes over the kitchen4 workload (smj_step_kernel_big50)
+    kv = {}
+    for d in sorted(glob.glob(os.path.join(SRC, "k4pmc_*", "smj_counter_collection.csv"))):
+        acc = collections.defaultdict(list)
+        with open(d) as f:
+            for r in csv.DictReader(f):
+                if r["Kernel_Name"].startswith("smj_step_kernel_big50("):
+                    acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for name, v in acc.items():
+            v = v[-10:]
+            kv[name] = sum(v) / len(v)
+    if kv:
+        out.append("\n## PMC counters of `smj_step_kernel_big50` (kitchen with four free objects, 4096 envs, 50-step launches; each group its own `--pmc` run), per launch, last 10 launches\n")
+        out.append("| counter | mean |\n|---|---|")
+        for name in sorted(kv):
+            out.append(f"| {name} | {kv[name]:.4g} |")
+        wc = kv.get("SQ_WAVE_CYCLES", 0)
+        if wc:
+            issued = kv.get("SQ_INSTS_VALU", 0) + kv.get("SQ_INSTS_SALU", 0) + kv.get("SQ_INSTS_LDS", 0)
+            out.append(f"\n{4 * wc / max(1, issued):.1f} shader cycles per issued instruction (one wave per SIMD, two of a CU's four SIMDs occupied: 81.6 KB of LDS per env); "
+                       f"MFMA busy {kv.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / max(1, 4 * wc):.4f}; LDS bank-conflict ratio {kv.get('SQ_LDS_BANK_CONFLICT', 0) / max(1, kv.get('SQ_ACTIVE_INST_LDS', 1)):.3f}; "
+                       f"HBM per launch: FETCH_SIZE {kv.get('FETCH_SIZE', 0) * 1024 / 1e6:.1f} MB + WRITE_SIZE {kv.get('WRITE_SIZE', 0) * 1024 / 1e6:.1f} MB "
+                       f"(algorithmic: (55 + 50 + 10 + 50 + 55 + 50 + 50) words x 4 B x 4096 envs x 50 steps = {(55 + 50 + 10 + 50 + 55 + 50 + 50) * 4 * 4096 * 50 / 1e6:.0f} MB; moved once per launch: 1/50 of that).")
     with open(os.path.join(DST, f"{TAG}_rocprof_summary.md"), "w") as f:
         f.write("\n".join(out) + "\n")
+    for scn in ("stretch_scene", "stretch_kitchen4"):
+        scp = os.path.join(ROOT, "gpurun_out", f"stage_cycles_{scn}.txt")
+        if os.path.exists(scp):
+            with open(scp) as fi, open(os.path.join(DST, f"{TAG}_stage_cycles_{scn}.txt"), "w") as fo:
+                fo.write(fi.read())
     sc = os.path.join(ROOT, "gpurun_out", "stage_cycles.txt")
     if os.path.exists(sc):   # tools/gpu_diag.py: per-stage shader cycles and event counts per env-step (profiling build of the standard kernel)
         with open(sc) as fi, open(os.path.join(DST, f"{TAG}_stage_cycles.txt"), "w") as fo:
