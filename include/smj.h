@@ -99,7 +99,11 @@ int smj_base_controller_tick(smj_ctx* ctx, void* stream);
  * scheduling only, results are bit-identical; 0 = one workgroup per env per call), "pollers" (default 2: workgroups of the
  * tall variant that run beside the standard kernel on a second stream, finish the current chunk of an env that ran out of
  * rows and hand it back -- they leave at once unless one of the last 8 calls had such envs; -n: n pollers that always stay; 0 = such envs are
- * finished after the standard kernel). */
+ * finished after the standard kernel), "pipeline_big" (the same chunking for the 38- / 50-column variants),
+ * "primary_rows" (0 = the variant's own limit; tests lower it to force hand-overs to the larger variant),
+ * "depth_raster" (default 1: smj_render_depth draws meshes and boxes with the meshlet rasteriser and resolves the remaining
+ * primitives per pixel; 0: per-pixel ray cast of every geom through the mesh BVHs -- the same image up to fp32 rounding at
+ * silhouette pixels), "depth_raster_splits" (default 8: workgroups per env of the rasteriser). */
 int smj_set_option(smj_ctx* ctx, const char* name, double value);
 
 /* Depth image of camera `camera_id` (index into the model's cameras, stretch.xml order: d405_rgb, d405_depth,
