@@ -208,7 +208,7 @@ enum { SMJ_PROF_KIN = 0, SMJ_PROF_COMCRB, SMJ_PROF_SMOOTH, SMJ_PROF_FACTOR, SMJ_
        SMJ_PROF_N_PREP, SMJ_PROF_N_LS, SMJ_PROF_N_LSEVALS,
        // convex collision: cycles of the pose / bounding-sphere / oriented-box / narrowphase parts, and counts per step
        SMJ_PROF_C_POSE, SMJ_PROF_C_SPHERE, SMJ_PROF_C_OBB, SMJ_PROF_C_NARROW, SMJ_PROF_C_NSPHERE, SMJ_PROF_C_NOBB, SMJ_PROF_C_NHIT,
-       SMJ_PROF_C_NMULTI, SMJ_PROF_SLOTS = 32 };
+       SMJ_PROF_C_NMULTI, SMJ_PROF_C_TBOXBOX, SMJ_PROF_C_TMPR1, SMJ_PROF_C_TMULTI, SMJ_PROF_C_ROUNDS, SMJ_PROF_H_K, SMJ_PROF_H_CONE, SMJ_PROF_H_STORE, SMJ_PROF_H_NKS, SMJ_PROF_SLOTS = 40 };
 enum { SMJ_INFO_NEFC = 0, SMJ_INFO_NCON = 1, SMJ_INFO_NITER = 2, SMJ_INFO_FLAGS = 3 };
 enum { SMJ_FLAG_EFC_OVERFLOW = 1, SMJ_FLAG_CON_OVERFLOW = 2, SMJ_FLAG_BAD_STATE = 4, SMJ_FLAG_PIPE_TIMEOUT = 8 };
 

@@ -1924,8 +1924,10 @@ struct StepKernel {
     else ncon += total;
   }
 
-  SMJ_DEV static void axis_angle_mat(float* Rm, const float* ax, float ang) {
-    const float c = cosf(ang), sn = sinf(ang), t = 1 - c, x = ax[0], y = ax[1], z = ax[2];
+  // rotation by +-1e-3 rad about a unit axis.  The angle is multiccd's constant, so cos / sin / 1 - cos are literals (fp64 values
+  // rounded once: 1 - cosf(1e-3f) evaluated in fp32 would be off by 5 %), not two libm calls per matrix
+  SMJ_DEV static void axis_angle_mat(float* Rm, const float* ax, bool negative) {
+    const float c = 0.9999995000000417f, sn = negative ? -9.999998333333417e-4f : 9.999998333333417e-4f, t = 4.999999583333347e-7f, x = ax[0], y = ax[1], z = ax[2];
     Rm[0] = t * x * x + c; Rm[1] = t * x * y - sn * z; Rm[2] = t * x * z + sn * y;
     Rm[3] = t * x * y + sn * z; Rm[4] = t * y * y + c; Rm[5] = t * y * z - sn * x;
     Rm[6] = t * x * z - sn * y; Rm[7] = t * y * z + sn * x; Rm[8] = t * z * z + c;
@@ -1950,10 +1952,10 @@ struct StepKernel {
     for (int q = 0; q < 4; q++) {
       const float* ax = fr + 3 * (1 + (q >> 1));
       const float axv[3] = {uni(ax[0]), uni(ax[1]), uni(ax[2])};
-      const float ang = (q & 1) ? -1e-3f : 1e-3f;
+      const bool neg = (q & 1) != 0;
       // the unrotated poses and MPR interior points come from the LDS geom cache every round (no register copies kept)
       float Rp[9], Rn[9], ca[3], cb[3], mA[9], mB[9];
-      axis_angle_mat(Rp, axv, ang); axis_angle_mat(Rn, axv, -ang);
+      axis_angle_mat(Rp, axv, neg); axis_angle_mat(Rn, axv, !neg);
       for (int k = 0; k < 3; k++) {
         A.pos[k] = uni(s.u.c.pos[slotA][k]); Bs.pos[k] = uni(s.u.c.pos[slotB][k]); ca[k] = uni(s.u.c.ccen[slotA][k]); cb[k] = uni(s.u.c.ccen[slotB][k]);
       }
@@ -2102,7 +2104,7 @@ struct StepKernel {
       m.pos[i] = 0.5f * (p1 + p2) / sum;
     }
   }
-  SMJ_DEV void convex_multi4(const int* rec, const Shape& A, const Shape& Bs, int slotA, int slotB, const float* pos0, const float* dir0,
+  SMJ_DEV int convex_multi4(const int* rec, const Shape& A, const Shape& Bs, int slotA, int slotB, const float* pos0, const float* dir0,
                              float margin, float tol) {
     float fr[9] = {dir0[0], dir0[1], dir0[2], 0, 0, 0, 0, 0, 0};
     make_frame(fr);
@@ -2114,9 +2116,9 @@ struct StepKernel {
       const int q = lane >> 4;
       const float* ax = fr + 3 * (1 + (q >> 1));
       const float axv[3] = {ax[0], ax[1], ax[2]};
-      const float ang = (q & 1) ? -1e-3f : 1e-3f;
+      const bool neg = (q & 1) != 0;
       float Rp[9], Rn[9], ca[3], cb[3], mA[9], mB[9];
-      axis_angle_mat(Rp, axv, ang); axis_angle_mat(Rn, axv, -ang);
+      axis_angle_mat(Rp, axv, neg); axis_angle_mat(Rn, axv, !neg);
       for (int k = 0; k < 3; k++) { m.apos[k] = s.u.c.pos[slotA][k]; m.bpos[k] = s.u.c.pos[slotB][k]; ca[k] = s.u.c.ccen[slotA][k]; cb[k] = s.u.c.ccen[slotB][k]; }
       for (int k = 0; k < 9; k++) { mA[k] = s.u.c.mat[slotA][k]; mB[k] = s.u.c.mat[slotB][k]; }
       rotate_point(m.apos, pos0, Rp); rotate_point(m.bpos, pos0, Rn); rotate_point(ca, pos0, Rp); rotate_point(cb, pos0, Rn);
@@ -2129,18 +2131,18 @@ struct StepKernel {
       m.phase = MQ_W1; m.it = 0; m.ok = 0; m.depth = 0;
       for (int i = 0; i < 3; i++) { m.pdir[i] = 0; m.pos[i] = 0; }
     }
-    for (int round = 0; round < 256; round++) {
+    int round = 0;
+    for (; round < 256; round++) {
       // what each query needs before its next support point (loop heads of mpr_penetration)
       PL<int> need;
       LANES {
         MprLane& m = st[lane];
         if (m.phase == MQ_W3 && m.it > 100) m.phase = MQ_DONE;
-        if (m.phase == MQ_R1) {
+        if (m.phase == MQ_R1 || m.phase == MQ_R2) {   // both refinement loops start from the portal's normal
           portal_dir(m.P, m.dir);
           const float dot = dot3(m.dir, m.P[1].v);
-          if (ccd_zero(dot) || dot > 0) { m.phase = MQ_R2; m.it = 0; }
+          if (m.phase == MQ_R1 && (ccd_zero(dot) || dot > 0)) { m.phase = MQ_R2; m.it = 0; }
         }
-        if (m.phase == MQ_R2) portal_dir(m.P, m.dir);
         need[lane] = m.phase != MQ_DONE;
       }
       if (wave_ballot(need) == 0) break;
@@ -2209,17 +2211,20 @@ struct StepKernel {
               m.it++;
             } else { m.phase = MQ_R1; m.it = 0; }
           }
-        } else if (m.phase == MQ_R1) {
+        } else if (m.phase == MQ_R1 || m.phase == MQ_R2) {
+          // one body for the two refinement loops: the first also leaves when the new point is behind the origin (no
+          // penetration), the second leaves with a result -- computed after the rounds, once for all four queries
           m.v4 = np;
           const float dot = dot3(m.v4.v, m.dir);
-          if (!(ccd_zero(dot) || dot > 0) || reach_tolerance(m.P, m.v4, m.dir, tolm) || m.it > maxit) m.phase = MQ_DONE;
-          else { expand_portal(m.P, m.v4); m.it++; }
-        } else if (m.phase == MQ_R2) {
-          m.v4 = np;
-          if (reach_tolerance(m.P, m.v4, m.dir, tolm) || m.it > maxit) { mpr_finish(m); m.ok = 1; m.phase = MQ_DONE; }
+          const bool behind = m.phase == MQ_R1 && !(ccd_zero(dot) || dot > 0);
+          if (behind || reach_tolerance(m.P, m.v4, m.dir, tolm) || m.it > maxit) { m.ok = m.phase == MQ_R2 ? 2 : 0; m.phase = MQ_DONE; }
           else { expand_portal(m.P, m.v4); m.it++; }
         }
       }
+    }
+    LANES {
+      MprLane& m = st[lane];
+      if (m.ok == 2) { mpr_finish(m); m.ok = 1; }
     }
     // the results in query order: the manifold's duplicate test is sequential (convex_multi)
     PL<int> okp;
@@ -2251,6 +2256,7 @@ struct StepKernel {
       n++;
       add_contact(rec, -dp, ps, dir0);
     }
+    return round;
   }
 
   // non-plane pairs: cache world frames of the participating geoms, sphere + oriented-box broadphase with lane = pair,
@@ -2397,8 +2403,16 @@ struct StepKernel {
           }
           continue;
         }
-        if (A.type == GT_BOX && Bs.type == GT_BOX && M.multiccd) { box_box(r, uni(r[SMJ_CP_S1]), uni(r[SMJ_CP_S2]), margin); continue; }
-        if (!mpr_penetration(A, Bs, c0, c1, depth, dir, pos)) continue;
+        if (A.type == GT_BOX && Bs.type == GT_BOX && M.multiccd) {
+          const long long tb = prof ? smj_clock() : 0;
+          box_box(r, uni(r[SMJ_CP_S1]), uni(r[SMJ_CP_S2]), margin);
+          if (prof) pc[SMJ_PROF_C_TBOXBOX] += (float)(smj_clock() - tb);
+          continue;
+        }
+        const long long tm = prof ? smj_clock() : 0;
+        const bool pen = mpr_penetration(A, Bs, c0, c1, depth, dir, pos);
+        if (prof) pc[SMJ_PROF_C_TMPR1] += (float)(smj_clock() - tm);
+        if (!pen) continue;
         if (-depth > margin || dot3(dir, dir) < 0.5f) continue;
         add_contact(r, -depth, pos, dir);
         if (prof) pc[SMJ_PROF_C_NHIT] += 1.f;
@@ -2407,7 +2421,9 @@ struct StepKernel {
 #ifdef SMJ_EMUL   // the serial formulation stays in the lane emulator as the comparator of the four-wide one (tests/test_emul_parity.py)
           if (M.multi_serial) { convex_multi(r, A, Bs, uni(r[SMJ_CP_S1]), uni(r[SMJ_CP_S2]), pos, dir, margin, 1e-3f * asf(uni(r[SMJ_CP_RBMIN]))); continue; }
 #endif
-          convex_multi4(r, A, Bs, uni(r[SMJ_CP_S1]), uni(r[SMJ_CP_S2]), pos, dir, margin, 1e-3f * asf(uni(r[SMJ_CP_RBMIN])));
+          const long long t4 = prof ? smj_clock() : 0;
+          const int rounds = convex_multi4(r, A, Bs, uni(r[SMJ_CP_S1]), uni(r[SMJ_CP_S2]), pos, dir, margin, 1e-3f * asf(uni(r[SMJ_CP_RBMIN])));
+          if (prof) { pc[SMJ_PROF_C_TMULTI] += (float)(smj_clock() - t4); pc[SMJ_PROF_C_ROUNDS] += (float)rounds; }
         }
       }
       CTICK(SMJ_PROF_C_NARROW)
@@ -3566,13 +3582,17 @@ struct StepKernel {
             }
           }
         }
+        long long th = 0;
+        if (prof) { th = smj_clock(); pc[SMJ_PROF_H_K] += (float)(th - t0); }
         // contacts in the cone zone: k = the contact's rows q = 0..dim-1 (zero-padded to 4 or 8), A = (Hc Jc)[q][:], B = Jc[q][:].
         // cH is stored 6 x 6 with zero padding beyond the contact's condim (newton_update), rows past the block meet those zeros.
+        int nks = 0;
         for (uint64_t cm = conemask; cm;) {
           const int c = ffs64(cm);
           cm &= cm - 1;
           const int r0 = uni(s.cefc[c]), dim = uni(s.cdim[c]);
           for (int q0 = 0; q0 < dim; q0 += 4) {
+            nks++;
             PL<float> pa[NT], pb[NT];
             LANES {
               const int q = q0 + (lane >> 4), col = lane & 15, qc = q < 6 ? q : 5;
@@ -3597,6 +3617,7 @@ struct StepKernel {
               for (int tb = 0; tb <= ta; tb++) mfma16x16x4(acc[ta * (ta + 1) / 2 + tb], pa[ta], pb[tb]);
           }
         }
+        if (prof) { const long long t1 = smj_clock(); pc[SMJ_PROF_H_CONE] += (float)(t1 - th); th = t1; pc[SMJ_PROF_H_NKS] += (float)nks; }
         LANES {
 #pragma unroll
           for (int ta = 0; ta < NT; ta++)
@@ -3616,6 +3637,7 @@ struct StepKernel {
         }
       }
       SYNC();
+      if (prof) pc[SMJ_PROF_H_STORE] += (float)(smj_clock() - t0);   // (whole stage: k-steps + cone + store)
       TICK(SMJ_PROF_N_HMFMA)
       LANES { search[lane] = lane < nv ? grad[lane] : 0.f; }
       solve_H(search);

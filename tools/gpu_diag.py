@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stretch_mujoco_amd import StretchBatchSimulator
 from oracle.oracle import Oracle
 np.set_printoptions(precision=5, suppress=True, linewidth=200)
-PROF = ["kin", "comcrb", "smooth", "factor", "collision", "makecon", "project", "warm", "pgs", "post", "integrate", "total", "sweeps", "setup", "n_update", "n_grad", "n_xa", "n_hmfma", "n_gauss_jordan", "n_solve", "n_prep", "n_ls", "n_lsevals", "c_pose", "c_sphere", "c_obb", "c_narrow", "c_nsphere", "c_nobb", "c_nhit", "c_nmulti"]
+PROF = ["kin", "comcrb", "smooth", "factor", "collision", "makecon", "project", "warm", "pgs", "post", "integrate", "total", "sweeps", "setup", "n_update", "n_grad", "n_xa", "n_hmfma", "n_gauss_jordan", "n_solve", "n_prep", "n_ls", "n_lsevals", "c_pose", "c_sphere", "c_obb", "c_narrow", "c_nsphere", "c_nobb", "c_nhit", "c_nmulti", "c_tboxbox", "c_tmpr1", "c_tmulti", "c_rounds", "h_k", "h_cone", "h_store", "h_nks"]
 
 def stage_parity(nsteps=1):
     sim = StretchBatchSimulator(num_envs=4, device="cuda:0", debug=True)
@@ -59,7 +59,7 @@ def profile(B, random_ctrl, steps=50, solver="pgs", scene=None):
     info = sim.info.cpu().numpy()
     print(f"[{solver}] B={B} random={random_ctrl}: launch {ms:.2f} ms for {steps} steps -> {B*steps/ms*1e3:.0f} env-steps/s; nefc mean {info[0].mean():.1f} max {info[0].max()}, ncon mean {info[1].mean():.1f}, flags {np.bitwise_or.reduce(info[3])}")
     print("  cycles/step (mean over envs):", {n: int(p[i].mean()) for i, n in enumerate(PROF)})
-    print("  counts/step (mean over envs):", {n: round(float(p[i].mean()), 3) for i, n in enumerate(PROF) if n.startswith("c_n") or n in ("sweeps", "n_lsevals", "c_sphere")})
+    print("  counts/step (mean over envs):", {n: round(float(p[i].mean()), 3) for i, n in enumerate(PROF) if n.startswith("c_n") or n in ("sweeps", "n_lsevals", "c_sphere", "h_nks", "c_rounds")})
     hist = np.bincount(np.round(p[PROF.index("c_nobb")] * steps).astype(int) // steps, minlength=6)
     print("  envs by narrowphase calls per step (floor):", hist.tolist())
     print("  cycles/step (max over envs): ", {n: int(p[i].max()) for i, n in enumerate(PROF)})
