@@ -77,6 +77,7 @@ struct DevModel {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, neq, npair, nlevel, nfric, nlimit, nplanepair, nldl, nlidar, imu_site,
       ngc, nroot, nkey, ncgeom, nconvpair, njump, maxsubtree;
   int iterations, warmstart, pgs_fixed_iter, max_con_pair, solver /* 0 PGS, 2 Newton */, ls_iterations, convex_pairs;
+  int sep_cache;      // 1 = use DevState::sepcache (separating directions of convex pairs kept between steps)
   int multi_serial;   // lane emulator only: 1 = the four multiccd queries of a pair one after the other (convex_multi), the comparator of convex_multi4
   int row_limit;  // > 0: the primary variant hands an env over to the escalation variant beyond this many constraint rows (tests; option "primary_rows")
   int multiccd;   // stretch.xml:8 <flag multiccd="enable"/>: multi-point contacts for convex pairs (box-box polygon, counter-rotated queries)
@@ -191,7 +192,14 @@ struct DevState {
   int pipe_total;   // workgroups of the standard launch
   int pollers;      // workgroups of the poller launch; negative: they stay even if the previous launch had no escalation
   int* hot;         // > 0: one of the last SMJ_HOT_LAUNCHES launches had escalations (kept by the sweep)
+  // Separating directions of convex pairs (null = off): [B][SMJ_SEP_SLOTS] x {dir[3], pair id as int bits}, direct-mapped by
+  // pair id.  A pair whose penetration query ended with "the origin lies outside the Minkowski difference" leaves the
+  // direction that showed it; the next steps test that direction first (one support query) and skip the query while it
+  // still separates.  Any direction with a negative support proves the shapes disjoint, so a stale or foreign entry can only
+  // fail the test, never change a result.
+  float* sepcache;
 };
+enum { SMJ_SEP_SLOTS = 64 };
 enum { SMJ_PIPE_ABANDONED = 0x7fffffff, SMJ_PIPE_SWEPT = 0x7ffffffe, SMJ_HOT_LAUNCHES = 8 };
 enum { SMJ_SCHED_CLAIMED = 0, SMJ_SCHED_EXITED = 1, SMJ_SCHED_POLLERS = 2, SMJ_SCHED_COUNT = 3, SMJ_SCHED_WORDS = 4 };
 // BaseController state rows (floats; mode: 0 none, 1 translate-by, 2 rotate-by, 3 velocity)

@@ -214,6 +214,9 @@ SMJ_DEV float impedance(const float* solimp, float pos, float margin) {
   return dmin + y * (dmax - dmin);
 }
 
+#ifdef SMJ_EMUL
+static long smj_emul_sep_skips = 0;
+#endif
 // ---------------------------------------------------------------------------------------------- the step
 struct StepKernel {
   const DevModel& M;
@@ -1570,18 +1573,22 @@ struct StepKernel {
     }
     return best;
   }
-  SMJ_DEV bool mpr_penetration(const Shape& A, const Shape& Bs, const float* c0, const float* c1, float& depth, float* pdir, float* pos) {
+  // sep (optional): on a `false` that came from a support point behind the origin, the direction that showed it (the shapes are
+  // disjoint along it), else zero
+  SMJ_DEV bool mpr_penetration(const Shape& A, const Shape& Bs, const float* c0, const float* c1, float& depth, float* pdir, float* pos, float* sep = nullptr) {
     const float tol = 1e-6f;
     const int maxit = 50;
     MprPt P[4], v4;
     float dir[3], va[3], vb[3], dot;
+    if (sep) sep[0] = sep[1] = sep[2] = 0.f;
+#define SMJ_SEP_OUT() { if (sep && dot < 0) { sep[0] = dir[0]; sep[1] = dir[1]; sep[2] = dir[2]; } }
     for (int i = 0; i < 3; i++) { P[0].a[i] = c0[i]; P[0].b[i] = c1[i]; P[0].v[i] = c0[i] - c1[i]; }
     if (ccd_zero(P[0].v[0]) && ccd_zero(P[0].v[1]) && ccd_zero(P[0].v[2])) P[0].v[0] += 10.f * CCD_EPS;
     for (int i = 0; i < 3; i++) dir[i] = -P[0].v[i];
     normalize3(dir);
     mpr_support(A, Bs, dir, P[1]);
     dot = dot3(P[1].v, dir);
-    if (ccd_zero(dot) || dot < 0) return false;
+    if (ccd_zero(dot) || dot < 0) { SMJ_SEP_OUT() return false; }
     cross3(dir, P[0].v, P[1].v);
     if (ccd_zero(dot3(dir, dir))) {
       if (ccd_zero(P[1].v[0]) && ccd_zero(P[1].v[1]) && ccd_zero(P[1].v[2])) { depth = 0; pdir[0] = pdir[1] = pdir[2] = 0; }
@@ -1596,7 +1603,7 @@ struct StepKernel {
     normalize3(dir);
     mpr_support(A, Bs, dir, P[2]);
     dot = dot3(P[2].v, dir);
-    if (ccd_zero(dot) || dot < 0) return false;
+    if (ccd_zero(dot) || dot < 0) { SMJ_SEP_OUT() return false; }
     for (int i = 0; i < 3; i++) { va[i] = P[1].v[i] - P[0].v[i]; vb[i] = P[2].v[i] - P[0].v[i]; }
     cross3(dir, va, vb);
     normalize3(dir);
@@ -1616,7 +1623,7 @@ struct StepKernel {
       if (it > 100) return false;
       mpr_support(A, Bs, dir, P[3]);
       dot = dot3(P[3].v, dir);
-      if (ccd_zero(dot) || dot < 0) return false;
+      if (ccd_zero(dot) || dot < 0) { SMJ_SEP_OUT() return false; }
       bool cont = false;
       cross3(va, P[1].v, P[3].v);
       dot = dot3(va, P[0].v);
@@ -1637,7 +1644,8 @@ struct StepKernel {
       if (ccd_zero(dot) || dot > 0) break;
       mpr_support(A, Bs, dir, v4);
       dot = dot3(v4.v, dir);
-      if (!(ccd_zero(dot) || dot > 0) || reach_tolerance(P, v4, dir, tol) || it > maxit) return false;
+      if (!(ccd_zero(dot) || dot > 0)) { SMJ_SEP_OUT() return false; }
+      if (reach_tolerance(P, v4, dir, tol) || it > maxit) return false;
       expand_portal(P, v4);
     }
     for (int it = 0;; it++) {
@@ -1671,6 +1679,7 @@ struct StepKernel {
       }
       expand_portal(P, v4);
     }
+#undef SMJ_SEP_OUT
   }
 
   // [MJ] mjc_SphereBox / mjc_SphereSphere: primitive pairs have closed forms and do not go through MPR.  Wave-uniform.
@@ -2374,6 +2383,15 @@ struct StepKernel {
         tt[lane] = t;
       }
       uint64_t mask = wave_ballot(hit);
+      // the survivors' cached separating directions, fetched lane-parallel (lane = pair) ahead of the serial loop
+      PL<float> sdx, sdy, sdz;
+      PL<int> stag;
+      float* const sepbase = (S.sepcache && M.sep_cache) ? S.sepcache + (size_t)env * (SMJ_SEP_SLOTS * 4) : nullptr;
+      LANES {
+        Vec4 e = {0.f, 0.f, 0.f, 0.f};
+        if (sepbase && hit[lane]) e = *reinterpret_cast<const Vec4*>(sepbase + 4 * (tt[lane] & (SMJ_SEP_SLOTS - 1)));
+        sdx[lane] = e.x; sdy[lane] = e.y; sdz[lane] = e.z; stag[lane] = __builtin_bit_cast(int, e.w);
+      }
       CTICK(SMJ_PROF_C_OBB)
       if (prof) pc[SMJ_PROF_C_NOBB] += (float)popc64(mask);
       while (mask) {
@@ -2410,7 +2428,25 @@ struct StepKernel {
           continue;
         }
         const long long tm = prof ? smj_clock() : 0;
-        const bool pen = mpr_penetration(A, Bs, c0, c1, depth, dir, pos);
+        float sep[3];
+        bool pen = false, skipped = false;
+        if (sepbase && wave_read(stag, l) == t + 1) {   // (tag = pair + 1: a zeroed cache holds no entry)
+          // one support query along the direction that separated the pair last time: still behind the origin (by more than the
+          // rounding of the test) -> disjoint, what the full query would find
+          const float sd[3] = {wave_read(sdx, l), wave_read(sdy, l), wave_read(sdz, l)};
+          MprPt q;
+          mpr_support(A, Bs, sd, q);
+          skipped = dot3(q.v, sd) < -1e-6f;
+#ifdef SMJ_EMUL
+          if (skipped) smj_emul_sep_skips++;   // (tests: the cache is exercised)
+#endif
+        }
+        if (!skipped) {
+          pen = mpr_penetration(A, Bs, c0, c1, depth, dir, pos, sep);
+          if (sepbase && !pen && (sep[0] != 0.f || sep[1] != 0.f || sep[2] != 0.f)) {
+            LANES { if (lane == 0) *reinterpret_cast<Vec4*>(sepbase + 4 * (t & (SMJ_SEP_SLOTS - 1))) = Vec4{sep[0], sep[1], sep[2], asf(t + 1)}; }
+          }
+        }
         if (prof) pc[SMJ_PROF_C_TMPR1] += (float)(smj_clock() - tm);
         if (!pen) continue;
         if (-depth > margin || dot3(dir, dir) < 0.5f) continue;
