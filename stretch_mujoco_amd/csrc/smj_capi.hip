@@ -232,26 +232,23 @@ static int setup_render(smj_ctx* c, const void* blob, size_t nbytes) {
       const float f[8] = {m.cen[0], m.cen[1], m.cen[2], m.rad, m.axis[0], m.axis[1], m.axis[2], m.cosc};
       memcpy(q + 4, f, sizeof f);
     }
-    const int grpsz = getenv("SMJ_MLGROUP") ? atoi(getenv("SMJ_MLGROUP")) : 8;
-    for (int i = 0; i < nrgeom && gt; i++) {
+    for (int i = 0; i < nrgeom && gt; i++) {   // the work list: one (geom entry, meshlet) item per meshlet, mesh after mesh
       const int g = rgh[i];
-      if (boxlet[i] >= 0) { work.push_back(i); work.push_back(boxlet[i]); work.push_back(1); work.push_back(0); continue; }
+      if (boxlet[i] >= 0) { work.push_back(i); work.push_back(boxlet[i]); continue; }
       if (gth[g] != 7 || gmh[g] < 0) continue;
-      for (int k = 0; k < ml.mesh_count[gmh[g]]; k += grpsz) {   // groups of meshlets: the wave culls a group lane-parallel
-        work.push_back(i); work.push_back(ml.mesh_first[gmh[g]] + k); work.push_back(ml.mesh_count[gmh[g]] - k < grpsz ? ml.mesh_count[gmh[g]] - k : grpsz); work.push_back(0);
-      }
+      for (int k = 0; k < ml.mesh_count[gmh[g]]; k++) { work.push_back(i); work.push_back(ml.mesh_first[gmh[g]] + k); }
     }
     r.raster_boxes = gsh.empty() ? 0 : 1;
-    r.nmlist = (int)(work.size() / 4);
-    if (work.empty()) work.assign(4, 0);
+    r.nmlist = (int)(work.size() / 2);
+    if (work.empty()) work.assign(2, 0);
     if (ml.vert.empty()) ml.vert.assign(4, 0.f);
     std::vector<int> tri(ml.tri.begin(), ml.tri.end());
     if (tri.empty()) tri.assign(1, 0);
     r.mlvert = reinterpret_cast<const float4*>(up.f32(ml.vert));
     r.mltri = reinterpret_cast<const unsigned*>(up.i32(tri));
     r.mlrec = reinterpret_cast<const int4*>(up.i32(rec));
-    r.mlist = reinterpret_cast<const int4*>(up.i32(work));
-    if (!r.mlvert || !r.mltri || !r.mlrec || !r.mlist) return fail(c, -2, "device allocation failed for the meshlet tables");
+    r.mlitem = reinterpret_cast<const int2*>(up.i32(work));
+    if (!r.mlvert || !r.mltri || !r.mlrec || !r.mlitem) return fail(c, -2, "device allocation failed for the meshlet tables");
     r.raster = 1;
     r.raster_splits = 8;
   }

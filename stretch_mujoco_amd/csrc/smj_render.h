@@ -40,7 +40,7 @@ struct DevRender {
   const float4* mlvert;
   const unsigned* mltri;
   const int4* mlrec;
-  const int4* mlist;
+  const int2* mlitem;   // (visible-geom table entry, meshlet) for every meshlet of every mesh / box geom a camera can see; nmlist of them
   int nmlist, raster, raster_splits, raster_boxes;   // raster_boxes: box geoms are in the work list too (one meshlet each)
   int stat_select;                 // tools-only build (-DSMJ_DEPTH_STATS): >= 0 writes that work counter instead of the depth
 };

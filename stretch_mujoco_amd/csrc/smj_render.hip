@@ -743,9 +743,20 @@ constexpr int RASTER_MAX_BOX = 16384;   // candidate pixels a wave still takes i
 #else
 #define ZMIN(p, t) atomicMin(reinterpret_cast<unsigned*>(p), __float_as_uint(t))
 #endif
-struct MlEntry { float la[3], lb[3], lc[3], w[3]; int u0, w0, nu, npx; };   // lambda_k(col, row) = la[k] col + lb[k] row + lc[k]
+struct MlEntry { float la[3], lb[3], lc[3], w[3]; int u0, w0, nu, npx; };
+#ifdef SMJ_MESHLET_STATS   // tools build: work counters and shader cycles per phase, summed over the waves of a dispatch
+__device__ unsigned long long g_mlstat[16];
+#define MLC(i, v) mlc[i] += (unsigned long long)(v)
+#define MLT(i) { const long long t1_ = __builtin_readcyclecounter(); mlc[i] += (unsigned long long)(t1_ - mlt); mlt = t1_; }
+#else
+#define MLC(i, v)
+#define MLT(i)
+#endif   // lambda_k(col, row) = la[k] col + lb[k] row + lc[k]
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void smj_meshlet_kernel(const DevRender R, float* __restrict__ ws, int width, int height,
+#ifndef SMJ_ML_WAVES
+#define SMJ_ML_WAVES 4
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMJ_ML_WAVES, 8))) void smj_meshlet_kernel(const DevRender R, float* __restrict__ ws, int width, int height,
                                                           float tan_half_fovy, float tfar_eps, float* __restrict__ zbuf, int single_image) {
   __shared__ float vx[4][SMJ_MESHLET_VERTS], vy[4][SMJ_MESHLET_VERTS], vd[4][SMJ_MESHLET_VERTS];
   __shared__ MlEntry queue[4][64];
@@ -764,60 +775,99 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   float* X = vx[wv]; float* Y = vy[wv]; float* Dp = vd[wv];
   MlEntry* Q = queue[wv];
   int* pre = prefix[wv];
-  for (int m = blockIdx.y * 4 + wv; m < R.nmlist; m += gridDim.y * 4) {
-    const int4 grp = R.mlist[m];                      // (visible-geom table entry, first meshlet, meshlets <= 32, 0)
-    const int sl = __builtin_amdgcn_readfirstlane(slot_of[grp.x]);
-    if (sl < 0) continue;                             // dropped by the staging pass for this env (out of range, other layer)
-    const float* S = W + WS_HDR + (long)sl * WS_SLOT;
-    float rcg[9], tcg[3], lp[3];
-    for (int k = 0; k < 9; k++) rcg[k] = S[WS_RCG + k];
-    for (int k = 0; k < 3; k++) { tcg[k] = S[WS_TCG + k]; lp[k] = S[WS_LP + k]; }
-    // lane = meshlet of the group: bounding sphere against depth range and frustum, normal cone against the camera -- one pass of
-    // coalesced record loads and lane-parallel tests instead of a chain of dependent loads per meshlet; the survivors are then
-    // taken one after the other by the whole wave
+#ifdef SMJ_MESHLET_STATS
+  unsigned long long mlc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long mlt = __builtin_readcyclecounter();
+  const long long mlt0 = mlt;
+#endif
+  // lane = meshlet: the env's (geom, meshlet) items are dealt out to its waves round-robin (neighbouring meshlets of a mesh share
+  // their fate -- visible or not -- so a stride of one wave per item balances the waves), and a wave culls 64 of its items in one
+  // pass of lane-parallel loads and tests: bounding sphere against depth range and frustum, normal cone against the camera.  The
+  // survivors are then taken one after the other by the whole wave, the vertices and triangle words of the NEXT survivor being
+  // fetched while the current one is worked on.
+  const int nw = gridDim.y * 4, wid = blockIdx.y * 4 + wv;
+  for (int c0 = 0; c0 < R.nmlist; c0 += 64 * nw) {
+    const int item = c0 + lane * nw + wid;
+    MLC(0, 1);
     int4 r0 = make_int4(0, 0, 0, 0);
     int alive_l = 0;
-    if (lane < grp.z) {
-      r0 = R.mlrec[3 * (grp.y + lane)];
-      const float4 r1 = reinterpret_cast<const float4*>(R.mlrec)[3 * (grp.y + lane) + 1], r2 = reinterpret_cast<const float4*>(R.mlrec)[3 * (grp.y + lane) + 2];
-      const float cen[3] = {r1.x, r1.y, r1.z}, rad = r1.w;
-      float cc[3];
-      mul(cc, rcg, cen);
-      const float ccx = cc[0] + tcg[0], ccy = cc[1] + tcg[1], D = -(cc[2] + tcg[2]);
-      alive_l = !(D + rad < tnear || D - rad > tfar_eps);
-      // (a point at depth d is on screen iff |x| <= d tx, |y| <= d ty; the sphere's points have depth <= D + rad)
-      if (ccx - rad > (D + rad) * tx || -ccx - rad > (D + rad) * tx || ccy - rad > (D + rad) * ty || -ccy - rad > (D + rad) * ty) alive_l = 0;
-      if (r2.w > 0.f) {
-        // every face normal within theta of the axis; u = direction camera -> centre, phi its angle to the axis.  A face at x is
-        // turned away iff n . (x - camera) >= 0; n . (x - camera) >= dist cos(phi + theta) - rad when phi + theta < 90 deg
-        const float uv[3] = {cen[0] - lp[0], cen[1] - lp[1], cen[2] - lp[2]};
-        const float dist = sqrtf(uv[0] * uv[0] + uv[1] * uv[1] + uv[2] * uv[2]);
-        const float cf = (r2.x * uv[0] + r2.y * uv[1] + r2.z * uv[2]) * frcp(fmaxf(dist, 1e-20f));
-        const float sf = sqrtf(fmaxf(0.f, 1.f - cf * cf)), sc = sqrtf(fmaxf(0.f, 1.f - r2.w * r2.w));
-        const float val = cf * r2.w - sf * sc;
-        if (cf > 0.f && val > 0.f && val * dist >= rad) alive_l = 0;
+    float rcgl[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tcgl[3] = {0, 0, 0};
+    if (item < R.nmlist) {
+      MLC(1, 1);
+      const int2 it = R.mlitem[item];                  // (visible-geom table entry, meshlet)
+      const int sl = slot_of[it.x];
+      if (sl >= 0) {                                   // else: dropped by the staging pass for this env (out of range, other layer)
+        const float* S = W + WS_HDR + (long)sl * WS_SLOT;
+        float lp[3];
+        for (int k = 0; k < 9; k++) rcgl[k] = S[WS_RCG + k];
+        for (int k = 0; k < 3; k++) { tcgl[k] = S[WS_TCG + k]; lp[k] = S[WS_LP + k]; }
+        r0 = R.mlrec[3 * it.y];
+        const float4 r1 = reinterpret_cast<const float4*>(R.mlrec)[3 * it.y + 1], r2 = reinterpret_cast<const float4*>(R.mlrec)[3 * it.y + 2];
+        const float cen[3] = {r1.x, r1.y, r1.z}, rad = r1.w;
+        float cc[3];
+        mul(cc, rcgl, cen);
+        const float ccx = cc[0] + tcgl[0], ccy = cc[1] + tcgl[1], D = -(cc[2] + tcgl[2]);
+        alive_l = !(D + rad < tnear || D - rad > tfar_eps);
+        // (a point at depth d is on screen iff |x| <= d tx, |y| <= d ty; the sphere's points have depth <= D + rad)
+        if (ccx - rad > (D + rad) * tx || -ccx - rad > (D + rad) * tx || ccy - rad > (D + rad) * ty || -ccy - rad > (D + rad) * ty) alive_l = 0;
+        if (r2.w > 0.f) {
+          // every face normal within theta of the axis; u = direction camera -> centre, phi its angle to the axis.  A face at x is
+          // turned away iff n . (x - camera) >= 0; n . (x - camera) >= dist cos(phi + theta) - rad when phi + theta < 90 deg
+          const float uv[3] = {cen[0] - lp[0], cen[1] - lp[1], cen[2] - lp[2]};
+          const float dist = sqrtf(uv[0] * uv[0] + uv[1] * uv[1] + uv[2] * uv[2]);
+          const float cf = (r2.x * uv[0] + r2.y * uv[1] + r2.z * uv[2]) * frcp(fmaxf(dist, 1e-20f));
+          const float sf = sqrtf(fmaxf(0.f, 1.f - cf * cf)), sc = sqrtf(fmaxf(0.f, 1.f - r2.w * r2.w));
+          const float val = cf * r2.w - sf * sc;
+          if (cf > 0.f && val > 0.f && val * dist >= rad) alive_l = 0;
+        }
       }
     }
-    for (unsigned long long alive = __ballot(alive_l); alive;) {
+    unsigned long long alive = __ballot(alive_l);
+    MLC(2, __popcll(alive));
+    MLT(10)
+    float4 pv[3];
+    unsigned pt[SMJ_MESHLET_TRIS / 64];
+#define ML_FETCH(ML) { \
+      const int vb_ = __builtin_amdgcn_readlane(r0.x, ML), nv_ = __builtin_amdgcn_readlane(r0.y, ML), tb_ = __builtin_amdgcn_readlane(r0.z, ML), nt_ = __builtin_amdgcn_readlane(r0.w, ML); \
+      _Pragma("unroll") for (int u = 0; u < 3; u++) { const int j = lane + 64 * u; pv[u] = R.mlvert[vb_ + (j < nv_ ? j : nv_ - 1)]; } \
+      _Pragma("unroll") for (int u = 0; u < SMJ_MESHLET_TRIS / 64; u++) { const int k = lane + 64 * u; pt[u] = R.mltri[tb_ + (k < nt_ ? k : nt_ - 1)]; } }
+    if (alive) { const int f_ = __ffsll((long long)alive) - 1; ML_FETCH(f_) }
+    while (alive) {
     const int ml = __ffsll((long long)alive) - 1;
     alive &= alive - 1;
-    const int vbase = __builtin_amdgcn_readlane(r0.x, ml), nvert = __builtin_amdgcn_readlane(r0.y, ml);
-    const int tbase = __builtin_amdgcn_readlane(r0.z, ml), ntri = __builtin_amdgcn_readlane(r0.w, ml);
+    const int nvert = __builtin_amdgcn_readlane(r0.y, ml), ntri = __builtin_amdgcn_readlane(r0.w, ml);
+    float rcg[9], tcg[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) rcg[k] = rl(rcgl[k], ml);
+#pragma unroll
+    for (int k = 0; k < 3; k++) tcg[k] = rl(tcgl[k], ml);
+    float4 cvv[3];
+    unsigned ctt[SMJ_MESHLET_TRIS / 64];
+#pragma unroll
+    for (int u = 0; u < 3; u++) cvv[u] = pv[u];
+#pragma unroll
+    for (int u = 0; u < SMJ_MESHLET_TRIS / 64; u++) ctt[u] = pt[u];
+    if (alive) { const int n_ = __ffsll((long long)alive) - 1; ML_FETCH(n_) }
     // lane = vertex: camera frame, then the screen (pixel coordinates); a vertex nearer than the near plane keeps its camera x, y
-    for (int j = lane; j < nvert; j += 64) {
-      const float4 v = R.mlvert[vbase + j];
-      const float pv[3] = {v.x, v.y, v.z};
-      float cv[3];
-      mul(cv, rcg, pv);
-      const float cxx = cv[0] + tcg[0], cyy = cv[1] + tcg[1], D = -(cv[2] + tcg[2]);
-      if (D >= dn) {
-        const float inv = frcp(D);
-        X[j] = cxx * inv * sx + 0.5f * width; Y[j] = 0.5f * height - cyy * inv * sy;
-      } else { X[j] = cxx; Y[j] = cyy; }
-      Dp[j] = D;
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+      const int j = lane + 64 * u;
+      if (j < nvert) {
+        const float pvv[3] = {cvv[u].x, cvv[u].y, cvv[u].z};
+        float cv[3];
+        mul(cv, rcg, pvv);
+        const float cxx = cv[0] + tcg[0], cyy = cv[1] + tcg[1], D = -(cv[2] + tcg[2]);
+        if (D >= dn) {
+          const float inv = frcp(D);
+          X[j] = cxx * inv * sx + 0.5f * width; Y[j] = 0.5f * height - cyy * inv * sy;
+        } else { X[j] = cxx; Y[j] = cyy; }
+        Dp[j] = D;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    MLT(11)
+#pragma unroll
     for (int round = 0; round < SMJ_MESHLET_TRIS / 64; round++) {
       if (round * 64 >= ntri) break;                  // uniform
       const int k = round * 64 + lane;
@@ -826,7 +876,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       float qx[4] = {0, 0, 0, 0}, qy[4] = {0, 0, 0, 0}, qd[4] = {1, 1, 1, 1};
       int nsub = 0;
       if (k < ntri) {
-        const unsigned t = R.mltri[tbase + k];
+        const unsigned t = ctt[round];
         const int ia = t & 255, ib = (t >> 8) & 255, ic = (t >> 16) & 255;
         float px[3] = {X[ia], X[ib], X[ic]}, py[3] = {Y[ia], Y[ib], Y[ic]}, pd[3] = {Dp[ia], Dp[ib], Dp[ic]};
         const float dmin = fminf(pd[0], fminf(pd[1], pd[2])), dmax = fmaxf(pd[0], fmaxf(pd[1], pd[2]));
@@ -903,6 +953,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
           }
         }
       }
+      MLC(3, __popcll(__ballot(k < ntri))); MLC(4, __popcll(__ballot(nsub > 0)));
+      MLT(12)
       for (int sub = 0; sub < 2; sub++) {
       if (__ballot(nsub > sub) == 0) break;            // uniform (the second pass: only waves that hold a quadrilateral)
       int u0 = 0, w0 = 0, nu = 0, npx = 0, lost = 0, npx_lost = 0;
@@ -1000,6 +1052,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       const int total = pre[n];
+      MLC(5, n); MLC(6, total);
+      MLT(13)
       for (int pidx = lane; pidx < total; pidx += 64) {
         int lo = 0, hi = n;          // the entry j with pre[j] <= pidx < pre[j + 1]
 #pragma unroll
@@ -1017,13 +1071,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
           const float t = frcp(l0 * E.w[0] + l1 * E.w[1] + l2 * E.w[2]);
           if (t >= tnear) ZMIN(zimg + (long)(E.w0 + row) * width + E.u0 + col, t);   // t > 0: the bit patterns order like the values
         }
+        MLC(7, __popcll(__ballot(l0 >= -2e-5f && l1 >= -2e-5f && l2 >= -2e-5f)));
       }
+      MLT(14)
       __builtin_amdgcn_wave_barrier();   // the queue is rewritten by the next pass
       }
     }
     __builtin_amdgcn_wave_barrier();     // ... and the vertices by the next meshlet
     }
+#undef ML_FETCH
   }
+#ifdef SMJ_MESHLET_STATS
+  mlc[15] = (unsigned long long)(__builtin_readcyclecounter() - mlt0);
+  mlc[9] = 1;
+  if (lane == 0) for (int i = 0; i < 16; i++) atomicAdd(&g_mlstat[i], mlc[i]);
+#endif
 }
 
 __global__ void smj_fill_kernel(float* __restrict__ p, long n, float v) {
@@ -1059,6 +1121,18 @@ void smj_launch_depth(const DevRender& r, const float* xpose, long ld, int num_e
     hipLaunchKernelGGL(smj_meshlet_kernel, dim3(nenv, r.raster_splits), dim3(256), 0, stream, rr, ws, width, height, th, tfar * (1.f + 1e-6f), out, mode == 1 ? 1 : 0);
     hipLaunchKernelGGL((smj_depth_kernel<false, true>), dim3(tiles_r, nenv), dim3(256), 0, stream, rr, ws, width, height, th, md, out, layer, mode,
                        (unsigned char*)nullptr, (int*)nullptr);
+#ifdef SMJ_MESHLET_STATS
+    if (mode != 1) {
+      (void)hipStreamSynchronize(stream);
+      unsigned long long h[16], z[16] = {0};
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mlstat), sizeof(h));
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mlstat), z, sizeof(z));
+      const char* nm[16] = {"groups", "meshlets", "alive", "triangles", "tri_front", "queued", "candidates", "fragments", "-", "waves", "cyc_cull", "cyc_vertex", "cyc_setup", "cyc_queue", "cyc_shade", "cyc_total"};
+      fprintf(stderr, "meshlet stats cam %d, per env:", cam);
+      for (int i = 0; i < 16; i++) if (i != 8) fprintf(stderr, " %s %.1f", nm[i], (double)h[i] / nenv);
+      fprintf(stderr, "\n");
+    }
+#endif
     if (getenv("SMJ_DEPTH_DEBUG")) {   // tools: how many triangles the rasteriser handed over, per env
       (void)hipStreamSynchronize(stream);
       int cnt[64]; double sum = 0; int mx = 0; const int ne = nenv < 64 ? nenv : 64;
