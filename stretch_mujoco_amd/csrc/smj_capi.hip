@@ -29,7 +29,7 @@ struct smj_ctx {
   std::string err;
   float* qpos0_dev = nullptr;
   float* stage = nullptr;      // env-major staging copy of the state, [num_envs][layout.stride] (DevState::stage)
-  int variant = 0;             // 0: standard step kernel, 1: tall, 2 / 3 / 4: big with 38 / 50 / 64 dof columns (smj_model.h)
+  int variant = 0;             // 0: standard step kernel, 1: tall (its 128-row build, three envs per CU), 2 / 3 / 4: big with 38 / 50 / 64 dof columns (smj_model.h)
   // capacity escalation (standard variant): the model once more with the tall variant's records, and the list of parked envs
   DevModel model_esc{};
   bool has_esc = false;
@@ -275,7 +275,10 @@ int smj_create(const void* blob, size_t nbytes, int num_envs, int device, smj_ct
   DeviceUploader up{c};
   SmjCaps caps[5] = {{NVP, NBP, NENT, NEFC, NCON, 0}, {}, {}, {}, {}};   // standard, tall, big38, big50, big (smj_model.h)
   int dbg[5] = {SMJ_DEBUG_FLOATS, 0, 0, 0, 0};
-  smj_tall_caps(&caps[1].nvp, &caps[1].nbp, &caps[1].nent, &caps[1].nefc, &caps[1].ncon, &dbg[1]);
+  SmjCaps tall{};   // the 160-row build: escalation target of the standard variant and of the 128-row build
+  int dbg_tall = 0;
+  smj_tall_caps(&tall.nvp, &tall.nbp, &tall.nent, &tall.nefc, &tall.ncon, &dbg_tall);
+  smj_mid_caps(&caps[1].nvp, &caps[1].nbp, &caps[1].nent, &caps[1].nefc, &caps[1].ncon, &dbg[1]);
   smj_big38_caps(&caps[2].nvp, &caps[2].nbp, &caps[2].nent, &caps[2].nefc, &caps[2].ncon, &dbg[2], &caps[2].nvs);
   smj_big50_caps(&caps[3].nvp, &caps[3].nbp, &caps[3].nent, &caps[3].nefc, &caps[3].ncon, &dbg[3], &caps[3].nvs);
   smj_big_caps(&caps[4].nvp, &caps[4].nbp, &caps[4].nent, &caps[4].nefc, &caps[4].ncon, &dbg[4], &caps[4].nvs);
@@ -284,10 +287,10 @@ int smj_create(const void* blob, size_t nbytes, int num_envs, int device, smj_ct
   c->caps = caps[c->variant];
   c->layout = smj_stage_layout(c->caps.nvp, c->caps.nbp);
   c->debug_floats = dbg[c->variant];
-  if (c->variant == 0 || c->variant == 2 || c->variant == 3) {
-    // escalation target: the same model loaded for the tall variant (standard) / the 64-column big build (38 / 50 columns)
+  if (c->variant <= 3) {
+    // escalation target: the same model loaded for the 160-row tall build (standard, 128-row tall) / the 64-column big build (38 / 50 columns)
     int dummy = 0;
-    rc = smj_load_model(blob, nbytes, c->model_esc, up, c->err, caps + (c->variant == 0 ? 1 : 4), 1, &dummy);
+    rc = smj_load_model(blob, nbytes, c->model_esc, up, c->err, c->variant <= 1 ? &tall : caps + 4, 1, &dummy);
     if (rc) return rc;
     c->has_esc = true;
     void* d = nullptr;
@@ -600,7 +603,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
       lrc = c->variant == 4   ? smj_launch_step_big(c->model, st, k, fl, sm)
             : c->variant == 3 ? smj_launch_step_big50(c->model, st, k, fl, sm)
             : c->variant == 2 ? smj_launch_step_big38(c->model, st, k, fl, sm)
-            : c->variant == 1 ? smj_launch_step_tall(c->model, st, k, fl, sm)
+            : c->variant == 1 ? smj_launch_step_mid(c->model, st, k, fl, sm)
             : st.prof         ? smj_launch_step_prof(c->model, st, k, fl, sm)
                               : smj_launch_step(c->model, st, k, fl, sm);
     if (poll) HIPCHK(c, hipStreamWaitEvent(sm, c->ev_join, 0));
@@ -609,7 +612,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
       // offending step) is finished by the tall variant (160 rows / 48 contacts); an empty list returns at once
       st.redo_worker = 1;
       st.pipe_len = 0;
-      lrc = c->variant == 0 ? smj_launch_step_tall(c->model_esc, st, k, fl, sm) : smj_launch_step_big(c->model_esc, st, k, fl, sm);
+      lrc = c->variant <= 1 ? smj_launch_step_tall(c->model_esc, st, k, fl, sm) : smj_launch_step_big(c->model_esc, st, k, fl, sm);
     }
   }
   if (lrc) return fail(c, -2, "step kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));

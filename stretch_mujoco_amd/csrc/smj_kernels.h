@@ -24,10 +24,12 @@ struct StagePlan {
 int smj_launch_step(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);
 int smj_launch_step_prof(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);   // standard + cycle counters
 int smj_launch_step_tall(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);
+int smj_launch_step_mid(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);      // tall with 128 rows: three envs per CU
 int smj_launch_step_big(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);     // 64 dof columns
 int smj_launch_step_big38(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);   // 38
 int smj_launch_step_big50(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);   // 50
 void smj_tall_caps(int* nvp, int* nbp, int* nent, int* nefc, int* ncon, int* debug_floats);
+void smj_mid_caps(int* nvp, int* nbp, int* nent, int* nefc, int* ncon, int* debug_floats);
 void smj_big_caps(int* nvp, int* nbp, int* nent, int* nefc, int* ncon, int* debug_floats, int* nvs);
 void smj_big38_caps(int* nvp, int* nbp, int* nent, int* nefc, int* ncon, int* debug_floats, int* nvs);
 void smj_big50_caps(int* nvp, int* nbp, int* nent, int* nefc, int* ncon, int* debug_floats, int* nvs);

@@ -25,6 +25,9 @@
 #if SMJ_NVS == 64   // one env per CU anyway: the build that takes over when a 38- / 50-column env runs out of rows / contacts
 #define NEFC 224
 #define NCON 64
+#elif defined(SMJ_BIG_ROWS)   // (capacities chosen per build so that the env's LDS is a whole number of 1280-byte granules a CU holds three of)
+#define NEFC SMJ_BIG_ROWS
+#define NCON SMJ_BIG_CONTACTS
 #else
 #define NEFC 160  // constraint-row capacity: rows 64.. take further passes on lanes 0..63
 #define NCON 48   // contact capacity (<= 64: contact stages are lane = contact)
@@ -32,8 +35,13 @@
 #define NENT 8    // mass-matrix pattern entries per lane (64 lanes)
 #elif defined(SMJ_TALL)
 #define NVP 32
+#ifdef SMJ_TALL_ROWS   // the three-envs-per-CU build of the tall variant (smj_kernels_mid.hip)
+#define NEFC SMJ_TALL_ROWS
+#define NCON SMJ_TALL_CONTACTS
+#else
 #define NEFC 160
 #define NCON 48
+#endif
 #define NENT 5
 #else
 #define NVP 32

@@ -14,6 +14,9 @@
 #if SMJ_NVS == 64   // the escalation target of the 38- / 50-column builds
 #define SMJ_WORKER_KERNEL smj_step_kernel_big_worker
 #endif
+#elif defined(SMJ_TALL) && defined(SMJ_TALL_ROWS)   // the 128-row build: primary kernel only, its steps escalate to the 160-row build
+#define SMJ_STEP_KERNEL smj_step_kernel_mid
+#define SMJ_LAUNCH_STEP smj_launch_step_mid
 #elif defined(SMJ_TALL)
 #define SMJ_STEP_KERNEL smj_step_kernel_tall
 #define SMJ_LAUNCH_STEP smj_launch_step_tall

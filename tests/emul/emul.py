@@ -17,7 +17,7 @@ def lib(variant: str = "standard"):
     big = variant   # cache key
     if big not in _LIB:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
-        L = ctypes.CDLL(os.path.join(_HERE, {"standard": "libsmj_emul.so", "tall": "libsmj_emul_tall.so", "big": "libsmj_emul_big.so", "big38": "libsmj_emul_big38.so", "big50": "libsmj_emul_big50.so", "poison": "libsmj_emul_poison.so"}[variant]))
+        L = ctypes.CDLL(os.path.join(_HERE, {"standard": "libsmj_emul.so", "tall": "libsmj_emul_tall.so", "mid": "libsmj_emul_mid.so", "big": "libsmj_emul_big.so", "big38": "libsmj_emul_big38.so", "big50": "libsmj_emul_big50.so", "poison": "libsmj_emul_poison.so"}[variant]))
         L.emul_create.restype = ctypes.c_void_p
         L.emul_create.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
         L.emul_bind.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_long]
@@ -30,7 +30,9 @@ def lib(variant: str = "standard"):
 
 class Emul:
     def __init__(self, blob: bytes, dims: dict, num_envs: int = 1, debug: bool = True, big: bool | None = None, variant: str | None = None):
-        """variant: "standard" (32 dofs / 80 rows / 16 contacts), "tall" (32 / 160 / 48) or "big" (64 / 160 / 48); default: chosen
+        """variant: "standard" (32 dofs / 80 rows / 16 contacts), "tall" (32 / 160 / 48), "mid" (32 / 128 / 44: the build of the tall
+        variant that smj_create runs as the primary kernel; the emulator has no escalation, so the default stays "tall") or "big"
+        (64 / 160 / 48); default: chosen
         like smj_create does, by the model's size and the blob's capacity hint.  `big=True` is shorthand for variant="big"."""
         if variant is None:
             if big or dims["nv"] > 32:   # the big variant is built for 38 / 50 / 64 dof columns (smj_model.h); big=True with a small model: 64

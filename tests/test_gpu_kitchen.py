@@ -115,6 +115,43 @@ def test_pipelined_chunks_on_the_tall_variant_are_bit_identical():
         sim.stop()
 
 
+def test_three_envs_per_cu_build_hands_over_to_the_160_row_build():
+    """The kitchen stand-in's primary kernel is the 128-row / 44-contact build of the tall variant (53 KB of LDS per env: three
+    envs per CU instead of two); an env whose step needs more is parked and the 160-row build finishes the launch's remaining
+    steps, as for the standard variant.  Forced with `primary_rows` just under the rows of the arm-on-the-counter scenario;
+    state-synchronised against the fp64 oracle: no flag, its row / contact counts, its velocities."""
+    sim = _sim(3)
+    assert sim.nefc_max == 128
+    o = Oracle(sim._blob); o.set_option("solver", 2)
+    ctrl = [0.5, -0.5, 0.9, 0.5, 1.0, -0.5, 0.3, 0.0, 0.2, -0.3]
+    o.arr("ctrl")[:10] = ctrl
+    sim.ctrl[:] = torch.tensor(ctrl, dtype=torch.float32, device=sim.device).unsqueeze(1)
+    o.step(150)
+    limit = max(30, o.nefc - 4)
+    sim.set_option("primary_rows", limit)
+    over, errs = 0, []
+    for k in range(40):
+        for e in range(3):
+            sim.qpos[:, e] = torch.tensor(o.arr("qpos"), dtype=torch.float32, device=sim.device)
+            sim.qvel[:, e] = torch.tensor(o.arr("qvel"), dtype=torch.float32, device=sim.device)
+            sim.qacc_warmstart[:, e] = torch.tensor(o.arr("qacc_warmstart"), dtype=torch.float32, device=sim.device)
+        o.step(1); sim.step(1)
+        torch.cuda.synchronize()
+        assert int(sim.info[3].max()) == 0, k
+        assert torch.equal(sim.qpos[:, 0], sim.qpos[:, 2])
+        over += o.nefc > limit
+        if (int(sim.info[0, 0]), int(sim.info[1, 0])) == (o.nefc, o.ncon):
+            errs.append(np.abs(sim.qvel[:, 0].cpu().numpy() - o.arr("qvel")).max() / max(1.0, np.abs(o.arr("qvel")).max()))
+    assert over >= 25
+    errs = np.sort(np.array(errs))
+    assert len(errs) >= 30 and errs[int(0.8 * len(errs))] < 2e-3 and errs[-1] < 0.3, errs[-8:]
+    sim.set_option("escalate", 0)
+    sim.step(1)
+    torch.cuda.synchronize()
+    assert int(sim.info[3].max()) & 1   # without the hand-over the same step is flagged
+    sim.stop()
+
+
 @pytest.mark.parametrize("scene", ["stretch_scene", "stretch_kitchen4"])
 def test_big_builds_hand_over_to_the_224_row_build(scene):
     """The two-envs-per-CU builds of the big variant (38 / 50 dof columns, 160 rows / 48 contacts) park an env whose step needs

@@ -97,3 +97,26 @@ def test_ball_rests_on_the_counter_and_is_pushed(blob_kitchen):
     assert o.arr("qpos")[27] > -0.3 + 0.02 and abs(e.qpos[27, 0] - o.arr("qpos")[27]) < 2e-3
     assert abs(o.arr("qvel")[30]) > 1.0                           # rolling: spin about y has built up from friction
 
+
+
+def test_three_envs_per_cu_build_equals_the_tall_variant(blob_kitchen):
+    """smj_create runs contact-rich 32-dof scenes on the 128-row / 44-contact build of the tall variant (53 KB of LDS: three envs
+    per CU) and hands steps beyond that to the 160-row build.  Same source, smaller arrays: while a rollout stays inside 128 rows
+    the two builds must produce the same states, bit for bit -- the arm driven into the counter, 120 steps."""
+    from stretch_mujoco_amd import model_blob
+
+    m = model_blob.loads(blob_kitchen)
+    out = {}
+    for variant in ("tall", "mid"):
+        e = Emul(blob_kitchen, DIMS, num_envs=2, variant=variant); e.set_option("solver", 2)
+        e.qpos[:] = np.asarray(m["qpos0"], np.float32)[:, None]
+        e.ctrl[:, 0] = np.array([0.5, -0.5, 0.9, 0.5, 1.0, -0.5, 0.3, 0.0, 0.2, -0.3], np.float32)
+        e.ctrl[:, 1] = np.array([-1.0, 1.0, 0.6, 0.3, -1.0, 0.2, -0.3, 0.02, -0.5, 0.3], np.float32)
+        rows = 0
+        for _ in range(120):
+            e.step(1)
+            rows = max(rows, int(e.info[0].max()))
+        out[variant] = (e.qpos.copy(), e.qvel.copy(), e.info.copy(), rows)
+    assert out["tall"][3] <= 128 and int((out["tall"][2][3] & 3).max()) == 0
+    for k in range(3):
+        assert np.array_equal(out["tall"][k], out["mid"][k])
