@@ -101,6 +101,8 @@ int smj_base_controller_tick(smj_ctx* ctx, void* stream);
  * rows and hand it back -- they leave at once unless one of the last 8 calls had such envs; -n: n pollers that always stay; 0 = such envs are
  * finished after the standard kernel), "pipeline_big" (the same chunking for the 38- / 50-column variants),
  * "primary_rows" (0 = the variant's own limit; tests lower it to force hand-overs to the larger variant),
+ * "sep_cache" (default 1: a convex pair found disjoint keeps the separating direction and tests it first on the next steps --
+ * a proof of disjointness whatever the entry holds, so results do not depend on the option),
  * "depth_raster" (default 1: smj_render_depth draws meshes and boxes with the meshlet rasteriser and resolves the remaining
  * primitives per pixel; 0: per-pixel ray cast of every geom through the mesh BVHs -- the same image up to fp32 rounding at
  * silhouette pixels), "depth_raster_splits" (default 8: workgroups per env of the rasteriser). */

@@ -87,7 +87,7 @@ def test_depth_sees_the_fixtures():
 
 
 def test_pipelined_chunks_on_the_tall_variant_are_bit_identical():
-    """The kitchen stand-in runs the tall variant as its primary kernel; its launches are pipelined in chunks of 10 steps
+    """The kitchen stand-in runs the tall variant as its primary kernel; its launches are pipelined in chunks of 8 steps
     (smj_step, DevState::pipe_len).  Scheduling only: 2048 envs under random actions, 2 x 37 steps -- every state word and the
     sensor readouts equal those of the one-workgroup-per-env launch."""
     from stretch_mujoco_amd import StretchSensors

@@ -151,7 +151,7 @@ def main():
     render_summary(out)
     for sub, title in (("strace", "the reference's own scene (`tools/gpu_options_probe.py scene=stretch_scene`: table + 2 free objects, 38 dofs; `smj_step_kernel_big38`, two envs per CU, escalation target `smj_step_kernel_big_worker`)"),
                        ("k4trace", "kitchen with four free objects (`scene=stretch_kitchen4`, 50 dofs; `smj_step_kernel_big50`, two envs per CU)"),
-                       ("ktrace", "kitchen stand-in (`tools/gpu_options_probe.py scene=stretch_kitchen_standin`: 300 settle steps, 14 random-action launches of 50 steps; the tall variant is the primary kernel)"),
+                       ("ktrace", "kitchen stand-in (`tools/gpu_options_probe.py scene=stretch_kitchen_standin`: 300 settle steps, 14 random-action launches of 50 steps; primary kernel `smj_step_kernel_mid`: the 128-row build of the tall variant, three envs per CU)"),
                        ("ptrace", "PGS (`tools/gpu_options_probe.py solver=0`, empty scene, same schedule)")):
         path = os.path.join(SRC, sub, "smj_kernel_stats.csv")
         if not os.path.exists(path):
