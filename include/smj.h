@@ -89,7 +89,9 @@ int smj_step(smj_ctx* ctx, int nsteps, unsigned read_flags, void* stream);
  * of the reference's controller on scripted poses). */
 int smj_base_controller_tick(smj_ctx* ctx, void* stream);
 
-/* Solver / collision options (mjOption fields): "iterations", "tolerance", "warmstart", "pgs_fixed_iter",
+/* Solver / collision options (mjOption fields): "iterations", "tolerance", "warmstart", "pgs_fixed_iter", "qcqp_exact" (PGS, default 0:
+ * the friction QCQP of an elliptic contact finds mju_QCQP's root through the secular form, started at the contact's multiplier of
+ * the previous sweep; 1: mju_QCQP's own iteration from 0, cap 20 -- the two differ where that cap is hit),
  * "max_contacts_per_pair", "solver" (0 PGS, 2 Newton), "convex_pairs", "multiccd" (mjENBL_MULTICCD, stretch.xml:8; default on), "escalate" (default on: an env whose step needs more constraint rows / contacts
  * than the standard kernel variant holds is finished by the tall variant instead of being flagged), "balance" (default on:
  * workgroups are dispatched in the order of the envs' shader time in the previous dispatch, longest first), "chunk" (default 0 = one dispatch; k > 0:

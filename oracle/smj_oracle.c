@@ -188,11 +188,14 @@ smjo_model* smjo_load(const void* blob, size_t nbytes) {
 
 void smjo_free_model(smjo_model* m) { free(m); /* arrays leak by design: test process lifetime */ }
 
+static int g_qcqp_cap = 20;   /* see qcqp() */
+
 int smjo_set_option(smjo_model* m, const char* name, double v) {
   if (!strcmp(name, "iterations")) m->iterations = (int)v;
   else if (!strcmp(name, "tolerance")) m->tolerance = v;
   else if (!strcmp(name, "warmstart")) m->warmstart = (int)v;
   else if (!strcmp(name, "pgs_fixed_iter")) m->pgs_fixed_iter = (int)v;
+  else if (!strcmp(name, "qcqp_cap")) g_qcqp_cap = (int)v;
   else if (!strcmp(name, "max_contacts_per_pair")) m->max_con_pair = (int)v;
   else if (!strcmp(name, "solver")) m->solver = (int)v; /* 0 = PGS (north_star), 2 = Newton (the reference model's default) */
   else if (!strcmp(name, "convex_pairs")) m->convex_pairs = (int)v;
@@ -1548,13 +1551,15 @@ static void fwd_actuation(const smjo_model* m, smjo_data* d) {
 }
 
 /* ------------------------------------------------------------------ B.7 solver (PGS, dual) */
+/* [MJ] mju_QCQP: Newton on the multiplier from la = 0, at most 20 iterates.  g_qcqp_cap (option "qcqp_cap", default 20 = MuJoCo)
+ * lifts that cap for one purpose: tests of the HIP path's default QCQP, which finds the converged root (smj_step_impl.h qcqp). */
 static int qcqp(double* res, const double* Ain, const double* bin, const double* dd, double r, int n) {
   double A[25], b[5], Ala[25], tmp[5], la = 0;
   for (int i = 0; i < n; i++) {
     b[i] = bin[i] * dd[i];
     for (int j = 0; j < n; j++) A[i * n + j] = Ain[i * n + j] * dd[i] * dd[j];
   }
-  for (int it = 0; it < 20; it++) {
+  for (int it = 0; it < g_qcqp_cap; it++) {
     memcpy(Ala, A, sizeof(double) * n * n);
     for (int i = 0; i < n; i++) Ala[i * n + i] += la;
     if (n == 2) { /* [MJ] mju_QCQP2: determinant test */

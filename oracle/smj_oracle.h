@@ -38,7 +38,7 @@ void smjo_step(const smjo_model* m, smjo_data* d);           /* mj_step (implici
 void smjo_step_n(const smjo_model* m, smjo_data* d, int n);
 void smjo_sensors(const smjo_model* m, smjo_data* d, int with_lidar); /* gyro, accel, lidar into d */
 
-/* options: name in {"iterations","tolerance","warmstart","pgs_fixed_iter","max_contacts_per_pair"} */
+/* options: name in {"iterations","tolerance","warmstart","pgs_fixed_iter","max_contacts_per_pair", "qcqp_cap" (process-wide; 20 = MuJoCo)} */
 int smjo_set_option(smjo_model* m, const char* name, double value);
 
 /* array access for tests: returns pointer (double*) or NULL; *n receives element count.

@@ -533,7 +533,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
   if (esc) {   // the escalation target runs with the same options
     DevModel& mb = c->model_esc;
     const DevModel& ms = c->model;
-    mb.iterations = ms.iterations; mb.warmstart = ms.warmstart; mb.pgs_fixed_iter = ms.pgs_fixed_iter; mb.max_con_pair = ms.max_con_pair;
+    mb.iterations = ms.iterations; mb.warmstart = ms.warmstart; mb.pgs_fixed_iter = ms.pgs_fixed_iter; mb.qcqp_exact = ms.qcqp_exact; mb.max_con_pair = ms.max_con_pair;
     mb.solver = ms.solver; mb.ls_iterations = ms.ls_iterations; mb.convex_pairs = ms.convex_pairs; mb.multiccd = ms.multiccd; mb.multi_serial = ms.multi_serial; mb.sep_cache = ms.sep_cache;
     mb.ls_tolerance = ms.ls_tolerance; mb.tolerance = ms.tolerance;
   }
@@ -701,6 +701,7 @@ int smj_set_option(smj_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "tolerance")) m.tolerance = (float)v;
   else if (!strcmp(name, "warmstart")) m.warmstart = (int)v;
   else if (!strcmp(name, "pgs_fixed_iter")) m.pgs_fixed_iter = (int)v;
+  else if (!strcmp(name, "qcqp_exact")) m.qcqp_exact = (int)v;
   else if (!strcmp(name, "max_contacts_per_pair")) m.max_con_pair = (int)v;
   else if (!strcmp(name, "solver")) m.solver = (int)v;
   else if (!strcmp(name, "convex_pairs")) m.convex_pairs = (int)v;

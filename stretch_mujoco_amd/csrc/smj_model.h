@@ -85,6 +85,7 @@ struct DevModel {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, neq, npair, nlevel, nfric, nlimit, nplanepair, nldl, nlidar, imu_site,
       ngc, nroot, nkey, ncgeom, nconvpair, njump, maxsubtree;
   int iterations, warmstart, pgs_fixed_iter, max_con_pair, solver /* 0 PGS, 2 Newton */, ls_iterations, convex_pairs;
+  int qcqp_exact;   // PGS: 1 = the friction QCQP iterates exactly as mju_QCQP does (from la = 0 on |x|^2 - r^2, cap 20); 0 (default) = same root, secular form, started at the last sweep's multiplier
   int sep_cache;      // 1 = use DevState::sepcache (separating directions of convex pairs kept between steps)
   int multi_serial;   // lane emulator only: 1 = the four multiccd queries of a pair one after the other (convex_multi), the comparator of convex_multi4
   int row_limit;  // > 0: the primary variant hands an env over to the escalation variant beyond this many constraint rows (tests; option "primary_rows")

@@ -121,20 +121,37 @@ __device__ __forceinline__ void mfma16x16x4(PL<F4v>& acc, const PL<float>& a, co
 #endif
 
 // ---------------------------------------------------------------------------------------------- QCQP (uniform)
-// min 0.5 x'Ax + x'b  s.t. sum (x_i/d_i)^2 <= r^2   [MJ] mju_QCQP2 / mju_QCQP3 / mju_QCQP: Newton iteration on the
-// multiplier la with a Cholesky factor of (A + la I) per iterate (rank test 1e-10).  Returns 1 if the constraint
-// is active.  Reciprocal-based factor/solves: no IEEE divides on the serial path.
+// min 0.5 x'Ax + x'b  s.t. sum (x_i/d_i)^2 <= r^2   [MJ] mju_QCQP2 / mju_QCQP3 / mju_QCQP: the multiplier la >= 0 with
+// |x(la)| = r, x(la) = -(A + la I)^-1 b (scaled variables), by a Newton iteration with a Cholesky factor of (A + la I) per
+// iterate (rank test 1e-10).  Returns 1 if the constraint is active.  Reciprocal-based factor / solves: no IEEE divides on the
+// serial path; x'(A + la I)^-1 x = |L^-1 x|^2 takes one forward substitution, not a second full solve.
+//  exact = true (option qcqp_exact): MuJoCo's iteration -- from la = 0 on val(la) = |x|^2 - r^2, stops at val < 1e-10,
+//    delta < 1e-10 or after 20 iterates.  From la = 0 that iteration grows (A + la I) by at most 1.5x per step when the
+//    unconstrained minimum lies far outside the cone (rolling / torsional friction of a driven wheel): 9.6 iterations per call on
+//    the bench workload, 3 % of the active calls end at the cap -- 2/3 of the PGS path's time.
+//  exact = false (default): the SAME root, found faster.  (a) The secular form 1 / |x(la)| - 1 / r (Hebden / More-Sorensen) is
+//    concave and nearly linear in la: its Newton step is MuJoCo's times 2 |x|^2 / (r (|x| + r)) -- equal at the root, larger far
+//    from it -- and lands left of the root from either side (20 000 random spectra: no overshoot), so a clamp at la = 0 is the
+//    only safeguard.  (b) The iteration starts at the multiplier the contact's block had in the PREVIOUS SWEEP (la_io; 0 in the
+//    first sweep of a step): 1.8 iterations per call.  (c) fp32 tolerances: val carries the rounding of the solve
+//    (1e-7 r^2 times the condition number), a step of la matters relative to la + min A_ii; both tests get a relative part of
+//    1e-5 (the caller rescales an active solution onto the cone anyway).  Where MuJoCo's iteration converges the two agree to
+//    that tolerance; where it ends at its cap MuJoCo returns the direction of an unconverged x, this returns the root's.
 template <int N>
-SMJ_DEV int qcqp(float* res, const float* Ain, const float* bin, const float* dd, float r) {
-  float A[N * N], b[N], L[N * N], Li[N], tmp[N], la = 0;
+SMJ_DEV int qcqp(float* res, const float* Ain, const float* bin, const float* dd, float r, float& la_io, bool exact, float* iters = nullptr) {
+  float A[N * N], b[N], L[N * N], Li[N], la = exact ? 0.f : la_io;
 #pragma unroll
   for (int i = 0; i < N; i++) {
     b[i] = bin[i] * dd[i];
 #pragma unroll
     for (int j = 0; j <= i; j++) A[i * N + j] = Ain[i * N + j] * dd[i] * dd[j];
   }
-  const float r2 = r * r;
+  float dmin = A[0];
+#pragma unroll
+  for (int i = 1; i < N; i++) dmin = fminf(dmin, A[i * N + i]);
+  const float r2 = r * r, vtol = exact ? 1e-10f : 1e-10f + 1e-5f * r2, dtol = exact ? 1e-10f : 1e-10f + 1e-5f * dmin, drel = exact ? 0.f : 1e-5f;   // a step below 1e-5 (la + min A_ii) moves x by less than that, relatively
   for (int it = 0; it < 20; it++) {
+    if (iters) *iters += 1.f;
     bool bad = false;
 #pragma unroll
     for (int j = 0; j < N; j++) {
@@ -157,46 +174,50 @@ SMJ_DEV int qcqp(float* res, const float* Ain, const float* bin, const float* dd
       for (int i = 0; i < N; i++) res[i] = 0;
       return 0;
     }
-    // res = -(A+la)^-1 b ; tmp = (A+la)^-1 res
+    // res = -(A + la)^-1 b
+    float x[N], nn = 0;
 #pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-      float x[N];
+    for (int i = 0; i < N; i++) {
+      float sv = -b[i];
 #pragma unroll
-      for (int i = 0; i < N; i++) {
-        float sv = pass == 0 ? -b[i] : res[i];
-#pragma unroll
-        for (int k = 0; k < i; k++) sv -= L[i * N + k] * x[k];
-        x[i] = sv * Li[i];
-      }
-#pragma unroll
-      for (int i = N - 1; i >= 0; i--) {
-        float sv = x[i];
-#pragma unroll
-        for (int k = i + 1; k < N; k++) sv -= L[k * N + i] * x[k];
-        x[i] = sv * Li[i];
-      }
-#pragma unroll
-      for (int i = 0; i < N; i++) {
-        if (pass == 0) res[i] = x[i];
-        else tmp[i] = x[i];
-      }
-      if (pass == 0) {
-        float val = -r2;
-#pragma unroll
-        for (int i = 0; i < N; i++) val += res[i] * res[i];
-        if (val < 1e-10f) { it = 100; break; }  // converged, or the unconstrained minimum is inside the cone
-      }
+      for (int k = 0; k < i; k++) sv -= L[i * N + k] * x[k];
+      x[i] = sv * Li[i];
     }
-    if (it >= 100) break;
-    float val = -r2, deriv = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) { val += res[i] * res[i]; deriv -= 2 * res[i] * tmp[i]; }
-    const float delta = -val * fast_rcp(deriv);
-    if (delta < 1e-10f) break;
-    la += delta;
+    for (int i = N - 1; i >= 0; i--) {
+      float sv = x[i];
+#pragma unroll
+      for (int k = i + 1; k < N; k++) sv -= L[k * N + i] * x[k];
+      x[i] = sv * Li[i];
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) { res[i] = x[i]; nn += x[i] * x[i]; }
+    const float val = nn - r2;
+    if (val < vtol && (exact || la == 0.f || val > -vtol)) break;  // converged, or (la = 0) the unconstrained minimum is inside the cone
+    // q = res'(A + la)^-1 res = |L^-1 res|^2
+    float q = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      float sv = res[i];
+#pragma unroll
+      for (int k = 0; k < i; k++) sv -= L[i * N + k] * x[k];
+      x[i] = sv * Li[i];
+      q += x[i] * x[i];
+    }
+    float delta;
+    if (exact) {   // [MJ] delta = -val / deriv, deriv = -2 x'(A + la)^-1 x
+      delta = val * fast_rcp(2.f * q);
+      if (delta < dtol) break;
+    } else {
+      const float nrm = nn * fast_rsqrt(nn);
+      delta = (nrm - r) * nn * fast_rcp(r * q);
+      if (fabsf(delta) < dtol + drel * la) break;
+    }
+    la = fmaxf(0.f, la + delta);
   }
 #pragma unroll
   for (int i = 0; i < N; i++) res[i] *= dd[i];
+  la_io = la;
   return la != 0;
 }
 
@@ -230,7 +251,9 @@ struct StepKernel {
   PL<float[6]> cdof, cdof_dot;          // lane = dof
   PL<float> qvel_r, g_r, qacc_r;
   PL<float> f_r[NPS], r_r[NPS], ARinv_r[NPS];   // lane = row (PGS), one register set per 64 rows
+  PL<float> qla_r;                              // lane = contact (PGS): the QCQP multiplier of the contact's last sweep, the next sweep's starting point
   int nefc, ncon, niter, flags;
+  float* ppc = nullptr;  // profiling builds: the launch's counter array while the PGS sweeps run (pgs_block's QCQP time / iterations)
   int step_base = 0;     // steps of this launch that earlier chunks of the env already ran (pipelined chunks, DevState::pipe_len)
   int pipe_chunk = 0;    // the chunk this workgroup runs
   bool parked = false;   // run() handed the env to the escalation list
@@ -2862,11 +2885,14 @@ struct StepKernel {
       aii_r[p][lane] = aii; ARinv_r[p][lane] = 1.0f / aii;
       fl_r[p][lane] = row < ne ? s.efloss[row] : 0.f;
     }
+    LANES { qla_r[lane] = 0.f; }
     const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
     int iter = 0;
     for (; iter < M.iterations; iter++) {
       float improvement = 0;
       if (iter > 0 && (iter & 7) == 0) residual_refresh<WIDE>(bb);
+      ppc = prof ? pc : nullptr;
+      long long tp = prof ? smj_clock() : 0;   // profiling builds: cycles in scalar rows / elliptic blocks (the Newton slots are free under PGS)
       for (int i = 0; i < ne;) {
         const int t = prow<NP>(type_r, i);
         if (t != CT_CONTACT_ELLIPTIC) {
@@ -2886,12 +2912,14 @@ struct StepKernel {
             if (lane + 64 * p == i) f_r[p][lane] += delta;
           }
           i += 1;
+          if (prof) { const long long t1 = smj_clock(); pc[SMJ_PROF_N_UPDATE] += (float)(t1 - tp); tp = t1; pc[SMJ_PROF_N_FACTSOLVE] += 1.f; }
         } else {
           const int dc = prow<NP>(dimc_r, i), dim = dc & 255, c = dc >> 8;
           if (dim == 3) improvement += pgs_block<3, WIDE>(i, c);
           else if (dim == 4) improvement += pgs_block<4, WIDE>(i, c);
           else improvement += pgs_block<6, WIDE>(i, c);
           i += dim;
+          if (prof) { const long long t1 = smj_clock(); pc[SMJ_PROF_N_GRAD] += (float)(t1 - tp); tp = t1; pc[SMJ_PROF_N_SOLVE] += 1.f; }
         }
       }
       improvement *= scale;
@@ -3008,7 +3036,11 @@ struct StepKernel {
 #pragma unroll
       for (int j = 1; j < DIM; j++) f[j] = 0;
     } else {
-      const int active = qcqp<DIM - 1>(v, Ac, bc, mu, f[0]);
+      const long long tq = (SMJ_PROFILING && ppc) ? smj_clock() : 0;
+      float la = wave_read(qla_r, c);
+      const int active = qcqp<DIM - 1>(v, Ac, bc, mu, f[0], la, M.qcqp_exact != 0, (SMJ_PROFILING && ppc) ? &ppc[SMJ_PROF_N_HMFMA] : nullptr);
+      LANES { if (lane == c) qla_r[lane] = la; }
+      if (SMJ_PROFILING && ppc) ppc[SMJ_PROF_N_XA] += (float)(smj_clock() - tq);
       if (active) {
         float sc = 0;
 #pragma unroll

@@ -89,6 +89,7 @@ int emul_set_option(emul_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "tolerance")) m.tolerance = (float)v;
   else if (!strcmp(name, "warmstart")) m.warmstart = (int)v;
   else if (!strcmp(name, "pgs_fixed_iter")) m.pgs_fixed_iter = (int)v;
+  else if (!strcmp(name, "qcqp_exact")) m.qcqp_exact = (int)v;
   else if (!strcmp(name, "max_contacts_per_pair")) m.max_con_pair = (int)v;
   else if (!strcmp(name, "solver")) m.solver = (int)v;
   else if (!strcmp(name, "convex_pairs")) m.convex_pairs = (int)v;

@@ -406,6 +406,7 @@ def test_pgs_rows_beyond_one_wavefront(blob_fused):
     o.arr("ctrl")[:10] = ctrl
     e = Emul(blob_fused, DIMS, num_envs=1, variant="tall")
     e.set_option("solver", 0)
+    e.set_option("qcqp_exact", 1)   # mju_QCQP's own iteration: in this scenario it ends at its cap of 20, which is part of the oracle's path
     e.ctrl[:, 0] = np.asarray(ctrl, np.float32)
     wide = 0
     for k in range(40):
@@ -429,8 +430,71 @@ def test_pgs_launch_crossing_64_rows(blob_fused):
     o.step(29)
     e = Emul(blob_fused, DIMS, num_envs=1, variant="tall")
     e.set_option("solver", 0)
+    e.set_option("qcqp_exact", 1)
     e.ctrl[:, 0] = np.asarray(ctrl, np.float32)
     e.qpos[:, 0] = o.arr("qpos"); e.qvel[:, 0] = o.arr("qvel"); e.warm[:, 0] = o.arr("qacc_warmstart")
     o.step(8); e.step(8)
     assert int(e.info[3, 0]) == 0 and int(e.info[0, 0]) == o.nefc > 64
     assert np.abs(e.qvel[:, 0] - o.arr("qvel")).max() < 5e-2 and np.abs(e.qpos[:, 0] - o.arr("qpos")).max() < 1e-3
+
+
+def test_pgs_qcqp_root_finder_agrees_with_mujocos_iteration(blob_fused):
+    """The PGS path's default friction QCQP (secular form, started at the contact's multiplier of the previous sweep:
+    smj_step_impl.h qcqp) finds the root mju_QCQP iterates towards; option qcqp_exact = 1 runs MuJoCo's own iteration (from 0,
+    cap 20).  Bench workload (random ctrl in ctrlrange), the fast build's state re-synchronised to the exact one's before every
+    step: the one-step velocities agree at fp32 level on nearly every step (they differ where MuJoCo's iteration ends at its
+    cap, and where the two stop on different sweeps), and both stay on the fp64 oracle's rollout from a settled start."""
+    import stretch_mujoco_amd.model_blob as mb
+
+    cr = np.asarray(mb.loads(blob_fused)["actuator_ctrlrange"])
+    lo, hi = cr[:, 0], cr[:, 1]
+    B = 4
+    es = []
+    for exact in (0, 1):
+        e = Emul(blob_fused, DIMS, num_envs=B)
+        e.set_option("solver", 0); e.set_option("qcqp_exact", exact)
+        e.qpos[:] = home_qpos(Oracle(blob_fused).arr("qpos"))[:, None]
+        e.ctrl[:] = np.asarray(HOME_CTRL, np.float32)[:, None]
+        e.step(150)
+        es.append(e)
+    assert np.abs(es[0].qpos - es[1].qpos).max() < 1e-5   # settled: the contacts stick, one QCQP iterate either way
+    rng = np.random.default_rng(7)
+    diffs = []
+    for _ in range(2):
+        c = (lo[:, None] + (hi - lo)[:, None] * rng.random((10, B))).astype(np.float32)
+        for _ in range(40):
+            es[0].qpos[:] = es[1].qpos; es[0].qvel[:] = es[1].qvel; es[0].warm[:] = es[1].warm
+            for e in es:
+                e.ctrl[:] = c
+                e.step(1)
+            diffs.append(np.abs(es[0].qvel - es[1].qvel).max(0))
+    diffs = np.concatenate(diffs)
+    assert int(es[0].info[3].max()) == 0 and int(es[1].info[3].max()) == 0
+    assert np.median(diffs) < 2e-5 and np.mean(diffs > 2e-4) < 0.1 and diffs.max() < 2e-2, (np.median(diffs), np.mean(diffs > 2e-4), diffs.max())
+
+
+def test_pgs_default_qcqp_carries_wide_rows(blob_fused):
+    """The deep-penetration scenario of test_pgs_rows_beyond_one_wavefront with the default QCQP, against the oracle with
+    mju_QCQP's cap of 20 iterates lifted (option qcqp_cap: the converged root, which is what the default finds): same rows and
+    contacts, no flag; both PGS runs end at their 100-sweep cap there, so the velocities agree to what an unconverged sweep
+    leaves (state-synchronised, |v| ~ 10-30 rad/s)."""
+    ctrl = [0, 0, 0.0, 0.3, 0, -1.57, 0, 0, 0, 0]
+    o = Oracle(blob_fused)
+    try:
+        o.set_option("solver", 0); o.set_option("qcqp_cap", 1000); o.reset()
+        o.arr("ctrl")[:10] = ctrl
+        e = Emul(blob_fused, DIMS, num_envs=1, variant="tall")
+        e.set_option("solver", 0)
+        e.ctrl[:, 0] = np.asarray(ctrl, np.float32)
+        wide = 0
+        for k in range(30):
+            e.qpos[:, 0] = o.arr("qpos"); e.qvel[:, 0] = o.arr("qvel"); e.warm[:, 0] = o.arr("qacc_warmstart")
+            o.step(1); e.step(1)
+            assert int(e.info[3, 0]) == 0, k
+            if o.nefc > 64:
+                assert (int(e.info[0, 0]), int(e.info[1, 0])) == (o.nefc, o.ncon), k
+                assert np.abs(e.qvel[:, 0] - o.arr("qvel")).max() < 0.15, k
+                wide += 1
+        assert wide >= 6
+    finally:
+        o.set_option("qcqp_cap", 20)   # process-wide in the oracle library

@@ -315,6 +315,7 @@ def test_pgs_carries_every_row_and_escalates_like_newton():
     o.set_option("solver", 0); o.reset()
     o.arr("ctrl")[:10] = ctrl
     sim = _sim(2, solver="pgs")
+    sim.set_option("qcqp_exact", 1)   # mju_QCQP's own iteration: its cap of 20 iterates is part of the oracle's path in this scenario
     sim.ctrl[:] = torch.tensor(HOME_CTRL, dtype=torch.float32, device=sim.device).unsqueeze(1)
     sim.ctrl[:, 0] = torch.tensor(ctrl, dtype=torch.float32, device=sim.device)
     wide = 0
@@ -332,6 +333,40 @@ def test_pgs_carries_every_row_and_escalates_like_newton():
             wide += 1
     assert wide >= 6 and torch.isfinite(sim.qpos).all()
     sim.stop()
+
+
+def test_pgs_qcqp_root_finder_agrees_with_mujocos_iteration():
+    """Default friction QCQP of the PGS path (secular form, started at the previous sweep's multiplier) against option
+    qcqp_exact = 1 (mju_QCQP's iteration from 0, cap 20) on the device: bench workload, 64 envs, the default build's state
+    re-synchronised to the exact one's before every step -- same protocol and bounds as tests/test_emul_parity.py."""
+    sims = []
+    for exact in (0, 1):
+        sim = _sim(64, solver="pgs")
+        sim.set_option("qcqp_exact", exact)
+        _set_ctrl(sim, HOME_CTRL)
+        sim.qpos[:] = torch.tensor(home_qpos(Oracle(sim._blob).arr("qpos")), dtype=torch.float32, device=sim.device).unsqueeze(1)
+        sim.step(150)
+        sims.append(sim)
+    torch.cuda.synchronize()
+    assert float((sims[0].qpos - sims[1].qpos).abs().max()) < 1e-5
+    dev = sims[0].device
+    lo = torch.tensor(sims[0].model["actuator_ctrlrange"][:, 0], dtype=torch.float32, device=dev).unsqueeze(1)
+    hi = torch.tensor(sims[0].model["actuator_ctrlrange"][:, 1], dtype=torch.float32, device=dev).unsqueeze(1)
+    g = torch.Generator(device=dev).manual_seed(7)
+    diffs = []
+    for _ in range(2):
+        c = lo + (hi - lo) * torch.rand(10, 64, generator=g, device=dev)
+        for _ in range(40):
+            sims[0].qpos.copy_(sims[1].qpos); sims[0].qvel.copy_(sims[1].qvel); sims[0].qacc_warmstart.copy_(sims[1].qacc_warmstart)
+            for sim in sims:
+                sim.ctrl.copy_(c)
+                sim.step(1)
+            diffs.append((sims[0].qvel - sims[1].qvel).abs().max(0).values.cpu().numpy())
+    diffs = np.concatenate(diffs)
+    assert int(sims[0].info[3].max()) == 0 and int(sims[1].info[3].max()) == 0
+    assert np.median(diffs) < 2e-5 and np.mean(diffs > 2e-4) < 0.1 and diffs.max() < 5e-2, (np.median(diffs), np.mean(diffs > 2e-4), diffs.max())
+    for sim in sims:
+        sim.stop()
 
 
 @pytest.mark.parametrize("B,solver", [(1024, "pgs"), (4096, "newton"), (32768, "newton")])
