@@ -119,13 +119,13 @@ def other_configs(B, dev, hold, solver):
 
     res = {}
 
-    def rollout(sim, n, chunk):
+    def rollout(sim, n, chunk, settle=500, preroll=4):
         gen = torch.Generator(device=dev).manual_seed(99)
         lo = torch.tensor(sim.model["actuator_ctrlrange"][:, 0], dtype=torch.float32, device=dev).unsqueeze(1)
         hi = torch.tensor(sim.model["actuator_ctrlrange"][:, 1], dtype=torch.float32, device=dev).unsqueeze(1)
         sim.ctrl[:] = torch.tensor(sim.model["key_ctrl"][0, : sim.nu], dtype=torch.float32, device=dev).unsqueeze(1)
-        sim.step(500)
-        for _ in range(4):   # into the steady state of the random-action rollout
+        sim.step(settle)
+        for _ in range(preroll):   # into the steady state of the random-action rollout
             sim.ctrl.copy_(lo + (hi - lo) * torch.rand(sim.nu, sim.num_envs, generator=gen, device=dev))
             sim.step(hold)
         torch.cuda.synchronize(dev)
@@ -171,6 +171,16 @@ def other_configs(B, dev, hold, solver):
         sim.start(home=False)
         res[scene + "_physics"] = {"value": rollout(sim, 200, hold), "unit": "env-steps/s", **flags_of(sim)}
         sim.stop()
+    # config 4 as north_star words it ("contact-rich PGS solve"): the same scenes under PGS.  The sweeps are serial over the rows
+    # (100 sweeps x ~100 rows at one wavefront per env), so this is the slowest path of the library; Newton is the model's own solver.
+    if solver != "pgs":
+        for scene, n in (("stretch_kitchen_standin", 100), ("stretch_kitchen4", 50)):
+            if not os.path.exists(os.path.join(ROOT, "stretch_mujoco_amd", "models", scene + ".smjb")):
+                continue
+            sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver="pgs", scene=scene)
+            sim.start(home=False)
+            res[scene + "_physics_pgs"] = {"value": rollout(sim, n, hold, settle=200, preroll=1), "unit": "env-steps/s", **flags_of(sim)}
+            sim.stop()
     # config 5 ingredient: both depth cameras, kitchen stand-in, rendered from the poses of the last step
     sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver=solver, scene="stretch_kitchen_standin",
                                 cameras_to_use=StretchCameras.depth())

@@ -88,6 +88,7 @@ struct DevModel {
   int qcqp_exact;   // PGS: 1 = the friction QCQP iterates exactly as mju_QCQP does (from la = 0 on |x|^2 - r^2, cap 20); 0 (default) = same root, secular form, started at the last sweep's multiplier
   int sep_cache;      // 1 = use DevState::sepcache (separating directions of convex pairs kept between steps)
   int multi_serial;   // lane emulator only: 1 = the four multiccd queries of a pair one after the other (convex_multi), the comparator of convex_multi4
+  int pgs_cap;    // > 0 (set per launch, smj_step_tu.h): a PGS step of this launch holds at most this many rows -- its packed A then starts at row pgs_cap of J and ends inside the struct (no dynamic LDS); a step with more rows goes to the escalation variant
   int row_limit;  // > 0: the primary variant hands an env over to the escalation variant beyond this many constraint rows (tests; option "primary_rows")
   int multiccd;   // stretch.xml:8 <flag multiccd="enable"/>: multi-point contacts for convex pairs (box-box polygon, counter-rotated queries)
   float ls_tolerance;

@@ -80,7 +80,7 @@ struct Smem {
       float rxf[15][NEFC > 64 ? NEFC - 64 : 1];
     } n;
   } u;
-  SMJ_DEV float* A() { return reinterpret_cast<float*>(&u); }   // PGS: A = Y D^-1 Y' + R as a packed lower triangle, NEFC_P (NEFC_P + 1) / 2 floats
+  SMJ_DEV float* A(int cap) { return &J[cap][0]; }   // PGS: A = Y D^-1 Y' + R as a packed lower triangle of cap (cap + 1) / 2 floats behind the rows a step may use (cap = NEFC_P: the union's start)
 };
 // Row passes of the Newton path: rows 0..63 on lanes 0..63 (rb = 0), then rows 64..NEFC-1 on lanes 0..NEFC-65 (rb = 64), the
 // second pass only for an env that has that many rows (wave-uniform test).
@@ -91,6 +91,17 @@ struct Smem {
 #define ROWS_BEGIN(rb, ne) ROWPASS(rb, ne) { NRow nrx_; if (rb != 0) rx_load(nrx_, rb); NRow& nr = (rb != 0) ? nrx_ : nr0; (void)nr;
 #define ROWS_END_RW(rb) if (rb != 0) rx_store(nrx_, rb); }
 #define ROWS_END_RO() }
+// PGS without dynamic LDS: the largest row count (a multiple of 16: the MFMA tiles of A's build must not read rows of J that A
+// has taken) whose packed A, placed behind that many rows of J, ends inside the struct -- 80 rows for the standard variant (all
+// it has), 96 for the 128-row tall build and big38, 112 for big50.  A launch whose steps are capped there (DevModel::pgs_cap)
+// runs at the variant's Newton occupancy (3 / 2 envs per CU instead of 1); steps beyond it go to the escalation variant.
+static inline int smj_pgs_rows_static() {
+  const size_t a_sq = offsetof(Smem, J) + sizeof(float) * (NEFP * JS + NEFP * NEFP);
+  if (a_sq > sizeof(Smem)) return 0;
+  for (int n = NEFC_P & ~15; n > NEFP; n -= 16)
+    if (offsetof(Smem, J) + sizeof(float) * ((size_t)n * JS + (size_t)n * (n + 1) / 2) <= sizeof(Smem)) return n;
+  return 0;
+}
 static inline size_t smj_lds_bytes(bool pgs) {
   const size_t a_wide = offsetof(Smem, u) + sizeof(float) * (NEFC_P * (NEFC_P + 1) / 2);      // packed triangle in the union
   const size_t a_sq = offsetof(Smem, J) + sizeof(float) * (NEFP * JS + NEFP * NEFP);           // 64 x 64 square from row 64 of J
@@ -2509,7 +2520,7 @@ struct StepKernel {
       }
     }
     SYNC();
-    int cap = M.solver == 2 ? NEFC : NEFC_P;
+    int cap = M.solver == 2 ? NEFC : M.pgs_cap > 0 ? M.pgs_cap : NEFC_P;
     if (M.row_limit > 0 && M.row_limit < cap) cap = M.row_limit;
     // static rows (equalities -- all active, an inactive one gets an empty row with R large -> force 0 -- then friction-loss
     // dofs) and the limit slots, each from its row record (DevModel::k_rowrec): one level of loads
@@ -2733,7 +2744,7 @@ struct StepKernel {
     return v;
   }
   template <bool WIDE>
-  SMJ_DEV float* Amat() { return WIDE ? s.A() : &s.J[NEFP][0]; }
+  SMJ_DEV float* Amat() { return WIDE ? s.A(M.pgs_cap > 0 ? M.pgs_cap : NEFC_P) : &s.J[NEFP][0]; }
   template <bool WIDE>
   SMJ_DEV static int ai(int r, int c) { return WIDE ? tri(r, c) : r * NEFP + c; }
   template <bool WIDE>
@@ -2806,7 +2817,7 @@ struct StepKernel {
               const int row = 16 * tr + (lane >> 4) * 4 + r, col = 16 * tc + (lane & 15);
               float v = acc[lane].r[r];
               if (row == col) v += row < ne ? s.eR[row] : 1.f;
-              if (WIDE) { if (col <= row && row < NEFC) A[tri(row, col)] = v; }
+              if (WIDE) { if (col <= row && row < (M.pgs_cap > 0 ? M.pgs_cap : NEFC_P)) A[tri(row, col)] = v; }
               else { A[row * NEFP + col] = v; if (tr != tc) A[col * NEFP + row] = v; }
             }
           }
@@ -2873,7 +2884,7 @@ struct StepKernel {
     // Row metadata lives in the registers of the row's lane and is fetched with v_readlane (no LDS round trip on the
     // serial path); the A row needed for the residual update is loaded first so its latency overlaps the scalar math.
     PL<int> type_r[NP], dimc_r[NP];   // row type; for the first row of an elliptic block: dim | contact << 8
-    PL<float> aii_r[NP], fl_r[NP];
+    PL<float> aii_r[NP], lo_r[NP], hi_r[NP];   // diagonal of A; the row's bounds (equality: none, friction loss: -floss..floss, limit / frictionless contact: 0..)
     PSETS_ALL(p) LANES {
       const int row = lane + 64 * p;
       const int t = row < ne ? s.etype[row] : CT_NONE;
@@ -2883,7 +2894,9 @@ struct StepKernel {
       dimc_r[p][lane] = dc;
       const float aii = row < ne ? A[ai<WIDE>(row, row)] : 1.f;
       aii_r[p][lane] = aii; ARinv_r[p][lane] = 1.0f / aii;
-      fl_r[p][lane] = row < ne ? s.efloss[row] : 0.f;
+      const float fl = row < ne ? s.efloss[row] : 0.f;
+      lo_r[p][lane] = t == CT_EQUALITY ? -INFINITY : t == CT_FRICTION ? -fl : 0.f;
+      hi_r[p][lane] = t == CT_FRICTION ? fl : INFINITY;
     }
     LANES { qla_r[lane] = 0.f; }
     const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
@@ -2896,23 +2909,34 @@ struct StepKernel {
       for (int i = 0; i < ne;) {
         const int t = prow<NP>(type_r, i);
         if (t != CT_CONTACT_ELLIPTIC) {
+          // A run of scalar rows (equality, friction loss, limit, frictionless contact): f <- clamp(f - r / A_ii) between the row's
+          // bounds (-inf..inf, -floss..floss, 0..inf: one code path), straight-line; the A row of the NEXT row is fetched while
+          // this one is worked on (its LDS latency was a third of a row's time on the serial path).
           PL<float> arow[NP];
           PSETS(p, ne) LANES { const int col = lane + 64 * p; arow[p][lane] = (!WIDE || col < ne) ? A[ai<WIDE>(i, col)] : 0.f; }
-          const float res = prow<NP>(r_r, i), old = prow<NP>(f_r, i), ainv = prow<NP>(ARinv_r, i);
-          const float aii = prow<NP>(aii_r, i);
-          float fn = old - res * ainv;
-          if (t == CT_FRICTION) { const float fl = prow<NP>(fl_r, i); fn = fminf(fl, fmaxf(-fl, fn)); }
-          else if (t != CT_EQUALITY) fn = fmaxf(0.f, fn);
-          float delta = fn - old;
-          float change = delta * (0.5f * aii * delta + res);
-          if (change > 1e-10f) { delta = 0; change = 0; }
-          improvement -= change;
-          PSETS(p, ne) LANES {
-            r_r[p][lane] += arow[p][lane] * delta;
-            if (lane + 64 * p == i) f_r[p][lane] += delta;
+          int nrun = 0;
+          for (;;) {
+            const bool more = i + 1 < ne;
+            const int inext = more ? i + 1 : i;   // (past the end: row i again, not used)
+            PL<float> anext[NP];
+            PSETS(p, ne) LANES { const int col = lane + 64 * p; anext[p][lane] = (!WIDE || col < ne) ? A[ai<WIDE>(inext, col)] : 0.f; }
+            const int tnext = more ? prow<NP>(type_r, inext) : CT_CONTACT_ELLIPTIC;
+            const float res = prow<NP>(r_r, i), old = prow<NP>(f_r, i), ainv = prow<NP>(ARinv_r, i);
+            const float aii = prow<NP>(aii_r, i), lo = prow<NP>(lo_r, i), hi = prow<NP>(hi_r, i);
+            const float fn = fminf(hi, fmaxf(lo, old - res * ainv));
+            float delta = fn - old;
+            float change = delta * (0.5f * aii * delta + res);
+            if (change > 1e-10f) { delta = 0; change = 0; }
+            improvement -= change;
+            PSETS(p, ne) LANES {
+              r_r[p][lane] += arow[p][lane] * delta;
+              if (lane + 64 * p == i) f_r[p][lane] += delta;
+            }
+            i += 1; nrun++;
+            if (tnext == CT_CONTACT_ELLIPTIC) break;   // the next row starts a contact block, or there is none
+            PSETS(p, ne) LANES { arow[p][lane] = anext[p][lane]; }
           }
-          i += 1;
-          if (prof) { const long long t1 = smj_clock(); pc[SMJ_PROF_N_UPDATE] += (float)(t1 - tp); tp = t1; pc[SMJ_PROF_N_FACTSOLVE] += 1.f; }
+          if (prof) { const long long t1 = smj_clock(); pc[SMJ_PROF_N_UPDATE] += (float)(t1 - tp); tp = t1; pc[SMJ_PROF_N_FACTSOLVE] += (float)nrun; }
         } else {
           const int dc = prow<NP>(dimc_r, i), dim = dc & 255, c = dc >> 8;
           if (dim == 3) improvement += pgs_block<3, WIDE>(i, c);
@@ -2982,13 +3006,18 @@ struct StepKernel {
     SYNC();
   }
 
-  // one elliptic contact block of the PGS sweep  [MJ] mj_solPGS elliptic branch (ray update + QCQP); uniform math
+  // one elliptic contact block of the PGS sweep  [MJ] mj_solPGS elliptic branch (ray update + QCQP); uniform math.
+  // The block's own DIM x DIM part of A is never read as such: rows i..i+DIM of A are in the lanes anyway (arow, for the
+  // residual update; A is symmetric, so lane i + r holds row r of the block), hence At old and At delta are DIM vector FMAs
+  // each, read back from the block's lanes, instead of DIM^2 uniform ones on DIM^2 uniform loads; the QCQP takes the lower
+  // triangle of the friction part.
   template <int DIM, bool WIDE>
   SMJ_DEV float pgs_block(int i, int c) {
     constexpr int NP = WIDE ? NPS : 1;
+    constexpr int NF = DIM - 1;
     const int ne = nefc;
     const float* const A = Amat<WIDE>();
-    float res[DIM], old[DIM], f[DIM], At[DIM * DIM], v1[DIM], mu[DIM - 1];
+    float res[DIM], old[DIM], f[DIM], v1[DIM], mu[NF], Ac[NF * NF], a0[NF];
     PL<float[DIM]> arow[NP];  // rows i..i+DIM of A for the residual update, issued up front
     PSETS(p, ne) LANES {
       const int col = lane + 64 * p;
@@ -2996,23 +3025,25 @@ struct StepKernel {
       for (int r = 0; r < DIM; r++) arow[p][lane][r] = (!WIDE || col < ne) ? A[ai<WIDE>(i + r, col)] : 0.f;
     }
 #pragma unroll
-    for (int r = 0; r < DIM; r++) {
-      res[r] = prow<NP>(r_r, i + r); old[r] = prow<NP>(f_r, i + r); f[r] = old[r];
+    for (int j = 0; j < NF; j++) {
+      mu[j] = s.cfric[c][j];
+      a0[j] = A[ai<WIDE>(i + 1 + j, i)];
 #pragma unroll
-      for (int q = 0; q < DIM; q++) At[r * DIM + q] = A[ai<WIDE>(i + r, i + q)];
+      for (int q = 0; q <= j; q++) Ac[j * NF + q] = A[ai<WIDE>(i + 1 + j, i + 1 + q)];   // (the QCQP reads the lower triangle)
     }
 #pragma unroll
-    for (int j = 0; j < DIM - 1; j++) mu[j] = s.cfric[c][j];
+    for (int r = 0; r < DIM; r++) { res[r] = prow<NP>(r_r, i + r); old[r] = prow<NP>(f_r, i + r); f[r] = old[r]; }
     // v1 = At * old (used by the ray update and by the friction right-hand side)
+    PL<float> vv[NP];
+    PSETS(p, ne) LANES {
+      float a = arow[p][lane][0] * old[0];
+#pragma unroll
+      for (int q = 1; q < DIM; q++) a += arow[p][lane][q] * old[q];
+      vv[p][lane] = a;
+    }
     float denom = 0, num = 0;
 #pragma unroll
-    for (int r = 0; r < DIM; r++) {
-      float a = 0;
-#pragma unroll
-      for (int q = 0; q < DIM; q++) a += At[r * DIM + q] * old[q];
-      v1[r] = a;
-      denom += old[r] * a; num += old[r] * res[r];
-    }
+    for (int r = 0; r < DIM; r++) { v1[r] = prow<NP>(vv, i + r); denom += old[r] * v1[r]; num += old[r] * res[r]; }
     if (f[0] < SMJ_MINVAL) {  // normal update
       f[0] -= res[0] * prow<NP>(ARinv_r, i);
       if (f[0] < 0) f[0] = 0;
@@ -3025,52 +3056,48 @@ struct StepKernel {
       for (int r = 0; r < DIM; r++) f[r] += x * old[r];
     }
     // friction update with the normal fixed
-    float Ac[(DIM - 1) * (DIM - 1)], bc[DIM - 1], v[DIM - 1];
+    float bc[NF], v[NF];
 #pragma unroll
-    for (int j = 0; j < DIM - 1; j++) {
-#pragma unroll
-      for (int q = 0; q < DIM - 1; q++) Ac[j * (DIM - 1) + q] = At[(j + 1) * DIM + q + 1];
-      bc[j] = res[j + 1] - v1[j + 1] + At[(j + 1) * DIM] * f[0];
-    }
+    for (int j = 0; j < NF; j++) bc[j] = res[j + 1] - v1[j + 1] + a0[j] * f[0];
     if (f[0] < SMJ_MINVAL) {
 #pragma unroll
       for (int j = 1; j < DIM; j++) f[j] = 0;
     } else {
       const long long tq = (SMJ_PROFILING && ppc) ? smj_clock() : 0;
       float la = wave_read(qla_r, c);
-      const int active = qcqp<DIM - 1>(v, Ac, bc, mu, f[0], la, M.qcqp_exact != 0, (SMJ_PROFILING && ppc) ? &ppc[SMJ_PROF_N_HMFMA] : nullptr);
+      const int active = qcqp<NF>(v, Ac, bc, mu, f[0], la, M.qcqp_exact != 0, (SMJ_PROFILING && ppc) ? &ppc[SMJ_PROF_N_HMFMA] : nullptr);
       LANES { if (lane == c) qla_r[lane] = la; }
       if (SMJ_PROFILING && ppc) ppc[SMJ_PROF_N_XA] += (float)(smj_clock() - tq);
       if (active) {
         float sc = 0;
 #pragma unroll
-        for (int j = 0; j < DIM - 1; j++) { const float t = v[j] * fast_rcp(mu[j]); sc += t * t; }
+        for (int j = 0; j < NF; j++) { const float t = v[j] * fast_rcp(mu[j]); sc += t * t; }
         sc = f[0] * fast_rsqrt(fmaxf(SMJ_MINVAL, sc));
 #pragma unroll
-        for (int j = 0; j < DIM - 1; j++) v[j] *= sc;
+        for (int j = 0; j < NF; j++) v[j] *= sc;
       }
 #pragma unroll
-      for (int j = 0; j < DIM - 1; j++) f[j + 1] = v[j];
+      for (int j = 0; j < NF; j++) f[j + 1] = v[j];
     }
     float change = 0, delta[DIM];
 #pragma unroll
     for (int r = 0; r < DIM; r++) delta[r] = f[r] - old[r];
+    // sv = At * delta is the block's part of the residual update A[:, i..i+DIM] delta
+    PL<float> dr[NP];
+    PSETS(p, ne) LANES {
+      float a = arow[p][lane][0] * delta[0];
 #pragma unroll
-    for (int r = 0; r < DIM; r++) {
-      float sv = 0;
-#pragma unroll
-      for (int q = 0; q < DIM; q++) sv += At[r * DIM + q] * delta[q];
-      change += delta[r] * (0.5f * sv + res[r]);
+      for (int r = 1; r < DIM; r++) a += arow[p][lane][r] * delta[r];
+      dr[p][lane] = a;
     }
+#pragma unroll
+    for (int r = 0; r < DIM; r++) change += delta[r] * (0.5f * prow<NP>(dr, i + r) + res[r]);
     if (change > 1e-10f) return 0.f;
     PSETS(p, ne) LANES {
-      float acc = r_r[p][lane];
+      r_r[p][lane] += dr[p][lane];
 #pragma unroll
-      for (int r = 0; r < DIM; r++) {
-        acc += arow[p][lane][r] * delta[r];
+      for (int r = 0; r < DIM; r++)
         if (lane + 64 * p == i + r) f_r[p][lane] += delta[r];
-      }
-      r_r[p][lane] = acc;
     }
     return -change;
   }

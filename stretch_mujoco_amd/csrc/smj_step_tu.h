@@ -169,8 +169,15 @@ __global__ __launch_bounds__(64) void SMJ_WORKER_KERNEL(const DevModel M, const 
 }
 #endif
 
-int SMJ_LAUNCH_STEP(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream) {
-  const size_t lds = smj_lds_bytes(m.solver != 2);
+int SMJ_LAUNCH_STEP(const DevModel& m_in, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream) {
+  DevModel m = m_in;
+  size_t lds = smj_lds_bytes(m.solver != 2);
+  // A PGS launch of a primary kernel that can hand steps over (DevState::redo) keeps to the rows whose A fits the struct
+  // (smj_pgs_rows_static) and asks for no dynamic LDS: the variant's Newton occupancy instead of one env per CU.
+  if (m.solver != 2 && s.redo && !s.redo_worker && lds > sizeof(Smem) && smj_pgs_rows_static() > 0) {
+    m.pgs_cap = smj_pgs_rows_static();
+    lds = sizeof(Smem);
+  }
   static size_t lds_allowed_dev[64] = {};   // per device: the attribute belongs to the device's copy of the kernel
   int dev_now = 0;
   (void)hipGetDevice(&dev_now);

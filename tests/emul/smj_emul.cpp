@@ -90,6 +90,7 @@ int emul_set_option(emul_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "warmstart")) m.warmstart = (int)v;
   else if (!strcmp(name, "pgs_fixed_iter")) m.pgs_fixed_iter = (int)v;
   else if (!strcmp(name, "qcqp_exact")) m.qcqp_exact = (int)v;
+  else if (!strcmp(name, "pgs_cap")) m.pgs_cap = (int)v;   // what smj_step sets for a PGS launch without dynamic LDS (smj_step_tu.h)
   else if (!strcmp(name, "max_contacts_per_pair")) m.max_con_pair = (int)v;
   else if (!strcmp(name, "solver")) m.solver = (int)v;
   else if (!strcmp(name, "convex_pairs")) m.convex_pairs = (int)v;

@@ -498,3 +498,39 @@ def test_pgs_default_qcqp_carries_wide_rows(blob_fused):
         assert wide >= 6
     finally:
         o.set_option("qcqp_cap", 20)   # process-wide in the oracle library
+
+
+def test_pgs_row_cap_moves_the_matrix_not_the_result(blob_fused):
+    """A PGS launch of a primary kernel that can hand steps over keeps to the rows whose packed A fits the struct behind
+    that many rows of J (DevModel::pgs_cap, 96 for the tall builds) and asks for no dynamic LDS.  The deep-penetration scenario,
+    state-synchronised: a step with 65..96 rows gives bit-identical velocities with and without the cap (A only sits elsewhere);
+    a step beyond it is flagged for the escalation variant (the emulator has none) instead of being solved."""
+    ctrl = [0, 0, 0.0, 0.3, 0, -1.57, 0, 0, 0, 0]
+    o = Oracle(blob_fused)
+    o.set_option("solver", 0); o.set_option("qcqp_cap", 1000); o.reset()   # (this variant of the scenario passes through 71-95 rows)
+    o.arr("ctrl")[:10] = ctrl
+    es = []
+    for cap in (0, 96):
+        e = Emul(blob_fused, DIMS, num_envs=1, variant="tall")
+        e.set_option("solver", 0); e.set_option("pgs_cap", cap)
+        e.ctrl[:, 0] = np.asarray(ctrl, np.float32)
+        es.append(e)
+    inside = beyond = 0
+    try:
+        for k in range(40):
+            for e in es:
+                e.qpos[:, 0] = o.arr("qpos"); e.qvel[:, 0] = o.arr("qvel"); e.warm[:, 0] = o.arr("qacc_warmstart")
+                e.info[3, 0] = 0
+                e.step(1)
+            o.step(1)
+            ne = int(es[0].info[0, 0])
+            if 64 < ne <= 96:
+                assert int(es[1].info[3, 0]) == 0 and int(es[1].info[0, 0]) == ne
+                assert np.array_equal(es[0].qvel, es[1].qvel), k
+                inside += 1
+            elif ne > 96:
+                assert int(es[1].info[3, 0]) & 1, k
+                beyond += 1
+    finally:
+        o.set_option("qcqp_cap", 20)   # process-wide in the oracle library
+    assert inside >= 1 and beyond >= 3, (inside, beyond)

@@ -10,8 +10,8 @@ sys.path.insert(0, ".")
 from stretch_mujoco_amd import StretchBatchSimulator  # noqa: E402
 
 
-def main(B=4096, steps=20000, scene="stretch_empty"):
-    sim = StretchBatchSimulator(num_envs=B, device="cuda:0", solver="newton", scene=scene)
+def main(B=4096, steps=20000, scene="stretch_empty", solver="newton"):
+    sim = StretchBatchSimulator(num_envs=B, device="cuda:0", solver=solver, scene=scene)
     sim.start(home=True)
     dev = sim.device
     g = torch.Generator(device=dev).manual_seed(99)
@@ -36,7 +36,7 @@ def main(B=4096, steps=20000, scene="stretch_empty"):
     fl = ever
     z = sim.qpos[2]
     up = 1 - 2 * (sim.qpos[4] ** 2 + sim.qpos[5] ** 2)
-    print(f"{scene}: {B} envs x {steps} steps in {dt:.1f} s = {B*steps/dt/1e6:.2f} M env-steps/s; "
+    print(f"{scene} [{solver}]: {B} envs x {steps} steps in {dt:.1f} s = {B*steps/dt/1e6:.2f} M env-steps/s; "
           f"flags: rows {float(((fl & 1) != 0).float().mean()):.3f} contacts {float(((fl & 2) != 0).float().mean()):.3f} "
           f"(per 50-step launch: mean {np.mean(per_launch):.4f}, max {np.max(per_launch):.4f}) "
           f"bad-state resets {float(((fl & 4) != 0).float().mean()):.4f}; pipeline timeouts {int(((fl & 8) != 0).sum())}; "
@@ -46,4 +46,4 @@ def main(B=4096, steps=20000, scene="stretch_empty"):
 
 
 if __name__ == "__main__":
-    main(steps=int(sys.argv[1]) if len(sys.argv) > 1 else 20000, scene=sys.argv[2] if len(sys.argv) > 2 else "stretch_empty")
+    main(steps=int(sys.argv[1]) if len(sys.argv) > 1 else 20000, scene=sys.argv[2] if len(sys.argv) > 2 else "stretch_empty", solver=sys.argv[3] if len(sys.argv) > 3 else "newton")
