@@ -146,8 +146,11 @@ __device__ __forceinline__ void mfma16x16x4(PL<F4v>& acc, const PL<float>& a, co
 //    only safeguard.  (b) The iteration starts at the multiplier the contact's block had in the PREVIOUS SWEEP (la_io; 0 in the
 //    first sweep of a step): 1.8 iterations per call.  (c) fp32 tolerances: val carries the rounding of the solve
 //    (1e-7 r^2 times the condition number), a step of la matters relative to la + min A_ii; both tests get a relative part of
-//    1e-5 (the caller rescales an active solution onto the cone anyway).  Where MuJoCo's iteration converges the two agree to
-//    that tolerance; where it ends at its cap MuJoCo returns the direction of an unconverged x, this returns the root's.
+//    1e-5 (the caller rescales an active solution onto the cone anyway).  (d) A step below 3e-3 (la + min A_ii) is taken to
+//    first order -- x(la + d) = x - d (A + la I)^-1 x, one more back substitution -- instead of a new factorisation (error
+//    d^2 / (la + A)^2 <= 1e-5): from the second sweep on an active block costs ONE factorisation.  Where MuJoCo's iteration
+//    converges the two agree to that tolerance; where it ends at its cap MuJoCo returns the direction of an unconverged x, this
+//    returns the root's.
 template <int N>
 SMJ_DEV int qcqp(float* res, const float* Ain, const float* bin, const float* dd, float r, float& la_io, bool exact, float* iters = nullptr) {
   float A[N * N], b[N], L[N * N], Li[N], la = exact ? 0.f : la_io;
@@ -223,6 +226,22 @@ SMJ_DEV int qcqp(float* res, const float* Ain, const float* bin, const float* dd
       const float nrm = nn * fast_rsqrt(nn);
       delta = (nrm - r) * nn * fast_rcp(r * q);
       if (fabsf(delta) < dtol + drel * la) break;
+      if (fabsf(delta) < 3e-3f * (la + dmin)) {
+        // close (the usual case from the second sweep on): finish to first order instead of factoring again --
+        // x(la + d) = x(la) - d (A + la I)^-1 x(la) + O(d^2 / (la + A)^2) <= 1e-5 relative; (A + la I)^-1 x = L^-T (L^-1 x), L^-1 x is in x[]
+        const float lan = fmaxf(0.f, la + delta), d = lan - la;
+#pragma unroll
+        for (int i = N - 1; i >= 0; i--) {
+          float sv = x[i];
+#pragma unroll
+          for (int k = i + 1; k < N; k++) sv -= L[k * N + i] * x[k];
+          x[i] = sv * Li[i];
+        }
+#pragma unroll
+        for (int i = 0; i < N; i++) res[i] -= d * x[i];
+        la = lan;
+        break;
+      }
     }
     la = fmaxf(0.f, la + delta);
   }
