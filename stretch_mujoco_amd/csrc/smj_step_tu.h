@@ -193,7 +193,7 @@ int SMJ_LAUNCH_STEP(const DevModel& m_in, const DevState& s, int nsteps, unsigne
   }
 #if defined(SMJ_WORKER_KERNEL)
   if (s.redo_worker) {
-    const unsigned wg = s.redo_worker == 2 ? (unsigned)(s.pollers < 0 ? -s.pollers : s.pollers) : (unsigned)(s.B < 128 ? s.B : 128);
+    const unsigned wg = s.redo_worker == 2 ? (unsigned)(s.pollers < 0 ? -s.pollers : s.pollers) : (unsigned)(s.B < 512 ? s.B : 512);   // sweep: two envs per CU fit (one under PGS); surplus workgroups find the list drained and leave
     hipLaunchKernelGGL(SMJ_WORKER_KERNEL, dim3(wg), dim3(64), lds, stream, m, s, nsteps, read_flags);
     return 0;
   }
