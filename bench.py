@@ -169,7 +169,7 @@ def other_configs(B, dev, hold, solver):
             continue
         sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver=solver, scene=scene)
         sim.start(home=False)
-        res[scene + "_physics"] = {"value": rollout(sim, 200, hold), "unit": "env-steps/s", **flags_of(sim)}
+        res[scene + "_physics"] = {"value": rollout(sim, 500, hold), "unit": "env-steps/s", **flags_of(sim)}   # 10 launches: one with a hand-over to the larger variant costs +30 %
         sim.stop()
     # config 4 as north_star words it ("contact-rich PGS solve"): the same scenes under PGS.  The sweeps are serial over the rows
     # (100 sweeps x ~100 rows at one wavefront per env), so this is the slowest path of the library; Newton is the model's own solver.
