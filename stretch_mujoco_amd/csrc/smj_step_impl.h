@@ -3819,8 +3819,15 @@ struct StepKernel {
       float alpha = 0, d10 = 0;
       {
         const float gtol = M.tolerance * M.ls_tolerance * snorm * M.meaninertia * (float)(nv > 1 ? nv : 1);
+        // the derivatives at 0 need no evaluation along the line: d1(0) = grad . search, and with the exact Hessian H search =
+        // -grad gives d2(0) = search' H search = -d1(0) -- the first trial point is the full Newton step (MuJoCo evaluates at 0
+        // because its CG directions share the code; one evaluation of ~2.3 per iteration saved)
         float d1, d2, lo = 0, hi = -1;
-        ls_eval(nr0, qg, 0.f, d1, d2);
+        {
+          PL<float> gs;
+          LANES { gs[lane] = lane < nv ? grad[lane] * search[lane] : 0.f; }
+          d1 = wave_sum(gs); d2 = -d1;
+        }
         d10 = d1;
         float bestd = fabsf(d1), a = 0;
         if (d1 < 0 && d2 > 0) {
