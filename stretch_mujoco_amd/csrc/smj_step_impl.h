@@ -3609,6 +3609,7 @@ struct StepKernel {
     float cost = 0;
     TICK(SMJ_PROF_WARM)
     int iter = 0;
+    bool at_update = false;   // the loop was left right after a constraint update + gradient: forces and J'f are those of the accepted point
     for (; iter < M.iterations;) {
       TICK(SMJ_PROF_PGS)
       cost = newton_update(nr0, true);
@@ -3639,7 +3640,7 @@ struct StepKernel {
       // J'f, not of their terms: where stiff contact forces cancel inside J'f -- a gripper wedged on the base -- the test then
       // does not fire and the iteration runs as before; with the terms' size as the scale it fired there too and the
       // acceleration error of light dofs doubled.)
-      if (iter > 0 && (scale * gnorm < M.tolerance || wave_ballot(gsig) == 0)) break;
+      if (iter > 0 && (scale * gnorm < M.tolerance || wave_ballot(gsig) == 0)) { at_update = true; break; }
       TICK(SMJ_PROF_N_GRAD)
       // H = M + J' W J on the matrix cores, without a weighted copy of J.  W is diagonal (D for rows in the quadratic zone, 0 for
       // satisfied / linear rows) except for the contacts whose block sits in the cone (middle) zone, which carry a dense
@@ -3871,8 +3872,10 @@ struct StepKernel {
     niter = iter;
     TICK(SMJ_PROF_PGS)
     // final forces at the accepted point, qfrc_constraint = J' f
-    newton_update(nr0, false);
-    matT_J(tmpv, nr0);
+    if (!at_update) {
+      newton_update(nr0, false);
+      matT_J(tmpv, nr0);
+    }
     LANES {
       qacc_r[lane] = lane < nv ? qacc[lane] : 0.f;
       if (lane < nv) { s.qacc[lane] = qacc[lane]; s.warm[lane] = qacc[lane]; s.tmp[lane] = g_r[lane] + tmpv[lane]; }
