@@ -539,3 +539,41 @@ def test_pgs_row_cap_moves_the_matrix_not_the_result(blob_fused):
     finally:
         o.set_option("qcqp_cap", 20)   # process-wide in the oracle library
     assert inside >= 1 and beyond >= 3, (inside, beyond)
+
+
+def test_newton_stops_on_a_gradient_that_is_rounding(blob_fused):
+    """MuJoCo leaves the Newton loop before building the Hessian when the scaled gradient norm is below 1e-8; in fp32 that is
+    below the rounding of the gradient's own terms, so the kernel also stops (after the first iteration) when every component is
+    below 64 ulp of |Ma| + |g| + |J'f| of its dof, takes the line search's derivatives at 0 from grad . search, and keeps the
+    forces of a loop that ended at the gradient test (smj_step_impl.h solve_newton).  Bench workload, the oracle's state uploaded
+    before every step: no more iterations than the fp64 oracle on average (before: 3.65 against 3.25), same one-step velocities."""
+    import stretch_mujoco_amd.model_blob as mb
+
+    cr = np.asarray(mb.loads(blob_fused)["actuator_ctrlrange"])
+    lo, hi = cr[:, 0], cr[:, 1]
+    B = 4
+    e = Emul(blob_fused, DIMS, num_envs=B)
+    e.set_option("solver", 2)
+    os_ = [Oracle(blob_fused) for _ in range(B)]
+    for o in os_:
+        o.set_option("solver", 2); o.arr("qpos")[:] = home_qpos(o.arr("qpos")); o.arr("ctrl")[:] = HOME_CTRL
+        o.step(200)
+    rng = np.random.default_rng(5)
+    ni_e, ni_o, dv = [], [], []
+    for _ in range(2):
+        c = (lo[:, None] + (hi - lo)[:, None] * rng.random((10, B))).astype(np.float32)
+        e.ctrl[:] = c
+        for i, o in enumerate(os_):
+            o.arr("ctrl")[:] = c[:, i]
+        for _ in range(40):
+            for i, o in enumerate(os_):
+                e.qpos[:, i] = o.arr("qpos"); e.qvel[:, i] = o.arr("qvel"); e.warm[:, i] = o.arr("qacc_warmstart")
+            e.step(1)
+            for o in os_:
+                o.step(1)
+            ni_e.append(e.info[2].copy()); ni_o.append([int(o.iarr("solver_niter")[0]) for o in os_])
+            dv.append([np.abs(e.qvel[:, i] - o.arr("qvel")).max() / max(1.0, np.abs(o.arr("qvel")).max()) for i, o in enumerate(os_)])
+    ni_e, ni_o, dv = np.array(ni_e), np.array(ni_o), np.array(dv)
+    assert int(e.info[3].max()) == 0
+    assert ni_e.mean() <= ni_o.mean() + 0.1, (ni_e.mean(), ni_o.mean())
+    assert np.median(dv) < 2e-6 and np.quantile(dv, 0.99) < 1e-4, (np.median(dv), np.quantile(dv, 0.99))
