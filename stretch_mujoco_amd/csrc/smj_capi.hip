@@ -349,27 +349,48 @@ int smj_comm_init(smj_ctx* c, int rank, int world, const char* id_path, double t
   HIPCHK(c, hipSetDevice(c->device));
   ncclUniqueId id;
   memset(&id, 0, sizeof id);
+  // The id file: {magic, job nonce, ncclUniqueId}.  The nonce is a hash of what every rank of ONE job shares and two jobs do
+  // not (SMJ_JOB_NONCE if the launcher sets it, else MASTER_ADDR : MASTER_PORT : TORCHELASTIC_RUN_ID : WORLD_SIZE as torchrun
+  // exports them): a file left behind by an earlier job at the same path -- right size, wrong job -- is not accepted, and rank 0
+  // removes whatever is there before it publishes.  (With torch.distributed up, parallel.init_comm also puts a barrier between
+  // that removal and the readers' first look.)
+  struct IdFile { char magic[8]; uint64_t nonce; ncclUniqueId id; } rec;
+  memset(&rec, 0, sizeof rec);
+  memcpy(rec.magic, "SMJRCCL1", 8);
+  {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const char* sv) { for (const char* p = sv ? sv : ""; *p; p++) { h ^= (unsigned char)*p; h *= 1099511628211ull; } h ^= 0xff; h *= 1099511628211ull; };
+    if (getenv("SMJ_JOB_NONCE")) mix(getenv("SMJ_JOB_NONCE"));
+    else { mix(getenv("MASTER_ADDR")); mix(getenv("MASTER_PORT")); mix(getenv("TORCHELASTIC_RUN_ID")); mix(getenv("WORLD_SIZE")); }
+    rec.nonce = h;
+  }
   if (rank == 0) {
+    if (world > 1) remove(id_path);   // a stale file of an earlier job must not be readable while the new id is being made
     ncclResult_t r = R->GetUniqueId(&id);
     if (r != ncclSuccess) return fail(c, -7, "ncclGetUniqueId: %s", R->GetErrorString(r));
     if (world > 1) {   // publish atomically: write a temporary, then rename
+      rec.id = id;
       std::string tmp = std::string(id_path) + ".tmp";
       FILE* f = fopen(tmp.c_str(), "wb");
-      if (!f || fwrite(&id, sizeof id, 1, f) != 1) { if (f) fclose(f); return fail(c, -7, "cannot write %s", tmp.c_str()); }
+      if (!f || fwrite(&rec, sizeof rec, 1, f) != 1) { if (f) fclose(f); return fail(c, -7, "cannot write %s", tmp.c_str()); }
       fclose(f);
       if (rename(tmp.c_str(), id_path) != 0) return fail(c, -7, "cannot publish %s", id_path);
     }
   } else {
     const double t_end = (timeout_s > 0 ? timeout_s : 120.0);
     double waited = 0;
+    bool foreign = false;
     for (;;) {
       FILE* f = fopen(id_path, "rb");
       if (f) {
-        const size_t n = fread(&id, 1, sizeof id, f);
+        IdFile got;
+        const size_t n = fread(&got, 1, sizeof got, f);
         fclose(f);
-        if (n == sizeof id) break;
+        if (n == sizeof got && !memcmp(got.magic, rec.magic, 8) && got.nonce == rec.nonce) { id = got.id; break; }
+        foreign = foreign || n > 0;   // something is there, but not this job's record: keep waiting for rank 0 to replace it
       }
-      if (waited >= t_end) return fail(c, -7, "timed out waiting for the RCCL id file %s", id_path);
+      if (waited >= t_end)
+        return fail(c, -7, foreign ? "timed out: the RCCL id file %s belongs to another job (stale file? nonce mismatch)" : "timed out waiting for the RCCL id file %s", id_path);
       struct timespec ts = {0, 20 * 1000 * 1000};
       nanosleep(&ts, nullptr);
       waited += 0.02;

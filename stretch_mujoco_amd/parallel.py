@@ -68,6 +68,15 @@ def init_comm(sim, rank: int | None = None, world: int | None = None, id_path: s
         if not have_dist:
             raise ValueError("init_comm: pass id_path (a file path shared by all ranks) when torch.distributed is not initialised")
         id_path = os.path.join(tempfile.gettempdir(), f"smj_rccl_id_{_job_token()}")
+    if world > 1 and have_dist:
+        # a file an earlier job left at this path must be gone before any rank looks for the new one (the library also checks
+        # the record's job nonce and lets rank 0 remove the path first; this barrier closes the window for good)
+        if rank == 0:
+            try:
+                os.remove(id_path)
+            except OSError:
+                pass
+        dist.barrier()
     rc = sim._L.smj_comm_init(sim._ctx, int(rank), int(world), id_path.encode() if id_path else None, float(timeout_s))
     _lib.check(sim._L, sim._ctx, rc, "smj_comm_init")
     sim._comm_world = world
@@ -107,4 +116,5 @@ def gather_returns_native(sim, local_returns: torch.Tensor):
             local_returns = pad   # ragged shards: padded to the largest shard
         if getattr(sim, "_comm_world", 1) != world:
             init_comm(sim)
-    return allgather_returns(sim, local_returns), f"smj_allgather_returns (RCCL ncclAllGather inside libsmj.so), world {world}"
+    how = "RCCL ncclAllGather inside libsmj.so" if world > 1 else "world 1: a device-to-device copy, no collective"
+    return allgather_returns(sim, local_returns), f"smj_allgather_returns ({how}), world {world}"

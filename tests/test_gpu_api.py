@@ -212,3 +212,46 @@ def test_base_pose_at_t_8_26_lies_inside_the_start_transient_ensemble_on_the_dev
         got = getattr(st, name).pos
         assert float((got - val).abs().max()) < tol, (name, float((got - val).abs().max()), val)
     sim.stop()
+
+
+def test_lidar_scan_reproduces_the_notebook_figure_through_the_api():
+    """docs/getting_started.ipynb cell 18 (the reference's MuJoCo lidar scan, kept as a figure; tests/golden/lidar_figure.json):
+    the same calls here -- default scene, start(), `pull_sensor_data().lidar` of the settled robot -- drawn the way the cell draws
+    it fall on the figure ray by ray.  Pins, on the device: the clip to the cutoff (exactly 10.0 on the arc of rays that meet
+    the floor beyond it), -1 for no hit, the ray index -> direction convention, the sign of the settled base's tilt, the table and
+    the mast's shadow.  Rays 140..143 excused (docking station absent from the checkout), see tests/test_oracle_physics.py."""
+    from test_oracle_physics import _lidar_figure, lidar_figure_check
+    from stretch_mujoco_amd import StretchBatchSimulator, StretchSensors
+
+    fig = _lidar_figure()
+    sim = StretchBatchSimulator(num_envs=4, device="cuda:0", scene="stretch_scene", sensors_to_use=[StretchSensors.base_lidar])
+    sim.start(home=False)
+    sim.home(settle=False)
+    sim.step(1600)
+    scan = sim.pull_sensor_data().lidar.cpu().numpy().astype(np.float64)
+    assert scan.shape == (4, 360)
+    for b in range(4):
+        off, covered = lidar_figure_check(scan[b], fig)
+        assert off == [], (b, off)
+        assert covered > 0.85
+        at_cut = [i for i in range(360) if scan[b, i] == 10.0]
+        assert at_cut == list(range(at_cut[0], at_cut[-1] + 1)) and set(range(144, 271)) <= set(at_cut) and abs(at_cut[-1] - 271) <= 2
+        assert not np.any((scan[b] > 1.5) & (scan[b] < 9.6))
+        assert np.all(scan[b][list(range(272, 290)) + list(range(310, 360)) + list(range(0, 40))] == -1.0)
+    sim.stop()
+
+
+def test_status_at_t_6_422_against_the_readme_through_the_api():
+    """README.md:136-145: 'time': 6.421999999999515 (MuJoCo's fp64 sum of 3211 timesteps; pull_status().time is
+    nstep * dt here, 5e-13 from it), head_tilt -0.00451929555883404 and head_pan -4.968686850480367e-06.  The other joints of that
+    printout predate the model's current gains (tests/test_oracle_physics.py): documented band only."""
+    sim = _sim(2)
+    sim.home(settle=False)
+    sim.step(3211)
+    st = sim.pull_status()
+    torch.cuda.synchronize()
+    assert float(st.time[0]) == pytest.approx(6.421999999999515, abs=1e-9)
+    assert float((st.head_tilt.pos - (-0.00451929555883404)).abs().max()) < 2e-5
+    assert float((st.head_pan.pos - (-4.968686850480367e-06)).abs().max()) < 2e-5
+    assert 0.5885 <= float(st.lift.pos[0]) <= 0.5912 and 0.0975 <= float(st.arm.pos[0]) <= 0.1005
+    sim.stop()

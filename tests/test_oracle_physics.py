@@ -316,3 +316,77 @@ def test_status_at_t_8_26_holds_when_home_is_sent_k_steps_after_the_reset(k):
           4: (9.232975816659571e-05, 1e-4), 5: (-0.005324523093874352, 1e-6), 6: (-9.586627571896982e-05, 1e-6)}
     for a, (val, tol) in nb.items():
         assert abs(L[a] - val) < tol, (a, L[a], val)
+
+
+def test_status_at_t_6_422_against_the_readme(blob_full):
+    """README.md:136-145 prints a second pull_status(): 'time': 6.421999999999515, a robot that was started and left alone (the
+    commands above the printout in the README were evidently not what produced it: head_pan -5e-6 after `move_by('head_pan',
+    -1.1)`, base velocity 3e-7 after `set_base_velocity(0.3, -0.1)`).  What it pins:
+      * the clock: 6.421999999999515 is the fp64 sum of 3211 timesteps of 0.002 -- digit for digit what the oracle's `time` holds
+        after 3211 steps (MuJoCo adds the timestep every step; nstep * dt would print 6.422);
+      * head_tilt -0.00451929555883404 and head_pan -4.968686850480367e-06 to 1e-7: the same quasi-static balance (position
+        servo + gravity sag + equality / friction rows) as the notebook's t = 8.26 s printout, from another MuJoCo run.
+    The lift / arm / wrist values of this printout (0.58897, 0.09806, ...) contradict the notebook's own MuJoCo output at a LATER
+    time (lift 0.59055 still creeping upwards at 2.2e-4 m/s): the README predates the current actuator gains of stretch.xml, so
+    only the documented band is asserted for them (test_stretch_home_settles_inside_the_documented_bands)."""
+    o = Oracle(blob_full)
+    o.arr("ctrl")[:] = HOME_CTRL
+    o.step(3211)
+    o.forward()
+    assert repr(float(o.time)) == "6.421999999999515"
+    L = o.arr("actuator_length")
+    assert abs(L[9] - (-0.00451929555883404)) < 1e-7, L[9]
+    assert abs(L[8] - (-4.968686850480367e-06)) < 1e-7, L[8]
+    assert 0.5885 <= L[2] <= 0.5912 and 0.0975 <= L[3] <= 0.1005
+
+
+def _lidar_figure():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "lidar_figure.json")))
+
+
+def lidar_figure_check(scan, fig, absent_rays=range(140, 144)):
+    """Compare a 360-ray scan (metres, -1 = no hit, clipped to the cutoff) with the notebook's figure (tests/golden/
+    lidar_figure.json, tools/gen_lidar_golden.py): every ray, drawn the way cell 18 draws it (x = -r cos i, y = -r sin i,
+    negative -> 0), must land on a red pixel of the figure -- within 3 px: 0.13 m at the figure's scale, 0.8 degree at r = 10 m.
+    Returns (rays off the drawing, fraction of the figure's red pixels within 3.5 px of a drawn ray)."""
+    x0, x1, y0, y1 = fig["axes_px"]
+    lim = fig["lim"]
+    red = np.array([(r, c) for r, c0, n in fig["red_runs"] for c in range(c0, c0 + n)], float)
+    r = np.where(scan < 0, 0.0, scan)
+    a = np.radians(np.arange(360))
+    px = x0 + (-r * np.cos(a) + lim) / (2 * lim) * (x1 - x0)
+    py = y1 - (-r * np.sin(a) + lim) / (2 * lim) * (y1 - y0)
+    d = np.sqrt((red[:, 1][None, :] - px[:, None]) ** 2 + (red[:, 0][None, :] - py[:, None]) ** 2)
+    off = [i for i in range(360) if d[i].min() > 3.0 and i not in absent_rays]
+    return off, float((d.min(0) <= 3.5).mean())
+
+
+def test_lidar_scan_reproduces_the_notebook_figure():
+    """docs/getting_started.ipynb cell 18 keeps the reference's lidar scan as a figure (MuJoCo's own rangefinder output, default
+    scene, settled robot).  The oracle's scan of the compiled default scene, drawn the same way, falls on it ray by ray:
+      * rays 144..270 return EXACTLY the cutoff (10 m): the base rests pitched forward by a fraction of a degree, these rays
+        meet the infinite floor plane beyond the cutoff and the sensor clips to it ([MJ] rangefinder + cutoff) -- the figure's
+        arc spans rays 144..271: the same half plane, its edge within one degree (sign and direction of the settled tilt, the
+        180-degree turn of the laser body, the sense of the replicate's rotation);
+      * rays pointing upwards return -1 (drawn at the origin after `scan_data[scan_data < 0] = 0`), nothing returns between 1.5 and
+        9.6 m in either;
+      * rays 42..138 meet the table's front edge (y = -0.5) where the figure draws its line, rays 290..306 the robot's own mast
+        at 0.13-0.15 m (the cluster at the origin).
+    Rays 140..143 are excused: in the figure they end on the docking station, whose meshes are absent from this checkout
+    (.MISSING_LARGE_BLOBS); it also owns the 12 % of the figure's red pixels no ray of this scene explains."""
+    fig = _lidar_figure()
+    o = Oracle(open(os.path.join(MODELS, "stretch_scene.smjb"), "rb").read())
+    o.arr("ctrl")[:] = HOME_CTRL
+    o.step(1600)
+    o.sensors(True)
+    scan = o.arr("lidar").copy()
+    off, covered = lidar_figure_check(scan, fig)
+    assert off == [], off
+    assert covered > 0.85, covered
+    at_cut = [i for i in range(360) if scan[i] == fig["cutoff"]]
+    assert at_cut == list(range(at_cut[0], at_cut[-1] + 1))                      # one contiguous arc
+    assert set(range(144, 271)) <= set(at_cut) and abs(at_cut[-1] - fig["rays_at_cutoff"][-1]) <= 2
+    assert not np.any((scan > 1.5) & (scan < 9.6))
+    assert np.all(scan[list(range(272, 290)) + list(range(310, 360)) + list(range(0, 40))] == -1.0)
+    assert np.all((scan[290:307] > 0.12) & (scan[290:307] < 0.16))

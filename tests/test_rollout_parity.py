@@ -29,23 +29,34 @@ def _report(tag, r):
 OBJECT_SCENES = ("stretch_scene", "stretch_kitchen4")   # free objects (and a table) within the arm's reach
 
 
-def _check_free_running(r, min_frac, scene=""):
+# Fraction of the 16 envs that must stay inside north_star's drift bound (1e-4 on base AND arm over 1000 steps), per scene: the
+# fraction MEASURED on the device (gpurun_out/pytest_gpu.log, round 4 baseline: 13 / 16 / 5 / 15 of 16) minus one env.  The envs
+# that leave do so at a bifurcation of the contact algorithm (state-synchronised test); in `stretch_scene` the gripper reaches the
+# table's free objects and most rollouts diverge after the first knock -- there the bound is asserted on the first 250 steps too.
+GPU_MIN_INSIDE = {"stretch_empty": 12 / 16, "stretch_kitchen_standin": 15 / 16, "stretch_scene": 4 / 16, "stretch_kitchen4": 14 / 16}
+GPU_MIN_INSIDE_EARLY = {"stretch_scene": 15 / 16, "stretch_kitchen4": 15 / 16}
+
+
+def _check_free_running(r, min_frac, scene="", early_frac=None):
     B = len(r["base"])
     assert (r["flags"] == 0).all(), r["flags"]
+    ok = (r["base"] < 1e-4) & (r["arm"] < 1e-4)
+    print(f"   inside 1e-4 over the whole rollout: {int(ok.sum())} / {B}")
     if scene in OBJECT_SCENES:
         # Manipulation of 0.2-0.5 kg objects is chaotic: once the gripper has knocked one over, the fp32 and fp64 runs are two
         # different rollouts (MPR's portal noise on cylinder rims seeds it, tools/parity_probe.py) -- as two MuJoCo builds
-        # would be.  Free-running drift is therefore only REPORTED for the whole rollout and asserted over the first 250
-        # steps; step-level parity of these scenes is the state-synchronised test's job.
+        # would be.  Asserted over the first 250 steps, and (with the measured fraction) over the whole rollout.
         h = r["hist"][:5]
         early = np.max(np.stack([np.maximum(x[0], x[1]) for x in h]), 0)
-        assert (early < 1e-4).mean() >= 0.7, early
-        return
-    ok = (r["base"] < 1e-4) & (r["arm"] < 1e-4)
+        print(f"   inside 1e-4 over the first 250 steps: {int((early < 1e-4).sum())} / {B}")
+        assert (early < 1e-4).mean() >= (early_frac if early_frac is not None else 0.7), early
+        if early_frac is None:
+            return
     # north_star: drift < 1e-4 over 1000 steps.  Envs that run into a bifurcation of the contact algorithm (see the
     # state-synchronised test) leave that band; everything else must stay inside it.
     assert ok.mean() >= min_frac, (ok.mean(), r["base"], r["arm"])
-    assert np.median(np.maximum(r["base"], r["arm"])) < 1e-4
+    if scene not in OBJECT_SCENES:
+        assert np.median(np.maximum(r["base"], r["arm"])) < 1e-4
 
 
 def _check_contacts():
@@ -102,7 +113,7 @@ def test_gpu_random_ctrl_free_running_1000_steps(scene):
     r = rc.free_running(be, blob, model, 16, 20, seed=7)
     be.close()
     _report(f"HIP {scene}", r)
-    _check_free_running(r, 0.7, scene)
+    _check_free_running(r, GPU_MIN_INSIDE[scene], scene, GPU_MIN_INSIDE_EARLY.get(scene))
 
 
 @pytest.mark.gpu
