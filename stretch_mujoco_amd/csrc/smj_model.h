@@ -14,7 +14,24 @@
 //   big (SMJ_BIG) -- scenes with several free objects (the reference's own scene.xml: table + 2 objects; kitchens):
 //               64 dofs, 160 rows, 48 contacts; ~130 KB of LDS per env, one env per CU.
 // smj_create picks the variant from the model's dimensions (and the model compiler's capacity hint).
-#if defined(SMJ_BIG)
+// Satellite builds (SMJ_SAT = satellite capacity, csrc/smj_sat.h, model_fuse.find_satellites): the MAIN tree (the robot: 32 dof lanes /
+// columns, as the standard variant) plus up to SMJ_SAT single-body mechanisms -- free objects, doors, drawers -- that meet it
+// only through contacts.  Each satellite is one LANE (32 + s) with its own 6 x 6 mass block; constraint rows that touch the main
+// tree come first and are the only ones with a dense Jacobian row (NDR of them), every row has two 6-column satellite slots.
+#if defined(SMJ_SAT)
+#define NSAT SMJ_SAT
+#define NVP 32
+#ifndef SMJ_SAT_ROWS
+#define SMJ_SAT_ROWS 192
+#define SMJ_SAT_CONTACTS 56
+#define SMJ_SAT_DENSE 96
+#endif
+#define NEFC SMJ_SAT_ROWS
+#define NCON SMJ_SAT_CONTACTS
+#define NDR SMJ_SAT_DENSE     // rows with a dense Jacobian row (rows 0 .. nd-1 of a step: the rows that touch the main tree)
+#define NXS 4                 // satellites that may be coupled to the main tree / to each other in one step (dense extension of the Newton system)
+#define NENT 5
+#elif defined(SMJ_BIG)
 #define NVP 64    // dof LANES (lane = dof stages run on 64 lanes)
 #ifndef SMJ_NVS
 #define SMJ_NVS 64
@@ -52,8 +69,15 @@
 #ifndef NVS
 #define NVS NVP
 #endif
+#ifndef NSAT
+#define NSAT 0
+#endif
+#ifndef NDR
+#define NDR NEFC
+#endif
 static_assert(NVS % 2 == 0 && NVS <= NVP && (NVP == 64 ? NVS >= 38 : NVS == NVP), "column capacity: even (packed pairs), odd row stride NVS + 1");
-#define NBP 32   // fused-body capacity
+#define NBP 32   // fused-body capacity of the main tree (lane = body stages)
+#define NBT (NBP + NSAT)   // body slots: main tree + satellites (body nbody + s = satellite s)
 #define NCG 128  // geoms that take part in non-plane collision pairs (world-frame cache of the broadphase)
 
 #define SMJ_MODEL_I32(X)                                                                                          \
@@ -93,6 +117,10 @@ struct DevModel {
   int multiccd;   // stretch.xml:8 <flag multiccd="enable"/>: multi-point contacts for convex pairs (box-box polygon, counter-rotated queries)
   float ls_tolerance;
   float timestep, gravity[3], impratio, tolerance, meaninertia, lidar_cutoff;
+  // satellites: nq / nv / nbody / njnt above are those of the MAIN part (a prefix of the model's coordinates); the *_all counts
+  // cover the whole model (equal to the main ones when nsat = 0)
+  int nsat, nq_all, nv_all, nbody_all, nfric_main, nlimit_main;
+  const int* k_satrec;    // [nsat][SMJ_SR_STRIDE], floats as bit patterns
 #define X(n) const int* n;
   SMJ_MODEL_I32(X)
 #undef X
@@ -117,7 +145,7 @@ enum { SMJ_CP_PAIR = 0, SMJ_CP_G1, SMJ_CP_G2, SMJ_CP_S1, SMJ_CP_S2, SMJ_CP_MARGI
 // row record: type, id (equality / dof / joint), dofs (limit: dof, side), qpos addresses, reference values (equality: qpos0 of
 // both joints; limit: range bound of the side, margin), equality polynomial, diagonal approximation, friction loss, solref, solimp
 enum { SMJ_RR_TYPE = 0, SMJ_RR_ID, SMJ_RR_D1, SMJ_RR_D2, SMJ_RR_Q1, SMJ_RR_Q2, SMJ_RR_V1, SMJ_RR_V2, SMJ_RR_DATA = 8, SMJ_RR_DIAG = 13,
-       SMJ_RR_FLOSS = 14, SMJ_RR_SOLREF = 15, SMJ_RR_SOLIMP = 17, SMJ_RR_USED = 22, SMJ_RR_STRIDE = 24 };
+       SMJ_RR_FLOSS = 14, SMJ_RR_SOLREF = 15, SMJ_RR_SOLIMP = 17, SMJ_RR_SAT = 22 /* satellite owning the row's dof, or -1 */, SMJ_RR_SDOF = 23 /* its dof inside the satellite */, SMJ_RR_STRIDE = 24 };
 // per-lane stage record: KinTab 36 words, BodyTab 24, DofTab 16, EntryTab 7 arrays of `nent` slots (padded to 4 words), ActTab 28
 constexpr int smj_lr_act(int nent) { return 76 + ((7 * nent + 3) & ~3); }
 constexpr int smj_lr_stride(int nent) { return smj_lr_act(nent) + 28; }
@@ -133,14 +161,19 @@ enum { SMJ_PP_PAIR = 0, SMJ_PP_G1, SMJ_PP_G2, SMJ_PP_B1, SMJ_PP_B2, SMJ_PP_T2, S
 enum { SMJ_CG_GEOM = 0, SMJ_CG_BODY, SMJ_CG_META, SMJ_CG_POS = 3, SMJ_CG_MAT = 6, SMJ_CG_LCEN = 15, SMJ_CG_HALF = 18, SMJ_CG_CCEN = 21,
        SMJ_CG_SIZE = 24, SMJ_CG_STRIDE = 28 };
 
+// satellite record: ints, then floats (bit patterns); model_fuse.SAT_I / SAT_F
+enum { SMJ_SR_BODY = 0, SMJ_SR_JTYPE, SMJ_SR_QADR, SMJ_SR_DADR, SMJ_SR_NDOF, SMJ_SR_JNT, SMJ_SR_F = 8,
+       SMJ_SR_POS = SMJ_SR_F + 0, SMJ_SR_QUAT = SMJ_SR_F + 3, SMJ_SR_JPOS = SMJ_SR_F + 7, SMJ_SR_JAXIS = SMJ_SR_F + 10, SMJ_SR_Q0 = SMJ_SR_F + 13,
+       SMJ_SR_INL = SMJ_SR_F + 14, SMJ_SR_ARM = SMJ_SR_F + 24, SMJ_SR_DAMP = SMJ_SR_F + 30, SMJ_SR_STIFF = SMJ_SR_F + 36, SMJ_SR_SPRING = SMJ_SR_F + 37,
+       SMJ_SR_GCMASS = SMJ_SR_F + 38, SMJ_SR_GCIPOS = SMJ_SR_F + 39, SMJ_SR_STRIDE = 52 };
 // layout of one env's staging row (4-byte words); a function of the variant's capacities, so that host code compiled once
 // (smj_capi.hip) can address the rows of either kernel variant
 struct SmjStageLayout {
   int qpos, qvel, warm, ctrl, bctl, nstep, info, actlen, actvel, base, gyro, accel, xpose, stride;
 };
-constexpr SmjStageLayout smj_stage_layout(int nvp, int nbp) {
+constexpr SmjStageLayout smj_stage_layout(int nvp, int nbp, int nsat = 0) {   // nbp: ALL body slots (main + satellites)
   SmjStageLayout L{};
-  L.qpos = 0; L.qvel = L.qpos + nvp + 8; L.warm = L.qvel + nvp; L.ctrl = L.warm + nvp; L.bctl = L.ctrl + 16; L.nstep = L.bctl + 8;
+  L.qpos = 0; L.qvel = L.qpos + nvp + 8 + 7 * nsat; L.warm = L.qvel + nvp + 6 * nsat; L.ctrl = L.warm + nvp + 6 * nsat; L.bctl = L.ctrl + 16; L.nstep = L.bctl + 8;
   L.info = L.nstep + 4; L.actlen = L.info + 4; L.actvel = L.actlen + 16; L.base = L.actvel + 16; L.gyro = L.base + 4;
   L.accel = L.gyro + 4; L.xpose = L.accel + 4; L.stride = L.xpose + 12 * nbp;
   return L;
@@ -232,15 +265,15 @@ enum { SMJ_FLAG_EFC_OVERFLOW = 1, SMJ_FLAG_CON_OVERFLOW = 2, SMJ_FLAG_BAD_STATE 
 
 // layout of the optional debug dump (floats), one column per env; a function of the variant's capacities (smj_dims reports
 // the offsets of the running variant, lib.py: debug_layout)
-struct SmjDebugLayout { int qm, g, qacc, efc_force, efc_b, efc_r, efc_aref, ar_diag, xpos, qfrc_bias, qfrc_passive, qfrc_act, con, ar, floats; };
-constexpr SmjDebugLayout smj_debug_layout(int nvp, int ncon) {
+struct SmjDebugLayout { int qm, g, qacc, efc_force, efc_b, efc_r, efc_aref, ar_diag, xpos, qfrc_bias, qfrc_passive, qfrc_act, con, ar, satqacc, floats; };
+constexpr SmjDebugLayout smj_debug_layout(int nvp, int ncon, int nsat = 0) {
   SmjDebugLayout L{};
   L.qm = 0; L.g = nvp * nvp; L.qacc = L.g + nvp; L.efc_force = L.qacc + nvp; L.efc_b = L.efc_force + 64; L.efc_r = L.efc_b + 64;
   L.efc_aref = L.efc_r + 64; L.ar_diag = L.efc_aref + 64; L.xpos = L.ar_diag + 64; L.qfrc_bias = L.xpos + 96; L.qfrc_passive = L.qfrc_bias + nvp;
-  L.qfrc_act = L.qfrc_passive + nvp; L.con = L.qfrc_act + nvp; L.ar = L.con + 8 * ncon; L.floats = L.ar + 64 * 64;
+  L.qfrc_act = L.qfrc_passive + nvp; L.con = L.qfrc_act + nvp; L.ar = L.con + 8 * ncon; L.satqacc = L.ar + 64 * 64; L.floats = L.satqacc + 6 * nsat;
   return L;
 }
-constexpr SmjDebugLayout SMJ_DBG = smj_debug_layout(NVP, NCON);
+constexpr SmjDebugLayout SMJ_DBG = smj_debug_layout(NVP, NCON, NSAT);
 enum {
   SMJ_DBG_QM = SMJ_DBG.qm,                     // NVP*NVP dense mass matrix (row-major, stride NVP)
   SMJ_DBG_G = SMJ_DBG.g,                       // NVP qfrc_smooth
@@ -251,6 +284,7 @@ enum {
   SMJ_DBG_QFRC_BIAS = SMJ_DBG.qfrc_bias, SMJ_DBG_QFRC_PASSIVE = SMJ_DBG.qfrc_passive, SMJ_DBG_QFRC_ACT = SMJ_DBG.qfrc_act,   // NVP each
   SMJ_DBG_CON = SMJ_DBG.con,                   // NCON contacts x (dist, pos3, normal3, condim | geom1 << 4 | geom2 << 14) = 8 floats
   SMJ_DBG_AR = SMJ_DBG.ar,                     // 64*64 AR (PGS)
+  SMJ_DBG_SATQACC = SMJ_DBG.satqacc,           // 6 per satellite: qacc of the satellite's dofs (satellite builds)
   SMJ_DEBUG_FLOATS = SMJ_DBG.floats
 };
 static_assert(NVP != 32 || NCON != 16 || (SMJ_DBG_QACC == 1056 && SMJ_DBG_CON == 1600 && SMJ_DBG_AR == 1728), "standard variant: the layout the tests index");

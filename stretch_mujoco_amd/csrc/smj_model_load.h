@@ -44,7 +44,7 @@ struct SmjBlob {
 // Host restatement of what the kernel's stage-table loaders (smj_step_impl.h: KinTab, BodyTab, DofTab, EntryTab, ActTab)
 // used to gather per lane from the individual tables, one record per lane.
 // capacities of a kernel variant (smj_model.h): the loader builds its records for the variant that will run
-struct SmjCaps { int nvp, nbp, nent, nefc, ncon, nvs; };   // nvs: dof columns of the variant's matrices (0: nvp)
+struct SmjCaps { int nvp, nbp, nent, nefc, ncon, nvs, nsat; };   // nvs: dof columns of the variant's matrices (0: nvp); nsat: satellite capacity (0: a build without satellites)
 static inline std::vector<int> smj_build_lanerec(const DevModel& m, std::map<std::string, std::vector<int>>& I,
                                                  std::map<std::string, std::vector<float>>& F, int nent) {
   const int LR_ACT = smj_lr_act(nent), LR_STRIDE = smj_lr_stride(nent);
@@ -184,9 +184,20 @@ static inline std::vector<int> smj_build_rowrec(const DevModel& m, std::map<std:
     k[SMJ_RR_DIAG] = fb(diag);
     k[SMJ_RR_SOLREF] = fb(gf("eq_solref", 2 * e)); k[SMJ_RR_SOLREF + 1] = fb(gf("eq_solref", 2 * e + 1));
   }
+  // (satellite of a dof / its index inside it; -1, 0 for dofs of the main tree)
+  auto sat_of = [&](int d, int* local) {
+    *local = 0;
+    for (int sidx = 0; sidx < m.nsat; sidx++) {
+      const int da = gi("k_sat_i", 8 * sidx + 3), nd = gi("k_sat_i", 8 * sidx + 4);
+      if (d >= da && d < da + nd) { *local = d - da; return sidx; }
+    }
+    return -1;
+  };
+  for (int e = 0; e < m.neq; e++) rec[(size_t)e * SMJ_RR_STRIDE + SMJ_RR_SAT] = -1;
   for (int f = 0; f < m.nfric; f++) {    // CT_FRICTION = 1
     int* k = rec.data() + (size_t)(m.neq + f) * SMJ_RR_STRIDE;
     const int d = gi("k_fric_dof", f);
+    k[SMJ_RR_SAT] = sat_of(d, &k[SMJ_RR_SDOF]);
     k[SMJ_RR_TYPE] = 1; k[SMJ_RR_ID] = d; k[SMJ_RR_D1] = d; k[SMJ_RR_D2] = -1;
     k[SMJ_RR_DIAG] = fb(gf("dof_invweight0", d)); k[SMJ_RR_FLOSS] = fb(gf("dof_frictionloss", d));
     k[SMJ_RR_SOLREF] = fb(gf("dof_solref", 2 * d)); k[SMJ_RR_SOLREF + 1] = fb(gf("dof_solref", 2 * d + 1));
@@ -195,6 +206,7 @@ static inline std::vector<int> smj_build_rowrec(const DevModel& m, std::map<std:
   for (int L = 0; L < 2 * m.nlimit; L++) {   // CT_LIMIT = 3; slot L = (joint, side), lower side first
     int* k = rec.data() + (size_t)(nstat + L) * SMJ_RR_STRIDE;
     const int j = gi("k_limit_jnt", L >> 1), d = gi("jnt_dofadr", j);
+    k[SMJ_RR_SAT] = sat_of(d, &k[SMJ_RR_SDOF]);
     k[SMJ_RR_TYPE] = 3; k[SMJ_RR_ID] = j; k[SMJ_RR_D1] = d; k[SMJ_RR_D2] = (L & 1) ? 1 : -1; k[SMJ_RR_Q1] = gi("jnt_qposadr", j);
     k[SMJ_RR_V1] = fb(gf("jnt_range", 2 * j + (L & 1))); k[SMJ_RR_V2] = fb(gf("jnt_margin", j));
     k[SMJ_RR_DIAG] = fb(gf("dof_invweight0", d));
@@ -246,7 +258,12 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
   };
 #define GI(field, name, idx) if (!geti(name, idx, &m.field)) return -3;
 #define GF(field, name, idx) if (!getf(name, idx, &m.field)) return -3;
-  GI(nq, "dims", 0) GI(nv, "dims", 1) GI(nu, "dims", 2) GI(nbody, "dims", 3) GI(njnt, "dims", 4) GI(ngeom, "dims", 5)
+  GI(nq_all, "dims", 0) GI(nv_all, "dims", 1) GI(nu, "dims", 2) GI(nbody_all, "dims", 3) GI(njnt, "dims", 4) GI(ngeom, "dims", 5)
+  m.nq = m.nq_all; m.nv = m.nv_all; m.nbody = m.nbody_all; m.nsat = 0;
+  if (b.find("k_nsat")) {   // satellites (model_fuse.find_satellites): the main part's counts index the lane tables
+    GI(nsat, "k_nsat", 0)
+    if (m.nsat > 0) { GI(nq, "k_main_dims", 0) GI(nv, "k_main_dims", 1) GI(nbody, "k_main_dims", 2) GI(njnt, "k_main_dims", 3) }
+  }
   GI(nsite, "dims", 6) GI(neq, "dims", 8) GI(nkey, "dims", 11) GI(npair, "dims", 12)
   GI(nlevel, "k_nlevel", 0) GI(nfric, "k_nfric", 0) GI(nlimit, "k_nlimit", 0) GI(nplanepair, "k_nplanepair", 0)
   GI(nldl, "k_nldl", 0) GI(imu_site, "sensor_imu_site", 0) GI(ngc, "k_ngc", 0) GI(nroot, "k_nroot", 0)
@@ -270,11 +287,16 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
     if (hint > 0 && ncaps > 1) first = 1;   // skip the standard variant: tall if the model fits it, else big
   }
   for (int v = first; v < ncaps && pick < 0; v++)
-    if (m.nv <= (caps[v].nvs ? caps[v].nvs : caps[v].nvp) && m.nbody <= caps[v].nbp && m.nq <= caps[v].nvp + 8 && m.nldl <= caps[v].nent * 64) pick = v;
+    if ((m.nsat > 0) == (caps[v].nsat > 0) && m.nsat <= caps[v].nsat &&
+        m.nv <= (caps[v].nvs ? caps[v].nvs : caps[v].nvp) && m.nbody <= caps[v].nbp && m.nq <= caps[v].nvp + 8 && m.nldl <= caps[v].nent * 64) pick = v;
+  if (pick < 0 && first > 0)   // (the hint skips the standard variant; a satellite model has its own builds)
+    for (int v = 0; v < first && pick < 0; v++)
+      if ((m.nsat > 0) == (caps[v].nsat > 0) && m.nsat <= caps[v].nsat &&
+          m.nv <= (caps[v].nvs ? caps[v].nvs : caps[v].nvp) && m.nbody <= caps[v].nbp && m.nq <= caps[v].nvp + 8 && m.nldl <= caps[v].nent * 64) pick = v;
   if (pick < 0 || m.nu > 16) {
     const SmjCaps& c = caps[ncaps - 1];
-    snprintf(buf, sizeof buf, "model exceeds kernel capacity (nv %d<=%d, nbody %d<=%d, nq %d<=%d, nu %d<=16, mass-matrix entries %d<=%d)",
-             m.nv, c.nvp, m.nbody, c.nbp, m.nq, c.nvp + 8, m.nu, m.nldl, c.nent * 64);
+    snprintf(buf, sizeof buf, "model exceeds kernel capacity (nv %d<=%d, nbody %d<=%d, nq %d<=%d, nu %d<=16, mass-matrix entries %d<=%d, satellites %d)",
+             m.nv, c.nvp, m.nbody, c.nbp, m.nq, c.nvp + 8, m.nu, m.nldl, c.nent * 64, m.nsat);
     err = buf;
     return -4;
   }
@@ -314,6 +336,28 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
   }
   SMJ_MODEL_F32(X)
 #undef X
+  m.nfric_main = m.nfric; m.nlimit_main = m.nlimit; m.k_satrec = nullptr;
+  if (m.nsat > 0) {
+    const SmjBlobEntry* ei = b.find("k_sat_i");
+    const SmjBlobEntry* ef = b.find("k_sat_f");
+    if (!ei || !ef || ei->dtype != 1 || ef->dtype != 0 || ei->nbytes < 32u * m.nsat || ef->nbytes < 8u * 44u * m.nsat) { err = "model blob: satellite tables missing"; return -3; }
+    std::vector<int> si(8 * (size_t)m.nsat), rec((size_t)m.nsat * SMJ_SR_STRIDE, 0);
+    memcpy(si.data(), b.p + ei->offset, 32u * m.nsat);
+    hosti["k_sat_i"] = si;
+    const double* sf = reinterpret_cast<const double*>(b.p + ef->offset);
+    for (int sidx = 0; sidx < m.nsat; sidx++) {
+      int* k = rec.data() + (size_t)sidx * SMJ_SR_STRIDE;
+      for (int q = 0; q < 8; q++) k[q] = si[8 * sidx + q];
+      for (int q = 0; q < 44; q++) { const float v = (float)sf[44 * sidx + q]; memcpy(&k[SMJ_SR_F + q], &v, 4); }
+    }
+    m.k_satrec = up.i32(rec);
+    if (!m.k_satrec) { err = "device allocation failed for k_satrec"; return -2; }
+    // static rows / limit slots of the main tree come first in their tables (dof / joint order)
+    m.nfric_main = 0;
+    for (int f = 0; f < m.nfric; f++) m.nfric_main += hosti["k_fric_dof"][f] < m.nv;
+    m.nlimit_main = 0;
+    for (int L = 0; L < m.nlimit; L++) m.nlimit_main += hosti["jnt_dofadr"][hosti["k_limit_jnt"][L]] < m.nv;
+  }
   {
     std::vector<int> rec = smj_build_lanerec(m, hosti, hostf, nent);
     m.k_lanerec = up.i32(rec);

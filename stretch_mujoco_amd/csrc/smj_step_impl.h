@@ -14,6 +14,7 @@
 #include <cstddef>
 #include "smj_model.h"
 #include "smj_wave.h"
+#include "smj_sat_mem.h"
 
 // NVS: columns the dof-indexed matrices (J, M, H) hold -- the 64-lane variant is built for 40, 52 or 64 dofs (smj_model.h)
 #define JS (NVS + 1)
@@ -37,7 +38,7 @@ struct TreeTmp {  // lives in the A region until A is built
 struct Smem {
   float MM[NVS][MS];    // strict upper: M; lower + diag: working copy -> L (unit, strictly lower), D on diag
   float Mdiag[NVP], Dinv[NVP];
-  float xpos[NBP][3], xquat[NBP][4], xmat[NBP][9], com[NBP][3];
+  float xpos[NBT][3], xquat[NBT][4], xmat[NBT][9], com[NBT][3];   // main bodies, then the satellites' (NBT = NBP without them)
   float xaxis[NVP][3], xanchor[NVP][3];
   float qpos[NVP + 8], qvel[NVP], ctrl[16], g[NVP], uu[NVP], w[NVP], qacc[NVP], warm[NVP], tmp[NVP];
   float act_force[16], act_len[16], act_vel[16], act_free[16];
@@ -52,7 +53,11 @@ struct Smem {
   // NEFC_P (NEFC_P + 1) / 2 floats, see A()).  In the standard variant the 80-row triangle (13 KB) ends inside the struct, so a PGS
   // launch needs no more LDS than a Newton launch (four workgroups per CU); the 160-row variants ask for the tail as dynamic
   // LDS (smj_lds_bytes).
+#if NSAT > 0
+  float J[NDR + 1][JS];   // dense Jacobian rows of the rows that touch the main tree (rows 0 .. nd-1 of a step); row NDR stays zero: the dense row of every other row
+#else
   float J[NEFC][JS];    // constraint Jacobian, transformed in place to Y = J L^-1
+#endif
   union {
     TreeTmp t;
     struct {                // collision: world frames of the geoms taking part in convex pairs (tree temporaries are dead)
@@ -71,16 +76,24 @@ struct Smem {
       float cd[NVP][6];     // cdof, so that both half-waves of the Jacobian fill can read any dof's motion axis
     } k;
     struct {                // Newton: the Hessian H = M + J' W J (or M - h*D of the integrator)
+#if NSAT > 0
+      float H[NXV][NXV + 1];   // main block + the dense extension of coupled satellites (smj_sat.h); the cone Hessians stay valid beside it (the satellites' blocks read them after the main block is stored)
+      float cH[NCON][36];
+#else
       union {               // the cone Hessians are consumed (as MFMA operands) before the Hessian of the same iteration is written
         float H[NVS][NVS + 1];
         float cH[NCON][36];   // cone Hessians of contacts in the middle zone
       };
+#endif
       // per-row solver registers (NRow) of rows 64..NEFC-1: the second row pass loads them at the start of a stage and
       // stores them back at its end, so that the (rare) second pass holds no registers across the Newton loop
       int rxi[3][NEFC > 64 ? NEFC - 64 : 1];      // indexed by row - 64
       float rxf[15][NEFC > 64 ? NEFC - 64 : 1];
     } n;
   } u;
+#if NSAT > 0
+  SatMem sat;
+#endif
   SMJ_DEV float* A(int cap) { return &J[cap][0]; }   // PGS: A = Y D^-1 Y' + R as a packed lower triangle of cap (cap + 1) / 2 floats behind the rows a step may use (cap = NEFC_P: the union's start)
 };
 // Row passes of the Newton path: rows 0..63 on lanes 0..63 (rb = 0), then rows 64..NEFC-1 on lanes 0..NEFC-65 (rb = 64), the
@@ -104,6 +117,9 @@ static inline int smj_pgs_rows_static() {
   return 0;
 }
 static inline size_t smj_lds_bytes(bool pgs) {
+#if NSAT > 0
+  return sizeof(Smem);   // (the satellite builds run Newton only)
+#endif
   const size_t a_wide = offsetof(Smem, u) + sizeof(float) * (NEFC_P * (NEFC_P + 1) / 2);      // packed triangle in the union
   const size_t a_sq = offsetof(Smem, J) + sizeof(float) * (NEFP * JS + NEFP * NEFP);           // 64 x 64 square from row 64 of J
   const size_t a_end = a_wide > a_sq ? a_wide : a_sq;
@@ -268,6 +284,7 @@ SMJ_DEV float impedance(const float* solimp, float pos, float margin) {
 
 #ifdef SMJ_EMUL
 static long smj_emul_sep_skips = 0;
+static long smj_emul_ext_steps = 0;
 #endif
 // ---------------------------------------------------------------------------------------------- the step
 struct StepKernel {
@@ -406,6 +423,9 @@ struct StepKernel {
       }
     }
     SYNC();
+#if NSAT > 0
+    LANES { for (int k = lane; k < (NDR + 1) * JS; k += 64) (&s.J[0][0])[k] = 0.f; }   // (row NDR: the dense row of every row without one)
+#endif
     // identity padding of the dof block nv..NVP-1, written once: the per-step mass-matrix entries never touch it, and the
     // Newton Hessian H = M + J'WJ / the dense M x products can then take MM as it is, with no `< nv` select per element
     LANES { if (lane >= M.nv && lane < NVS) s.MM[lane][lane] = 1.f; }
@@ -463,12 +483,18 @@ struct StepKernel {
       }
     }
     SYNC();
+#if NSAT > 0
+    sat_load_state();
+#endif
   }
   // State, counters and the post-step readout.  actuator_length / velocity and the base pose are those of the LAST FORWARD
   // PASS -- what MjData holds after mj_step, which integrates after computing them (pull_status reads exactly these fields,
   // mujoco_server.py:465-515, :124-129): they lag qpos by one step, as in the reference.
   SMJ_DEV void store_state(int nsteps) {
     const long ld = S.ld;
+#if NSAT > 0
+    sat_store_state();
+#endif
     const int b = 1;  // base_link is the first body after the world
     const float bx = s.xpos[b][0], by = s.xpos[b][1], bth = atan2f(s.xmat[b][3], s.xmat[b][0]);
     if (S.stage) {
@@ -2738,6 +2764,21 @@ struct StepKernel {
     SYNC();
   }
 
+  // the dense Jacobian row of constraint row `row` (satellite builds: rows beyond the dense ones share the zero row NDR)
+  SMJ_DEV const float* jrow(int row) const {
+#if NSAT > 0
+    return s.J[row < NDR ? row : NDR];
+#else
+    return s.J[row];
+#endif
+  }
+  SMJ_DEV int ndense() const {
+#if NSAT > 0
+    return nd;
+#else
+    return nefc;
+#endif
+  }
   // contact regularised-cone mu  [MJ] con->mu = friction[0]*sqrt(R[1]/R[0])
   SMJ_DEV float contact_mu(int c) const {
     const int i = s.cefc[c];
@@ -3298,8 +3339,9 @@ struct StepKernel {
     PL<float> hi0, lo0, hi1, lo1;
     LANES {
       const int row = lane + rb < NEFC ? lane + rb : 0;
+      const float* jr = jrow(row);
 #pragma unroll
-      for (int k = 0; k < NVS; k++) a[lane][k] = s.J[row][k];
+      for (int k = 0; k < NVS; k++) a[lane][k] = jr[k];
       hi0[lane] = -sub[lane]; lo0[lane] = 0.f; hi1[lane] = 0.f; lo1[lane] = 0.f;
     }
 #pragma unroll
@@ -3322,6 +3364,24 @@ struct StepKernel {
         }
       }
     }
+#if NSAT > 0
+    // the satellite columns of the row, in the same compensated sum (x = the satellites' qacc)
+    LANES {
+      const int row = lane + rb < NEFC ? lane + rb : 0;
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int si = s.sat.esat[row][u];
+        if (si >= 0 && lane + rb < NEFC)
+          for (int k = 0; k < 6; k++) {
+            const float av = s.sat.Js[row][u][k], xv = s.sat.x[SX_QA][si][k];
+            const float p = av * xv, pe = fmaf(av, xv, -p);
+            const float t = hi0[lane] + p, z = t - hi0[lane];
+            const float se = (hi0[lane] - (t - z)) + (p - z);
+            hi0[lane] = t; lo0[lane] += se + pe;
+          }
+      }
+    }
+#endif
     LANES {
       const float t = hi0[lane] + hi1[lane], z = t - hi0[lane];
       const float se = (hi0[lane] - (t - z)) + (hi1[lane] - z);
@@ -3330,10 +3390,10 @@ struct StepKernel {
   }
   // out[dof] = sum_rows J[row][dof] * f[row]   (lane = dof, f lane-resident over rows), sixteen rows per pass
   SMJ_DEV void matT_J(PL<float>& out, const NRow& nr0) {
-    const int ne = nefc;
+    const int ne = ndense();
     LANES { out[lane] = 0.f; }
 #pragma unroll
-    for (int r0 = 0; r0 < NEFC; r0 += 16) {
+    for (int r0 = 0; r0 < NDR; r0 += 16) {   // (NDR = NEFC unless the build has satellites: only rows 0 .. nd-1 have dense columns)
       if (r0 < 64 ? r0 < ne : __builtin_expect(r0 < ne, 0)) {
         PL<float[16]> a;
         LANES {
@@ -3359,8 +3419,9 @@ struct StepKernel {
     PL<float[NVS]> a;
     LANES {
       const int row = lane + rb < NEFC ? lane + rb : 0;
+      const float* jr = jrow(row);
 #pragma unroll
-      for (int k = 0; k < NVS; k++) a[lane][k] = s.J[row][k];
+      for (int k = 0; k < NVS; k++) a[lane][k] = jr[k];
     }
     PL<F2> acc;
     LANES { acc[lane] = F2{0.f, 0.f}; }
@@ -3571,6 +3632,16 @@ struct StepKernel {
       LANES {
         qacc_r[lane] = lane < nv ? qacc[lane] : 0.f;
         if (lane < nv) { s.qacc[lane] = qacc[lane]; s.warm[lane] = qacc[lane]; s.tmp[lane] = g_r[lane]; }
+#if NSAT > 0
+        if (lane >= 32 && lane - 32 < M.nsat) {   // the satellites: Mb^-1 g on their own lanes
+          const int si = lane - 32;
+          float A[21], x[6];
+          for (int k = 0; k < 21; k++) A[k] = s.sat.Mb[si][k];
+          for (int k = 0; k < 6; k++) { x[k] = s.sat.x[SX_G][si][k]; s.sat.x[SX_TMP][si][k] = x[k]; }
+          sat_solve6(A, x);
+          for (int k = 0; k < 6; k++) s.sat.x[SX_QA][si][k] = k < s.sat.ndof[si] ? x[k] : 0.f;
+        }
+#endif
       }
       niter = 0;
       SYNC();
@@ -3581,8 +3652,13 @@ struct StepKernel {
       const int row = lane + rb;
       float vel = 0;
       const bool on = row < ne;
-      if (on)
-        for (int k = 0; k < nv; k++) vel += s.J[row][k] * s.qvel[k];
+      if (on) {
+        const float* jr = jrow(row);
+        for (int k = 0; k < nv; k++) vel += jr[k] * s.qvel[k];
+#if NSAT > 0
+        vel += sat_jdot(row, SX_V);
+#endif
+      }
       nr.type[lane] = on ? s.etype[row] : CT_NONE;
       nr.R[lane] = on ? s.eR[row] : 1.f;
       nr.D[lane] = on ? 1.0f / s.eR[row] : 0.f;
@@ -3600,11 +3676,21 @@ struct StepKernel {
       }
       if (dbg && row < NEFC) s.earef[row] = nr.aref[lane];
     } ROWS_END_RW(rb)
-    const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
+#if NSAT > 0
+    const int nvt = M.nv_all;   // ([MJ] the solver's scale and tolerances use the whole model's dof count)
+#else
+    const int nvt = nv;
+#endif
+    const float scale = 1.0f / (M.meaninertia * (float)(nvt > 1 ? nvt : 1));
     // start from qacc_warmstart (MuJoCo also tries qacc_smooth and keeps the cheaper; Newton reaches the same unique
     // optimum from either, so the extra M^-1 g solve is skipped)
     LANES { qacc[lane] = (lane < nv && M.warmstart) ? s.warm[lane] : 0.f; }
     mat_M(Ma, qacc);
+#if NSAT > 0
+    if (!M.warmstart) { LANES { if (lane >= 32 && lane - 32 < M.nsat) for (int k = 0; k < 6; k++) s.sat.x[SX_QA][lane - 32][k] = 0.f; } }
+    sat_matM(SX_MA, SX_QA);
+    SYNC();
+#endif
     ROWS_BEGIN(rb, ne) mat_J_exact(nr.jar, qacc, nr.aref, rb); ROWS_END_RW(rb)
     float cost = 0;
     TICK(SMJ_PROF_WARM)
@@ -3616,7 +3702,13 @@ struct StepKernel {
       float gauss;
       {
         PL<float> gs;
-        LANES { gs[lane] = lane < nv ? qacc[lane] * (0.5f * Ma[lane] - g_r[lane]) : 0.f; }
+        LANES {
+          gs[lane] = lane < nv ? qacc[lane] * (0.5f * Ma[lane] - g_r[lane]) : 0.f;
+#if NSAT > 0
+          if (lane >= 32 && lane - 32 < M.nsat)
+            for (int k = 0; k < 6; k++) gs[lane] += s.sat.x[SX_QA][lane - 32][k] * (0.5f * s.sat.x[SX_MA][lane - 32][k] - s.sat.x[SX_G][lane - 32][k]);
+#endif
+        }
         gauss = wave_sum(gs);
       }
       cost += gauss;
@@ -3624,11 +3716,25 @@ struct StepKernel {
       TICK(SMJ_PROF_N_UPDATE)
       // gradient = Ma - g - J'f   (lanes = dofs; force broadcast by readlane)
       matT_J(tmpv, nr0);
+#if NSAT > 0
+      sat_JTf();
+#endif
       PL<float> g2;
       PL<int> gsig;
       LANES {
         grad[lane] = lane < nv ? Ma[lane] - g_r[lane] - tmpv[lane] : 0.f; g2[lane] = grad[lane] * grad[lane];
         gsig[lane] = fabsf(grad[lane]) > SMJ_GRAD_NOISE * (fabsf(Ma[lane]) + fabsf(g_r[lane]) + fabsf(tmpv[lane]));
+#if NSAT > 0
+        if (lane >= 32 && lane - 32 < M.nsat) {
+          const int si = lane - 32;
+          for (int k = 0; k < 6; k++) {
+            const float ma = s.sat.x[SX_MA][si][k], gg = s.sat.x[SX_G][si][k], jf = s.sat.x[SX_TMP][si][k], gr = k < s.sat.ndof[si] ? ma - gg - jf : 0.f;
+            s.sat.x[SX_GRAD][si][k] = gr;
+            g2[lane] += gr * gr;
+            gsig[lane] |= fabsf(gr) > SMJ_GRAD_NOISE * (fabsf(ma) + fabsf(gg) + fabsf(jf));
+          }
+        }
+#endif
       }
       const float gnorm = sqrtf(wave_sum(g2));
       // [MJ] "gradient < tolerance" ends the iteration before the Hessian is built.  fp32: 1e-8 is below the rounding of the
@@ -3671,7 +3777,7 @@ struct StepKernel {
       // latency nor the MFMA latency of one tile serialises the others.
       {
         constexpr int NT = (NVS + 15) / 16, NTRI = NT * (NT + 1) / 2, KB = NVP == 32 ? 16 : 8;   // (the last tile may read past column NVS: those products land in rows / columns >= NVS of H, which are not stored)
-        const int ksteps = (ne + 3) >> 2;
+        const int ksteps = (ndense() + 3) >> 2;   // (rows beyond the dense ones have no main columns)
         PL<F4v> acc[NTRI];
         LANES {
 #pragma unroll
@@ -3680,14 +3786,14 @@ struct StepKernel {
         }
         // rows 0..63 in batches of KB k-steps, rows 64..NEFC-1 (rare) in further ones, entered only by an env that has them
 #pragma unroll
-        for (int kb = 0; kb < NEFC / 4; kb += KB) {
+        for (int kb = 0; kb < NDR / 4; kb += KB) {
           if (kb < 16 ? kb < ksteps : __builtin_expect(kb < ksteps, 0)) {
             PL<float[KB]> b[NT], wk;
             LANES {
 #pragma unroll
               for (int ks = 0; ks < KB; ks++) {
                 const int k = 4 * (kb + ks) + (lane >> 4), c = lane & 15;
-                if (kb + ks < NEFC / 4) {                      // compile-time: k stays inside J
+                if (kb + ks < NDR / 4) {                       // compile-time: k stays inside J
                   // unconditional: rows >= ne of J are zero, and the k-steps beyond ne are skipped below anyway
                   wk[lane][ks] = s.ediag[k];
 #pragma unroll
@@ -3697,7 +3803,7 @@ struct StepKernel {
             }
 #pragma unroll
             for (int ks = 0; ks < KB; ks++) {
-              if (kb + ks < ksteps && kb + ks < NEFC / 4) {
+              if (kb + ks < ksteps && kb + ks < NDR / 4) {
                 PL<float> pa[NT], pb[NT];
                 LANES {
 #pragma unroll
@@ -3720,6 +3826,7 @@ struct StepKernel {
           const int c = ffs64(cm);
           cm &= cm - 1;
           const int r0 = uni(s.cefc[c]), dim = uni(s.cdim[c]);
+          if (r0 >= ndense()) continue;   // (satellite builds: a contact that touches no main body has no main columns)
           for (int q0 = 0; q0 < dim; q0 += 4) {
             nks++;
             PL<float> pa[NT], pb[NT];
@@ -3733,11 +3840,11 @@ struct StepKernel {
               for (int t = 0; t < NT; t++) {
                 float jv[6], av = 0.f;
 #pragma unroll
-                for (int p = 0; p < 6; p++) jv[p] = s.J[r0 + p < NEFC ? r0 + p : NEFC - 1][16 * t + col];
+                for (int p = 0; p < 6; p++) jv[p] = s.J[r0 + p < NDR ? r0 + p : NDR - 1][16 * t + col];
 #pragma unroll
                 for (int p = 0; p < 6; p++) av += hq[p] * jv[p];
                 pa[t][lane] = av;
-                pb[t][lane] = on * s.J[r0 + qc < NEFC ? r0 + qc : NEFC - 1][16 * t + col];
+                pb[t][lane] = on * s.J[r0 + qc < NDR ? r0 + qc : NDR - 1][16 * t + col];
               }
             }
 #pragma unroll
@@ -3769,21 +3876,63 @@ struct StepKernel {
       if (prof) pc[SMJ_PROF_H_STORE] += (float)(smj_clock() - t0);   // (whole stage: k-steps + cone + store)
       TICK(SMJ_PROF_N_HMFMA)
       LANES { search[lane] = lane < nv ? grad[lane] : 0.f; }
+#if NSAT > 0
+      // the satellites' blocks; the coupled ones (contacts with the main tree / with each other) extend the dense system of this step
+      sat_hessian(conemask);
+      SYNC();
+      if (next_sat > 0) {
+        sat_extend_hessian(next_sat, conemask);
+        LANES {
+          if (lane >= NVS && lane < NVS + 6 * next_sat) { const int e = (lane - NVS) / 6; search[lane] = s.sat.x[SX_GRAD][s.sat.xs[e]][lane - NVS - 6 * e]; }
+        }
+        gj_solve_ext(search, NVS + 6 * next_sat);
+        LANES {
+          if (lane >= NVS && lane < NVS + 6 * next_sat) { const int e = (lane - NVS) / 6; s.sat.x[SX_SRCH][s.sat.xs[e]][lane - NVS - 6 * e] = -search[lane]; }
+        }
+      } else solve_H(search);
+      sat_solve_own();
+      SYNC();
+#else
       solve_H(search);
+#endif
       TICK(SMJ_PROF_N_FACTSOLVE)
       PL<float> sq;
-      LANES { search[lane] = lane < nv ? -search[lane] : 0.f; sq[lane] = search[lane] * search[lane]; }
+      LANES {
+        search[lane] = lane < nv ? -search[lane] : 0.f; sq[lane] = search[lane] * search[lane];
+#if NSAT > 0
+        if (lane >= 32 && lane - 32 < M.nsat)
+          for (int k = 0; k < 6; k++) sq[lane] += s.sat.x[SX_SRCH][lane - 32][k] * s.sat.x[SX_SRCH][lane - 32][k];
+#endif
+      }
       const float snorm = sqrtf(wave_sum(sq));
       TICK(SMJ_PROF_N_SOLVE)
       // line-search preparation  ([MJ] CGprepare)
       mat_M(Mv, search);
+#if NSAT > 0
+      sat_matM(SX_MV, SX_SRCH);
+      SYNC();
+      ROWS_BEGIN(rb, ne) {
+        mat_J(nr.jv, search, rb);
+        LANES { if (lane + rb < ne) nr.jv[lane] += sat_jdot(lane + rb, SX_SRCH); }
+      } ROWS_END_RW(rb)
+#else
       ROWS_BEGIN(rb, ne) mat_J(nr.jv, search, rb); ROWS_END_RW(rb)
+#endif
       float qg[3];
       {
         PL<float> a1, a2;
         LANES {
           a1[lane] = lane < nv ? search[lane] * (Ma[lane] - g_r[lane]) : 0.f;
           a2[lane] = lane < nv ? 0.5f * search[lane] * Mv[lane] : 0.f;
+#if NSAT > 0
+          if (lane >= 32 && lane - 32 < M.nsat) {
+            const int si = lane - 32;
+            for (int k = 0; k < 6; k++) {
+              a1[lane] += s.sat.x[SX_SRCH][si][k] * (s.sat.x[SX_MA][si][k] - s.sat.x[SX_G][si][k]);
+              a2[lane] += 0.5f * s.sat.x[SX_SRCH][si][k] * s.sat.x[SX_MV][si][k];
+            }
+          }
+#endif
         }
         qg[0] = gauss; qg[1] = wave_sum(a1); qg[2] = wave_sum(a2);
       }
@@ -3819,14 +3968,20 @@ struct StepKernel {
       // the decrease is far below one ulp of the cost.
       float alpha = 0, d10 = 0;
       {
-        const float gtol = M.tolerance * M.ls_tolerance * snorm * M.meaninertia * (float)(nv > 1 ? nv : 1);
+        const float gtol = M.tolerance * M.ls_tolerance * snorm * M.meaninertia * (float)(nvt > 1 ? nvt : 1);
         // the derivatives at 0 need no evaluation along the line: d1(0) = grad . search, and with the exact Hessian H search =
         // -grad gives d2(0) = search' H search = -d1(0) -- the first trial point is the full Newton step (MuJoCo evaluates at 0
         // because its CG directions share the code; one evaluation of ~2.3 per iteration saved)
         float d1, d2, lo = 0, hi = -1;
         {
           PL<float> gs;
-          LANES { gs[lane] = lane < nv ? grad[lane] * search[lane] : 0.f; }
+          LANES {
+            gs[lane] = lane < nv ? grad[lane] * search[lane] : 0.f;
+#if NSAT > 0
+            if (lane >= 32 && lane - 32 < M.nsat)
+              for (int k = 0; k < 6; k++) gs[lane] += s.sat.x[SX_GRAD][lane - 32][k] * s.sat.x[SX_SRCH][lane - 32][k];
+#endif
+          }
           d1 = wave_sum(gs); d2 = -d1;
         }
         d10 = d1;
@@ -3854,8 +4009,17 @@ struct StepKernel {
       TICK(SMJ_PROF_N_LS)
       iter++;
       if (alpha == 0.f) break;
-      LANES { qacc[lane] += alpha * search[lane]; Ma[lane] += alpha * Mv[lane]; }
-      if (M.nroot > 1) {
+      LANES {
+        qacc[lane] += alpha * search[lane]; Ma[lane] += alpha * Mv[lane];
+#if NSAT > 0
+        if (lane >= 32 && lane - 32 < M.nsat)
+          for (int k = 0; k < 6; k++) { s.sat.x[SX_QA][lane - 32][k] += alpha * s.sat.x[SX_SRCH][lane - 32][k]; s.sat.x[SX_MA][lane - 32][k] += alpha * s.sat.x[SX_MV][lane - 32][k]; }
+#endif
+      }
+#if NSAT > 0
+      SYNC();
+#endif
+      if (NSAT > 0 || M.nroot > 1) {
         // scenes with free objects: the residual is re-evaluated from the new qacc with error-free transformations instead
         // of being advanced by alpha * jv.  jv = J search is a plain fp32 product (error ~1e-5 of terms that cancel to 1e-2),
         // and with D = 1/R up to 1e4 that is 0.1 N of force noise per iteration -- invisible on the 20 kg robot, 5 % of the
@@ -3875,10 +4039,18 @@ struct StepKernel {
     if (!at_update) {
       newton_update(nr0, false);
       matT_J(tmpv, nr0);
+#if NSAT > 0
+      SYNC();
+      sat_JTf();
+#endif
     }
     LANES {
       qacc_r[lane] = lane < nv ? qacc[lane] : 0.f;
       if (lane < nv) { s.qacc[lane] = qacc[lane]; s.warm[lane] = qacc[lane]; s.tmp[lane] = g_r[lane] + tmpv[lane]; }
+#if NSAT > 0
+      if (lane >= 32 && lane - 32 < M.nsat)   // qfrc_smooth + qfrc_constraint of the satellite: the integrator's right-hand side
+        for (int k = 0; k < 6; k++) s.sat.x[SX_TMP][lane - 32][k] += s.sat.x[SX_G][lane - 32][k];
+#endif
     }
     SYNC();
     if (dbg && S.debug) {
@@ -3901,7 +4073,11 @@ struct StepKernel {
     LANES {
       for (int k = lane; k < NVS * (NVS + 1); k += 64) {
         const int r = k / (NVS + 1), c = k - r * (NVS + 1);
+#if NSAT > 0
+        s.u.n.H[r][c] = (r == c && r >= M.nv) ? 1.f : 0.f;   // (the row stride of H is that of the extended system here)
+#else
         (&s.u.n.H[0][0])[k] = (r == c && r >= M.nv) ? 1.f : 0.f;
+#endif
       }
     }
     SYNC();
@@ -3962,12 +4138,18 @@ struct StepKernel {
       if (lane < nv) { const float v = s.qvel[lane]; b |= !(fabsf(v) < 1e10f); }
       bad[lane] = b;
     }
+#if NSAT > 0
+    sat_integrate(bad);
+#endif
     if (wave_ballot(bad) != 0) {
       flags |= SMJ_FLAG_BAD_STATE;
       LANES {
         for (int k = lane; k < M.nq; k += 64) s.qpos[k] = M.qpos0[k];
         if (lane < nv) { s.qvel[lane] = 0.f; s.warm[lane] = 0.f; }
       }
+#if NSAT > 0
+      sat_reset_state();
+#endif
       SYNC();
     }
   }
@@ -4016,7 +4198,7 @@ struct StepKernel {
     if (S.stage) {   // contiguous: 12 words per body
       float* st = stage_row() + S.lay.xpose;
       LANES {
-        for (int k = lane; k < 12 * M.nbody; k += 64) {
+        for (int k = lane; k < 12 * (M.nbody + M.nsat); k += 64) {
           const int b = k / 12, c = k - 12 * b;
           st[k] = c < 3 ? s.xpos[b][c] : s.xmat[b][c - 3];
         }
@@ -4025,7 +4207,7 @@ struct StepKernel {
     }
     if (!S.xpose) return;
     LANES {
-      if (lane < M.nbody) {
+      if (lane < M.nbody + M.nsat) {
         for (int k = 0; k < 3; k++) S.xpose[(long)(12 * lane + k) * S.ld + env] = s.xpos[lane][k];
         for (int k = 0; k < 9; k++) S.xpose[(long)(12 * lane + 3 + k) * S.ld + env] = s.xmat[lane][k];
       }
@@ -4060,6 +4242,10 @@ struct StepKernel {
     }
   }
 
+#if NSAT > 0
+#include "smj_sat.h"
+#endif
+
   // ------------------------------------------------------------------ driver
   SMJ_DEV void run(int nsteps, unsigned read_flags) {
     const int want_imu = read_flags & 1;
@@ -4076,6 +4262,9 @@ struct StepKernel {
     for (int st = 0; st < nsteps; st++) {
       const bool last = st == nsteps - 1;
       kinematics();
+#if NSAT > 0
+      sat_forward();   // pose, mass block, smooth forces of every satellite (one lane each)
+#endif
       if (last && (read_flags & 4)) dump_poses();
       TICK(SMJ_PROF_KIN)
       com_crb();
@@ -4089,17 +4278,31 @@ struct StepKernel {
       collision_convex(pc, prof);
       if (last) dump_contacts();
       TICK(SMJ_PROF_COLLISION)
+#if NSAT > 0
+      make_constraint_sat();
+#else
       if (M.solver != 2) nefc = NEFC;   // PGS: the A of a step with at most 64 rows sits in rows 64.. of J (solve<false>) -- have them cleared
       make_constraint();
+#endif
       TICK(SMJ_PROF_MAKECON)
       if (S.redo && !S.redo_worker && (flags & (SMJ_FLAG_EFC_OVERFLOW | SMJ_FLAG_CON_OVERFLOW))) {
         escalate(st);
         if (S.cost) { const int cst = (int)((smj_clock() - tlaunch) >> 6); LANES { if (lane == 0) st_coh(&S.cost[env], step_base ? ld_coh(&S.cost[env]) + cst : cst); } }
         return;
       }
+#if NSAT > 0
+      solve_newton(last, pc, t0, prof);   // (the satellite builds run the model's own solver only; smj_step refuses PGS for them)
+      if (last && S.debug) {
+        LANES {
+          if (lane >= 32 && lane - 32 < M.nsat)
+            for (int k = 0; k < 6; k++) S.debug[(SMJ_DBG_SATQACC + 6 * (lane - 32) + k) * S.ld + env] = s.sat.x[SX_QA][lane - 32][k];
+        }
+      }
+#else
       if (M.solver == 2) solve_newton(last, pc, t0, prof);
       else if (nefc > NEFP) solve<true>(last, pc, t0, prof);
       else solve<false>(last, pc, t0, prof);
+#endif
       if (last && want_imu) imu();
       TICK(SMJ_PROF_POST)
       integrate();

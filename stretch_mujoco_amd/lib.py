@@ -21,17 +21,35 @@ EXPORTS = ("smj_create", "smj_destroy", "smj_bind", "smj_dims", "smj_reset", "sm
 _lib = None
 
 
-def debug_layout(nvp: int = 32, ncon: int = 16) -> dict:
+def debug_layout(nvp: int = 32, ncon: int = 16, nsat: int = 0) -> dict:
     """Offsets of the optional debug dump (SMJ_SLOT_DEBUG) for a kernel variant with `nvp` dof lanes and `ncon` contact slots
-    (csrc/smj_model.h, smj_debug_layout): standard variant 32 / 16, big variant 64 / 48."""
+    (csrc/smj_model.h, smj_debug_layout): standard variant 32 / 16, big variant 64 / 48; `nsat`: satellite capacity of the
+    satellite builds (their qacc follows the classic layout, 6 per satellite)."""
     L, o = {}, 0
     for name, n in (("qm", nvp * nvp), ("g", nvp), ("qacc", nvp), ("efc_force", 64), ("efc_b", 64), ("efc_r", 64), ("efc_aref", 64),
                     ("ar_diag", 64), ("xpos", 96), ("qfrc_bias", nvp), ("qfrc_passive", nvp), ("qfrc_act", nvp), ("con", 8 * ncon),
-                    ("ar", 64 * 64)):
+                    ("ar", 64 * 64), ("satqacc", 6 * nsat)):
         L[name] = o
         o += n
     L["floats"] = o
     return L
+
+
+def full_qacc(debug, layout: dict, model: dict):
+    """qacc of the whole model [nv, B] from a debug dump: the main tree's dofs from the classic slot, the satellites' from theirs."""
+    import numpy as np
+
+    nsat = int(np.asarray(model.get("k_nsat", [0])).ravel()[0])
+    if nsat == 0:
+        nv = int(model["dims"][1])
+        return debug[layout["qacc"]:layout["qacc"] + nv]
+    nvm = int(model["k_main_dims"][1])
+    parts = [debug[layout["qacc"]:layout["qacc"] + nvm]]
+    si = np.asarray(model["k_sat_i"]).reshape(nsat, -1)
+    for k in range(nsat):
+        parts.append(debug[layout["satqacc"] + 6 * k:layout["satqacc"] + 6 * k + int(si[k, 4])])
+    cat = np.concatenate if isinstance(parts[0], np.ndarray) else __import__("torch").cat
+    return cat(parts, 0)
 
 
 class SmjError(RuntimeError):

@@ -109,12 +109,20 @@ def fuse_static_bodies(m: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     return f
 
 
-def kernel_tables(f: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
-    """Lane-indexed scheduling tables for csrc/smj_kernels.hip (added in place, `k_` prefix)."""
-    nb, nv = len(f["body_parentid"]), len(f["dof_bodyid"])
+def kernel_tables(f: Dict[str, np.ndarray], nsat: int = 0) -> Dict[str, np.ndarray]:
+    """Lane-indexed scheduling tables for csrc/smj_kernels.hip (added in place, `k_` prefix).
+
+    nsat > 0: the last `nsat` bodies are SATELLITES (find_satellites) -- the tree tables below then describe the MAIN part only
+    (bodies / dofs / joints before the first satellite: lane = body and lane = dof stages of the kernels); the satellites get
+    one record each (`k_sat_i`, `k_sat_f`).  Row tables (friction-loss dofs, limited joints), geoms and pairs cover everything."""
+    nb_all, nv_all = len(f["body_parentid"]), len(f["dof_bodyid"])
+    nb = nb_all - nsat
+    nv = int(f["body_dofadr"][nb]) if nsat else nv_all
     if nb > 64 or nv > 64:
         raise ValueError("kernels map bodies / dofs to the 64 lanes of one wavefront")
-    par = f["body_parentid"]
+    if nsat:
+        _satellite_tables(f, nb, nv, nsat)
+    par = np.asarray(f["body_parentid"][:nb])
     level = np.zeros(nb, np.int32)
     for b in range(1, nb):
         level[b] = level[par[b]] + 1
@@ -166,7 +174,7 @@ def kernel_tables(f: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
             ei.append(i); ej.append(j); j = dpar[j]
     pad = (-len(ei)) % 64
     f["k_ldl_i"] = np.array(ei + [-1] * pad, np.int32); f["k_ldl_j"] = np.array(ej + [0] * pad, np.int32)
-    f["k_fric_dof"] = np.array([k for k in range(nv) if f["dof_frictionloss"][k] > 0] + [0], np.int32)
+    f["k_fric_dof"] = np.array([k for k in range(nv_all) if f["dof_frictionloss"][k] > 0] + [0], np.int32)
     f["k_nfric"] = np.array([int((f["dof_frictionloss"] > 0).sum())], np.int32)
     lim = [j for j in range(len(f["jnt_type"])) if f["jnt_limited"][j] and f["jnt_type"][j] != JNT_FREE]
     f["k_limit_jnt"] = np.array(lim + [0], np.int32); f["k_nlimit"] = np.array([len(lim)], np.int32)
@@ -224,7 +232,7 @@ def kernel_tables(f: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
         assert all(_is_desc(par, x, b) for x in range(b, b + size[b])), "bodies must be in depth-first order"
     f["k_body_subtreesize"] = size
     f["k_maxsubtree"] = np.array([int(max([f["k_body_subtreesize"][b] for b in range(1, nb)] + [1]))], np.int32)
-    roots = [b for b in range(1, nb) if par[b] == 0 and f["body_rootid"][b] == b and f["body_subtreemass"][b] > 0]
+    roots = [b for b in range(1, nb) if par[b] == 0 and f["body_rootid"][b] == b and f["body_subtreemass"][b] > 0]   # (main trees)
     f["k_root_list"] = np.array(roots + [0], np.int32); f["k_nroot"] = np.array([len(roots)], np.int32)
     gcb = [b for b in range(1, nb) if f["body_gcmass"][b] != 0]
     f["k_gc_body"] = np.array(gcb + [0], np.int32); f["k_ngc"] = np.array([len(gcb)], np.int32)
@@ -247,6 +255,10 @@ def kernel_tables(f: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     f["k_dof_qposadr"] = qadr
     # static actuator moments (joint and fixed-tendon transmissions have configuration-independent moments)
     nu = len(f["actuator_trntype"])
+    for a in range(nu):   # (satellites carry no actuators: find_satellites)
+        js = [f["actuator_trnid"][a]] if f["actuator_trntype"][a] == 0 else \
+            [f["wrap_objid"][w] for w in range(f["tendon_adr"][f["actuator_trnid"][a]], f["tendon_adr"][f["actuator_trnid"][a]] + f["tendon_num"][f["actuator_trnid"][a]])]
+        assert all(f["jnt_dofadr"][j] < nv for j in js), "actuator on a satellite joint"
     mom = np.zeros((max(nu, 1), nv))
     for a in range(nu):
         gear = f["actuator_gear"][a]
@@ -322,16 +334,94 @@ def kernel_tables(f: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     return f
 
 
+# ----------------------------------------------------------------------------- satellites
+# A kitchen is the robot plus many SMALL mechanisms that only meet it through contacts: free objects (6 dofs each) and the
+# doors / drawers / knobs of fixtures (one hinge or slide each, on a body welded to the world).  Their mass matrix blocks are
+# independent of the robot's and of each other's, so the kernels keep them out of the dense 32-column robot problem: the main
+# tree runs lane = body / lane = dof as before, every satellite is ONE lane with a record of its own (kinematics, inertia,
+# passive forces in closed form), and the constraint solver eliminates the satellite blocks from the Newton system (Schur
+# complement on the rows that couple them to the robot) -- csrc/smj_sat.h.
+SAT_MAX = 32
+SAT_I = dict(body=0, jtype=1, qadr=2, dadr=3, ndof=4, jnt=5, stride=8)
+SAT_F = dict(pos=0, quat=3, jpos=7, jaxis=10, q0=13, inl=14, arm=24, damp=30, stiff=36, spring=37, gcmass=38, gcipos=39, stride=44)
+
+
+def find_satellites(f: Dict[str, np.ndarray], limit: int = SAT_MAX) -> int:
+    """Number of trailing bodies of the fused model that can run as satellites: children of the world without children of their
+    own, exactly one joint (free, hinge or slide), no actuator / equality / tendon on it, no sensor site or camera on the body.
+    Only a SUFFIX of the body list qualifies (the main tree's bodies, joints, dofs and qpos entries then form a prefix, which is
+    what the lane tables index); a free object declared before the robot simply stays in the main part."""
+    nb = len(f["body_parentid"])
+    par = f["body_parentid"]
+    parents = set(int(p) for p in par[1:])
+    busy = set()
+    for a in range(len(f["actuator_trntype"])):
+        t = int(f["actuator_trnid"][a])
+        if f["actuator_trntype"][a] == 0:
+            busy.add(t)
+        else:
+            busy.update(int(f["wrap_objid"][w]) for w in range(f["tendon_adr"][t], f["tendon_adr"][t] + f["tendon_num"][t]))
+    for w in range(len(f["wrap_objid"])):
+        busy.add(int(f["wrap_objid"][w]))
+    for e in range(len(f["eq_obj1id"])):
+        busy.add(int(f["eq_obj1id"][e]))
+        if f["eq_obj2id"][e] >= 0:
+            busy.add(int(f["eq_obj2id"][e]))
+    sens = set(int(f["site_bodyid"][s]) for s in list(f.get("sensor_lidar_site", [])))
+    if len(f.get("sensor_imu_site", [])) and int(f["sensor_imu_site"][0]) >= 0:
+        sens.add(int(f["site_bodyid"][int(f["sensor_imu_site"][0])]))
+    sens.update(int(b) for b in f.get("cam_bodyid", []))
+    n = 0
+    for b in range(nb - 1, 0, -1):
+        j = int(f["body_jntadr"][b])
+        ok = (par[b] == 0 and b not in parents and f["body_jntnum"][b] == 1 and int(f["jnt_type"][j]) in (JNT_FREE, 2, 3)
+              and j not in busy and b not in sens and f["body_mass"][b] > 0)
+        if not ok or n >= limit:
+            break
+        n += 1
+    return n if n < nb - 1 else max(0, nb - 2)   # (keep at least one body in the main part)
+
+
+def _satellite_tables(f, nb, nv, nsat):
+    """k_sat_i / k_sat_f: one record per satellite (body nb + s), in body order; k_main_dims = the main part's nq, nv, nbody, njnt."""
+    si = np.zeros((nsat, SAT_I["stride"]), np.int32)
+    sf = np.zeros((nsat, SAT_F["stride"]))
+    nq = int(f["jnt_qposadr"][int(f["body_jntadr"][nb])])
+    njnt = int(f["body_jntadr"][nb])
+    for s in range(nsat):
+        b = nb + s
+        j = int(f["body_jntadr"][b]); jt = int(f["jnt_type"][j]); qa = int(f["jnt_qposadr"][j]); da = int(f["jnt_dofadr"][j])
+        nd = 6 if jt == JNT_FREE else 1
+        si[s, :6] = [b, jt, qa, da, nd, j]
+        r = sf[s]
+        r[0:3] = f["body_pos"][b]; r[3:7] = f["body_quat"][b]; r[7:10] = f["jnt_pos"][j]; r[10:13] = f["jnt_axis"][j]
+        r[13] = f["qpos0"][qa] if jt != JNT_FREE else 0.0
+        R = quat2mat(f["body_iquat"][b])
+        I = R @ np.diag(f["body_inertia"][b]) @ R.T
+        r[14:20] = [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]]; r[20:23] = f["body_ipos"][b]; r[23] = f["body_mass"][b]
+        r[24:24 + nd] = f["dof_armature"][da:da + nd]; r[30:30 + nd] = f["dof_damping"][da:da + nd]
+        if jt != JNT_FREE:
+            r[36] = f["jnt_stiffness"][j]; r[37] = f["qpos_spring"][qa]
+        r[38] = f["body_gcmass"][b]; r[39:42] = f["body_gcipos"][b]
+    f["k_sat_i"], f["k_sat_f"] = si, sf
+    f["k_main_dims"] = np.array([nq, nv, nb, njnt], np.int32)
+
+
 def _is_desc(par, x, b):
     while x > b:
         x = par[x]
     return x == b
 
 
-def prepare_for_kernels(m: Dict[str, np.ndarray], capacity: str = "auto") -> Dict[str, np.ndarray]:
+def prepare_for_kernels(m: Dict[str, np.ndarray], capacity: str = "auto", satellites: bool = False) -> Dict[str, np.ndarray]:
     """Fused model + kernel tables.  capacity: "auto" lets smj_create pick the step-kernel variant by the model's size (standard:
     32 dofs / 80 constraint rows / 16 contacts; big: 64 / 160 / 48); "big" asks for the big variant regardless -- for
-    contact-rich scenes (fixtures all around the robot) whose steps would keep escalating out of the standard one."""
-    f = kernel_tables(fuse_static_bodies(m))
+    contact-rich scenes (fixtures all around the robot) whose steps would keep escalating out of the standard one.
+    satellites: free objects and single-joint fixture parts declared after the robot run as satellites (find_satellites) -- the
+    blob then addresses the satellite builds of the step kernel (the main part must fit 32 dofs / 32 bodies)."""
+    f = fuse_static_bodies(m)
+    nsat = find_satellites(f) if satellites else 0
+    f = kernel_tables(f, nsat)
+    f["k_nsat"] = np.array([nsat], np.int32)
     f["k_capacity_hint"] = np.array([1 if capacity == "big" else 0], np.int32)
     return f

@@ -40,7 +40,7 @@ extern "C" {
 emul_ctx* emul_create(const void* blob, size_t nbytes, int num_envs) {
   emul_ctx* c = new emul_ctx();
   HostUploader up{&c->keep};
-  const SmjCaps caps{NVP, NBP, NENT, NEFC, NCON, NVS};   // this build's variant (Makefile: -DSMJ_BIG for libsmj_emul_big.so)
+  const SmjCaps caps{NVP, NBP, NENT, NEFC, NCON, NVS, NSAT};   // this build's variant (Makefile: -DSMJ_BIG for libsmj_emul_big.so)
   int chosen = 0;
   if (smj_load_model(blob, nbytes, c->m, up, c->err, &caps, 1, &chosen)) {
     fprintf(stderr, "emul_create: %s\n", c->err.c_str());
@@ -49,7 +49,7 @@ emul_ctx* emul_create(const void* blob, size_t nbytes, int num_envs) {
   }
   c->s.B = num_envs;
   c->s.ld = num_envs;
-  c->s.lay = smj_stage_layout(NVP, NBP);
+  c->s.lay = smj_stage_layout(NVP, NBT, NSAT);
   c->s.sepcache = (float*)calloc((size_t)num_envs * SMJ_SEP_SLOTS * 4, sizeof(float));
   c->keep.push_back(c->s.sepcache);
   return c;
@@ -102,6 +102,7 @@ int emul_set_option(emul_ctx* c, const char* name, double v) {
 }
 // LDS is uninitialised when a workgroup starts: tests poison the emulated LDS to catch reads before writes
 long emul_sep_skips() { return smj_emul_sep_skips; }
+long emul_ext_steps() { return smj_emul_ext_steps; }
 int emul_poison = -1;
 void emul_set_poison(int byte) { emul_poison = byte; }
 int emul_step(emul_ctx* c, int nsteps, unsigned read_flags) {

@@ -192,9 +192,11 @@ class EmulBackend:
         self.e = Emul(blob, dict(nq=o.dim("nq"), nv=o.dim("nv"), nu=o.dim("nu"), nlidar=360), num_envs=B, debug=True)   # variant as smj_create picks it
         self.e.set_option("solver", solver)
         from stretch_mujoco_amd.lib import debug_layout
+        import stretch_mujoco_amd.model_blob as mb
 
-        self.D = debug_layout(self.e.nvp, self.e.ncon_max)
+        self.D = debug_layout(self.e.nvp, self.e.ncon_max, self.e.nsat_max)
         self.ncon_max, self.nvp = self.e.ncon_max, self.e.nvp
+        self.model = mb.loads(blob)
 
     def upload(self, qpos, qvel, warm):
         self.e.qpos[:] = qpos; self.e.qvel[:] = qvel; self.e.warm[:] = warm
@@ -207,8 +209,11 @@ class EmulBackend:
 
     def download(self):
         e = self.e
+        from stretch_mujoco_amd.lib import full_qacc
+
+        qacc = full_qacc(e.debug, self.D, self.model) if self.e.nsat_max else e.debug[self.D["qacc"]:self.D["qacc"] + self.nvp]
         return dict(qpos=e.qpos.astype(np.float64), qvel=e.qvel.astype(np.float64), info=e.info.copy(),
-                    qacc=e.debug[self.D["qacc"]:self.D["qacc"] + self.nvp].astype(np.float64),
+                    qacc=qacc.astype(np.float64),
                     contacts=e.debug[self.D["con"]:self.D["con"] + 8 * self.ncon_max].copy())
 
 
