@@ -53,7 +53,9 @@ enum smj_dim {
   SMJ_DIM_NQ = 0, SMJ_DIM_NV = 1, SMJ_DIM_NU = 2, SMJ_DIM_NBODY = 3, SMJ_DIM_NLIDAR = 4, SMJ_DIM_NKEY = 5,
   SMJ_DIM_NUM_ENVS = 6, SMJ_DIM_DEBUG_FLOATS = 7, SMJ_DIM_NEFC_MAX = 8, SMJ_DIM_NCON_MAX = 9, SMJ_DIM_NCAM = 10,
   SMJ_DIM_NV_MAX = 11,   /* dof capacity of the kernel variant chosen for this model: 32 (standard) or 64 (big) */
-  SMJ_DIM_COUNT = 12
+  SMJ_DIM_NSAT_MAX = 12, /* satellite capacity of the variant (0: a build without satellites; the debug dump then ends with 6 floats
+                            of qacc per satellite slot) */
+  SMJ_DIM_COUNT = 13
 };
 
 /* readout flags for smj_step */

@@ -29,7 +29,7 @@ struct smj_ctx {
   std::string err;
   float* qpos0_dev = nullptr;
   float* stage = nullptr;      // env-major staging copy of the state, [num_envs][layout.stride] (DevState::stage)
-  int variant = 0;             // 0: standard step kernel, 1: tall (its 128-row build, three envs per CU), 2 / 3 / 4: big with 38 / 50 / 64 dof columns (smj_model.h)
+  int variant = 0;             // 0: standard step kernel, 1: tall (its 128-row build, three envs per CU), 2 / 3 / 4: big with 38 / 50 / 64 dof columns, 5 / 6: main tree + up to 16 / 32 satellites (smj_model.h, smj_sat.h)
   // capacity escalation (standard variant): the model once more with the tall variant's records, and the list of parked envs
   DevModel model_esc{};
   bool has_esc = false;
@@ -159,7 +159,7 @@ static int setup_render(smj_ctx* c, const void* blob, size_t nbytes) {
   if (nrgeom > SMJ_RGEOM_MAX) return fail(c, -4, "model has %d camera-visible geoms, renderer capacity is %d", nrgeom, SMJ_RGEOM_MAX);
   r.nrgeom = nrgeom;
   r.ncam = (int)(cb->nbytes / 4);
-  r.nbody = c->model.nbody;
+  r.nbody = c->model.nbody_all;
   double z[3];
   memcpy(z, b.p + vz->offset, 24);
   r.znear = (float)(z[0] * z[2]);
@@ -273,8 +273,8 @@ int smj_create(const void* blob, size_t nbytes, int num_envs, int device, smj_ct
   c->num_envs = num_envs;
   HIPCHK(c, hipSetDevice(device));
   DeviceUploader up{c};
-  SmjCaps caps[5] = {{NVP, NBP, NENT, NEFC, NCON, 0}, {}, {}, {}, {}};   // standard, tall, big38, big50, big (smj_model.h)
-  int dbg[5] = {SMJ_DEBUG_FLOATS, 0, 0, 0, 0};
+  SmjCaps caps[7] = {{NVP, NBP, NENT, NEFC, NCON, 0, 0}, {}, {}, {}, {}, {}, {}};   // standard, tall, big38, big50, big, sat, sat32 (smj_model.h)
+  int dbg[7] = {SMJ_DEBUG_FLOATS, 0, 0, 0, 0, 0, 0};
   SmjCaps tall{};   // the 160-row build: escalation target of the standard variant and of the 128-row build
   int dbg_tall = 0;
   smj_tall_caps(&tall.nvp, &tall.nbp, &tall.nent, &tall.nefc, &tall.ncon, &dbg_tall);
@@ -282,15 +282,17 @@ int smj_create(const void* blob, size_t nbytes, int num_envs, int device, smj_ct
   smj_big38_caps(&caps[2].nvp, &caps[2].nbp, &caps[2].nent, &caps[2].nefc, &caps[2].ncon, &dbg[2], &caps[2].nvs);
   smj_big50_caps(&caps[3].nvp, &caps[3].nbp, &caps[3].nent, &caps[3].nefc, &caps[3].ncon, &dbg[3], &caps[3].nvs);
   smj_big_caps(&caps[4].nvp, &caps[4].nbp, &caps[4].nent, &caps[4].nefc, &caps[4].ncon, &dbg[4], &caps[4].nvs);
-  int rc = smj_load_model(blob, nbytes, c->model, up, c->err, caps, 5, &c->variant);
+  smj_sat_caps(&caps[5].nvp, &caps[5].nbp, &caps[5].nent, &caps[5].nefc, &caps[5].ncon, &dbg[5], &caps[5].nsat);
+  smj_sat32_caps(&caps[6].nvp, &caps[6].nbp, &caps[6].nent, &caps[6].nefc, &caps[6].ncon, &dbg[6], &caps[6].nsat);
+  int rc = smj_load_model(blob, nbytes, c->model, up, c->err, caps, 7, &c->variant);
   if (rc) return rc;
   c->caps = caps[c->variant];
-  c->layout = smj_stage_layout(c->caps.nvp, c->caps.nbp);
+  c->layout = smj_stage_layout(c->caps.nvp, c->caps.nbp + c->caps.nsat, c->caps.nsat);
   c->debug_floats = dbg[c->variant];
-  if (c->variant <= 3) {
-    // escalation target: the same model loaded for the 160-row tall build (standard, 128-row tall) / the 64-column big build (38 / 50 columns)
+  if (c->variant <= 3 || c->variant == 5) {
+    // escalation target: the same model loaded for the 160-row tall build (standard, 128-row tall) / the 64-column big build (38 / 50 columns) / the 32-satellite build
     int dummy = 0;
-    rc = smj_load_model(blob, nbytes, c->model_esc, up, c->err, c->variant <= 1 ? &tall : caps + 4, 1, &dummy);
+    rc = smj_load_model(blob, nbytes, c->model_esc, up, c->err, c->variant <= 1 ? &tall : c->variant == 5 ? caps + 6 : caps + 4, 1, &dummy);
     if (rc) return rc;
     c->has_esc = true;
     void* d = nullptr;
@@ -446,8 +448,9 @@ int smj_destroy(smj_ctx* c) {
 
 int smj_dims(const smj_ctx* c, int* out) {
   if (!c || !out) return -1;
-  out[SMJ_DIM_NQ] = c->model.nq; out[SMJ_DIM_NV] = c->model.nv; out[SMJ_DIM_NU] = c->model.nu;
-  out[SMJ_DIM_NBODY] = c->model.nbody; out[SMJ_DIM_NLIDAR] = c->model.nlidar; out[SMJ_DIM_NKEY] = c->model.nkey;
+  out[SMJ_DIM_NQ] = c->model.nq_all; out[SMJ_DIM_NV] = c->model.nv_all; out[SMJ_DIM_NU] = c->model.nu;
+  out[SMJ_DIM_NSAT_MAX] = c->caps.nsat;
+  out[SMJ_DIM_NBODY] = c->model.nbody_all; out[SMJ_DIM_NLIDAR] = c->model.nlidar; out[SMJ_DIM_NKEY] = c->model.nkey;
   out[SMJ_DIM_NUM_ENVS] = c->num_envs; out[SMJ_DIM_DEBUG_FLOATS] = c->debug_floats; out[SMJ_DIM_NEFC_MAX] = c->caps.nefc;
   out[SMJ_DIM_NCON_MAX] = c->caps.ncon; out[SMJ_DIM_NV_MAX] = c->caps.nvp; out[SMJ_DIM_NCAM] = c->has_render ? c->render.ncam : 0;
   return 0;
@@ -524,7 +527,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
     if (!st.xpose) {
       if (!c->pose_ws) {
         void* d = nullptr;
-        HIPCHK(c, hipMalloc(&d, sizeof(float) * 12 * (size_t)c->model.nbody * (size_t)c->num_envs));
+        HIPCHK(c, hipMalloc(&d, sizeof(float) * 12 * (size_t)c->model.nbody_all * (size_t)c->num_envs));
         c->allocs.push_back(d);
         c->pose_ws = (float*)d;
       }
@@ -539,13 +542,14 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
   const DevModel& m = c->model;
   StagePlan in, out;
   const SmjStageLayout& Y = c->layout;
-  in.add(st.qpos, m.nq, Y.qpos); in.add(st.qvel, m.nv, Y.qvel); in.add(st.warm, m.nv, Y.warm);
+  if (m.nsat > 0 && m.solver != 2) return fail(c, -6, "the satellite builds of the step kernel run the model's own solver (Newton) only: set solver = 2");
+  in.add(st.qpos, m.nq_all, Y.qpos); in.add(st.qvel, m.nv_all, Y.qvel); in.add(st.warm, m.nv_all, Y.warm);
   in.add(st.ctrl, m.nu, Y.ctrl); in.add(st.bctl, SMJ_BC_ROWS, Y.bctl); in.add(st.nstep, 1, Y.nstep);
   in.add(st.info, 4, Y.info);
   out = in;
   out.add(st.act_len, m.nu, Y.actlen); out.add(st.act_vel, m.nu, Y.actvel); out.add(st.base, 3, Y.base);
   if (read_flags & SMJ_READ_IMU) { out.add(st.gyro, 3, Y.gyro); out.add(st.accel, 3, Y.accel); }
-  if (read_flags & SMJ_READ_POSES) out.add(st.xpose, 12 * m.nbody, Y.xpose);
+  if (read_flags & SMJ_READ_POSES) out.add(st.xpose, 12 * m.nbody_all, Y.xpose);
   st.stage = c->stage;
   st.lay = Y;
   const bool esc = c->has_esc && c->escalate;   // standard -> tall, big38 / big50 -> big (has_esc: smj_create)
@@ -568,7 +572,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
   // measured: standard +19 % at chunks of 5, tall (2 envs per CU) +7 % at 10, big with 64 columns (1 env per CU, 16 rounds of workgroups) nothing
   // (three envs per CU: chunks of 8 measured 3 % ahead of 10)
   const int pipe_len = c->variant >= 2 ? 2 * c->pipeline : c->variant == 1 ? (3 * c->pipeline + 1) / 2 : c->pipeline;
-  const bool pipe = c->variant != 4 && (c->variant < 2 || c->pipeline_big) && c->pipeline > 0 && chunk == nsteps && nsteps > pipe_len && !st.debug && !st.prof && c->num_envs > 1024;
+  const bool pipe = c->variant != 4 && c->variant != 6 && (c->variant < 2 || c->pipeline_big) && c->pipeline > 0 && chunk == nsteps && nsteps > pipe_len && !st.debug && !st.prof && c->num_envs > 1024;
   st.progress = st.done_steps = st.sched = st.hot = nullptr;
   if (esc || pipe) {
     st.progress = c->progress;
@@ -622,7 +626,9 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
       HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
     }
     if (!lrc)
-      lrc = c->variant == 4   ? smj_launch_step_big(c->model, st, k, fl, sm)
+      lrc = c->variant == 6   ? smj_launch_step_sat32(c->model, st, k, fl, sm)
+            : c->variant == 5 ? smj_launch_step_sat(c->model, st, k, fl, sm)
+            : c->variant == 4 ? smj_launch_step_big(c->model, st, k, fl, sm)
             : c->variant == 3 ? smj_launch_step_big50(c->model, st, k, fl, sm)
             : c->variant == 2 ? smj_launch_step_big38(c->model, st, k, fl, sm)
             : c->variant == 1 ? smj_launch_step_mid(c->model, st, k, fl, sm)
@@ -634,7 +640,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
       // offending step) is finished by the tall variant (160 rows / 48 contacts); an empty list returns at once
       st.redo_worker = 1;
       st.pipe_len = 0;
-      lrc = c->variant <= 1 ? smj_launch_step_tall(c->model_esc, st, k, fl, sm) : smj_launch_step_big(c->model_esc, st, k, fl, sm);
+      lrc = c->variant <= 1 ? smj_launch_step_tall(c->model_esc, st, k, fl, sm) : c->variant == 5 ? smj_launch_step_sat32(c->model_esc, st, k, fl, sm) : smj_launch_step_big(c->model_esc, st, k, fl, sm);
     }
   }
   if (lrc) return fail(c, -2, "step kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));

@@ -12,8 +12,8 @@ __global__ __launch_bounds__(256) void smj_reset_kernel(const DevModel M, const 
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= S.B) return;
   if (mask && !mask[e]) return;
-  for (int k = 0; k < M.nq; k++) S.qpos[k * S.ld + e] = M.qpos0[k];
-  for (int k = 0; k < M.nv; k++) { S.qvel[k * S.ld + e] = 0.f; S.warm[k * S.ld + e] = 0.f; }
+  for (int k = 0; k < M.nq_all; k++) S.qpos[k * S.ld + e] = M.qpos0[k];
+  for (int k = 0; k < M.nv_all; k++) { S.qvel[k * S.ld + e] = 0.f; S.warm[k * S.ld + e] = 0.f; }
   for (int k = 0; k < M.nu; k++) S.ctrl[k * S.ld + e] = 0.f;
   if (S.bctl)
     for (int k = 0; k < SMJ_BC_ROWS; k++) S.bctl[k * S.ld + e] = 0.f;

@@ -22,14 +22,18 @@
 #define NSAT SMJ_SAT
 #define NVP 32
 #ifndef SMJ_SAT_ROWS
-#define SMJ_SAT_ROWS 192
-#define SMJ_SAT_CONTACTS 56
-#define SMJ_SAT_DENSE 96
+#define SMJ_SAT_ROWS 224
+#define SMJ_SAT_CONTACTS 64
+#define SMJ_SAT_DENSE 128
 #endif
 #define NEFC SMJ_SAT_ROWS
 #define NCON SMJ_SAT_CONTACTS
 #define NDR SMJ_SAT_DENSE     // rows with a dense Jacobian row (rows 0 .. nd-1 of a step: the rows that touch the main tree)
-#define NXS 4                 // satellites that may be coupled to the main tree / to each other in one step (dense extension of the Newton system)
+#ifndef SMJ_SAT_EXT
+#define SMJ_SAT_EXT 4
+#endif
+#define NXS SMJ_SAT_EXT       // satellites that may be coupled to the main tree / to each other in one step (dense extension of the Newton system)
+static_assert(NDR % 16 == 0 && NDR <= NEFC, "dense rows: whole 16-row blocks (matT_J, MFMA k-steps)");
 #define NENT 5
 #elif defined(SMJ_BIG)
 #define NVP 64    // dof LANES (lane = dof stages run on 64 lanes)
@@ -121,6 +125,16 @@ struct DevModel {
   // cover the whole model (equal to the main ones when nsat = 0)
   int nsat, nq_all, nv_all, nbody_all, nfric_main, nlimit_main;
   const int* k_satrec;    // [nsat][SMJ_SR_STRIDE], floats as bit patterns
+  // static collision geometry (the world body's geoms: a kitchen's fixtures) behind a uniform grid (model_fuse._static_grid_tables)
+  int nsgeom, nstatpair, grid_dim[3];
+  float grid_org[3], grid_h, grid_margin;
+  const int* k_sgrec;     // [nsgeom][SMJ_CG_STRIDE]: as k_cgrec, body 0 -- local frame = world frame
+  const int* k_sprec;     // [nstatpair][SMJ_CP_STRIDE]: as k_cprec; the static geom's slot is -1 - (its index)
+  const int* k_spair;     // [ncgeom][nsgeom] -> index into k_sprec, or -1 (pair filtered out)
+  const int* k_grid_adr;  // [cells + 1]
+  const int* k_grid_list; // static-geom indices, cell after cell
+  const int* k_sg_cell;   // [nsgeom][6] cell range of the geom (lo xyz, hi xyz)
+  const float* k_sg_bound;   // [nsgeom][4] world centre of the geom's box, bounding radius
 #define X(n) const int* n;
   SMJ_MODEL_I32(X)
 #undef X
@@ -159,7 +173,7 @@ enum { SMJ_PP_PAIR = 0, SMJ_PP_G1, SMJ_PP_G2, SMJ_PP_B1, SMJ_PP_B2, SMJ_PP_T2, S
 // convex-cache geom record: geom, body, packed type|hull count|hull address, local frame, bounding-box centre and half
 // sizes, MPR interior point, geom size
 enum { SMJ_CG_GEOM = 0, SMJ_CG_BODY, SMJ_CG_META, SMJ_CG_POS = 3, SMJ_CG_MAT = 6, SMJ_CG_LCEN = 15, SMJ_CG_HALF = 18, SMJ_CG_CCEN = 21,
-       SMJ_CG_SIZE = 24, SMJ_CG_STRIDE = 28 };
+       SMJ_CG_SIZE = 24, SMJ_CG_RBOUND = 27, SMJ_CG_STRIDE = 28 };
 
 // satellite record: ints, then floats (bit patterns); model_fuse.SAT_I / SAT_F
 enum { SMJ_SR_BODY = 0, SMJ_SR_JTYPE, SMJ_SR_QADR, SMJ_SR_DADR, SMJ_SR_NDOF, SMJ_SR_JNT, SMJ_SR_F = 8,

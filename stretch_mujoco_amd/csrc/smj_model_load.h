@@ -143,22 +143,24 @@ static inline std::vector<int> smj_build_pprec(const DevModel& m, std::map<std::
   return rec;
 }
 static inline std::vector<int> smj_build_cgrec(const DevModel& m, std::map<std::string, std::vector<int>>& I,
-                                               std::map<std::string, std::vector<float>>& F) {
-  std::vector<int> rec((size_t)(m.ncgeom > 0 ? m.ncgeom : 1) * SMJ_CG_STRIDE, 0);
+                                               std::map<std::string, std::vector<float>>& F, bool stat = false) {
+  const int ncg = stat ? m.nsgeom : m.ncgeom;
+  std::vector<int> rec((size_t)(ncg > 0 ? ncg : 1) * SMJ_CG_STRIDE, 0);
   auto fb = [](float v) { int b; memcpy(&b, &v, 4); return b; };
   auto gi = [&](const char* n, size_t k) { const std::vector<int>& v = I[n]; return k < v.size() ? v[k] : 0; };
   auto gf = [&](const char* n, size_t k) { const std::vector<float>& v = F[n]; return k < v.size() ? v[k] : 0.f; };
-  for (int c = 0; c < m.ncgeom; c++) {
+  for (int c = 0; c < ncg; c++) {
     int* k = rec.data() + (size_t)c * SMJ_CG_STRIDE;
-    const int g = gi("k_cgeom", c), adr = gi("geom_hulladr", g);
+    const int g = gi(stat ? "k_sgeom" : "k_cgeom", c), adr = gi("geom_hulladr", g);
     k[SMJ_CG_GEOM] = g; k[SMJ_CG_BODY] = gi("geom_bodyid", g);
     k[SMJ_CG_META] = (int)((unsigned)gi("geom_type", g) | ((unsigned)gi("geom_hullnum", g) << 4) | ((unsigned)(adr < 0 ? 0 : adr) << 16));
     for (int q = 0; q < 3; q++) {
-      k[SMJ_CG_POS + q] = fb(gf("geom_pos", 3 * g + q)); k[SMJ_CG_LCEN + q] = fb(gf("k_cgeom_lcen", 3 * c + q));
-      k[SMJ_CG_HALF + q] = fb(gf("k_cgeom_half", 3 * c + q)); k[SMJ_CG_CCEN + q] = fb(gf("geom_ccenter", 3 * g + q));
+      k[SMJ_CG_POS + q] = fb(gf("geom_pos", 3 * g + q)); k[SMJ_CG_LCEN + q] = fb(gf("geom_aabb", 6 * g + q));
+      k[SMJ_CG_HALF + q] = fb(gf("geom_aabb", 6 * g + 3 + q)); k[SMJ_CG_CCEN + q] = fb(gf("geom_ccenter", 3 * g + q));
       k[SMJ_CG_SIZE + q] = fb(gf("geom_size", 3 * g + q));
     }
     for (int q = 0; q < 9; q++) k[SMJ_CG_MAT + q] = fb(gf("k_geom_mat", 9 * g + q));
+    k[SMJ_CG_RBOUND] = fb(gf("geom_rbound", g));
   }
   return rec;
 }
@@ -217,16 +219,25 @@ static inline std::vector<int> smj_build_rowrec(const DevModel& m, std::map<std:
 }
 
 static inline std::vector<int> smj_build_cprec(const DevModel& m, std::map<std::string, std::vector<int>>& I,
-                                               std::map<std::string, std::vector<float>>& F) {
-  std::vector<int> rec((size_t)(m.nconvpair > 0 ? m.nconvpair : 1) * SMJ_CP_STRIDE, 0);
+                                               std::map<std::string, std::vector<float>>& F, bool stat = false) {
+  const int np = stat ? m.nstatpair : m.nconvpair;
+  std::vector<int> rec((size_t)(np > 0 ? np : 1) * SMJ_CP_STRIDE, 0);
   auto fb = [](float v) { int b; memcpy(&b, &v, 4); return b; };
   auto gi = [&](const char* nm, size_t k) { const std::vector<int>& v = I[nm]; return k < v.size() ? v[k] : 0; };
   auto gf = [&](const char* nm, size_t k) { const std::vector<float>& v = F[nm]; return k < v.size() ? v[k] : 0.f; };
-  for (int t = 0; t < m.nconvpair; t++) {
+  std::map<int, int> dslot, sslot;   // static pairs: geom -> cache slot of the moving geom / index of the static geom
+  if (stat) {
+    for (int c = 0; c < m.ncgeom; c++) dslot[gi("k_cgeom", c)] = c;
+    for (int c = 0; c < m.nsgeom; c++) sslot[gi("k_sgeom", c)] = c;
+  }
+  for (int t = 0; t < np; t++) {
     int* k = rec.data() + (size_t)t * SMJ_CP_STRIDE;
-    const int p = gi("k_convpair", t);
+    const int p = gi(stat ? "k_statpair" : "k_convpair", t);
     k[SMJ_CP_PAIR] = p; k[SMJ_CP_G1] = gi("pair_geom1", p); k[SMJ_CP_G2] = gi("pair_geom2", p);
-    k[SMJ_CP_S1] = gi("k_convpair_s1", t); k[SMJ_CP_S2] = gi("k_convpair_s2", t);
+    if (stat) {
+      k[SMJ_CP_S1] = sslot.count(k[SMJ_CP_G1]) ? -1 - sslot[k[SMJ_CP_G1]] : dslot[k[SMJ_CP_G1]];
+      k[SMJ_CP_S2] = sslot.count(k[SMJ_CP_G2]) ? -1 - sslot[k[SMJ_CP_G2]] : dslot[k[SMJ_CP_G2]];
+    } else { k[SMJ_CP_S1] = gi("k_convpair_s1", t); k[SMJ_CP_S2] = gi("k_convpair_s2", t); }
     k[SMJ_CP_MARGIN] = fb(gf("pair_margin", p)); k[SMJ_CP_MG] = fb(gf("pair_margin", p) - gf("pair_gap", p)); k[SMJ_CP_CONDIM] = gi("pair_condim", p);
     for (int q = 0; q < 5; q++) { k[SMJ_CP_FRIC + q] = fb(gf("pair_friction", 5 * p + q)); k[SMJ_CP_SOLIMP + q] = fb(gf("pair_solimp", 5 * p + q)); }
     k[SMJ_CP_SOLREF] = fb(gf("pair_solref", 2 * p)); k[SMJ_CP_SOLREF + 1] = fb(gf("pair_solref", 2 * p + 1));
@@ -336,6 +347,44 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
   }
   SMJ_MODEL_F32(X)
 #undef X
+  m.nsgeom = 0; m.nstatpair = 0; m.k_sgrec = m.k_sprec = m.k_spair = m.k_grid_adr = m.k_grid_list = m.k_sg_cell = nullptr; m.k_sg_bound = nullptr;
+  if (b.find("k_nsgeom")) {
+    if (!geti("k_nsgeom", 0, &m.nsgeom) || !geti("k_nstatpair", 0, &m.nstatpair)) return -3;
+    if (m.nsgeom > 0) {
+      for (int q = 0; q < 3; q++) { if (!geti("k_grid", q, &m.grid_dim[q]) || !getf("k_grid_f", q, &m.grid_org[q])) return -3; }
+      if (!getf("k_grid_f", 3, &m.grid_h) || !getf("k_grid_f", 4, &m.grid_margin)) return -3;
+      auto loadi = [&](const char* name, const int** dst) -> bool {
+        const SmjBlobEntry* e = b.find(name);
+        if (!e || e->dtype != 1) { err = std::string("model blob: missing i32 array ") + name; return false; }
+        std::vector<int> h(e->nbytes / 4 ? e->nbytes / 4 : 1, 0);
+        memcpy(h.data(), b.p + e->offset, e->nbytes);
+        hosti[name] = h;
+        *dst = up.i32(h);
+        return *dst != nullptr;
+      };
+      const int* dummy = nullptr;
+      if (!loadi("k_sgeom", &dummy) || !loadi("k_statpair", &dummy) || !loadi("k_spair", &m.k_spair) || !loadi("k_grid_adr", &m.k_grid_adr) ||
+          !loadi("k_grid_list", &m.k_grid_list) || !loadi("k_sg_cell", &m.k_sg_cell)) return err.empty() ? -2 : -3;
+      {
+        const SmjBlobEntry* e = b.find("geom_aabb");   // (already among the float tables: hostf)
+        (void)e;
+      }
+      std::vector<int> sg = smj_build_cgrec(m, hosti, hostf, true), spr = smj_build_cprec(m, hosti, hostf, true);
+      m.k_sgrec = up.i32(sg);
+      m.k_sprec = up.i32(spr);
+      std::vector<float> bound(4 * (size_t)m.nsgeom);
+      for (int c = 0; c < m.nsgeom; c++) {   // world centre of the geom's box: pos + R lcen
+        const int* k = sg.data() + (size_t)c * SMJ_CG_STRIDE;
+        float f[SMJ_CG_STRIDE];
+        memcpy(f, k, sizeof f);
+        for (int i = 0; i < 3; i++)
+          bound[4 * c + i] = f[SMJ_CG_POS + i] + f[SMJ_CG_MAT + 3 * i] * f[SMJ_CG_LCEN] + f[SMJ_CG_MAT + 3 * i + 1] * f[SMJ_CG_LCEN + 1] + f[SMJ_CG_MAT + 3 * i + 2] * f[SMJ_CG_LCEN + 2];
+        bound[4 * c + 3] = f[SMJ_CG_RBOUND];
+      }
+      m.k_sg_bound = up.f32(bound);
+      if (!m.k_sgrec || !m.k_sprec || !m.k_sg_bound) { err = "device allocation failed for the static-geometry tables"; return -2; }
+    }
+  }
   m.nfric_main = m.nfric; m.nlimit_main = m.nlimit; m.k_satrec = nullptr;
   if (m.nsat > 0) {
     const SmjBlobEntry* ei = b.find("k_sat_i");

@@ -863,3 +863,139 @@ SMJ_DEV void gj_solve_ext(PL<float>& x, int n) {
   LANES { x[lane] = lane < n ? s.u.n.H[lane][NXV] * fast_rcp(fmaxf(s.u.n.H[lane][lane], 1e-30f)) : 0.f; }
   SYNC();
 }
+
+// ------------------------------------------------------------------ collision against the static world (a kitchen's fixtures)
+// The world body's collision geoms never move: their frames are model constants (DevModel::k_sgrec), they take no slot in the
+// collision stage's LDS cache and no pair of theirs is in the table the kernels scan.  Broadphase: lane = moving geom (cache
+// slot), which visits the cells of the uniform grid (DevModel::k_grid_*) its bounding sphere overlaps and tests the static geoms
+// listed there -- a pair is reported from the FIRST cell the two cell ranges share, so never twice -- with the same two tests as
+// the moving-moving pairs (bounding spheres, then the six face axes of the two oriented boxes) and MuJoCo's pair filters
+// (k_spair: -1 = filtered).  The survivors are put in pair-table order and go through the same narrowphase, the static geom staged
+// in cache slot NCG.  Same contacts as the oracle's scan of the whole table (oracle/smj_oracle.c collision()).
+SMJ_DEV void stage_static(int sg) {
+  LANES {
+    if (lane == 0) {
+      const int* r = M.k_sgrec + sg * SMJ_CG_STRIDE;
+      float pos[3], mat[9], lc[3], lcc[3], wc[3], wcc[3];
+      for (int k = 0; k < 3; k++) { pos[k] = asf(r[SMJ_CG_POS + k]); lc[k] = asf(r[SMJ_CG_LCEN + k]); lcc[k] = asf(r[SMJ_CG_CCEN + k]); }
+      for (int k = 0; k < 9; k++) mat[k] = asf(r[SMJ_CG_MAT + k]);
+      mulmat3vec(wc, mat, lc);
+      mulmat3vec(wcc, mat, lcc);
+      for (int k = 0; k < 3; k++) {
+        s.u.c.pos[NCG][k] = pos[k]; s.u.c.cen[NCG][k] = pos[k] + wc[k]; s.u.c.half[NCG][k] = asf(r[SMJ_CG_HALF + k]);
+        s.u.c.ccen[NCG][k] = pos[k] + wcc[k]; s.u.c.size[NCG][k] = asf(r[SMJ_CG_SIZE + k]);
+      }
+      for (int k = 0; k < 9; k++) s.u.c.mat[NCG][k] = mat[k];
+      s.u.c.meta[NCG] = r[SMJ_CG_META];
+    }
+  }
+  SYNC();
+}
+SMJ_DEV void collision_static(float* pc, bool prof) {
+  const int nsg = M.nsgeom;
+  if (nsg == 0 || M.nstatpair == 0) return;
+  LANES { if (lane == 0) s.u.c.sl_n = 0; }
+  SYNC();
+  const float ih = 1.0f / M.grid_h, gm = M.grid_margin;
+  const int dx = M.grid_dim[0], dy = M.grid_dim[1], dz = M.grid_dim[2];
+  for (int c0 = 0; c0 < M.ncgeom; c0 += 64) {
+    LANES {
+      const int c = c0 + lane;
+      if (c < M.ncgeom) {
+        const float rb = asf(M.k_cgrec[opaque(c) * SMJ_CG_STRIDE + SMJ_CG_RBOUND]);
+        const float cen[3] = {s.u.c.cen[c][0], s.u.c.cen[c][1], s.u.c.cen[c][2]}, R = rb + gm;
+        int lo[3], hi[3];
+        bool in = true;
+        for (int k = 0; k < 3; k++) {
+          const int dk = k == 0 ? dx : k == 1 ? dy : dz;
+          const float a = floorf((cen[k] - R - M.grid_org[k]) * ih), b = floorf((cen[k] + R - M.grid_org[k]) * ih);
+          in = in && b >= 0.f && a < (float)dk;
+          lo[k] = a < 0.f ? 0 : (int)a; hi[k] = b >= (float)dk ? dk - 1 : (int)b;
+        }
+        if (in) {
+          float Ra[9], ha[3];
+          for (int k = 0; k < 9; k++) Ra[k] = s.u.c.mat[c][k];
+          for (int k = 0; k < 3; k++) ha[k] = s.u.c.half[c][k];
+          for (int z = lo[2]; z <= hi[2]; z++)
+            for (int y = lo[1]; y <= hi[1]; y++)
+              for (int x = lo[0]; x <= hi[0]; x++) {
+                const int cell = (z * dy + y) * dx + x;
+                const int k1 = M.k_grid_adr[cell + 1];
+                for (int k = M.k_grid_adr[cell]; k < k1; k++) {
+                  const int sg = M.k_grid_list[k];
+                  const int* cr = M.k_sg_cell + 6 * sg;
+                  // (reported from the first cell common to the two cell ranges)
+                  if (x != (lo[0] > cr[0] ? lo[0] : cr[0]) || y != (lo[1] > cr[1] ? lo[1] : cr[1]) || z != (lo[2] > cr[2] ? lo[2] : cr[2])) continue;
+                  const float* bd = M.k_sg_bound + 4 * sg;
+                  const float dv[3] = {bd[0] - cen[0], bd[1] - cen[1], bd[2] - cen[2]}, rr = rb + bd[3] + gm;
+                  if (dot3(dv, dv) > rr * rr) continue;
+                  const int sid = M.k_spair[c * nsg + sg];
+                  if (sid < 0) continue;
+                  // the six face axes of the two oriented boxes
+                  const int* sr = M.k_sgrec + sg * SMJ_CG_STRIDE;
+                  float Rb[9], hb[3], Rm[3][3], ta[3], tb[3];
+                  for (int q = 0; q < 9; q++) Rb[q] = asf(sr[SMJ_CG_MAT + q]);
+                  for (int q = 0; q < 3; q++) hb[q] = asf(sr[SMJ_CG_HALF + q]);
+                  bool hit = true;
+                  for (int i = 0; i < 3; i++) {
+                    ta[i] = Ra[i] * dv[0] + Ra[3 + i] * dv[1] + Ra[6 + i] * dv[2];
+                    tb[i] = Rb[i] * dv[0] + Rb[3 + i] * dv[1] + Rb[6 + i] * dv[2];
+                    for (int j = 0; j < 3; j++) Rm[i][j] = fabsf(Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j]);
+                  }
+                  for (int q = 0; q < 3; q++) {
+                    if (fabsf(ta[q]) > ha[q] + (Rm[q][0] * hb[0] + Rm[q][1] * hb[1] + Rm[q][2] * hb[2]) + gm) hit = false;
+                    if (fabsf(tb[q]) > hb[q] + (Rm[0][q] * ha[0] + Rm[1][q] * ha[1] + Rm[2][q] * ha[2]) + gm) hit = false;
+                  }
+                  if (!hit) continue;
+                  const int at = lds_atomic_inc(&s.u.c.sl_n);
+                  if (at < NSURV) { s.u.c.sl_sid[at] = sid; s.u.c.sl_c[at] = (unsigned char)c; }
+                }
+              }
+        }
+      }
+    }
+  }
+  SYNC();
+  int n = uni(s.u.c.sl_n);
+  if (n > NSURV) { n = NSURV; flags |= SMJ_FLAG_CON_OVERFLOW; }
+  if (prof) pc[SMJ_PROF_C_NSPHERE] += (float)n;
+  if (n == 0) return;
+  // pair-table order: rank of every survivor among the pair indices (all different)
+  LANES {
+    for (int i = lane; i < n; i += 64) {
+      const int key = s.u.c.sl_sid[i];
+      int rank = 0;
+      for (int j = 0; j < n; j++) rank += s.u.c.sl_sid[j] < key;
+      s.u.c.sl_ord[rank] = (unsigned char)i;
+    }
+  }
+  SYNC();
+  float* const sepbase = (S.sepcache && M.sep_cache) ? S.sepcache + (size_t)env * (SMJ_SEP_SLOTS * 4) : nullptr;
+  for (int k0 = 0; k0 < n; k0 += 64) {
+    // the survivors' separating directions, fetched lane-parallel ahead of the serial loop (slots shared with the moving-moving
+    // pairs; the tag tells whose entry it is)
+    PL<float> sdx, sdy, sdz;
+    PL<int> stag, ssid;
+    LANES {
+      Vec4 e = {0.f, 0.f, 0.f, 0.f};
+      int sid = -1;
+      if (k0 + lane < n) {
+        sid = s.u.c.sl_sid[s.u.c.sl_ord[k0 + lane]];
+        if (sepbase) e = *reinterpret_cast<const Vec4*>(sepbase + 4 * ((sid * 7 + 29) & (SMJ_SEP_SLOTS - 1)));
+      }
+      sdx[lane] = e.x; sdy[lane] = e.y; sdz[lane] = e.z; stag[lane] = __builtin_bit_cast(int, e.w); ssid[lane] = sid;
+    }
+    const int m = n - k0 < 64 ? n - k0 : 64;
+    for (int l = 0; l < m; l++) {
+      const int sid = wave_read(ssid, l);
+      const int* r = static_cast<const int*>(__builtin_assume_aligned(M.k_sprec + sid * SMJ_CP_STRIDE, 16));
+      const int S1 = uni(r[SMJ_CP_S1]), S2 = uni(r[SMJ_CP_S2]);
+      stage_static(S1 < 0 ? -1 - S1 : -1 - S2);
+      const float sd[3] = {wave_read(sdx, l), wave_read(sdy, l), wave_read(sdz, l)};
+      const int tag = 0x40000000 | sid;
+      narrow_pair(r, S1 < 0 ? NCG : S1, S2 < 0 ? NCG : S2, sepbase ? sepbase + 4 * ((sid * 7 + 29) & (SMJ_SEP_SLOTS - 1)) : nullptr, tag,
+                  sepbase && wave_read(stag, l) == tag, sd, pc, prof);
+      SYNC();
+    }
+  }
+}

@@ -2,7 +2,7 @@
 #pragma once
 #if NSAT > 0
 #define NXV (NVS + 6 * NXS)   // order of the dense Newton system of a step in which satellites are coupled: the main columns + NXS satellites
-#define NIT 24                // row items (a contact's rows / a friction-loss row / a limit row) one satellite can hold in a step
+#define NIT 20                // row items (a contact's rows / a friction-loss row / a limit row) one satellite can hold in a step
 #define NSS 8                 // satellite-satellite contacts of a step
 // satellite 6-vectors (one per satellite and field)
 enum { SX_V = 0, SX_QA, SX_MA, SX_GRAD, SX_SRCH, SX_MV, SX_G, SX_TMP, SX_N };

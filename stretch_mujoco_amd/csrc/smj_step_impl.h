@@ -28,6 +28,12 @@ enum { JT_FREE = 0, JT_BALL = 1, JT_SLIDE = 2, JT_HINGE = 3 };
 enum { GT_PLANE = 0, GT_SPHERE = 2, GT_CAPSULE = 3, GT_ELLIPSOID = 4, GT_CYLINDER = 5, GT_BOX = 6, GT_MESH = 7 };
 enum { CT_EQUALITY = 0, CT_FRICTION = 1, CT_LIMIT = 3, CT_CONTACT_FRICTIONLESS = 5, CT_CONTACT_ELLIPTIC = 7, CT_NONE = -1 };
 
+#if NSAT > 0
+#define NCGS (NCG + 1)
+#define NSURV 128
+#else
+#define NCGS NCG
+#endif
 struct TreeTmp {  // lives in the A region until A is built
   float cinert[NBP][10], crb[NBP][10], cvel[NBP][6], cfrc[NBP][6], buf[NVP][6], cdof[NVP][6], cdof_dot[NVP][6];
 };
@@ -61,11 +67,15 @@ struct Smem {
   union {
     TreeTmp t;
     struct {                // collision: world frames of the geoms taking part in convex pairs (tree temporaries are dead)
-      float pos[NCG][3], mat[NCG][9], cen[NCG][3], half[NCG][3];
-      float ccen[NCG][3], size[NCG][3];   // world centre used as MPR's interior point, geom size
-      int meta[NCG];                      // geom type (bits 0-3) | hull vertex count (4-15) | hull address (16-31)
+      float pos[NCGS][3], mat[NCGS][9], cen[NCGS][3], half[NCGS][3];   // (NCGS = NCG, + 1 staging slot for a static geom in the satellite builds)
+      float ccen[NCGS][3], size[NCGS][3];   // world centre used as MPR's interior point, geom size
+      int meta[NCGS];                      // geom type (bits 0-3) | hull vertex count (4-15) | hull address (16-31)
       unsigned short list[1024];   // bounding-sphere survivors of the convex pair list, table order
       float mc[5][3];              // multiccd: contact points found so far for the pair in hand
+#if NSAT > 0
+      int sl_n, sl_sid[NSURV];     // static-geometry broadphase (collision_static): survivors = index into k_sprec ...
+      unsigned char sl_c[NSURV], sl_ord[NSURV];   // ... the moving geom's cache slot; the survivors in pair-table order
+#endif
     } c;
     struct {                // plane narrowphase staging: contacts of the pair owned by each lane, emitted in pair order
       int cnt[64], pair[64];
@@ -451,6 +461,9 @@ struct StepKernel {
         st_coh(&S.done_steps[env], ld_coh(&S.done_steps[env]) + st);
       }
     }
+#if NSAT > 0
+    sat_store_state();
+#endif
     coh_release();
     LANES {
       if (lane == 0) {
@@ -2348,10 +2361,76 @@ struct StepKernel {
     return round;
   }
 
+  // narrowphase of one convex pair: record r (DevModel::k_cprec / k_sprec), s1 / s2 = the geoms' slots in the collision stage's
+  // LDS cache.  sepslot / septag: the pair's entry of the separating-direction cache (or null), sep_hit: it holds this pair's
+  // direction sd.
+  SMJ_DEV void narrow_pair(const int* r, int s1, int s2, float* sepslot, int septag, bool sep_hit, const float* sd, float* pc, bool prof) {
+    const int g1 = uni(r[SMJ_CP_G1]), g2 = uni(r[SMJ_CP_G2]);
+    Shape A, Bs;
+    float c0[3], c1[3], depth, dir[3], pos[3];
+    load_shape(A, g1, s1, c0);
+    load_shape(Bs, g2, s2, c1);
+    const float margin = asf(uni(r[SMJ_CP_MARGIN]));
+    if (A.type == GT_SPHERE && Bs.type == GT_SPHERE) {
+      if (sphere_sphere(A.pos, A.size[0], Bs.pos, Bs.size[0], margin, depth, dir, pos)) add_contact(r, depth, pos, dir);
+      return;
+    }
+    if (A.type == GT_SPHERE && Bs.type == GT_BOX) {
+      if (sphere_box(A.pos, A.size[0], Bs, margin, depth, dir, pos)) add_contact(r, depth, pos, dir);
+      return;
+    }
+    if (A.type == GT_BOX && Bs.type == GT_SPHERE) {
+      if (sphere_box(Bs.pos, Bs.size[0], A, margin, depth, dir, pos)) {
+        for (int k = 0; k < 3; k++) dir[k] = -dir[k];   // the contact keeps the pair's geom order
+        add_contact(r, depth, pos, dir);
+      }
+      return;
+    }
+    if (A.type == GT_BOX && Bs.type == GT_BOX && M.multiccd) {
+      const long long tb = prof ? smj_clock() : 0;
+      box_box(r, s1, s2, margin);
+      if (prof) pc[SMJ_PROF_C_TBOXBOX] += (float)(smj_clock() - tb);
+      return;
+    }
+    const long long tm = prof ? smj_clock() : 0;
+    float sep[3];
+    bool pen = false, skipped = false;
+    if (sep_hit) {   // (tag = pair + 1: a zeroed cache holds no entry)
+      // one support query along the direction that separated the pair last time: still behind the origin (by more than the
+      // rounding of the test) -> disjoint, what the full query would find
+      MprPt q;
+      mpr_support(A, Bs, sd, q);
+      skipped = dot3(q.v, sd) < -1e-6f;
+#ifdef SMJ_EMUL
+      if (skipped) smj_emul_sep_skips++;   // (tests: the cache is exercised)
+#endif
+    }
+    if (!skipped) {
+      pen = mpr_penetration(A, Bs, c0, c1, depth, dir, pos, sep);
+      if (sepslot && !pen && (sep[0] != 0.f || sep[1] != 0.f || sep[2] != 0.f)) {
+        LANES { if (lane == 0) *reinterpret_cast<Vec4*>(sepslot) = Vec4{sep[0], sep[1], sep[2], asf(septag)}; }
+      }
+    }
+    if (prof) pc[SMJ_PROF_C_TMPR1] += (float)(smj_clock() - tm);
+    if (!pen) return;
+    if (-depth > margin || dot3(dir, dir) < 0.5f) return;
+    add_contact(r, -depth, pos, dir);
+    if (prof) pc[SMJ_PROF_C_NHIT] += 1.f;
+    if (prof && M.multiccd && A.type != GT_SPHERE && Bs.type != GT_SPHERE) pc[SMJ_PROF_C_NMULTI] += 1.f;
+    if (M.multiccd && A.type != GT_SPHERE && Bs.type != GT_SPHERE) {
+#ifdef SMJ_EMUL   // the serial formulation stays in the lane emulator as the comparator of the four-wide one (tests/test_emul_parity.py)
+      if (M.multi_serial) { convex_multi(r, A, Bs, s1, s2, pos, dir, margin, 1e-3f * asf(uni(r[SMJ_CP_RBMIN]))); return; }
+#endif
+      const long long t4 = prof ? smj_clock() : 0;
+      const int rounds = convex_multi4(r, A, Bs, s1, s2, pos, dir, margin, 1e-3f * asf(uni(r[SMJ_CP_RBMIN])));
+      if (prof) { pc[SMJ_PROF_C_TMULTI] += (float)(smj_clock() - t4); pc[SMJ_PROF_C_ROUNDS] += (float)rounds; }
+    }
+  }
+
   // non-plane pairs: cache world frames of the participating geoms, sphere + oriented-box broadphase with lane = pair,
   // MPR on the survivors in pair-table order
   SMJ_DEV void collision_convex(float* pc, bool prof) {
-    if (!M.convex_pairs || M.nconvpair == 0) return;
+    if (!M.convex_pairs || (M.nconvpair == 0 && (NSAT == 0 || M.nsgeom == 0))) return;
     long long tc = prof ? smj_clock() : 0;
 #define CTICK(slot) if (prof) { const long long t1 = smj_clock(); pc[slot] += (float)(t1 - tc); tc = t1; }
     for (int c0 = 0; c0 < M.ncgeom; c0 += 64) {
@@ -2380,6 +2459,10 @@ struct StepKernel {
     }
     SYNC();
     CTICK(SMJ_PROF_C_POSE)
+#if NSAT > 0
+    collision_static(pc, prof);   // moving geoms against the world body's geoms, through the uniform grid (before the moving-moving pairs: pair-table order)
+    CTICK(SMJ_PROF_C_NARROW)
+#endif
     // pass 1: bounding spheres of all pairs (lane = pair), survivors compacted in table order.  The pair words of eight
     // chunks are fetched up front so that their load latency is paid once per group, not once per chunk.
     int nsurv = 0;
@@ -2477,70 +2560,11 @@ struct StepKernel {
       while (mask) {
         const int l = ffs64(mask);
         mask &= mask - 1;
-        // the pair's record: one wide scalar load instead of pair -> geoms / slots / margin / parameters
         const int t = wave_read(tt, l);
         const int* r = static_cast<const int*>(__builtin_assume_aligned(M.k_cprec + t * SMJ_CP_STRIDE, 16));
-        const int g1 = uni(r[SMJ_CP_G1]), g2 = uni(r[SMJ_CP_G2]);
-        Shape A, Bs;
-        float c0[3], c1[3], depth, dir[3], pos[3];
-        load_shape(A, g1, uni(r[SMJ_CP_S1]), c0);
-        load_shape(Bs, g2, uni(r[SMJ_CP_S2]), c1);
-        const float margin = asf(uni(r[SMJ_CP_MARGIN]));
-        if (A.type == GT_SPHERE && Bs.type == GT_SPHERE) {
-          if (sphere_sphere(A.pos, A.size[0], Bs.pos, Bs.size[0], margin, depth, dir, pos)) add_contact(r, depth, pos, dir);
-          continue;
-        }
-        if (A.type == GT_SPHERE && Bs.type == GT_BOX) {
-          if (sphere_box(A.pos, A.size[0], Bs, margin, depth, dir, pos)) add_contact(r, depth, pos, dir);
-          continue;
-        }
-        if (A.type == GT_BOX && Bs.type == GT_SPHERE) {
-          if (sphere_box(Bs.pos, Bs.size[0], A, margin, depth, dir, pos)) {
-            for (int k = 0; k < 3; k++) dir[k] = -dir[k];   // the contact keeps the pair's geom order
-            add_contact(r, depth, pos, dir);
-          }
-          continue;
-        }
-        if (A.type == GT_BOX && Bs.type == GT_BOX && M.multiccd) {
-          const long long tb = prof ? smj_clock() : 0;
-          box_box(r, uni(r[SMJ_CP_S1]), uni(r[SMJ_CP_S2]), margin);
-          if (prof) pc[SMJ_PROF_C_TBOXBOX] += (float)(smj_clock() - tb);
-          continue;
-        }
-        const long long tm = prof ? smj_clock() : 0;
-        float sep[3];
-        bool pen = false, skipped = false;
-        if (sepbase && wave_read(stag, l) == t + 1) {   // (tag = pair + 1: a zeroed cache holds no entry)
-          // one support query along the direction that separated the pair last time: still behind the origin (by more than the
-          // rounding of the test) -> disjoint, what the full query would find
-          const float sd[3] = {wave_read(sdx, l), wave_read(sdy, l), wave_read(sdz, l)};
-          MprPt q;
-          mpr_support(A, Bs, sd, q);
-          skipped = dot3(q.v, sd) < -1e-6f;
-#ifdef SMJ_EMUL
-          if (skipped) smj_emul_sep_skips++;   // (tests: the cache is exercised)
-#endif
-        }
-        if (!skipped) {
-          pen = mpr_penetration(A, Bs, c0, c1, depth, dir, pos, sep);
-          if (sepbase && !pen && (sep[0] != 0.f || sep[1] != 0.f || sep[2] != 0.f)) {
-            LANES { if (lane == 0) *reinterpret_cast<Vec4*>(sepbase + 4 * (t & (SMJ_SEP_SLOTS - 1))) = Vec4{sep[0], sep[1], sep[2], asf(t + 1)}; }
-          }
-        }
-        if (prof) pc[SMJ_PROF_C_TMPR1] += (float)(smj_clock() - tm);
-        if (!pen) continue;
-        if (-depth > margin || dot3(dir, dir) < 0.5f) continue;
-        add_contact(r, -depth, pos, dir);
-        if (prof) pc[SMJ_PROF_C_NHIT] += 1.f;
-        if (prof && M.multiccd && A.type != GT_SPHERE && Bs.type != GT_SPHERE) pc[SMJ_PROF_C_NMULTI] += 1.f;
-        if (M.multiccd && A.type != GT_SPHERE && Bs.type != GT_SPHERE) {
-#ifdef SMJ_EMUL   // the serial formulation stays in the lane emulator as the comparator of the four-wide one (tests/test_emul_parity.py)
-          if (M.multi_serial) { convex_multi(r, A, Bs, uni(r[SMJ_CP_S1]), uni(r[SMJ_CP_S2]), pos, dir, margin, 1e-3f * asf(uni(r[SMJ_CP_RBMIN]))); continue; }
-#endif
-          const long long t4 = prof ? smj_clock() : 0;
-          const int rounds = convex_multi4(r, A, Bs, uni(r[SMJ_CP_S1]), uni(r[SMJ_CP_S2]), pos, dir, margin, 1e-3f * asf(uni(r[SMJ_CP_RBMIN])));
-          if (prof) { pc[SMJ_PROF_C_TMULTI] += (float)(smj_clock() - t4); pc[SMJ_PROF_C_ROUNDS] += (float)rounds; }
-        }
+        const float sd[3] = {wave_read(sdx, l), wave_read(sdy, l), wave_read(sdz, l)};
+        narrow_pair(r, uni(r[SMJ_CP_S1]), uni(r[SMJ_CP_S2]), sepbase ? sepbase + 4 * (t & (SMJ_SEP_SLOTS - 1)) : nullptr, t + 1,
+                    sepbase && wave_read(stag, l) == t + 1, sd, pc, prof);
       }
       CTICK(SMJ_PROF_C_NARROW)
     }

@@ -8,7 +8,13 @@
 
 #define SMJ_CAT2(a, b) a##b
 #define SMJ_CAT(a, b) SMJ_CAT2(a, b)
-#if defined(SMJ_BIG)   // three builds: SMJ_VARIANT_TAG = big38 / big50 / big (column capacity SMJ_NVS, smj_model.h)
+#if defined(SMJ_SAT)   // the satellite build (smj_sat.h)
+#define SMJ_STEP_KERNEL SMJ_CAT(smj_step_kernel_, SMJ_VARIANT_TAG)
+#define SMJ_LAUNCH_STEP SMJ_CAT(smj_launch_step_, SMJ_VARIANT_TAG)
+#if SMJ_SAT == 32   // the escalation target of the 16-satellite build
+#define SMJ_WORKER_KERNEL smj_step_kernel_sat32_worker
+#endif
+#elif defined(SMJ_BIG)   // three builds: SMJ_VARIANT_TAG = big38 / big50 / big (column capacity SMJ_NVS, smj_model.h)
 #define SMJ_STEP_KERNEL SMJ_CAT(smj_step_kernel_, SMJ_VARIANT_TAG)
 #define SMJ_LAUNCH_STEP SMJ_CAT(smj_launch_step_, SMJ_VARIANT_TAG)
 #if SMJ_NVS == 64   // the escalation target of the 38- / 50-column builds

@@ -75,6 +75,7 @@ static inline int uni(int x) { return x; }
 static inline float uni(float x) { return x; }
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline float fast_rsqrt(float x) { return 1.0f / sqrtf(x); }
+static inline int lds_atomic_inc(int* p) { const int v = *p; *p = v + 1; return v; }   // (lanes run one after the other here)
 #else
 #include <hip/hip_runtime.h>
 #define SMJ_DEV __device__ __forceinline__
@@ -151,6 +152,7 @@ __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlan
 __device__ __forceinline__ float uni(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); }
 // 1-ulp hardware reciprocal / reciprocal square root (v_rcp_f32 / v_rsq_f32): the serial solver math is latency
 // bound, an IEEE divide costs ~10 dependent instructions
+__device__ __forceinline__ int lds_atomic_inc(int* p) { return atomicAdd(p, 1); }   // a counter in LDS bumped from divergent lanes (ds_add_rtn)
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 #endif

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("SMJ_LIB_PATH") or os.path.join(_HERE, "libsmj.so")   
 
 SLOT = dict(QPOS=0, QVEL=1, CTRL=2, WARMSTART=3, NSTEP=4, ACT_LENGTH=5, ACT_VELOCITY=6, BASE_POSE=7, GYRO=8, ACCEL=9,
             LIDAR=10, INFO=11, DEBUG=12, PROF=13, XPOSE=14, BASECTL=15)
-DIM = dict(NQ=0, NV=1, NU=2, NBODY=3, NLIDAR=4, NKEY=5, NUM_ENVS=6, DEBUG_FLOATS=7, NEFC_MAX=8, NCON_MAX=9, NCAM=10, NV_MAX=11)
+DIM = dict(NQ=0, NV=1, NU=2, NBODY=3, NLIDAR=4, NKEY=5, NUM_ENVS=6, DEBUG_FLOATS=7, NEFC_MAX=8, NCON_MAX=9, NCAM=10, NV_MAX=11, NSAT_MAX=12)
 READ_IMU, READ_LIDAR, READ_POSES = 1, 2, 4
 EXPORTS = ("smj_create", "smj_destroy", "smj_bind", "smj_dims", "smj_reset", "smj_step", "smj_set_option",
            "smj_last_error", "smj_version", "smj_render_depth", "smj_render_rgb", "smj_comm_init", "smj_allgather_returns", "smj_comm_destroy",

@@ -542,6 +542,14 @@ class MjcfCompiler:
         for ch in elem:
             if ch.tag == "mesh":
                 f = ch.get("file")
+                if f is None:
+                    # [MJ] inline mesh: vertex="x y z ..." (+ optional face="i j k ..."); without faces MuJoCo takes the convex hull
+                    if ch.get("vertex") is None or ch.get("name") is None:
+                        raise ValueError("<mesh> needs a file, or a name and inline vertex data")
+                    v = np.array(_floats(ch.get("vertex")), float).reshape(-1, 3)
+                    fc = np.array([int(x) for x in ch.get("face").split()], np.int64).reshape(-1, 3) if ch.get("face") else None
+                    self.meshes[ch.get("name")] = dict(path=None, scale=_floats(ch.get("scale", "1 1 1")), inline=(v, fc))
+                    continue
                 name = ch.get("name") or os.path.splitext(os.path.basename(f))[0]
                 self.meshes[name] = dict(path=os.path.join(assetdir, f), scale=_floats(ch.get("scale", "1 1 1")))
             elif ch.tag == "material":
@@ -642,11 +650,24 @@ class MjcfCompiler:
             if name in mesh_cache:
                 return mesh_cache[name]
             m = self.meshes[name]
-            if not os.path.exists(m["path"]):
+            if m.get("inline") is not None:
+                v, f = m["inline"]
+                if f is None:   # hull faces, wound outwards
+                    from scipy.spatial import ConvexHull
+
+                    h = ConvexHull(v)
+                    f = h.simplices.copy()
+                    cen = v[h.vertices].mean(0)
+                    for k in range(len(f)):
+                        a, b, c = v[f[k]]
+                        if np.dot(np.cross(b - a, c - a), a - cen) < 0:
+                            f[k] = f[k][::-1]
+            elif not os.path.exists(m["path"]):
                 mesh_cache[name] = None
                 self.meshes_missing.append(name)
                 return None
-            v, f = load_mesh(m["path"])
+            else:
+                v, f = load_mesh(m["path"])
             v = v * np.array(m["scale"])
             if np.prod(m["scale"]) < 0:
                 f = f[:, ::-1]

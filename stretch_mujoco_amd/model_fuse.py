@@ -109,7 +109,57 @@ def fuse_static_bodies(m: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     return f
 
 
-def kernel_tables(f: Dict[str, np.ndarray], nsat: int = 0) -> Dict[str, np.ndarray]:
+def _static_grid_tables(f, sp, slot, cell=0.25, maxdim=(48, 48, 16)):
+    """Static collision geoms (world body) of the pairs `sp`, their uniform grid, and the (moving geom slot, static geom) -> pair
+    look-up.  k_sgeom: geom ids; k_sg_cell [nsg][6]: cell range lo / hi per axis; k_grid: dims (3), then origin / cell size in
+    k_grid_f; k_grid_adr [ncell + 1] / k_grid_list: static-geom indices per cell; k_spair [ncgeom][nsg]: index into k_statpair
+    (the pair ids, table order) or -1 where MuJoCo's filters drop the pair."""
+    gb = f["geom_bodyid"]
+    sg = sorted({int(g) for p in sp for g in (f["pair_geom1"][p], f["pair_geom2"][p]) if gb[g] == 0})
+    sidx = {g: i for i, g in enumerate(sg)}
+    nsg, ncg = len(sg), len(slot)
+    f["k_sgeom"] = np.array(sg + [0], np.int32); f["k_nsgeom"] = np.array([nsg], np.int32)
+    f["k_statpair"] = np.array(sp + [0], np.int32); f["k_nstatpair"] = np.array([len(sp)], np.int32)
+    tab = np.full((max(ncg, 1), max(nsg, 1)), -1, np.int32)
+    for i, p in enumerate(sp):
+        g1, g2 = int(f["pair_geom1"][p]), int(f["pair_geom2"][p])
+        s_, d_ = (g1, g2) if gb[g1] == 0 else (g2, g1)
+        tab[slot[d_], sidx[s_]] = i
+    f["k_spair"] = tab
+    margin = float(max([f["pair_margin"][p] for p in sp] + [0.0]))
+    lo = np.zeros((max(nsg, 1), 3)); hi = np.zeros((max(nsg, 1), 3))
+    for i, g in enumerate(sg):   # world AABB of the geom's oriented box (the world body's frame is the world frame)
+        R = quat2mat(f["geom_quat"][g])
+        c = f["geom_pos"][g] + R @ f["geom_aabb"][g][:3]
+        h = np.abs(R) @ f["geom_aabb"][g][3:] + margin
+        lo[i], hi[i] = c - h, c + h
+    org = lo[:nsg].min(0) - 1e-6 if nsg else np.zeros(3)
+    ext = (hi[:nsg].max(0) - org) if nsg else np.ones(3)
+    h = cell
+    dims = np.maximum(1, np.ceil(ext / h).astype(int))
+    while np.any(dims > np.array(maxdim)):   # (a large scene: coarser cells rather than more of them)
+        h *= 1.5
+        dims = np.maximum(1, np.ceil(ext / h).astype(int))
+    cells = [[] for _ in range(int(np.prod(dims)))]
+    rng = np.zeros((max(nsg, 1), 6), np.int32)
+    for i in range(nsg):
+        a = np.clip(np.floor((lo[i] - org) / h).astype(int), 0, dims - 1)
+        b = np.clip(np.floor((hi[i] - org) / h).astype(int), 0, dims - 1)
+        rng[i] = list(a) + list(b)
+        for z in range(a[2], b[2] + 1):
+            for y in range(a[1], b[1] + 1):
+                for x in range(a[0], b[0] + 1):
+                    cells[(z * dims[1] + y) * dims[0] + x].append(i)
+    adr = np.zeros(len(cells) + 1, np.int32)
+    adr[1:] = np.cumsum([len(c) for c in cells])
+    f["k_grid"] = np.array(list(dims), np.int32)
+    f["k_grid_f"] = np.array(list(org) + [h, margin])
+    f["k_grid_adr"] = adr
+    f["k_grid_list"] = np.array([i for c in cells for i in c] + [0], np.int32)
+    f["k_sg_cell"] = rng
+
+
+def kernel_tables(f: Dict[str, np.ndarray], nsat: int = 0, static_grid: bool = False) -> Dict[str, np.ndarray]:
     """Lane-indexed scheduling tables for csrc/smj_kernels.hip (added in place, `k_` prefix).
 
     nsat > 0: the last `nsat` bodies are SATELLITES (find_satellites) -- the tree tables below then describe the MAIN part only
@@ -190,14 +240,21 @@ def kernel_tables(f: Dict[str, np.ndarray], nsat: int = 0) -> Dict[str, np.ndarr
     pp = [p for p in range(len(f["pair_geom1"])) if f["geom_type"][f["pair_geom1"][p]] == GEOM_PLANE]
     pp_set = set(pp)
     f["k_planepair"] = np.array(pp + [0], np.int32); f["k_nplanepair"] = np.array([len(pp)], np.int32)
-    # convex (non-plane) pairs: collision-geom slots for the per-step world OBB cache, pair list in table order
-    cg = sorted({int(g) for p in range(len(f["pair_geom1"])) if p not in pp_set for g in (f["pair_geom1"][p], f["pair_geom2"][p])})
+    # convex (non-plane) pairs: collision-geom slots for the per-step world OBB cache, pair list in table order.
+    # static_grid: the geoms of the WORLD body (a kitchen's fixtures: hundreds) stay out of the cache and of the pair list the
+    # kernels scan -- their world frames never change -- and are found through a uniform grid instead (k_grid_*, k_sg*): the
+    # broadphase of a moving geom against them visits the cells its bounding box overlaps (csrc: StepKernel::collision_static).
+    gb = f["geom_bodyid"]
+    nonplane = [p for p in range(len(f["pair_geom1"])) if p not in pp_set]
+    is_static_pair = lambda p: static_grid and (gb[f["pair_geom1"][p]] == 0 or gb[f["pair_geom2"][p]] == 0)
+    sp = [p for p in nonplane if is_static_pair(p)]
+    cp = [p for p in nonplane if not is_static_pair(p)]
+    cg = sorted({int(g) for p in nonplane for g in (f["pair_geom1"][p], f["pair_geom2"][p]) if not (static_grid and gb[g] == 0)})
     if len(cg) > 128:
-        raise ValueError("more than 128 geoms take part in non-plane collision pairs")
+        raise ValueError("more than 128 moving geoms take part in non-plane collision pairs")
     if len(f["geom_hullnum"]) and (int(np.max(f["geom_hullnum"])) >= 4096 or int(np.max(f["geom_hulladr"])) >= 65536):
         raise ValueError("convex hulls: the kernel packs vertex count (< 4096) and hull address (< 65536) into one word")
     slot = {g: i for i, g in enumerate(cg)}
-    cp = [p for p in range(len(f["pair_geom1"])) if p not in pp_set]
     f["k_cgeom"] = np.array(cg + [0], np.int32); f["k_ncgeom"] = np.array([len(cg)], np.int32)
     f["k_convpair"] = np.array(cp + [0], np.int32); f["k_nconvpair"] = np.array([len(cp)], np.int32)
     f["k_convpair_s1"] = np.array([slot[int(f["pair_geom1"][p])] for p in cp] + [0], np.int32)
@@ -209,6 +266,7 @@ def kernel_tables(f: Dict[str, np.ndarray], nsat: int = 0) -> Dict[str, np.ndarr
     f["k_hull_vert4"] = np.concatenate([hv, np.zeros((len(hv), 1))], axis=1) if len(hv) else np.zeros((1, 4))   # one 16-byte load per vertex
     f["k_cgeom_half"] = np.array([f["geom_aabb"][g][3:] for g in cg] + [[0, 0, 0]], float)
     f["k_cgeom_lcen"] = np.array([f["geom_aabb"][g][:3] for g in cg] + [[0, 0, 0]], float)
+    _static_grid_tables(f, sp, slot)
     # sites: local matrices
     ns = len(f["site_bodyid"])
     smat = np.zeros((ns, 9))
@@ -421,7 +479,7 @@ def prepare_for_kernels(m: Dict[str, np.ndarray], capacity: str = "auto", satell
     blob then addresses the satellite builds of the step kernel (the main part must fit 32 dofs / 32 bodies)."""
     f = fuse_static_bodies(m)
     nsat = find_satellites(f) if satellites else 0
-    f = kernel_tables(f, nsat)
+    f = kernel_tables(f, nsat, static_grid=satellites)   # (the satellite builds carry the static-geometry grid)
     f["k_nsat"] = np.array([nsat], np.int32)
     f["k_capacity_hint"] = np.array([1 if capacity == "big" else 0], np.int32)
     return f

@@ -98,7 +98,8 @@ class StretchBatchSimulator:
         self.nlidar = dims[D["NLIDAR"]]
         # capacities of the kernel variant smj_create chose for this model (standard: 32 dofs / 80 rows / 16 contacts; big: 64 / 160 / 48)
         self.nv_max, self.nefc_max, self.ncon_max = dims[D["NV_MAX"]], dims[D["NEFC_MAX"]], dims[D["NCON_MAX"]]
-        self.debug_layout = _lib.debug_layout(self.nv_max, self.ncon_max)
+        self.nsat_max = dims[D["NSAT_MAX"]]   # > 0: the model runs on a satellite build of the step kernel (csrc/smj_sat.h)
+        self.debug_layout = _lib.debug_layout(self.nv_max, self.ncon_max, self.nsat_max)
         B, f = self.num_envs, dict(dtype=torch.float32, device=self.device)
         i32 = dict(dtype=torch.int32, device=self.device)
         self.qpos = torch.zeros(self.nq, B, **f); self.qvel = torch.zeros(self.nv, B, **f)

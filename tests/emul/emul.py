@@ -17,7 +17,7 @@ def lib(variant: str = "standard"):
     big = variant   # cache key
     if big not in _LIB:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
-        L = ctypes.CDLL(os.path.join(_HERE, {"standard": "libsmj_emul.so", "tall": "libsmj_emul_tall.so", "mid": "libsmj_emul_mid.so", "big": "libsmj_emul_big.so", "big38": "libsmj_emul_big38.so", "big50": "libsmj_emul_big50.so", "poison": "libsmj_emul_poison.so", "sat": "libsmj_emul_sat.so"}[variant]))
+        L = ctypes.CDLL(os.path.join(_HERE, {"standard": "libsmj_emul.so", "tall": "libsmj_emul_tall.so", "mid": "libsmj_emul_mid.so", "big": "libsmj_emul_big.so", "big38": "libsmj_emul_big38.so", "big50": "libsmj_emul_big50.so", "poison": "libsmj_emul_poison.so", "sat": "libsmj_emul_sat.so", "sat32": "libsmj_emul_sat32.so"}[variant]))
         L.emul_create.restype = ctypes.c_void_p
         L.emul_create.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
         L.emul_bind.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_long]
@@ -39,7 +39,7 @@ class Emul:
 
             ns = mb0.loads(blob).get("k_nsat")
             if ns is not None and int(np.asarray(ns).ravel()[0]) > 0:
-                variant = "sat"
+                variant = "sat" if int(np.asarray(ns).ravel()[0]) <= 16 else "sat32"
         if variant is None:
             if big or dims["nv"] > 32:   # the big variant is built for 38 / 50 / 64 dof columns (smj_model.h); big=True with a small model: 64
                 variant = "big38" if 32 < dims["nv"] <= 38 else "big50" if 38 < dims["nv"] <= 50 else "big"
@@ -52,7 +52,7 @@ class Emul:
         self.big = variant.startswith("big")
         self.L = lib(variant)
         self.nvp, self.ncon_max = self.L.emul_nvp(), self.L.emul_ncon_max()
-        self.nsat_max = 32 if variant == "sat" else 0
+        self.nsat_max = {"sat": 16, "sat32": 32}.get(variant, 0)
         self.B = B = num_envs
         self.c = self.L.emul_create(blob, len(blob), B)
         if not self.c:

@@ -116,6 +116,7 @@ int emul_step(emul_ctx* c, int nsteps, unsigned read_flags) {
 }
 int emul_debug_floats() { return SMJ_DEBUG_FLOATS; }
 int emul_nvp() { return NVP; }
+int emul_lds_bytes() { return (int)sizeof(Smem); }
 int emul_ncon_max() { return NCON; }
 int emul_nefc_max() { return NEFC; }
 }

@@ -162,13 +162,17 @@ def state_synchronised(backend, blob, model, B, windows, seed, solver=2):
 
 def _compare_contacts(cstat, dump, ncon_k, o):
     """Contact list of the kernel (debug slot: dist, pos, normal, condim | geom1 << 4 | geom2 << 14 per contact) against the
-    oracle's on the same state, contact by contact in list order (both emit in pair-table order)."""
+    oracle's on the same state, contact by contact.  Both lists are put in geom-pair order first (stable: the contacts of one pair
+    keep their order): the oracle emits in pair-table order, the kernel plane pairs first, then the pairs with static geoms, then
+    the moving-moving pairs, each group in table order."""
     n = o.ncon
     ck = dump.reshape(-1, 8)[:ncon_k]
     co = o.arr("contact").reshape(n, -1) if n else np.zeros((0, 29))
     code = ck[:, 7].astype(np.int64)
     gk = [(int((c >> 4) & 1023), int(c >> 14)) for c in code]
     go = [tuple(int(v) for v in co[k, -2:].copy().view(np.int32)[1:3]) for k in range(n)]
+    ik, io = sorted(range(len(gk)), key=lambda k: gk[k]), sorted(range(n), key=lambda k: go[k])
+    gk, go, ck, co = [gk[k] for k in ik], [go[k] for k in io], ck[ik], co[io]
     if gk != go:
         cstat["mismatched_steps"] += 1
         return False
@@ -185,11 +189,11 @@ def _compare_contacts(cstat, dump, ncon_k, o):
 class EmulBackend:
     """The kernel source through the CPU lane emulator (tests/emul)."""
 
-    def __init__(self, blob, B, solver=2):
+    def __init__(self, blob, B, solver=2, variant=None):
         from emul.emul import Emul
 
         o = Oracle(blob)
-        self.e = Emul(blob, dict(nq=o.dim("nq"), nv=o.dim("nv"), nu=o.dim("nu"), nlidar=360), num_envs=B, debug=True)   # variant as smj_create picks it
+        self.e = Emul(blob, dict(nq=o.dim("nq"), nv=o.dim("nv"), nu=o.dim("nu"), nlidar=360), num_envs=B, debug=True, variant=variant)   # variant as smj_create picks it
         self.e.set_option("solver", solver)
         from stretch_mujoco_amd.lib import debug_layout
         import stretch_mujoco_amd.model_blob as mb
@@ -245,8 +249,12 @@ class HipBackend:
     def download(self):
         s = self.sim
         self.torch.cuda.synchronize()
+        from stretch_mujoco_amd.lib import full_qacc
+
+        dbg = s.debug.cpu().numpy()
+        qacc = full_qacc(dbg, self.D, s.model) if s.nsat_max else dbg[self.D["qacc"]:self.D["qacc"] + self.nvp]
         return dict(qpos=s.qpos.cpu().numpy().astype(np.float64), qvel=s.qvel.cpu().numpy().astype(np.float64),
-                    info=s.info.cpu().numpy(), qacc=s.debug[self.D["qacc"]:self.D["qacc"] + self.nvp].cpu().numpy().astype(np.float64),
+                    info=s.info.cpu().numpy(), qacc=qacc.astype(np.float64),
                     contacts=s.debug[self.D["con"]:self.D["con"] + 8 * self.ncon_max].cpu().numpy())
 
     def close(self):

@@ -34,6 +34,8 @@ def main():
     for name, xml in (("stretch_scene", C.scene_table_xml(stretch)), ("stretch_kitchen4", C.kitchen_standin_xml(stretch, free_objects=True))):
         mm = C.compile_string(xml)
         B.save(os.path.join(out, name + ".smjb"), F.prepare_for_kernels(mm))
+        # the same scene for the satellite builds of the step kernel (csrc/smj_sat.h): the free objects leave the dense problem
+        B.save(os.path.join(out, name + "_sat.smjb"), F.prepare_for_kernels(mm, satellites=True))
         print(name + ":", dict(zip("nq nv nu nbody njnt ngeom".split(), [int(x) for x in mm["dims"][:6]])), "npair", int(mm["dims"][12]))
     # a robosuite-style kitchen export (hand-written test fixture: articulated fixtures, <inertial>, capsule / ellipsoid objects)
     # through the converter for pre-exported Robocasa kitchens (robocasa_import.py; robocasa_gen.py:242-280)
@@ -43,7 +45,18 @@ def main():
     kx, pose = convert_kitchen_xml(KITCHEN_EXPORT, stretch)
     ke = C.compile_string(kx)
     B.save(os.path.join(out, "stretch_kitchen_export.smjb"), F.prepare_for_kernels(ke))
+    B.save(os.path.join(out, "stretch_kitchen_export_sat.smjb"), F.prepare_for_kernels(ke, satellites=True))   # door, drawer and the objects as satellites
     print("stretch_kitchen_export:", dict(zip("nq nv nu nbody njnt ngeom".split(), [int(x) for x in ke["dims"][:6]])), "npair", int(ke["dims"][12]), "spawn pose", pose)
+    # a kitchen at Robocasa scale (generated test fixture: 44 fixture bodies, 307 collision geoms incl. 36 convex mesh pieces, 8
+    # articulated doors / drawers / knobs, 8 free objects) through the same converter; the removed robot's pose becomes the start
+    # pose (what change_start_pose does in the reference, mujoco_server.py:206-229).  Satellite build + static-geometry grid.
+    from kitchen_robocasa_fixture import kitchen_xml
+    rx, rstats = kitchen_xml()
+    rkx, rpose = convert_kitchen_xml(rx, stretch)
+    rk = C.compile_string(rkx)
+    rk["qpos0"][0:3] = rpose["pos"]; rk["qpos0"][3:7] = rpose["quat"]
+    B.save(os.path.join(out, "stretch_kitchen_robocasa.smjb"), F.prepare_for_kernels(rk, satellites=True))
+    print("stretch_kitchen_robocasa:", rstats, dict(zip("nq nv nu nbody njnt ngeom".split(), [int(x) for x in rk["dims"][:6]])), "npair", int(rk["dims"][12]))
     print("stretch_kitchen_standin:", dict(zip("nq nv nu nbody njnt ngeom".split(), [int(x) for x in k["dims"][:6]])),
           "npair", int(k["dims"][12]))
     print("stretch_empty:", dict(zip("nq nv nu nbody njnt ngeom nsite ncam neq ntendon nwrap nkey npair nhullvert".split(),
