@@ -2,7 +2,7 @@
 // one env per CU.  Models with more than 16 satellites, and the escalation target of the 16-satellite build: an env whose step
 // needs more rows / contacts / coupled satellites than that build holds is finished here (DevState::redo, as standard -> tall).
 #define SMJ_SAT 32
-#define SMJ_SAT_ROWS 224
+#define SMJ_SAT_ROWS 256
 #define SMJ_SAT_CONTACTS 64
 #define SMJ_SAT_DENSE 128
 #define SMJ_SAT_EXT 4

@@ -22,7 +22,7 @@
 #define NSAT SMJ_SAT
 #define NVP 32
 #ifndef SMJ_SAT_ROWS
-#define SMJ_SAT_ROWS 224
+#define SMJ_SAT_ROWS 256
 #define SMJ_SAT_CONTACTS 64
 #define SMJ_SAT_DENSE 128
 #endif
@@ -115,6 +115,7 @@ struct DevModel {
   int iterations, warmstart, pgs_fixed_iter, max_con_pair, solver /* 0 PGS, 2 Newton */, ls_iterations, convex_pairs;
   int qcqp_exact;   // PGS: 1 = the friction QCQP iterates exactly as mju_QCQP does (from la = 0 on |x|^2 - r^2, cap 20); 0 (default) = same root, secular form, started at the last sweep's multiplier
   int sep_cache;      // 1 = use DevState::sepcache (separating directions of convex pairs kept between steps)
+  int manifold_cache; // 1 = use DevState::mcache (contact manifolds of convex pairs whose two bodies have not moved)
   int multi_serial;   // lane emulator only: 1 = the four multiccd queries of a pair one after the other (convex_multi), the comparator of convex_multi4
   int pgs_cap;    // > 0 (set per launch, smj_step_tu.h): a PGS step of this launch holds at most this many rows -- its packed A then starts at row pgs_cap of J and ends inside the struct (no dynamic LDS); a step with more rows goes to the escalation variant
   int row_limit;  // > 0: the primary variant hands an env over to the escalation variant beyond this many constraint rows (tests; option "primary_rows")
@@ -134,7 +135,8 @@ struct DevModel {
   const int* k_grid_adr;  // [cells + 1]
   const int* k_grid_list; // static-geom indices, cell after cell
   const int* k_sg_cell;   // [nsgeom][6] cell range of the geom (lo xyz, hi xyz)
-  const float* k_sg_bound;   // [nsgeom][4] world centre of the geom's box, bounding radius
+  const float* k_sg_bound;   // [nsgeom][8] world AABB of the geom's oriented box: lo xyz, pad, hi xyz, pad
+  const float* k_sgw;        // [nsgeom][32] the geom in the world frame, in the order of the collision cache's arrays: pos 3, mat 9, box centre 3, half sizes 3, MPR centre 3, size 3, meta (bits)
 #define X(n) const int* n;
   SMJ_MODEL_I32(X)
 #undef X
@@ -155,7 +157,8 @@ struct DevModel {
   const int* k_cprec;     // [nconvpair][SMJ_CP_STRIDE]
 };
 enum { SMJ_CP_PAIR = 0, SMJ_CP_G1, SMJ_CP_G2, SMJ_CP_S1, SMJ_CP_S2, SMJ_CP_MARGIN, SMJ_CP_MG, SMJ_CP_CONDIM, SMJ_CP_FRIC = 8, SMJ_CP_SOLIMP = 13,
-       SMJ_CP_SOLREF = 18, SMJ_CP_RBMIN = 20 /* min bounding radius of the two geoms (multiccd duplicate tolerance) */, SMJ_CP_STRIDE = 24 };
+       SMJ_CP_SOLREF = 18, SMJ_CP_RBMIN = 20 /* min bounding radius of the two geoms (multiccd duplicate tolerance) */,
+       SMJ_CP_B1 = 21, SMJ_CP_B2 = 22 /* bodies of the two geoms */, SMJ_CP_STRIDE = 24 };
 // row record: type, id (equality / dof / joint), dofs (limit: dof, side), qpos addresses, reference values (equality: qpos0 of
 // both joints; limit: range bound of the side, margin), equality polynomial, diagonal approximation, friction loss, solref, solimp
 enum { SMJ_RR_TYPE = 0, SMJ_RR_ID, SMJ_RR_D1, SMJ_RR_D2, SMJ_RR_Q1, SMJ_RR_Q2, SMJ_RR_V1, SMJ_RR_V2, SMJ_RR_DATA = 8, SMJ_RR_DIAG = 13,
@@ -255,8 +258,15 @@ struct DevState {
   // still separates.  Any direction with a negative support proves the shapes disjoint, so a stale or foreign entry can only
   // fail the test, never change a result.
   float* sepcache;
+  // Contact manifolds of convex pairs (null = off): [B][SMJ_MC_SLOTS][SMJ_MC_WORDS], direct-mapped by pair key.  An entry holds the
+  // poses (xpos, xquat) the pair's two BODIES had when its narrowphase last ran and the contacts it found; while both poses are
+  // within SMJ_MC_EPS of those, the pair's contacts are the stored ones and MPR / multiccd / the box-box polygon are skipped --
+  // an object resting on a counter costs one 160-byte load per step instead of five penetration queries.  The contacts move by
+  // at most the pose tolerance (3e-7 m: a few ulp of a metre-scale coordinate), three orders below the parity bounds.
+  float* mcache;
 };
-enum { SMJ_SEP_SLOTS = 64 };
+enum { SMJ_SEP_SLOTS = 64, SMJ_MC_SLOTS = 32, SMJ_MC_WORDS = 40 };
+#define SMJ_MC_EPS 3e-7f
 enum { SMJ_PIPE_ABANDONED = 0x7fffffff, SMJ_PIPE_SWEPT = 0x7ffffffe, SMJ_HOT_LAUNCHES = 8 };
 enum { SMJ_SCHED_CLAIMED = 0, SMJ_SCHED_EXITED = 1, SMJ_SCHED_POLLERS = 2, SMJ_SCHED_COUNT = 3, SMJ_SCHED_WORDS = 4 };
 // BaseController state rows (floats; mode: 0 none, 1 translate-by, 2 rotate-by, 3 velocity)
@@ -273,7 +283,9 @@ enum { SMJ_PROF_KIN = 0, SMJ_PROF_COMCRB, SMJ_PROF_SMOOTH, SMJ_PROF_FACTOR, SMJ_
        SMJ_PROF_N_PREP, SMJ_PROF_N_LS, SMJ_PROF_N_LSEVALS,
        // convex collision: cycles of the pose / bounding-sphere / oriented-box / narrowphase parts, and counts per step
        SMJ_PROF_C_POSE, SMJ_PROF_C_SPHERE, SMJ_PROF_C_OBB, SMJ_PROF_C_NARROW, SMJ_PROF_C_NSPHERE, SMJ_PROF_C_NOBB, SMJ_PROF_C_NHIT,
-       SMJ_PROF_C_NMULTI, SMJ_PROF_C_TBOXBOX, SMJ_PROF_C_TMPR1, SMJ_PROF_C_TMULTI, SMJ_PROF_C_ROUNDS, SMJ_PROF_H_K, SMJ_PROF_H_CONE, SMJ_PROF_H_STORE, SMJ_PROF_H_NKS, SMJ_PROF_SLOTS = 40 };
+       SMJ_PROF_C_NMULTI, SMJ_PROF_C_TBOXBOX, SMJ_PROF_C_TMPR1, SMJ_PROF_C_TMULTI, SMJ_PROF_C_ROUNDS, SMJ_PROF_H_K, SMJ_PROF_H_CONE, SMJ_PROF_H_STORE, SMJ_PROF_H_NKS,
+       // satellite builds: static broadphase / its narrowphase loop; make_constraint_sat: clear + static rows, contact rows, Jacobian fill, row items, impedance; satellites' Hessian blocks + own solves
+       SMJ_PROF_S_BROAD = 40, SMJ_PROF_S_NARROW, SMJ_PROF_MC_ROWS, SMJ_PROF_MC_CON, SMJ_PROF_MC_JAC, SMJ_PROF_MC_ITEMS, SMJ_PROF_MC_IMP, SMJ_PROF_SAT_H, SMJ_PROF_SLOTS = 48 };
 enum { SMJ_INFO_NEFC = 0, SMJ_INFO_NCON = 1, SMJ_INFO_NITER = 2, SMJ_INFO_FLAGS = 3 };
 enum { SMJ_FLAG_EFC_OVERFLOW = 1, SMJ_FLAG_CON_OVERFLOW = 2, SMJ_FLAG_BAD_STATE = 4, SMJ_FLAG_PIPE_TIMEOUT = 8 };
 

@@ -3,6 +3,7 @@
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
+#include <math.h>
 #include <string.h>
 
 #include <map>
@@ -243,6 +244,7 @@ static inline std::vector<int> smj_build_cprec(const DevModel& m, std::map<std::
     k[SMJ_CP_SOLREF] = fb(gf("pair_solref", 2 * p)); k[SMJ_CP_SOLREF + 1] = fb(gf("pair_solref", 2 * p + 1));
     const float r1 = gf("geom_rbound", k[SMJ_CP_G1]), r2 = gf("geom_rbound", k[SMJ_CP_G2]);
     k[SMJ_CP_RBMIN] = fb(r1 < r2 ? r1 : r2);
+    k[SMJ_CP_B1] = gi("geom_bodyid", k[SMJ_CP_G1]); k[SMJ_CP_B2] = gi("geom_bodyid", k[SMJ_CP_G2]);
   }
   return rec;
 }
@@ -288,7 +290,7 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
     const SmjBlobEntry* e = b.find("sensor_lidar_site");
     m.nlidar = e ? (int)(e->nbytes / 4) : 0;
   }
-  m.row_limit = 0; m.pgs_cap = 0; m.warmstart = 1; m.pgs_fixed_iter = 0; m.qcqp_exact = 0; m.max_con_pair = 4; m.solver = 0; m.convex_pairs = 1; m.multiccd = 1; m.sep_cache = getenv("SMJ_NO_SEPCACHE") ? 0 : 1; m.multi_serial = 0; m.ls_iterations = 50; m.ls_tolerance = 0.01f;
+  m.row_limit = 0; m.pgs_cap = 0; m.warmstart = 1; m.pgs_fixed_iter = 0; m.qcqp_exact = 0; m.max_con_pair = 4; m.solver = 0; m.convex_pairs = 1; m.multiccd = 1; m.sep_cache = getenv("SMJ_NO_SEPCACHE") ? 0 : 1; m.manifold_cache = getenv("SMJ_NO_MCACHE") ? 0 : 1; m.multi_serial = 0; m.ls_iterations = 50; m.ls_tolerance = 0.01f;
   char buf[256];
   int pick = -1, first = 0;
   {   // optional hint of the model compiler: contact-rich scene, start at the big variant (model_fuse.prepare_for_kernels)
@@ -347,7 +349,7 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
   }
   SMJ_MODEL_F32(X)
 #undef X
-  m.nsgeom = 0; m.nstatpair = 0; m.k_sgrec = m.k_sprec = m.k_spair = m.k_grid_adr = m.k_grid_list = m.k_sg_cell = nullptr; m.k_sg_bound = nullptr;
+  m.nsgeom = 0; m.nstatpair = 0; m.k_sgrec = m.k_sprec = m.k_spair = m.k_grid_adr = m.k_grid_list = m.k_sg_cell = nullptr; m.k_sg_bound = nullptr; m.k_sgw = nullptr;
   if (b.find("k_nsgeom")) {
     if (!geti("k_nsgeom", 0, &m.nsgeom) || !geti("k_nstatpair", 0, &m.nstatpair)) return -3;
     if (m.nsgeom > 0) {
@@ -372,17 +374,38 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
       std::vector<int> sg = smj_build_cgrec(m, hosti, hostf, true), spr = smj_build_cprec(m, hosti, hostf, true);
       m.k_sgrec = up.i32(sg);
       m.k_sprec = up.i32(spr);
-      std::vector<float> bound(4 * (size_t)m.nsgeom);
-      for (int c = 0; c < m.nsgeom; c++) {   // world centre of the geom's box: pos + R lcen
+      std::vector<float> bound(8 * (size_t)m.nsgeom, 0.f);   // world AABB of the geom's oriented box: lo xyz, pad, hi xyz, pad
+      std::vector<float> wcen(3 * (size_t)m.nsgeom, 0.f);
+      for (int c = 0; c < m.nsgeom; c++) {
         const int* k = sg.data() + (size_t)c * SMJ_CG_STRIDE;
         float f[SMJ_CG_STRIDE];
         memcpy(f, k, sizeof f);
-        for (int i = 0; i < 3; i++)
-          bound[4 * c + i] = f[SMJ_CG_POS + i] + f[SMJ_CG_MAT + 3 * i] * f[SMJ_CG_LCEN] + f[SMJ_CG_MAT + 3 * i + 1] * f[SMJ_CG_LCEN + 1] + f[SMJ_CG_MAT + 3 * i + 2] * f[SMJ_CG_LCEN + 2];
-        bound[4 * c + 3] = f[SMJ_CG_RBOUND];
+        for (int i = 0; i < 3; i++) {
+          const float cen = f[SMJ_CG_POS + i] + f[SMJ_CG_MAT + 3 * i] * f[SMJ_CG_LCEN] + f[SMJ_CG_MAT + 3 * i + 1] * f[SMJ_CG_LCEN + 1] + f[SMJ_CG_MAT + 3 * i + 2] * f[SMJ_CG_LCEN + 2];
+          const float ext = fabsf(f[SMJ_CG_MAT + 3 * i]) * f[SMJ_CG_HALF] + fabsf(f[SMJ_CG_MAT + 3 * i + 1]) * f[SMJ_CG_HALF + 1] + fabsf(f[SMJ_CG_MAT + 3 * i + 2]) * f[SMJ_CG_HALF + 2];
+          wcen[3 * c + i] = cen;
+          bound[8 * c + i] = cen - ext; bound[8 * c + 4 + i] = cen + ext;
+        }
       }
       m.k_sg_bound = up.f32(bound);
-      if (!m.k_sgrec || !m.k_sprec || !m.k_sg_bound) { err = "device allocation failed for the static-geometry tables"; return -2; }
+      std::vector<float> sgw(32 * (size_t)m.nsgeom, 0.f);
+      for (int c = 0; c < m.nsgeom; c++) {
+        const int* k = sg.data() + (size_t)c * SMJ_CG_STRIDE;
+        float f[SMJ_CG_STRIDE];
+        memcpy(f, k, sizeof f);
+        float* w = sgw.data() + 32 * (size_t)c;
+        for (int i = 0; i < 3; i++) {
+          w[i] = f[SMJ_CG_POS + i];
+          w[12 + i] = wcen[3 * c + i];
+          w[15 + i] = f[SMJ_CG_HALF + i];
+          w[18 + i] = f[SMJ_CG_POS + i] + f[SMJ_CG_MAT + 3 * i] * f[SMJ_CG_CCEN] + f[SMJ_CG_MAT + 3 * i + 1] * f[SMJ_CG_CCEN + 1] + f[SMJ_CG_MAT + 3 * i + 2] * f[SMJ_CG_CCEN + 2];
+          w[21 + i] = f[SMJ_CG_SIZE + i];
+        }
+        for (int i = 0; i < 9; i++) w[3 + i] = f[SMJ_CG_MAT + i];
+        memcpy(&w[24], &k[SMJ_CG_META], 4);
+      }
+      m.k_sgw = up.f32(sgw);
+      if (!m.k_sgrec || !m.k_sprec || !m.k_sg_bound || !m.k_sgw) { err = "device allocation failed for the static-geometry tables"; return -2; }
     }
   }
   m.nfric_main = m.nfric; m.nlimit_main = m.nlimit; m.k_satrec = nullptr;

@@ -17,6 +17,9 @@
 
 SMJ_DEV const int* satrec(int si) const { return M.k_satrec + si * SMJ_SR_STRIDE; }
 SMJ_DEV static int tri6(int i, int j) { return i >= j ? (i * (i + 1)) / 2 + j : (j * (j + 1)) / 2 + i; }
+// the six satellite columns of slot u of a row
+SMJ_DEV const float* jsp(int row, int u) const { return u ? s.sat.Js2[s.sat.e2[row]] : s.sat.Js[row]; }
+SMJ_DEV float* jspw(int row, int u) { return u ? s.sat.Js2[s.sat.e2[row]] : s.sat.Js[row]; }
 
 // ------------------------------------------------------------------ state
 SMJ_DEV void sat_load_state() {
@@ -209,7 +212,7 @@ SMJ_DEV float sat_jdot(int row, int fld) const {
   for (int u = 0; u < 2; u++) {
     const int si = s.sat.esat[row][u];
     if (si >= 0)
-      for (int k = 0; k < 6; k++) v += s.sat.Js[row][u][k] * s.sat.x[fld][si][k];
+      { const float* js = jsp(row, u); for (int k = 0; k < 6; k++) v += js[k] * s.sat.x[fld][si][k]; }
   }
   return v;
 }
@@ -223,7 +226,7 @@ SMJ_DEV void sat_JTf() {
         const int r0 = s.sat.irow[si][it], inf = s.sat.iinf[si][it], n = inf & ITEM_N, u = (inf & ITEM_SLOT) ? 1 : 0;
         for (int p = 0; p < n; p++) {
           const float f = s.ef[r0 + p];
-          for (int k = 0; k < 6; k++) acc[k] += s.sat.Js[r0 + p][u][k] * f;
+          { const float* js = jsp(r0 + p, u); for (int k = 0; k < 6; k++) acc[k] += js[k] * f; }
         }
       }
       for (int k = 0; k < 6; k++) s.sat.x[SX_TMP][si][k] = acc[k];
@@ -233,20 +236,21 @@ SMJ_DEV void sat_JTf() {
 
 // in-register LDL' solve of a 6 x 6 symmetric positive definite block (packed lower triangle), x <- A^-1 x
 SMJ_DEV static void sat_solve6(const float* A, float* x) {
-  float L[21], D[6];
+  float L[21], D[6], Dv[6];
 #pragma unroll
   for (int j = 0; j < 6; j++) {
     float d = A[tri6(j, j)];
 #pragma unroll
-    for (int k = 0; k < j; k++) d -= L[tri6(j, k)] * L[tri6(j, k)] * D[k];
+    for (int k = 0; k < j; k++) d -= L[tri6(j, k)] * L[tri6(j, k)] * Dv[k];
     d = fmaxf(d, 1e-30f);
-    D[j] = d;
-    const float inv = 1.0f / d;
+    Dv[j] = d;
+    D[j] = fast_rcp(d);   // (kept as the reciprocal)
+    const float inv = D[j];
 #pragma unroll
     for (int i = j + 1; i < 6; i++) {
       float v = A[tri6(i, j)];
 #pragma unroll
-      for (int k = 0; k < j; k++) v -= L[tri6(i, k)] * L[tri6(j, k)] * D[k];
+      for (int k = 0; k < j; k++) v -= L[tri6(i, k)] * L[tri6(j, k)] * Dv[k];
       L[tri6(i, j)] = v * inv;
     }
   }
@@ -255,7 +259,7 @@ SMJ_DEV static void sat_solve6(const float* A, float* x) {
 #pragma unroll
     for (int k = 0; k < i; k++) x[i] -= L[tri6(i, k)] * x[k];
 #pragma unroll
-  for (int i = 0; i < 6; i++) x[i] /= D[i];
+  for (int i = 0; i < 6; i++) x[i] *= D[i];
 #pragma unroll
   for (int i = 5; i >= 0; i--)
 #pragma unroll
@@ -274,28 +278,33 @@ SMJ_DEV void sat_hessian(uint64_t conemask) {
         const int r0 = s.sat.irow[si][it], inf = s.sat.iinf[si][it], n = inf & ITEM_N, u = (inf & ITEM_SLOT) ? 1 : 0;
         const int c = s.sat.icon[si][it];
         if ((inf & ITEM_CONTACT) && ((conemask >> c) & 1)) {
-          const float* Hc = s.u.n.cH[c];
-          float T[6][6];   // T[p][k] = sum_q Hc[p][q] Js[r0+q][k]
-          for (int p = 0; p < 6; p++)
+          const float* Hc = s.u.n.cH[s.sat.chs[c]];
+          float Jc[6][6];   // the contact's rows, satellite columns (zero beyond the contact's condim)
+          for (int p = 0; p < 6; p++) {
+            const float* js = jsp(r0 + (p < n ? p : 0), u);
+            for (int k = 0; k < 6; k++) Jc[p][k] = p < n ? js[k] : 0.f;
+          }
+#pragma unroll
+          for (int p = 0; p < 6; p++) {   // H += Jc' (Hc Jc), one row of T = Hc Jc at a time (rows beyond the condim: Jc[p] = 0)
+            float T[6];
             for (int k = 0; k < 6; k++) {
               float v = 0;
-              for (int q = 0; q < 6; q++) v += (q < n && p < n) ? Hc[6 * p + q] * s.sat.Js[r0 + q][u][k] : 0.f;
-              T[p][k] = v;
+              for (int q = 0; q < 6; q++) v += Hc[6 * p + q] * Jc[q][k];   // (cH is stored 6 x 6, zero beyond the condim)
+              T[k] = v;
             }
-          for (int i = 0; i < 6; i++)
-            for (int j = 0; j <= i; j++) {
-              float v = 0;
-              for (int p = 0; p < 6; p++) v += p < n ? s.sat.Js[r0 + p][u][i] * T[p][j] : 0.f;
-              H[tri6(i, j)] += v;
-            }
+            for (int i = 0; i < 6; i++)
+              for (int j = 0; j <= i; j++) H[tri6(i, j)] += Jc[p][i] * T[j];
+          }
         } else {
           for (int p = 0; p < n; p++) {
             const float w = s.ediag[r0 + p];
-            if (w != 0.f)
+            if (w != 0.f) {
+              const float* js = jsp(r0 + p, u);
               for (int i = 0; i < 6; i++) {
-                const float wi = w * s.sat.Js[r0 + p][u][i];
-                for (int j = 0; j <= i; j++) H[tri6(i, j)] += wi * s.sat.Js[r0 + p][u][j];
+                const float wi = w * js[i];
+                for (int j = 0; j <= i; j++) H[tri6(i, j)] += wi * js[j];
               }
+            }
           }
         }
       }
@@ -355,9 +364,10 @@ SMJ_DEV void sat_extend_hessian(int next, uint64_t conemask) {
             float wj;   // (W J)[p][lane]
             if (cone) {
               wj = 0.f;
-              for (int q = 0; q < nr; q++) wj += s.u.n.cH[c][6 * p + q] * s.J[r0 + q][lane];
+              for (int q = 0; q < nr; q++) wj += s.u.n.cH[s.sat.chs[c]][6 * p + q] * s.J[r0 + q][lane];
             } else wj = s.ediag[r0 + p] * s.J[r0 + p][lane];
-            for (int k = 0; k < 6; k++) acc[k] += wj * s.sat.Js[r0 + p][u][k];
+            const float* js = jsp(r0 + p, u);
+            for (int k = 0; k < 6; k++) acc[k] += wj * js[k];
           }
           for (int k = 0; k < 6; k++) { s.u.n.H[o + k][lane] += acc[k]; s.u.n.H[lane][o + k] += acc[k]; }
         }
@@ -385,9 +395,9 @@ SMJ_DEV void sat_extend_hessian(int next, uint64_t conemask) {
           float wj;
           if (cone) {
             wj = 0.f;
-            for (int q = 0; q < nr; q++) wj += s.u.n.cH[c][6 * p + q] * s.sat.Js[r0 + q][1][l];
-          } else wj = s.ediag[r0 + p] * s.sat.Js[r0 + p][1][l];
-          v += s.sat.Js[r0 + p][0][k] * wj;
+            for (int q = 0; q < nr; q++) wj += s.u.n.cH[s.sat.chs[c]][6 * p + q] * jsp(r0 + q, 1)[l];
+          } else wj = s.ediag[r0 + p] * jsp(r0 + p, 1)[l];
+          v += s.sat.Js[r0 + p][k] * wj;
         }
         s.u.n.H[oa + k][ob + l] += v;
         s.u.n.H[ob + l][oa + k] += v;
@@ -453,7 +463,14 @@ SMJ_DEV void sat_reset_state() {
 // ones with a dense Jacobian row -- then the satellites' friction-loss rows, their active limits and the contacts among
 // satellites and static geoms.  (Newton's result does not depend on the order of the rows; the oracle keeps MuJoCo's.)
 int nd = 0, nd_prev = NDR, next_sat = 0;
-SMJ_DEV void make_constraint_sat() {
+// enter rows r0 .. r0 + n - 1 (slot `slot` of their satellite columns) in satellite si's item list; called from divergent lanes
+SMJ_DEV void sat_item(int si, int r0, int n, int slot, int inf, int c = 0) {
+  const int at = lds_atomic_inc(&s.sat.nitem[si]);
+  if (at < NIT) { s.sat.irow[si][at] = (unsigned char)r0; s.sat.iinf[si][at] = (unsigned char)(n | (slot ? ITEM_SLOT : 0) | inf); s.sat.icon[si][at] = (unsigned char)c; }
+}
+SMJ_DEV void make_constraint_sat(float* pc, bool prof) {
+  long long tq = prof ? smj_clock() : 0;
+#define QTICK(slot) if (prof) { const long long t1 = smj_clock(); pc[slot] += (float)(t1 - tq); tq = t1; }
   const int nv = M.nv, neq = M.neq, nfm = M.nfric_main, nlm = M.nlimit_main, nbm = M.nbody, nsat = M.nsat;
   const int nfs = M.nfric - nfm, nls = M.nlimit - nlm;
   // clear: the dense rows the previous step used, row metadata and satellite columns of its rows
@@ -464,8 +481,8 @@ SMJ_DEV void make_constraint_sat() {
     const int row = lane + rb;
     if (row < NEFC) {
       s.etype[row] = CT_NONE; s.efloss[row] = 0; s.eid[row] = 0; s.epos[row] = 0; s.emargin[row] = 0; s.ediag[row] = 0;
-      s.sat.esat[row][0] = -1; s.sat.esat[row][1] = -1; s.sat.erec[row] = 0;
-      for (int k = 0; k < 12; k++) (&s.sat.Js[row][0][0])[k] = 0.f;
+      s.sat.esat[row][0] = -1; s.sat.esat[row][1] = -1; s.sat.erec[row] = 0; s.sat.e2[row] = 0;
+      for (int k = 0; k < 6; k++) s.sat.Js[row][k] = 0.f;
     }
   }
   SYNC();
@@ -531,6 +548,7 @@ SMJ_DEV void make_constraint_sat() {
   row0 += popc64(lm);
   if (row0 > cap || row0 > NDR) { row0 = cap < NDR ? cap : NDR; flags |= SMJ_FLAG_EFC_OVERFLOW; }
   SYNC();
+  QTICK(SMJ_PROF_MC_ROWS)
   // ---- contacts, phase 1 (lane = contact): bodies, classes, dof masks, diagonal approximations
   PL<int> cact, cdimv, crow, cmain, csa, csb;   // csa / csb: satellite of geom1's / geom2's body, or -1
   PL<float> ctran, crot;
@@ -555,30 +573,51 @@ SMJ_DEV void make_constraint_sat() {
     if (lane < NVP)
       for (int x = 0; x < 6; x++) s.u.k.cd[lane][x] = lane < nv ? cdof[lane][x] : 0.f;
   }
-  // rows of the contacts that touch the main tree (dense rows)
-  for (int c = 0; c < ncon; c++) {
-    int d = wave_read(cdimv, c);
-    if (!wave_read(cact, c) || !wave_read(cmain, c)) continue;
-    const int lim = cap < NDR ? cap : NDR;
-    if (row0 + d > lim) {
-      flags |= SMJ_FLAG_EFC_OVERFLOW;
-      if (d > 3 && row0 + 3 <= lim) d = 3;
-      else if (row0 + 1 <= lim) d = 1;
-      else continue;
-      LANES { if (lane == c) { cdimv[lane] = d; s.cdim[c] = d; } }
+  // rows of the contacts that touch the main tree (dense rows): offsets by ballot prefix of the contacts' row counts; the serial
+  // loop only when the rows run out (it degrades contacts one by one, as make_constraint does)
+  {
+    PL<int> bit;
+    LANES { bit[lane] = (cact[lane] && cmain[lane]) ? cdimv[lane] & 1 : 0; }
+    const uint64_t m0 = wave_ballot(bit);
+    LANES { bit[lane] = (cact[lane] && cmain[lane]) ? cdimv[lane] & 2 : 0; }
+    const uint64_t m1 = wave_ballot(bit);
+    LANES { bit[lane] = (cact[lane] && cmain[lane]) ? cdimv[lane] & 4 : 0; }
+    const uint64_t m2 = wave_ballot(bit);
+    const int total = popc64(m0) + 2 * popc64(m1) + 4 * popc64(m2), lim = cap < NDR ? cap : NDR;
+    if (row0 + total <= lim) {
+      LANES {
+        const uint64_t lt = (1ull << lane) - 1;
+        if (cact[lane] && cmain[lane]) crow[lane] = row0 + popc64(m0 & lt) + 2 * popc64(m1 & lt) + 4 * popc64(m2 & lt);
+      }
+      row0 += total;
+    } else {
+      for (int c = 0; c < ncon; c++) {
+        int d = wave_read(cdimv, c);
+        if (!wave_read(cact, c) || !wave_read(cmain, c)) continue;
+        if (row0 + d > lim) {
+          flags |= SMJ_FLAG_EFC_OVERFLOW;
+          if (d > 3 && row0 + 3 <= lim) d = 3;
+          else if (row0 + 1 <= lim) d = 1;
+          else continue;
+          LANES { if (lane == c) { cdimv[lane] = d; s.cdim[c] = d; } }
+        }
+        LANES { if (lane == c) crow[lane] = row0; }
+        row0 += d;
+      }
     }
-    LANES { if (lane == c) crow[lane] = row0; }
-    row0 += d;
   }
   nd = row0;
-  // ---- the satellites' friction-loss rows and active limits
+  // ---- the satellites' friction-loss rows and active limits (every row is entered in its satellite's item list as it is made)
+  LANES { if (lane >= 32 && lane - 32 < nsat) { s.sat.nitem[lane - 32] = 0; s.sat.ext[lane - 32] = -1; } }
+  SYNC();
   LANES {
     if (lane < nfs) {
       const int rec = neq + nfm + lane, e = row0 + lane;
       const int* r = static_cast<const int*>(__builtin_assume_aligned(M.k_rowrec + opaque(rec) * SMJ_RR_STRIDE, 16));
       if (e < cap) {
         const int si = r[SMJ_RR_SAT], k = r[SMJ_RR_SDOF];
-        s.sat.esat[e][0] = (signed char)si; s.sat.Js[e][0][k] = 1.f;
+        s.sat.esat[e][0] = (signed char)si; s.sat.Js[e][k] = 1.f;
+        sat_item(si, e, 1, 0, 0);
         s.etype[e] = CT_FRICTION; s.eid[e] = r[SMJ_RR_ID]; s.efloss[e] = asf(r[SMJ_RR_FLOSS]); s.ediag[e] = asf(r[SMJ_RR_DIAG]);
         s.sat.erec[e] = (short)rec;
       }
@@ -606,7 +645,8 @@ SMJ_DEV void make_constraint_sat() {
       const int r = row0 + popc64(lm & ((1ull << lane) - 1));
       if (r < cap) {
         const int side = lrow[1][lane];
-        s.sat.esat[r][0] = (signed char)lrow[0][lane]; s.sat.Js[r][0][0] = (float)(-side);
+        s.sat.esat[r][0] = (signed char)lrow[0][lane]; s.sat.Js[r][0] = (float)(-side);
+        sat_item(lrow[0][lane], r, 1, 0, 0);
         s.etype[r] = CT_LIMIT; s.eid[r] = 2 * nlm + lane; s.sat.erec[r] = (short)(nstat_all + 2 * nlm + lane);
         s.epos[r] = side * (asf(lrow[2][lane]) - lq[lane]);
         s.emargin[r] = asf(lrow[3][lane]); s.ediag[r] = asf(lrow[4][lane]);
@@ -615,20 +655,42 @@ SMJ_DEV void make_constraint_sat() {
   }
   row0 += popc64(lm);
   if (row0 > cap) { row0 = cap; flags |= SMJ_FLAG_EFC_OVERFLOW; }
-  // ---- rows of the contacts that touch no main body
-  for (int c = 0; c < ncon; c++) {
-    int d = wave_read(cdimv, c);
-    if (!wave_read(cact, c) || wave_read(cmain, c)) continue;
-    if (row0 + d > cap) {
-      flags |= SMJ_FLAG_EFC_OVERFLOW;
-      if (d > 3 && row0 + 3 <= cap) d = 3;
-      else if (row0 + 1 <= cap) d = 1;
-      else continue;
-      LANES { if (lane == c) { cdimv[lane] = d; s.cdim[c] = d; } }
+  // ---- rows of the contacts that touch no main body (same scheme)
+  {
+    PL<int> bit;
+    LANES { bit[lane] = (cact[lane] && !cmain[lane]) ? cdimv[lane] & 1 : 0; }
+    const uint64_t m0 = wave_ballot(bit);
+    LANES { bit[lane] = (cact[lane] && !cmain[lane]) ? cdimv[lane] & 2 : 0; }
+    const uint64_t m1 = wave_ballot(bit);
+    LANES { bit[lane] = (cact[lane] && !cmain[lane]) ? cdimv[lane] & 4 : 0; }
+    const uint64_t m2 = wave_ballot(bit);
+    const int total = popc64(m0) + 2 * popc64(m1) + 4 * popc64(m2);
+    if (row0 + total <= cap) {
+      LANES {
+        const uint64_t lt = (1ull << lane) - 1;
+        if (cact[lane] && !cmain[lane]) crow[lane] = row0 + popc64(m0 & lt) + 2 * popc64(m1 & lt) + 4 * popc64(m2 & lt);
+      }
+      row0 += total;
+    } else {
+      for (int c = 0; c < ncon; c++) {
+        int d = wave_read(cdimv, c);
+        if (!wave_read(cact, c) || wave_read(cmain, c)) continue;
+        if (row0 + d > cap) {
+          flags |= SMJ_FLAG_EFC_OVERFLOW;
+          if (d > 3 && row0 + 3 <= cap) d = 3;
+          else if (row0 + 1 <= cap) d = 1;
+          else continue;
+          LANES { if (lane == c) { cdimv[lane] = d; s.cdim[c] = d; } }
+        }
+        LANES { if (lane == c) crow[lane] = row0; }
+        row0 += d;
+      }
     }
-    LANES { if (lane == c) crow[lane] = row0; }
-    row0 += d;
   }
+  QTICK(SMJ_PROF_MC_CON)
+  PL<int> over2;
+  LANES { over2[lane] = 0; if (lane == 0) s.sat.ns2 = 0; }
+  SYNC();
   LANES {
     if (lane < ncon) {
       const int c = lane, r0 = crow[lane], dim = cdimv[lane];
@@ -644,6 +706,11 @@ SMJ_DEV void make_constraint_sat() {
         // satellite columns: slot 0 = the first satellite of the pair, slot 1 = the second (both bodies satellites)
         const int sa = csa[lane], sb = csb[lane];
         int slot = 0;
+        if (sa >= 0 && sb >= 0) {   // a contact between two satellites: rows of the second-slot pool
+          int base = lds_atomic_add(&s.sat.ns2, dim);
+          if (base + dim > NS2) { base = 0; over2[lane] = 1; }   // (pool exhausted: flagged below)
+          for (int r = 0; r < dim; r++) s.sat.e2[r0 + r] = (short)(base + r);
+        }
 #pragma unroll
         for (int w = 0; w < 2; w++) {
           const int si = w ? sb : sa;
@@ -665,17 +732,22 @@ SMJ_DEV void make_constraint_sat() {
             for (int r = 0; r < 6; r++)
               if (r < dim) {
                 const float* ax = s.cframe[c] + 3 * (r < 3 ? r : r - 3);
-                s.sat.Js[r0 + r][slot][k] = sg * (r < 3 ? dot3(ax, jp) : dot3(ax, jr));
+                jspw(r0 + r, slot)[k] = sg * (r < 3 ? dot3(ax, jp) : dot3(ax, jr));
               }
           }
 #pragma unroll
           for (int r = 0; r < 6; r++)
             if (r < dim) s.sat.esat[r0 + r][slot] = (signed char)si;
+          // the satellite's item; a contact with anything but the static world couples it (dense extension of this step)
+          const int ob = w ? s.u.k.b1[c] : s.u.k.b2[c];
+          sat_item(si, r0, dim, slot, ITEM_CONTACT | ((ob > 0 && ob < nbm) ? ITEM_MAIN : 0), c);
+          if (ob > 0) s.sat.ext[si] = 0;   // (marker; slots are handed out below)
           slot++;
         }
       }
     }
   }
+  if (wave_ballot(over2)) flags |= SMJ_FLAG_EFC_OVERFLOW;
   SYNC();
   // contacts phase 2: the main columns of the dense rows (as make_constraint: lanes = dofs, two contacts per pass)
   constexpr int CPP = 64 / NVP;
@@ -714,33 +786,15 @@ SMJ_DEV void make_constraint_sat() {
   if ((flags & SMJ_FLAG_EFC_OVERFLOW) && getenv("SMJ_SAT_TRACE")) fprintf(stderr, "row overflow: nd %d nefc %d ncon %d\n", nd, nefc, ncon);
 #endif
   SYNC();
-  // ---- the satellites' row items (lane = satellite scans the rows), extension slots, satellite-satellite contacts
+  QTICK(SMJ_PROF_MC_JAC)
+  // ---- extension slots of the coupled satellites, satellite-satellite contacts
   PL<int> wantx;
   LANES {
     const int si = lane - 32;
     int want = 0;
     if (lane >= 32 && si < nsat) {
-      int ni = 0, over = 0;
-      for (int r = 0; r < row0;) {
-        int u = -1;
-        if (s.sat.esat[r][0] == si) u = 0; else if (s.sat.esat[r][1] == si) u = 1;
-        if (u < 0) { r++; continue; }
-        const int t = s.etype[r];
-        int n = 1, inf = 0, c = 0;
-        if (t == CT_CONTACT_ELLIPTIC || t == CT_CONTACT_FRICTIONLESS) {
-          c = s.eid[r];
-          n = s.cdim[c];
-          inf = ITEM_CONTACT;
-          const int b1 = s.u.k.b1[c], b2 = s.u.k.b2[c];
-          if ((b1 > 0 && b1 < nbm) || (b2 > 0 && b2 < nbm)) { inf |= ITEM_MAIN; want = 1; }
-          if (b1 >= nbm && b2 >= nbm) want = 1;
-        }
-        if (ni < NIT) { s.sat.irow[si][ni] = (unsigned char)r; s.sat.iinf[si][ni] = (unsigned char)(n | (u ? ITEM_SLOT : 0) | inf); s.sat.icon[si][ni] = (unsigned char)c; ni++; }
-        else over = 1;
-        r += n;
-      }
-      s.sat.nitem[si] = ni;
-      if (over) want |= 2;
+      want = s.sat.ext[si] == 0;
+      if (s.sat.nitem[si] > NIT) { s.sat.nitem[si] = NIT; want |= 2; }
     }
     wantx[lane] = want;
   }
@@ -789,6 +843,7 @@ SMJ_DEV void make_constraint_sat() {
     }
   }
   SYNC();
+  QTICK(SMJ_PROF_MC_ITEMS)
   // ---- impedance, R, K, B  [MJ] mj_makeImpedance (row records through erec: rows do not sit at their record's index here)
   ROWPASS(rb, nefc) LANES {
     const int i = lane + rb;
@@ -830,37 +885,65 @@ SMJ_DEV void make_constraint_sat() {
     }
   }
   SYNC();
+  QTICK(SMJ_PROF_MC_IMP)
+#undef QTICK
 }
 
-// x <- H^-1 x for the order-n system in s.u.n.H (main block + dense extension), Gauss-Jordan in LDS with lane = row (gj_solve_lds
-// with a run-time order); x: lanes 0 .. n-1.  H is destroyed.
-SMJ_DEV void gj_solve_ext(PL<float>& x, int n) {
-  LANES { if (lane < n) s.u.n.H[lane][NXV] = x[lane]; }
+// x <- H^-1 x for the extended system in s.u.n.H: main block A (NVS x NVS), extension block C (nx = 6 next rows / columns from
+// NVS on), coupling B.  The extension is eliminated first -- Gauss-Jordan on the rows [C | Bt | rhs], lane = COLUMN, so that the
+// nx pivots cost nx - 1 fused multiply-adds per lane each -- which leaves Y = C^-1 Bt and z = C^-1 x_ext; the main block takes the
+// Schur complement A - B Y, is solved in registers like any other step (solve_H), and x_ext = z - Y x_main.  (The first version
+// ran the LDS Gauss-Jordan of the 64-column builds over the whole order-50 system: 60-70 k cycles per solve, this: under 20 k.)
+SMJ_DEV void solve_ext_schur(PL<float>& x, int next) {
+  const int nx = 6 * next, o = NVS;
+  LANES { if (lane >= o && lane < o + nx) s.u.n.H[lane][NXV] = x[lane]; }
   SYNC();
-  for (int k = 0; k < n; k++) {
-    const float rp = fast_rcp(fmaxf(uni(s.u.n.H[k][k]), 1e-30f));
+  for (int k = 0; k < nx; k++) {
+    const float rp = fast_rcp(fmaxf(uni(s.u.n.H[o + k][o + k]), 1e-30f));
     LANES {
-      if (lane < n && lane != k) {
-        float* row = s.u.n.H[lane];
-        const float* piv = s.u.n.H[k];
-        const float mult = row[k] * rp;
-        if (mult != 0.f) {
-          int j = k + 1;
-          for (; j + 8 <= n; j += 8) {
-            float a[8], b[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { a[u] = row[j + u]; b[u] = piv[j + u]; }
-#pragma unroll
-            for (int u = 0; u < 8; u++) row[j + u] = a[u] - mult * b[u];
-          }
-          for (; j < n; j++) row[j] -= mult * piv[j];
-          row[NXV] -= mult * piv[NXV];
-        }
+      // lane -> column: the main columns, the extension columns beyond the pivot's, the right-hand side
+      const int col = lane < NVS ? lane : (lane - NVS < nx ? o + (lane - NVS) : (lane == 63 ? NXV : -1));
+      if (col >= 0 && (col < o || col > o + k)) {
+        const float pv = s.u.n.H[o + k][col];
+        if (pv != 0.f)
+          for (int i = 0; i < nx; i++)
+            if (i != k) s.u.n.H[o + i][col] -= s.u.n.H[o + i][o + k] * rp * pv;
       }
     }
     SYNC();
   }
-  LANES { x[lane] = lane < n ? s.u.n.H[lane][NXV] * fast_rcp(fmaxf(s.u.n.H[lane][lane], 1e-30f)) : 0.f; }
+  // Schur complement and right-hand side of the main block: lane = main row d
+  LANES {
+    if (lane < NVS) {
+      float bd[6 * NXS], acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 6 * NXS; i++) bd[i] = i < nx ? s.u.n.H[lane][o + i] * fast_rcp(fmaxf(s.u.n.H[o + i][o + i], 1e-30f)) : 0.f;   // B[d][i] / C_ii
+#pragma unroll
+      for (int i = 0; i < 6 * NXS; i++) acc += i < nx ? bd[i] * s.u.n.H[o + i][NXV] : 0.f;
+      x[lane] -= acc;
+      for (int e = 0; e < NVS; e++) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6 * NXS; i++) v += i < nx ? bd[i] * s.u.n.H[o + i][e] : 0.f;
+        s.u.n.H[lane][e] -= v;
+      }
+    }
+  }
+  SYNC();
+  PL<float> xm;
+  LANES { xm[lane] = lane < M.nv ? x[lane] : 0.f; }
+  solve_H(xm);
+  LANES { if (lane < NVS) s.tmp[lane] = lane < M.nv ? xm[lane] : 0.f; }
+  SYNC();
+  LANES {
+    if (lane < NVS) x[lane] = s.tmp[lane];
+    else if (lane - NVS < nx) {
+      const int i = lane - NVS;
+      float v = s.u.n.H[o + i][NXV];
+      for (int d = 0; d < NVS; d++) v -= s.u.n.H[o + i][d] * s.tmp[d];
+      x[lane] = v * fast_rcp(fmaxf(s.u.n.H[o + i][o + i], 1e-30f));
+    }
+  }
   SYNC();
 }
 
@@ -874,19 +957,12 @@ SMJ_DEV void gj_solve_ext(PL<float>& x, int n) {
 // in cache slot NCG.  Same contacts as the oracle's scan of the whole table (oracle/smj_oracle.c collision()).
 SMJ_DEV void stage_static(int sg) {
   LANES {
-    if (lane == 0) {
-      const int* r = M.k_sgrec + sg * SMJ_CG_STRIDE;
-      float pos[3], mat[9], lc[3], lcc[3], wc[3], wcc[3];
-      for (int k = 0; k < 3; k++) { pos[k] = asf(r[SMJ_CG_POS + k]); lc[k] = asf(r[SMJ_CG_LCEN + k]); lcc[k] = asf(r[SMJ_CG_CCEN + k]); }
-      for (int k = 0; k < 9; k++) mat[k] = asf(r[SMJ_CG_MAT + k]);
-      mulmat3vec(wc, mat, lc);
-      mulmat3vec(wcc, mat, lcc);
-      for (int k = 0; k < 3; k++) {
-        s.u.c.pos[NCG][k] = pos[k]; s.u.c.cen[NCG][k] = pos[k] + wc[k]; s.u.c.half[NCG][k] = asf(r[SMJ_CG_HALF + k]);
-        s.u.c.ccen[NCG][k] = pos[k] + wcc[k]; s.u.c.size[NCG][k] = asf(r[SMJ_CG_SIZE + k]);
-      }
-      for (int k = 0; k < 9; k++) s.u.c.mat[NCG][k] = mat[k];
-      s.u.c.meta[NCG] = r[SMJ_CG_META];
+    if (lane < 25) {   // one word per lane: the loader's world-frame record (DevModel::k_sgw) into the cache arrays' staging slot
+      const float v = M.k_sgw[sg * 32 + lane];
+      float* dst = lane < 3 ? &s.u.c.pos[NCG][lane] : lane < 12 ? &s.u.c.mat[NCG][lane - 3] : lane < 15 ? &s.u.c.cen[NCG][lane - 12]
+                 : lane < 18 ? &s.u.c.half[NCG][lane - 15] : lane < 21 ? &s.u.c.ccen[NCG][lane - 18] : lane < 24 ? &s.u.c.size[NCG][lane - 21]
+                 : reinterpret_cast<float*>(&s.u.c.meta[NCG]);
+      *dst = v;
     }
   }
   SYNC();
@@ -896,69 +972,117 @@ SMJ_DEV void collision_static(float* pc, bool prof) {
   if (nsg == 0 || M.nstatpair == 0) return;
   LANES { if (lane == 0) s.u.c.sl_n = 0; }
   SYNC();
-  const float ih = 1.0f / M.grid_h, gm = M.grid_margin;
-  const int dx = M.grid_dim[0], dy = M.grid_dim[1], dz = M.grid_dim[2];
-  for (int c0 = 0; c0 < M.ncgeom; c0 += 64) {
+  const long long tb0 = prof ? smj_clock() : 0;
+  // Broadphase in two phases (below).  The first version walked the grid cells of every moving geom with lane = moving geom
+  // (dependent, uncoalesced loads per cell: 600 k cycles per step), the second ran sphere test, filter look-up and box test in one
+  // loop with lane = static geom (the lanes that passed the sphere test paid a global load inside the loop, the others waited:
+  // 260 k).  The uniform grid (k_grid_*) stays in the blob for scenes with thousands of static geoms.
+  const float gm = M.grid_margin;
+  const int ncg = M.ncgeom;
+  // bounding radii of the moving geoms, staged once (the `size` column of the staging slot NCG is free until a pair is staged)
+  for (int c0 = 0; c0 < ncg; c0 += 64) {
+    LANES { if (c0 + lane < ncg) s.u.c.mc_r[c0 + lane] = asf(M.k_cgrec[opaque(c0 + lane) * SMJ_CG_STRIDE + SMJ_CG_RBOUND]); }
+  }
+  SYNC();
+  if (prof) pc[SMJ_PROF_FACTOR] += (float)(smj_clock() - tb0);   // (profiling builds: PGS slots are free under Newton -- "factor": radii staged, "project": + phase 1)
+  // phase 1 (only when a moving geom has travelled SMJ_SB_SLACK since the list was built, or at the start of a launch), lane =
+  // static geom: its world AABB against every moving geom's bounding sphere inflated by the slack.  22 k tests: 116 k cycles when
+  // it ran every step -- a launch-long LDS list of the ~200 near pairs makes it a once-in-ten-steps cost.
+  {
+    PL<int> mv;
     LANES {
-      const int c = c0 + lane;
-      if (c < M.ncgeom) {
-        const float rb = asf(M.k_cgrec[opaque(c) * SMJ_CG_STRIDE + SMJ_CG_RBOUND]);
-        const float cen[3] = {s.u.c.cen[c][0], s.u.c.cen[c][1], s.u.c.cen[c][2]}, R = rb + gm;
-        int lo[3], hi[3];
-        bool in = true;
-        for (int k = 0; k < 3; k++) {
-          const int dk = k == 0 ? dx : k == 1 ? dy : dz;
-          const float a = floorf((cen[k] - R - M.grid_org[k]) * ih), b = floorf((cen[k] + R - M.grid_org[k]) * ih);
-          in = in && b >= 0.f && a < (float)dk;
-          lo[k] = a < 0.f ? 0 : (int)a; hi[k] = b >= (float)dk ? dk - 1 : (int)b;
-        }
-        if (in) {
-          float Ra[9], ha[3];
-          for (int k = 0; k < 9; k++) Ra[k] = s.u.c.mat[c][k];
-          for (int k = 0; k < 3; k++) ha[k] = s.u.c.half[c][k];
-          for (int z = lo[2]; z <= hi[2]; z++)
-            for (int y = lo[1]; y <= hi[1]; y++)
-              for (int x = lo[0]; x <= hi[0]; x++) {
-                const int cell = (z * dy + y) * dx + x;
-                const int k1 = M.k_grid_adr[cell + 1];
-                for (int k = M.k_grid_adr[cell]; k < k1; k++) {
-                  const int sg = M.k_grid_list[k];
-                  const int* cr = M.k_sg_cell + 6 * sg;
-                  // (reported from the first cell common to the two cell ranges)
-                  if (x != (lo[0] > cr[0] ? lo[0] : cr[0]) || y != (lo[1] > cr[1] ? lo[1] : cr[1]) || z != (lo[2] > cr[2] ? lo[2] : cr[2])) continue;
-                  const float* bd = M.k_sg_bound + 4 * sg;
-                  const float dv[3] = {bd[0] - cen[0], bd[1] - cen[1], bd[2] - cen[2]}, rr = rb + bd[3] + gm;
-                  if (dot3(dv, dv) > rr * rr) continue;
-                  const int sid = M.k_spair[c * nsg + sg];
-                  if (sid < 0) continue;
-                  // the six face axes of the two oriented boxes
-                  const int* sr = M.k_sgrec + sg * SMJ_CG_STRIDE;
-                  float Rb[9], hb[3], Rm[3][3], ta[3], tb[3];
-                  for (int q = 0; q < 9; q++) Rb[q] = asf(sr[SMJ_CG_MAT + q]);
-                  for (int q = 0; q < 3; q++) hb[q] = asf(sr[SMJ_CG_HALF + q]);
-                  bool hit = true;
-                  for (int i = 0; i < 3; i++) {
-                    ta[i] = Ra[i] * dv[0] + Ra[3 + i] * dv[1] + Ra[6 + i] * dv[2];
-                    tb[i] = Rb[i] * dv[0] + Rb[3 + i] * dv[1] + Rb[6 + i] * dv[2];
-                    for (int j = 0; j < 3; j++) Rm[i][j] = fabsf(Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j]);
-                  }
-                  for (int q = 0; q < 3; q++) {
-                    if (fabsf(ta[q]) > ha[q] + (Rm[q][0] * hb[0] + Rm[q][1] * hb[1] + Rm[q][2] * hb[2]) + gm) hit = false;
-                    if (fabsf(tb[q]) > hb[q] + (Rm[0][q] * ha[0] + Rm[1][q] * ha[1] + Rm[2][q] * ha[2]) + gm) hit = false;
-                  }
-                  if (!hit) continue;
-                  const int at = lds_atomic_inc(&s.u.c.sl_n);
-                  if (at < NSURV) { s.u.c.sl_sid[at] = sid; s.u.c.sl_c[at] = (unsigned char)c; }
-                }
+      int m = 0;
+      for (int c = lane; c < ncg; c += 64) {
+        const float d[3] = {s.u.c.cen[c][0] - s.sat.refcen[c][0], s.u.c.cen[c][1] - s.sat.refcen[c][1], s.u.c.cen[c][2] - s.sat.refcen[c][2]};
+        m |= !(dot3(d, d) < SMJ_SB_SLACK * SMJ_SB_SLACK);
+      }
+      mv[lane] = m;
+    }
+    if (!uni(s.sat.cand_ok) || wave_ballot(mv) != 0) {
+      LANES {
+        if (lane == 0) { s.sat.ncand = 0; s.sat.cand_ok = 1; }
+        for (int c = lane; c < ncg; c += 64)
+          for (int k = 0; k < 3; k++) s.sat.refcen[c][k] = s.u.c.cen[c][k];
+      }
+      SYNC();
+      for (int g0 = 0; g0 < nsg; g0 += 64) {
+        LANES {
+          const int sg = g0 + lane;
+          if (sg < nsg) {
+            const Vec4 blo = *reinterpret_cast<const Vec4*>(M.k_sg_bound + 8 * opaque(sg)), bhi = *reinterpret_cast<const Vec4*>(M.k_sg_bound + 8 * opaque(sg) + 4);
+            // eight moving geoms per round: centres / radii fetched first, the tests leave a bit mask, a round with a hit enters the append loop
+            for (int c0 = 0; c0 < ncg; c0 += 8) {
+              float cx[8], cy[8], cz[8], cr[8];
+#pragma unroll
+              for (int u = 0; u < 8; u++) {
+                const int c = c0 + u < ncg ? c0 + u : ncg - 1;
+                cx[u] = s.u.c.cen[c][0]; cy[u] = s.u.c.cen[c][1]; cz[u] = s.u.c.cen[c][2]; cr[u] = s.u.c.mc_r[c];
               }
+              unsigned mask = 0;
+#pragma unroll
+              for (int u = 0; u < 8; u++) {
+                const float dx = fmaxf(0.f, fmaxf(blo.x - cx[u], cx[u] - bhi.x)), dy = fmaxf(0.f, fmaxf(blo.y - cy[u], cy[u] - bhi.y)),
+                            dz = fmaxf(0.f, fmaxf(blo.z - cz[u], cz[u] - bhi.z)), rr = cr[u] + gm + 2.f * SMJ_SB_SLACK;
+                mask |= (c0 + u < ncg && dx * dx + dy * dy + dz * dz <= rr * rr) ? 1u << u : 0u;
+              }
+              while (mask) {
+                const int u = __builtin_ctz(mask);
+                mask &= mask - 1;
+                const int at = lds_atomic_inc(&s.sat.ncand);
+                if (at < NCAND) s.sat.cand[at] = (unsigned short)(sg | ((c0 + u) << 9));   // (512 static geoms x 128 cache slots)
+              }
+            }
+          }
+        }
+      }
+      SYNC();
+      if (uni(s.sat.ncand) > NCAND) {   // more near pairs than the list holds: flagged, and the list is rebuilt next step
+        LANES { if (lane == 0) { s.sat.ncand = NCAND; s.sat.cand_ok = 0; } }
+        flags |= SMJ_FLAG_CON_OVERFLOW;
+        SYNC();
+      }
+    }
+  }
+  if (prof) pc[SMJ_PROF_PROJECT] += (float)(smj_clock() - tb0);
+  const int ncand = uni(s.sat.ncand);
+  // phase 2, lane = candidate: MuJoCo's pair filter (k_spair), then the six face axes of the two oriented boxes
+  for (int k0 = 0; k0 < ncand; k0 += 64) {
+    LANES {
+      if (k0 + lane < ncand) {
+        const int w = s.sat.cand[k0 + lane], sg = w & 511, c = w >> 9;
+        const int sid = M.k_spair[c * nsg + sg];
+        if (sid >= 0) {
+          const float* sw = M.k_sgw + 32 * sg;
+          float Rb[9], hb[3], Ra[9], ha[3], Rm[3][3], ta[3], tb[3];
+          for (int q = 0; q < 9; q++) { Rb[q] = sw[3 + q]; Ra[q] = s.u.c.mat[c][q]; }
+          for (int q = 0; q < 3; q++) { hb[q] = sw[15 + q]; ha[q] = s.u.c.half[c][q]; }
+          const float dv[3] = {sw[12] - s.u.c.cen[c][0], sw[13] - s.u.c.cen[c][1], sw[14] - s.u.c.cen[c][2]};
+          bool hit = true;
+          for (int i = 0; i < 3; i++) {
+            ta[i] = Ra[i] * dv[0] + Ra[3 + i] * dv[1] + Ra[6 + i] * dv[2];
+            tb[i] = Rb[i] * dv[0] + Rb[3 + i] * dv[1] + Rb[6 + i] * dv[2];
+            for (int j = 0; j < 3; j++) Rm[i][j] = fabsf(Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j]);
+          }
+          for (int q = 0; q < 3; q++) {
+            if (fabsf(ta[q]) > ha[q] + (Rm[q][0] * hb[0] + Rm[q][1] * hb[1] + Rm[q][2] * hb[2]) + gm) hit = false;
+            if (fabsf(tb[q]) > hb[q] + (Rm[0][q] * ha[0] + Rm[1][q] * ha[1] + Rm[2][q] * ha[2]) + gm) hit = false;
+          }
+          if (hit) {
+            const int at = lds_atomic_inc(&s.u.c.sl_n);
+            if (at < NSURV) { s.u.c.sl_sid[at] = sid; s.u.c.sl_c[at] = (unsigned char)c; }
+          }
         }
       }
     }
   }
   SYNC();
+  if (prof) pc[SMJ_PROF_S_BROAD] += (float)(smj_clock() - tb0);
   int n = uni(s.u.c.sl_n);
   if (n > NSURV) { n = NSURV; flags |= SMJ_FLAG_CON_OVERFLOW; }
   if (prof) pc[SMJ_PROF_C_NSPHERE] += (float)n;
+#ifdef SMJ_EMUL
+  if (getenv("SMJ_SAT_TRACE")) { fprintf(stderr, "static candidates %d survivors %d:", ncand, n); for (int i = 0; i < n; i++) fprintf(stderr, " %d", M.k_sprec[s.u.c.sl_sid[i] * SMJ_CP_STRIDE + SMJ_CP_PAIR]); fprintf(stderr, "\n"); }
+#endif
   if (n == 0) return;
   // pair-table order: rank of every survivor among the pair indices (all different)
   LANES {
@@ -971,6 +1095,7 @@ SMJ_DEV void collision_static(float* pc, bool prof) {
   }
   SYNC();
   float* const sepbase = (S.sepcache && M.sep_cache) ? S.sepcache + (size_t)env * (SMJ_SEP_SLOTS * 4) : nullptr;
+  const long long tn0 = prof ? smj_clock() : 0;
   for (int k0 = 0; k0 < n; k0 += 64) {
     // the survivors' separating directions, fetched lane-parallel ahead of the serial loop (slots shared with the moving-moving
     // pairs; the tag tells whose entry it is)
@@ -986,7 +1111,66 @@ SMJ_DEV void collision_static(float* pc, bool prof) {
       sdx[lane] = e.x; sdy[lane] = e.y; sdz[lane] = e.z; stag[lane] = __builtin_bit_cast(int, e.w); ssid[lane] = sid;
     }
     const int m = n - k0 < 64 ? n - k0 : 64;
+    // stored manifolds (DevState::mcache), all survivors of the batch at once: lane = pair compares the poses of the pair's two
+    // bodies with the entry's and, where neither has moved, writes the entry's contacts (ballot prefix of the counts)
+    PL<int> done;
+    LANES { done[lane] = 0; }
+    if (S.mcache && M.manifold_cache) {
+      PL<int> cnt;
+      LANES {
+        int c = 0;
+        if (lane < m) {
+          const int sid = ssid[lane], tag = 0x40000000 | sid;
+          const int* r = M.k_sprec + sid * SMJ_CP_STRIDE;
+          const float* mc = mc_entry(tag);
+          const Vec4* m4 = reinterpret_cast<const Vec4*>(mc);
+          const Vec4 a = m4[0], b = m4[1], cc = m4[2], d = m4[3];
+          const float w[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, cc.x, cc.y, cc.z, cc.w, d.x, d.y, d.z, d.w};
+          bool ok = __builtin_bit_cast(int, w[0]) == tag;
+          const int b1 = r[SMJ_CP_B1], b2 = r[SMJ_CP_B2];
+          for (int k = 0; k < 7; k++) {
+            ok = ok && fabsf((k < 3 ? s.xpos[b1][k] : s.xquat[b1][k - 3]) - w[1 + k]) <= SMJ_MC_EPS;
+            ok = ok && fabsf((k < 3 ? s.xpos[b2][k] : s.xquat[b2][k - 3]) - w[8 + k]) <= SMJ_MC_EPS;
+          }
+          if (ok) { c = (int)w[15]; c = c < 0 ? 0 : c > 5 ? 5 : c; done[lane] = 1; }
+        }
+        cnt[lane] = c;
+      }
+      PL<int> bit;
+      LANES { bit[lane] = cnt[lane] & 1; }
+      const uint64_t m0 = wave_ballot(bit);
+      LANES { bit[lane] = cnt[lane] & 2; }
+      const uint64_t m1 = wave_ballot(bit);
+      LANES { bit[lane] = cnt[lane] & 4; }
+      const uint64_t m2 = wave_ballot(bit);
+      const int total = popc64(m0) + 2 * popc64(m1) + 4 * popc64(m2);
+      if (total) {
+        LANES {
+          const int c = cnt[lane];
+          if (c) {
+            const uint64_t lt = (1ull << lane) - 1;
+            const int off = ncon + popc64(m0 & lt) + 2 * popc64(m1 & lt) + 4 * popc64(m2 & lt);
+            const int sid = ssid[lane];
+            const int* r = M.k_sprec + sid * SMJ_CP_STRIDE;
+            const float* mc = mc_entry(0x40000000 | sid);
+            const float nrm[3] = {mc[16], mc[17], mc[18]};
+            for (int k = 0; k < c; k++)
+              if (off + k < NCON) {
+                const float p3[3] = {mc[20 + 4 * k], mc[21 + 4 * k], mc[22 + 4 * k]};
+                write_contact(off + k, r, mc[19 + 4 * k], p3, nrm);
+              }
+          }
+        }
+        if (ncon + total > NCON) { flags |= SMJ_FLAG_CON_OVERFLOW; ncon = NCON; }
+        else ncon += total;
+        SYNC();
+#ifdef SMJ_EMUL
+        smj_emul_mc_hits += popc64(wave_ballot(done));
+#endif
+      }
+    }
     for (int l = 0; l < m; l++) {
+      if (wave_read(done, l)) continue;
       const int sid = wave_read(ssid, l);
       const int* r = static_cast<const int*>(__builtin_assume_aligned(M.k_sprec + sid * SMJ_CP_STRIDE, 16));
       const int S1 = uni(r[SMJ_CP_S1]), S2 = uni(r[SMJ_CP_S2]);
@@ -994,8 +1178,9 @@ SMJ_DEV void collision_static(float* pc, bool prof) {
       const float sd[3] = {wave_read(sdx, l), wave_read(sdy, l), wave_read(sdz, l)};
       const int tag = 0x40000000 | sid;
       narrow_pair(r, S1 < 0 ? NCG : S1, S2 < 0 ? NCG : S2, sepbase ? sepbase + 4 * ((sid * 7 + 29) & (SMJ_SEP_SLOTS - 1)) : nullptr, tag,
-                  sepbase && wave_read(stag, l) == tag, sd, pc, prof);
+                  sepbase && wave_read(stag, l) == tag, sd, pc, prof, false);
       SYNC();
     }
   }
+  if (prof) pc[SMJ_PROF_S_NARROW] += (float)(smj_clock() - tn0);
 }

@@ -75,6 +75,7 @@ struct Smem {
 #if NSAT > 0
       int sl_n, sl_sid[NSURV];     // static-geometry broadphase (collision_static): survivors = index into k_sprec ...
       unsigned char sl_c[NSURV], sl_ord[NSURV];   // ... the moving geom's cache slot; the survivors in pair-table order
+      float mc_r[NCG];             // bounding radii of the cached geoms
 #endif
     } c;
     struct {                // plane narrowphase staging: contacts of the pair owned by each lane, emitted in pair order
@@ -88,7 +89,7 @@ struct Smem {
     struct {                // Newton: the Hessian H = M + J' W J (or M - h*D of the integrator)
 #if NSAT > 0
       float H[NXV][NXV + 1];   // main block + the dense extension of coupled satellites (smj_sat.h); the cone Hessians stay valid beside it (the satellites' blocks read them after the main block is stored)
-      float cH[NCON][36];
+      float cH[NCH][36];       // pool: block SatMem::chs[c] holds contact c's cone Hessian
 #else
       union {               // the cone Hessians are consumed (as MFMA operands) before the Hessian of the same iteration is written
         float H[NVS][NVS + 1];
@@ -295,6 +296,7 @@ SMJ_DEV float impedance(const float* solimp, float pos, float margin) {
 #ifdef SMJ_EMUL
 static long smj_emul_sep_skips = 0;
 static long smj_emul_ext_steps = 0;
+static long smj_emul_mc_hits = 0;
 #endif
 // ---------------------------------------------------------------------------------------------- the step
 struct StepKernel {
@@ -434,7 +436,11 @@ struct StepKernel {
     }
     SYNC();
 #if NSAT > 0
-    LANES { for (int k = lane; k < (NDR + 1) * JS; k += 64) (&s.J[0][0])[k] = 0.f; }   // (row NDR: the dense row of every row without one)
+    LANES {
+      for (int k = lane; k < (NDR + 1) * JS; k += 64) (&s.J[0][0])[k] = 0.f;   // (row NDR: the dense row of every row without one)
+      if (lane == 0) { s.sat.cand_ok = 0; s.sat.ncand = 0; }                    // the static-broadphase candidate list is rebuilt by the first step
+      for (int k = lane; k < NCG * 3; k += 64) (&s.sat.refcen[0][0])[k] = 0.f;
+    }
 #endif
     // identity padding of the dof block nv..NVP-1, written once: the per-step mass-matrix entries never touch it, and the
     // Newton Hessian H = M + J'WJ / the dense M x products can then take MM as it is, with no `< nv` select per element
@@ -2364,8 +2370,58 @@ struct StepKernel {
   // narrowphase of one convex pair: record r (DevModel::k_cprec / k_sprec), s1 / s2 = the geoms' slots in the collision stage's
   // LDS cache.  sepslot / septag: the pair's entry of the separating-direction cache (or null), sep_hit: it holds this pair's
   // direction sd.
-  SMJ_DEV void narrow_pair(const int* r, int s1, int s2, float* sepslot, int septag, bool sep_hit, const float* sd, float* pc, bool prof) {
+  SMJ_DEV float* mc_entry(int tag) const { return S.mcache + ((size_t)env * SMJ_MC_SLOTS + (((unsigned)tag * 2654435761u) >> 27)) * SMJ_MC_WORDS; }
+  SMJ_DEV void narrow_pair(const int* r, int s1, int s2, float* sepslot, int septag, bool sep_hit, const float* sd, float* pc, bool prof, bool lookup = true) {
     const int g1 = uni(r[SMJ_CP_G1]), g2 = uni(r[SMJ_CP_G2]);
+    // the pair's stored manifold (DevState::mcache): valid while neither body has moved
+    const int ta0 = uni(s.u.c.meta[s1]) & 15, tb0 = uni(s.u.c.meta[s2]) & 15;
+    float* mc = nullptr;
+    const int ncon0 = ncon;
+    if (S.mcache && M.manifold_cache && ta0 != GT_SPHERE && tb0 != GT_SPHERE) {
+      mc = mc_entry(septag);
+      const int b1 = uni(r[SMJ_CP_B1]), b2 = uni(r[SMJ_CP_B2]);
+      PL<float> w;
+      PL<int> moved;
+      if (lookup) LANES {
+        w[lane] = lane < SMJ_MC_WORDS ? mc[lane] : 0.f;
+        float cur = w[lane];
+        if (lane >= 1 && lane < 15) {
+          const int b = lane < 8 ? b1 : b2, k = lane < 8 ? lane - 1 : lane - 8;
+          cur = k < 3 ? s.xpos[b][k] : s.xquat[b][k - 3];
+        }
+        moved[lane] = !(fabsf(cur - w[lane]) <= SMJ_MC_EPS);
+      }
+      if (lookup && __builtin_bit_cast(int, wave_read(w, 0)) == septag && wave_ballot(moved) == 0) {
+        const int n = (int)wave_read(w, 15);
+        const float nrm[3] = {wave_read(w, 16), wave_read(w, 17), wave_read(w, 18)};
+        for (int k = 0; k < n && k < 5; k++) {
+          const float p3[3] = {wave_read(w, 20 + 4 * k), wave_read(w, 21 + 4 * k), wave_read(w, 22 + 4 * k)};
+          add_contact(r, wave_read(w, 19 + 4 * k), p3, nrm);
+        }
+#ifdef SMJ_EMUL
+        smj_emul_mc_hits++;
+#endif
+        return;
+      }
+    }
+    narrow_pair_run(r, g1, g2, s1, s2, sepslot, septag, sep_hit, sd, pc, prof);
+    if (mc && ncon > ncon0 && ncon - ncon0 <= 5) {   // keep what the narrowphase found, with the poses it was found at
+      const int b1 = uni(r[SMJ_CP_B1]), b2 = uni(r[SMJ_CP_B2]), n = ncon - ncon0;
+      SYNC();
+      LANES {
+        if (lane < SMJ_MC_WORDS) {
+          float v = 0.f;
+          if (lane == 0) v = asf(septag);
+          else if (lane < 15) { const int b = lane < 8 ? b1 : b2, k = lane < 8 ? lane - 1 : lane - 8; v = k < 3 ? s.xpos[b][k] : s.xquat[b][k - 3]; }
+          else if (lane == 15) v = (float)n;
+          else if (lane < 19) v = s.cframe[ncon0][lane - 16];
+          else if (lane < 19 + 4 * n) { const int k = (lane - 19) >> 2, q = (lane - 19) & 3; v = q == 0 ? s.cdist[ncon0 + k] : s.cpos[ncon0 + k][q - 1]; }
+          mc[lane] = v;
+        }
+      }
+    }
+  }
+  SMJ_DEV void narrow_pair_run(const int* r, int g1, int g2, int s1, int s2, float* sepslot, int septag, bool sep_hit, const float* sd, float* pc, bool prof) {
     Shape A, Bs;
     float c0[3], c1[3], depth, dir[3], pos[3];
     load_shape(A, g1, s1, c0);
@@ -3233,6 +3289,9 @@ struct StepKernel {
     PL<float> cost;
     LANES { cost[lane] = 0.f; }
     ROWS_BEGIN(rb, ne) LANES { if (lane + rb < NEFC) s.eb[lane + rb] = nr.jar[lane]; } ROWS_END_RO()
+#if NSAT > 0
+    LANES { if (lane == 0) s.sat.nch = 0; }
+#endif
     SYNC();
     ROWS_BEGIN(rb, ne) LANES {
       float c = 0, f = 0;
@@ -3291,8 +3350,15 @@ struct StepKernel {
           ef[0] = fn;
 #pragma unroll
           for (int j = 1; j < 6; j++) ef[j] = -fn * Ti * U[j] * S[j];
+#if NSAT > 0
+          const int hslot = want_hess ? lds_atomic_inc(&s.sat.nch) : NCH;   // a block of the cone-Hessian pool (beyond it: none, see NCH)
+          s.sat.chs[c] = hslot < NCH ? (signed char)hslot : (signed char)-1;
+          if (want_hess && hslot < NCH) {
+            float* H = s.u.n.cH[hslot];
+#else
           if (want_hess) {
             float* H = s.u.n.cH[c];
+#endif
             const float a = mu * N * Ti * Ti * Ti, b = mu * NT * Ti;
             // stored 6x6 with a fixed stride: S[j] = 0 beyond the contact's condim zero-pads the block by itself, and the
             // readers (XA stage) get immediate offsets instead of condim-dependent addresses
@@ -3397,7 +3463,7 @@ struct StepKernel {
         const int si = s.sat.esat[row][u];
         if (si >= 0 && lane + rb < NEFC)
           for (int k = 0; k < 6; k++) {
-            const float av = s.sat.Js[row][u][k], xv = s.sat.x[SX_QA][si][k];
+            const float av = jsp(row, u)[k], xv = s.sat.x[SX_QA][si][k];
             const float p = av * xv, pe = fmaf(av, xv, -p);
             const float t = hi0[lane] + p, z = t - hi0[lane];
             const float se = (hi0[lane] - (t - z)) + (p - z);
@@ -3789,6 +3855,9 @@ struct StepKernel {
           if (lane < ncon) {
             const int r0 = s.cefc[lane];
             z = r0 >= 0 && s.cdim[lane] >= 3 && s.estate[r0 >= 0 ? r0 : 0] == 4;   // row states as left by newton_update
+#if NSAT > 0
+            z = z && s.sat.chs[lane] >= 0;   // (its Hessian is in the pool)
+#endif
           }
           cz[lane] = z;
         }
@@ -3858,8 +3927,13 @@ struct StepKernel {
               const int q = q0 + (lane >> 4), col = lane & 15, qc = q < 6 ? q : 5;
               const float on = q < dim ? 1.f : 0.f;
               float hq[6];
+#if NSAT > 0
+              const int hc = s.sat.chs[c];
+#else
+              const int hc = c;
+#endif
 #pragma unroll
-              for (int p = 0; p < 6; p++) hq[p] = on * s.u.n.cH[c][6 * qc + p];
+              for (int p = 0; p < 6; p++) hq[p] = on * s.u.n.cH[hc][6 * qc + p];
 #pragma unroll
               for (int t = 0; t < NT; t++) {
                 float jv[6], av = 0.f;
@@ -3902,14 +3976,16 @@ struct StepKernel {
       LANES { search[lane] = lane < nv ? grad[lane] : 0.f; }
 #if NSAT > 0
       // the satellites' blocks; the coupled ones (contacts with the main tree / with each other) extend the dense system of this step
+      const long long tsh = prof ? smj_clock() : 0;
       sat_hessian(conemask);
       SYNC();
+      if (prof) pc[SMJ_PROF_SAT_H] += (float)(smj_clock() - tsh);
       if (next_sat > 0) {
         sat_extend_hessian(next_sat, conemask);
         LANES {
           if (lane >= NVS && lane < NVS + 6 * next_sat) { const int e = (lane - NVS) / 6; search[lane] = s.sat.x[SX_GRAD][s.sat.xs[e]][lane - NVS - 6 * e]; }
         }
-        gj_solve_ext(search, NVS + 6 * next_sat);
+        solve_ext_schur(search, next_sat);
         LANES {
           if (lane >= NVS && lane < NVS + 6 * next_sat) { const int e = (lane - NVS) / 6; s.sat.x[SX_SRCH][s.sat.xs[e]][lane - NVS - 6 * e] = -search[lane]; }
         }
@@ -4303,7 +4379,7 @@ struct StepKernel {
       if (last) dump_contacts();
       TICK(SMJ_PROF_COLLISION)
 #if NSAT > 0
-      make_constraint_sat();
+      make_constraint_sat(pc, prof);
 #else
       if (M.solver != 2) nefc = NEFC;   // PGS: the A of a step with at most 64 rows sits in rows 64.. of J (solve<false>) -- have them cleared
       make_constraint();

@@ -76,6 +76,7 @@ static inline float uni(float x) { return x; }
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline float fast_rsqrt(float x) { return 1.0f / sqrtf(x); }
 static inline int lds_atomic_inc(int* p) { const int v = *p; *p = v + 1; return v; }   // (lanes run one after the other here)
+static inline int lds_atomic_add(int* p, int n) { const int v = *p; *p = v + n; return v; }
 #else
 #include <hip/hip_runtime.h>
 #define SMJ_DEV __device__ __forceinline__
@@ -153,6 +154,7 @@ __device__ __forceinline__ float uni(float x) { return __builtin_bit_cast(float,
 // 1-ulp hardware reciprocal / reciprocal square root (v_rcp_f32 / v_rsq_f32): the serial solver math is latency
 // bound, an IEEE divide costs ~10 dependent instructions
 __device__ __forceinline__ int lds_atomic_inc(int* p) { return atomicAdd(p, 1); }   // a counter in LDS bumped from divergent lanes (ds_add_rtn)
+__device__ __forceinline__ int lds_atomic_add(int* p, int n) { return atomicAdd(p, n); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 #endif

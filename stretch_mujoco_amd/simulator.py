@@ -117,7 +117,7 @@ class StretchBatchSimulator:
                  ("INFO", self.info)]
         if self._debug:
             self.debug = torch.zeros(dims[D["DEBUG_FLOATS"]], B, **f)
-            self.prof = torch.zeros(40, B, **f)
+            self.prof = torch.zeros(48, B, **f)
             binds.append(("DEBUG", self.debug))
             binds.append(("PROF", self.prof))
         for name, t in binds:

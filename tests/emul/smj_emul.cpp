@@ -52,6 +52,8 @@ emul_ctx* emul_create(const void* blob, size_t nbytes, int num_envs) {
   c->s.lay = smj_stage_layout(NVP, NBT, NSAT);
   c->s.sepcache = (float*)calloc((size_t)num_envs * SMJ_SEP_SLOTS * 4, sizeof(float));
   c->keep.push_back(c->s.sepcache);
+  c->s.mcache = (float*)calloc((size_t)num_envs * SMJ_MC_SLOTS * SMJ_MC_WORDS, sizeof(float));
+  c->keep.push_back(c->s.mcache);
   return c;
 }
 void emul_destroy(emul_ctx* c) {
@@ -97,12 +99,14 @@ int emul_set_option(emul_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "multiccd")) m.multiccd = (int)v;
   else if (!strcmp(name, "multi_serial")) m.multi_serial = (int)v;
   else if (!strcmp(name, "sep_cache")) m.sep_cache = (int)v;
+  else if (!strcmp(name, "manifold_cache")) m.manifold_cache = (int)v;
   else return -1;
   return 0;
 }
 // LDS is uninitialised when a workgroup starts: tests poison the emulated LDS to catch reads before writes
 long emul_sep_skips() { return smj_emul_sep_skips; }
 long emul_ext_steps() { return smj_emul_ext_steps; }
+long emul_mc_hits() { return smj_emul_mc_hits; }
 int emul_poison = -1;
 void emul_set_poison(int byte) { emul_poison = byte; }
 int emul_step(emul_ctx* c, int nsteps, unsigned read_flags) {

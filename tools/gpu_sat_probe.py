@@ -11,7 +11,7 @@ what = sys.argv[1] if len(sys.argv) > 1 else "both"
 MODELS = os.path.join(ROOT, "stretch_mujoco_amd", "models")
 if what in ("parity", "both"):
     import rollout_common as rc
-    for scene in ("stretch_scene_sat", "stretch_kitchen4_sat", "stretch_kitchen_export_sat"):
+    for scene in ("stretch_scene_sat", "stretch_kitchen4_sat", "stretch_kitchen_export_sat", "stretch_kitchen_robocasa"):
         blob = open(f"{MODELS}/{scene}.smjb", "rb").read()
         be = rc.HipBackend(scene, 8)
         rel, events = rc.state_synchronised(be, blob, mb.loads(blob), 8, 6, seed=3)
@@ -23,7 +23,7 @@ if what in ("parity", "both"):
         for e in bad: print("   ", e)
 if what in ("speed", "both"):
     B, HOLD, WIN = 4096, 50, 12
-    for scene in ("stretch_scene", "stretch_scene_sat", "stretch_kitchen4", "stretch_kitchen4_sat", "stretch_kitchen_export", "stretch_kitchen_export_sat"):
+    for scene in ("stretch_scene", "stretch_scene_sat", "stretch_kitchen4", "stretch_kitchen4_sat", "stretch_kitchen_export", "stretch_kitchen_export_sat", "stretch_kitchen_robocasa"):
         sim = StretchBatchSimulator(num_envs=B, device="cuda:0", scene=scene)
         sim.start(home=False)
         sim.home(settle=False)
