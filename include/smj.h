@@ -35,7 +35,9 @@ enum smj_slot {
                              clears them: bit 0 = constraint rows beyond the kernel variant's capacity were degraded / dropped,
                              bit 1 = contacts beyond capacity dropped, bit 2 = non-finite state reset to qpos0, bit 3 = the
                              pipelined dispatch gave up waiting for the env's previous chunk: the env ran fewer steps than
-                             asked for (NSTEP tells how many) -- never observed, it bounds a wait that would otherwise hang)  */
+                             asked for (NSTEP tells how many) -- never observed, it bounds a wait that would otherwise hang); bits 8..14: which capacity
+                             bits 0 / 1 refer to in the satellite builds (diagnostic: items, coupled satellites, satellite-satellite rows,
+                             broadphase lists, dense rows, rows, contacts)  */
   SMJ_SLOT_DEBUG = 12,    /* [SMJ_DEBUG_FLOATS][B] optional stage dumps for parity tests (may stay unbound) */
   SMJ_SLOT_PROF = 13,     /* [32][B] optional per-stage shader-cycle counters and event counts of a launch (filled by the
                              standard kernel variant only: binding it selects that variant's profiling build)           */

@@ -620,17 +620,18 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
     // sixteen, any poll interval, any stream priority), and escalations are rare events (0-2 envs per 50-step launch of 4096
     // under random actions, each worth milliseconds when left to the sweep): the pollers leave at once unless one of the last
     // SMJ_HOT_LAUNCHES launches had an escalation (DevState::hot, kept on the device -- the host runs many launches ahead)
-    const bool poll = esc && pipe && c->pollers > 0 && c->variant == 0;
+    const bool poll = esc && pipe && c->pollers > 0 && (c->variant == 0 || c->variant == 5);   // (the 16-satellite build hands over to the 32-satellite one the same way)
     if (poll) {
       // pollers first, on their own stream, so that they are resident when the standard kernel fills the device; should they
       // not be (nothing guarantees it), parked envs are given up to the sweep, as without pollers
       DevState sp = st;
       sp.redo_worker = 2;
-      sp.pollers = c->pollers_always ? -c->pollers : c->pollers;
+      const int np = c->variant == 5 ? 6 * c->pollers : c->pollers;   // a kitchen's random-action workload parks ~10 envs per launch, each chunk of the large build takes milliseconds
+      sp.pollers = c->pollers_always ? -np : np;
       sp.order = nullptr;
       HIPCHK(c, hipEventRecord(c->ev_fork, sm));
       HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
-      lrc = smj_launch_step_tall(c->model_esc, sp, k, fl, c->aux);
+      lrc = c->variant == 5 ? smj_launch_step_sat32(c->model_esc, sp, k, fl, c->aux) : smj_launch_step_tall(c->model_esc, sp, k, fl, c->aux);
       HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
     }
     if (!lrc)

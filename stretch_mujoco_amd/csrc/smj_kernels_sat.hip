@@ -1,12 +1,13 @@
 // The satellite build of the step kernel (smj_sat.h): the main tree with the standard variant's mapping (32 dof lanes / columns)
-// plus up to 16 satellites -- free objects, doors, drawers, knobs -- one lane each.  216 constraint rows (80 of them with a dense
+// plus up to 16 satellites -- free objects, doors, drawers, knobs -- one lane each.  208 constraint rows (96 of them with a dense
 // Jacobian row: the rows that touch the main tree), 56 contacts, up to 3 satellites coupled to the robot / to each other per step:
 // 79 KB of LDS per env, two envs per CU.  The kernel of kitchens: the reference's scene.xml (table + 2 free objects), the kitchen
 // stand-ins with free objects, exported Robocasa kitchens (robocasa_gen.py:129-239).  Larger models / steps: smj_kernels_sat32.hip.
 #define SMJ_SAT 16
-#define SMJ_SAT_ROWS 216
+#define SMJ_SAT_ROWS 208
 #define SMJ_SAT_CONTACTS 56
-#define SMJ_SAT_DENSE 80
+#define SMJ_SAT_DENSE 96
+#define SMJ_SAT_ITEMS 16
 #define SMJ_SAT_EXT 3
 #define SMJ_VARIANT_TAG sat
 #ifndef SMJ_PROFILING

@@ -1,11 +1,12 @@
-// The large satellite build (smj_sat.h): up to 32 satellites, 224 rows (128 dense), 64 contacts, 4 coupled satellites per step --
+// The large satellite build (smj_sat.h): up to 32 satellites, 320 rows (256 of them dense), 64 contacts, 4 coupled satellites per step --
 // one env per CU.  Models with more than 16 satellites, and the escalation target of the 16-satellite build: an env whose step
 // needs more rows / contacts / coupled satellites than that build holds is finished here (DevState::redo, as standard -> tall).
 #define SMJ_SAT 32
-#define SMJ_SAT_ROWS 256
+#define SMJ_SAT_ROWS 320
 #define SMJ_SAT_CONTACTS 64
-#define SMJ_SAT_DENSE 128
+#define SMJ_SAT_DENSE 256
 #define SMJ_SAT_EXT 4
+#define SMJ_SAT_ITEMS 40
 #define SMJ_VARIANT_TAG sat32
 #ifndef SMJ_PROFILING
 #define SMJ_PROFILING 0

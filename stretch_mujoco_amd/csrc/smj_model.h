@@ -22,9 +22,9 @@
 #define NSAT SMJ_SAT
 #define NVP 32
 #ifndef SMJ_SAT_ROWS
-#define SMJ_SAT_ROWS 256
+#define SMJ_SAT_ROWS 320
 #define SMJ_SAT_CONTACTS 64
-#define SMJ_SAT_DENSE 128
+#define SMJ_SAT_DENSE 256
 #endif
 #define NEFC SMJ_SAT_ROWS
 #define NCON SMJ_SAT_CONTACTS

@@ -466,7 +466,7 @@ int nd = 0, nd_prev = NDR, next_sat = 0;
 // enter rows r0 .. r0 + n - 1 (slot `slot` of their satellite columns) in satellite si's item list; called from divergent lanes
 SMJ_DEV void sat_item(int si, int r0, int n, int slot, int inf, int c = 0) {
   const int at = lds_atomic_inc(&s.sat.nitem[si]);
-  if (at < NIT) { s.sat.irow[si][at] = (unsigned char)r0; s.sat.iinf[si][at] = (unsigned char)(n | (slot ? ITEM_SLOT : 0) | inf); s.sat.icon[si][at] = (unsigned char)c; }
+  if (at < NIT) { s.sat.irow[si][at] = (unsigned short)r0; s.sat.iinf[si][at] = (unsigned char)(n | (slot ? ITEM_SLOT : 0) | inf); s.sat.icon[si][at] = (unsigned char)c; }
 }
 SMJ_DEV void make_constraint_sat(float* pc, bool prof) {
   long long tq = prof ? smj_clock() : 0;
@@ -546,7 +546,7 @@ SMJ_DEV void make_constraint_sat(float* pc, bool prof) {
     }
   }
   row0 += popc64(lm);
-  if (row0 > cap || row0 > NDR) { row0 = cap < NDR ? cap : NDR; flags |= SMJ_FLAG_EFC_OVERFLOW; }
+  if (row0 > cap || row0 > NDR) { row0 = cap < NDR ? cap : NDR; flags |= SMJ_FLAG_EFC_OVERFLOW | 0x1000; }
   SYNC();
   QTICK(SMJ_PROF_MC_ROWS)
   // ---- contacts, phase 1 (lane = contact): bodies, classes, dof masks, diagonal approximations
@@ -595,7 +595,7 @@ SMJ_DEV void make_constraint_sat(float* pc, bool prof) {
         int d = wave_read(cdimv, c);
         if (!wave_read(cact, c) || !wave_read(cmain, c)) continue;
         if (row0 + d > lim) {
-          flags |= SMJ_FLAG_EFC_OVERFLOW;
+          flags |= SMJ_FLAG_EFC_OVERFLOW | 0x1000;
           if (d > 3 && row0 + 3 <= lim) d = 3;
           else if (row0 + 1 <= lim) d = 1;
           else continue;
@@ -624,7 +624,7 @@ SMJ_DEV void make_constraint_sat(float* pc, bool prof) {
     }
   }
   row0 += nfs;
-  if (row0 > cap) { row0 = cap; flags |= SMJ_FLAG_EFC_OVERFLOW; }
+  if (row0 > cap) { row0 = cap; flags |= SMJ_FLAG_EFC_OVERFLOW | 0x2000; }
   LANES {
     int a = 0;
     float q = 0;
@@ -654,7 +654,7 @@ SMJ_DEV void make_constraint_sat(float* pc, bool prof) {
     }
   }
   row0 += popc64(lm);
-  if (row0 > cap) { row0 = cap; flags |= SMJ_FLAG_EFC_OVERFLOW; }
+  if (row0 > cap) { row0 = cap; flags |= SMJ_FLAG_EFC_OVERFLOW | 0x2000; }
   // ---- rows of the contacts that touch no main body (same scheme)
   {
     PL<int> bit;
@@ -676,7 +676,7 @@ SMJ_DEV void make_constraint_sat(float* pc, bool prof) {
         int d = wave_read(cdimv, c);
         if (!wave_read(cact, c) || wave_read(cmain, c)) continue;
         if (row0 + d > cap) {
-          flags |= SMJ_FLAG_EFC_OVERFLOW;
+          flags |= SMJ_FLAG_EFC_OVERFLOW | 0x2000;
           if (d > 3 && row0 + 3 <= cap) d = 3;
           else if (row0 + 1 <= cap) d = 1;
           else continue;
@@ -747,7 +747,7 @@ SMJ_DEV void make_constraint_sat(float* pc, bool prof) {
       }
     }
   }
-  if (wave_ballot(over2)) flags |= SMJ_FLAG_EFC_OVERFLOW;
+  if (wave_ballot(over2)) flags |= SMJ_FLAG_EFC_OVERFLOW | 0x400;
   SYNC();
   // contacts phase 2: the main columns of the dense rows (as make_constraint: lanes = dofs, two contacts per pass)
   constexpr int CPP = 64 / NVP;
@@ -803,7 +803,7 @@ SMJ_DEV void make_constraint_sat(float* pc, bool prof) {
     LANES { b0[lane] = wantx[lane] & 1; b1[lane] = wantx[lane] & 2; }
     const uint64_t xm = wave_ballot(b0);
     if (wave_ballot(b1)) {   // more row items on one satellite than NIT: its later rows are not in its block
-      flags |= SMJ_FLAG_EFC_OVERFLOW;
+      flags |= SMJ_FLAG_EFC_OVERFLOW | 0x100;
 #ifdef SMJ_EMUL
       if (getenv("SMJ_SAT_TRACE")) fprintf(stderr, "item overflow\n");
 #endif
@@ -821,7 +821,7 @@ SMJ_DEV void make_constraint_sat(float* pc, bool prof) {
     if (next_sat > 0) smj_emul_ext_steps++;   // (tests: the dense extension is exercised)
     if (popc64(wave_ballot(b0)) > 0 && getenv("SMJ_SAT_TRACE")) fprintf(stderr, "ext step: %d satellites coupled, nd %d nefc %d\n", next_sat, nd, row0);
 #endif
-    if (next_sat > NXS) { next_sat = NXS; flags |= SMJ_FLAG_EFC_OVERFLOW; }   // beyond the extension's capacity the coupling blocks of the surplus satellites are dropped: flagged
+    if (next_sat > NXS) { next_sat = NXS; flags |= SMJ_FLAG_EFC_OVERFLOW | 0x200; }   // beyond the extension's capacity the coupling blocks of the surplus satellites are dropped: flagged
     PL<int> ss;
     LANES { ss[lane] = lane < ncon && s.cefc[lane] >= 0 && csa[lane] >= 0 && csb[lane] >= 0; }
     const uint64_t sm = wave_ballot(ss);
@@ -836,7 +836,7 @@ SMJ_DEV void make_constraint_sat(float* pc, bool prof) {
       }
     }
     if (popc64(sm) > NSS) {
-      flags |= SMJ_FLAG_EFC_OVERFLOW;
+      flags |= SMJ_FLAG_EFC_OVERFLOW | 0x400;
 #ifdef SMJ_EMUL
       if (getenv("SMJ_SAT_TRACE")) fprintf(stderr, "sat-sat contact overflow %d\n", popc64(sm));
 #endif
@@ -1038,7 +1038,7 @@ SMJ_DEV void collision_static(float* pc, bool prof) {
       SYNC();
       if (uni(s.sat.ncand) > NCAND) {   // more near pairs than the list holds: flagged, and the list is rebuilt next step
         LANES { if (lane == 0) { s.sat.ncand = NCAND; s.sat.cand_ok = 0; } }
-        flags |= SMJ_FLAG_CON_OVERFLOW;
+        flags |= SMJ_FLAG_CON_OVERFLOW | 0x800;
         SYNC();
       }
     }
@@ -1078,7 +1078,7 @@ SMJ_DEV void collision_static(float* pc, bool prof) {
   SYNC();
   if (prof) pc[SMJ_PROF_S_BROAD] += (float)(smj_clock() - tb0);
   int n = uni(s.u.c.sl_n);
-  if (n > NSURV) { n = NSURV; flags |= SMJ_FLAG_CON_OVERFLOW; }
+  if (n > NSURV) { n = NSURV; flags |= SMJ_FLAG_CON_OVERFLOW | 0x800; }
   if (prof) pc[SMJ_PROF_C_NSPHERE] += (float)n;
 #ifdef SMJ_EMUL
   if (getenv("SMJ_SAT_TRACE")) { fprintf(stderr, "static candidates %d survivors %d:", ncand, n); for (int i = 0; i < n; i++) fprintf(stderr, " %d", M.k_sprec[s.u.c.sl_sid[i] * SMJ_CP_STRIDE + SMJ_CP_PAIR]); fprintf(stderr, "\n"); }
@@ -1161,7 +1161,7 @@ SMJ_DEV void collision_static(float* pc, bool prof) {
               }
           }
         }
-        if (ncon + total > NCON) { flags |= SMJ_FLAG_CON_OVERFLOW; ncon = NCON; }
+        if (ncon + total > NCON) { flags |= SMJ_FLAG_CON_OVERFLOW | 0x4000; ncon = NCON; }
         else ncon += total;
         SYNC();
 #ifdef SMJ_EMUL

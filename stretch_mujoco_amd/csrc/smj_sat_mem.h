@@ -2,9 +2,12 @@
 #pragma once
 #if NSAT > 0
 #define NXV (NVS + 6 * NXS)   // order of the dense Newton system of a step in which satellites are coupled: the main columns + NXS satellites
-#define NIT 20                // row items (a contact's rows / a friction-loss row / a limit row) one satellite can hold in a step
+#ifndef SMJ_SAT_ITEMS
+#define SMJ_SAT_ITEMS 20
+#endif
+#define NIT SMJ_SAT_ITEMS    // row items (a contact's rows / a friction-loss row / a limit row) one satellite can hold in a step
 #define NSS 8                 // satellite-satellite contacts of a step
-#define NCAND 512             // static-broadphase candidates kept between steps
+#define NCAND 288             // static-broadphase candidates kept between steps
 #define SMJ_SB_SLACK 0.03f    // metres a moving geom may travel before the candidate list is rebuilt
 #define NS2 (6 * NSS)         // rows of the second-slot pool
 #define NCH 16                // contacts whose cone Hessian is kept per constraint update (contacts in the middle zone of their cone: sliding); beyond it a contact's block is left out of H for that iteration (the step stays exact: gradient and line search are)
@@ -20,7 +23,8 @@ struct SatMem {
   int ext[NSAT];            // slot in the dense extension of this step's Newton system (-1: the block is solved on the satellite's own lane)
   int xs[NXS];              // satellites of the extension, slot order
   int nitem[NSAT];
-  unsigned char irow[NSAT][NIT], iinf[NSAT][NIT], icon[NSAT][NIT];   // first row | rows (ITEM_N), slot, flags | contact index
+  unsigned short irow[NSAT][NIT];   // first row of the item
+  unsigned char iinf[NSAT][NIT], icon[NSAT][NIT];   // rows (ITEM_N), slot, flags | contact index
   int sscon[NSS];           // contacts between two satellites
   float Js[NEFC][6];        // the satellite columns of a constraint row: those of satellite esat[row][0] ...
   float Js2[NS2][6];        // ... and, for the rows of a contact between two satellites, those of esat[row][1]: row e2[row] of this pool

@@ -1131,7 +1131,7 @@ struct StepKernel {
   }
   SMJ_DEV void add_contact(const int* r, float dist, const float* pos, const float* n) {
     // uniform: every lane calls with identical arguments; lane 0 writes
-    if (ncon >= NCON) { flags |= SMJ_FLAG_CON_OVERFLOW; return; }
+    if (ncon >= NCON) { flags |= SMJ_FLAG_CON_OVERFLOW | 0x4000; return; }
     const int c = ncon++;
     LANES { if (lane == 0) write_contact(c, r, dist, pos, n); }
   }

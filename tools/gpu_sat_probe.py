@@ -37,5 +37,5 @@ if what in ("speed", "both"):
         for _ in range(WIN): act(); sim.step(HOLD)
         torch.cuda.synchronize(); dt = time.time() - t0
         fl = sim.info[3]
-        print(f"[{scene}] {B * HOLD * WIN / dt / 1e6:.2f} M env-steps/s; flagged envs {int((fl != 0).sum())} (bits {int(torch.bitwise_or(fl[0], fl.max()))}); nefc mean {float(sim.info[0].float().mean()):.1f} max {int(sim.info[0].max())}; ncon max {int(sim.info[1].max())}", flush=True)
+        print(f"[{scene}] {B * HOLD * WIN / dt / 1e6:.2f} M env-steps/s; flagged envs {int((fl != 0).sum())} (bits {hex(sum(int(((fl >> b) & 1).any()) << b for b in range(16)))}); nefc mean {float(sim.info[0].float().mean()):.1f} max {int(sim.info[0].max())}; ncon max {int(sim.info[1].max())}", flush=True)
         sim.stop()
