@@ -164,13 +164,32 @@ def other_configs(B, dev, hold, solver):
     res["lidar_imu_every_step"] = {"value": rollout(sim, 50, 1), "unit": "env-steps/s"}
     sim.stop()
     # config 4 stand-in: static kitchen fixtures around the robot + free objects, physics only
-    for scene in ("stretch_kitchen_standin", "stretch_kitchen4", "stretch_scene"):
+    # `_sat`: the same scene on the satellite builds of the step kernel (free objects / fixture parts one lane each, csrc/smj_sat.h).
+    # `stretch_kitchen_robocasa`: the generated kitchen at Robocasa scale -- 44 fixture bodies, 307 collision geoms (36 convex mesh
+    # pieces) behind the static-geometry broadphase, 8 articulated doors / drawers / knobs, 8 free objects: 82 dofs, 16 satellites.
+    for scene in ("stretch_kitchen_standin", "stretch_kitchen4", "stretch_kitchen4_sat", "stretch_scene", "stretch_scene_sat", "stretch_kitchen_robocasa"):
         if not os.path.exists(os.path.join(ROOT, "stretch_mujoco_amd", "models", scene + ".smjb")):
             continue
         sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver=solver, scene=scene)
         sim.start(home=False)
         res[scene + "_physics"] = {"value": rollout(sim, 500, hold), "unit": "env-steps/s", **flags_of(sim)}   # 10 launches: one with a hand-over to the larger variant costs +30 %
+        if scene == "stretch_kitchen_robocasa":
+            res[scene + "_physics"].update(dofs=sim.nv, kernel_variant="sat (16 satellites, 208 rows, 2 envs per CU) -> sat32 (320 rows) for steps beyond it",
+                                           note="overflow_flags bit 2 = more than 64 contacts in one env (a lane count); rows / dense rows / coupled satellites hand over and are not flagged")
         sim.stop()
+    # north_star's target sentence (>= 1 M env-steps/s on 4096 kitchen envs at 8 GPUs): the per-rank share of 4096 kitchen envs in
+    # total, on this one GPU -- 512 envs per rank at 8 GPUs, 1024 at 4
+    kshare = {}
+    for scene in ("stretch_kitchen_robocasa", "stretch_kitchen4_sat"):
+        if not os.path.exists(os.path.join(ROOT, "stretch_mujoco_amd", "models", scene + ".smjb")):
+            continue
+        kshare[scene] = {}
+        for nb in (1024, 512):
+            sim = StretchBatchSimulator(num_envs=nb, device=str(dev), solver=solver, scene=scene)
+            sim.start(home=False)
+            kshare[scene][str(nb)] = {"value": rollout(sim, 200, hold), "unit": "env-steps/s", **flags_of(sim)}
+            sim.stop()
+    res["kitchen_rank_share"] = {"envs_per_rank": kshare, "note": "one GPU, physics only, random actions: x8 (512 envs) / x4 (1024) = what 4096 kitchen envs in total can reach on a node"}
     # config 4 as north_star words it ("contact-rich PGS solve"): the same scenes under PGS.  The sweeps are serial over the rows
     # (100 sweeps x ~100 rows at one wavefront per env), so this is the slowest path of the library; Newton is the model's own solver.
     if solver != "pgs":
@@ -398,7 +417,7 @@ def main():
         if not args.no_second_solver and world == 1:
             other = "pgs" if args.solver == "newton" else "newton"
             sim.set_option("solver", {"pgs": 0, "newton": 2}[other])
-            n2 = min(args.steps, 300)   # six launches: two made the figure swing by 5 %
+            n2 = 300   # six launches whatever --steps is: two made the figure swing by 5 %
             random_action(); sim.step(hold)
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
