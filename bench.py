@@ -193,7 +193,10 @@ def other_configs(B, dev, hold, solver):
     # config 4 as north_star words it ("contact-rich PGS solve"): the same scenes under PGS.  The sweeps are serial over the rows
     # (100 sweeps x ~100 rows at one wavefront per env), so this is the slowest path of the library; Newton is the model's own solver.
     if solver != "pgs":
-        for scene, n in (("stretch_kitchen_standin", 100), ("stretch_kitchen4", 50)):
+        # `_sat` / the Robocasa-scale kitchen: PGS with constraint islands (csrc/smj_sat_pgs.h) -- the robot's rows as one dense system,
+        # every free object / fixture part that touches only the static world swept by its own lane, all in the same iteration
+        for scene, n in (("stretch_kitchen_standin", 100), ("stretch_kitchen4", 50), ("stretch_kitchen4_sat", 100), ("stretch_scene", 50), ("stretch_scene_sat", 100),
+                         ("stretch_kitchen_robocasa", 100)):
             if not os.path.exists(os.path.join(ROOT, "stretch_mujoco_amd", "models", scene + ".smjb")):
                 continue
             sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver="pgs", scene=scene)

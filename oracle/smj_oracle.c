@@ -59,6 +59,7 @@ struct smjo_model {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, ncam, neq, ntendon, nwrap, nkey, npair, nhullvert, nlidar;
   double timestep, gravity[3], impratio, tolerance, meaninertia, lidar_cutoff;
   int iterations, cone, warmstart, pgs_fixed_iter, max_con_pair, solver, ls_iterations;
+  int qcqp_cap;      /* iterates of mju_QCQP (20 = MuJoCo); option "qcqp_cap" */
   int multiccd;      /* stretch.xml:8 <flag multiccd="enable"/>: multi-point contacts for convex pairs (default on) */
   double ls_tolerance;
   int *body_parentid, *body_weldid, *body_rootid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum;
@@ -144,7 +145,7 @@ smjo_model* smjo_load(const void* blob, size_t nbytes) {
   ti = blob_i32(b, "sensor_imu_site", NULL); m->imu_site = ti[0]; free(ti);
   m->lidar_site = blob_i32(b, "sensor_lidar_site", &m->nlidar);
   m->lidar_static = blob_f64(b, "sensor_lidar_static", NULL);
-  m->warmstart = 1; m->pgs_fixed_iter = 0; m->max_con_pair = 4; m->solver = 0; m->ls_iterations = 50; m->ls_tolerance = 0.01; m->multiccd = 1;
+  m->warmstart = 1; m->pgs_fixed_iter = 0; m->max_con_pair = 4; m->qcqp_cap = 20; m->solver = 0; m->ls_iterations = 50; m->ls_tolerance = 0.01; m->multiccd = 1;
   LOADI(body_parentid); LOADI(body_weldid); LOADI(body_rootid); LOADI(body_jntadr); LOADI(body_jntnum);
   LOADI(body_dofadr); LOADI(body_dofnum);
   LOADF(body_pos); LOADF(body_quat); LOADF(body_ipos); LOADF(body_iquat); LOADF(body_mass); LOADF(body_inertia);
@@ -188,14 +189,13 @@ smjo_model* smjo_load(const void* blob, size_t nbytes) {
 
 void smjo_free_model(smjo_model* m) { free(m); /* arrays leak by design: test process lifetime */ }
 
-static int g_qcqp_cap = 20;   /* see qcqp() */
 
 int smjo_set_option(smjo_model* m, const char* name, double v) {
   if (!strcmp(name, "iterations")) m->iterations = (int)v;
   else if (!strcmp(name, "tolerance")) m->tolerance = v;
   else if (!strcmp(name, "warmstart")) m->warmstart = (int)v;
   else if (!strcmp(name, "pgs_fixed_iter")) m->pgs_fixed_iter = (int)v;
-  else if (!strcmp(name, "qcqp_cap")) g_qcqp_cap = (int)v;
+  else if (!strcmp(name, "qcqp_cap")) m->qcqp_cap = (int)v;   /* per model; 20 = MuJoCo */
   else if (!strcmp(name, "max_contacts_per_pair")) m->max_con_pair = (int)v;
   else if (!strcmp(name, "solver")) m->solver = (int)v; /* 0 = PGS (north_star), 2 = Newton (the reference model's default) */
   else if (!strcmp(name, "convex_pairs")) m->convex_pairs = (int)v;
@@ -1551,15 +1551,15 @@ static void fwd_actuation(const smjo_model* m, smjo_data* d) {
 }
 
 /* ------------------------------------------------------------------ B.7 solver (PGS, dual) */
-/* [MJ] mju_QCQP: Newton on the multiplier from la = 0, at most 20 iterates.  g_qcqp_cap (option "qcqp_cap", default 20 = MuJoCo)
+/* [MJ] mju_QCQP: Newton on the multiplier from la = 0, at most 20 iterates.  cap (model option "qcqp_cap", default 20 = MuJoCo)
  * lifts that cap for one purpose: tests of the HIP path's default QCQP, which finds the converged root (smj_step_impl.h qcqp). */
-static int qcqp(double* res, const double* Ain, const double* bin, const double* dd, double r, int n) {
+static int qcqp(double* res, const double* Ain, const double* bin, const double* dd, double r, int n, int cap) {
   double A[25], b[5], Ala[25], tmp[5], la = 0;
   for (int i = 0; i < n; i++) {
     b[i] = bin[i] * dd[i];
     for (int j = 0; j < n; j++) A[i * n + j] = Ain[i * n + j] * dd[i] * dd[j];
   }
-  for (int it = 0; it < g_qcqp_cap; it++) {
+  for (int it = 0; it < cap; it++) {
     memcpy(Ala, A, sizeof(double) * n * n);
     for (int i = 0; i < n; i++) Ala[i * n + i] += la;
     if (n == 2) { /* [MJ] mju_QCQP2: determinant test */
@@ -1704,7 +1704,7 @@ static void fwd_constraint(const smjo_model* m, smjo_data* d) {
         }
         if (f[i] < MINVAL) { for (int j = 1; j < dim; j++) f[i + j] = 0; }
         else {
-          int active = qcqp(v, Ac, bc, mu, f[i], n);
+          int active = qcqp(v, Ac, bc, mu, f[i], n, m->qcqp_cap);
           if (active) {
             double s = 0;
             for (int j = 0; j < n; j++) s += v[j] * v[j] / (mu[j] * mu[j]);

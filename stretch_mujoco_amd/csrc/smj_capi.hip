@@ -550,7 +550,6 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
   const DevModel& m = c->model;
   StagePlan in, out;
   const SmjStageLayout& Y = c->layout;
-  if (m.nsat > 0 && m.solver != 2) return fail(c, -6, "the satellite builds of the step kernel run the model's own solver (Newton) only: set solver = 2");
   in.add(st.qpos, m.nq_all, Y.qpos); in.add(st.qvel, m.nv_all, Y.qvel); in.add(st.warm, m.nv_all, Y.warm);
   in.add(st.ctrl, m.nu, Y.ctrl); in.add(st.bctl, SMJ_BC_ROWS, Y.bctl); in.add(st.nstep, 1, Y.nstep);
   in.add(st.info, 4, Y.info);

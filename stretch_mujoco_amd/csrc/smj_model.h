@@ -32,6 +32,9 @@
 #ifndef SMJ_SAT_EXT
 #define SMJ_SAT_EXT 4
 #endif
+#ifndef SMJ_SAT_PGS
+#define SMJ_SAT_PGS (SMJ_SAT_DENSE < 160 ? SMJ_SAT_DENSE : 160)   // rows of the PGS path's dense system (packed A in LDS)
+#endif
 #define NXS SMJ_SAT_EXT       // satellites that may be coupled to the main tree / to each other in one step (dense extension of the Newton system)
 static_assert(NDR % 16 == 0 && NDR <= NEFC, "dense rows: whole 16-row blocks (matT_J, MFMA k-steps)");
 #define NENT 5

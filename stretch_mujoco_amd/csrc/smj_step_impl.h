@@ -39,7 +39,11 @@ struct TreeTmp {  // lives in the A region until A is built
 };
 
 #define NEFP 64   // rows per register set of the PGS path (set p: rows 64 p .. 64 p + 63)
+#if NSAT > 0
+#define NEFC_P SMJ_SAT_PGS   // satellite builds: rows of the DENSE system of the PGS path (the rows that touch the main tree + the rows of coupled satellites, smj_sat_pgs.h)
+#else
 #define NEFC_P (NEFC > 160 ? 160 : NEFC)   // rows of the PGS path: every row of the variant up to 160 (the packed A of the 224-row build would not fit the CU's LDS)
+#endif
 #define NPS ((NEFC_P + 63) / 64)   // register sets of the PGS path
 struct Smem {
   float MM[NVS][MS];    // strict upper: M; lower + diag: working copy -> L (unit, strictly lower), D on diag
@@ -54,7 +58,13 @@ struct Smem {
   float epos[NEFC], emargin[NEFC], ediag[NEFC], efloss[NEFC], eR[NEFC], eK[NEFC], eBv[NEFC], eimp[NEFC], earef[NEFC],
       eb[NEFC], ef[NEFC];
   float cpos[NCON][3], cframe[NCON][9], cdist[NCON], cfric[NCON][5], csolref[NCON][2], csolimp[NCON][5], cmargin[NCON];
+#if NSAT > 0
+  int cdim[NCON], cefc[NCON];
+  unsigned short cgeom1[NCON], cgeom2[NCON];
+  int cpair[NCON];      // the contact's pair (index in the model's pair list): MuJoCo's contact order, which the PGS sweeps follow
+#else
   int cdim[NCON], cgeom1[NCON], cgeom2[NCON], cefc[NCON];
+#endif
   // The stage-local union comes LAST on purpose: the PGS path keeps its matrix A = J M^-1 J' + R there (packed lower triangle,
   // NEFC_P (NEFC_P + 1) / 2 floats, see A()).  In the standard variant the 80-row triangle (13 KB) ends inside the struct, so a PGS
   // launch needs no more LDS than a Newton launch (four workgroups per CU); the 160-row variants ask for the tail as dynamic
@@ -78,6 +88,9 @@ struct Smem {
       float mc_r[NCG];             // bounding radii of the cached geoms
 #endif
     } c;
+#if NSAT > 0
+    float pa[NEFC_P * (NEFC_P + 1) / 2];   // PGS: A of the dense system, packed lower triangle
+#endif
     struct {                // plane narrowphase staging: contacts of the pair owned by each lane, emitted in pair order
       int cnt[64], pair[64];
       float dist[64][4], pos[64][4][3], nrm[64][3];
@@ -1128,6 +1141,9 @@ struct StepKernel {
     s.csolref[c][0] = asf(r[SMJ_CP_SOLREF]); s.csolref[c][1] = asf(r[SMJ_CP_SOLREF + 1]);
     s.cmargin[c] = asf(r[SMJ_CP_MG]);
     s.cdim[c] = r[SMJ_CP_CONDIM]; s.cgeom1[c] = r[SMJ_CP_G1]; s.cgeom2[c] = r[SMJ_CP_G2]; s.cefc[c] = -1;
+#if NSAT > 0
+    s.cpair[c] = r[SMJ_CP_PAIR];
+#endif
   }
   SMJ_DEV void add_contact(const int* r, float dist, const float* pos, const float* n) {
     // uniform: every lane calls with identical arguments; lane 0 writes
@@ -1233,6 +1249,9 @@ struct StepKernel {
                 s.csolref[ci][0] = sr0; s.csolref[ci][1] = sr1;
                 s.cmargin[ci] = mg;
                 s.cdim[ci] = cd; s.cgeom1[ci] = g1; s.cgeom2[ci] = g2; s.cefc[ci] = -1;
+#if NSAT > 0
+                s.cpair[ci] = r[SMJ_PP_PAIR];
+#endif
               }
             }
           }
@@ -2884,8 +2903,13 @@ struct StepKernel {
       if (i >= 64 * p) v = wave_read(a[p], i & 63);
     return v;
   }
+#if NSAT > 0
+  template <bool WIDE>
+  SMJ_DEV float* Amat() { return s.u.pa; }
+#else
   template <bool WIDE>
   SMJ_DEV float* Amat() { return WIDE ? s.A(M.pgs_cap > 0 ? M.pgs_cap : NEFC_P) : &s.J[NEFP][0]; }
+#endif
   template <bool WIDE>
   SMJ_DEV static int ai(int r, int c) { return WIDE ? tri(r, c) : r * NEFP + c; }
   template <bool WIDE>
@@ -3133,15 +3157,21 @@ struct StepKernel {
   template <bool WIDE>
   SMJ_DEV void residual_refresh(const PL<float>* bb) {
     constexpr int NP = WIDE ? NPS : 1;
+#if NSAT > 0
+    const int ne = ndp;          // rows of the dense system; their forces are staged in s.epos (free once aref is known): s.ef is indexed by row
+    float* const fv = s.epos;
+#else
     const int ne = nefc;
+    float* const fv = s.ef;
+#endif
     const float* const A = Amat<WIDE>();
-    PSETS_ALL(p) LANES { if (lane + 64 * p < NEFC) s.ef[lane + 64 * p] = f_r[p][lane]; }
+    PSETS_ALL(p) LANES { if (lane + 64 * p < NEFC) fv[lane + 64 * p] = f_r[p][lane]; }
     SYNC();
     PSETS(p, ne) LANES {
       const int row = lane + 64 * p;
       float v = bb[p][lane];
       if (row < ne)
-        for (int k = 0; k < ne; k++) v += A[ai<WIDE>(k, row)] * s.ef[k];
+        for (int k = 0; k < ne; k++) v += A[ai<WIDE>(k, row)] * fv[k];
       r_r[p][lane] = v;
     }
     SYNC();
@@ -3156,7 +3186,11 @@ struct StepKernel {
   SMJ_DEV float pgs_block(int i, int c) {
     constexpr int NP = WIDE ? NPS : 1;
     constexpr int NF = DIM - 1;
+#if NSAT > 0
+    const int ne = ndp;
+#else
     const int ne = nefc;
+#endif
     const float* const A = Amat<WIDE>();
     float res[DIM], old[DIM], f[DIM], v1[DIM], mu[NF], Ac[NF * NF], a0[NF];
     PL<float[DIM]> arow[NP];  // rows i..i+DIM of A for the residual update, issued up front
@@ -3244,6 +3278,9 @@ struct StepKernel {
   }
 #undef PSETS
 #undef PSETS_ALL
+#if NSAT > 0
+#include "smj_sat_pgs.h"
+#endif
 
 
   // ------------------------------------------------------------------ B.7' Newton solver (primal)
@@ -4391,7 +4428,8 @@ struct StepKernel {
         return;
       }
 #if NSAT > 0
-      solve_newton(last, pc, t0, prof);   // (the satellite builds run the model's own solver only; smj_step refuses PGS for them)
+      if (M.solver == 2) solve_newton(last, pc, t0, prof);
+      else solve_pgs_sat(last, pc, t0, prof);   // islands: the dense system + one lane per uncoupled satellite (smj_sat_pgs.h)
       if (last && S.debug) {
         LANES {
           if (lane >= 32 && lane - 32 < M.nsat)

@@ -369,6 +369,27 @@ def test_pgs_qcqp_root_finder_agrees_with_mujocos_iteration():
         sim.stop()
 
 
+def test_pgs_default_qcqp_against_the_unmodified_oracle():
+    """The shipped default (qcqp_exact = 0) on the device against the oracle as MuJoCo has it (mju_QCQP from 0, cap 20, no option
+    touched): bench workload, 8 envs x 200 steps, the oracle's state uploaded before every step.  Stated bounds: relative one-step
+    acceleration error p50 < 3e-4, p99 < 1e-3, at most 1 % of the steps beyond 1e-2, none beyond 5e-2 (emulator twin:
+    tests/test_emul_parity.py, measured p50 1.0e-4 / p99 3.2e-4)."""
+    import rollout_common as rc
+    import stretch_mujoco_amd.model_blob as mb
+    from conftest import MODELS
+
+    with open(f"{MODELS}/stretch_empty.smjb", "rb") as f:
+        blob = f.read()
+    be = rc.HipBackend("stretch_empty", 8, solver=0)
+    rel, events = rc.state_synchronised(be, blob, mb.loads(blob), 8, 4, seed=7, solver=0)
+    flags = int(be.sim.info[3].max())
+    be.close()
+    print(f"\ndefault QCQP vs unmodified oracle: {len(rel)} env-steps, rel qacc p50 {np.percentile(rel, 50):.1e} p99 {np.percentile(rel, 99):.1e} max {rel.max():.1e}, events {len(events)}")
+    assert flags == 0
+    assert np.percentile(rel, 50) < 3e-4 and np.percentile(rel, 99) < 1e-3 and rel.max() < 5e-2
+    assert np.mean(rel > 1e-2) <= 0.01
+
+
 @pytest.mark.parametrize("B,solver", [(1024, "pgs"), (4096, "newton"), (32768, "newton")])
 def test_full_batch_properties(B, solver):
     """BASELINE.json sizes.  Size-independent properties: (1) envs are independent -- a permutation of the inputs
