@@ -96,6 +96,11 @@ int smj_base_controller_tick(smj_ctx* ctx, void* stream);
 /* Solver / collision options (mjOption fields): "iterations", "tolerance", "warmstart", "pgs_fixed_iter", "qcqp_exact" (PGS, default 0:
  * the friction QCQP of an elliptic contact finds mju_QCQP's root through the secular form, started at the contact's multiplier of
  * the previous sweep; 1: mju_QCQP's own iteration from 0, cap 20 -- the two differ where that cap is hit),
+ * "pgs_island_stop" (PGS on the satellite builds, default 1: a satellite's constraint island whose own scaled improvement fell below
+ * tolerance / 64 stops sweeping while the rest goes on; 0: every island sweeps until the whole system stops, as mj_solPGS without islands),
+ * "grad_noise" (Newton, default 4e-6: the loop also stops when every gradient component is below grad_noise * (|M a| + |qfrc| + |J' f|) of
+ * its dof -- the rounding of the gradient's own terms in fp32; 0 = MuJoCo's scale * |grad| < tolerance test only),
+ * "manifold_cache" (default on for models with free objects: a convex pair whose two bodies have not moved reuses its contacts),
  * "max_contacts_per_pair", "solver" (0 PGS, 2 Newton), "convex_pairs", "multiccd" (mjENBL_MULTICCD, stretch.xml:8; default on), "escalate" (default on: an env whose step needs more constraint rows / contacts
  * than the standard kernel variant holds is finished by the tall variant instead of being flagged), "balance" (default on:
  * workgroups are dispatched in the order of the envs' shader time in the previous dispatch, longest first), "chunk" (default 0 = one dispatch; k > 0:

@@ -1001,6 +1001,47 @@ static int sphere_sphere(const double* p1, double r1, const double* p2, double r
   return 1;
 }
 
+/* [MJ] mjc_SphereCapsule (engine_collision_primitive.c): the sphere against the sphere of the capsule's radius centred on the
+ * nearest point of the capsule's segment.  size = (radius, half length), axis = the frame's z. */
+static int sphere_capsule(const double* p1, double r1, const double* p2, const double* mat2, const double* size2, double margin, rawcon* rc) {
+  const double ax[3] = {mat2[2], mat2[5], mat2[8]}, vec[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+  double x = dot3(ax, vec);
+  x = fmax(-size2[1], fmin(size2[1], x));
+  const double q[3] = {p2[0] + ax[0] * x, p2[1] + ax[1] * x, p2[2] + ax[2] * x};
+  return sphere_sphere(p1, r1, q, size2[0], margin, rc);
+}
+/* [MJ] mjc_CapsuleCapsule: nearest points of the two segments (axes scaled by the half lengths, parameters in [-1, 1], the
+ * clamped one re-solved for the other), then sphere-sphere; PARALLEL axes (det < mjMINVAL): the two ends of capsule 1 against
+ * the segment of capsule 2, then -- while fewer than two contacts -- the two ends of capsule 2 against segment 1: up to 2 contacts. */
+static int capsule_capsule(const double* p1, const double* mat1, const double* size1, const double* p2, const double* mat2,
+                           const double* size2, double margin, rawcon* rc) {
+  const double a1[3] = {mat1[2] * size1[1], mat1[5] * size1[1], mat1[8] * size1[1]}, a2[3] = {mat2[2] * size2[1], mat2[5] * size2[1], mat2[8] * size2[1]};
+  const double dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+  const double ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2), u = -dot3(a1, dif), v = dot3(a2, dif), det = ma * mc - mb * mb;
+  double v1[3], v2[3];
+  if (fabs(det) >= MINVAL) {
+    double x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
+    if (x1 > 1) { x1 = 1; x2 = (v - mb) / mc; }
+    else if (x1 < -1) { x1 = -1; x2 = (v + mb) / mc; }
+    if (x2 > 1) { x2 = 1; x1 = fmax(-1, fmin(1, (u - mb) / ma)); }
+    else if (x2 < -1) { x2 = -1; x1 = fmax(-1, fmin(1, (u + mb) / ma)); }
+    for (int i = 0; i < 3; i++) { v1[i] = p1[i] + a1[i] * x1; v2[i] = p2[i] + a2[i] * x2; }
+    return sphere_sphere(v1, size1[0], v2, size2[0], margin, rc);
+  }
+  int n = 0;
+  for (int e = 0; e < 2; e++) {   /* x1 = +1, -1 */
+    const double sg = e ? -1 : 1, x2 = fmax(-1, fmin(1, (v - sg * mb) / mc));
+    for (int i = 0; i < 3; i++) { v1[i] = p1[i] + sg * a1[i]; v2[i] = p2[i] + a2[i] * x2; }
+    n += sphere_sphere(v1, size1[0], v2, size2[0], margin, rc + n);
+  }
+  for (int e = 0; e < 2 && n < 2; e++) {   /* x2 = +1, -1 */
+    const double sg = e ? -1 : 1, x1 = fmax(-1, fmin(1, (u - sg * mb) / ma));
+    for (int i = 0; i < 3; i++) { v1[i] = p1[i] + a1[i] * x1; v2[i] = p2[i] + sg * a2[i]; }
+    n += sphere_sphere(v1, size1[0], v2, size2[0], margin, rc + n);
+  }
+  return n;
+}
+
 /* ------------------------------------------------------------------ box-box, multi-point convex contacts
  * [MJ] mjc_BoxBox (engine_collision_box.c) and the multiccd branch of mjc_Convex (engine_collision_convex.c).  MuJoCo's
  * sources are not available here; what follows restates their published behaviour -- separating-axis test over the 15 axes,
@@ -1181,6 +1222,14 @@ static int convex_pair(const smjo_model* m, const smjo_data* d, int g1, int g2, 
       for (int i = 0; i < 3; i++) rc->normal[i] = -rc->normal[i]; /* the contact keeps the pair's geom order */
       return 1;
     }
+    if (t1 == G_SPHERE && t2 == G_CAPSULE) return sphere_capsule(x1, m->geom_size[3 * g1], x2, d->geom_xmat + 9 * g2, m->geom_size + 3 * g2, margin, rc);
+    if (t1 == G_CAPSULE && t2 == G_SPHERE) {
+      if (!sphere_capsule(x2, m->geom_size[3 * g2], x1, d->geom_xmat + 9 * g1, m->geom_size + 3 * g1, margin, rc)) return 0;
+      for (int i = 0; i < 3; i++) rc->normal[i] = -rc->normal[i];
+      return 1;
+    }
+    if (t1 == G_CAPSULE && t2 == G_CAPSULE)
+      return capsule_capsule(x1, d->geom_xmat + 9 * g1, m->geom_size + 3 * g1, x2, d->geom_xmat + 9 * g2, m->geom_size + 3 * g2, margin, rc);
     if (t1 == G_BOX && t2 == G_BOX && m->multiccd)
       return box_box(x1, d->geom_xmat + 9 * g1, m->geom_size + 3 * g1, x2, d->geom_xmat + 9 * g2, m->geom_size + 3 * g2, margin,
                      m->max_con_pair < 4 ? 4 : m->max_con_pair, rc);

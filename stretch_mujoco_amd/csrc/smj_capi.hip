@@ -39,6 +39,7 @@ struct smj_ctx {
   int* cost = nullptr;
   int* order = nullptr;
   int balance = 1;
+  int balance_min = 1;   // steps per launch from which the cost-ordered dispatch is used (round 4: 1 -- a one-step launch is as long as its slowest round of workgroups; was 4)
   int chunk = 0;               // steps per dispatch inside one smj_step (0: the whole launch at once; measured: no gain)
   int pipeline_big = 1;        // pipelined dispatch for the two-envs-per-CU builds of the big variant too (option "pipeline_big")
   int pipeline = 5;            // chunk length of the pipelined dispatch (DevState::pipe_len; 0 = one workgroup per env for the whole launch)
@@ -565,7 +566,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
   if (esc) {   // the escalation target runs with the same options
     DevModel& mb = c->model_esc;
     const DevModel& ms = c->model;
-    mb.iterations = ms.iterations; mb.warmstart = ms.warmstart; mb.pgs_fixed_iter = ms.pgs_fixed_iter; mb.qcqp_exact = ms.qcqp_exact; mb.max_con_pair = ms.max_con_pair;
+    mb.iterations = ms.iterations; mb.warmstart = ms.warmstart; mb.pgs_fixed_iter = ms.pgs_fixed_iter; mb.qcqp_exact = ms.qcqp_exact; mb.grad_noise = ms.grad_noise; mb.pgs_island_stop = ms.pgs_island_stop; mb.max_con_pair = ms.max_con_pair;
     mb.solver = ms.solver; mb.ls_iterations = ms.ls_iterations; mb.convex_pairs = ms.convex_pairs; mb.multiccd = ms.multiccd; mb.multi_serial = ms.multi_serial; mb.sep_cache = ms.sep_cache; mb.manifold_cache = ms.manifold_cache;
     mb.ls_tolerance = ms.ls_tolerance; mb.tolerance = ms.tolerance;
   }
@@ -611,7 +612,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
       }
       HIPCHK(c, hipMemsetAsync(c->redo, 0xff, sizeof(int) * (size_t)st.pipe_total, sm));   // -1 = entry not published yet
     }
-    if (c->balance && k >= 4 && c->num_envs > 1024) {   // a launch of one or two steps is not worth the sort
+    if (c->balance && k >= c->balance_min && c->num_envs > 1024) {
       smj_launch_order(c->cost, c->order, c->num_envs, sm);
       st.order = c->order;
     }
@@ -737,6 +738,8 @@ int smj_set_option(smj_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "warmstart")) m.warmstart = (int)v;
   else if (!strcmp(name, "pgs_fixed_iter")) m.pgs_fixed_iter = (int)v;
   else if (!strcmp(name, "qcqp_exact")) m.qcqp_exact = (int)v;
+  else if (!strcmp(name, "grad_noise")) m.grad_noise = (float)v;
+  else if (!strcmp(name, "pgs_island_stop")) m.pgs_island_stop = (int)v;
   else if (!strcmp(name, "max_contacts_per_pair")) m.max_con_pair = (int)v;
   else if (!strcmp(name, "solver")) m.solver = (int)v;
   else if (!strcmp(name, "convex_pairs")) m.convex_pairs = (int)v;
@@ -748,6 +751,7 @@ int smj_set_option(smj_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "primary_rows")) m.row_limit = (int)v;   // the escalation variant keeps its full capacity (model_esc is not touched)
   else if (!strcmp(name, "escalate")) c->escalate = (int)v;
   else if (!strcmp(name, "balance")) c->balance = (int)v;
+  else if (!strcmp(name, "balance_min")) c->balance_min = (int)v;
   else if (!strcmp(name, "chunk")) c->chunk = (int)v;
   else if (!strcmp(name, "pipeline")) c->pipeline = (int)v;
   else if (!strcmp(name, "pipeline_big")) c->pipeline_big = (int)v;

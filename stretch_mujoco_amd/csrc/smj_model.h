@@ -116,6 +116,8 @@ struct DevModel {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, neq, npair, nlevel, nfric, nlimit, nplanepair, nldl, nlidar, imu_site,
       ngc, nroot, nkey, ncgeom, nconvpair, njump, maxsubtree;
   int iterations, warmstart, pgs_fixed_iter, max_con_pair, solver /* 0 PGS, 2 Newton */, ls_iterations, convex_pairs;
+  float grad_noise;       // Newton: a gradient component below grad_noise * (|Ma| + |g| + |J'f|) is rounding (default 4e-6 = 64 ulp; 0 = MuJoCo's scale * |grad| < tolerance test only)
+  int pgs_island_stop;    // PGS, satellite builds: 1 (default) = a satellite island whose own scaled improvement fell below tolerance / 64 stops sweeping (smj_sat_pgs.h); 0 = every island sweeps until the whole system stops
   int qcqp_exact;   // PGS: 1 = the friction QCQP iterates exactly as mju_QCQP does (from la = 0 on |x|^2 - r^2, cap 20); 0 (default) = same root, secular form, started at the last sweep's multiplier
   int sep_cache;      // 1 = use DevState::sepcache (separating directions of convex pairs kept between steps)
   int manifold_cache; // 1 = use DevState::mcache (contact manifolds of convex pairs whose two bodies have not moved)

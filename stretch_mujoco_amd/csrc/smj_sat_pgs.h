@@ -500,14 +500,21 @@ SMJ_DEV void pgs_sat_core(PL<float>& u, bool dbg, float* pc, long long& t0, bool
     hi_r[p][lane] = t == CT_FRICTION ? fl : INFINITY;
   }
   LANES { qla_r[lane] = 0.f; }
+  PL<int> frozen;   // lane = satellite: its island has stopped sweeping (option pgs_island_stop)
+  LANES { frozen[lane] = 0; }
   const float scale = 1.0f / (M.meaninertia * (float)(M.nv_all > 1 ? M.nv_all : 1));
+  // An island sees no row of another, so its improvement falls on its own schedule; once it is below 1/64 of the tolerance the
+  // SUM over all islands is tested against, further sweeps of it cannot decide the test and move its forces by less than the
+  // solver's own tolerance: the island stops (its lane idles) while the dense system goes on.  An island whose updates are all
+  // rejected by the costChange guard (improvement exactly 0) would repeat itself anyway.
+  const float istop = M.pgs_island_stop ? M.tolerance * (1.f / 64) : -1.f;
   const int nD = ndp;
   int iter = 0;
   for (; iter < M.iterations; iter++) {
     float improvement = 0;
     if (iter > 0 && (iter & 7) == 0) {
       residual_refresh<WIDE>(bb);
-      LANES { const int si = lane - 32; if (lane >= 32 && si < nsat && s.sat.ext[si] < 0) sat_yf(si, zs[lane]); }
+      LANES { const int si = lane - 32; if (lane >= 32 && si < nsat && s.sat.ext[si] < 0 && !frozen[lane]) sat_yf(si, zs[lane]); }
     }
     ppc = prof ? pc : nullptr;
     long long tp = prof ? smj_clock() : 0;
@@ -553,7 +560,7 @@ SMJ_DEV void pgs_sat_core(PL<float>& u, bool dbg, float* pc, long long& t0, bool
     LANES {
       float im = 0;
       const int si = lane - 32;
-      if (lane >= 32 && si < nsat && s.sat.ext[si] < 0) {
+      if (lane >= 32 && si < nsat && s.sat.ext[si] < 0 && !frozen[lane]) {
         float* z = zs[lane];
         for (int it = 0; it < s.sat.nitem[si]; it++) {
           const int r0 = s.sat.irow[si][it], inf = s.sat.iinf[si][it], n = inf & ITEM_N;
@@ -581,6 +588,10 @@ SMJ_DEV void pgs_sat_core(PL<float>& u, bool dbg, float* pc, long long& t0, bool
         }
       }
       imp[lane] = im;
+#ifdef SMJ_EMUL
+      if (lane >= 32 && si < nsat && s.sat.ext[si] < 0 && s.sat.nitem[si] > 0) { smj_emul_isl_total++; smj_emul_isl_swept += !frozen[lane]; }
+#endif
+      if (im * scale < istop) frozen[lane] = 1;
     }
     improvement += wave_sum(imp);
     if (prof) { const long long t1 = smj_clock(); pc[SMJ_PROF_SAT_H] += (float)(t1 - tp); tp = t1; }

@@ -20,7 +20,6 @@
 #define JS (NVS + 1)
 #define MS (NVS + 1)
 #define SMJ_MINVAL 1e-15f
-#define SMJ_GRAD_NOISE 4e-6f   // Newton: a gradient component below 64 ulp of the terms it is the difference of is rounding (solve_newton)
 #define SMJ_MINIMP 0.0001f
 #define SMJ_MAXIMP 0.9999f
 
@@ -310,6 +309,7 @@ SMJ_DEV float impedance(const float* solimp, float pos, float margin) {
 static long smj_emul_sep_skips = 0;
 static long smj_emul_ext_steps = 0;
 static long smj_emul_mc_hits = 0;
+static long smj_emul_isl_total = 0, smj_emul_isl_swept = 0;   // PGS islands: satellite-lane sweeps with / without the island stop
 #endif
 // ---------------------------------------------------------------------------------------------- the step
 struct StepKernel {
@@ -1838,6 +1838,49 @@ struct StepKernel {
     for (int i = 0; i < 3; i++) { dir[i] = dif[i]; pos[i] = p1[i] + dif[i] * (r1 + 0.5f * dist_out); }
     return true;
   }
+  // [MJ] mjc_SphereCapsule: the sphere against the nearest point of the capsule's segment (size = radius, half length; axis = z)
+  SMJ_DEV bool sphere_capsule(const float* p1, float r1, const Shape& cp, float margin, float& dist_out, float* dir, float* pos) {
+    const float ax[3] = {cp.mat[2], cp.mat[5], cp.mat[8]}, vec[3] = {p1[0] - cp.pos[0], p1[1] - cp.pos[1], p1[2] - cp.pos[2]};
+    const float x = fmaxf(-cp.size[1], fminf(cp.size[1], dot3(ax, vec)));
+    const float q[3] = {cp.pos[0] + ax[0] * x, cp.pos[1] + ax[1] * x, cp.pos[2] + ax[2] * x};
+    return sphere_sphere(p1, r1, q, cp.size[0], margin, dist_out, dir, pos);
+  }
+  // [MJ] mjc_CapsuleCapsule: nearest points of the two segments, then sphere-sphere; parallel axes: segment ends against the
+  // other segment, up to two contacts.  fp32: MuJoCo's det = ma mc - mb^2 and the numerators mc u - mb v, ma v - mb u lose all
+  // their digits below an angle of 3e-4 rad between the axes; by Lagrange's identity they are |c|^2, c . (a2 x d) and
+  // c . (a1 x d) with c = a1 x a2 -- the same numbers without the cancellation, good down to 1e-6 rad (the "parallel" test
+  // here; MuJoCo's is an absolute 1e-15 on det).  Emits its contacts; uniform.
+  SMJ_DEV void capsule_capsule(const int* r, const Shape& A, const Shape& Bs, float margin) {
+    const float a1[3] = {A.mat[2] * A.size[1], A.mat[5] * A.size[1], A.mat[8] * A.size[1]};
+    const float a2[3] = {Bs.mat[2] * Bs.size[1], Bs.mat[5] * Bs.size[1], Bs.mat[8] * Bs.size[1]};
+    const float dif[3] = {A.pos[0] - Bs.pos[0], A.pos[1] - Bs.pos[1], A.pos[2] - Bs.pos[2]};
+    const float ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2), u = -dot3(a1, dif), v = dot3(a2, dif);
+    float c[3], c1[3], c2[3];
+    cross3(c, a1, a2); cross3(c2, a2, dif); cross3(c1, a1, dif);
+    const float det = dot3(c, c);
+    float v1[3], v2[3], depth, dir[3], pos[3];
+    if (det >= 1e-12f * ma * mc) {
+      float x1 = dot3(c, c2) / det, x2 = dot3(c, c1) / det;
+      if (x1 > 1) { x1 = 1; x2 = (v - mb) / mc; }
+      else if (x1 < -1) { x1 = -1; x2 = (v + mb) / mc; }
+      if (x2 > 1) { x2 = 1; x1 = fmaxf(-1.f, fminf(1.f, (u - mb) / ma)); }
+      else if (x2 < -1) { x2 = -1; x1 = fmaxf(-1.f, fminf(1.f, (u + mb) / ma)); }
+      for (int i = 0; i < 3; i++) { v1[i] = A.pos[i] + a1[i] * x1; v2[i] = Bs.pos[i] + a2[i] * x2; }
+      if (sphere_sphere(v1, A.size[0], v2, Bs.size[0], margin, depth, dir, pos)) add_contact(r, depth, pos, dir);
+      return;
+    }
+    int n = 0;
+    for (int e = 0; e < 2; e++) {
+      const float sg = e ? -1.f : 1.f, x2 = fmaxf(-1.f, fminf(1.f, (v - sg * mb) / mc));
+      for (int i = 0; i < 3; i++) { v1[i] = A.pos[i] + sg * a1[i]; v2[i] = Bs.pos[i] + a2[i] * x2; }
+      if (sphere_sphere(v1, A.size[0], v2, Bs.size[0], margin, depth, dir, pos)) { add_contact(r, depth, pos, dir); n++; }
+    }
+    for (int e = 0; e < 2 && n < 2; e++) {
+      const float sg = e ? -1.f : 1.f, x1 = fmaxf(-1.f, fminf(1.f, (u - sg * mb) / ma));
+      for (int i = 0; i < 3; i++) { v1[i] = A.pos[i] + a1[i] * x1; v2[i] = Bs.pos[i] + sg * a2[i]; }
+      if (sphere_sphere(v1, A.size[0], v2, Bs.size[0], margin, depth, dir, pos)) { add_contact(r, depth, pos, dir); n++; }
+    }
+  }
   SMJ_DEV void load_shape(Shape& sh, int g, int slot, float* cen) {
     (void)g;
     const unsigned meta = (unsigned)uni(s.u.c.meta[slot]);
@@ -2461,6 +2504,18 @@ struct StepKernel {
       }
       return;
     }
+    if (A.type == GT_SPHERE && Bs.type == GT_CAPSULE) {
+      if (sphere_capsule(A.pos, A.size[0], Bs, margin, depth, dir, pos)) add_contact(r, depth, pos, dir);
+      return;
+    }
+    if (A.type == GT_CAPSULE && Bs.type == GT_SPHERE) {
+      if (sphere_capsule(Bs.pos, Bs.size[0], A, margin, depth, dir, pos)) {
+        for (int k = 0; k < 3; k++) dir[k] = -dir[k];
+        add_contact(r, depth, pos, dir);
+      }
+      return;
+    }
+    if (A.type == GT_CAPSULE && Bs.type == GT_CAPSULE) { capsule_capsule(r, A, Bs, margin); return; }
     if (A.type == GT_BOX && Bs.type == GT_BOX && M.multiccd) {
       const long long tb = prof ? smj_clock() : 0;
       box_box(r, s1, s2, margin);
@@ -3850,7 +3905,7 @@ struct StepKernel {
       PL<int> gsig;
       LANES {
         grad[lane] = lane < nv ? Ma[lane] - g_r[lane] - tmpv[lane] : 0.f; g2[lane] = grad[lane] * grad[lane];
-        gsig[lane] = fabsf(grad[lane]) > SMJ_GRAD_NOISE * (fabsf(Ma[lane]) + fabsf(g_r[lane]) + fabsf(tmpv[lane]));
+        gsig[lane] = fabsf(grad[lane]) > M.grad_noise * (fabsf(Ma[lane]) + fabsf(g_r[lane]) + fabsf(tmpv[lane]));
 #if NSAT > 0
         if (lane >= 32 && lane - 32 < M.nsat) {
           const int si = lane - 32;
@@ -3858,7 +3913,7 @@ struct StepKernel {
             const float ma = s.sat.x[SX_MA][si][k], gg = s.sat.x[SX_G][si][k], jf = s.sat.x[SX_TMP][si][k], gr = k < s.sat.ndof[si] ? ma - gg - jf : 0.f;
             s.sat.x[SX_GRAD][si][k] = gr;
             g2[lane] += gr * gr;
-            gsig[lane] |= fabsf(gr) > SMJ_GRAD_NOISE * (fabsf(ma) + fabsf(gg) + fabsf(jf));
+            gsig[lane] |= fabsf(gr) > M.grad_noise * (fabsf(ma) + fabsf(gg) + fabsf(jf));
           }
         }
 #endif

@@ -383,20 +383,18 @@ class _Body:
         self.id = -1
 
 
-_ANGLE_SCALE = [1.0]   # radians per angle unit of the document being parsed ([MJ] <compiler angle>: global, default degree)
-_EULER_SEQ = ["xyz"]
-
-
-def _orient(attrib: Dict[str, str]) -> np.ndarray:
+def _orient(attrib: Dict[str, str], angle_scale: float, eulerseq: str) -> np.ndarray:
+    """Orientation attributes of a body / geom / site / camera / inertial.  `angle_scale` = radians per angle unit of the document
+    ([MJ] <compiler angle>, default degree), `eulerseq` its <compiler eulerseq>: the compiler instance's, passed in (no module state)."""
     if "quat" in attrib:
         return quat_norm(_floats(attrib["quat"]))
     if "euler" in attrib:
-        return euler2quat([a * _ANGLE_SCALE[0] for a in _floats(attrib["euler"])], _EULER_SEQ[0])
+        return euler2quat([a * angle_scale for a in _floats(attrib["euler"])], eulerseq)
     if "zaxis" in attrib:
         return zaxis2quat(_floats(attrib["zaxis"]))
     if "axisangle" in attrib:
         v = _floats(attrib["axisangle"])
-        return axisangle2quat(v[:3], v[3] * _ANGLE_SCALE[0])
+        return axisangle2quat(v[:3], v[3] * angle_scale)
     if "xyaxes" in attrib:
         v = np.array(_floats(attrib["xyaxes"]))
         x = v[:3] / np.linalg.norm(v[:3])
@@ -478,7 +476,6 @@ class MjcfCompiler:
             for ch in part:
                 if ch.tag == "default":
                     self.defaults.parse(ch)
-        _ANGLE_SCALE[0], _EULER_SEQ[0] = self.angle_scale, self.eulerseq
         for part, d in parts:
             for ch in part:
                 if ch.tag == "asset":
@@ -561,7 +558,7 @@ class MjcfCompiler:
 
         def place(attrib):
             p = np.array(_floats(attrib.get("pos", "0 0 0")))
-            q = _orient(attrib)
+            q = _orient(attrib, self.angle_scale, self.eulerseq)
             return fpos + quat2mat(fquat) @ p, quat_norm(quat_mul(fquat, q))
 
         for ch in elem:
@@ -591,7 +588,9 @@ class MjcfCompiler:
                     if a["type"] in ("capsule", "cylinder"):
                         a["size"] = f"{sz[0]} {half} 0"
                     else:
-                        a["size"] = f"{sz[0]} {sz[1] if len(sz) > 1 else sz[0]} {half}"
+                        if len(sz) < 2:   # [MJ] a box / ellipsoid given by fromto needs its two cross-section half sizes
+                            raise ValueError(f"geom '{a.get('name', '?')}': fromto {a['type']} needs two size values (x and y half sizes), got {len(sz)}")
+                        a["size"] = f"{sz[0]} {sz[1]} {half}"
                     a = {k: v for k, v in a.items() if k not in ("quat", "euler", "axisangle", "xyaxes")}
                     a["pos"] = " ".join(repr(float(x)) for x in 0.5 * (ft[0:3] + ft[3:6]))
                     a["zaxis"] = " ".join(repr(float(x)) for x in vec)
@@ -613,7 +612,7 @@ class MjcfCompiler:
                 body.cams.append(a)
             elif ch.tag == "replicate":
                 count = int(ch.get("count"))
-                dq = _orient(ch.attrib)
+                dq = _orient(ch.attrib, self.angle_scale, self.eulerseq)
                 dp = np.array(_floats(ch.get("offset", "0 0 0")))
                 width = len(str(count - 1))
                 p, q = fpos.copy(), fquat.copy()
@@ -624,7 +623,7 @@ class MjcfCompiler:
                     q = quat_norm(quat_mul(q, dq))
             elif ch.tag == "inertial":
                 # [MJ] explicit body inertia: replaces what the geoms would give (compiler inertiafromgeom="auto")
-                body.inertial = dict(pos=np.array(_floats(ch.get("pos", "0 0 0"))), quat=_orient(ch.attrib), mass=float(ch.get("mass")),
+                body.inertial = dict(pos=np.array(_floats(ch.get("pos", "0 0 0"))), quat=_orient(ch.attrib, self.angle_scale, self.eulerseq), mass=float(ch.get("mass")),
                                      diag=_floats(ch.get("diaginertia")) if "diaginertia" in ch.attrib else None,
                                      full=_floats(ch.get("fullinertia")) if "fullinertia" in ch.attrib else None)
             elif ch.tag == "light":

@@ -92,6 +92,8 @@ int emul_set_option(emul_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "warmstart")) m.warmstart = (int)v;
   else if (!strcmp(name, "pgs_fixed_iter")) m.pgs_fixed_iter = (int)v;
   else if (!strcmp(name, "qcqp_exact")) m.qcqp_exact = (int)v;
+  else if (!strcmp(name, "grad_noise")) m.grad_noise = (float)v;
+  else if (!strcmp(name, "pgs_island_stop")) m.pgs_island_stop = (int)v;
   else if (!strcmp(name, "pgs_cap")) m.pgs_cap = (int)v;   // what smj_step sets for a PGS launch without dynamic LDS (smj_step_tu.h)
   else if (!strcmp(name, "max_contacts_per_pair")) m.max_con_pair = (int)v;
   else if (!strcmp(name, "solver")) m.solver = (int)v;
@@ -107,6 +109,8 @@ int emul_set_option(emul_ctx* c, const char* name, double v) {
 long emul_sep_skips() { return smj_emul_sep_skips; }
 long emul_ext_steps() { return smj_emul_ext_steps; }
 long emul_mc_hits() { return smj_emul_mc_hits; }
+long emul_isl_total() { return smj_emul_isl_total; }
+long emul_isl_swept() { return smj_emul_isl_swept; }
 int emul_poison = -1;
 void emul_set_poison(int byte) { emul_poison = byte; }
 int emul_step(emul_ctx* c, int nsteps, unsigned read_flags) {
