@@ -39,6 +39,7 @@ struct smj_ctx {
   int* cost = nullptr;
   int* order = nullptr;
   int balance = 1;
+  int pgs_two_waves = 1;   // PGS on the 16-satellite build: 1 = the two-wavefront kernel (smj_kernels_satp.hip), 0 = one wavefront per env
   int balance_min = 1;   // steps per launch from which the cost-ordered dispatch is used (round 4: 1 -- a one-step launch is as long as its slowest round of workgroups; was 4)
   int chunk = 0;               // steps per dispatch inside one smj_step (0: the whole launch at once; measured: no gain)
   int pipeline_big = 1;        // pipelined dispatch for the two-envs-per-CU builds of the big variant too (option "pipeline_big")
@@ -610,7 +611,8 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
         c->redo = (int*)d;
         st.redo = c->redo;
       }
-      HIPCHK(c, hipMemsetAsync(c->redo, 0xff, sizeof(int) * (size_t)st.pipe_total, sm));   // -1 = entry not published yet
+      // -1 = entry not published yet: only the pollers read entries while the list grows (the sweep runs after the kernel, the count is final)
+      if (pipe && c->pollers > 0) HIPCHK(c, hipMemsetAsync(c->redo, 0xff, sizeof(int) * (size_t)st.pipe_total, sm));
     }
     if (c->balance && k >= c->balance_min && c->num_envs > 1024) {
       smj_launch_order(c->cost, c->order, c->num_envs, sm);
@@ -636,7 +638,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
     }
     if (!lrc)
       lrc = c->variant == 6   ? smj_launch_step_sat32(c->model, st, k, fl, sm)
-            : c->variant == 5 ? smj_launch_step_sat(c->model, st, k, fl, sm)
+            : c->variant == 5 ? ((c->model.solver != 2 && c->pgs_two_waves && !st.prof) ? smj_launch_step_satp(c->model, st, k, fl, sm) : smj_launch_step_sat(c->model, st, k, fl, sm))
             : c->variant == 4 ? smj_launch_step_big(c->model, st, k, fl, sm)
             : c->variant == 3 ? smj_launch_step_big50(c->model, st, k, fl, sm)
             : c->variant == 2 ? smj_launch_step_big38(c->model, st, k, fl, sm)
@@ -752,6 +754,7 @@ int smj_set_option(smj_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "escalate")) c->escalate = (int)v;
   else if (!strcmp(name, "balance")) c->balance = (int)v;
   else if (!strcmp(name, "balance_min")) c->balance_min = (int)v;
+  else if (!strcmp(name, "pgs_two_waves")) c->pgs_two_waves = (int)v;
   else if (!strcmp(name, "chunk")) c->chunk = (int)v;
   else if (!strcmp(name, "pipeline")) c->pipeline = (int)v;
   else if (!strcmp(name, "pipeline_big")) c->pipeline_big = (int)v;

@@ -28,6 +28,7 @@ int smj_launch_step_mid(const DevModel& m, const DevState& s, int nsteps, unsign
 int smj_launch_step_big(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);     // 64 dof columns
 int smj_launch_step_big38(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);   // 38
 int smj_launch_step_big50(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);   // 50
+int smj_launch_step_satp(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);    // the same build with two wavefronts per env: PGS, satellite islands beside the dense system (smj_kernels_satp.hip)
 int smj_launch_step_sat(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);     // main tree + satellites (smj_sat.h)
 int smj_launch_step_sat32(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);   // up to 32 satellites, one env per CU
 void smj_sat_caps(int* nvp, int* nbp, int* nent, int* nefc, int* ncon, int* debug_floats, int* nsat);

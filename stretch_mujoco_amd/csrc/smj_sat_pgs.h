@@ -151,6 +151,82 @@ SMJ_DEV void sat_yf(int si, float* z) const {
   }
 }
 
+// One sweep of the satellite islands, each by its own lane (lane = 32 + satellite); returns the sum of their improvements.
+// zs: z = sum y_i f_i of the lane's island (refreshed from the forces every 8th sweep), frozen: islands that have stopped.
+SMJ_DEV float sat_lanes_sweep(PL<float[6]>& zs, PL<int>& frozen, int iter, float scale, float istop) {
+  const int nsat = M.nsat;
+  if (iter > 0 && (iter & 7) == 0) {
+    LANES { const int si = lane - 32; if (lane >= 32 && si < nsat && s.sat.ext[si] < 0 && !frozen[lane]) sat_yf(si, zs[lane]); }
+  }
+    PL<float> imp;
+  LANES {
+    float im = 0;
+    const int si = lane - 32;
+    if (lane >= 32 && si < nsat && s.sat.ext[si] < 0 && !frozen[lane]) {
+      float* z = zs[lane];
+      for (int it = 0; it < s.sat.nitem[si]; it++) {
+        const int r0 = s.sat.irow[si][it], inf = s.sat.iinf[si][it], n = inf & ITEM_N;
+        if ((inf & ITEM_CONTACT) && n >= 3) {
+          const int c = s.sat.icon[si][it];
+          if (n == 3) im += pgs_block_lane<3>(r0, c, z);
+          else if (n == 4) im += pgs_block_lane<4>(r0, c, z);
+          else im += pgs_block_lane<6>(r0, c, z);
+        } else {
+          const float* y = s.sat.Js[r0];
+          const int t = s.etype[r0];
+          const float R = s.eR[r0], old = s.ef[r0], fl = s.efloss[r0];
+          float a = 0, aii = R;
+          for (int k = 0; k < 6; k++) { a += y[k] * z[k]; aii += y[k] * y[k]; }
+          const float res = a + R * old + s.eb[r0];
+          const float lo = t == CT_EQUALITY ? -INFINITY : t == CT_FRICTION ? -fl : 0.f, hi = t == CT_FRICTION ? fl : INFINITY;
+          const float fn = fminf(hi, fmaxf(lo, old - res * fast_rcp(aii)));
+          float delta = fn - old;
+          float change = delta * (0.5f * aii * delta + res);
+          if (change > 1e-10f) { delta = 0; change = 0; }
+          im -= change;
+          s.ef[r0] = old + delta;
+          for (int k = 0; k < 6; k++) z[k] += y[k] * delta;
+        }
+      }
+    }
+    imp[lane] = im;
+#ifdef SMJ_EMUL
+    if (lane >= 32 && si < nsat && s.sat.ext[si] < 0 && s.sat.nitem[si] > 0) { smj_emul_isl_total++; smj_emul_isl_swept += !frozen[lane]; }
+#endif
+    if (im * scale < istop) frozen[lane] = 1;
+  }
+  return wave_sum(imp);
+}
+
+#ifdef SMJ_TWO_WAVES
+// The second wavefront of the env (smj_kernels_satp.hip): waits for the first one to reach the sweeps of a step, sweeps the
+// satellite islands beside its dense sweeps -- one barrier per sweep, where the two exchange their improvements and take the same
+// decision --, and leaves when the first wavefront is through with the launch.  Mailbox: SatMem::x[SX_MV][0] (Newton only):
+// [0..3] improvements (sweep parity x wavefront), [4] command; z of the islands comes over in x[SX_SRCH].
+enum { PGS2_RUN = 1, PGS2_EXIT = 2 };
+SMJ_DEV void pgs_helper() {
+  for (;;) {
+    WG_BARRIER();
+    if (uni(__builtin_bit_cast(int, s.sat.x[SX_MV][0][4])) != PGS2_RUN) return;
+    PL<float[6]> zs;
+    PL<int> frozen;
+    LANES {
+      frozen[lane] = 0;
+      for (int k = 0; k < 6; k++) zs[lane][k] = (lane >= 32 && lane - 32 < M.nsat) ? s.sat.x[SX_SRCH][lane - 32][k] : 0.f;
+    }
+    const float scale = 1.0f / (M.meaninertia * (float)(M.nv_all > 1 ? M.nv_all : 1));
+    const float istop = M.pgs_island_stop ? M.tolerance * (1.f / 64) : -1.f;
+    for (int iter = 0; iter < M.iterations; iter++) {
+      const float mine = sat_lanes_sweep(zs, frozen, iter, scale, istop);
+      LANES { if (lane == 0) s.sat.x[SX_MV][0][2 * (iter & 1) + 1] = mine; }
+      WG_BARRIER();
+      const float improvement = (uni(s.sat.x[SX_MV][0][2 * (iter & 1)]) + mine) * scale;
+      if (!M.pgs_fixed_iter && improvement < M.tolerance) break;
+    }
+  }
+}
+#endif
+
 #define PSETS(p, ne) _Pragma("unroll") for (int p = 0; p < NP; p++) if (p == 0 || (ne) > 64 * p)
 #define PSETS_ALL(p) _Pragma("unroll") for (int p = 0; p < NP; p++)
 SMJ_DEV void solve_pgs_sat(bool dbg, float* pc, long long& t0, bool prof) {
@@ -509,12 +585,18 @@ SMJ_DEV void pgs_sat_core(PL<float>& u, bool dbg, float* pc, long long& t0, bool
   // rejected by the costChange guard (improvement exactly 0) would repeat itself anyway.
   const float istop = M.pgs_island_stop ? M.tolerance * (1.f / 64) : -1.f;
   const int nD = ndp;
+#ifdef SMJ_TWO_WAVES
+  LANES {
+    if (lane >= 32 && lane - 32 < nsat) for (int k = 0; k < 6; k++) s.sat.x[SX_SRCH][lane - 32][k] = zs[lane][k];
+    if (lane == 0) s.sat.x[SX_MV][0][4] = __builtin_bit_cast(float, (int)PGS2_RUN);
+  }
+  WG_BARRIER();   // the second wavefront starts its sweeps
+#endif
   int iter = 0;
   for (; iter < M.iterations; iter++) {
     float improvement = 0;
     if (iter > 0 && (iter & 7) == 0) {
       residual_refresh<WIDE>(bb);
-      LANES { const int si = lane - 32; if (lane >= 32 && si < nsat && s.sat.ext[si] < 0 && !frozen[lane]) sat_yf(si, zs[lane]); }
     }
     ppc = prof ? pc : nullptr;
     long long tp = prof ? smj_clock() : 0;
@@ -555,45 +637,14 @@ SMJ_DEV void pgs_sat_core(PL<float>& u, bool dbg, float* pc, long long& t0, bool
         if (prof) { const long long t1 = smj_clock(); pc[SMJ_PROF_N_GRAD] += (float)(t1 - tp); tp = t1; pc[SMJ_PROF_N_SOLVE] += 1.f; }
       }
     }
-    // the satellite islands, each by its own lane
-    PL<float> imp;
-    LANES {
-      float im = 0;
-      const int si = lane - 32;
-      if (lane >= 32 && si < nsat && s.sat.ext[si] < 0 && !frozen[lane]) {
-        float* z = zs[lane];
-        for (int it = 0; it < s.sat.nitem[si]; it++) {
-          const int r0 = s.sat.irow[si][it], inf = s.sat.iinf[si][it], n = inf & ITEM_N;
-          if ((inf & ITEM_CONTACT) && n >= 3) {
-            const int c = s.sat.icon[si][it];
-            if (n == 3) im += pgs_block_lane<3>(r0, c, z);
-            else if (n == 4) im += pgs_block_lane<4>(r0, c, z);
-            else im += pgs_block_lane<6>(r0, c, z);
-          } else {
-            const float* y = s.sat.Js[r0];
-            const int t = s.etype[r0];
-            const float R = s.eR[r0], old = s.ef[r0], fl = s.efloss[r0];
-            float a = 0, aii = R;
-            for (int k = 0; k < 6; k++) { a += y[k] * z[k]; aii += y[k] * y[k]; }
-            const float res = a + R * old + s.eb[r0];
-            const float lo = t == CT_EQUALITY ? -INFINITY : t == CT_FRICTION ? -fl : 0.f, hi = t == CT_FRICTION ? fl : INFINITY;
-            const float fn = fminf(hi, fmaxf(lo, old - res * fast_rcp(aii)));
-            float delta = fn - old;
-            float change = delta * (0.5f * aii * delta + res);
-            if (change > 1e-10f) { delta = 0; change = 0; }
-            im -= change;
-            s.ef[r0] = old + delta;
-            for (int k = 0; k < 6; k++) z[k] += y[k] * delta;
-          }
-        }
-      }
-      imp[lane] = im;
-#ifdef SMJ_EMUL
-      if (lane >= 32 && si < nsat && s.sat.ext[si] < 0 && s.sat.nitem[si] > 0) { smj_emul_isl_total++; smj_emul_isl_swept += !frozen[lane]; }
+#ifdef SMJ_TWO_WAVES
+    // the satellite islands are swept by the env's second wavefront meanwhile (pgs_helper): exchange the improvements
+    LANES { if (lane == 0) s.sat.x[SX_MV][0][2 * (iter & 1)] = improvement; }
+    WG_BARRIER();
+    improvement += uni(s.sat.x[SX_MV][0][2 * (iter & 1) + 1]);
+#else
+    improvement += sat_lanes_sweep(zs, frozen, iter, scale, istop);   // the satellite islands, each by its own lane
 #endif
-      if (im * scale < istop) frozen[lane] = 1;
-    }
-    improvement += wave_sum(imp);
     if (prof) { const long long t1 = smj_clock(); pc[SMJ_PROF_SAT_H] += (float)(t1 - tp); tp = t1; }
     improvement *= scale;
     if (!M.pgs_fixed_iter && improvement < M.tolerance) { iter++; break; }

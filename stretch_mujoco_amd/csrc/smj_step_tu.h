@@ -87,10 +87,22 @@ static __device__ __forceinline__ SmjTicket smj_take_ticket(const DevState& S, i
 #endif
 // The primary kernel of a variant: workgroup = one env (or one chunk of one env), no loop around run() -- a loop at this level
 // keeps the whole step pipeline's live ranges alive across its back edge and costs hundreds of bytes of scratch per lane.
-__global__ __launch_bounds__(64) SMJ_KERNEL_ATTR void SMJ_STEP_KERNEL(const DevModel M, const DevState S, int nsteps, unsigned read_flags) {
+#ifdef SMJ_TWO_WAVES
+#define SMJ_WG_THREADS 128
+#else
+#define SMJ_WG_THREADS 64
+#endif
+__global__ __launch_bounds__(SMJ_WG_THREADS) SMJ_KERNEL_ATTR void SMJ_STEP_KERNEL(const DevModel M, const DevState S, int nsteps, unsigned read_flags) {
   // dynamic LDS: a Newton launch asks for sizeof(Smem), a PGS launch for the extra tail that holds A (smj_lds_bytes)
   extern __shared__ __align__(16) unsigned char smj_lds[];
   Smem& smem = *reinterpret_cast<Smem*>(smj_lds);
+#ifdef SMJ_TWO_WAVES
+  if (threadIdx.x >= 64) {   // the env's second wavefront: the satellite islands' PGS sweeps (smj_sat_pgs.h pgs_helper), nothing else
+    StepKernel h(M, S, smem, 0);
+    h.pgs_helper();
+    return;
+  }
+#endif
   const SmjTicket t = smj_take_ticket(S, nsteps, read_flags);
   if (t.go) {
     StepKernel k(M, S, smem, t.env);
@@ -103,6 +115,10 @@ __global__ __launch_bounds__(64) SMJ_KERNEL_ATTR void SMJ_STEP_KERNEL(const DevM
     }
   }
   if (S.sched && threadIdx.x == 0) atomicAdd(&S.sched[SMJ_SCHED_EXITED], 1);
+#ifdef SMJ_TWO_WAVES
+  if (threadIdx.x == 0) smem.sat.x[SX_MV][0][4] = __builtin_bit_cast(float, (int)StepKernel::PGS2_EXIT);   // release the second wavefront (every path of the first one ends here)
+  WG_BARRIER();
+#endif
 }
 
 #if defined(SMJ_WORKER_KERNEL)
@@ -199,14 +215,14 @@ int SMJ_LAUNCH_STEP(const DevModel& m_in, const DevState& s, int nsteps, unsigne
   }
 #if defined(SMJ_WORKER_KERNEL)
   if (s.redo_worker) {
-    const unsigned wg = s.redo_worker == 2 ? (unsigned)(s.pollers < 0 ? -s.pollers : s.pollers) : (unsigned)(s.B < 512 ? s.B : 512);   // sweep: two envs per CU fit (one under PGS); surplus workgroups find the list drained and leave
+    const unsigned wg = s.redo_worker == 2 ? (unsigned)(s.pollers < 0 ? -s.pollers : s.pollers) : (unsigned)(nsteps <= 2 ? (s.B < 64 ? s.B : 64) : s.B < 512 ? s.B : 512);   // sweep: two envs per CU fit (one under PGS); surplus workgroups find the list drained and leave (a one-step launch: 64 -- the empty sweep is pure launch cost there)
     hipLaunchKernelGGL(SMJ_WORKER_KERNEL, dim3(wg), dim3(64), lds, stream, m, s, nsteps, read_flags);
     return 0;
   }
 #endif
   unsigned grid = s.B;
   if (s.pipe_len) grid = (unsigned)s.B * (unsigned)((nsteps + s.pipe_len - 1) / s.pipe_len);
-  hipLaunchKernelGGL(SMJ_STEP_KERNEL, dim3(grid), dim3(64), lds, stream, m, s, nsteps, read_flags);
+  hipLaunchKernelGGL(SMJ_STEP_KERNEL, dim3(grid), dim3(SMJ_WG_THREADS), lds, stream, m, s, nsteps, read_flags);
   return 0;
 }
 

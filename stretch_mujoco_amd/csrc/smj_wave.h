@@ -81,8 +81,18 @@ static inline int lds_atomic_add(int* p, int n) { const int v = *p; *p = v + n; 
 #include <hip/hip_runtime.h>
 #define SMJ_DEV __device__ __forceinline__
 // a region is a one-trip scope that names the lane id
+#ifdef SMJ_TWO_WAVES
+// Two wavefronts per env (smj_kernels_satp.hip: the PGS kernel of the satellite build -- wavefront 0 runs the step, wavefront 1
+// sweeps the satellite islands beside the dense system's sweeps): `lane` is the lane inside the wavefront, SYNC() orders the LDS
+// accesses of ONE wavefront (its DS operations execute in order; the fence keeps the compiler from moving them), and the two
+// wavefronts meet at WG_BARRIER() only.
+#define LANES for (int lane = (int)(threadIdx.x & 63u), _k = 0; _k < 1; ++_k)
+#define SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define WG_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+#else
 #define LANES for (int lane = (int)threadIdx.x, _k = 0; _k < 1; ++_k)
 #define SYNC() __syncthreads()
+#endif
 template <class T>
 struct PL {
   T v;

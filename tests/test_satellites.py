@@ -268,6 +268,52 @@ def test_gpu_pgs_satellite_build_state_synchronised(scene):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["stretch_kitchen4_sat", "stretch_kitchen_robocasa"])
+def test_gpu_pgs_two_wavefronts_per_env_agree_with_one(scene):
+    """The PGS kernel of the 16-satellite build runs TWO wavefronts per env (smj_kernels_satp.hip): the second one sweeps the
+    satellite islands beside the first one's sweeps of the dense system, one workgroup barrier per sweep.  Same algorithm, same
+    order of operations as the one-wavefront kernel (option pgs_two_waves = 0) in another translation unit: 256 envs, random
+    actions, the one-wavefront sim re-synchronised to the two-wavefront one before every compared step -- same row / contact /
+    sweep counts, one-step velocities to fp32 rounding (the compiler contracts multiply-adds differently in the two builds; 100
+    sweeps carry that to ~1e-8 relative, 1e-6 on a step whose contact manifold comes from the cache in one sim only)."""
+    import torch
+    from stretch_mujoco_amd import StretchBatchSimulator
+
+    B = 256
+    sims = []
+    for two in (1, 0):
+        sim = StretchBatchSimulator(num_envs=B, device="cuda:0", scene=scene, solver="pgs")
+        sim.start(home=False)
+        sim.set_option("pgs_two_waves", two)
+        sim.home(settle=False)
+        sims.append(sim)
+    a, b = sims
+    a.step(50)
+    b.step(1)   # (the first step after home() applies the pending keyframe: out of the way before states are copied in)
+    cr = torch.tensor(np.asarray(a.model["actuator_ctrlrange"]), dtype=torch.float32, device=a.device)
+    g = torch.Generator(device=a.device); g.manual_seed(11)
+    rel, same_counts = [], []
+    for w in range(3):
+        a.ctrl[:] = cr[:, :1] + (cr[:, 1:] - cr[:, :1]) * torch.rand(a.nu, B, generator=g, device=a.device)
+        b.ctrl[:] = a.ctrl
+        for k in range(12):
+            a.step(3)
+            b.qpos[:] = a.qpos; b.qvel[:] = a.qvel; b.qacc_warmstart[:] = a.qacc_warmstart; b.ctrl[:] = a.ctrl   # (the base controller writes the wheels' ctrl)
+            a.step(1); b.step(1)
+            torch.cuda.synchronize()
+            d = (a.qvel - b.qvel).abs().amax(0) / (1.0 + a.qvel.abs().amax(0))
+            rel.append(d.cpu().numpy())
+            same_counts.append(float((a.info[:3] == b.info[:3]).all(0).float().mean()))
+    rel = np.concatenate(rel)
+    print(f"\n[{scene}] two wavefronts vs one, {len(rel)} env-steps: rel dqvel p50 {np.percentile(rel, 50):.1e} p99 {np.percentile(rel, 99):.1e} max {rel.max():.1e}; "
+          f"same nefc / ncon / sweeps on {100 * np.mean(same_counts):.2f} % of the env-steps")
+    assert bool(torch.isfinite(a.qpos).all())
+    assert np.percentile(rel, 50) < 1e-6 and np.percentile(rel, 99) < 1e-3 and rel.max() < 5e-2 and np.mean(same_counts) > 0.99   # (observed: kitchen4 3e-9 / 5e-6 / 1.5e-3, Robocasa-scale kitchen 3e-7 / 2e-4 / 9e-3)
+    for sim in sims:
+        sim.stop()
+
+
+@pytest.mark.gpu
 def test_gpu_pgs_kitchen_at_robocasa_scale_steps_every_env():
     """PGS, 1024 envs of the kitchen at Robocasa scale, 200 steps of random actions: every env steps, dense systems beyond the
     16-satellite build's 96 rows go to the 32-satellite build (160), states stay finite, at most 1 % of the envs carry a flag."""
