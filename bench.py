@@ -174,7 +174,7 @@ def other_configs(B, dev, hold, solver):
         sim.start(home=False)
         res[scene + "_physics"] = {"value": rollout(sim, 500, hold), "unit": "env-steps/s", **flags_of(sim)}   # 10 launches: one with a hand-over to the larger variant costs +30 %
         if scene == "stretch_kitchen_robocasa":
-            res[scene + "_physics"].update(dofs=sim.nv, kernel_variant="sat (16 satellites, 208 rows, 2 envs per CU) -> sat32 (320 rows) for steps beyond it",
+            res[scene + "_physics"].update(dofs=sim.nv, kernel_variant="sat (16 satellites, 208 rows, 2 envs per CU) -> sat32 (320 rows) for steps beyond it; under PGS the two-wavefront build satp (satellite islands swept beside the dense system)",
                                            note="overflow_flags bit 2 = more than 64 contacts in one env (a lane count); rows / dense rows / coupled satellites hand over and are not flagged")
         sim.stop()
     # north_star's target sentence (>= 1 M env-steps/s on 4096 kitchen envs at 8 GPUs): the per-rank share of 4096 kitchen envs in

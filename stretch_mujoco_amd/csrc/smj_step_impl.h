@@ -125,8 +125,17 @@ struct Smem {
 #define ROWPASS_ALL(rb) _Pragma("unroll") for (int rb = 0; rb < NEFC; rb += 64)
 // A solver stage over all rows: `nr` names the per-row registers of the pass -- nr0 (registers, live across the Newton loop)
 // in the first pass, a stage-local copy of the LDS-resident state (rx_load / rx_store) in the second.
-#define ROWS_BEGIN(rb, ne) ROWPASS(rb, ne) { NRow nrx_; if (rb != 0) rx_load(nrx_, rb); NRow& nr = (rb != 0) ? nrx_ : nr0; (void)nr;
+#if NEFC > 128
+// Builds with more than two passes (160 .. 320 rows): the first pass (registers) and ONE copy of the later passes as a run-time
+// loop -- unrolled, every solver stage existed four or five times over (the 320-row build: 2.4 KB of scratch per lane, most of it
+// addresses of the LDS-resident row state kept alive across the copies).
+#define ROWS_BEGIN_(rb, ne, LOAD) _Pragma("unroll") for (int rp_ = 0; rp_ < 2; rp_++) _Pragma("nounroll") for (int rb = rp_ ? 64 : 0; rp_ ? (rb < NEFC && (ne) > rb) : rb < 64; rb += 64) { NRow nrx_; if (rp_ && (LOAD)) rx_load(nrx_, rb); NRow& nr = rp_ ? nrx_ : nr0; (void)nr;
+#define ROWS_END_RW(rb) if (rp_) rx_store(nrx_, rb); }
+#else
+#define ROWS_BEGIN_(rb, ne, LOAD) ROWPASS(rb, ne) { NRow nrx_; if (rb != 0 && (LOAD)) rx_load(nrx_, rb); NRow& nr = (rb != 0) ? nrx_ : nr0; (void)nr;
 #define ROWS_END_RW(rb) if (rb != 0) rx_store(nrx_, rb); }
+#endif
+#define ROWS_BEGIN(rb, ne) ROWS_BEGIN_(rb, ne, true)
 #define ROWS_END_RO() }
 // PGS without dynamic LDS: the largest row count (a multiple of 16: the MFMA tiles of A's build must not read rows of J that A
 // has taken) whose packed A, placed behind that many rows of J, ends inside the struct -- 80 rows for the standard variant (all
@@ -3830,7 +3839,7 @@ struct StepKernel {
       return;
     }
     // per-row constants, efc_vel, aref
-    ROWPASS(rb, ne) { NRow nrx_; NRow& nr = (rb != 0) ? nrx_ : nr0; LANES {   // the first stage: nothing to load yet
+    ROWS_BEGIN_(rb, ne, false) LANES {   // the first stage: nothing to load yet
       const int row = lane + rb;
       float vel = 0;
       const bool on = row < ne;

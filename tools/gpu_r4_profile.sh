@@ -28,4 +28,13 @@ done
 timeout 600 python tools/gpu_diag.py 2>&1 | grep -v amdgpu.ids > gpurun_out/stage_cycles.txt
 python tools/gpu_sat_caps.py 2>&1 | grep -v amdgpu > gpurun_out/sat_caps.txt
 for sc in stretch_kitchen_robocasa stretch_kitchen4_sat stretch_kitchen4 stretch_scene_sat stretch_scene stretch_kitchen_export_sat; do python tools/gpu_options_probe.py scene=$sc 2>&1 | grep -v amdgpu; done > gpurun_out/scene_probes.txt
+# PGS with constraint islands: throughput beside the dense builds, sweep sub-counters (one-wavefront profiling build), step(1)
+bash tools/gpu_pgs_sat_probe.sh > gpurun_out/pgs_sat_probe.txt 2>&1
+for sc in stretch_kitchen4_sat stretch_kitchen_robocasa; do
+  SMJ_LIB_PATH=$PWD/stretch_mujoco_amd/csrc/build/exp/libsmj_bigprof.so timeout 400 python tools/gpu_pgs_diag.py $sc 2>&1 | grep -v amdgpu.ids > gpurun_out/pgs_stage_cycles_$sc.txt
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/trace_pgs_kitchen4_sat -o smj -- python tools/gpu_options_probe.py solver=0 scene=stretch_kitchen4_sat > gpurun_out/prof/trace_pgs_kitchen4_sat.log 2>&1
+for o in balance_min=4 balance_min=1; do python tools/gpu_step1_probe.py $o 2>&1 | grep -v amdgpu; done > gpurun_out/step1_probe.txt
+bash tools/gpu_step1_trace.sh > gpurun_out/step1_trace.txt 2>&1
+python tools/gpu_steplen_probe.py 2>&1 | grep -v amdgpu > gpurun_out/steplen.txt
 find gpurun_out/prof -name "*.csv" | wc -l

@@ -117,6 +117,34 @@ def satellite_summary(out):
         if os.path.exists(scp):
             with open(scp) as fi, open(os.path.join(DST, f"{TAG}_stage_cycles_{scn}.txt"), "w") as fo:
                 fo.write(fi.read())
+    path = os.path.join(SRC, "trace_pgs_kitchen4_sat", "smj_kernel_stats.csv")
+    if os.path.exists(path):
+        out.append("\n## `rocprofv3 --kernel-trace --stats`: PGS with constraint islands, `stretch_kitchen4_sat` (`tools/gpu_options_probe.py solver=0 scene=stretch_kitchen4_sat`; `smj_step_kernel_satp` = the 16-satellite build with TWO wavefronts per env: grid x 128 threads)\n")
+        out.append("| kernel | calls | total ms | avg ms | % | min ms | max ms |\n|---|---|---|---|---|---|---|")
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                if float(r["Percentage"]) > 0.05:
+                    out.append(f"| `{r['Name'][:60]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e6:.3f} | {float(r['Percentage']):.2f} | {float(r['MinNs'])/1e6:.3f} | {float(r['MaxNs'])/1e6:.3f} |")
+        lp = os.path.join(SRC, "trace_pgs_kitchen4_sat.log")
+        if os.path.exists(lp):
+            last = [l for l in open(lp) if "env-steps/s" in l]
+            if last:
+                out.append("\nProbe output under the profiler: `" + last[-1].strip()[:200] + "`")
+        tp = os.path.join(SRC, "trace_pgs_kitchen4_sat", "smj_kernel_trace.csv")
+        with open(tp) as f:
+            tr = [r for r in csv.DictReader(f) if r["Kernel_Name"].startswith("smj_step_kernel_satp(")]
+        if tr:
+            r0 = tr[0]
+            out.append(f"Resources of `smj_step_kernel_satp`: VGPR {r0['VGPR_Count']} (+AGPR {r0['Accum_VGPR_Count']}), scratch {r0['Scratch_Size']} B, workgroup {r0['Workgroup_Size_X']}, grid {r0['Grid_Size_X']}.")
+    for name in ("pgs_stage_cycles_stretch_kitchen4_sat.txt", "pgs_stage_cycles_stretch_kitchen_robocasa.txt", "pgs_sat_probe.txt", "step1_probe.txt", "step1_trace.txt"):
+        src = os.path.join(ROOT, "gpurun_out", name)
+        if os.path.exists(src):
+            with open(src) as fi, open(os.path.join(DST, f"{TAG}_{name}"), "w") as fo:
+                fo.write(fi.read())
+    src = os.path.join(ROOT, "gpurun_out", "steplen.txt")
+    if os.path.exists(src):
+        with open(src) as fi, open(os.path.join(DST, f"{TAG}_step_length.txt"), "w") as fo:
+            fo.write(fi.read())
     for name in ("sat_caps.txt", "scene_probes.txt"):
         src = os.path.join(ROOT, "gpurun_out", name)
         if os.path.exists(src):
