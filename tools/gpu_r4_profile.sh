@@ -22,7 +22,7 @@ done
 for sc in stretch_kitchen4_sat stretch_scene_sat; do
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/trace_$sc -o smj -- python tools/gpu_options_probe.py scene=$sc > gpurun_out/prof/trace_$sc.log 2>&1
 done
-for sc in stretch_kitchen_robocasa stretch_kitchen4_sat stretch_scene_sat; do
+for sc in stretch_kitchen_robocasa stretch_kitchen4_sat stretch_scene_sat stretch_kitchen4 stretch_scene; do
   SMJ_LIB_PATH=$PWD/stretch_mujoco_amd/csrc/build/exp/libsmj_bigprof.so timeout 600 python tools/gpu_diag.py $sc 2>&1 | grep -v amdgpu.ids > gpurun_out/stage_cycles_$sc.txt
 done
 timeout 600 python tools/gpu_diag.py 2>&1 | grep -v amdgpu.ids > gpurun_out/stage_cycles.txt
