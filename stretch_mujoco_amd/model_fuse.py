@@ -476,8 +476,14 @@ def prepare_for_kernels(m: Dict[str, np.ndarray], capacity: str = "auto", satell
     32 dofs / 80 constraint rows / 16 contacts; big: 64 / 160 / 48); "big" asks for the big variant regardless -- for
     contact-rich scenes (fixtures all around the robot) whose steps would keep escalating out of the standard one.
     satellites: free objects and single-joint fixture parts declared after the robot run as satellites (find_satellites) -- the
-    blob then addresses the satellite builds of the step kernel (the main part must fit 32 dofs / 32 bodies)."""
+    blob then addresses the satellite builds of the step kernel (the main part must fit 32 dofs / 32 bodies); "auto": only when the
+    model does not fit the dense builds (what StretchBatchSimulator does for a scene given as an .xml path)."""
     f = fuse_static_bodies(m)
+    if satellites == "auto":
+        # the dense builds hold 64 dofs, 32 fused bodies and 128 geoms in convex pairs (smj_model.h); a scene beyond that -- a kitchen
+        # with its fixtures and objects -- goes to the satellite builds when its extra bodies qualify as satellites
+        pg = set(int(g) for k in ("pair_geom1", "pair_geom2") for g in f[k] if f["geom_type"][int(g)] != 0)
+        satellites = (len(f["dof_bodyid"]) > 64 or len(f["body_parentid"]) > 32 or len(pg) > 128) and find_satellites(f) > 0
     nsat = find_satellites(f) if satellites else 0
     f = kernel_tables(f, nsat, static_grid=satellites)   # (the satellite builds carry the static-geometry grid)
     f["k_nsat"] = np.array([nsat], np.int32)

@@ -52,7 +52,8 @@ class StretchBatchSimulator:
                 # compiled here with the build's own MJCF compiler; needs the mesh assets next to the XML
                 from . import mjcf_compiler, model_fuse
 
-                model_blob_bytes = model_blob.dumps(model_fuse.prepare_for_kernels(mjcf_compiler.compile_file(scene)))
+                # (a scene beyond the dense builds' 64 dofs / 32 bodies / 128 collision geoms -- a kitchen -- is prepared for the satellite builds)
+                model_blob_bytes = model_blob.dumps(model_fuse.prepare_for_kernels(mjcf_compiler.compile_file(scene), satellites="auto"))
             else:
                 with open(os.path.join(_MODELS, scene + ".smjb"), "rb") as f:
                     model_blob_bytes = f.read()

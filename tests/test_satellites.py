@@ -45,6 +45,32 @@ def test_kitchen_fixture_is_at_robocasa_scale_and_goes_through_the_import():
     assert joints.count("hinge") + joints.count("slide") == st["articulated"] and len(list(root.iter("freejoint"))) == st["free_objects"]
 
 
+def test_xml_scenes_pick_the_satellite_build_when_they_outgrow_the_dense_ones():
+    """A scene handed over as an .xml path (the reference's `scene_xml_path`) is prepared with satellites = "auto": scene.xml
+    (38 dofs, 20-odd geoms) fits the dense builds and stays there; the kitchen at Robocasa scale (82 dofs, 307 collision geoms)
+    does not and comes out with 16 satellites and the static-geometry tables -- a blob equal to the committed one."""
+    import os
+
+    from kitchen_robocasa_fixture import kitchen_xml
+    from stretch_mujoco_amd import mjcf_compiler as C, model_fuse as F
+    from stretch_mujoco_amd.robocasa_import import convert_kitchen_xml
+
+    ref = "/root/reference/stretch_mujoco/models"
+    if not os.path.isdir(ref):
+        pytest.skip("the reference's MJCF is not on this box")
+    small = F.prepare_for_kernels(C.compile_file(os.path.join(ref, "scene.xml")), satellites="auto")
+    assert int(small["k_nsat"][0]) == 0
+    rx, _ = kitchen_xml()
+    rkx, pose = convert_kitchen_xml(rx, os.path.join(ref, "stretch.xml"))
+    rk = C.compile_string(rkx)
+    rk["qpos0"][0:3] = pose["pos"]; rk["qpos0"][3:7] = pose["quat"]
+    big = F.prepare_for_kernels(rk, satellites="auto")
+    _, committed = _blob("stretch_kitchen_robocasa")
+    assert int(big["k_nsat"][0]) == 16 == int(committed["k_nsat"][0])
+    for k in ("k_sat_i", "k_main_dims", "k_nstatpair", "dims"):
+        assert np.array_equal(np.asarray(big[k]), np.asarray(committed[k])), k
+
+
 def test_compiled_kitchen_tables():
     """The committed blob: 16 satellites behind the robot's 26 dofs, the static world split off the scanned pair table, and the
     (moving geom, static geom) -> pair look-up consistent with the pair table MuJoCo's filters leave."""

@@ -42,7 +42,7 @@ def main(B=4096, steps=20000, scene="stretch_empty", solver="newton"):
           f"bad-state resets {float(((fl & 4) != 0).float().mean()):.4f}; pipeline timeouts {int(((fl & 8) != 0).sum())}; "
           f"steps per env min {int(sim.nstep.min())} max {int(sim.nstep.max())}; |quat|-1 max {worst_q:.1e}; "
           f"base z in [{float(z.min()):.3f}, {float(z.max()):.3f}], upright (R22>0.9) {float((up > 0.9).float().mean()):.3f}, "
-          f"|x|,|y| max {float(sim.qpos[0:2].abs().max()):.1f} m")
+          f"|x|,|y| max {float(sim.qpos[0:2].abs().max()):.1f} m; union of all flag bits {hex(int(np.bitwise_or.reduce(fl.cpu().numpy())))} (satellite builds: include/smj.h names the capacity bits)")
 
 
 if __name__ == "__main__":
