@@ -269,12 +269,17 @@ SMJ_DEV static void sat_solve6(const float* A, float* x) {
 // Newton blocks of the satellites: Hb = Mb + sum over the satellite's rows of J_s' W J_s  (W = D for rows in the quadratic
 // zone, the cone Hessian for contacts in the middle zone -- s.ediag / s.u.n.cH as staged by solve_newton), lane = satellite
 SMJ_DEV void sat_hessian(uint64_t conemask) {
+  // 64 / NSAT lanes per satellite (4 in the 16-satellite build, 2 in the 32-satellite one): each takes every LPS-th item of the
+  // satellite's list, the partial blocks are summed over the lane group with quad permutes (round 4: 10 k -> 3 k cycles per call)
+  constexpr int LPS = 64 / NSAT;
+  static_assert(LPS == 2 || LPS == 4, "satellite Hessian: 2 or 4 lanes per satellite");
+  PL<float[21]> Hp;
   LANES {
-    const int si = lane - 32;
-    if (lane >= 32 && si < M.nsat) {
-      float H[21];
-      for (int k = 0; k < 21; k++) H[k] = s.sat.Mb[si][k];
-      for (int it = 0; it < s.sat.nitem[si]; it++) {
+    const int si = lane / LPS, sub = lane % LPS;
+    float H[21];
+    for (int k = 0; k < 21; k++) H[k] = (sub == 0 && si < M.nsat) ? s.sat.Mb[si][k] : 0.f;
+    if (si < M.nsat)
+      for (int it = sub; it < s.sat.nitem[si]; it += LPS) {
         const int r0 = s.sat.irow[si][it], inf = s.sat.iinf[si][it], n = inf & ITEM_N, u = (inf & ITEM_SLOT) ? 1 : 0;
         const int c = s.sat.icon[si][it];
         if ((inf & ITEM_CONTACT) && ((conemask >> c) & 1)) {
@@ -308,8 +313,19 @@ SMJ_DEV void sat_hessian(uint64_t conemask) {
           }
         }
       }
-      for (int k = 0; k < 21; k++) s.sat.Hb[si][k] = H[k];
-    }
+    for (int k = 0; k < 21; k++) Hp[lane][k] = H[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 21; k++) {
+    PL<float> t;
+    LANES { t[lane] = Hp[lane][k]; }
+    wave_group_sum<LPS>(t);
+    LANES { Hp[lane][k] = t[lane]; }
+  }
+  LANES {
+    const int si = lane / LPS;
+    if (lane % LPS == 0 && si < M.nsat)
+      for (int k = 0; k < 21; k++) s.sat.Hb[si][k] = Hp[lane][k];
   }
 }
 
@@ -751,10 +767,17 @@ SMJ_DEV void make_constraint_sat(float* pc, bool prof) {
   SYNC();
   // contacts phase 2: the main columns of the dense rows (as make_constraint: lanes = dofs, two contacts per pass)
   constexpr int CPP = 64 / NVP;
-  for (int c0 = 0; c0 < ncon; c0 += CPP) {
+  // (only the contacts with dense rows -- the ones that touch the main tree: a handful of a kitchen's 20-40 -- two per pass)
+  PL<int> hasd;
+  LANES { hasd[lane] = lane < ncon && s.cefc[lane] >= 0 && s.cefc[lane] < nd; }
+  uint64_t dm = wave_ballot(hasd);
+  while (dm) {
+    int cc[CPP];
+#pragma unroll
+    for (int q = 0; q < CPP; q++) { cc[q] = dm ? ffs64(dm) : -1; if (dm) dm &= dm - 1; }
     LANES {
-      const int c = c0 + lane / NVP, d = lane % NVP;
-      if (c < ncon && d < nv) {
+      const int c = cc[lane / NVP < CPP ? lane / NVP : 0], d = lane % NVP;
+      if (c >= 0 && d < nv) {
         const int r0 = s.cefc[c];
         if (r0 >= 0 && r0 < nd) {
           const int dim = s.cdim[c], b1 = s.u.k.b1[c], b2 = s.u.k.b2[c];

@@ -42,6 +42,15 @@ static inline float wave_sum(const PL<float>& x) {
   }
   return t[0];
 }
+// sum over the caller's group of G = 2 or 4 consecutive lanes, left in every lane of the group (xor-1, then xor-2: the GPU's quad permutes)
+template <int G>
+static inline void wave_group_sum(PL<float>& x) {
+  for (int off = 1; off < G; off <<= 1) {
+    float u[64];
+    for (int i = 0; i < 64; i++) u[i] = x.v[i] + x.v[i ^ off];
+    for (int i = 0; i < 64; i++) x.v[i] = u[i];
+  }
+}
 static inline float wave_min(const PL<float>& x) {
   float m = x.v[0];
   for (int i = 1; i < 64; i++) m = fminf(m, x.v[i]);
@@ -120,6 +129,12 @@ __device__ __forceinline__ float smj_addf(float a, float b) { return a + b; }
 __device__ __forceinline__ float wave_sum(const PL<float>& x) {
   float t = x.v;
   SMJ_WAVE_REDUCE(smj_addf, 0.0f)
+}
+// sum over the caller's group of G = 2 or 4 consecutive lanes, left in every lane of the group (quad permutes [1,0,3,2] and [2,3,0,1])
+template <int G>
+__device__ __forceinline__ void wave_group_sum(PL<float>& x) {
+  x.v += smj_dpp<0xB1, 0xF>(0.0f, x.v);
+  if (G > 2) x.v += smj_dpp<0x4E, 0xF>(0.0f, x.v);
 }
 __device__ __forceinline__ float wave_min(const PL<float>& x) {
   float t = x.v;
