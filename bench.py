@@ -231,6 +231,28 @@ def other_configs(B, dev, hold, solver):
     res["kitchen_with_depth_30hz"] = {"value": B * n / (time.perf_counter() - t), "unit": "env-steps/s",
                                       "note": "whole loop: 17 physics steps + one render of both depth cameras, repeated"}
     sim.stop()
+    # config 5's per-rank shape on the kitchen at Robocasa scale (satellite builds + both depth cameras every 17 steps)
+    if os.path.exists(os.path.join(ROOT, "stretch_mujoco_amd", "models", "stretch_kitchen_robocasa.smjb")):
+        sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver=solver, scene="stretch_kitchen_robocasa", cameras_to_use=StretchCameras.depth())
+        sim.start(home=False)
+        rollout(sim, hold, hold)
+        sim.pull_camera_data()
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        n = 0
+        for _ in range(6):
+            sim.step(17)
+            sim.pull_camera_data()
+            n += 17
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t
+        t = time.perf_counter()
+        for _ in range(3):
+            sim.pull_camera_data()
+        torch.cuda.synchronize(dev)
+        res["kitchen_robocasa_with_depth_30hz"] = {"value": B * n / dt, "unit": "env-steps/s", "ms_per_render": (time.perf_counter() - t) / 3 * 1e3,
+                                                   "note": "config 5's per-rank share (4096 of 32768 envs): the generated Robocasa-scale kitchen, 17 physics steps + one render of both depth cameras, repeated"}
+        sim.stop()
     return res
 
 

@@ -299,7 +299,8 @@ def test_capacity_escalation_matches_the_capacity_free_oracle():
             # the drop starts 5 cm inside the base hull: on a few of these steps MPR finds one contact more or less in fp32
             assert same >= 30, same
             print("\nescalation rollout, |dv| of steps 8..39, largest five:", [float(f"{x:.2e}") for x in sorted(dvs)[-5:]], "0.85 quantile %.1e" % np.quantile(dvs, 0.85))
-            assert np.quantile(dvs, 0.85) < 1e-3 and max(dvs) < 0.2, sorted(dvs)[-5:]
+            # at most ONE of these ~30 steps may sit on an MPR facet change (observed: one step at 4.9e-2, every other one <= 2.3e-4)
+            assert sorted(dvs)[-2] < 1e-3 and max(dvs) < 0.1, sorted(dvs)[-5:]
         if not esc:
             assert flagged > 0
         assert torch.isfinite(sim.qpos).all()
