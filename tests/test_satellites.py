@@ -365,6 +365,34 @@ def test_gpu_pgs_kitchen_at_robocasa_scale_steps_every_env():
 
 
 @pytest.mark.gpu
+def test_gpu_lidar_in_the_kitchen_at_robocasa_scale():
+    """Config 3's readout in config 4's scene: the 360-ray lidar among 300 fixture geoms (boxes, cylinders, convex mesh pieces),
+    doors and drawers at their settled angles, objects where they came to rest -- against the oracle's ray caster on the state the
+    device reached after 60 steps (1e-3 m, at most 3 rays at silhouettes), IMU alongside."""
+    import torch
+    from oracle.oracle import Oracle
+    from stretch_mujoco_amd import StretchBatchSimulator, StretchSensors
+
+    sim = StretchBatchSimulator(num_envs=2, device="cuda:0", scene="stretch_kitchen_robocasa", sensors_to_use=StretchSensors.all())
+    sim.start(home=False)
+    sim.step(60)
+    q = sim.qpos[:, 0].cpu().numpy().astype(np.float64)
+    v = sim.qvel[:, 0].cpu().numpy().astype(np.float64)
+    sim.step(1)
+    torch.cuda.synchronize()
+    L = sim.pull_sensor_data().lidar.cpu().numpy()[0]
+    o = Oracle(sim._blob)
+    o.arr("qpos")[:] = q; o.arr("qvel")[:] = v
+    o.forward(); o.sensors(True)
+    ref = o.arr("lidar")
+    bad = np.abs(L - ref) > 1e-3
+    print(f"\nkitchen lidar: {int((ref > 0).sum())} of 360 rays return, {int(bad.sum())} differ, nearest {ref[ref > 0].min():.3f} m")
+    assert bad.sum() <= 3, (int(bad.sum()), L[bad], ref[bad])
+    assert (ref > 0).sum() > 200 and ref[ref > 0].min() < 1.5   # fixtures all around the robot
+    sim.stop()
+
+
+@pytest.mark.gpu
 def test_gpu_kitchen_at_robocasa_scale_runs_the_bench_workload_without_flags():
     """4096 envs of the generated kitchen, 600 steps of full-range random actions: every env steps every step; rows, dense rows,
     coupled satellites beyond the 16-satellite build go to the 32-satellite one (320 rows) and are NOT flagged.  What can still be
