@@ -1958,7 +1958,10 @@ struct StepKernel {
       for (int j = 0; j < 3; j++) {
         const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
         const float l = sqrtf(fmaxf(0.f, 1.f - R[i][j] * R[i][j]));
-        if (l >= 1e-6f) {
+        // (parallel edges are covered by the face axes.  fp32: 1 - R^2 resolves 6e-8, i.e. l = 2.4e-4 -- the z axes of two boxes
+        // lying flat give R = 1 - 1 ulp as often as 1, and at l = 3.4e-4 e and the radii below are rounding: the axis "separated"
+        // the boxes by ~0 and won over the face axis with ONE bogus point.  Edges within 0.11 degrees count as parallel.)
+        if (l >= 2e-3f) {
           const float e = pp[i2] * R[i1][j] - pp[i1] * R[i2][j];
           const float sv = (fabsf(e) - (A[i1] * Q[i2][j] + A[i2] * Q[i1][j] + B[j1] * Q[i][j2] + B[j2] * Q[i][j1])) / l;
           sep = sep || sv > margin;
@@ -1970,6 +1973,9 @@ struct StepKernel {
           }
         }
       }
+#ifdef SMJ_EMUL
+    if (getenv("SMJ_BOXBOX_TRACE")) { fprintf(stderr, "box_box: code %d best %.9g sep %d R:", code, best, (int)sep); for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) fprintf(stderr, " %.9g", R[i][j]); fprintf(stderr, " pp %.9g %.9g %.9g\n", pp[0], pp[1], pp[2]); }
+#endif
     if (sep) return;
     if (code >= 6) {   // edge-edge: one point, midway between the closest points of the two edges
       float n[3] = {en[0], en[1], en[2]};

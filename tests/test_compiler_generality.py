@@ -212,6 +212,31 @@ def test_kernel_logic_capsule_closed_forms_vs_oracle():
     assert int(e.info[1, 0]) == o.ncon == 2 and np.abs(e.qvel[:, 0] - o.arr("qvel")).max() < 1e-4 * max(1.0, np.abs(o.arr("qvel")).max())
 
 
+def test_box_box_face_polygon_of_eight_points_with_the_option():
+    """[MJ] mjc_BoxBox keeps up to 8 points of a face contact; oracle and kernels keep max_contacts_per_pair (default 4: the extreme
+    points along the two axes of the reference face -- DESIGN.md section 7).  Two equal squares, one turned by 45 degrees, overlap in
+    an octagon: with the option at 8 both sides give its eight corners, with the default both give four, same depths."""
+    from emul.emul import Emul
+    from stretch_mujoco_amd import model_fuse as F
+
+    scene = ('<mujoco><compiler angle="radian"/>' + OPT + '<worldbody><geom type="box" size=".2 .2 .1" pos="0 0 0.1"/>'
+             '<body pos="0 0 0.299" euler="0 0 0.7853981633974483"><freejoint/><geom type="box" size=".2 .2 .1" mass="1"/></body></worldbody></mujoco>')
+    blob = B.dumps(F.prepare_for_kernels(_compile(scene)))
+    for cap, want in ((8, 8), (4, 4)):
+        o = Oracle(blob); o.set_option("solver", 2); o.set_option("max_contacts_per_pair", cap)
+        e = Emul(blob, dict(nq=o.dim("nq"), nv=o.dim("nv"), nu=0, nlidar=0), num_envs=1, variant="standard", debug=True)
+        e.set_option("solver", 2); e.set_option("max_contacts_per_pair", cap)
+        e.qpos[:, 0] = o.arr("qpos")
+        o.step(1); e.step(1)
+        c = o.arr("contact").reshape(o.ncon, -1)
+        assert o.ncon == want == int(e.info[1, 0]), (cap, o.ncon, int(e.info[1, 0]))
+        assert np.allclose(c[:, 0], -0.001, atol=1e-9) and np.allclose(np.abs(c[:, 6]), 1, atol=1e-9)
+        r = np.hypot(c[:, 1], c[:, 2])
+        if cap == 8:   # the octagon's corners: |x| + |y| = 0.2 sqrt 2 on the turned square's edges and max(|x|, |y|) = 0.2 on the other's
+            assert np.allclose(r, 0.2 / math.cos(math.pi / 8), atol=1e-6)
+        assert np.abs(e.qvel[:, 0] - o.arr("qvel")).max() < 1e-4 * max(1.0, np.abs(o.arr("qvel")).max())
+
+
 def test_capsule_box_penetration_through_mpr():
     """A vertical capsule pushed 4 mm into the top face of a box: depth and normal of the first MPR contact.  (KNOWN DEVIATION,
     DESIGN.md section 7: MuJoCo runs its closed form mjc_CapsuleBox here -- at most two contacts, no MPR tolerance; its ~300 lines
