@@ -1145,7 +1145,7 @@ static int box_box(const double* p1, const double* R1, const double* A, const do
     double x[3] = {0, 0, 0};
     int ok = 0;
     if (cand < 4) {
-      ok = fabs(wu[cand]) <= hu && fabs(wv[cand]) <= hv;
+      ok = fabs(wu[cand]) <= hu * (1 + 1e-9) && fabs(wv[cand]) <= hv * (1 + 1e-9);   /* (a corner ON the reference face's edge -- boxes of equal size stacked in line -- is inside) */
       memcpy(x, w[cand], 24);
     } else if (cand < 8) {
       const int c = cand - 4;
@@ -1153,7 +1153,7 @@ static int box_box(const double* p1, const double* R1, const double* A, const do
       for (int k = 0; k < 3; k++) { r[k] = cA[k] + sg[c][0] * hu * u[k] + sg[c][1] * hv * v[k]; d[k] = cB[k] - r[k]; }
       const double t = dot3(d, nb) / nnb;
       for (int k = 0; k < 3; k++) { x[k] = r[k] + t * n[k]; d[k] = x[k] - cB[k]; }
-      ok = fabs(dot3(d, pv)) < hp && fabs(dot3(d, qv)) < hq;
+      ok = fabs(dot3(d, pv)) <= hp * (1 + 1e-9) && fabs(dot3(d, qv)) <= hq * (1 + 1e-9);   /* (inclusive, as the incident corners: coincident edges) */
     } else {
       const int e = (cand - 8) / 4, r = (cand - 8) % 4, c0 = e, c1 = (e + 1) % 4;   /* incident edge e, reference edge r */
       const int along_u = r < 2;                         /* r = 0,1: the lines u = -hu, +hu; r = 2,3: v = -hv, +hv */
@@ -1172,6 +1172,17 @@ static int box_box(const double* p1, const double* R1, const double* A, const do
     cok[cand] = ok; nok += ok;
     memcpy(cx[cand], x, 24);
   }
+  /* candidates that coincide (a corner of one face ON an edge or a corner of the other: boxes of equal size stacked in line) are
+   * one point: the later one goes, before the count is taken (within 1e-5 m) */
+  for (int cand = 1; cand < 24; cand++) {
+    if (!cok[cand]) continue;
+    const double pc[3] = {cx[cand][0] + 0.5 * cdepth[cand] * n[0], cx[cand][1] + 0.5 * cdepth[cand] * n[1], cx[cand][2] + 0.5 * cdepth[cand] * n[2]};
+    for (int c2 = 0; c2 < cand; c2++) {
+      if (!cok[c2]) continue;
+      const double p2[3] = {cx[c2][0] + 0.5 * cdepth[c2] * n[0], cx[c2][1] + 0.5 * cdepth[c2] * n[1], cx[c2][2] + 0.5 * cdepth[c2] * n[2]};
+      if (fabs(pc[0] - p2[0]) < 1e-5 && fabs(pc[1] - p2[1]) < 1e-5 && fabs(pc[2] - p2[2]) < 1e-5) { cok[cand] = 0; nok--; break; }
+    }
+  }
   /* more points than max_contacts_per_pair: keep the extreme ones along the two axes of the reference face (ties: lowest
    * candidate), a support polygon as wide as the full one */
   if (nok > maxcon) {
@@ -1183,7 +1194,11 @@ static int box_box(const double* p1, const double* R1, const double* A, const do
       if (pick[2] < 0 || cv[cand] < cv[pick[2]]) pick[2] = cand;
       if (pick[3] < 0 || cv[cand] > cv[pick[3]]) pick[3] = cand;
     }
-    for (int k = 0; k < 4; k++) keep[pick[k]] = 1;
+    int nkeep = 0;
+    for (int k = 0; k < 4; k++) { nkeep += !keep[pick[k]]; keep[pick[k]] = 1; }
+    /* (one point can be extreme in two directions: the places left go to the remaining candidates, lowest first) */
+    for (int cand = 0; cand < 24 && nkeep < maxcon; cand++)
+      if (cok[cand] && !keep[cand]) { keep[cand] = 1; nkeep++; }
     for (int cand = 0; cand < 24; cand++) cok[cand] = cok[cand] && keep[cand];
   }
   int cnt = 0;

@@ -2037,14 +2037,14 @@ struct StepKernel {
       if (cand < 4) {
         float d[3];
         for (int k = 0; k < 3; k++) { x[k] = cB[k] + SG0(cand) * hp * pv[k] + SG1(cand) * hq * qv[k]; d[k] = x[k] - cA[k]; }
-        ok = fabsf(dot3(d, u)) <= hu && fabsf(dot3(d, v)) <= hv;
+        ok = fabsf(dot3(d, u)) <= hu * (1.f + 2e-6f) && fabsf(dot3(d, v)) <= hv * (1.f + 2e-6f);   // (a corner ON the reference face's edge -- boxes of equal size stacked in line -- is inside)
       } else if (cand < 8) {
         const int c = cand - 4;
         float r[3], d[3];
         for (int k = 0; k < 3; k++) { r[k] = cA[k] + SG0(c) * hu * u[k] + SG1(c) * hv * v[k]; d[k] = cB[k] - r[k]; }
         const float t = dot3(d, nb) / nnb;
         for (int k = 0; k < 3; k++) { x[k] = r[k] + t * n[k]; d[k] = x[k] - cB[k]; }
-        ok = fabsf(dot3(d, pv)) < hp && fabsf(dot3(d, qv)) < hq;
+        ok = fabsf(dot3(d, pv)) <= hp * (1.f + 2e-6f) && fabsf(dot3(d, qv)) <= hq * (1.f + 2e-6f);   // (inclusive, as the incident corners: coincident edges)
       } else if (cand < 24) {
         const int e = (cand - 8) >> 2, r = (cand - 8) & 3, c0 = e, c1 = (e + 1) & 3;
         float w0[3], w1[3], d0[3], d1[3];
@@ -2073,6 +2073,22 @@ struct StepKernel {
     }
     uint64_t mask = wave_ballot(okv);
     if (mask == 0) return;
+    // candidates that coincide (a corner of one face ON an edge or a corner of the other: boxes of equal size stacked in line) are one
+    // point: the later one goes, before the count is taken (within 1e-5 m)
+    {
+      PL<int> dup;
+      LANES {
+        int dd = 0;
+        if (okv[lane])
+          for (int c2 = 0; c2 < 24; c2++) {
+            const float ox = wave_read(px, c2), oy = wave_read(py, c2), oz = wave_read(pz, c2);
+            if (c2 < lane && ((mask >> c2) & 1) && fabsf(ox - px[lane]) < 1e-5f && fabsf(oy - py[lane]) < 1e-5f && fabsf(oz - pz[lane]) < 1e-5f) dd = 1;
+          }
+        dup[lane] = dd;
+      }
+      mask &= ~wave_ballot(dup);
+      LANES { okv[lane] = (int)((mask >> lane) & 1); }
+    }
     const int maxcon = M.max_con_pair < 4 ? 4 : M.max_con_pair;
     if (popc64(mask) > maxcon) {
       // more points than max_contacts_per_pair: keep the extreme ones along the two axes of the reference face (ties: lowest
@@ -2091,6 +2107,9 @@ struct StepKernel {
       keep |= 1ull << pick_index(kk, li, wave_min(kk));
       LANES { kk[lane] = okv[lane] ? -kv[lane] : 3.0e38f; }
       keep |= 1ull << pick_index(kk, li, wave_min(kk));
+      // (one point can be extreme in two directions: the places left go to the remaining candidates, lowest first)
+      uint64_t rest = mask & ~keep;
+      while (popc64(keep) < maxcon && rest) { keep |= rest & (~rest + 1); rest &= rest - 1; }
       mask &= keep;
       LANES { okv[lane] = (int)((mask >> lane) & 1); }
     }

@@ -187,13 +187,26 @@ def _compare_contacts(cstat, dump, ncon_k, o):
 
 
 class EmulBackend:
-    """The kernel source through the CPU lane emulator (tests/emul)."""
+    """The kernel source through the CPU lane emulator (tests/emul).  The emulator has no escalation of its own; for single steps
+    from an uploaded state (the state-synchronised protocol) this backend does what smj_step does on the device: an env whose step
+    ran out of constraint rows / contacts in the primary variant is stepped again, from the same state, by the variant the
+    device hands it to (standard / mid -> tall, big38 / big50 -> big, sat -> sat32), and that result is the one reported."""
+    ESC = {"standard": "tall", "mid": "tall", "big38": "big", "big50": "big", "sat": "sat32"}
 
     def __init__(self, blob, B, solver=2, variant=None):
         from emul.emul import Emul
 
         o = Oracle(blob)
-        self.e = Emul(blob, dict(nq=o.dim("nq"), nv=o.dim("nv"), nu=o.dim("nu"), nlidar=360), num_envs=B, debug=True, variant=variant)   # variant as smj_create picks it
+        self.dims = dict(nq=o.dim("nq"), nv=o.dim("nv"), nu=o.dim("nu"), nlidar=360)
+        self.blob, self.B = blob, B
+        self.e = Emul(blob, self.dims, num_envs=B, debug=True, variant=variant)   # variant as smj_create picks it
+        self._opts = {}
+        orig = self.e.set_option
+
+        def record(name, v):   # options set on the primary reach the hand-over variant too
+            self._opts[name] = v
+            return orig(name, v)
+        self.e.set_option = record
         self.e.set_option("solver", solver)
         from stretch_mujoco_amd.lib import debug_layout
         import stretch_mujoco_amd.model_blob as mb
@@ -201,24 +214,65 @@ class EmulBackend:
         self.D = debug_layout(self.e.nvp, self.e.ncon_max, self.e.nsat_max)
         self.ncon_max, self.nvp = self.e.ncon_max, self.e.nvp
         self.model = mb.loads(blob)
+        self.x = None          # the hand-over variant's emulator, made when first needed
+        self.handed = []       # envs of the last step that it finished
+        self._state = None
 
     def upload(self, qpos, qvel, warm):
         self.e.qpos[:] = qpos; self.e.qvel[:] = qvel; self.e.warm[:] = warm
+        self._state = (np.array(qpos, np.float32), np.array(qvel, np.float32), np.array(warm, np.float32))
 
     def set_ctrl(self, ctrl):
         self.e.ctrl[:] = ctrl
 
     def step(self, n):
-        self.e.step(n)
+        self.handed = []
+        st, self._state = self._state, None
+        if n != 1 or st is None or self.e.variant not in self.ESC:
+            self.e.step(n)
+            return
+        ctrl0 = self.e.ctrl.copy()
+        before = self.e.info[3].copy()
+        self.e.info[3] = 0
+        self.e.step(1)
+        over = [b for b in range(self.B) if int(self.e.info[3, b]) & 3]
+        if over:
+            from emul.emul import Emul
+            from stretch_mujoco_amd.lib import debug_layout
+
+            if self.x is None:
+                self.x = Emul(self.blob, self.dims, num_envs=self.B, debug=True, variant=self.ESC[self.e.variant])
+                self.xD = debug_layout(self.x.nvp, self.x.ncon_max, self.x.nsat_max)
+            for k, v in self._opts.items():
+                self.x.set_option(k, v)
+            self.x.qpos[:] = st[0]; self.x.qvel[:] = st[1]; self.x.warm[:] = st[2]; self.x.ctrl[:] = ctrl0
+            self.x.info[3] = 0
+            self.x.step(1)
+            for b in over:
+                self.e.qpos[:, b] = self.x.qpos[:, b]; self.e.qvel[:, b] = self.x.qvel[:, b]; self.e.warm[:, b] = self.x.warm[:, b]
+                self.e.info[:, b] = self.x.info[:, b]
+            self.handed = over
+        self.e.info[3] |= before
 
     def download(self):
         e = self.e
         from stretch_mujoco_amd.lib import full_qacc
 
-        qacc = full_qacc(e.debug, self.D, self.model) if self.e.nsat_max else e.debug[self.D["qacc"]:self.D["qacc"] + self.nvp]
-        return dict(qpos=e.qpos.astype(np.float64), qvel=e.qvel.astype(np.float64), info=e.info.copy(),
-                    qacc=qacc.astype(np.float64),
-                    contacts=e.debug[self.D["con"]:self.D["con"] + 8 * self.ncon_max].copy())
+        def parts(em, D):
+            qacc = full_qacc(em.debug, D, self.model) if em.nsat_max else em.debug[D["qacc"]:D["qacc"] + em.nvp]
+            return qacc.astype(np.float64), em.debug[D["con"]:D["con"] + 8 * em.ncon_max].copy()
+
+        qacc, con = parts(e, self.D)
+        if self.handed:
+            qx, cx = parts(self.x, self.xD)
+            big = np.zeros((max(con.shape[0], cx.shape[0]), self.B), con.dtype)
+            big[:con.shape[0]] = con
+            nq = min(qacc.shape[0], qx.shape[0])
+            for b in self.handed:
+                qacc[:nq, b] = qx[:nq, b]
+                big[:, b] = 0; big[:cx.shape[0], b] = cx[:, b]
+            con = big
+        return dict(qpos=e.qpos.astype(np.float64), qvel=e.qvel.astype(np.float64), info=e.info.copy(), qacc=qacc, contacts=con)
 
 
 class HipBackend:
