@@ -1295,7 +1295,10 @@ struct StepKernel {
       const float dist0 = dot3(vec, n);
       for (int k = 0; k < 3; k++) vec[k] = axis[k] * prjaxis - n[k];
       const float len2 = dot3(vec, vec);
-      if (len2 >= 1e-30f) { const float sc = size[0] / sqrtf(len2); for (int k = 0; k < 3; k++) vec[k] *= sc; }
+      // (vec = sin(tilt) x the downhill direction.  fp32: its components are differences of O(1) numbers, noise 1e-7 -- a cylinder
+      // STANDING on the plane after a yaw gave vec = (0, 0, -1.2e-7), "downhill" straight into the plane, and lost its contacts or got
+      // one 8 cm deep.  Below a tilt of 3e-5 rad the cylinder is upright: MuJoCo's branch for len2 < mjMINVAL^2.)
+      if (len2 >= 1e-9f) { const float sc = size[0] / sqrtf(len2); for (int k = 0; k < 3; k++) vec[k] *= sc; }
       else { vec[0] = gm[0] * size[0]; vec[1] = gm[3] * size[0]; vec[2] = gm[6] * size[0]; }
       const float prjvec = dot3(vec, n);
       for (int k = 0; k < 3; k++) axis[k] *= size[1];
