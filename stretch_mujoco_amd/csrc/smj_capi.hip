@@ -274,6 +274,17 @@ int smj_create(const void* blob, size_t nbytes, int num_envs, int device, smj_ct
   c->device = device;
   c->num_envs = num_envs;
   HIPCHK(c, hipSetDevice(device));
+  {
+    // The pipelined chunks (and the pollers beside them) lean on workgroups being dispatched in index order: an env's chunk k + 1
+    // waits -- bounded, 3 s -- for chunk k, which sits B workgroups earlier in the grid.  That holds on the gfx94x / gfx950
+    // command processors this was measured on; on any other architecture the default is the plain launch (one workgroup per env
+    // for the whole call).  smj_set_option("pipeline", k) overrides it either way.
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess || (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && strncmp(prop.gcnArchName, "gfx94", 5) != 0)) {
+      c->pipeline = 0;
+      c->pollers = 0;
+    }
+  }
   DeviceUploader up{c};
   SmjCaps caps[7] = {{NVP, NBP, NENT, NEFC, NCON, 0, 0}, {}, {}, {}, {}, {}, {}};   // standard, tall, big38, big50, big, sat, sat32 (smj_model.h)
   int dbg[7] = {SMJ_DEBUG_FLOATS, 0, 0, 0, 0, 0, 0};
