@@ -104,16 +104,19 @@ class StretchBatchSimulator:
         B, f = self.num_envs, dict(dtype=torch.float32, device=self.device)
         i32 = dict(dtype=torch.int32, device=self.device)
         self.qpos = torch.zeros(self.nq, B, **f); self.qvel = torch.zeros(self.nv, B, **f)
-        self.ctrl = torch.zeros(self.nu, B, **f); self.qacc_warmstart = torch.zeros(self.nv, B, **f)
+        nu1 = max(self.nu, 1)   # (a model without actuators -- a scene of objects only -- still binds every slot: zero-row views of real storage)
+        store = {k: torch.zeros(nu1, B, **f) for k in ("ctrl", "actlen", "actvel")}
+        self.ctrl = store["ctrl"][: self.nu]; self.qacc_warmstart = torch.zeros(self.nv, B, **f)
         self.nstep = torch.zeros(B, **i32)
-        self.actuator_length = torch.zeros(self.nu, B, **f); self.actuator_velocity = torch.zeros(self.nu, B, **f)
+        self.actuator_length = store["actlen"][: self.nu]; self.actuator_velocity = store["actvel"][: self.nu]
+        self._store = store
         self.base_pose = torch.zeros(3, B, **f)
         self.gyro = torch.zeros(3, B, **f); self.accel = torch.zeros(3, B, **f)
         self.lidar = torch.zeros(max(self.nlidar, 1), B, **f)
         self.info = torch.zeros(4, B, **i32)
         S = _lib.SLOT
-        binds = [("QPOS", self.qpos), ("QVEL", self.qvel), ("CTRL", self.ctrl), ("WARMSTART", self.qacc_warmstart),
-                 ("NSTEP", self.nstep), ("ACT_LENGTH", self.actuator_length), ("ACT_VELOCITY", self.actuator_velocity),
+        binds = [("QPOS", self.qpos), ("QVEL", self.qvel), ("CTRL", store["ctrl"]), ("WARMSTART", self.qacc_warmstart),
+                 ("NSTEP", self.nstep), ("ACT_LENGTH", store["actlen"]), ("ACT_VELOCITY", store["actvel"]),
                  ("BASE_POSE", self.base_pose), ("GYRO", self.gyro), ("ACCEL", self.accel), ("LIDAR", self.lidar),
                  ("INFO", self.info)]
         if self._debug:

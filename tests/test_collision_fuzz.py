@@ -6,6 +6,7 @@ depended on ties in the cap's selection rule.)  TEST INFRASTRUCTURE (imports ora
 import math
 
 import numpy as np
+import pytest
 
 from oracle.oracle import Oracle
 from stretch_mujoco_amd import mjcf_compiler as C
@@ -131,3 +132,58 @@ def test_primitives_resting_on_a_box_at_right_angles():
         same, nk, no = _rest_on("box", a, e, rng.choice([0, math.pi / 4, math.pi / 2, 0.3]))
         lying_cylinder = a == "cylinder" and abs(math.cos(e[0]) * math.cos(e[1])) < 0.5
         assert nk >= 1 and (same or (lying_cylinder and abs(nk - no) <= 1)), (trial, a, e, nk, no)
+
+
+# ------------------------------------------------------------------------------------------------------------------- GPU
+def _device_contacts(scene_xml):
+    """One step of the scene on the device (libsmj.so through StretchBatchSimulator on a robot-less blob) and in the oracle:
+    (same, device count, oracle count)."""
+    import torch
+    from stretch_mujoco_amd import StretchBatchSimulator
+
+    blob = B.dumps(F.prepare_for_kernels(C.compile_string(scene_xml)))
+    o = Oracle(blob); o.set_option("solver", 2)
+    sim = StretchBatchSimulator(num_envs=1, device="cuda:0", model_blob_bytes=blob, debug=True)
+    sim.start(home=False)
+    sim.qpos[:, 0] = torch.tensor(o.arr("qpos"), dtype=torch.float32, device=sim.device)
+    o.step(1); sim.step(1)
+    torch.cuda.synchronize()
+    D = sim.debug_layout
+    nk = int(sim.info[1, 0])
+    dk = np.sort(sim.debug[D["con"]:D["con"] + 8 * nk, 0].cpu().numpy().reshape(nk, 8)[:, 0])
+    do = np.sort(o.arr("contact").reshape(o.ncon, -1)[:, 0]) if o.ncon else np.zeros(0)
+    fl = int(sim.info[3, 0])
+    sim.stop()
+    return nk == o.ncon and (nk == 0 or np.abs(dk - do).max() < 2e-5), nk, o.ncon, fl
+
+
+@pytest.mark.gpu
+def test_gpu_degenerate_resting_configurations():
+    """The sweeps above through the compiled kernels (v_rcp / v_sqrt sequences instead of IEEE divides, fused multiply-adds where the
+    compiler chose them): 120 box-on-box pairs, 100 bodies on the plane and 100 on a box top, every one as in the emulator runs --
+    box pairs and plane contacts exact, a cylinder lying on a box within one point."""
+    rng = np.random.default_rng(17)
+    for trial in range(120):
+        ya, yb = rng.choice(YAWS), rng.choice(YAWS)
+        off = [rng.choice([0, 0.05, -0.1, 0.13]), rng.choice([0, 0.05, -0.08]), 0]
+        static = rng.random() < 0.5
+        A = (f'<geom type="box" size=".2 .15 .1" pos="0 0 0.3" euler="0 0 {ya}"/>' if static else
+             f'<body pos="0 0 0.3" euler="0 0 {ya}"><freejoint/><geom type="box" size=".2 .15 .1" mass="1"/></body>')
+        scene = ('<mujoco><compiler angle="radian"/>' + OPT + '<worldbody>' + A +
+                 f'<body pos="{off[0]} {off[1]} 0.499" euler="0 0 {yb}"><freejoint/><geom type="box" size=".2 .15 .1" mass="1"/></body></worldbody></mujoco>')
+        same, nk, no, fl = _device_contacts(scene)
+        assert same and fl == 0 and nk >= 3, ("box-box", trial, ya, yb, off, static, nk, no)
+    ang = [0, math.pi / 2, math.pi, -math.pi / 2]
+    for support in ("plane", "box"):
+        for trial in range(100):
+            a = rng.choice(list(SHAPES))
+            e = [rng.choice(ang), rng.choice(ang), rng.choice(ang)] if rng.random() < 0.6 else [0, 0, rng.choice(ang + [math.pi / 4, 0.3])]
+            yawb = rng.choice([0, math.pi / 4, math.pi / 2, 0.3])
+            ta, sa, _ = SHAPES[a]
+            h = _rest_height(a, e)
+            ground = ('<geom type="plane" size="0 0 1"/>' if support == "plane" else f'<geom type="box" size=".5 .4 .2" pos="0 0 -0.2" euler="0 0 {yawb}"/>')
+            scene = ('<mujoco><compiler angle="radian"/>' + OPT + '<worldbody>' + ground +
+                     f'<body pos="0.1 -0.2 {h - 0.001}" euler="{e[0]} {e[1]} {e[2]}"><freejoint/><geom type="{ta}" size="{sa}" mass="1"/></body></worldbody></mujoco>')
+            same, nk, no, fl = _device_contacts(scene)
+            lying_cylinder = support == "box" and a == "cylinder" and abs(math.cos(e[0]) * math.cos(e[1])) < 0.5
+            assert fl == 0 and nk >= 1 and (same or (lying_cylinder and abs(nk - no) <= 1)), (support, trial, a, e, nk, no)
