@@ -211,3 +211,45 @@ def test_gpu_degenerate_resting_configurations():
             same, nk, no, fl = _device_contacts(scene)
             lying_cylinder = support == "box" and a == "cylinder" and abs(math.cos(e[0]) * math.cos(e[1])) < 0.5
             assert fl == 0 and nk >= 1 and (same or (lying_cylinder and abs(nk - no) <= 1)), (support, trial, a, e, nk, no)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nbodies", [5, 8])
+def test_gpu_piles_of_primitives_state_synchronised(nbodies):
+    """Six random piles -- five (30 dofs: the standard kernel) or eight (48 dofs: the 50-column build) bodies of mixed shapes dropped
+    on a box and the plane, orientations from the quarter-turn set -- 200 steps each on the device with the oracle's state uploaded
+    before every step: contact / row counts equal on >= 99 % of the steps (the rest: multiccd ties, one point more or less), one-step
+    velocities p90 < 1e-4 relative on the steps that agree (observed 1198 of 1200, p90 9e-6), no flag."""
+    import torch
+    from stretch_mujoco_amd import StretchBatchSimulator
+
+    rng = np.random.default_rng(23)
+    ang = [0, math.pi / 2, math.pi / 4, 0.3, -math.pi / 2]
+    agree, total, errs = 0, 0, []
+    for pile in range(6):
+        bodies = ""
+        for k in range(nbodies):
+            a = rng.choice(list(SHAPES)); ta, sa, _ = SHAPES[a]
+            e = [rng.choice(ang), rng.choice(ang), rng.choice(ang)]
+            bodies += (f'<body pos="{rng.uniform(-0.25, 0.25):.3f} {rng.uniform(-0.2, 0.2):.3f} {0.35 + 0.28 * k:.3f}" euler="{e[0]} {e[1]} {e[2]}"><freejoint/>'
+                       f'<geom type="{ta}" size="{sa}" mass="{rng.uniform(0.2, 1.5):.2f}"/></body>')
+        scene = ('<mujoco><compiler angle="radian"/>' + OPT + '<option timestep="0.002"/><worldbody><geom type="plane" size="0 0 1"/>'
+                 '<geom type="box" size=".35 .3 .1" pos="0 0 0.1"/>' + bodies + '</worldbody></mujoco>')
+        blob = B.dumps(F.prepare_for_kernels(C.compile_string(scene)))
+        o = Oracle(blob); o.set_option("solver", 2)
+        sim = StretchBatchSimulator(num_envs=1, device="cuda:0", model_blob_bytes=blob)
+        sim.start(home=False)
+        for step in range(200):
+            for name, t in (("qpos", sim.qpos), ("qvel", sim.qvel), ("qacc_warmstart", sim.qacc_warmstart)):
+                t[:, 0] = torch.tensor(o.arr(name), dtype=torch.float32, device=sim.device)
+            o.step(1); sim.step(1)
+            torch.cuda.synchronize()
+            total += 1
+            if int(sim.info[1, 0]) == o.ncon and int(sim.info[0, 0]) == o.nefc:
+                agree += 1
+                v = o.arr("qvel")
+                errs.append(np.abs(sim.qvel[:, 0].cpu().numpy() - v).max() / max(1.0, np.abs(v).max()))
+        assert int(sim.info[3, 0]) == 0, (pile, hex(int(sim.info[3, 0])))
+        sim.stop()
+    print(f"\npiles of {nbodies}: {agree} of {total} steps with equal contact / row counts; rel dqvel p50 {np.percentile(errs, 50):.1e} p90 {np.percentile(errs, 90):.1e} max {max(errs):.1e}")
+    assert agree >= 0.99 * total and np.percentile(errs, 90) < 1e-4
