@@ -214,8 +214,8 @@ def test_gpu_degenerate_resting_configurations():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nbodies", [5, 8])
-def test_gpu_piles_of_primitives_state_synchronised(nbodies):
+@pytest.mark.parametrize("nbodies,solver", [(5, "newton"), (8, "newton"), (5, "pgs")])
+def test_gpu_piles_of_primitives_state_synchronised(nbodies, solver):
     """Six random piles -- five (30 dofs: the standard kernel) or eight (48 dofs: the 50-column build) bodies of mixed shapes dropped
     on a box and the plane, orientations from the quarter-turn set -- 200 steps each on the device with the oracle's state uploaded
     before every step: contact / row counts equal on >= 99 % of the steps (the rest: multiccd ties, one point more or less), one-step
@@ -236,9 +236,11 @@ def test_gpu_piles_of_primitives_state_synchronised(nbodies):
         scene = ('<mujoco><compiler angle="radian"/>' + OPT + '<option timestep="0.002"/><worldbody><geom type="plane" size="0 0 1"/>'
                  '<geom type="box" size=".35 .3 .1" pos="0 0 0.1"/>' + bodies + '</worldbody></mujoco>')
         blob = B.dumps(F.prepare_for_kernels(C.compile_string(scene)))
-        o = Oracle(blob); o.set_option("solver", 2)
-        sim = StretchBatchSimulator(num_envs=1, device="cuda:0", model_blob_bytes=blob)
+        o = Oracle(blob); o.set_option("solver", 2 if solver == "newton" else 0)
+        sim = StretchBatchSimulator(num_envs=1, device="cuda:0", model_blob_bytes=blob, solver=solver)
         sim.start(home=False)
+        if solver == "pgs":
+            sim.set_option("qcqp_exact", 1)   # MuJoCo's own QCQP iteration on both sides
         for step in range(200):
             for name, t in (("qpos", sim.qpos), ("qvel", sim.qvel), ("qacc_warmstart", sim.qacc_warmstart)):
                 t[:, 0] = torch.tensor(o.arr(name), dtype=torch.float32, device=sim.device)
@@ -251,5 +253,6 @@ def test_gpu_piles_of_primitives_state_synchronised(nbodies):
                 errs.append(np.abs(sim.qvel[:, 0].cpu().numpy() - v).max() / max(1.0, np.abs(v).max()))
         assert int(sim.info[3, 0]) == 0, (pile, hex(int(sim.info[3, 0])))
         sim.stop()
-    print(f"\npiles of {nbodies}: {agree} of {total} steps with equal contact / row counts; rel dqvel p50 {np.percentile(errs, 50):.1e} p90 {np.percentile(errs, 90):.1e} max {max(errs):.1e}")
+    print(f"\npiles of {nbodies} [{solver}]: {agree} of {total} steps with equal contact / row counts; rel dqvel p50 {np.percentile(errs, 50):.1e} p90 {np.percentile(errs, 90):.1e} max {max(errs):.1e}")
+    # (PGS observed: 1199 of 1200, p90 4e-6, max 1.3e-3)
     assert agree >= 0.99 * total and np.percentile(errs, 90) < 1e-4
