@@ -10,7 +10,9 @@
 #define NCAND 288             // static-broadphase candidates kept between steps
 #define SMJ_SB_SLACK 0.03f    // metres a moving geom may travel before the candidate list is rebuilt
 #define NS2 (6 * NSS)         // rows of the second-slot pool
+#ifndef NCH
 #define NCH 16                // contacts whose cone Hessian is kept per constraint update (contacts in the middle zone of their cone: sliding); beyond it a contact's block is left out of H for that iteration (the step stays exact: gradient and line search are)
+#endif
 // satellite 6-vectors (one per satellite and field)
 enum { SX_V = 0, SX_QA, SX_MA, SX_GRAD, SX_SRCH, SX_MV, SX_G, SX_TMP, SX_N };
 enum { ITEM_N = 7, ITEM_SLOT = 8, ITEM_CONTACT = 16, ITEM_MAIN = 32 /* the other body of the contact belongs to the main tree */ };

@@ -3979,13 +3979,24 @@ struct StepKernel {
       uint64_t conemask;
       {
         PL<int> cz;
+#if NSAT > 0
+        SYNC();
+#endif
         LANES {
           int z = 0;
           if (lane < ncon) {
             const int r0 = s.cefc[lane];
             z = r0 >= 0 && s.cdim[lane] >= 3 && s.estate[r0 >= 0 ? r0 : 0] == 4;   // row states as left by newton_update
 #if NSAT > 0
-            z = z && s.sat.chs[lane] >= 0;   // (its Hessian is in the pool)
+            // A sliding contact beyond the cone-Hessian pool (more than NCH of them at once: a toppled robot ploughing through
+            // the kitchen) enters H with the diagonal weights of its rows instead of its cone Hessian -- a positive definite
+            // stand-in of the same scale.  Left out altogether (the first version), H lacked those contacts' stiffness, the
+            // iteration crept and ran into its cap of 100 with a wrong acceleration: a robot lying on its side rose at 2 m/s
+            // (found by the long soak of round 4; the search direction stays a descent direction, the line search is exact).
+            if (z && s.sat.chs[lane] < 0) {
+              for (int j = 0; j < s.cdim[lane]; j++) s.ediag[r0 + j] = 1.0f / s.eR[r0 + j];
+              z = 0;
+            }
 #endif
           }
           cz[lane] = z;

@@ -247,6 +247,31 @@ def test_emul_pgs_satellite_build_state_synchronised(scene, variant):
     assert c["mismatched_steps"] <= 0.01 * len(rel) + 1 and c["n"] > 1000
 
 
+def test_emul_more_sliding_contacts_than_cone_hessian_blocks():
+    """A state the long soak of round 4 ran into (tests/golden/toppled_robot_state.npz: stretch_kitchen4 on the satellite build,
+    the robot on its side, 37 contacts, most of them sliding): more contacts in the middle zone of their cone than the 16-block
+    cone-Hessian pool holds.  The first version left the surplus out of H; Newton crept to its cap of 100 iterations and the robot
+    rose at 2 m/s where the oracle's stays down.  With the diagonal stand-in the iteration count is the oracle's and 30 free-running
+    steps stay on the oracle's."""
+    import os
+    from emul.emul import Emul
+    from oracle.oracle import Oracle
+
+    blob, _ = _blob("stretch_kitchen4_sat")
+    st = np.load(os.path.join(os.path.dirname(__file__), "golden", "toppled_robot_state.npz"))
+    o = Oracle(blob); o.set_option("solver", 2)
+    nu = o.dim("nu")
+    o.arr("qpos")[:] = st["qpos"]; o.arr("qvel")[:] = st["qvel"]; o.arr("qacc_warmstart")[:] = st["warm"]; o.arr("ctrl")[:nu] = st["ctrl"]
+    e = Emul(blob, dict(nq=o.dim("nq"), nv=o.dim("nv"), nu=nu, nlidar=360), num_envs=1, variant="sat"); e.set_option("solver", 2)
+    e.ctrl[:, 0] = st["ctrl"]; e.qpos[:, 0] = st["qpos"]; e.qvel[:, 0] = st["qvel"]; e.warm[:, 0] = st["warm"]
+    for k in range(30):
+        e.step(1); o.step(1)
+        assert int(e.info[2, 0]) < 20 and int(e.info[3, 0]) == 0, (k, e.info[:, 0])
+        if k == 0:
+            assert (int(e.info[0, 0]), int(e.info[1, 0])) == (o.nefc, o.ncon) == (138, 37)
+    assert abs(float(e.qpos[2, 0]) - o.arr("qpos")[2]) < 1e-4 and np.abs(e.qpos[:27, 0] - o.arr("qpos")[:27]).max() < 2e-3
+
+
 # ------------------------------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("scene", SAT_SCENES)

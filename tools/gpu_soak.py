@@ -21,12 +21,15 @@ def main(B=4096, steps=20000, scene="stretch_empty", solver="newton"):
     worst_q = 0.0
     per_launch = []
     ever = torch.zeros(B, dtype=torch.int32, device=dev)
+    capped = 0   # launches x envs whose last step's solver ended at the iteration cap
+    itmax = int(sim.model.get('opt_iterations', [100])[0]) if hasattr(sim.model, 'get') else 100
     for k in range(steps // 50):
         sim.ctrl.copy_(lo + (hi - lo) * torch.rand(sim.nu, B, generator=g, device=dev))
         sim.info[3].zero_()          # flags are sticky: clear them to count per launch
         sim.step(50)
         per_launch.append(float(((sim.info[3] & 1) != 0).float().mean()))
         ever |= sim.info[3]
+        capped += int((sim.info[2] >= itmax).sum())
         if k % 40 == 39:
             q = sim.qpos
             assert torch.isfinite(q).all() and torch.isfinite(sim.qvel).all(), k
@@ -42,7 +45,7 @@ def main(B=4096, steps=20000, scene="stretch_empty", solver="newton"):
           f"bad-state resets {float(((fl & 4) != 0).float().mean()):.4f}; pipeline timeouts {int(((fl & 8) != 0).sum())}; "
           f"steps per env min {int(sim.nstep.min())} max {int(sim.nstep.max())}; |quat|-1 max {worst_q:.1e}; "
           f"base z in [{float(z.min()):.3f}, {float(z.max()):.3f}], upright (R22>0.9) {float((up > 0.9).float().mean()):.3f}, "
-          f"|x|,|y| max {float(sim.qpos[0:2].abs().max()):.1f} m; union of all flag bits {hex(int(np.bitwise_or.reduce(fl.cpu().numpy())))} (satellite builds: include/smj.h names the capacity bits)")
+          f"|x|,|y| max {float(sim.qpos[0:2].abs().max()):.1f} m; solver at its iteration cap on the last step of a launch: {capped} of {B * (steps // 50)} (env, launch) samples; union of all flag bits {hex(int(np.bitwise_or.reduce(fl.cpu().numpy())))} (satellite builds: include/smj.h names the capacity bits)")
 
 
 if __name__ == "__main__":
