@@ -7,6 +7,7 @@
 #define SMJ_SAT_DENSE 256
 #define SMJ_SAT_EXT 4
 #define SMJ_SAT_ITEMS 40
+#define NCH 64   // a cone-Hessian block for every contact (one env per CU: the LDS is there)
 #define SMJ_VARIANT_TAG sat32
 #ifndef SMJ_PROFILING
 #define SMJ_PROFILING 0
