@@ -284,3 +284,82 @@ def test_rgb_stand_in_matches_the_oracle_ray_caster():
             assert (oc == c[e]).all(-1).mean() >= 0.995
     assert L.smj_render_rgb(sim._ctx, 9, 8, 8, 42.0, ctypes.c_void_p(rgb.data_ptr()), None, sim._stream()) != 0
     sim.stop()
+
+
+def test_notebook_images_of_cells_15_and_23_through_the_raw_entries():
+    """The camera images the reference's notebook stores (tests/golden/notebook_images.npz; tests/test_notebook_images.py has the story
+    and the oracle's numbers) against the HIP renderer: start() / home / 1601 steps in the default scene, the base placed at the pose
+    cell 20 prints, then (i) cam_d405_depth through smj_render_depth(640, 480, fovy 50): MuJoCo's 53 400 stored pixels to 0.3 grey
+    levels on average, fingers' silhouette IoU > 0.975, table-top depths within 1 level; the yaw scan has its minimum at the printed
+    -0.065 rad; (ii) after the head has run into its tilt stop, cam_nav_rgb's geom ids through smj_render_rgb: the table's outline
+    against the wood MuJoCo drew (IoU > 0.94), the red cylinder and the blue box where it drew them."""
+    import ctypes
+
+    import notebook_images as nbi
+    from scipy.ndimage import binary_dilation, binary_erosion
+    from stretch_mujoco_amd import StretchBatchSimulator, lib
+    from stretch_mujoco_amd.enums import StretchCameras
+
+    pytest.importorskip("PIL")
+    G = nbi.golden()
+    yaws = np.round(np.arange(-0.105, 0.016, 0.01), 3)
+    B = len(yaws)
+    sim = StretchBatchSimulator(num_envs=B, device="cuda:0", cameras_to_use=StretchCameras.all(), solver="newton", scene="stretch_scene")
+    sim.start(home=False)
+    sim.home(settle=False)
+    sim.step(1601)
+    L = lib.load()
+    x, y, th = nbi.NB_BASE_POSE
+
+    def place(thetas):
+        q = sim.qpos.t().cpu().numpy().astype(np.float64)
+        sim.qpos[:] = torch.tensor(np.stack([nbi.place_base(q[e], x, y, thetas[e]) for e in range(B)], 1), dtype=torch.float32, device=sim.device)
+        sim.qvel[:6] = 0
+        sim.step(1)
+
+    place(yaws)
+    img = torch.zeros(B, 480, 640, dtype=torch.float32, device=sim.device)
+    assert L.smj_render_depth(sim._ctx, nbi.CAM_D405_DEPTH, 640, 480, nbi.fovy_of(nbi.NB_F_D405), 1.0, ctypes.c_void_p(img.data_ptr()), sim._stream()) == 0
+    torch.cuda.synchronize()
+    g = G["cell15_cam_d405_depth"].astype(int)
+    shown = [nbi.display(img[e].cpu().numpy(), (267, 200)).astype(int) for e in range(B)]
+    cost = np.array([np.abs(r - g).mean() for r in shown])
+    print(dict(zip(yaws.tolist(), np.round(cost, 3).tolist())))
+    k = int(np.argmin(cost))
+    assert abs(yaws[k] - th) < 1e-9 and cost[k] < 0.45 and np.sort(cost)[1] > 1.3 * cost[k]
+    r = shown[k]
+    diff = np.abs(r - g)
+    assert (diff <= 2).mean() > 0.988 and ((r > 0) != (g > 0)).sum() < 90
+    assert nbi.iou((g > 0) & (g < 80), (r > 0) & (r < 80)) > 0.975
+    top = binary_erosion((g > 100) & (r > 100), iterations=3)
+    assert top.sum() > 10000 and diff[top].mean() < 0.6 and np.percentile(diff[top], 99.5) <= 2
+    # cell 23: head into its tilt stop, every env at the printed pose
+    sim.move_to("head_tilt", -2.0)
+    sim.step(2500)
+    assert abs(float(sim.pull_status().head_tilt.pos[0]) - (-1.522573472981672)) < 2e-5
+    place(np.full(B, th))
+    table, blue, red = nbi.scene_geoms(sim.model)
+    cls = nbi.colour_classes(G["cell23_cam_nav_rgb"])
+    gid = torch.full((B, 533, 400), -7, dtype=torch.int32, device=sim.device)
+    rgb = torch.zeros(B, 533, 400, 3, dtype=torch.uint8, device=sim.device)
+    fits = {}
+    for fv in (64.0, 69.0, 74.0):
+        assert L.smj_render_rgb(sim._ctx, nbi.CAM_NAV, 400, 533, nbi.nav_display_fovy(fv), ctypes.c_void_p(rgb.data_ptr()),
+                                ctypes.c_void_p(gid.data_ptr()), sim._stream()) == 0
+        torch.cuda.synchronize()
+        ids = np.rot90(gid[0].cpu().numpy(), 1)
+        fits[fv] = nbi.iou(ids == table, cls["wood"])
+        if fv == 69.0:
+            keep = ids
+    print(fits)
+    assert fits[69.0] > 0.94 and fits[64.0] < 0.9 and fits[74.0] < 0.9
+
+    def centroid(mask):
+        ys, xs = np.nonzero(mask)
+        return np.array([xs.mean(), ys.mean()])
+
+    for mask, gold in ((keep == red, cls["red"]), (keep == blue, cls["blue"])):
+        assert gold.sum() > 150 and mask.sum() > 150
+        assert (gold & binary_dilation(mask, iterations=3)).sum() / gold.sum() > 0.9
+        assert np.abs(centroid(mask & binary_dilation(gold, iterations=6)) - centroid(gold)).max() < 6.0
+    sim.stop()
