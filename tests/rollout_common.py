@@ -56,15 +56,21 @@ def drift_groups(nq):
     return base, arm, obj
 
 
-def free_running(backend, blob, model, B, windows, seed, solver=2):
-    """Returns per-env max drift over the rollout: dict(base=[B], arm=[B], obj=[B]), the per-window history and the flags."""
+def free_running(backend, blob, model, B, windows, seed, solver=2, band=1e-4):
+    """Returns per-env max drift over the rollout: dict(base=[B], arm=[B], obj=[B]), the per-window history and the flags -- and, for
+    every env whose drift leaves `band`, WHY (`departures`, see explain_departures): the rollout keeps the kernel's and the oracles'
+    state at every window boundary so that the stretch in which an env leaves can be run again step by step afterwards."""
     oracles = settled_oracles(blob, B, solver)
     nq, nu = oracles[0].dim("nq"), oracles[0].dim("nu")
     backend.upload(*state_of(oracles))
     sched = ctrl_schedule(model, nu, B, windows, seed)
     base, arm, obj = drift_groups(nq)
     hist = []
+    snaps_k, snaps_o = [], []          # state at the START of window w (entry `windows`: the end): the kernel's (fp32), the oracles' (fp64)
     for w in range(windows):
+        k = backend.download()
+        snaps_k.append((k["qpos"].copy(), k["qvel"].copy(), k["warm"].copy()))
+        snaps_o.append(state_of(oracles))
         backend.set_ctrl(sched[w])
         for b, o in enumerate(oracles):
             o.arr("ctrl")[:nu] = sched[w][:, b]
@@ -73,8 +79,167 @@ def free_running(backend, blob, model, B, windows, seed, solver=2):
         q = backend.download()["qpos"]
         d = np.abs(q - np.stack([o.arr("qpos") for o in oracles], 1))
         hist.append((d[base].max(0), d[arm].max(0), d[obj].max(0) if obj else np.zeros(B)))
+    snaps_o.append(state_of(oracles))
     mx = lambda k: np.max(np.stack([h[k] for h in hist]), 0)
-    return dict(base=mx(0), arm=mx(1), obj=mx(2), hist=hist, flags=backend.download()["info"][3], oracles=oracles)
+    flags = backend.download()["info"][3].copy()
+    robot = np.stack([np.maximum(h[0], h[1]) for h in hist])          # [windows, B]
+    left = {b: int(np.argmax(robot[:, b] >= band)) for b in range(B) if (robot[:, b] >= band).any()}
+    departures = explain_departures(backend, blob, model, sched, snaps_k, snaps_o, left, solver, band)
+    return dict(base=mx(0), arm=mx(1), obj=mx(2), hist=hist, flags=flags, oracles=oracles, departures=departures)
+
+
+def step_error(qk, qa, nrobot=26):
+    """One-step acceleration error, relative, the robot's dofs and everything else (free objects, fixture parts) each on their own scale:
+    a 0.1 kg object at 1e4 rad/s^2 must not hide a gross error of a finger joint."""
+    e = np.abs(qk - qa)
+    r = e[:nrobot].max() / max(1.0, np.abs(qa[:nrobot]).max())
+    if len(qa) > nrobot:
+        r = max(r, e[nrobot:].max() / max(1.0, np.abs(qa[nrobot:]).max()))
+    return float(r)
+
+
+def _sensitivity_explains(blob, solver, state, ctrl, qk, qa, trials=8):
+    """A step whose error is small on the scale of EVENT_TOL but large on the scale of the drift band (violent contact phases: 1e3-1e5
+    rad/s^2, where 1e-3 relative is 50 steps' worth of the band): is the kernel's deviation within what the reference algorithm itself
+    does with an input perturbed at fp32 resolution?  The oracle is run at inputs perturbed by 1e-7 (fp32 rounding of the poses), 1e-6
+    (MPR's own tolerance) and 1e-5; explained when a perturbed run reproduces at least half of the kernel's deviation, or when the
+    perturbed runs scatter around the unperturbed one by at least the kernel's deviation.  Returns (explained, eps, spread / error)."""
+    qpos, qvel, warm = state
+    nr = min(26, len(qa))
+    wgt = np.full(len(qa), 1.0 / max(1.0, np.abs(qa[:nr]).max()))
+    if len(qa) > nr:
+        wgt[nr:] = 1.0 / max(1.0, np.abs(qa[nr:]).max())
+    err = float((wgt * np.abs(qk - qa)).max())
+    rng = np.random.default_rng(4321)
+    spread = 0.0
+    for eps in (1e-7, 1e-6, 1e-5):
+        for t in range(trials):
+            o = Oracle(blob)
+            o.set_option("solver", solver)
+            o.arr("qpos")[:] = qpos + rng.normal(size=qpos.shape) * eps
+            o.arr("qvel")[:] = qvel; o.arr("qacc_warmstart")[:] = warm
+            o.arr("ctrl")[: len(ctrl)] = ctrl
+            o.forward()
+            qp = o.arr("qacc")
+            spread = max(spread, float((wgt * np.abs(qp - qa)).max()))
+            if float((wgt * np.abs(qk - qp)).max()) <= 0.5 * err or spread >= err:
+                return True, eps, spread / max(err, 1e-30)
+    return False, None, spread / max(err, 1e-30)
+
+
+def explain_departures(backend, blob, model, sched, snaps_k, snaps_o, left, solver, band):
+    """Every env that leaves the drift band must say why.  For env b leaving in window w the kernel is run again from ITS OWN state at
+    the start of window w - 1 (where both sides were still inside the band), one step at a time, and at every step the oracle is
+    evaluated on the kernel's state of that step (state-synchronised along the kernel's trajectory: each discrepancy belongs to the step
+    that produced it).  The departure is explained as
+
+      * "bifurcation": at least one of those <= 100 steps is an EVENT -- a one-step acceleration error above EVENT_TOL (robot dofs and
+        object dofs each on their own scale) or a different contact count -- and every event is one the reference algorithm itself
+        produces: the oracle reproduces the kernel's result at an input perturbed by <= 1e-5, or on the kernel's contact list (see
+        state_synchronised); or
+      * "sensitivity": no gross event, but steps whose absolute error matters on the scale of the band (more than band / (2 HOLD dt^2) =
+        0.25 rad/s^2 on a robot dof: the violent phases, fingers against objects at 1e3-1e5 rad/s^2), and the largest of them (up to 10)
+        are each within the reference algorithm's own response to an input perturbed at fp32 resolution (_sensitivity_explains); or
+      * "conditioning": there is no event -- every step the kernel took is the oracle's step to within the one-step tolerance -- and
+        the trajectory is not determined to within the band by its state at the start of the stretch: either two fp64 oracles, one from
+        the oracle's state and one from the kernel's in-band state at the start of window w - 1, end >= band / 2 apart, or the kernel's
+        second run from the same state does not leave the band at all (the two runs differ only by what the contact-manifold cache
+        holds: reuse within 3e-7 of a pose).
+
+    Anything else is "unexplained" and fails the test.  Returns {env: dict(window, kind, events, ...)}."""
+    out = {}
+    if not left:
+        return out
+    nu = sched[0].shape[0]
+    envs = sorted(left)
+    w0 = {b: max(left[b] - 1, 0) for b in envs}
+    nwin = {b: left[b] - w0[b] + 1 for b in envs}
+    # the kernel's second run: slot b runs env b's stretch; the slots of envs that stayed inside idle at their last state
+    qpos, qvel, warm = (a.copy() for a in snaps_k[-1])
+    for b in envs:
+        for dst, src in zip((qpos, qvel, warm), snaps_k[w0[b]]):
+            dst[:, b] = src[:, b]
+    backend.upload(qpos, qvel, warm)
+    ctrl = sched[-1].copy()
+    events = {b: [] for b in envs}
+    steprel = {b: [] for b in envs}
+    relevant = {b: [] for b in envs}     # steps whose absolute error matters for the band: (error, step, state, ctrl, qk, qa)
+    dt = float(np.asarray(model["opt_timestep"]).ravel()[0]) if "opt_timestep" in model else 0.002
+    a_band = band / (2 * HOLD * dt * dt)
+    endq = {}
+    o = {b: Oracle(blob) for b in envs}
+    for b in envs:
+        o[b].set_option("solver", solver)
+    nv = o[envs[0]].dim("nv")
+    for s in range(2 * HOLD):
+        for b in envs:
+            if s < nwin[b] * HOLD:
+                ctrl[:, b] = sched[w0[b] + s // HOLD][:, b]
+        backend.set_ctrl(ctrl)
+        pre = backend.download()
+        backend.upload(pre["qpos"], pre["qvel"], pre["warm"])      # an exact round trip; lets the emulator backend hand a step over like smj_step
+        backend.step(1)
+        post = backend.download()
+        for b in envs:
+            if s >= nwin[b] * HOLD:
+                continue
+            st = (pre["qpos"][:, b].astype(np.float64), pre["qvel"][:, b].astype(np.float64), pre["warm"][:, b].astype(np.float64))
+            ob = o[b]
+            ob.arr("qpos")[:] = st[0]; ob.arr("qvel")[:] = st[1]; ob.arr("qacc_warmstart")[:] = st[2]
+            ob.arr("ctrl")[:nu] = ctrl[:, b]
+            ob.step(1)
+            qa, qk = ob.arr("qacc").copy(), post["qacc"][:nv, b]
+            r = step_error(qk, qa)
+            steprel[b].append(r)
+            nk = int(post["info"][1, b])
+            if r > EVENT_TOL or nk != ob.ncon:
+                ok, err, eps = _bifurcation_explains(blob, solver, st, ctrl[:, b], qk)
+                if not ok:
+                    ok, err = _same_contacts_same_dynamics(blob, solver, st, ctrl[:, b], qk, post["contacts"][:, b], nk)
+                    eps = "kernel contacts" if ok else None
+                events[b].append(dict(step=w0[b] * HOLD + s, rel=r, ncon_kernel=nk, ncon_oracle=ob.ncon, explained=bool(ok),
+                                      residual=float(err), eps=eps, flags=int(post["info"][3, b])))
+            ea = float(np.abs(qk - qa)[:26].max())
+            if ea > a_band:
+                relevant[b].append((ea, w0[b] * HOLD + s, st, ctrl[:, b].copy(), qk.copy(), qa))
+            if s == nwin[b] * HOLD - 1:
+                endq[b] = post["qpos"][:, b].copy()
+    base, arm, _ = drift_groups(snaps_k[0][0].shape[0])
+    robot = base + arm
+    for b in envs:
+        ev = events[b]
+        d0 = float(np.abs(snaps_k[w0[b]][0][robot, b] - snaps_o[w0[b]][0][robot, b]).max())
+        again = float(np.abs(endq[b][robot] - snaps_o[left[b] + 1][0][robot, b]).max())     # the second run against the free-running oracle
+        rec = dict(window=left[b], events=ev, start_drift=d0, step_rel_p99=float(np.percentile(steprel[b], 99)), second_run_drift=again,
+                   amplification=None, oracle_pair_drift=None)
+        rec["relevant_steps"] = len(relevant[b])
+        if ev:
+            rec["kind"] = "bifurcation" if all(e["explained"] for e in ev) else "unexplained"
+        elif relevant[b]:
+            checks = []
+            for ea, step, st, c, qk, qa in sorted(relevant[b], key=lambda t: -t[0])[:10]:
+                ok, eps, ratio = _sensitivity_explains(blob, solver, st, c, qk, qa)
+                checks.append(dict(step=step, abs_err=ea, explained=ok, eps=eps, spread_over_err=ratio))
+            rec["sensitivity"] = checks
+            rec["kind"] = "sensitivity" if all(c["explained"] for c in checks) else "unexplained"
+        else:
+            pair = []
+            for snap in (snaps_o, snaps_k):
+                ob = Oracle(blob)
+                ob.set_option("solver", solver)
+                ob.arr("qpos")[:] = snap[w0[b]][0][:, b]; ob.arr("qvel")[:] = snap[w0[b]][1][:, b]
+                ob.arr("qacc_warmstart")[:] = snap[w0[b]][2][:, b]
+                for w in range(w0[b], left[b] + 1):
+                    ob.arr("ctrl")[:nu] = sched[w][:, b]
+                    ob.step(HOLD)
+                pair.append(ob.arr("qpos")[robot].copy())
+            d1 = float(np.abs(pair[0] - pair[1]).max())
+            rec["amplification"] = d1 / max(d0, 1e-12)
+            rec["oracle_pair_drift"] = d1
+            clean = rec["step_rel_p99"] < 4 * TYPICAL_TOL
+            rec["kind"] = "conditioning" if clean and (d1 >= 0.5 * band or again < band) else "unexplained"
+        out[b] = rec
+    return out
 
 
 def _bifurcation_explains(blob, solver, state, ctrl, qacc_kernel, trials=12, tol=EVENT_TOL):
@@ -272,7 +437,8 @@ class EmulBackend:
                 qacc[:nq, b] = qx[:nq, b]
                 big[:, b] = 0; big[:cx.shape[0], b] = cx[:, b]
             con = big
-        return dict(qpos=e.qpos.astype(np.float64), qvel=e.qvel.astype(np.float64), info=e.info.copy(), qacc=qacc, contacts=con)
+        return dict(qpos=e.qpos.astype(np.float64), qvel=e.qvel.astype(np.float64), warm=e.warm.astype(np.float64), info=e.info.copy(), qacc=qacc,
+                    contacts=con)
 
 
 class HipBackend:
@@ -308,7 +474,7 @@ class HipBackend:
         dbg = s.debug.cpu().numpy()
         qacc = full_qacc(dbg, self.D, s.model) if s.nsat_max else dbg[self.D["qacc"]:self.D["qacc"] + self.nvp]
         return dict(qpos=s.qpos.cpu().numpy().astype(np.float64), qvel=s.qvel.cpu().numpy().astype(np.float64),
-                    info=s.info.cpu().numpy(), qacc=qacc.astype(np.float64),
+                    warm=s.qacc_warmstart.cpu().numpy().astype(np.float64), info=s.info.cpu().numpy(), qacc=qacc.astype(np.float64),
                     contacts=s.debug[self.D["con"]:self.D["con"] + 8 * self.ncon_max].cpu().numpy())
 
     def close(self):

@@ -26,35 +26,52 @@ def _report(tag, r):
         print("   free object :", np.array2string(r["obj"], formatter={"float_kind": lambda v: f"{v:.1e}"}))
 
 
-OBJECT_SCENES = ("stretch_scene", "stretch_kitchen4")   # free objects (and a table) within the arm's reach
+OBJECT_SCENES = ("stretch_scene", "stretch_kitchen4", "stretch_kitchen_robocasa")   # free objects (and a table) within the arm's reach
+
+# north_star: qpos drift < 1e-4 over 1000 steps.  The bound is asserted PER ENV with a cause (round 5; rounds 3-4 asserted "the measured
+# fraction of envs minus one", which a regression of one env per scene would have passed): an env may leave the band only through an
+# EXPLAINED departure -- rollout_common.explain_departures replays the stretch in which it leaves, state-synchronised along the kernel's
+# own trajectory, and accepts (i) a bifurcation of the reference algorithm itself (the oracle reproduces the kernel's step at an input
+# perturbed by <= 1e-5, or on the kernel's contact list), (ii) sensitivity (violent phases: the steps whose error matters for the band are each
+# within the oracle's own response to an input perturbed at fp32 resolution) or (iii) conditioning (no such step at all, and two fp64 oracles
+# started from the two in-band states end further apart than half the band).  The floors below only keep the test from passing vacuously.
+FLOOR_INSIDE = {"stretch_empty": 0.5, "stretch_kitchen_standin": 0.5, "stretch_scene": 0.0, "stretch_kitchen4": 0.25, "stretch_kitchen_robocasa": 0.25}
+FLOOR_INSIDE_EARLY = 0.7     # scenes with free objects in reach: the first 250 steps
 
 
-# Fraction of the 16 envs that must stay inside north_star's drift bound (1e-4 on base AND arm over 1000 steps), per scene: the
-# fraction MEASURED on the device (gpurun_out/pytest_gpu.log, round 4: 13 / 16 / 3-5 / 15 of 16) minus one env.  The envs
-# that leave do so at a bifurcation of the contact algorithm (state-synchronised test); in `stretch_scene` the gripper reaches the
-# table's free objects and most rollouts diverge after the first knock -- there the bound is asserted on the first 250 steps too.
-GPU_MIN_INSIDE = {"stretch_empty": 12 / 16, "stretch_kitchen_standin": 15 / 16, "stretch_scene": 2 / 16, "stretch_kitchen4": 14 / 16}
-GPU_MIN_INSIDE_EARLY = {"stretch_scene": 13 / 16, "stretch_kitchen4": 15 / 16}   # (scene.xml: 14-16 of 16 over the first 250 steps, the gripper reaches the objects early in some envs)
-
-
-def _check_free_running(r, min_frac, scene="", early_frac=None):
+def _check_free_running(r, scene):
     B = len(r["base"])
     assert (r["flags"] == 0).all(), r["flags"]
     ok = (r["base"] < 1e-4) & (r["arm"] < 1e-4)
     print(f"   inside 1e-4 over the whole rollout: {int(ok.sum())} / {B}")
+    dep = r["departures"]
+    assert set(dep) == {b for b in range(B) if not ok[b]}
+    for b in sorted(dep):
+        d = dep[b]
+        ev = d["events"]
+        if ev:
+            what = (f"{len(ev)} event(s), first at step {ev[0]['step']}: rel {ev[0]['rel']:.1e}, contacts {ev[0]['ncon_kernel']} / {ev[0]['ncon_oracle']}, "
+                    f"explained by {ev[0]['eps']}")
+        elif d.get("sensitivity"):
+            c = d["sensitivity"]
+            what = (f"no gross step; {d['relevant_steps']} steps with an error that matters for the band (largest {c[0]['abs_err']:.1e} rad/s^2 at step "
+                    f"{c[0]['step']}), the {len(c)} largest each within the oracle's own response to a perturbation of {max(x['eps'] or 0 for x in c):.0e}"
+                    if all(x["explained"] for x in c) else f"steps not explained by sensitivity: {[x for x in c if not x['explained']]}")
+        else:
+            what = (f"no gross step (p99 one-step error {d['step_rel_p99']:.1e}); two fp64 oracles from the two in-band states ({d['start_drift']:.1e} "
+                    f"apart) end {d['oracle_pair_drift']:.1e} apart; the kernel's second run from the same state ends {d['second_run_drift']:.1e} from the oracle")
+        print(f"   env {b} leaves in window {d['window']} (steps {50 * d['window']}..{50 * d['window'] + 49}): {d['kind']}: {what}")
+    bad = {b: d for b, d in dep.items() if d["kind"] == "unexplained"}
+    assert not bad, bad
+    assert all(e["flags"] == 0 for d in dep.values() for e in d["events"])
     if scene in OBJECT_SCENES:
-        # Manipulation of 0.2-0.5 kg objects is chaotic: once the gripper has knocked one over, the fp32 and fp64 runs are two
-        # different rollouts (MPR's portal noise on cylinder rims seeds it, tools/parity_probe.py) -- as two MuJoCo builds
-        # would be.  Asserted over the first 250 steps, and (with the measured fraction) over the whole rollout.
+        # Manipulation of 0.1-0.5 kg objects is chaotic: once the gripper has knocked one over, the fp32 and fp64 runs are two
+        # different rollouts (MPR's portal noise on cylinder rims seeds it, tools/parity_probe.py) -- as two MuJoCo builds would be.
         h = r["hist"][:5]
         early = np.max(np.stack([np.maximum(x[0], x[1]) for x in h]), 0)
         print(f"   inside 1e-4 over the first 250 steps: {int((early < 1e-4).sum())} / {B}")
-        assert (early < 1e-4).mean() >= (early_frac if early_frac is not None else 0.7), early
-        if early_frac is None:
-            return
-    # north_star: drift < 1e-4 over 1000 steps.  Envs that run into a bifurcation of the contact algorithm (see the
-    # state-synchronised test) leave that band; everything else must stay inside it.
-    assert ok.mean() >= min_frac, (ok.mean(), r["base"], r["arm"])
+        assert (early < 1e-4).mean() >= FLOOR_INSIDE_EARLY, early
+    assert ok.mean() >= FLOOR_INSIDE[scene], (ok.mean(), r["base"], r["arm"])
     if scene not in OBJECT_SCENES:
         assert np.median(np.maximum(r["base"], r["arm"])) < 1e-4
 
@@ -92,7 +109,7 @@ def test_emul_random_ctrl_free_running(scene):
     be = rc.EmulBackend(blob, 6)
     r = rc.free_running(be, blob, model, 6, 10, seed=11)
     _report(f"emulator {scene}", r)
-    _check_free_running(r, 0.6, scene)
+    _check_free_running(r, scene)
 
 
 @pytest.mark.parametrize("scene", SCENES)
@@ -105,15 +122,17 @@ def test_emul_state_synchronised_steps(scene):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("scene", SCENES)
+@pytest.mark.parametrize("scene", SCENES + ["stretch_kitchen_robocasa"])
 def test_gpu_random_ctrl_free_running_1000_steps(scene):
-    """16 heterogeneous envs x 1000 steps of the bench's action schedule on the HIP path, each against its own oracle."""
+    """16 heterogeneous envs x 1000 steps of the bench's action schedule on the HIP path, each against its own oracle -- north_star's
+    criterion on every bench scene, the kitchen at Robocasa scale (satellite builds, 82 dofs) included; an env outside 1e-4 must come
+    with an explained departure."""
     blob, model = _blob(scene)
     be = rc.HipBackend(scene, 16)
     r = rc.free_running(be, blob, model, 16, 20, seed=7)
     be.close()
     _report(f"HIP {scene}", r)
-    _check_free_running(r, GPU_MIN_INSIDE[scene], scene, GPU_MIN_INSIDE_EARLY.get(scene))
+    _check_free_running(r, scene)
 
 
 @pytest.mark.gpu
