@@ -19,6 +19,7 @@
 #include "smj_bvh.h"
 #include "smj_meshlet.h"
 #include "smj_render.h"
+#include "smj_comm.h"
 
 struct smj_ctx {
   int device = 0;
@@ -64,41 +65,11 @@ struct smj_ctx {
   void* slot_ptr[SMJ_SLOT_COUNT] = {};
   long slot_ld[SMJ_SLOT_COUNT] = {};
   // RCCL communicator of the env-sharded job (smj_comm_init); null in a single-GPU run
-  ncclComm_t comm = nullptr;
-  int comm_rank = 0, comm_world = 1;
+  SmjComm comm;
 };
 
-// RCCL is bound at run time (dlopen): a single-GPU user never loads it, and inside a PyTorch process the copy PyTorch has
-// already mapped is reused instead of a second one.
-struct RcclApi {
-  void* h = nullptr;
-  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  const char* (*GetErrorString)(ncclResult_t) = nullptr;
-};
-static RcclApi* rccl_api(std::string& err) {
-  static RcclApi api;
-  if (api.h) return &api;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  void* h = nullptr;
-  for (const char* n : names)
-    if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
-  for (int i = 0; !h && i < 3; i++) h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
-  if (!h) { err = std::string("librccl not found: ") + dlerror(); return nullptr; }
-  api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
-  api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
-  api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
-  api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
-  api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
-  if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy || !api.GetErrorString) {
-    err = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy";
-    return nullptr;
-  }
-  api.h = h;
-  return &api;
-}
+static_assert(sizeof(ncclUniqueId) == sizeof(SmjNcclId) && (int)ncclFloat == SMJ_NCCL_FLOAT32 && (int)ncclSuccess == SMJ_NCCL_SUCCESS && sizeof(ncclComm_t) == sizeof(void*),
+              "smj_comm.h spells out RCCL's ABI by hand");
 
 static int fail(smj_ctx* c, int code, const char* fmt, ...) {
   char buf[512];
@@ -364,94 +335,25 @@ int smj_create(const void* blob, size_t nbytes, int num_envs, int device, smj_ct
 
 int smj_comm_init(smj_ctx* c, int rank, int world, const char* id_path, double timeout_s) {
   if (!c) return -1;
-  if (world < 1 || rank < 0 || rank >= world) return fail(c, -1, "bad rank %d / world %d", rank, world);
-  if (c->comm) return fail(c, -1, "communicator already initialised");
-  if (world > 1 && (!id_path || !*id_path)) return fail(c, -1, "id_path is required for world > 1");
-  RcclApi* R = rccl_api(c->err);
-  if (!R) return -7;
   HIPCHK(c, hipSetDevice(c->device));
-  ncclUniqueId id;
-  memset(&id, 0, sizeof id);
-  // The id file: {magic, job nonce, ncclUniqueId}.  The nonce is a hash of what every rank of ONE job shares and two jobs do
-  // not (SMJ_JOB_NONCE if the launcher sets it, else MASTER_ADDR : MASTER_PORT : TORCHELASTIC_RUN_ID : WORLD_SIZE as torchrun
-  // exports them): a file left behind by an earlier job at the same path -- right size, wrong job -- is not accepted, and rank 0
-  // removes whatever is there before it publishes.  (With torch.distributed up, parallel.init_comm also puts a barrier between
-  // that removal and the readers' first look.)
-  struct IdFile { char magic[8]; uint64_t nonce; ncclUniqueId id; } rec;
-  memset(&rec, 0, sizeof rec);
-  memcpy(rec.magic, "SMJRCCL1", 8);
-  {
-    uint64_t h = 1469598103934665603ull;
-    auto mix = [&](const char* sv) { for (const char* p = sv ? sv : ""; *p; p++) { h ^= (unsigned char)*p; h *= 1099511628211ull; } h ^= 0xff; h *= 1099511628211ull; };
-    if (getenv("SMJ_JOB_NONCE")) mix(getenv("SMJ_JOB_NONCE"));
-    else { mix(getenv("MASTER_ADDR")); mix(getenv("MASTER_PORT")); mix(getenv("TORCHELASTIC_RUN_ID")); mix(getenv("WORLD_SIZE")); }
-    rec.nonce = h;
-  }
-  if (rank == 0) {
-    if (world > 1) remove(id_path);   // a stale file of an earlier job must not be readable while the new id is being made
-    ncclResult_t r = R->GetUniqueId(&id);
-    if (r != ncclSuccess) return fail(c, -7, "ncclGetUniqueId: %s", R->GetErrorString(r));
-    if (world > 1) {   // publish atomically: write a temporary, then rename
-      rec.id = id;
-      std::string tmp = std::string(id_path) + ".tmp";
-      FILE* f = fopen(tmp.c_str(), "wb");
-      if (!f || fwrite(&rec, sizeof rec, 1, f) != 1) { if (f) fclose(f); return fail(c, -7, "cannot write %s", tmp.c_str()); }
-      fclose(f);
-      if (rename(tmp.c_str(), id_path) != 0) return fail(c, -7, "cannot publish %s", id_path);
-    }
-  } else {
-    const double t_end = (timeout_s > 0 ? timeout_s : 120.0);
-    double waited = 0;
-    bool foreign = false;
-    for (;;) {
-      FILE* f = fopen(id_path, "rb");
-      if (f) {
-        IdFile got;
-        const size_t n = fread(&got, 1, sizeof got, f);
-        fclose(f);
-        if (n == sizeof got && !memcmp(got.magic, rec.magic, 8) && got.nonce == rec.nonce) { id = got.id; break; }
-        foreign = foreign || n > 0;   // something is there, but not this job's record: keep waiting for rank 0 to replace it
-      }
-      if (waited >= t_end)
-        return fail(c, -7, foreign ? "timed out: the RCCL id file %s belongs to another job (stale file? nonce mismatch)" : "timed out waiting for the RCCL id file %s", id_path);
-      struct timespec ts = {0, 20 * 1000 * 1000};
-      nanosleep(&ts, nullptr);
-      waited += 0.02;
-    }
-  }
-  ncclResult_t r = R->CommInitRank(&c->comm, world, id, rank);
-  if (r != ncclSuccess) { c->comm = nullptr; return fail(c, -7, "ncclCommInitRank: %s", R->GetErrorString(r)); }
-  c->comm_rank = rank;
-  c->comm_world = world;
-  return 0;
+  return smj_comm_open(c->comm, rank, world, id_path, timeout_s, c->err);   // binding, id-file rendezvous, ncclCommInitRank: smj_comm.h
 }
 
 int smj_allgather_returns(smj_ctx* c, const float* send_dev, float* recv_dev, int count, void* stream) {
   if (!c) return -1;
   if (!send_dev || !recv_dev || count <= 0) return fail(c, -1, "bad buffers / count");
-  if (!c->comm) {   // single-GPU job: the gather is a copy
-    HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->comm.comm) {   // single-GPU job: the gather is a copy
     if (send_dev != recv_dev)
       HIPCHK(c, hipMemcpyAsync(recv_dev, send_dev, sizeof(float) * (size_t)count, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return 0;
   }
-  RcclApi* R = rccl_api(c->err);
-  if (!R) return -7;
-  HIPCHK(c, hipSetDevice(c->device));
-  ncclResult_t r = R->AllGather(send_dev, recv_dev, (size_t)count, ncclFloat, c->comm, (hipStream_t)stream);
-  if (r != ncclSuccess) return fail(c, -7, "ncclAllGather: %s", R->GetErrorString(r));
-  return 0;
+  return smj_comm_allgather(c->comm, send_dev, recv_dev, count, stream, c->err);
 }
 
 int smj_comm_destroy(smj_ctx* c) {
   if (!c) return -1;
-  if (c->comm) {
-    RcclApi* R = rccl_api(c->err);
-    if (R) R->CommDestroy(c->comm);
-    c->comm = nullptr;
-    c->comm_world = 1;
-    c->comm_rank = 0;
-  }
+  smj_comm_close(c->comm);
   return 0;
 }
 

@@ -353,6 +353,8 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
   m.nsgeom = 0; m.nstatpair = 0; m.k_sgrec = m.k_sprec = m.k_spair = m.k_grid_adr = m.k_grid_list = m.k_sg_cell = nullptr; m.k_sg_bound = nullptr; m.k_sgw = nullptr;
   if (b.find("k_nsgeom")) {
     if (!geti("k_nsgeom", 0, &m.nsgeom) || !geti("k_nstatpair", 0, &m.nstatpair)) return -3;
+    if (m.nsgeom > 512) { err = "more than 512 static collision geoms (the static broadphase's candidate word holds 9 bits of static geom index)"; return -4; }
+    if (m.nstatpair > 0 && m.nsat == 0) { err = "static collision pairs (k_statpair) without satellites: only the satellite builds run collision_static; rebuild the blob (model_fuse.prepare_for_kernels)"; return -4; }
     if (m.nsgeom > 0) {
       for (int q = 0; q < 3; q++) { if (!geti("k_grid", q, &m.grid_dim[q]) || !getf("k_grid_f", q, &m.grid_org[q])) return -3; }
       if (!getf("k_grid_f", 3, &m.grid_h) || !getf("k_grid_f", 4, &m.grid_margin)) return -3;

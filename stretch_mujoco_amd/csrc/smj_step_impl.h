@@ -2504,7 +2504,7 @@ struct StepKernel {
       }
     }
     narrow_pair_run(r, g1, g2, s1, s2, sepslot, septag, sep_hit, sd, pc, prof);
-    if (mc && ncon > ncon0 && ncon - ncon0 <= 5) {   // keep what the narrowphase found, with the poses it was found at
+    if (mc && ncon > ncon0 && ncon - ncon0 <= 5 && ncon < NCON) {   // keep what the narrowphase found, with the poses it was found at -- unless the contact list is full: the manifold may be cut short, and the worker that redoes the step (same poses) must not replay it
       const int b1 = uni(r[SMJ_CP_B1]), b2 = uni(r[SMJ_CP_B2]), n = ncon - ncon0;
       SYNC();
       LANES {

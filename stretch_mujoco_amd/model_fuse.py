@@ -118,6 +118,9 @@ def _static_grid_tables(f, sp, slot, cell=0.25, maxdim=(48, 48, 16)):
     sg = sorted({int(g) for p in sp for g in (f["pair_geom1"][p], f["pair_geom2"][p]) if gb[g] == 0})
     sidx = {g: i for i, g in enumerate(sg)}
     nsg, ncg = len(sg), len(slot)
+    if nsg > 512:   # collision_static packs (static geom | cache slot << 9) into 16 bits (csrc/smj_sat.h, SatMem::cand)
+        raise ValueError(f"{nsg} static collision geoms in the world body: the satellite builds' static broadphase holds at most 512 "
+                         "(merge fixture pieces, or turn collision off for decorative geoms)")
     f["k_sgeom"] = np.array(sg + [0], np.int32); f["k_nsgeom"] = np.array([nsg], np.int32)
     f["k_statpair"] = np.array(sp + [0], np.int32); f["k_nstatpair"] = np.array([len(sp)], np.int32)
     tab = np.full((max(ncg, 1), max(nsg, 1)), -1, np.int32)
@@ -485,7 +488,10 @@ def prepare_for_kernels(m: Dict[str, np.ndarray], capacity: str = "auto", satell
         pg = set(int(g) for k in ("pair_geom1", "pair_geom2") for g in f[k] if f["geom_type"][int(g)] != 0)
         satellites = (len(f["dof_bodyid"]) > 64 or len(f["body_parentid"]) > 32 or len(pg) > 128) and find_satellites(f) > 0
     nsat = find_satellites(f) if satellites else 0
-    f = kernel_tables(f, nsat, static_grid=satellites)   # (the satellite builds carry the static-geometry grid)
+    # the static-geometry tables belong to the satellite builds: a model asked for with satellites=True in which nothing qualifies as a
+    # satellite runs on a dense build, whose convex-pair scan must keep the pairs against world-body geoms (collision_static is compiled
+    # for NSAT > 0 only)
+    f = kernel_tables(f, nsat, static_grid=nsat > 0)
     f["k_nsat"] = np.array([nsat], np.int32)
     f["k_capacity_hint"] = np.array([1 if capacity == "big" else 0], np.int32)
     return f
