@@ -119,7 +119,8 @@ def other_configs(B, dev, hold, solver):
 
     res = {}
 
-    def rollout(sim, n, chunk, settle=500, preroll=4):
+    def rollout(sim, n, chunk, settle=500, preroll=4, events=None):
+        """`events` (a list): HIP events around every timed sim.step (torch's current stream = the launch stream) are appended."""
         gen = torch.Generator(device=dev).manual_seed(99)
         lo = torch.tensor(sim.model["actuator_ctrlrange"][:, 0], dtype=torch.float32, device=dev).unsqueeze(1)
         hi = torch.tensor(sim.model["actuator_ctrlrange"][:, 1], dtype=torch.float32, device=dev).unsqueeze(1)
@@ -134,10 +135,39 @@ def other_configs(B, dev, hold, solver):
         while d < n:
             if d % hold == 0:
                 sim.ctrl.copy_(lo + (hi - lo) * torch.rand(sim.nu, sim.num_envs, generator=gen, device=dev))
+            if events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             sim.step(chunk)
+            if events is not None:
+                e1.record()
+                events.append((e0, e1, chunk))
             d += chunk
         torch.cuda.synchronize(dev)
         return sim.num_envs * d / (time.perf_counter() - t)
+
+    flops_table = {}
+    if os.path.exists(FLOPS_PER_ENV_STEP_FILE):
+        with open(FLOPS_PER_ENV_STEP_FILE) as fh:
+            flops_table = json.load(fh).get("scenes", {})
+
+    def roofline_of(sim, events, scene_key, kernel):
+        """The contract's roofline block for a scene other than the headline's, from THIS run's HIP events: algorithmic bytes = the state
+        a step has to read (qpos, qvel, ctrl, warm start) and write (qpos, qvel, warm start), fp32, x envs x steps of the timed launches
+        / their summed duration."""
+        nq, nv, nu = int(sim.qpos.shape[0]), int(sim.qvel.shape[0]), int(sim.nu)
+        bytes_step = 4.0 * ((nq + nv + nu + nv) + (nq + nv + nv))
+        ms = sum(a.elapsed_time(b) for a, b, _ in events)
+        steps = sum(k for _, _, k in events)
+        ach = sim.num_envs * steps * bytes_step / (ms / 1e3) / 1e9
+        r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+             "bytes_per_env_step": bytes_step, "kernel": kernel, "timed_launches": len(events), "timed_kernel_ms": ms,
+             "kernel_ms_per_step": ms / max(1, steps)}
+        fl = flops_table.get(scene_key, {}).get("flops_per_env_step")
+        if fl:
+            r["fp32"] = {"flops_per_env_step": fl, "achieved_tflops": fl * sim.num_envs * steps / (ms / 1e3) / 1e12, "peak_tflops": 157.3,
+                         "frac": fl * sim.num_envs * steps / (ms / 1e3) / 1e12 / 157.3}
+        return r
 
     def flags_of(sim):
         f = sim.info[3]
@@ -172,7 +202,10 @@ def other_configs(B, dev, hold, solver):
             continue
         sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver=solver, scene=scene)
         sim.start(home=False)
-        res[scene + "_physics"] = {"value": rollout(sim, 500, hold), "unit": "env-steps/s", **flags_of(sim)}   # 10 launches: one with a hand-over to the larger variant costs +30 %
+        evs = []
+        res[scene + "_physics"] = {"value": rollout(sim, 500, hold, events=evs), "unit": "env-steps/s", **flags_of(sim)}   # 10 launches: one with a hand-over to the larger variant costs +30 %
+        res[scene + "_physics"]["roofline"] = roofline_of(sim, evs, scene[:-4] if scene.endswith("_sat") else scene,
+                                                          "smj_step_kernel_sat (+ _sat32 workers)" if "robocasa" in scene or scene.endswith("_sat") else "smj_step_kernel (variant by model size)")
         if scene == "stretch_kitchen_robocasa":
             res[scene + "_physics"].update(dofs=sim.nv, kernel_variant="sat (16 satellites, 208 rows, 2 envs per CU) -> sat32 (320 rows) for steps beyond it; under PGS the two-wavefront build satp (satellite islands swept beside the dense system)",
                                            note="overflow_flags bit 2 = more than 64 contacts in one env (a lane count); rows / dense rows / coupled satellites hand over and are not flagged")
@@ -201,7 +234,11 @@ def other_configs(B, dev, hold, solver):
                 continue
             sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver="pgs", scene=scene)
             sim.start(home=False)
-            res[scene + "_physics_pgs"] = {"value": rollout(sim, n, hold, settle=200, preroll=1), "unit": "env-steps/s", **flags_of(sim)}
+            evs = []
+            res[scene + "_physics_pgs"] = {"value": rollout(sim, n, hold, settle=200, preroll=1, events=evs), "unit": "env-steps/s", **flags_of(sim)}
+            if scene == "stretch_kitchen_robocasa":
+                res[scene + "_physics_pgs"]["roofline"] = roofline_of(sim, evs, scene + ":pgs", "smj_step_kernel_satp (two wavefronts per env)")
+                res[scene + "_physics_pgs"]["solver_iterations_mean"] = float(sim.info[2].float().mean().item())
             sim.stop()
     # config 5 ingredient: both depth cameras, kitchen stand-in, rendered from the poses of the last step
     sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver=solver, scene="stretch_kitchen_standin",
@@ -370,15 +407,24 @@ def main():
         events.append((ev[0], ev[1], k))
         returns.add_(sim.base_pose[0])   # synthetic per-env return: accumulated forward displacement
 
-    barrier()
-    t0 = time.perf_counter()
-    rollout(args.steps, "timed", on_launch)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist_on:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    # The timed region: EXACTLY K steps between two barrier + synchronize brackets, max over ranks.  A K below one action interval is a
+    # single launch of a few milliseconds -- one sample, which moved the figure by +-4 % from round to round -- so such a region is
+    # measured `reps` times (each repetition its own bracket of exactly K steps, continuing the same action schedule) and the MEDIAN
+    # repetition is reported; every repetition is listed in `timed_region_ms`.
+    reps = 3 if args.steps < hold else 1
+    samples = []
+    for _ in range(reps):
+        barrier()
+        t0 = time.perf_counter()
+        rollout(args.steps, "timed", on_launch)
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist_on:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        samples.append(dt)
+    dt = sorted(samples)[len(samples) // 2]
     try:   # RCCL all-gather of per-env returns inside libsmj.so (the only collective of the path); after the timed region
         all_returns, gather_path = parallel.gather_returns_native(sim, returns)
     except Exception as e:   # never lose the measured line to the gather: fall back to torch.distributed's and say so
@@ -421,7 +467,8 @@ def main():
                                    f"(iterations<=100, tol 1e-8), elliptic cones impratio 20, implicitfast, dt=0.002",
                        "solver": args.solver, "envs_total": B_total,
                        "envs_per_gpu": B, "steps_per_action": hold, "parallelism": f"env-sharded x{world}",
-                       "returns_gathered": int(all_returns.numel()), "returns_gather_path": gather_path,
+                       "returns_gathered": int(all_returns.numel()), "ranks_seen": int(all_returns.numel()) // max(1, int(returns.numel())),
+                       "returns_gather_path": gather_path, "timed_region_ms": [round(x * 1e3, 3) for x in samples], "timed_region_reported": "median" if reps > 1 else "the one bracket",
                        "overflow_flags": flags, "envs_over_capacity_since_reset": flagged},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
