@@ -409,11 +409,14 @@ def main():
 
     # The timed region: EXACTLY K steps between two barrier + synchronize brackets, max over ranks.  A K below one action interval is a
     # single launch of a few milliseconds -- one sample, which moved the figure by +-4 % from round to round -- so such a region is
-    # measured `reps` times (each repetition its own bracket of exactly K steps, continuing the same action schedule) and the MEDIAN
+    # measured `reps` times (each repetition its own bracket of exactly K steps at the SAME phase of the action schedule: the untimed
+    # remainder of the action interval runs between two brackets, so the repetitions differ by their random actions only) and the MEDIAN
     # repetition is reported; every repetition is listed in `timed_region_ms`.
     reps = 3 if args.steps < hold else 1
     samples = []
-    for _ in range(reps):
+    for rep in range(reps):
+        if rep:
+            rollout((hold - args.steps) % hold, "between")
         barrier()
         t0 = time.perf_counter()
         rollout(args.steps, "timed", on_launch)

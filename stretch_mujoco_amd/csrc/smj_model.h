@@ -270,8 +270,13 @@ struct DevState {
   // at most the pose tolerance (3e-7 m: a few ulp of a metre-scale coordinate), three orders below the parity bounds.
   float* mcache;
 };
-enum { SMJ_SEP_SLOTS = 64, SMJ_MC_SLOTS = 32, SMJ_MC_WORDS = 40 };
+#ifndef SMJ_MC_LOG2
+#define SMJ_MC_LOG2 5
+#endif
+enum { SMJ_SEP_SLOTS = 64, SMJ_MC_SLOTS = 1 << SMJ_MC_LOG2, SMJ_MC_WORDS = 40 };
+#ifndef SMJ_MC_EPS
 #define SMJ_MC_EPS 3e-7f
+#endif
 enum { SMJ_PIPE_ABANDONED = 0x7fffffff, SMJ_PIPE_SWEPT = 0x7ffffffe, SMJ_HOT_LAUNCHES = 8 };
 enum { SMJ_SCHED_CLAIMED = 0, SMJ_SCHED_EXITED = 1, SMJ_SCHED_POLLERS = 2, SMJ_SCHED_COUNT = 3, SMJ_SCHED_WORDS = 4 };
 // BaseController state rows (floats; mode: 0 none, 1 translate-by, 2 rotate-by, 3 velocity)

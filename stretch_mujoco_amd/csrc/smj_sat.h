@@ -1156,6 +1156,13 @@ SMJ_DEV void collision_static(float* pc, bool prof) {
             ok = ok && fabsf((k < 3 ? s.xpos[b2][k] : s.xquat[b2][k - 3]) - w[8 + k]) <= SMJ_MC_EPS;
           }
           if (ok) { c = (int)w[15]; c = c < 0 ? 0 : c > 5 ? 5 : c; done[lane] = 1; }
+#ifdef SMJ_EMUL
+          else if (getenv("SMJ_SAT_TRACE")) {
+            float dmax = 0.f;
+            for (int k = 0; k < 7; k++) dmax = fmaxf(dmax, fabsf((k < 3 ? s.xpos[b1][k] : s.xquat[b1][k - 3]) - w[1 + k])), dmax = fmaxf(dmax, fabsf((k < 3 ? s.xpos[b2][k] : s.xquat[b2][k - 3]) - w[8 + k]));
+            fprintf(stderr, "  mcache miss: pair %d tag %s stored n %d pose delta %.2e\n", r[SMJ_CP_PAIR], __builtin_bit_cast(int, w[0]) == tag ? "ok" : "OTHER", (int)w[15], dmax);
+          }
+#endif
         }
         cnt[lane] = c;
       }

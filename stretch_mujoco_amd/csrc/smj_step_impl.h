@@ -2469,7 +2469,7 @@ struct StepKernel {
   // narrowphase of one convex pair: record r (DevModel::k_cprec / k_sprec), s1 / s2 = the geoms' slots in the collision stage's
   // LDS cache.  sepslot / septag: the pair's entry of the separating-direction cache (or null), sep_hit: it holds this pair's
   // direction sd.
-  SMJ_DEV float* mc_entry(int tag) const { return S.mcache + ((size_t)env * SMJ_MC_SLOTS + (((unsigned)tag * 2654435761u) >> 27)) * SMJ_MC_WORDS; }
+  SMJ_DEV float* mc_entry(int tag) const { return S.mcache + ((size_t)env * SMJ_MC_SLOTS + (((unsigned)tag * 2654435761u) >> (32 - SMJ_MC_LOG2))) * SMJ_MC_WORDS; }
   SMJ_DEV void narrow_pair(const int* r, int s1, int s2, float* sepslot, int septag, bool sep_hit, const float* sd, float* pc, bool prof, bool lookup = true) {
     const int g1 = uni(r[SMJ_CP_G1]), g2 = uni(r[SMJ_CP_G2]);
     // the pair's stored manifold (DevState::mcache): valid while neither body has moved

@@ -17,7 +17,7 @@ def lib(variant: str = "standard"):
     big = variant   # cache key
     if big not in _LIB:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
-        L = ctypes.CDLL(os.path.join(_HERE, {"standard": "libsmj_emul.so", "tall": "libsmj_emul_tall.so", "mid": "libsmj_emul_mid.so", "big": "libsmj_emul_big.so", "big38": "libsmj_emul_big38.so", "big50": "libsmj_emul_big50.so", "poison": "libsmj_emul_poison.so", "sat": "libsmj_emul_sat.so", "sat32": "libsmj_emul_sat32.so"}[variant]))
+        L = ctypes.CDLL(os.environ.get("SMJ_EMUL_LIB_" + variant.upper()) or os.path.join(_HERE, {"standard": "libsmj_emul.so", "tall": "libsmj_emul_tall.so", "mid": "libsmj_emul_mid.so", "big": "libsmj_emul_big.so", "big38": "libsmj_emul_big38.so", "big50": "libsmj_emul_big50.so", "poison": "libsmj_emul_poison.so", "sat": "libsmj_emul_sat.so", "sat32": "libsmj_emul_sat32.so"}[variant]))   # (SMJ_EMUL_LIB_<VARIANT>: an experimental build of that variant, tools only)
         L.emul_create.restype = ctypes.c_void_p
         L.emul_create.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
         L.emul_bind.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_long]
