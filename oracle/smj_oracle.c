@@ -60,6 +60,7 @@ struct smjo_model {
   double timestep, gravity[3], impratio, tolerance, meaninertia, lidar_cutoff;
   int iterations, cone, warmstart, pgs_fixed_iter, max_con_pair, solver, ls_iterations;
   int qcqp_cap;      /* iterates of mju_QCQP (20 = MuJoCo); option "qcqp_cap" */
+  int pgs_dual_warmstart; /* NOT MuJoCo (default 0): PGS may also start from the previous step's constraint forces, row by row (option "pgs_dual_warmstart"; the kernels' option of the same name) */
   int multiccd;      /* stretch.xml:8 <flag multiccd="enable"/>: multi-point contacts for convex pairs (default on) */
   double ls_tolerance;
   int *body_parentid, *body_weldid, *body_rootid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum;
@@ -116,6 +117,10 @@ struct smjo_data {
   double *efc_J, *efc_pos, *efc_margin, *efc_D, *efc_R, *efc_aref, *efc_b, *efc_force, *efc_vel, *efc_KBIP,
       *efc_diagApprox, *efc_frictionloss, *efc_AR;
   int *efc_type, *efc_id;
+  /* option pgs_dual_warmstart: the rows of the previous step (identity key, force) */
+  int prev_n;
+  long long* prev_key;
+  double* prev_force;
   double *gyro, *accel, *lidar;
   double* scratch;
 };
@@ -196,6 +201,7 @@ int smjo_set_option(smjo_model* m, const char* name, double v) {
   else if (!strcmp(name, "warmstart")) m->warmstart = (int)v;
   else if (!strcmp(name, "pgs_fixed_iter")) m->pgs_fixed_iter = (int)v;
   else if (!strcmp(name, "qcqp_cap")) m->qcqp_cap = (int)v;   /* per model; 20 = MuJoCo */
+  else if (!strcmp(name, "pgs_dual_warmstart")) m->pgs_dual_warmstart = (int)v;
   else if (!strcmp(name, "max_contacts_per_pair")) m->max_con_pair = (int)v;
   else if (!strcmp(name, "solver")) m->solver = (int)v; /* 0 = PGS (north_star), 2 = Newton (the reference model's default) */
   else if (!strcmp(name, "convex_pairs")) m->convex_pairs = (int)v;
@@ -1680,6 +1686,28 @@ static void constraint_update_force(const smjo_model* m, smjo_data* d, const dou
   }
 }
 
+/* identity of a constraint row across steps: (type, equality / dof / joint id) or, for a contact row, (geom pair, ordinal of the contact
+ * within its pair's manifold, row within the contact) */
+static long long row_key(const smjo_data* d, int i) {
+  int t = d->efc_type[i];
+  if (t == C_CONTACT_ELLIPTIC || t == C_CONTACT_FRICTIONLESS) {
+    int c = d->efc_id[i], ord = 0;
+    const contact_t* con = d->contact + c;
+    for (int k = c - 1; k >= 0 && d->contact[k].geom1 == con->geom1 && d->contact[k].geom2 == con->geom2; k--) ord++;
+    return ((long long)7 << 56) | ((long long)con->geom1 << 36) | ((long long)con->geom2 << 16) | (ord << 8) | (i - con->efc_address);
+  }
+  return ((long long)t << 56) | (unsigned)d->efc_id[i];
+}
+static double dual_cost(const smjo_data* d, const double* f, int ne) {
+  double cost = 0;
+  for (int i = 0; i < ne; i++) {
+    double s = 0;
+    for (int j = 0; j < ne; j++) s += d->efc_AR[(size_t)i * ne + j] * f[j];
+    cost += f[i] * (0.5 * s + d->efc_b[i]);
+  }
+  return cost;
+}
+
 /* [MJ] mj_fwdConstraint: warm start + mj_solPGS + dual->primal */
 static void fwd_constraint(const smjo_model* m, smjo_data* d) {
   int nv = m->nv, ne = d->nefc;
@@ -1715,6 +1743,35 @@ static void fwd_constraint(const smjo_model* m, smjo_data* d) {
       cost += f[i] * (0.5 * s + d->efc_b[i]);
     }
     if (cost > 0) memset(f, 0, sizeof(double) * ne);
+  }
+  if (m->pgs_dual_warmstart && d->prev_n > 0) {
+    /* NOT MuJoCo: a second candidate -- the forces the rows had at the end of the previous step's solve, matched by row identity and
+     * projected onto this step's bounds / cones; taken when its dual cost is below the start MuJoCo's rule gives.  The dual problem is
+     * strictly convex (R > 0): where the sweeps converge they converge to the same forces from either start. */
+    double* g = d->scratch + ne;
+    for (int i = 0; i < ne; i++) {
+      long long key = row_key(d, i);
+      g[i] = 0;
+      for (int j = 0; j < d->prev_n; j++) if (d->prev_key[j] == key) { g[i] = d->prev_force[j]; break; }
+    }
+    for (int i = 0; i < ne;) {
+      int t = d->efc_type[i];
+      if (t == C_FRICTION_DOF) { double fl = d->efc_frictionloss[i]; g[i] = fmin(fl, fmax(-fl, g[i])); i++; }
+      else if (t == C_LIMIT_JOINT || t == C_CONTACT_FRICTIONLESS) { g[i] = fmax(0, g[i]); i++; }
+      else if (t == C_CONTACT_ELLIPTIC) {
+        contact_t* con = d->contact + d->efc_id[i];
+        int dim = con->dim;
+        if (g[i] < MINVAL) { for (int j = 0; j < dim; j++) g[i + j] = 0; }
+        else {
+          double s2 = 0;
+          for (int j = 1; j < dim; j++) s2 += g[i + j] * g[i + j] / (con->friction[j - 1] * con->friction[j - 1]);
+          if (s2 > g[i] * g[i]) { double sc = g[i] / sqrt(s2); for (int j = 1; j < dim; j++) g[i + j] *= sc; }
+        }
+        i += dim;
+      } else i++;
+    }
+    double c0 = dual_cost(d, f, ne), c1 = dual_cost(d, g, ne);
+    if (c1 < c0) memcpy(f, g, sizeof(double) * ne);
   }
   double scale = 1.0 / (m->meaninertia * (nv > 1 ? nv : 1));
   int iter = 0;
@@ -1793,6 +1850,12 @@ static void fwd_constraint(const smjo_model* m, smjo_data* d) {
     if (!m->pgs_fixed_iter && improvement < m->tolerance) { iter++; break; }
   }
   d->solver_niter = iter;
+  if (m->pgs_dual_warmstart) {
+    d->prev_key = (long long*)realloc(d->prev_key, sizeof(long long) * (ne + 1));
+    d->prev_force = (double*)realloc(d->prev_force, sizeof(double) * (ne + 1));
+    for (int i = 0; i < ne; i++) { d->prev_key[i] = row_key(d, i); d->prev_force[i] = f[i]; }
+    d->prev_n = ne;
+  }
   for (int k = 0; k < nv; k++) {
     double s = 0;
     for (int i = 0; i < ne; i++) s += d->efc_J[(size_t)i * nv + k] * f[i];

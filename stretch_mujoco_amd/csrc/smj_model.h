@@ -265,9 +265,12 @@ struct DevState {
   float* sepcache;
   // Contact manifolds of convex pairs (null = off): [B][SMJ_MC_SLOTS][SMJ_MC_WORDS], direct-mapped by pair key.  An entry holds the
   // poses (xpos, xquat) the pair's two BODIES had when its narrowphase last ran and the contacts it found; while both poses are
-  // within SMJ_MC_EPS of those, the pair's contacts are the stored ones and MPR / multiccd / the box-box polygon are skipped --
-  // an object resting on a counter costs one 160-byte load per step instead of five penetration queries.  The contacts move by
-  // at most the pose tolerance (3e-7 m: a few ulp of a metre-scale coordinate), three orders below the parity bounds.
+  // within SMJ_MC_EPS of those, the pair keeps that manifold and MPR / multiccd / the box-box polygon are skipped -- an object
+  // resting on a counter costs one 160-byte load per step instead of five penetration queries.  Round 5: the kept manifold MOVES
+  // WITH THE BODIES to first order (smj_mc_motion): a contact point p rides on both bodies, its depth changes by the normal component
+  // of their relative displacement at p, dist' = dist + n . (u2(p) - u1(p)), u_b(p) = dx_b + dtheta_b x (p - x_b).  What is dropped is
+  // second order in the motion since the manifold was built (<= SMJ_MC_EPS^2 / feature size: 1e-9 m), far below MPR's own 1e-6 m
+  // tolerance -- which is what made resting bodies jitter by 1e-6 per step and miss the round-4 cache (3e-7, no update) every step.
   float* mcache;
 };
 #ifndef SMJ_MC_LOG2
@@ -275,7 +278,7 @@ struct DevState {
 #endif
 enum { SMJ_SEP_SLOTS = 64, SMJ_MC_SLOTS = 1 << SMJ_MC_LOG2, SMJ_MC_WORDS = 40 };
 #ifndef SMJ_MC_EPS
-#define SMJ_MC_EPS 3e-7f
+#define SMJ_MC_EPS 2e-5f
 #endif
 enum { SMJ_PIPE_ABANDONED = 0x7fffffff, SMJ_PIPE_SWEPT = 0x7ffffffe, SMJ_HOT_LAUNCHES = 8 };
 enum { SMJ_SCHED_CLAIMED = 0, SMJ_SCHED_EXITED = 1, SMJ_SCHED_POLLERS = 2, SMJ_SCHED_COUNT = 3, SMJ_SCHED_WORDS = 4 };

@@ -1184,10 +1184,18 @@ SMJ_DEV void collision_static(float* pc, bool prof) {
             const int* r = M.k_sprec + sid * SMJ_CP_STRIDE;
             const float* mc = mc_entry(0x40000000 | sid);
             const float nrm[3] = {mc[16], mc[17], mc[18]};
+            const int b1 = r[SMJ_CP_B1], b2 = r[SMJ_CP_B2];
+            float x0a[3], q0a[4], x0b[3], q0b[4], x1a[3], q1a[4], x1b[3], q1b[4], dxa[3], dta[3], dxb[3], dtb[3];
+            for (int k = 0; k < 3; k++) { x0a[k] = mc[1 + k]; x0b[k] = mc[8 + k]; x1a[k] = s.xpos[b1][k]; x1b[k] = s.xpos[b2][k]; }
+            for (int k = 0; k < 4; k++) { q0a[k] = mc[4 + k]; q0b[k] = mc[11 + k]; q1a[k] = s.xquat[b1][k]; q1b[k] = s.xquat[b2][k]; }
+            smj_mc_motion(x0a, q0a, x1a, q1a, dxa, dta);
+            smj_mc_motion(x0b, q0b, x1b, q1b, dxb, dtb);
             for (int k = 0; k < c; k++)
               if (off + k < NCON) {
-                const float p3[3] = {mc[20 + 4 * k], mc[21 + 4 * k], mc[22 + 4 * k]};
-                write_contact(off + k, r, mc[19 + 4 * k], p3, nrm);
+                float p3[3] = {mc[20 + 4 * k], mc[21 + 4 * k], mc[22 + 4 * k]};
+                float dist = mc[19 + 4 * k];
+                smj_mc_carry(x0a, dxa, dta, x0b, dxb, dtb, nrm, dist, p3);
+                write_contact(off + k, r, dist, p3, nrm);
               }
           }
         }

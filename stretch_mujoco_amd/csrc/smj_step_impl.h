@@ -2469,6 +2469,24 @@ struct StepKernel {
   // narrowphase of one convex pair: record r (DevModel::k_cprec / k_sprec), s1 / s2 = the geoms' slots in the collision stage's
   // LDS cache.  sepslot / septag: the pair's entry of the separating-direction cache (or null), sep_hit: it holds this pair's
   // direction sd.
+  // motion of a body since a manifold was stored: translation dx and small rotation vector dth (= 2 vec(q1 conj(q0)), q = w x y z)
+  SMJ_DEV static void smj_mc_motion(const float* x0, const float* q0, const float* x1, const float* q1, float* dx, float* dth) {
+    for (int k = 0; k < 3; k++) dx[k] = x1[k] - x0[k];
+    const float sw = q1[0] * q0[0] + q1[1] * q0[1] + q1[2] * q0[2] + q1[3] * q0[3];
+    const float sg = sw < 0.f ? -2.f : 2.f;
+    dth[0] = sg * (q0[0] * q1[1] - q1[0] * q0[1] - (q1[2] * q0[3] - q1[3] * q0[2]));
+    dth[1] = sg * (q0[0] * q1[2] - q1[0] * q0[2] - (q1[3] * q0[1] - q1[1] * q0[3]));
+    dth[2] = sg * (q0[0] * q1[3] - q1[0] * q0[3] - (q1[1] * q0[2] - q1[2] * q0[1]));
+  }
+  // a stored contact (dist, p, normal n from geom 1 to geom 2) carried along by the two bodies: u_b(p) = dx_b + dth_b x (p - x_b)
+  SMJ_DEV static void smj_mc_carry(const float* xa, const float* dxa, const float* dta, const float* xb, const float* dxb, const float* dtb, const float* n,
+                                   float& dist, float* p) {
+    const float ra[3] = {p[0] - xa[0], p[1] - xa[1], p[2] - xa[2]}, rb[3] = {p[0] - xb[0], p[1] - xb[1], p[2] - xb[2]};
+    const float ua[3] = {dxa[0] + dta[1] * ra[2] - dta[2] * ra[1], dxa[1] + dta[2] * ra[0] - dta[0] * ra[2], dxa[2] + dta[0] * ra[1] - dta[1] * ra[0]};
+    const float ub[3] = {dxb[0] + dtb[1] * rb[2] - dtb[2] * rb[1], dxb[1] + dtb[2] * rb[0] - dtb[0] * rb[2], dxb[2] + dtb[0] * rb[1] - dtb[1] * rb[0]};
+    dist += n[0] * (ub[0] - ua[0]) + n[1] * (ub[1] - ua[1]) + n[2] * (ub[2] - ua[2]);
+    for (int k = 0; k < 3; k++) p[k] += 0.5f * (ua[k] + ub[k]);
+  }
   SMJ_DEV float* mc_entry(int tag) const { return S.mcache + ((size_t)env * SMJ_MC_SLOTS + (((unsigned)tag * 2654435761u) >> (32 - SMJ_MC_LOG2))) * SMJ_MC_WORDS; }
   SMJ_DEV void narrow_pair(const int* r, int s1, int s2, float* sepslot, int septag, bool sep_hit, const float* sd, float* pc, bool prof, bool lookup = true) {
     const int g1 = uni(r[SMJ_CP_G1]), g2 = uni(r[SMJ_CP_G2]);
@@ -2493,9 +2511,16 @@ struct StepKernel {
       if (lookup && __builtin_bit_cast(int, wave_read(w, 0)) == septag && wave_ballot(moved) == 0) {
         const int n = (int)wave_read(w, 15);
         const float nrm[3] = {wave_read(w, 16), wave_read(w, 17), wave_read(w, 18)};
+        float x0a[3], q0a[4], x0b[3], q0b[4], x1a[3], q1a[4], x1b[3], q1b[4], dxa[3], dta[3], dxb[3], dtb[3];
+        for (int k = 0; k < 3; k++) { x0a[k] = wave_read(w, 1 + k); x0b[k] = wave_read(w, 8 + k); x1a[k] = uni(s.xpos[b1][k]); x1b[k] = uni(s.xpos[b2][k]); }
+        for (int k = 0; k < 4; k++) { q0a[k] = wave_read(w, 4 + k); q0b[k] = wave_read(w, 11 + k); q1a[k] = uni(s.xquat[b1][k]); q1b[k] = uni(s.xquat[b2][k]); }
+        smj_mc_motion(x0a, q0a, x1a, q1a, dxa, dta);
+        smj_mc_motion(x0b, q0b, x1b, q1b, dxb, dtb);
         for (int k = 0; k < n && k < 5; k++) {
-          const float p3[3] = {wave_read(w, 20 + 4 * k), wave_read(w, 21 + 4 * k), wave_read(w, 22 + 4 * k)};
-          add_contact(r, wave_read(w, 19 + 4 * k), p3, nrm);
+          float p3[3] = {wave_read(w, 20 + 4 * k), wave_read(w, 21 + 4 * k), wave_read(w, 22 + 4 * k)};
+          float dist = wave_read(w, 19 + 4 * k);
+          smj_mc_carry(x0a, dxa, dta, x0b, dxb, dtb, nrm, dist, p3);
+          add_contact(r, dist, p3, nrm);
         }
 #ifdef SMJ_EMUL
         smj_emul_mc_hits++;
