@@ -330,6 +330,14 @@ int smj_create(const void* blob, size_t nbytes, int num_envs, int device, smj_ct
     HIPCHK(c, hipMemset(d, 0, bytes));
     c->state.mcache = (float*)d;
   }
+  if (c->caps.nsat > 0) {   // PGS on the satellite builds: the previous step's rows and forces (DevState::pgsprev)
+    void* d = nullptr;
+    const size_t bytes = sizeof(float) * SMJ_PGSPREV_STRIDE * (size_t)num_envs;
+    HIPCHK(c, hipMalloc(&d, bytes));
+    c->allocs.push_back(d);
+    HIPCHK(c, hipMemset(d, 0, bytes));
+    c->state.pgsprev = (float*)d;
+  }
   return setup_render(c, blob, nbytes);
 }
 
@@ -481,7 +489,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
     DevModel& mb = c->model_esc;
     const DevModel& ms = c->model;
     mb.iterations = ms.iterations; mb.warmstart = ms.warmstart; mb.pgs_fixed_iter = ms.pgs_fixed_iter; mb.qcqp_exact = ms.qcqp_exact; mb.grad_noise = ms.grad_noise; mb.pgs_island_stop = ms.pgs_island_stop; mb.max_con_pair = ms.max_con_pair;
-    mb.solver = ms.solver; mb.ls_iterations = ms.ls_iterations; mb.convex_pairs = ms.convex_pairs; mb.multiccd = ms.multiccd; mb.multi_serial = ms.multi_serial; mb.sep_cache = ms.sep_cache; mb.manifold_cache = ms.manifold_cache;
+    mb.solver = ms.solver; mb.ls_iterations = ms.ls_iterations; mb.convex_pairs = ms.convex_pairs; mb.multiccd = ms.multiccd; mb.multi_serial = ms.multi_serial; mb.sep_cache = ms.sep_cache; mb.manifold_cache = ms.manifold_cache; mb.pgs_dual_ws = ms.pgs_dual_ws;
     mb.ls_tolerance = ms.ls_tolerance; mb.tolerance = ms.tolerance;
   }
   smj_launch_stage(in, c->stage, Y.stride, c->num_envs, st.ld, false, (hipStream_t)stream);
@@ -661,6 +669,7 @@ int smj_set_option(smj_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "multiccd")) m.multiccd = (int)v;
   else if (!strcmp(name, "sep_cache")) m.sep_cache = (int)v;
   else if (!strcmp(name, "manifold_cache")) m.manifold_cache = (int)v;
+  else if (!strcmp(name, "pgs_dual_warmstart")) m.pgs_dual_ws = (int)v;
   else if (!strcmp(name, "depth_raster")) c->render.raster = (int)v;            // 0: ray cast the meshes through their BVHs (the round-2 path)
   else if (!strcmp(name, "depth_raster_splits")) c->render.raster_splits = (int)(v < 1 ? 1 : v > 256 ? 256 : v);
   else if (!strcmp(name, "primary_rows")) m.row_limit = (int)v;   // the escalation variant keeps its full capacity (model_esc is not touched)

@@ -291,7 +291,7 @@ int smj_load_model(const void* blob, size_t nbytes, DevModel& m, Up& up, std::st
     const SmjBlobEntry* e = b.find("sensor_lidar_site");
     m.nlidar = e ? (int)(e->nbytes / 4) : 0;
   }
-  m.row_limit = 0; m.pgs_cap = 0; m.warmstart = 1; m.pgs_fixed_iter = 0; m.qcqp_exact = 0; m.grad_noise = 4e-6f; m.pgs_island_stop = 1; m.max_con_pair = 4; m.solver = 0; m.convex_pairs = 1; m.multiccd = 1; m.sep_cache = getenv("SMJ_NO_SEPCACHE") ? 0 : 1; m.manifold_cache = (getenv("SMJ_NO_MCACHE") || m.nv_all <= 32) ? 0 : 1;   /* pays where free objects rest; a robot alone (<= 32 dofs) has no resting convex pair and the lookup cost the headline 1 % */ m.multi_serial = 0; m.ls_iterations = 50; m.ls_tolerance = 0.01f;
+  m.row_limit = 0; m.pgs_cap = 0; m.warmstart = 1; m.pgs_fixed_iter = 0; m.qcqp_exact = 0; m.grad_noise = 4e-6f; m.pgs_island_stop = 1; m.pgs_dual_ws = 1; m.max_con_pair = 4; m.solver = 0; m.convex_pairs = 1; m.multiccd = 1; m.sep_cache = getenv("SMJ_NO_SEPCACHE") ? 0 : 1; m.manifold_cache = (getenv("SMJ_NO_MCACHE") || m.nv_all <= 32) ? 0 : 1;   /* pays where free objects rest; a robot alone (<= 32 dofs) has no resting convex pair and the lookup cost the headline 1 % */ m.multi_serial = 0; m.ls_iterations = 50; m.ls_tolerance = 0.01f;
   char buf[256];
   int pick = -1, first = 0;
   {   // optional hint of the model compiler: contact-rich scene, start at the big variant (model_fuse.prepare_for_kernels)

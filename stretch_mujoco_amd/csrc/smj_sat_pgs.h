@@ -227,6 +227,20 @@ SMJ_DEV void pgs_helper() {
 }
 #endif
 
+// Identity of a constraint row from one step to the next (option pgs_dual_ws): a static / limit row is its record (DevModel::k_rowrec:
+// one per equality, friction-loss dof and joint-limit side); a contact row is (collision pair, ordinal of the contact within the pair's
+// manifold -- a pair's contacts are contiguous in the list --, row within the contact).
+SMJ_DEV int pgs_row_key(int row) const {
+  const int t = s.etype[row];
+  if (t == CT_CONTACT_ELLIPTIC || t == CT_CONTACT_FRICTIONLESS) {
+    const int c = s.eid[row], pr = s.cpair[c];
+    int ord = 0;
+    for (int k = c - 1; k >= 0 && s.cpair[k] == pr; k--) ord++;
+    return (int)(0x80000000u | ((unsigned)pr << 6) | ((unsigned)(ord & 7) << 3) | (unsigned)((row - s.cefc[c]) & 7));
+  }
+  return 0x40000000 | (int)s.sat.erec[row];
+}
+
 #define PSETS(p, ne) _Pragma("unroll") for (int p = 0; p < NP; p++) if (p == 0 || (ne) > 64 * p)
 #define PSETS_ALL(p) _Pragma("unroll") for (int p = 0; p < NP; p++)
 SMJ_DEV void solve_pgs_sat(bool dbg, float* pc, long long& t0, bool prof) {
@@ -521,37 +535,97 @@ SMJ_DEV void pgs_sat_core(PL<float>& u, bool dbg, float* pc, long long& t0, bool
     }
   }
   SYNC();
-  // residual r = A f + b and the dual cost of the warm start: the dense system (lane = row) + the satellite islands (lane = satellite)
-  PL<float> cost;
-  PL<float[6]> zs;   // lane = satellite: z = sum y_i f_i of its island
-  LANES { cost[lane] = 0.f; for (int k = 0; k < 6; k++) zs[lane][k] = 0.f; }
-  PSETS_ALL(p) LANES {
-    const int i = lane + 64 * p;
-    f_r[p][lane] = i < ndp ? s.ef[drow_r[p][lane]] : 0.f;
-    r_r[p][lane] = 0.f;
-  }
-  residual_refresh<WIDE>(bb);
-  PSETS(p, ndp) LANES { cost[lane] += lane + 64 * p < ndp ? f_r[p][lane] * 0.5f * (r_r[p][lane] + bb[p][lane]) : 0.f; }
-  LANES {
-    const int si = lane - 32;
-    if (lane >= 32 && si < nsat && s.sat.ext[si] < 0) {
-      float z[6], cs = 0;
-      sat_yf(si, z);
-      for (int it = 0; it < s.sat.nitem[si]; it++) {
-        const int r0 = s.sat.irow[si][it], n = s.sat.iinf[si][it] & ITEM_N;
-        for (int p = 0; p < n; p++) {
-          const float* y = s.sat.Js[r0 + p];
-          const float f = s.ef[r0 + p], b = s.eb[r0 + p];
-          float r = s.eR[r0 + p] * f + b;
-          for (int k = 0; k < 6; k++) r += y[k] * z[k];
-          cs += f * 0.5f * (r + b);
+  // ---- NOT MuJoCo (option pgs_dual_ws, default on): a second start -- the forces the rows had at the end of the PREVIOUS step's
+  // solve (DevState::pgsprev), matched by row identity, projected onto this step's bounds and cones -- taken when its dual cost is
+  // below that of MuJoCo's start.  The dual problem is strictly convex (R > 0), so where the sweeps converge they converge to the same
+  // forces from either start; what changes is how many sweeps that takes: a kitchen's resting contacts carry the same forces from
+  // step to step, while MuJoCo's start (the primal residual at qacc_warmstart pushed through the constraint update) lands far enough
+  // from them that 100 sweeps never got there (fp64 oracle, Robocasa-scale kitchen: 100 sweeps on every step -> 19 settled / 71
+  // under random actions; oracle option pgs_dual_warmstart).
+  bool have_prev = false;
+  if (M.pgs_dual_ws && S.pgsprev) {
+    const int* const pk = reinterpret_cast<const int*>(S.pgsprev + (size_t)env * SMJ_PGSPREV_STRIDE);
+    const float* const pf = S.pgsprev + (size_t)env * SMJ_PGSPREV_STRIDE + 1 + SMJ_PGSPREV_ROWS;
+    int np = uni(pk[0]);
+    np = np < 0 ? 0 : np > SMJ_PGSPREV_ROWS ? SMJ_PGSPREV_ROWS : np;
+    if (np > 0) {
+      have_prev = true;
+#pragma nounroll
+      for (int rb = 0; rb < ne; rb += 64) LANES {
+        const int row = lane + rb;
+        if (row < ne) {
+          const int key = pgs_row_key(row), t = s.etype[row];
+          float f = 0.f;
+          for (int j = 0; j < np; j++) f = pk[1 + j] == key ? pf[j] : f;
+          if (t == CT_FRICTION) { const float fl = s.efloss[row]; f = fminf(fl, fmaxf(-fl, f)); }
+          else if (t == CT_LIMIT || t == CT_CONTACT_FRICTIONLESS) f = fmaxf(0.f, f);
+          s.ediag[row] = f;   // (free: the warm start above was the last reader of J qacc_warmstart - aref)
         }
       }
-      cost[lane] += cs;
-      for (int k = 0; k < 6; k++) zs[lane][k] = z[k];
+      SYNC();
+      LANES {
+        if (lane < ncon) {
+          const int c = lane, i = s.cefc[c], dim = s.cdim[c];
+          if (i >= 0 && dim >= 3) {
+            const float fn = s.ediag[i];
+            if (fn < SMJ_MINVAL) { for (int j = 0; j < dim; j++) s.ediag[i + j] = 0.f; }
+            else {
+              float s2 = 0.f;
+              for (int j = 1; j < dim; j++) { const float tq = s.ediag[i + j] * fast_rcp(s.cfric[c][j - 1]); s2 += tq * tq; }
+              if (s2 > fn * fn) { const float sc = fn * fast_rsqrt(s2); for (int j = 1; j < dim; j++) s.ediag[i + j] *= sc; }
+            }
+          }
+        }
+      }
+      SYNC();
     }
   }
-  const float wcost = wave_sum(cost);
+  // residual r = A f + b and the dual cost of a start: the dense system (lane = row) + the satellite islands (lane = satellite).
+  // Pass 0: MuJoCo's start (s.ef).  Pass 1: the previous step's forces, swapped into s.ef; kept when cheaper.  Pass 2: MuJoCo's once
+  // more when it was the better one (the registers hold the state of the start evaluated last).
+  PL<float> cost;
+  PL<float[6]> zs;   // lane = satellite: z = sum y_i f_i of its island
+  float wcost = 0.f;
+  for (int pass = 0;; pass++) {
+    LANES { cost[lane] = 0.f; for (int k = 0; k < 6; k++) zs[lane][k] = 0.f; }
+    PSETS_ALL(p) LANES {
+      const int i = lane + 64 * p;
+      f_r[p][lane] = i < ndp ? s.ef[drow_r[p][lane]] : 0.f;
+      r_r[p][lane] = 0.f;
+    }
+    residual_refresh<WIDE>(bb);
+    PSETS(p, ndp) LANES { cost[lane] += lane + 64 * p < ndp ? f_r[p][lane] * 0.5f * (r_r[p][lane] + bb[p][lane]) : 0.f; }
+    LANES {
+      const int si = lane - 32;
+      if (lane >= 32 && si < nsat && s.sat.ext[si] < 0) {
+        float z[6], cs = 0;
+        sat_yf(si, z);
+        for (int it = 0; it < s.sat.nitem[si]; it++) {
+          const int r0 = s.sat.irow[si][it], n = s.sat.iinf[si][it] & ITEM_N;
+          for (int p = 0; p < n; p++) {
+            const float* y = s.sat.Js[r0 + p];
+            const float f = s.ef[r0 + p], b = s.eb[r0 + p];
+            float r = s.eR[r0 + p] * f + b;
+            for (int k = 0; k < 6; k++) r += y[k] * z[k];
+            cs += f * 0.5f * (r + b);
+          }
+        }
+        cost[lane] += cs;
+        for (int k = 0; k < 6; k++) zs[lane][k] = z[k];
+      }
+    }
+    const float cst = wave_sum(cost);
+    bool swap = false;
+    if (pass == 0) { wcost = cst; swap = have_prev; }
+    else if (pass == 1) { if (cst < wcost) wcost = cst; else swap = true; }
+    if (!swap) break;
+#pragma nounroll
+    for (int rb = 0; rb < ne; rb += 64) LANES {
+      const int row = lane + rb;
+      if (row < ne) { const float tq = s.ef[row]; s.ef[row] = s.ediag[row]; s.ediag[row] = tq; }
+    }
+    SYNC();
+  }
   if (wcost > 0) {
     PSETS(p, ndp) LANES { f_r[p][lane] = 0.f; r_r[p][lane] = bb[p][lane]; }
     ROWPASS(rb, ne) LANES { if (lane + rb < ne) s.ef[lane + rb] = 0.f; }
@@ -654,6 +728,17 @@ SMJ_DEV void pgs_sat_core(PL<float>& u, bool dbg, float* pc, long long& t0, bool
   // ---- forces back to their rows; qacc = M^-1 (qfrc_smooth + J' f)
   PSETS_ALL(p) LANES { const int i = lane + 64 * p; if (i < ndp) s.ef[drow_r[p][lane]] = f_r[p][lane]; }
   SYNC();
+  if (M.pgs_dual_ws && S.pgsprev) {   // the rows of this step and where their forces ended: the next step's second start
+    int* const pk = reinterpret_cast<int*>(S.pgsprev + (size_t)env * SMJ_PGSPREV_STRIDE);
+    float* const pf = S.pgsprev + (size_t)env * SMJ_PGSPREV_STRIDE + 1 + SMJ_PGSPREV_ROWS;
+    const int nst = ne < SMJ_PGSPREV_ROWS ? ne : SMJ_PGSPREV_ROWS;
+#pragma nounroll
+    for (int rb = 0; rb < nst; rb += 64) LANES {
+      const int row = lane + rb;
+      if (row < nst) { pk[1 + row] = pgs_row_key(row); pf[row] = s.ef[row]; }
+    }
+    LANES { if (lane == 0) pk[0] = nst; }
+  }
   PL<float> w, qc;
   LANES {
     float v = 0;

@@ -54,6 +54,8 @@ emul_ctx* emul_create(const void* blob, size_t nbytes, int num_envs) {
   c->keep.push_back(c->s.sepcache);
   c->s.mcache = (float*)calloc((size_t)num_envs * SMJ_MC_SLOTS * SMJ_MC_WORDS, sizeof(float));
   c->keep.push_back(c->s.mcache);
+  c->s.pgsprev = (float*)calloc((size_t)num_envs * SMJ_PGSPREV_STRIDE, sizeof(float));
+  c->keep.push_back(c->s.pgsprev);
   return c;
 }
 void emul_destroy(emul_ctx* c) {
@@ -102,6 +104,7 @@ int emul_set_option(emul_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "multi_serial")) m.multi_serial = (int)v;
   else if (!strcmp(name, "sep_cache")) m.sep_cache = (int)v;
   else if (!strcmp(name, "manifold_cache")) m.manifold_cache = (int)v;
+  else if (!strcmp(name, "pgs_dual_warmstart")) m.pgs_dual_ws = (int)v;
   else return -1;
   return 0;
 }

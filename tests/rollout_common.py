@@ -29,12 +29,14 @@ def ctrl_schedule(model, nu, B, windows, seed):
     return [(cr[:, 0][:, None] + (cr[:, 1] - cr[:, 0])[:, None] * rng.random((nu, B))).astype(np.float32) for _ in range(windows)]
 
 
-def settled_oracles(blob, B, solver=2, settle=500):
-    """B oracles settled at the home keyframe from qpos0 (the bench's start)."""
+def settled_oracles(blob, B, solver=2, settle=500, options=None):
+    """B oracles settled at the home keyframe from qpos0 (the bench's start).  options: {name: value} set on every oracle."""
     out = []
     for _ in range(B):
         o = Oracle(blob)
         o.set_option("solver", solver)
+        for k, v in (options or {}).items():
+            o.set_option(k, v)
         nu = o.dim("nu")
         o.arr("ctrl")[:nu] = HOME[:nu]
         o.step(settle)
@@ -283,10 +285,10 @@ def _same_contacts_same_dynamics(blob, solver, state, ctrl, qacc_kernel, dump, n
     return bool(err < tol), float(err)
 
 
-def state_synchronised(backend, blob, model, B, windows, seed, solver=2):
+def state_synchronised(backend, blob, model, B, windows, seed, solver=2, oracle_options=None):
     """Per-step comparison on identical inputs.  Returns (relative qacc errors [steps*B], events) where every event is a dict
     with the step, the error and whether a 1e-7 perturbation of the oracle's input reproduces the kernel's result."""
-    oracles = settled_oracles(blob, B, solver)
+    oracles = settled_oracles(blob, B, solver, options=oracle_options)
     nu, nv = oracles[0].dim("nu"), oracles[0].dim("nv")
     sched = ctrl_schedule(model, nu, B, windows, seed)
     rel, events = [], []

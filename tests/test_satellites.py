@@ -243,6 +243,7 @@ def _pgs_backends(scenes, B):
         blob, model = _blob(sc)
         be = rc.EmulBackend(blob, B, solver=0)
         be.e.set_option("qcqp_exact", 1)   # MuJoCo's own QCQP iteration (the oracle's), so that the sweeps are the only difference
+        be.e.set_option("pgs_dual_warmstart", 0)   # MuJoCo's warm start on both sides (the dense builds have no other)
         out.append((blob, model, be))
     return out
 
@@ -284,20 +285,32 @@ def test_emul_pgs_islands_equal_the_serial_sweep():
     assert all(a == b for a, b in iters[:5]), iters[:5]   # one iteration count for the whole system, as the serial sweep's
 
 
+@pytest.mark.parametrize("dual", [0, 1])
 @pytest.mark.parametrize("scene,variant", [("stretch_kitchen_export_sat", None), ("stretch_kitchen_robocasa", "sat32")])
-def test_emul_pgs_satellite_build_state_synchronised(scene, variant):
+def test_emul_pgs_satellite_build_state_synchronised(scene, variant, dual):
     """PGS with hinged / sliding fixture parts among the satellites (friction-loss and limit rows on satellite lanes) and, in the
     kitchen at Robocasa scale, objects the robot pushes (coupled satellites in the dense system): one-step accelerations of every
-    dof against the fp64 PGS oracle, contact lists pair by pair."""
+    dof against the fp64 PGS oracle, contact lists pair by pair.  dual = 0: MuJoCo's warm start on both sides -- 100 sweeps on every
+    step, neither side converged, the remainder carries the sweeps' rounding.  dual = 1 (the kernels' default, round 5): both sides may
+    also start from the previous step's forces (option pgs_dual_warmstart, same fixed point): a quarter of the sweeps, and the two
+    CONVERGED answers agree to p99 < 5e-3 (VERDICT r4 item 2's bound; observed 2.3e-3, max 2.8e-3 where dual = 0 gives 5.7e-3 / 1.2e-2)."""
     blob, model = _blob(scene)
     be = rc.EmulBackend(blob, 2, solver=0, variant=variant)
     be.e.set_option("qcqp_exact", 1)
-    rel, events = rc.state_synchronised(be, blob, model, 2, 2, seed=5, solver=0)
+    be.e.set_option("pgs_dual_warmstart", dual)
+    sweeps = []
+    step = be.step
+    be.step = lambda n: (step(n), sweeps.append(float(be.e.info[2].mean())))[0]
+    rel, events = rc.state_synchronised(be, blob, model, 2, 2, seed=5, solver=0, oracle_options={"pgs_dual_warmstart": dual})
     c = rc.state_synchronised.contacts
-    print(f"\n[{scene}, PGS] {len(rel)} env-steps: rel qacc p50 {np.percentile(rel, 50):.1e} p90 {np.percentile(rel, 90):.1e} max {rel.max():.1e}; "
-          f"events {len(events)}; contacts {c['n']}, steps with differing pair lists {c['mismatched_steps']}")
+    print(f"\n[{scene}, PGS, dual warm start {dual}] {len(rel)} env-steps: rel qacc p50 {np.percentile(rel, 50):.1e} p90 {np.percentile(rel, 90):.1e} p99 {np.percentile(rel, 99):.1e} "
+          f"max {rel.max():.1e}; sweeps per step {np.mean(sweeps):.1f}; events {len(events)}; contacts {c['n']}, steps with differing pair lists {c['mismatched_steps']}")
     assert int(be.e.info[3].max()) == 0
     assert np.percentile(rel, 50) < 5e-4 and np.percentile(rel, 90) < 3e-3 and rel.max() < 3e-2
+    if dual:
+        assert np.percentile(rel, 99) < 5e-3 and rel.max() < 1e-2 and np.mean(sweeps) < 60
+    else:
+        assert np.mean(sweeps) > 90
     assert c["mismatched_steps"] <= 0.01 * len(rel) + 1 and c["n"] > 1000
 
 
@@ -333,19 +346,27 @@ def test_gpu_satellite_build_state_synchronised(scene):
     """8 envs x 300 steps on the device, the oracle's state uploaded before every step: accelerations of all 38 / 50 / 46 / 82 dofs
     and the contact lists, with the hand-over from the 16-satellite build to the 32-satellite one where a step needs it."""
     blob, model = _blob(scene)
-    be = rc.HipBackend(scene, 8)
-    assert be.sim.nsat_max == 16
-    rel, events = rc.state_synchronised(be, blob, model, 8, 6, seed=3)
-    flags = int(be.sim.info[3].max())
-    be.close()
-    c = rc.state_synchronised.contacts
-    clean = rc.state_synchronised.clean
-    print(f"\n[{scene}] {len(rel)} env-steps: rel qacc p50 {np.percentile(rel, 50):.1e} p99 {np.percentile(rel, 99):.1e} max {rel.max():.1e}; "
-          f"events {len(events)}; contacts {c['n']}, steps with differing pair lists {c['mismatched_steps']}")
-    assert flags == 0
-    assert len(clean) > 0.9 * len(rel) and np.percentile(clean, 99) < rc.TYPICAL_TOL
-    assert all(ev["explained"] and ev["flags"] == 0 for ev in events) and len(events) <= 0.005 * len(rel) + 2
-    assert c["mismatched_steps"] <= 0.005 * len(rel) + 1 and np.percentile(np.array(c["depth"]), 99) < 5e-5
+    # Twice: with the manifold cache OFF every manifold is built on the step's own poses, as the oracle's are -- the bound on the
+    # dynamics; with it ON (the default) a resting pair keeps the manifold it got up to 2e-5 of pose ago, carried to first order: the
+    # depths stay the oracle's, the contact POINTS are those of the earlier query where the oracle's own jump from step to step (MPR on a
+    # face contact: two solutions 1 cm apart in the settled kitchen, tests/test_satellites.py::test_emul_kept_manifolds...), so the
+    # one-step accelerations of the resting object's dofs scatter by what the oracle's own manifold scatter is worth -- bounded at 4 x
+    # the dynamics-only bound, every event the oracle's on the kernel's contact list.
+    for cache, tol in ((0, rc.TYPICAL_TOL), (1, 4 * rc.TYPICAL_TOL)):
+        be = rc.HipBackend(scene, 8)
+        assert be.sim.nsat_max == 16
+        be.sim.set_option("manifold_cache", cache)
+        rel, events = rc.state_synchronised(be, blob, model, 8, 6, seed=3)
+        flags = int(be.sim.info[3].max())
+        be.close()
+        c = rc.state_synchronised.contacts
+        clean = rc.state_synchronised.clean
+        print(f"\n[{scene}, manifold cache {cache}] {len(rel)} env-steps: rel qacc p50 {np.percentile(rel, 50):.1e} p99 {np.percentile(rel, 99):.1e} max {rel.max():.1e}; "
+              f"on steps with agreeing contact lists p99 {np.percentile(clean, 99):.1e}; events {len(events)}; contacts {c['n']}, steps with differing pair lists {c['mismatched_steps']}")
+        assert flags == 0
+        assert len(clean) > 0.9 * len(rel) and np.percentile(clean, 99) < tol
+        assert all(ev["explained"] and ev["flags"] == 0 for ev in events) and len(events) <= (0.005 if cache == 0 else 0.02) * len(rel) + 2
+        assert c["mismatched_steps"] <= 0.005 * len(rel) + 1 and np.percentile(np.array(c["depth"]), 99) < 5e-5
 
 
 @pytest.mark.gpu
@@ -355,21 +376,29 @@ def test_gpu_pgs_satellite_build_state_synchronised(scene):
     MuJoCo's QCQP iteration on both sides: accelerations of every dof against the fp64 PGS oracle.  Bounds as for the dense builds
     under PGS (100 sweeps leave a remainder that carries the sweeps' rounding)."""
     blob, model = _blob(scene)
-    be = rc.HipBackend(scene, 4, solver=0)
-    be.sim.set_option("qcqp_exact", 1)
-    assert be.sim.nsat_max == 16
-    rel, events = rc.state_synchronised(be, blob, model, 4, 4, seed=3, solver=0)
-    flags = int(be.sim.info[3].max())
-    be.close()
-    c = rc.state_synchronised.contacts
-    print(f"\n[{scene}, PGS] {len(rel)} env-steps: rel qacc p50 {np.percentile(rel, 50):.1e} p90 {np.percentile(rel, 90):.1e} p99 {np.percentile(rel, 99):.1e} "
-          f"max {rel.max():.1e}; events {len(events)}; contacts {c['n']}, steps with differing pair lists {c['mismatched_steps']}")
-    assert flags == 0
-    # (measured, emulator = device: p50 1.5e-4, p90 1.5e-3, p99 2.1e-2.  The tail is PGS's own: e.g. a gripper finger driven into its
-    # stop at 4e4 rad/s^2, where the fp64 oracle's sweeps end on a point the costChange guard will not leave (-9.9e3 on the finger
-    # dof after 100 or 5000 sweeps) while the fp32 sweeps reach Newton's answer (-975); DESIGN.md section 5)
-    assert np.percentile(rel, 50) < 5e-4 and np.percentile(rel, 90) < 3e-3 and np.percentile(rel, 99) < 5e-2
-    assert c["mismatched_steps"] <= 0.005 * len(rel) + 1
+    for dual in (0, 1):
+        be = rc.HipBackend(scene, 4, solver=0)
+        be.sim.set_option("qcqp_exact", 1)
+        be.sim.set_option("pgs_dual_warmstart", dual)
+        assert be.sim.nsat_max == 16
+        sweeps = []
+        step = be.step
+        be.step = lambda n: (step(n), sweeps.append(float(be.sim.info[2].float().mean())))[0]
+        rel, events = rc.state_synchronised(be, blob, model, 4, 4, seed=3, solver=0, oracle_options={"pgs_dual_warmstart": dual})
+        flags = int(be.sim.info[3].max())
+        be.close()
+        c = rc.state_synchronised.contacts
+        print(f"\n[{scene}, PGS, dual warm start {dual}] {len(rel)} env-steps: rel qacc p50 {np.percentile(rel, 50):.1e} p90 {np.percentile(rel, 90):.1e} p99 {np.percentile(rel, 99):.1e} "
+              f"max {rel.max():.1e}; sweeps per step {np.mean(sweeps):.1f}; events {len(events)}; contacts {c['n']}, steps with differing pair lists {c['mismatched_steps']}")
+        assert flags == 0
+        # dual = 0 (MuJoCo's warm start on both sides; measured, emulator = device: p50 1.5e-4, p90 1.5e-3, p99 2.1e-2): the tail is PGS's
+        # own -- e.g. a gripper finger driven into its stop at 4e4 rad/s^2, where the fp64 oracle's sweeps end on a point the costChange
+        # guard will not leave while the fp32 sweeps reach Newton's answer; DESIGN.md section 5.  dual = 1 (the default): both sides
+        # converge on most steps and the bound is VERDICT r4 item 2's p99 < 5e-3.
+        assert np.percentile(rel, 50) < 5e-4 and np.percentile(rel, 90) < 3e-3 and np.percentile(rel, 99) < (5e-3 if dual else 5e-2)
+        if dual:
+            assert np.mean(sweeps) < 70
+        assert c["mismatched_steps"] <= 0.005 * len(rel) + 1
 
 
 @pytest.mark.gpu
@@ -390,6 +419,7 @@ def test_gpu_pgs_two_wavefronts_per_env_agree_with_one(scene):
         sim = StretchBatchSimulator(num_envs=B, device="cuda:0", scene=scene, solver="pgs")
         sim.start(home=False)
         sim.set_option("pgs_two_waves", two)
+        sim.set_option("manifold_cache", 0)   # (sim a runs three steps for each one of sim b: their caches would hold manifolds built at different poses -- valid either way, 1e-5 apart in the velocities -- and this test is about the sweeps)
         sim.home(settle=False)
         sims.append(sim)
     a, b = sims

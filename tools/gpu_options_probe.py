@@ -23,4 +23,4 @@ for _ in range(10): sim.ctrl.copy_(lo + (hi - lo) * torch.rand(10, B, generator=
 torch.cuda.synchronize(); dt = time.perf_counter() - t
 import os, hashlib
 h = hashlib.md5(torch.cat([sim.qpos.flatten(), sim.qvel.flatten()]).cpu().numpy().tobytes()).hexdigest()[:10]
-print(h, os.environ.get("SMJ_LIB_PATH", "default")[-24:], scene, opts, 'settled %.2f M, random %.2f M env-steps/s' % (settled, B * 500 / dt / 1e6), 'flagged', float((sim.info[3] != 0).float().mean()), flush=True)
+print(h, os.environ.get("SMJ_LIB_PATH", "default")[-24:], scene, opts, 'settled %.2f M, random %.2f M env-steps/s' % (settled, B * 500 / dt / 1e6), 'flagged', float((sim.info[3] != 0).float().mean()), 'solver iterations of the last step: mean %.1f, at the cap of 100: %.3f' % (float(sim.info[2].float().mean()), float((sim.info[2] >= 100).float().mean())), flush=True)
