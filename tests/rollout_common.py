@@ -293,6 +293,7 @@ def state_synchronised(backend, blob, model, B, windows, seed, solver=2, oracle_
     sched = ctrl_schedule(model, nu, B, windows, seed)
     rel, events = [], []
     clean = []    # env-steps whose contact lists agree (same pairs, normals within 0.5 degree): the dynamics-only error sample
+    iters = []    # per env-step: (solver iterations of the kernel, of the oracle)
     cstat = dict(n=0, depth=[], pos=[], cosn=[], mismatched_steps=0)   # contact geometry on identical states
     for w in range(windows):
         backend.set_ctrl(sched[w])
@@ -309,6 +310,7 @@ def state_synchronised(backend, blob, model, B, windows, seed, solver=2, oracle_
                 qk = out["qacc"][:nv, b]
                 r = np.abs(qk - qa).max() / max(1.0, np.abs(qa).max())
                 rel.append(r)
+                iters.append((int(out["info"][2, b]), int(o.iarr("solver_niter")[0])))
                 if _compare_contacts(cstat, out["contacts"][:, b], int(out["info"][1, b]), o):
                     clean.append(r)
                 if r > EVENT_TOL or int(out["info"][1, b]) != o.ncon:
@@ -324,6 +326,7 @@ def state_synchronised(backend, blob, model, B, windows, seed, solver=2, oracle_
                                        explained=bool(ok), residual=float(err), eps=eps, flags=int(out["info"][3, b])))
     state_synchronised.contacts = cstat
     state_synchronised.clean = np.array(clean)
+    state_synchronised.iters = np.array(iters)
     return np.array(rel), events
 
 
