@@ -330,7 +330,7 @@ int smj_create(const void* blob, size_t nbytes, int num_envs, int device, smj_ct
     HIPCHK(c, hipMemset(d, 0, bytes));
     c->state.mcache = (float*)d;
   }
-  if (c->caps.nsat > 0) {   // PGS on the satellite builds: the previous step's rows and forces (DevState::pgsprev)
+  {   // PGS: the previous step's rows and forces (DevState::pgsprev), 2.6 KB per env
     void* d = nullptr;
     const size_t bytes = sizeof(float) * SMJ_PGSPREV_STRIDE * (size_t)num_envs;
     HIPCHK(c, hipMalloc(&d, bytes));

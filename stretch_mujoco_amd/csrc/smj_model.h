@@ -119,7 +119,7 @@ struct DevModel {
   float grad_noise;       // Newton: a gradient component below grad_noise * (|Ma| + |g| + |J'f|) is rounding (default 4e-6 = 64 ulp; 0 = MuJoCo's scale * |grad| < tolerance test only)
   int pgs_island_stop;    // PGS, satellite builds: 1 (default) = a satellite island whose own scaled improvement fell below tolerance / 64 stops sweeping (smj_sat_pgs.h); 0 = every island sweeps until the whole system stops
   int qcqp_exact;   // PGS: 1 = the friction QCQP iterates exactly as mju_QCQP does (from la = 0 on |x|^2 - r^2, cap 20); 0 (default) = same root, secular form, started at the last sweep's multiplier
-  int pgs_dual_ws;  // PGS, satellite builds: 1 (default) = the sweeps may also start from the forces the rows had at the end of the previous step's solve (DevState::pgsprev; NOT MuJoCo's rule, same fixed point: smj_sat_pgs.h), 0 = MuJoCo's warm start only
+  int pgs_dual_ws;  // PGS: 1 (default) = the sweeps may also start from the forces the rows had at the end of the previous step's solve (DevState::pgsprev; NOT MuJoCo's rule, same fixed point: smj_sat_pgs.h), 0 = MuJoCo's warm start only
   int sep_cache;      // 1 = use DevState::sepcache (separating directions of convex pairs kept between steps)
   int manifold_cache; // 1 = use DevState::mcache (contact manifolds of convex pairs whose two bodies have not moved)
   int multi_serial;   // lane emulator only: 1 = the four multiccd queries of a pair one after the other (convex_multi), the comparator of convex_multi4
@@ -273,7 +273,7 @@ struct DevState {
   // second order in the motion since the manifold was built (<= SMJ_MC_EPS^2 / feature size: 1e-9 m), far below MPR's own 1e-6 m
   // tolerance -- which is what made resting bodies jitter by 1e-6 per step and miss the round-4 cache (3e-7, no update) every step.
   float* mcache;
-  // PGS, satellite builds (null = off): the constraint rows of the env's previous step, [B][SMJ_PGSPREV_STRIDE] words: count, then
+  // PGS (null = off): the constraint rows of the env's previous step, [B][SMJ_PGSPREV_STRIDE] words: count, then
   // SMJ_PGSPREV_ROWS identity keys (type | equality / dof / limit record, or contact: pair | ordinal in the pair's manifold | row in
   // the contact), then as many forces.  Read by the next step's warm start (option pgs_dual_ws), whichever variant runs it.
   float* pgsprev;

@@ -3029,6 +3029,21 @@ struct StepKernel {
 #endif
   template <bool WIDE>
   SMJ_DEV static int ai(int r, int c) { return WIDE ? tri(r, c) : r * NEFP + c; }
+#if NSAT == 0
+  // Identity of a constraint row from one step to the next (option pgs_dual_ws; the satellite builds' twin is in smj_sat_pgs.h): type
+  // and equality / friction-loss dof / limit slot, or, for a contact row, (collision pair, ordinal of the contact within the pair's
+  // manifold -- a pair's contacts are contiguous in the list --, row within the contact).
+  SMJ_DEV int pgs_row_key(int row) const {
+    const int t = s.etype[row];
+    if (t == CT_CONTACT_ELLIPTIC || t == CT_CONTACT_FRICTIONLESS) {
+      const int c = s.eid[row], pr = ((s.cgeom1[c] & 0x3ff) << 10) | (s.cgeom2[c] & 0x3ff);   // (the dense builds hold <= 1023 geoms)
+      int ord = 0;
+      for (int k = c - 1; k >= 0 && (((s.cgeom1[k] & 0x3ff) << 10) | (s.cgeom2[k] & 0x3ff)) == pr; k--) ord++;
+      return (int)(0x80000000u | ((unsigned)pr << 6) | ((unsigned)(ord & 7) << 3) | (unsigned)((row - s.cefc[c]) & 7));
+    }
+    return 0x40000000 | (t << 20) | (s.eid[row] & 0xfffff);
+  }
+#endif
   template <bool WIDE>
   SMJ_DEV void solve(bool dbg, float* pc, long long& t0, bool prof) {
 #define TICK(slot) if (prof) { const long long t1 = smj_clock(); pc[slot] += (float)(t1 - t0); t0 = t1; }
@@ -3147,18 +3162,75 @@ struct StepKernel {
       }
     }
     SYNC();
-    // residual r = A f + b (lanes = rows; column reads via symmetry), dual cost of the warm start
-    PL<float> cost;
-    LANES { cost[lane] = 0.f; }
-    PSETS_ALL(p) LANES {
-      const int row = lane + 64 * p;
-      f_r[p][lane] = row < ne ? s.ef[row] : 0.f;
-      r_r[p][lane] = 0.f;
-      if (row < NEFC) s.earef[row] = row < ne ? aref[p][lane] : 0.f;
+    PSETS_ALL(p) LANES { const int row = lane + 64 * p; if (row < NEFC) s.earef[row] = row < ne ? aref[p][lane] : 0.f; }
+    // ---- NOT MuJoCo (option pgs_dual_ws, default on): a second start -- the forces the rows had at the end of the PREVIOUS step's solve
+    // (DevState::pgsprev), matched by row identity, projected onto this step's bounds and cones -- taken when its dual cost is below that
+    // of MuJoCo's start.  Same fixed point (the dual is strictly convex, R > 0), fewer sweeps to it; smj_sat_pgs.h has the measurements.
+    bool have_prev = false;
+#if NSAT == 0
+    if (M.pgs_dual_ws && S.pgsprev) {
+      const int* const pk = reinterpret_cast<const int*>(S.pgsprev + (size_t)env * SMJ_PGSPREV_STRIDE);
+      const float* const pf = S.pgsprev + (size_t)env * SMJ_PGSPREV_STRIDE + 1 + SMJ_PGSPREV_ROWS;
+      int np = uni(pk[0]);
+      np = np < 0 ? 0 : np > SMJ_PGSPREV_ROWS ? SMJ_PGSPREV_ROWS : np;
+      if (np > 0) {
+        have_prev = true;
+#pragma nounroll
+        for (int rb = 0; rb < ne; rb += 64) LANES {
+          const int row = lane + rb;
+          if (row < ne) {
+            const int key = pgs_row_key(row), t = s.etype[row];
+            float f = 0.f;
+            for (int j = 0; j < np; j++) f = pk[1 + j] == key ? pf[j] : f;
+            if (t == CT_FRICTION) { const float fl = s.efloss[row]; f = fminf(fl, fmaxf(-fl, f)); }
+            else if (t == CT_LIMIT || t == CT_CONTACT_FRICTIONLESS) f = fmaxf(0.f, f);
+            s.ediag[row] = f;   // (free: R was its last reader)
+          }
+        }
+        SYNC();
+        LANES {
+          if (lane < ncon) {
+            const int c = lane, i = s.cefc[c], dim = s.cdim[c];
+            if (i >= 0 && dim >= 3) {
+              const float fn = s.ediag[i];
+              if (fn < SMJ_MINVAL) { for (int j = 0; j < dim; j++) s.ediag[i + j] = 0.f; }
+              else {
+                float s2 = 0.f;
+                for (int j = 1; j < dim; j++) { const float tq = s.ediag[i + j] * fast_rcp(s.cfric[c][j - 1]); s2 += tq * tq; }
+                if (s2 > fn * fn) { const float sc = fn * fast_rsqrt(s2); for (int j = 1; j < dim; j++) s.ediag[i + j] *= sc; }
+              }
+            }
+          }
+        }
+        SYNC();
+      }
     }
-    residual_refresh<WIDE>(bb);
-    PSETS(p, ne) LANES { cost[lane] += lane + 64 * p < ne ? f_r[p][lane] * 0.5f * (r_r[p][lane] + bb[p][lane]) : 0.f; }
-    const float wcost = wave_sum(cost);
+#endif
+    // residual r = A f + b (lanes = rows; column reads via symmetry) and the dual cost of a start.  Pass 0: MuJoCo's (s.ef).  Pass 1: the
+    // previous step's forces, swapped into s.ef; kept when cheaper.  Pass 2: MuJoCo's once more when it was the better one.
+    PL<float> cost;
+    float wcost = 0.f;
+    for (int pass = 0;; pass++) {
+      LANES { cost[lane] = 0.f; }
+      PSETS_ALL(p) LANES {
+        const int row = lane + 64 * p;
+        f_r[p][lane] = row < ne ? s.ef[row] : 0.f;
+        r_r[p][lane] = 0.f;
+      }
+      residual_refresh<WIDE>(bb);
+      PSETS(p, ne) LANES { cost[lane] += lane + 64 * p < ne ? f_r[p][lane] * 0.5f * (r_r[p][lane] + bb[p][lane]) : 0.f; }
+      const float cst = wave_sum(cost);
+      bool swap = false;
+      if (pass == 0) { wcost = cst; swap = have_prev; }
+      else if (pass == 1) { if (cst < wcost) wcost = cst; else swap = true; }
+      if (!swap) break;
+#pragma nounroll
+      for (int rb = 0; rb < ne; rb += 64) LANES {
+        const int row = lane + rb;
+        if (row < ne) { const float tq = s.ef[row]; s.ef[row] = s.ediag[row]; s.ediag[row] = tq; }
+      }
+      SYNC();
+    }
     if (wcost > 0) { PSETS(p, ne) LANES { f_r[p][lane] = 0.f; r_r[p][lane] = bb[p][lane]; } }
 
     TICK(SMJ_PROF_WARM)
@@ -3236,6 +3308,19 @@ struct StepKernel {
 #undef TICK
     PSETS_ALL(p) LANES { if (lane + 64 * p < NEFC) s.ef[lane + 64 * p] = lane + 64 * p < ne ? f_r[p][lane] : 0.f; }
     SYNC();
+#if NSAT == 0
+    if (M.pgs_dual_ws && S.pgsprev) {   // the rows of this step and where their forces ended: the next step's second start
+      int* const pk = reinterpret_cast<int*>(S.pgsprev + (size_t)env * SMJ_PGSPREV_STRIDE);
+      float* const pf = S.pgsprev + (size_t)env * SMJ_PGSPREV_STRIDE + 1 + SMJ_PGSPREV_ROWS;
+      const int nst = ne < SMJ_PGSPREV_ROWS ? ne : SMJ_PGSPREV_ROWS;
+#pragma nounroll
+      for (int rb = 0; rb < nst; rb += 64) LANES {
+        const int row = lane + rb;
+        if (row < nst) { pk[1 + row] = pgs_row_key(row); pf[row] = s.ef[row]; }
+      }
+      LANES { if (lane == 0) pk[0] = nst; }
+    }
+#endif
     // w = Y' f (dof lanes); qfrc_constraint = L' w ; qacc = L^-1 ( Dinv (u + w) )
     PL<float> w, qc;
     LANES {

@@ -457,6 +457,7 @@ class HipBackend:
         self.torch = torch
         self.sim = StretchBatchSimulator(num_envs=B, device="cuda:0", scene=scene, solver={0: "pgs", 2: "newton"}[solver], debug=True)
         self.sim.start(home=False)
+        self.sim.set_option("pgs_dual_warmstart", 0)   # MuJoCo's own warm start, as the unmodified oracle's; tests of the default (1) set it, on both sides
         self.D, self.nvp, self.ncon_max = self.sim.debug_layout, self.sim.nv_max, self.sim.ncon_max
 
     def _put(self, dst, a):

@@ -241,6 +241,7 @@ def test_gpu_piles_of_primitives_state_synchronised(nbodies, solver):
         sim.start(home=False)
         if solver == "pgs":
             sim.set_option("qcqp_exact", 1)   # MuJoCo's own QCQP iteration on both sides
+            o.set_option("pgs_dual_warmstart", 1)   # the kernels' default: a second start from the previous step's forces, on both sides
         for step in range(200):
             for name, t in (("qpos", sim.qpos), ("qvel", sim.qvel), ("qacc_warmstart", sim.qacc_warmstart)):
                 t[:, 0] = torch.tensor(o.arr(name), dtype=torch.float32, device=sim.device)

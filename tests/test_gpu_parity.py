@@ -15,8 +15,10 @@ def _sim(B, **kw):
     from stretch_mujoco_amd import StretchBatchSimulator
 
     kw.setdefault("solver", "pgs")
+    dual = kw.pop("pgs_dual_warmstart", 0)   # these tests follow the unmodified oracle iterate for iterate: MuJoCo's warm start (the default, a second start from the previous step's forces, has its own test below)
     sim = StretchBatchSimulator(num_envs=B, device="cuda:0", **kw)
     sim.start(home=False)
+    sim.set_option("pgs_dual_warmstart", dual)
     return sim
 
 
@@ -390,6 +392,34 @@ def test_pgs_default_qcqp_against_the_unmodified_oracle():
     assert flags == 0
     assert np.percentile(rel, 50) < 3e-4 and np.percentile(rel, 99) < 1e-3 and rel.max() < 5e-2
     assert np.mean(rel > 1e-2) <= 0.01
+
+
+def test_pgs_second_start_from_the_previous_steps_forces_on_the_dense_builds():
+    """Round 5, option pgs_dual_warmstart (the default): the sweeps may start from the forces the rows had at the end of the previous
+    step's solve when that start has the lower dual cost.  Bench workload on the standard build, 8 envs x 200 steps, the oracle's state
+    uploaded before every step, the oracle running the same option: fewer sweeps than MuJoCo's start takes, and where both sides leave
+    the sweeps before the cap of 100 (the same fixed point from either start) the one-step accelerations agree to p99 < 2e-3."""
+    import rollout_common as rc
+    import stretch_mujoco_amd.model_blob as mb
+    from conftest import MODELS
+
+    with open(f"{MODELS}/stretch_empty.smjb", "rb") as f:
+        blob = f.read()
+    res = {}
+    for dual in (0, 1):
+        be = rc.HipBackend("stretch_empty", 8, solver=0)
+        be.sim.set_option("pgs_dual_warmstart", dual)
+        rel, events = rc.state_synchronised(be, blob, mb.loads(blob), 8, 4, seed=7, solver=0, oracle_options={"pgs_dual_warmstart": dual})
+        flags = int(be.sim.info[3].max())
+        be.close()
+        it = rc.state_synchronised.iters
+        conv = (it[:, 0] < 100) & (it[:, 1] < 100)
+        res[dual] = (it[:, 0].mean(), conv.mean(), np.percentile(rel[conv], 99), np.percentile(rel, 99))
+        print(f"\nPGS, dual warm start {dual}: sweeps per step {it[:, 0].mean():.1f} (oracle {it[:, 1].mean():.1f}); both sides below the cap on {conv.mean():.2f} of the steps; "
+              f"rel qacc p50 {np.percentile(rel, 50):.1e} p99 {np.percentile(rel, 99):.1e}, on the converged steps p99 {np.percentile(rel[conv], 99):.1e}")
+        assert flags == 0
+    assert res[1][0] < res[0][0] and res[1][1] >= res[0][1] - 0.02
+    assert res[1][2] < 2e-3 and res[1][3] < 5e-2
 
 
 @pytest.mark.parametrize("B,solver", [(1024, "pgs"), (4096, "newton"), (32768, "newton")])
