@@ -170,3 +170,44 @@ def test_simulator_compiles_a_scene_xml(tmp_path):
     assert sum(1 for g in range(127) if mm["geom_type"][g] == 6 and mm["geom_bodyid"][g] == 0) == 1    # the crate, on the world body
     with pytest.raises(Exception):
         sim.start()          # no CPU fallback for the physics path
+
+
+def test_default_scene_as_shipped_today_compiles_from_the_file_itself_and_steps():
+    """models/scene.xml (stretch_mujoco_simulator.py:47: the scene every reference user gets): stretch.xml + docking_station.xml + table
+    + two objects, compiled from the reference's file (where the reference is mounted) -- 44 dofs, the docking station's 18 convex
+    collision pieces and plate, its visual shell (one of the blobs missing from the checkout) skipped and recorded; the committed blob
+    `stretch_scene_docking.smjb` is that compile; on the lane emulator 60 steps follow the oracle."""
+    import json
+    import os
+
+    import numpy as np
+
+    from conftest import HOME_CTRL, MODELS
+    from oracle.oracle import Oracle
+    from stretch_mujoco_amd import mjcf_compiler, model_blob, model_fuse
+
+    with open(os.path.join(MODELS, "stretch_scene_docking.smjb"), "rb") as f:
+        blob = f.read()
+    m = model_blob.loads(blob)
+    names = json.loads(model_blob.get_str(m, "names_json"))
+    assert int(m["dims"][1]) == 44 and "link_docking_station" in names["body"] and "link_docking_base" in names["missing_meshes"]
+    ref = "/root/reference/stretch_mujoco/models/scene.xml"
+    if os.path.exists(ref):
+        f2 = model_fuse.prepare_for_kernels(mjcf_compiler.compile_file(ref))
+        for k in ("body_mass", "geom_size", "pair_geom1", "qpos0", "hull_vert"):
+            assert np.array_equal(np.asarray(f2[k]), np.asarray(m[k])), k
+    from emul.emul import Emul
+
+    o = Oracle(blob); o.set_option("solver", 2)
+    o.arr("ctrl")[:] = HOME_CTRL
+    # 43 contacts / 156 rows at rest (the docking station's pieces on the floor): the 50-column build (160 rows) is the primary kernel on
+    # the device and hands steps beyond it to the 64-column build (224 rows); the emulator has no hand-over and runs that one
+    e = Emul(blob, dict(nq=o.dim("nq"), nv=o.dim("nv"), nu=o.dim("nu"), nlidar=360), num_envs=1, variant="big")
+    e.set_option("solver", 2)
+    e.ctrl[:, 0] = HOME_CTRL
+    from conftest import home_qpos
+    q = home_qpos(o.arr("qpos"))          # (past the wrist-in-base start, a chaotic transient)
+    o.arr("qpos")[:] = q; e.qpos[:, 0] = q
+    o.step(60); e.step(60)
+    assert int(e.info[3, 0]) == 0 and (int(e.info[1, 0]), int(e.info[0, 0])) == (o.ncon, o.nefc)
+    assert np.abs(e.qpos[:, 0] - o.arr("qpos")).max() < 1e-4

@@ -345,7 +345,7 @@ def _lidar_figure():
     return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "lidar_figure.json")))
 
 
-def lidar_figure_check(scan, fig, absent_rays=range(140, 144)):
+def lidar_figure_check(scan, fig, absent_rays=()):
     """Compare a 360-ray scan (metres, -1 = no hit, clipped to the cutoff) with the notebook's figure (tests/golden/
     lidar_figure.json, tools/gen_lidar_golden.py): every ray, drawn the way cell 18 draws it (x = -r cos i, y = -r sin i,
     negative -> 0), must land on a red pixel of the figure -- within 3 px: 0.13 m at the figure's scale, 0.8 degree at r = 10 m.
@@ -373,12 +373,24 @@ def test_lidar_scan_reproduces_the_notebook_figure():
         9.6 m in either;
       * rays 42..138 meet the table's front edge (y = -0.5) where the figure draws its line, rays 290..306 the robot's own mast
         at 0.13-0.15 m (the cluster at the origin).
-    Rays 140..143 are excused: in the figure they end on the docking station, whose meshes are absent from this checkout
-    (.MISSING_LARGE_BLOBS); it also owns the 12 % of the figure's red pixels no ray of this scene explains."""
+    Round 5: NO ray is excused.  Rays 140..143 graze the table's front-right corner (0.6, -0.5): whether they meet the table or pass it
+    depends on the base's yaw, and they are on the drawing exactly when the robot stands at the base pose cell 20 prints
+    (theta = -0.065; at theta = -0.04 ray 143 is off it, at the oracle's own +0.01 all four are) -- the third MuJoCo output, after
+    the wrist depth map and the nav frame (tests/test_notebook_images.py), that the printed pose makes fall into place.  Rounds 3-4
+    blamed those rays on the docking station; with today's scene.xml (docking station at (-1, 0), `stretch_scene_docking`) six rays
+    behind the robot return 0.9 m where the figure has none: the notebook's scene had no docking station there, which is asserted too."""
+    import notebook_images as nbi
+
     fig = _lidar_figure()
     o = Oracle(open(os.path.join(MODELS, "stretch_scene.smjb"), "rb").read())
     o.arr("ctrl")[:] = HOME_CTRL
     o.step(1600)
+    own = o.arr("qpos").copy()
+    o.sensors(True)
+    off_own, _ = lidar_figure_check(o.arr("lidar").copy(), fig)
+    assert off_own == [140, 141, 142, 143], off_own        # (the oracle's own start transient leaves the robot at theta = +0.01)
+    o.arr("qpos")[:] = nbi.place_base(own, *nbi.NB_BASE_POSE)
+    o.forward()
     o.sensors(True)
     scan = o.arr("lidar").copy()
     off, covered = lidar_figure_check(scan, fig)
@@ -386,7 +398,20 @@ def test_lidar_scan_reproduces_the_notebook_figure():
     assert covered > 0.85, covered
     at_cut = [i for i in range(360) if scan[i] == fig["cutoff"]]
     assert at_cut == list(range(at_cut[0], at_cut[-1] + 1))                      # one contiguous arc
-    assert set(range(144, 271)) <= set(at_cut) and abs(at_cut[-1] - fig["rays_at_cutoff"][-1]) <= 2
+    assert set(range(145, 271)) <= set(at_cut) and abs(at_cut[-1] - fig["rays_at_cutoff"][-1]) <= 2 and abs(at_cut[0] - fig["rays_at_cutoff"][0]) <= 1   # (ray 144 grazes the table's corner)
     assert not np.any((scan > 1.5) & (scan < 9.6))
     assert np.all(scan[list(range(272, 290)) + list(range(310, 360)) + list(range(0, 40))] == -1.0)
     assert np.all((scan[290:307] > 0.12) & (scan[290:307] < 0.16))
+    x, y, th = nbi.NB_BASE_POSE
+    o.arr("qpos")[:] = nbi.place_base(own, x, y, -0.04)
+    o.forward(); o.sensors(True)
+    assert lidar_figure_check(o.arr("lidar").copy(), fig)[0] == [143]
+    dock = os.path.join(MODELS, "stretch_scene_docking.smjb")
+    if os.path.exists(dock):
+        od = Oracle(open(dock, "rb").read())
+        od.arr("ctrl")[:] = HOME_CTRL
+        od.step(1600)
+        od.arr("qpos")[:27] = nbi.place_base(od.arr("qpos")[:27].copy(), *nbi.NB_BASE_POSE)
+        od.forward(); od.sensors(True)
+        offd, _ = lidar_figure_check(od.arr("lidar").copy(), fig)
+        assert len(offd) >= 5 and all(i <= 10 or i >= 350 for i in offd), offd     # the rays that meet the docking station behind the robot

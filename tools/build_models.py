@@ -37,6 +37,12 @@ def main():
         # the same scene for the satellite builds of the step kernel (csrc/smj_sat.h): the free objects leave the dense problem
         B.save(os.path.join(out, name + "_sat.smjb"), F.prepare_for_kernels(mm, satellites=True))
         print(name + ":", dict(zip("nq nv nu nbody njnt ngeom".split(), [int(x) for x in mm["dims"][:6]])), "npair", int(mm["dims"][12]))
+    # the reference's default scene AS SHIPPED TODAY: models/scene.xml compiled from the file itself -- stretch.xml, the docking station
+    # (a free body of a plate + 18 convex collision pieces behind the robot; its visual shell link_docking_base.obj is one of the blobs
+    # missing from the checkout and is skipped like the robot's two), the table, the two objects: 44 dofs, the 50-column build
+    sd = C.compile_file(os.path.join(ref, "stretch_mujoco", "models", "scene.xml"))
+    B.save(os.path.join(out, "stretch_scene_docking.smjb"), F.prepare_for_kernels(sd))
+    print("stretch_scene_docking:", dict(zip("nq nv nu nbody njnt ngeom".split(), [int(x) for x in sd["dims"][:6]])), "npair", int(sd["dims"][12]))
     # a robosuite-style kitchen export (hand-written test fixture: articulated fixtures, <inertial>, capsule / ellipsoid objects)
     # through the converter for pre-exported Robocasa kitchens (robocasa_import.py; robocasa_gen.py:242-280)
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
