@@ -228,14 +228,15 @@ def other_configs(B, dev, hold, solver):
     if solver != "pgs":
         # `_sat` / the Robocasa-scale kitchen: PGS with constraint islands (csrc/smj_sat_pgs.h) -- the robot's rows as one dense system,
         # every free object / fixture part that touches only the static world swept by its own lane, all in the same iteration
-        for scene, n in (("stretch_kitchen_standin", 100), ("stretch_kitchen4", 50), ("stretch_kitchen4_sat", 100), ("stretch_scene", 50), ("stretch_scene_sat", 100),
-                         ("stretch_kitchen_robocasa", 100)):
+        for scene, n in (("stretch_kitchen_standin", 200), ("stretch_kitchen4", 100), ("stretch_kitchen4_sat", 200), ("stretch_scene", 100), ("stretch_scene_sat", 200),
+                         ("stretch_kitchen_robocasa", 200)):
             if not os.path.exists(os.path.join(ROOT, "stretch_mujoco_amd", "models", scene + ".smjb")):
                 continue
             sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver="pgs", scene=scene)
             sim.start(home=False)
             evs = []
-            res[scene + "_physics_pgs"] = {"value": rollout(sim, n, hold, settle=200, preroll=1, events=evs), "unit": "env-steps/s", **flags_of(sim)}
+            res[scene + "_physics_pgs"] = {"value": rollout(sim, n, hold, settle=200, preroll=2, events=evs), "unit": "env-steps/s", **flags_of(sim)}
+            res[scene + "_physics_pgs"]["sweeps_last_step"] = {"mean": float(sim.info[2].float().mean().item()), "at_cap_of_100": float((sim.info[2] >= 100).float().mean().item())}
             if scene == "stretch_kitchen_robocasa":
                 res[scene + "_physics_pgs"]["roofline"] = roofline_of(sim, evs, scene + ":pgs", "smj_step_kernel_satp (two wavefronts per env)")
                 res[scene + "_physics_pgs"]["solver_iterations_mean"] = float(sim.info[2].float().mean().item())
