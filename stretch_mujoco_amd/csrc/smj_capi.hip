@@ -557,14 +557,19 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
       lrc = c->variant == 5 ? smj_launch_step_sat32(c->model_esc, sp, k, fl, c->aux) : smj_launch_step_tall(c->model_esc, sp, k, fl, c->aux);
       HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
     }
+    // the primary builds exist once per solver (smj_step_impl.h newton()); a launch with the profiling slot bound stays on the base name,
+    // which is the both-solver profiling copy in tools builds (csrc/Makefile bigprof)
+    const bool pgs_twin = c->model.solver != 2 && !st.prof;
     if (!lrc)
       lrc = c->variant == 6   ? smj_launch_step_sat32(c->model, st, k, fl, sm)
-            : c->variant == 5 ? ((c->model.solver != 2 && c->pgs_two_waves && !st.prof) ? smj_launch_step_satp(c->model, st, k, fl, sm) : smj_launch_step_sat(c->model, st, k, fl, sm))
+            : c->variant == 5 ? ((c->model.solver != 2 && !st.prof) ? (c->pgs_two_waves ? smj_launch_step_satp(c->model, st, k, fl, sm) : smj_launch_step_sat1(c->model, st, k, fl, sm))
+                                                                       : smj_launch_step_sat(c->model, st, k, fl, sm))   // (Newton-only in the product build; both solvers in the profiling build)
             : c->variant == 4 ? smj_launch_step_big(c->model, st, k, fl, sm)
-            : c->variant == 3 ? smj_launch_step_big50(c->model, st, k, fl, sm)
-            : c->variant == 2 ? smj_launch_step_big38(c->model, st, k, fl, sm)
-            : c->variant == 1 ? smj_launch_step_mid(c->model, st, k, fl, sm)
+            : c->variant == 3 ? (pgs_twin ? smj_launch_step_big50p(c->model, st, k, fl, sm) : smj_launch_step_big50(c->model, st, k, fl, sm))
+            : c->variant == 2 ? (pgs_twin ? smj_launch_step_big38p(c->model, st, k, fl, sm) : smj_launch_step_big38(c->model, st, k, fl, sm))
+            : c->variant == 1 ? (pgs_twin ? smj_launch_step_midp(c->model, st, k, fl, sm) : smj_launch_step_mid(c->model, st, k, fl, sm))
             : st.prof         ? smj_launch_step_prof(c->model, st, k, fl, sm)
+            : c->model.solver != 2 ? smj_launch_step_pgs(c->model, st, k, fl, sm)   // the standard variant is built once per solver
                               : smj_launch_step(c->model, st, k, fl, sm);
     if (poll) HIPCHK(c, hipStreamWaitEvent(sm, c->ev_join, 0));
     if (!lrc && esc) {

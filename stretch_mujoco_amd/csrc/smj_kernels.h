@@ -22,13 +22,18 @@ struct StagePlan {
 
 // the capacity variants of the step kernel (smj_model.h); return 0 or a hipError_t
 int smj_launch_step(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);
+int smj_launch_step_pgs(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);    // standard, PGS-only build (smj_launch_step: Newton-only)
 int smj_launch_step_prof(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);   // standard + cycle counters
 int smj_launch_step_tall(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);
 int smj_launch_step_mid(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);      // tall with 128 rows: three envs per CU
+int smj_launch_step_midp(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);     // PGS-only twins of mid / big38 / big50 (those carry the Newton solver only)
+int smj_launch_step_big38p(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);
+int smj_launch_step_big50p(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);
 int smj_launch_step_big(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);     // 64 dof columns
 int smj_launch_step_big38(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);   // 38
 int smj_launch_step_big50(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);   // 50
 int smj_launch_step_satp(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);    // the same build with two wavefronts per env: PGS, satellite islands beside the dense system (smj_kernels_satp.hip)
+int smj_launch_step_sat1(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);    // 16 satellites, PGS only, one wavefront per env (option pgs_two_waves = 0)
 int smj_launch_step_sat(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);     // main tree + satellites (smj_sat.h)
 int smj_launch_step_sat32(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);   // up to 32 satellites, one env per CU
 void smj_sat_caps(int* nvp, int* nbp, int* nent, int* nefc, int* ncon, int* debug_floats, int* nsat);

@@ -5,6 +5,7 @@
 // the standard variant of the step kernel, without the per-stage cycle counters: they are runtime-optional but cost the
 // kernel registers it does not have (scratch 144 -> 48 B per lane); smj_kernels_prof.hip compiles the same kernel with them
 #define SMJ_PROFILING 0
+#define SMJ_ONLY_NEWTON 1   // this translation unit's step kernel carries the Newton solver only; smj_kernels_pgs.hip is its PGS twin (smj_step_impl.h newton())
 #include "smj_step_tu.h"
 
 // mj_resetData for masked envs: batch-major, lanes = envs (coalesced)

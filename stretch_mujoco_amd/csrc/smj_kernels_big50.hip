@@ -7,4 +7,7 @@
 #ifndef SMJ_PROFILING
 #define SMJ_PROFILING 0   // the per-stage cycle counters cost registers; tools build a profiling copy with -DSMJ_PROFILING=1
 #endif
+#if !SMJ_PROFILING
+#define SMJ_ONLY_NEWTON 1   // product build: the Newton solver only; PGS launches go to smj_kernels_big50p.hip (smj_step_impl.h newton()); the profiling copy keeps both
+#endif
 #include "smj_step_tu.h"

@@ -8,6 +8,9 @@
 #ifndef SMJ_PROFILING
 #define SMJ_PROFILING 0
 #endif
+#if !SMJ_PROFILING
+#define SMJ_ONLY_NEWTON 1   // product build: the Newton solver only; PGS launches go to smj_kernels_midp.hip (smj_step_impl.h newton()); the profiling copy keeps both
+#endif
 #include "smj_step_tu.h"
 
 void smj_mid_caps(int* nvp, int* nbp, int* nent, int* nefc, int* ncon, int* debug_floats) {

@@ -13,6 +13,9 @@
 #ifndef SMJ_PROFILING
 #define SMJ_PROFILING 0
 #endif
+#if !SMJ_PROFILING
+#define SMJ_ONLY_NEWTON 1   // the product build of this translation unit carries the Newton solver only (smj_step_impl.h newton()): PGS launches go to smj_kernels_satp.hip (two wavefronts per env) or smj_kernels_sat1.hip (one); the profiling build keeps both
+#endif
 #include "smj_step_tu.h"
 
 void smj_sat_caps(int* nvp, int* nbp, int* nent, int* nefc, int* ncon, int* debug_floats, int* nsat) {

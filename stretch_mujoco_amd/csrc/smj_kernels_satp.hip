@@ -5,6 +5,7 @@
 // the other two SIMDs idle), meet at one workgroup barrier per sweep, add their improvements and take the same decision.
 // Same capacities, same LDS, same results as the one-wavefront kernel (option pgs_two_waves = 0 selects that one).
 #define SMJ_TWO_WAVES 1
+#define SMJ_ONLY_PGS 1
 #define SMJ_SAT 16
 #define SMJ_SAT_ROWS 208
 #define SMJ_SAT_CONTACTS 56

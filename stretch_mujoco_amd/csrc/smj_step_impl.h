@@ -2782,7 +2782,7 @@ struct StepKernel {
       }
     }
     SYNC();
-    int cap = M.solver == 2 ? NEFC : M.pgs_cap > 0 ? M.pgs_cap : NEFC_P;
+    int cap = newton() ? NEFC : M.pgs_cap > 0 ? M.pgs_cap : NEFC_P;
     if (M.row_limit > 0 && M.row_limit < cap) cap = M.row_limit;
     // static rows (equalities -- all active, an inactive one gets an empty row with R large -> force 0 -- then friction-loss
     // dofs) and the limit slots, each from its row record (DevModel::k_rowrec): one level of loads
@@ -4597,6 +4597,16 @@ struct StepKernel {
 #endif
 
   // ------------------------------------------------------------------ driver
+  // Which solver a build carries: both (chosen per launch by DevModel::solver) or, where a translation unit says so, ONE -- the
+  // standard variant is built twice (smj_kernels.hip: Newton only, smj_kernels_pgs.hip: PGS only) because the other solver's code, dead
+  // in a launch, still costs the live one registers (the allocation is per kernel).
+#if defined(SMJ_ONLY_NEWTON)
+  SMJ_DEV bool newton() const { return true; }
+#elif defined(SMJ_ONLY_PGS)
+  SMJ_DEV bool newton() const { return false; }
+#else
+  SMJ_DEV bool newton() const { return M.solver == 2; }
+#endif
   SMJ_DEV void run(int nsteps, unsigned read_flags) {
     const int want_imu = read_flags & 1;
     flags = 0; nefc = NEFC; ncon = 0; niter = 0;   // nefc = NEFC: the first make_constraint clears every row
@@ -4622,7 +4632,7 @@ struct StepKernel {
       TICK(SMJ_PROF_COMCRB)
       smooth_forces(last);
       TICK(SMJ_PROF_SMOOTH)
-      if (M.solver != 2) factor();   // the sparse L'DL of M is only needed by the PGS path (Y = J L^-1)
+      if (!newton()) factor();   // the sparse L'DL of M is only needed by the PGS path (Y = J L^-1)
       TICK(SMJ_PROF_FACTOR)
       collision();
       collision_convex(pc, prof);
@@ -4631,7 +4641,7 @@ struct StepKernel {
 #if NSAT > 0
       make_constraint_sat(pc, prof);
 #else
-      if (M.solver != 2) nefc = NEFC;   // PGS: the A of a step with at most 64 rows sits in rows 64.. of J (solve<false>) -- have them cleared
+      if (!newton()) nefc = NEFC;   // PGS: the A of a step with at most 64 rows sits in rows 64.. of J (solve<false>) -- have them cleared
       make_constraint();
 #endif
       TICK(SMJ_PROF_MAKECON)
@@ -4641,7 +4651,7 @@ struct StepKernel {
         return;
       }
 #if NSAT > 0
-      if (M.solver == 2) solve_newton(last, pc, t0, prof);
+      if (newton()) solve_newton(last, pc, t0, prof);
       else solve_pgs_sat(last, pc, t0, prof);   // islands: the dense system + one lane per uncoupled satellite (smj_sat_pgs.h)
       if (last && S.debug) {
         LANES {
@@ -4650,7 +4660,7 @@ struct StepKernel {
         }
       }
 #else
-      if (M.solver == 2) solve_newton(last, pc, t0, prof);
+      if (newton()) solve_newton(last, pc, t0, prof);
       else if (nefc > NEFP) solve<true>(last, pc, t0, prof);
       else solve<false>(last, pc, t0, prof);
 #endif

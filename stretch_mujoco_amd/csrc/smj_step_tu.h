@@ -20,6 +20,9 @@
 #if SMJ_NVS == 64   // the escalation target of the 38- / 50-column builds
 #define SMJ_WORKER_KERNEL smj_step_kernel_big_worker
 #endif
+#elif defined(SMJ_TALL) && defined(SMJ_TALL_ROWS) && defined(SMJ_ONLY_PGS)   // the 128-row build, PGS-only twin (smj_kernels_midp.hip)
+#define SMJ_STEP_KERNEL smj_step_kernel_midp
+#define SMJ_LAUNCH_STEP smj_launch_step_midp
 #elif defined(SMJ_TALL) && defined(SMJ_TALL_ROWS)   // the 128-row build: primary kernel only, its steps escalate to the 160-row build
 #define SMJ_STEP_KERNEL smj_step_kernel_mid
 #define SMJ_LAUNCH_STEP smj_launch_step_mid
@@ -30,6 +33,9 @@
 #elif defined(SMJ_PROF_TU)
 #define SMJ_STEP_KERNEL smj_step_kernel_prof
 #define SMJ_LAUNCH_STEP smj_launch_step_prof
+#elif defined(SMJ_ONLY_PGS)   // the standard variant's PGS-only build (smj_kernels_pgs.hip)
+#define SMJ_STEP_KERNEL smj_step_kernel_pgs
+#define SMJ_LAUNCH_STEP smj_launch_step_pgs
 #else
 #define SMJ_STEP_KERNEL smj_step_kernel
 #define SMJ_LAUNCH_STEP smj_launch_step
@@ -192,6 +198,12 @@ __global__ __launch_bounds__(64) void SMJ_WORKER_KERNEL(const DevModel M, const 
 #endif
 
 int SMJ_LAUNCH_STEP(const DevModel& m_in, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream) {
+  // a build that carries one solver only (smj_step_impl.h newton()) refuses a launch for the other instead of running its own
+#if defined(SMJ_ONLY_NEWTON)
+  if (m_in.solver != 2) return (int)hipErrorInvalidValue;
+#elif defined(SMJ_ONLY_PGS)
+  if (m_in.solver == 2) return (int)hipErrorInvalidValue;
+#endif
   DevModel m = m_in;
   size_t lds = smj_lds_bytes(m.solver != 2);
   // A PGS launch of a primary kernel that can hand steps over (DevState::redo) keeps to the rows whose A fits the struct
