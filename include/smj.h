@@ -103,7 +103,9 @@ int smj_base_controller_tick(smj_ctx* ctx, void* stream);
  * tolerance / 64 stops sweeping while the rest goes on; 0: every island sweeps until the whole system stops, as mj_solPGS without islands),
  * "grad_noise" (Newton, default 4e-6: the loop also stops when every gradient component is below grad_noise * (|M a| + |qfrc| + |J' f|) of
  * its dof -- the rounding of the gradient's own terms in fp32; 0 = MuJoCo's scale * |grad| < tolerance test only),
- * "manifold_cache" (default on for models with free objects: a convex pair whose two bodies have not moved reuses its contacts),
+ * "manifold_cache" (default on for models with free objects: a convex pair whose two bodies stand within 2e-5 of the poses its manifold
+ * was built at keeps it, carried along to first order in the motion since), "pgs_dual_warmstart" (PGS, default on: the sweeps may start
+ * from the previous step's constraint forces, matched row by row, when that start has the lower dual cost; not MuJoCo's rule, same fixed point),
  * "max_contacts_per_pair", "solver" (0 PGS, 2 Newton), "convex_pairs", "multiccd" (mjENBL_MULTICCD, stretch.xml:8; default on), "escalate" (default on: an env whose step needs more constraint rows / contacts
  * than the standard kernel variant holds is finished by the tall variant instead of being flagged), "balance" (default on:
  * workgroups are dispatched in the order of the envs' shader time in the previous dispatch, longest first), "chunk" (default 0 = one dispatch; k > 0:

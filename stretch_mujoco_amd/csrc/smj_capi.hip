@@ -557,20 +557,27 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
       lrc = c->variant == 5 ? smj_launch_step_sat32(c->model_esc, sp, k, fl, c->aux) : smj_launch_step_tall(c->model_esc, sp, k, fl, c->aux);
       HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
     }
-    // the primary builds exist once per solver (smj_step_impl.h newton()); a launch with the profiling slot bound stays on the base name,
-    // which is the both-solver profiling copy in tools builds (csrc/Makefile bigprof)
-    const bool pgs_twin = c->model.solver != 2 && !st.prof;
+    // The primary builds exist once per solver (smj_step_impl.h newton()): the base name carries Newton, the twin PGS.  In a tools build
+    // (csrc/Makefile bigprof) the base name is the profiling copy with BOTH solvers: a PGS launch with the profiling slot bound tries it
+    // first and falls back to the twin when the base build refuses the solver (its launcher returns before launching anything).
+    typedef int (*Launch)(const DevModel&, const DevState&, int, unsigned, hipStream_t);
+    auto by_solver = [&](Launch base, Launch twin) -> int {
+      if (c->model.solver == 2) return base(c->model, st, k, fl, sm);
+      if (st.prof) {
+        const int r = base(c->model, st, k, fl, sm);
+        if (r != (int)hipErrorInvalidValue) return r;
+      }
+      return twin(c->model, st, k, fl, sm);
+    };
     if (!lrc)
       lrc = c->variant == 6   ? smj_launch_step_sat32(c->model, st, k, fl, sm)
-            : c->variant == 5 ? ((c->model.solver != 2 && !st.prof) ? (c->pgs_two_waves ? smj_launch_step_satp(c->model, st, k, fl, sm) : smj_launch_step_sat1(c->model, st, k, fl, sm))
-                                                                       : smj_launch_step_sat(c->model, st, k, fl, sm))   // (Newton-only in the product build; both solvers in the profiling build)
+            : c->variant == 5 ? by_solver(smj_launch_step_sat, c->pgs_two_waves ? smj_launch_step_satp : smj_launch_step_sat1)
             : c->variant == 4 ? smj_launch_step_big(c->model, st, k, fl, sm)
-            : c->variant == 3 ? (pgs_twin ? smj_launch_step_big50p(c->model, st, k, fl, sm) : smj_launch_step_big50(c->model, st, k, fl, sm))
-            : c->variant == 2 ? (pgs_twin ? smj_launch_step_big38p(c->model, st, k, fl, sm) : smj_launch_step_big38(c->model, st, k, fl, sm))
-            : c->variant == 1 ? (pgs_twin ? smj_launch_step_midp(c->model, st, k, fl, sm) : smj_launch_step_mid(c->model, st, k, fl, sm))
+            : c->variant == 3 ? by_solver(smj_launch_step_big50, smj_launch_step_big50p)
+            : c->variant == 2 ? by_solver(smj_launch_step_big38, smj_launch_step_big38p)
+            : c->variant == 1 ? by_solver(smj_launch_step_mid, smj_launch_step_midp)
             : st.prof         ? smj_launch_step_prof(c->model, st, k, fl, sm)
-            : c->model.solver != 2 ? smj_launch_step_pgs(c->model, st, k, fl, sm)   // the standard variant is built once per solver
-                              : smj_launch_step(c->model, st, k, fl, sm);
+                              : by_solver(smj_launch_step, smj_launch_step_pgs);
     if (poll) HIPCHK(c, hipStreamWaitEvent(sm, c->ev_join, 0));
     if (!lrc && esc) {
       // the sweep: whatever is left of the envs that ran out of constraint rows / contact slots (parked at the start of the
