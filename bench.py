@@ -160,7 +160,14 @@ def other_configs(B, dev, hold, solver):
         ms = sum(a.elapsed_time(b) for a, b, _ in events)
         steps = sum(k for _, _, k in events)
         ach = sim.num_envs * steps * bytes_step / (ms / 1e3) / 1e9
-        r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+        traffic, tsrc = None, None
+        tp = os.path.join(ROOT, "profiles", "pmc_traffic_scenes.json")
+        if os.path.exists(tp) and sim.num_envs == 4096 and hold == 50:   # HBM bytes per 50-step launch, rocprofv3 --pmc passes of the same workload on an earlier run
+            with open(tp) as fh:
+                pm = json.load(fh)
+            if scene_key in pm.get("scenes", {}):
+                traffic, tsrc = pm["scenes"][scene_key]["hbm_bytes_per_launch"], pm.get("source", "") + " -- NOT measured inside this run"
+        r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
              "bytes_per_env_step": bytes_step, "kernel": kernel, "timed_launches": len(events), "timed_kernel_ms": ms,
              "kernel_ms_per_step": ms / max(1, steps)}
         fl = flops_table.get(scene_key, {}).get("flops_per_env_step")

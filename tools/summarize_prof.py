@@ -59,6 +59,7 @@ def satellite_summary(out):
     """Satellite builds (tools/gpu_r4_profile.sh): kernel stats of the Robocasa-scale kitchen, kitchen4 and scene.xml on smj_step_kernel_sat,
     PMC means of the kitchen's launches."""
     for sub, log, title in (("rctrace", "rc_trace.log", "kitchen at Robocasa scale (`tools/gpu_options_probe.py scene=stretch_kitchen_robocasa`: 44 fixture bodies, 307 collision geoms, 8 articulated fixture parts + 8 free objects = 16 satellites; 4096 envs; primary kernel `smj_step_kernel_sat`, two envs per CU; parked chunks go to `smj_step_kernel_sat32_worker`: pollers beside the launch + the sweep after it)"),
+                            ("rcpgstrace", "rcpgs_trace.log", "the same kitchen under PGS (`tools/gpu_options_probe.py scene=stretch_kitchen_robocasa solver=0`; `smj_step_kernel_satp` = the 16-satellite build's PGS-only kernel, TWO wavefronts per env: the satellite islands swept beside the dense system; second start from the previous step's forces on)"),
                             ("trace_stretch_kitchen4_sat", "trace_stretch_kitchen4_sat.log", "kitchen with four free objects on the satellite build (`scene=stretch_kitchen4_sat`)"),
                             ("trace_stretch_scene_sat", "trace_stretch_scene_sat.log", "the reference's scene.xml on the satellite build (`scene=stretch_scene_sat`)")):
         path = os.path.join(SRC, sub, "smj_kernel_stats.csv")
@@ -79,40 +80,51 @@ def satellite_summary(out):
         if os.path.exists(tp):
             with open(tp) as f:
                 allk = list(csv.DictReader(f))
-            tr = [r for r in allk if r["Kernel_Name"].startswith("smj_step_kernel_sat(")]
+            kn = "smj_step_kernel_satp(" if sub == "rcpgstrace" else "smj_step_kernel_sat("
+            tr = [r for r in allk if r["Kernel_Name"].startswith(kn)]
             if tr:
                 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in tr]
                 r0 = tr[0]
-                out.append(f"\nPer-dispatch durations of `smj_step_kernel_sat` (ms; the first is the 300-step settle, then launches of 50 steps: "
+                out.append(f"\nPer-dispatch durations of `{kn[:-1]}` (ms; the first is the 300-step settle, then launches of 50 steps: "
                            f"6 settled + 14 under random actions): {[round(x, 1) for x in dur]}")
                 out.append(f"Resources: VGPR {r0['VGPR_Count']} (+AGPR {r0['Accum_VGPR_Count']}), SGPR {r0['SGPR_Count']}, scratch {r0['Scratch_Size']} B, "
                            f"workgroup {r0['Workgroup_Size_X']}, grid {r0['Grid_Size_X']} (dynamic LDS 81 904 B per env: two envs per CU).")
-    kv = {}
-    for d in sorted(glob.glob(os.path.join(SRC, "rcpmc_*", "smj_counter_collection.csv"))):
-        acc = collections.defaultdict(list)
-        with open(d) as f:
-            for r in csv.DictReader(f):
-                if r["Kernel_Name"].startswith("smj_step_kernel_sat("):
-                    acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        for name, v in acc.items():
-            v = v[-10:]
-            kv[name] = sum(v) / len(v)
-    if kv:
-        out.append("\n## PMC counters of `smj_step_kernel_sat` (Robocasa-scale kitchen, 4096 envs, 50-step launches under random actions; each group its own `--pmc` run), per launch, last 10 launches\n")
-        out.append("| counter | mean |\n|---|---|")
-        for name in sorted(kv):
-            out.append(f"| {name} | {kv[name]:.4g} |")
-        wc = kv.get("SQ_WAVE_CYCLES", 0)
-        if wc:
-            issued = kv.get("SQ_INSTS_VALU", 0) + kv.get("SQ_INSTS_SALU", 0) + kv.get("SQ_INSTS_LDS", 0)
-            nq, nv = 29 + 8 + 8 * 7, 28 + 8 + 8 * 6   # robot + 8 single-joint parts + 8 free objects
-            words = 2 * (nq + nv) + nv + 10 + nv   # qpos, qvel in and out; warm start; ctrl; act
-            out.append(f"\n{4 * wc / max(1, issued):.1f} shader cycles per issued instruction (one wave per SIMD, two of a CU's four SIMDs occupied); "
-                       f"MFMA busy {kv.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / max(1, 4 * wc):.4f}; LDS bank-conflict ratio {kv.get('SQ_LDS_BANK_CONFLICT', 0) / max(1, kv.get('SQ_ACTIVE_INST_LDS', 1)):.3f}; "
-                       f"VMEM reads per launch {kv.get('SQ_INSTS_VMEM_RD', 0):.3g} (static-geometry records and pair tables come from L2 / HBM, not LDS); "
-                       f"HBM per launch: FETCH_SIZE {kv.get('FETCH_SIZE', 0) * 1024 / 1e6:.1f} MB + WRITE_SIZE {kv.get('WRITE_SIZE', 0) * 1024 / 1e6:.1f} MB "
-                       f"(state moved once per launch: about {words} words x 4 B x 4096 envs = {words * 4 * 4096 / 1e6:.1f} MB; the model blob is 8 MB and stays in L2 / MALL; the writes beyond the state are manifold-cache entries -- 160 B per narrowphase miss, DevState::mcache -- and scratch spill stores, 528 B per lane: at the launch's duration a few GB/s, two orders of magnitude under the HBM roof -- this kernel is latency-bound like the standard one).")
-    for scn in ("stretch_kitchen_robocasa", "stretch_kitchen4_sat", "stretch_scene_sat"):
+    scenes_traffic = {}
+    for pre, kn, what in (("rc", "smj_step_kernel_sat(", "Newton"), ("rcpgs", "smj_step_kernel_satp(", "PGS, two wavefronts per env")):
+        kv = {}
+        for d in sorted(glob.glob(os.path.join(SRC, pre + "pmc_*", "smj_counter_collection.csv"))):
+            acc = collections.defaultdict(list)
+            with open(d) as f:
+                for r in csv.DictReader(f):
+                    if r["Kernel_Name"].startswith(kn):
+                        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            for name, v in acc.items():
+                v = v[-10:]
+                kv[name] = sum(v) / len(v)
+        if kv.get("FETCH_SIZE") or kv.get("WRITE_SIZE"):
+            scenes_traffic["stretch_kitchen_robocasa" + (":pgs" if pre == "rcpgs" else "")] = {
+                "kernel": kn[:-1], "envs_per_gpu": 4096, "steps_per_launch": 50, "hbm_bytes_per_launch": 2 * kv.get("FETCH_SIZE", 0) * 1024 + kv.get("WRITE_SIZE", 0) * 1024,
+                "fetch_bytes_raw": kv.get("FETCH_SIZE", 0) * 1024, "write_bytes_raw": kv.get("WRITE_SIZE", 0) * 1024}
+        if kv:
+            out.append(f"\n## PMC counters of `{kn[:-1]}` (Robocasa-scale kitchen, 4096 envs, {what}, 50-step launches under random actions; each group its own `--pmc` run), per launch, last 10 launches\n")
+            out.append("| counter | mean |\n|---|---|")
+            for name in sorted(kv):
+                out.append(f"| {name} | {kv[name]:.4g} |")
+            wc = kv.get("SQ_WAVE_CYCLES", 0)
+            if wc:
+                issued = kv.get("SQ_INSTS_VALU", 0) + kv.get("SQ_INSTS_SALU", 0) + kv.get("SQ_INSTS_LDS", 0)
+                nq, nv = 29 + 8 + 8 * 7, 28 + 8 + 8 * 6   # robot + 8 single-joint parts + 8 free objects
+                words = 2 * (nq + nv) + nv + 10 + nv   # qpos, qvel in and out; warm start; ctrl; act
+                out.append(f"\n{4 * wc / max(1, issued):.1f} shader cycles per issued instruction (one wave per SIMD, two of a CU's four SIMDs occupied); "
+                           f"MFMA busy {kv.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / max(1, 4 * wc):.4f}; LDS bank-conflict ratio {kv.get('SQ_LDS_BANK_CONFLICT', 0) / max(1, kv.get('SQ_ACTIVE_INST_LDS', 1)):.3f}; "
+                           f"VMEM reads per launch {kv.get('SQ_INSTS_VMEM_RD', 0):.3g} (static-geometry records and pair tables come from L2 / HBM, not LDS); "
+                           f"HBM per launch: FETCH_SIZE {kv.get('FETCH_SIZE', 0) * 1024 / 1e6:.1f} MB + WRITE_SIZE {kv.get('WRITE_SIZE', 0) * 1024 / 1e6:.1f} MB "
+                           f"(state moved once per launch: about {words} words x 4 B x 4096 envs = {words * 4 * 4096 / 1e6:.1f} MB; the model blob is 8 MB and stays in L2 / MALL; the writes beyond the state are manifold-cache entries -- 160 B per narrowphase miss, DevState::mcache -- and scratch spill stores: at the launch's duration a few GB/s, two orders of magnitude under the HBM roof -- this kernel is latency-bound like the standard one).")
+    if scenes_traffic:
+        with open(os.path.join(DST, "pmc_traffic_scenes.json"), "w") as f:
+            json.dump({"scenes": scenes_traffic, "source": f"profiles/{TAG}_rocprof_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of tools/gpu_options_probe.py scene=stretch_kitchen_robocasa [solver=0], "
+                                                              "separate passes, last 10 launches under random actions; read side x2 per MI355X_MICROARCH.md section HBM)"}, f, indent=1)
+    for scn in ("stretch_kitchen_robocasa", "stretch_kitchen4_sat", "stretch_scene_sat", "stretch_kitchen4", "stretch_scene"):
         scp = os.path.join(ROOT, "gpurun_out", f"stage_cycles_{scn}.txt")
         if os.path.exists(scp):
             with open(scp) as fi, open(os.path.join(DST, f"{TAG}_stage_cycles_{scn}.txt"), "w") as fo:
@@ -145,7 +157,7 @@ def satellite_summary(out):
     if os.path.exists(src):
         with open(src) as fi, open(os.path.join(DST, f"{TAG}_step_length.txt"), "w") as fo:
             fo.write(fi.read())
-    for name in ("sat_caps.txt", "scene_probes.txt"):
+    for name in ("sat_caps.txt", "scene_probes.txt", "soak.txt"):
         src = os.path.join(ROOT, "gpurun_out", name)
         if os.path.exists(src):
             with open(src) as fi, open(os.path.join(DST, f"{TAG}_{name}"), "w") as fo:
