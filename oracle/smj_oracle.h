@@ -11,9 +11,13 @@
  * What does pin it are the MuJoCo outputs the reference itself holds in print (docs/getting_started.ipynb): the joint
  * status at t = 8.26 s (cell 20: lift / arm to 1.4e-5, wrist and head joints to 5e-7, the lift's creep rate to 1 %), the
  * head_tilt limit stop (cell 23, to 2e-9) and 30 depth pixels of both depth cameras in the default scene (cell 14, to the
- * printed 1e-3) -- tests/test_oracle_physics.py, tests/test_depth_oracle.py.  They cover the quasi-static chain (kinematics,
- * gravity compensation, actuators, equality constraints, friction loss, limits, wheel contacts, implicitfast) and the camera
- * model; fast contact dynamics, multiccd and box-box manifolds stay unpinned.
+ * printed 1e-3) -- tests/test_oracle_physics.py, tests/test_depth_oracle.py -- and, since round 5, the IMAGES it stores: the five camera
+ * frames of cell 15 (the wrist depth map: 53 400 MuJoCo pixels to 0.3 grey levels on average), the nav frame of cell 23 and the lidar
+ * figure of cell 18 ray by ray, all of them at the one base pose cell 20 prints (tests/test_notebook_images.py; golden data decoded by
+ * tools/gen_notebook_images_golden.py / gen_lidar_golden.py).  They cover the quasi-static chain (kinematics, gravity compensation,
+ * actuators, equality constraints, friction loss, limits, wheel contacts, implicitfast), the camera and rangefinder models and the
+ * scene geometry; fast contact dynamics, multiccd and box-box manifolds stay unpinned.  Options that are NOT MuJoCo's (default off
+ * here): qcqp_cap, pgs_dual_warmstart.
  */
 #ifndef SMJ_ORACLE_H
 #define SMJ_ORACLE_H

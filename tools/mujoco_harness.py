@@ -25,8 +25,9 @@ sys.path.insert(0, ROOT)
 
 UNVERIFIED = ("MuJoCo oracle unavailable -- parity is against the build's own fp64 CPU restatement (oracle/); "
               "MuJoCo parity UNVERIFIED (the restatement is pinned to the MuJoCo output the reference's notebook prints: joint status "
-              "at t = 8.26 s to 1e-6..2e-5, head_tilt limit stop to 2e-9, 30 depth pixels of both cameras to the printed 1e-3; tests/test_oracle_physics.py, "
-              "tests/test_depth_oracle.py)")
+              "at t = 8.26 s to 1e-6..2e-5, head_tilt limit stop to 2e-9, 30 depth pixels of both cameras to the printed 1e-3, and to the images it stores: "
+              "53 400 pixels of the wrist depth map to 0.3 grey levels, the other camera frames by horizon / colour class, the lidar figure ray by ray, "
+              "all at the base pose it prints; tests/test_oracle_physics.py, tests/test_depth_oracle.py, tests/test_notebook_images.py)")
 SCRIPTS = {"home": [0, 0, 0.6, 0.1, 0, 0, 0, 0, 0, 0], "mixed": [2, -1, 0.6, 0.1, 1, -0.4, 0.5, 0.02, 0.3, -0.2],
            "driving": [3, -3, 0.2, 0.3, 2, -1, -1, 0.03, -2, 0.5], "head_tilt_limit": [0, 0, 0.6, 0.1, 0, 0, 0, 0, 0, -2.0]}
 
