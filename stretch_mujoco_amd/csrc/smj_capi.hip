@@ -40,6 +40,7 @@ struct smj_ctx {
   int* cost = nullptr;
   int* order = nullptr;
   int balance = 1;
+  int lidar_cull = 1;      // lidar: drop, per env, the geoms that cannot reach the scan plane (smj_render.h lidar_plane_*)
   int pgs_two_waves = 1;   // PGS on the 16-satellite build: 1 = the two-wavefront kernel (smj_kernels_satp.hip), 0 = one wavefront per env
   int balance_min = 1;   // steps per launch from which the cost-ordered dispatch is used (round 4: 1 -- a one-step launch is as long as its slowest round of workgroups; was 4)
   int chunk = 0;               // steps per dispatch inside one smj_step (0: the whole launch at once; measured: no gain)
@@ -158,6 +159,43 @@ static int setup_render(smj_ctx* c, const void* blob, size_t nbytes) {
   r.lidar_static = up.f32(getd(lt));
   r.site_bodyid = c->model.site_bodyid; r.site_pos = c->model.site_pos; r.site_mat = c->model.k_site_mat;
   if (!r.lgeom || !r.lidar_site || !r.lidar_static) return fail(c, -2, "device allocation failed for the lidar tables");
+  {   // the scan plane of the rangefinders (smj_render.h lidar_plane_*): all sites on one body, all rays within 1e-5 of one plane
+    r.lidar_plane_body = -1;
+    const SmjBlobEntry* sp = b.find("site_pos");
+    const SmjBlobEntry* sm = b.find("k_site_mat");
+    const SmjBlobEntry* sb = b.find("site_bodyid");
+    if (sp && sm && sb && sp->dtype == 0 && sm->dtype == 0 && r.nlidar >= 3) {
+      const std::vector<int> sites = geti(ls), sbody = geti(sb);
+      const double* P = reinterpret_cast<const double*>(b.p + sp->offset);
+      const double* Mx = reinterpret_cast<const double*>(b.p + sm->offset);
+      auto dir = [&](int i, double* d) { const double* m9 = Mx + 9 * (size_t)sites[i]; d[0] = m9[2]; d[1] = m9[5]; d[2] = m9[8]; };
+      double d0[3], n[3] = {0, 0, 0}, best = 0;
+      dir(0, d0);
+      for (int i = 1; i < r.nlidar; i++) {   // the normal from the pair of rays closest to a right angle
+        double d[3];
+        dir(i, d);
+        const double cx = d0[1] * d[2] - d0[2] * d[1], cy = d0[2] * d[0] - d0[0] * d[2], cz = d0[0] * d[1] - d0[1] * d[0], l = sqrt(cx * cx + cy * cy + cz * cz);
+        if (l > best) { best = l; n[0] = cx / l; n[1] = cy / l; n[2] = cz / l; }
+      }
+      bool ok = best > 0.5;
+      double p0[3] = {0, 0, 0}, slack = 0, slope = 0;
+      for (int i = 0; i < r.nlidar; i++) for (int k = 0; k < 3; k++) p0[k] += P[3 * (size_t)sites[i] + k] / r.nlidar;
+      for (int i = 0; ok && i < r.nlidar; i++) {
+        double d[3];
+        dir(i, d);
+        ok = sbody[sites[i]] == sbody[sites[0]];
+        const double* q = P + 3 * (size_t)sites[i];
+        slack = fmax(slack, fabs((q[0] - p0[0]) * n[0] + (q[1] - p0[1]) * n[1] + (q[2] - p0[2]) * n[2]));
+        slope = fmax(slope, fabs(d[0] * n[0] + d[1] * n[1] + d[2] * n[2]));
+      }
+      if (ok && slope < 1e-5) {
+        r.lidar_plane_body = sbody[sites[0]];
+        for (int k = 0; k < 3; k++) { r.lidar_plane_p[k] = (float)p0[k]; r.lidar_plane_n[k] = (float)n[k]; }
+        r.lidar_plane_slack = (float)slack + 1e-4f;          // + fp32 rounding of metre-scale coordinates
+        r.lidar_plane_slope = (float)fmax(slope, 2e-6);       // per metre along the ray (fp32 directions)
+      }
+    }
+  }
   r.geom_type = c->model.geom_type; r.geom_bodyid = c->model.geom_bodyid; r.geom_pos = c->model.geom_pos;
   r.geom_mat = c->model.k_geom_mat; r.geom_size = c->model.geom_size; r.geom_rbound = c->model.geom_rbound;
   r.geom_bcenter = c->model.k_geom_bcenter; r.geom_aabb = c->model.geom_aabb;
@@ -591,7 +629,9 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
   smj_launch_stage(out, c->stage, Y.stride, c->num_envs, st.ld, true, (hipStream_t)stream);
   HIPCHK(c, hipGetLastError());
   if (read_flags & SMJ_READ_LIDAR) {
-    smj_launch_lidar(c->render, st.xpose, pose_ld, c->num_envs, st.lidar, st.ld, (hipStream_t)stream);
+    DevRender rl = c->render;
+    if (!c->lidar_cull) rl.lidar_plane_body = -1;   // option "lidar_cull" = 0: every run-time geom staged for every env (the ranges must not change)
+    smj_launch_lidar(rl, st.xpose, pose_ld, c->num_envs, st.lidar, st.ld, (hipStream_t)stream);
     HIPCHK(c, hipGetLastError());
   }
   return 0;
@@ -682,6 +722,7 @@ int smj_set_option(smj_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "sep_cache")) m.sep_cache = (int)v;
   else if (!strcmp(name, "manifold_cache")) m.manifold_cache = (int)v;
   else if (!strcmp(name, "pgs_dual_warmstart")) m.pgs_dual_ws = (int)v;
+  else if (!strcmp(name, "lidar_cull")) c->lidar_cull = (int)v;                  // 1 (default): per env, only the geoms whose bounding sphere reaches the rangefinders' scan plane are staged
   else if (!strcmp(name, "depth_raster")) c->render.raster = (int)v;            // 0: ray cast the meshes through their BVHs (the round-2 path)
   else if (!strcmp(name, "depth_raster_splits")) c->render.raster_splits = (int)(v < 1 ? 1 : v > 256 ? 256 : v);
   else if (!strcmp(name, "primary_rows")) m.row_limit = (int)v;   // the escalation variant keeps its full capacity (model_esc is not touched)

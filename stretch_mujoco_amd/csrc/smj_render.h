@@ -34,6 +34,11 @@ struct DevRender {
   const float* site_pos;           // [nsite][3]
   const float* site_mat;           // [nsite][9]; the ray runs along the site's +Z
   const float* lidar_static;       // [nlidar] distance to the geoms welded to the laser (ray-cast by the model compiler), -1 none
+  // the scan plane, when every ray starts on one body and runs in one plane of it (setup_render checks): body, a point and the unit
+  // normal in the body frame, the rays' largest offset from the plane at their origins and their largest slope out of it -- the
+  // lidar kernel drops, per env, the geoms whose bounding sphere cannot reach the plane (a superset test: ranges do not depend on it)
+  int lidar_plane_body;            // -1: no such plane, no cull
+  float lidar_plane_p[3], lidar_plane_n[3], lidar_plane_slack, lidar_plane_slope;
   // mesh rasteriser (smj_meshlet_kernel; tables built at smj_create from smj_meshlet.h): meshlet vertices (float4), triangles (three
   // local vertex indices packed in 32 bits), records (three 16-byte words per meshlet: vbase nvert tbase ntri | sphere | cone) and
   // the work list over the mesh / box geoms of the visible-geom table: (table entry, first meshlet, count <= 32, 0).  raster = 0: ray cast the meshes (BVHs)

@@ -493,6 +493,42 @@ def test_lidar_floor_and_moving_meshes_vs_oracle():
     sim.stop()
 
 
+@pytest.mark.parametrize("scene", ["stretch_empty", "stretch_kitchen_standin", "stretch_kitchen_robocasa"])
+def test_lidar_scan_plane_cull_changes_no_range(scene):
+    """Round 5: the lidar kernel stages, per env, only the geoms whose bounding sphere reaches the rangefinders' scan plane (all 360
+    rays start at one point of the laser body and run in one plane of it: checked when the model is loaded, smj_render.h
+    lidar_plane_*).  A superset test: with option lidar_cull = 0 (every geom staged for every env) the scan is the same, bit for bit --
+    256 envs at random-action poses, tipped-over robots included (the plane tilts with the base)."""
+    from stretch_mujoco_amd import StretchBatchSimulator, StretchSensors
+
+    B = 256
+    sim = StretchBatchSimulator(num_envs=B, device="cuda:0", scene=scene, sensors_to_use=[StretchSensors.base_lidar], solver="newton")
+    sim.start(home=False)
+    g = torch.Generator(device=sim.device).manual_seed(5)
+    lo = torch.tensor(np.asarray(sim.model["actuator_ctrlrange"], np.float32)[:, 0], device=sim.device).unsqueeze(1)
+    hi = torch.tensor(np.asarray(sim.model["actuator_ctrlrange"], np.float32)[:, 1], device=sim.device).unsqueeze(1)
+    for w in range(4):
+        sim.ctrl.copy_(lo + (hi - lo) * torch.rand(sim.nu, B, generator=g, device=sim.device))
+        sim.step(50)
+    # a few envs with the base pitched / rolled so that the scan plane cuts through the robot's upper body and the floor
+    q = sim.qpos.clone()
+    for e, (ax, ang) in enumerate(((4, 0.3), (5, 0.4), (4, -0.5), (5, -0.2))):
+        q[3:7, e] = 0; q[3, e] = float(np.cos(ang / 2)); q[ax, e] = float(np.sin(ang / 2)); q[2, e] = 0.25
+    sim.qpos[:] = q
+    sim.step(1)
+    a = sim.pull_sensor_data().lidar.clone()
+    sim.set_option("lidar_cull", 0)
+    sim.qpos[:] = q
+    sim.step(1)
+    b = sim.pull_sensor_data().lidar.clone()
+    torch.cuda.synchronize()
+    # (the two step(1) calls start from the same uploaded qpos; qvel differs by one step, the poses of the readout do not: xpose is the
+    # forward pass of the state written)
+    assert torch.equal(a, b), int((a != b).sum())
+    assert float((a > 0).float().mean()) > 0.1
+    sim.stop()
+
+
 def test_bitwise_determinism_across_runs():
     """Two independent runs of the same rollout agree bitwise after every launch (not only at the end, where a damped system
     may have forgotten a one-ulp difference).  Catches reads of uninitialised LDS / registers / scratch, whose content
