@@ -3175,13 +3175,23 @@ struct StepKernel {
       np = np < 0 ? 0 : np > SMJ_PGSPREV_ROWS ? SMJ_PGSPREV_ROWS : np;
       if (np > 0) {
         have_prev = true;
+        // the stored rows into LDS, lane-parallel (keys -> emargin, forces -> eimp: both dead once aref is known); a row usually sits
+        // where it sat a step ago: its own index first, the scan of the whole list only for the lanes that miss
+        int* const lk = reinterpret_cast<int*>(s.emargin);
+        float* const lf = s.eimp;
+#pragma nounroll
+        for (int rb = 0; rb < np; rb += 64) LANES { const int j = lane + rb; if (j < np && j < NEFC) { lk[j] = pk[1 + j]; lf[j] = pf[j]; } }
+        if (np > NEFC) np = NEFC;
+        SYNC();
 #pragma nounroll
         for (int rb = 0; rb < ne; rb += 64) LANES {
           const int row = lane + rb;
           if (row < ne) {
             const int key = pgs_row_key(row), t = s.etype[row];
             float f = 0.f;
-            for (int j = 0; j < np; j++) f = pk[1 + j] == key ? pf[j] : f;
+            if (row < np && lk[row] == key) f = lf[row];
+            else
+              for (int j = 0; j < np; j++) f = lk[j] == key ? lf[j] : f;
             if (t == CT_FRICTION) { const float fl = s.efloss[row]; f = fminf(fl, fmaxf(-fl, f)); }
             else if (t == CT_LIMIT || t == CT_CONTACT_FRICTIONLESS) f = fmaxf(0.f, f);
             s.ediag[row] = f;   // (free: R was its last reader)
