@@ -148,7 +148,8 @@ int smj_render_rgb(smj_ctx* ctx, int camera_id, int width, int height, float fov
  * per-env returns of all ranks, rank-major, with RCCL (ncclAllGather over xGMI), issued on the caller's stream.
  * smj_comm_init joins this context to a communicator of `world` ranks: rank 0 creates the ncclUniqueId and publishes it
  * atomically in the file `id_path` (a path all ranks of the node can read, unique per job); the other ranks wait for it up to
- * `timeout_s` seconds.  librccl is bound at run time (dlopen; a copy already mapped by PyTorch is reused), so a single-GPU
+ * `timeout_s` seconds.  librccl is bound at run time (dlopen; a copy already mapped by PyTorch is reused; the environment variable
+ * SMJ_RCCL_LIB names another library file -- a site's own RCCL build, or the tests' stub), so a single-GPU
  * process never loads it.  Without smj_comm_init (or with world == 1) smj_allgather_returns is a device copy. */
 int smj_comm_init(smj_ctx* ctx, int rank, int world, const char* id_path, double timeout_s);
 int smj_allgather_returns(smj_ctx* ctx, const float* send_dev /* [count] */, float* recv_dev /* [world*count] */, int count,
