@@ -300,3 +300,20 @@ def test_status_at_t_6_422_against_the_readme_through_the_api():
     assert float((st.head_pan.pos - (-4.968686850480367e-06)).abs().max()) < 2e-5
     assert 0.5885 <= float(st.lift.pos[0]) <= 0.5912 and 0.0975 <= float(st.arm.pos[0]) <= 0.1005
     sim.stop()
+
+
+@pytest.mark.parametrize("script,args", [("move_joints_batch.py", ["4"]), ("sensors_batch.py", ["2"]), ("draw_circles_batch.py", ["4", "9"]), ("start_pose_batch.py", ["3"])])
+def test_examples_run(script, args):
+    """examples/: the flows of the reference's examples (move_joints.py, laser_scan.py + camera_feeds.py, draw_circles.py, start_pose.py /
+    world_frames.py) on a batch, each as its own process."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", script)] + args, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    if script == "draw_circles_batch.py":
+        last = [l for l in out.stdout.splitlines() if l.startswith("largest distance")][0]
+        worst = [float(v) for v in last.split("[m]:")[1].strip(" []").split(",")]
+        assert max(worst) < 0.06, last      # wait_until_at_setpoint's tolerance is 0.05 (stretch_mujoco_simulator.py:235-265)
