@@ -242,7 +242,7 @@ def other_configs(B, dev, hold, solver):
             sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver="pgs", scene=scene)
             sim.start(home=False)
             evs = []
-            res[scene + "_physics_pgs"] = {"value": rollout(sim, n, hold, events=evs)   # same settle / pre-roll as the Newton runs: the steady state of the random-action workload, "unit": "env-steps/s", **flags_of(sim)}
+            res[scene + "_physics_pgs"] = {"value": rollout(sim, n, hold, events=evs), "unit": "env-steps/s", **flags_of(sim)}   # same settle / pre-roll as the Newton runs: the steady state of the random-action workload
             res[scene + "_physics_pgs"]["sweeps_last_step"] = {"mean": float(sim.info[2].float().mean().item()), "at_cap_of_100": float((sim.info[2] >= 100).float().mean().item())}
             if scene == "stretch_kitchen_robocasa":
                 res[scene + "_physics_pgs"]["roofline"] = roofline_of(sim, evs, scene + ":pgs", "smj_step_kernel_satp (two wavefronts per env)")
