@@ -74,11 +74,11 @@ def test_no_cpu_fallback_in_the_product():
 def test_entry_points_and_scripts_compile():
     """bench.py, __graft_entry__.py, tools/ and examples/ are only ever executed on the GPU box: at least their syntax is checked here."""
     import glob
-    import py_compile
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     files = [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")] + sorted(glob.glob(os.path.join(root, "tools", "*.py")))
     files += sorted(glob.glob(os.path.join(root, "examples", "*.py")))
     assert len(files) > 20
     for f in files:
-        py_compile.compile(f, doraise=True, cfile=os.devnull)
+        with open(f) as fh:
+            compile(fh.read(), f, "exec")
