@@ -26,11 +26,11 @@ diameter = torch.linspace(0.08, 0.2, B, device=sim.device)       # draw_circles.
 worst = torch.zeros(B, device=sim.device)
 for k in range(N):
     t = 2 * math.pi * k / (N - 1)
-    sim.move_to(Actuators.arm, arm0 + diameter / 2 * (math.cos(t) - 1))      # (start ON the circle: the first point is where the arm is)
+    sim.move_to(Actuators.arm, arm0 + diameter / 2 * (1 - math.cos(t)))      # (start ON the circle: the first point is where the arm is; the circle lies outward, inside the arm's range)
     sim.move_to(Actuators.lift, lift0 + diameter / 2 * math.sin(t))
     ok = sim.wait_until_at_setpoint(Actuators.arm) & sim.wait_until_at_setpoint(Actuators.lift)   # [B] bool, sim clock, 0.05 tolerance like the reference
     st = sim.pull_status()
-    r = torch.sqrt((st.arm.pos - (arm0 - diameter / 2)) ** 2 + (st.lift.pos - lift0) ** 2)
+    r = torch.sqrt((st.arm.pos - (arm0 + diameter / 2)) ** 2 + (st.lift.pos - lift0) ** 2)
     worst = torch.maximum(worst, (r - diameter / 2).abs())
     if k % 4 == 0:
         print(f"point {k:2d}: reached in {int(ok.sum())} of {B} envs; radius error max {float((r - diameter / 2).abs().max()):.4f} m")
