@@ -1175,8 +1175,10 @@ SMJ_DEV void collision_static(float* pc, bool prof) {
       const uint64_t m2 = wave_ballot(bit);
       const int total = popc64(m0) + 2 * popc64(m1) + 4 * popc64(m2);
       if (total) {
+        // (side by side with the second wavefront the slots are claimed first, and a batch that does not fit is not written at all)
+        const bool fits = (SMJ_SPLIT_COLLIDE && split_on) ? con_claim(total) : ncon + total <= NCON;
         LANES {
-          const int c = cnt[lane];
+          const int c = (fits || !(SMJ_SPLIT_COLLIDE && split_on)) ? cnt[lane] : 0;
           if (c) {
             const uint64_t lt = (1ull << lane) - 1;
             const int off = ncon + popc64(m0 & lt) + 2 * popc64(m1 & lt) + 4 * popc64(m2 & lt);
@@ -1199,7 +1201,7 @@ SMJ_DEV void collision_static(float* pc, bool prof) {
               }
           }
         }
-        if (ncon + total > NCON) { flags |= SMJ_FLAG_CON_OVERFLOW | 0x4000; ncon = NCON; }
+        if (!fits) { flags |= SMJ_FLAG_CON_OVERFLOW | 0x4000; if (!(SMJ_SPLIT_COLLIDE && split_on)) ncon = NCON; }
         else ncon += total;
         SYNC();
 #ifdef SMJ_EMUL

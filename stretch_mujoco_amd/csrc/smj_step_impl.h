@@ -33,6 +33,13 @@ enum { CT_EQUALITY = 0, CT_FRICTION = 1, CT_LIMIT = 3, CT_CONTACT_FRICTIONLESS =
 #else
 #define NCGS NCG
 #endif
+// Two wavefronts per env under Newton (smj_kernels_sat2.hip): the collision stage runs on both -- the first wavefront takes the
+// pairs with the static world (collision_static), the second one the moving-moving pairs (collide_helper) -- see collision_convex().
+#if defined(SMJ_TWO_WAVES) && defined(SMJ_ONLY_NEWTON) && NSAT > 0 && !defined(SMJ_EMUL)
+#define SMJ_SPLIT_COLLIDE 1
+#else
+#define SMJ_SPLIT_COLLIDE 0
+#endif
 struct TreeTmp {  // lives in the A region until A is built
   float cinert[NBP][10], crb[NBP][10], cvel[NBP][6], cfrc[NBP][6], buf[NVP][6], cdof[NVP][6], cdof_dot[NVP][6];
 };
@@ -85,6 +92,13 @@ struct Smem {
       int sl_n, sl_sid[NSURV];     // static-geometry broadphase (collision_static): survivors = index into k_sprec ...
       unsigned char sl_c[NSURV], sl_ord[NSURV];   // ... the moving geom's cache slot; the survivors in pair-table order
       float mc_r[NCG];             // bounding radii of the cached geoms
+#endif
+#if SMJ_SPLIT_COLLIDE
+      // two wavefronts in the collision stage (smj_kernels_sat2.hip, collide_helper()): the second one's multiccd scratch, the
+      // mailbox {command, env, its contact count, its flags}, the contact slots the two have claimed together
+      float mc2[5][3];
+      int mbox[4];
+      int contotal;
 #endif
     } c;
 #if NSAT > 0
@@ -339,6 +353,10 @@ struct StepKernel {
   int step_base = 0;     // steps of this launch that earlier chunks of the env already ran (pipelined chunks, DevState::pipe_len)
   int pipe_chunk = 0;    // the chunk this workgroup runs
   bool parked = false;   // run() handed the env to the escalation list
+  // Collision stage on two wavefronts (SMJ_SPLIT_COLLIDE): `split_on` while the two run side by side (contact slots are claimed from
+  // the shared counter Smem::u.c.contotal), `rev` in the second wavefront, whose contact k sits in slot NCON - 1 - k until the first
+  // one appends them to its own
+  bool split_on = false, rev = false;
 
   SMJ_DEV StepKernel(const DevModel& M_, const DevState& S_, Smem& s_, int env_) : M(M_), S(S_), s(s_), env(env_) {}
 
@@ -1140,7 +1158,30 @@ struct StepKernel {
     cross3(fr + 6, fr, fr + 3);
   }
   // per-lane: fill contact slot c from the convex pair's record (DevModel::k_cprec)
-  SMJ_DEV void write_contact(int c, const int* r, float dist, const float* pos, const float* n) {
+  SMJ_DEV int cslot(int c) const { return (SMJ_SPLIT_COLLIDE && rev) ? NCON - 1 - c : c; }
+  SMJ_DEV float (*mcs())[3] {
+#if SMJ_SPLIT_COLLIDE
+    return rev ? s.u.c.mc2 : s.u.c.mc;
+#else
+    return s.u.c.mc;
+#endif
+  }
+  // room for n more contacts?  One wavefront: its own count.  Two side by side: the slots are claimed from the shared counter (an
+  // LDS atomic), so the two lists -- one growing from the bottom, one from the top -- cannot meet; a claim that fails leaves the
+  // counter above NCON, and every later claim of either wavefront fails too (the step is flagged and redone by the larger build).
+  SMJ_DEV bool con_claim(int n) {
+#if SMJ_SPLIT_COLLIDE
+    if (split_on) {
+      if (ncon + n > NCON) return false;
+      int old = 0;
+      LANES { if (lane == 0) old = lds_atomic_add(&s.u.c.contotal, n); }
+      return uni(old) + n <= NCON;
+    }
+#endif
+    return ncon + n <= NCON;
+  }
+  SMJ_DEV void write_contact(int c_, const int* r, float dist, const float* pos, const float* n) {
+    const int c = cslot(c_);
     s.cdist[c] = dist;
     float fr[9] = {n[0], n[1], n[2], 0, 0, 0, 0, 0, 0};
     make_frame(fr);
@@ -1156,7 +1197,7 @@ struct StepKernel {
   }
   SMJ_DEV void add_contact(const int* r, float dist, const float* pos, const float* n) {
     // uniform: every lane calls with identical arguments; lane 0 writes
-    if (ncon >= NCON) { flags |= SMJ_FLAG_CON_OVERFLOW | 0x4000; return; }
+    if (!con_claim(1)) { flags |= SMJ_FLAG_CON_OVERFLOW | 0x4000; return; }
     const int c = ncon++;
     LANES { if (lane == 0) write_contact(c, r, dist, pos, n); }
   }
@@ -2118,8 +2159,10 @@ struct StepKernel {
     }
     const int total = popc64(mask) < 8 ? popc64(mask) : 8;
     const float cn[3] = {swap ? -n[0] : n[0], swap ? -n[1] : n[1], swap ? -n[2] : n[2]};
+    // (side by side with the other wavefront the slots are claimed first, and a batch that does not fit is not written at all)
+    const bool fits = (SMJ_SPLIT_COLLIDE && split_on) ? con_claim(total) : ncon + total <= NCON;
     LANES {
-      if (okv[lane]) {
+      if (okv[lane] && (fits || !(SMJ_SPLIT_COLLIDE && split_on))) {
         const int k = popc64(mask & ((1ull << lane) - 1));
         if (k < 8 && ncon + k < NCON) {
           const float pos[3] = {px[lane], py[lane], pz[lane]};
@@ -2127,7 +2170,7 @@ struct StepKernel {
         }
       }
     }
-    if (ncon + total > NCON) { flags |= SMJ_FLAG_CON_OVERFLOW; ncon = NCON; }
+    if (!fits) { flags |= SMJ_FLAG_CON_OVERFLOW; if (!(SMJ_SPLIT_COLLIDE && split_on)) ncon = NCON; }   // (side by side nothing was written: the list stays the valid prefix it is)
     else ncon += total;
   }
 
@@ -2152,7 +2195,7 @@ struct StepKernel {
                             float margin, float tol) {
     float fr[9] = {dir0[0], dir0[1], dir0[2], 0, 0, 0, 0, 0, 0};
     make_frame(fr);
-    LANES { if (lane == 0) for (int k = 0; k < 3; k++) s.u.c.mc[0][k] = pos0[k]; }
+    LANES { if (lane == 0) for (int k = 0; k < 3; k++) mcs()[0][k] = pos0[k]; }
     SYNC();
     int n = 1;
 #pragma nounroll
@@ -2175,11 +2218,11 @@ struct StepKernel {
       bool dup = false;
 #pragma nounroll
       for (int k = 0; k < n; k++) {
-        const float e[3] = {ps[0] - uni(s.u.c.mc[k][0]), ps[1] - uni(s.u.c.mc[k][1]), ps[2] - uni(s.u.c.mc[k][2])};
+        const float e[3] = {ps[0] - uni(mcs()[k][0]), ps[1] - uni(mcs()[k][1]), ps[2] - uni(mcs()[k][2])};
         dup = dup || dot3(e, e) < tol * tol;
       }
       if (dup) continue;
-      LANES { if (lane == 0) for (int k = 0; k < 3; k++) s.u.c.mc[n][k] = ps[k]; }
+      LANES { if (lane == 0) for (int k = 0; k < 3; k++) mcs()[n][k] = ps[k]; }
       SYNC();
       n++;
       add_contact(rec, -dp, ps, dir0);
@@ -2441,7 +2484,7 @@ struct StepKernel {
       okp[lane] = m.ok; dpp[lane] = m.depth; drx[lane] = m.pdir[0]; dry[lane] = m.pdir[1]; drz[lane] = m.pdir[2];
       psx[lane] = m.pos[0]; psy[lane] = m.pos[1]; psz[lane] = m.pos[2];
     }
-    LANES { if (lane == 0) for (int k = 0; k < 3; k++) s.u.c.mc[0][k] = pos0[k]; }
+    LANES { if (lane == 0) for (int k = 0; k < 3; k++) mcs()[0][k] = pos0[k]; }
     SYNC();
     int n = 1;
 #pragma nounroll
@@ -2454,11 +2497,11 @@ struct StepKernel {
       bool dup = false;
 #pragma nounroll
       for (int k = 0; k < n; k++) {
-        const float e[3] = {ps[0] - uni(s.u.c.mc[k][0]), ps[1] - uni(s.u.c.mc[k][1]), ps[2] - uni(s.u.c.mc[k][2])};
+        const float e[3] = {ps[0] - uni(mcs()[k][0]), ps[1] - uni(mcs()[k][1]), ps[2] - uni(mcs()[k][2])};
         dup = dup || dot3(e, e) < tol * tol;
       }
       if (dup) continue;
-      LANES { if (lane == 0) for (int k = 0; k < 3; k++) s.u.c.mc[n][k] = ps[k]; }
+      LANES { if (lane == 0) for (int k = 0; k < 3; k++) mcs()[n][k] = ps[k]; }
       SYNC();
       n++;
       add_contact(rec, -dp, ps, dir0);
@@ -2487,7 +2530,12 @@ struct StepKernel {
     dist += n[0] * (ub[0] - ua[0]) + n[1] * (ub[1] - ua[1]) + n[2] * (ub[2] - ua[2]);
     for (int k = 0; k < 3; k++) p[k] += 0.5f * (ua[k] + ub[k]);
   }
-  SMJ_DEV float* mc_entry(int tag) const { return S.mcache + ((size_t)env * SMJ_MC_SLOTS + (((unsigned)tag * 2654435761u) >> (32 - SMJ_MC_LOG2))) * SMJ_MC_WORDS; }
+  // (moving-moving pairs in the lower half of the env's slots, pairs with the static world -- tag bit 30 -- in the upper half: the two
+  // groups never evict each other, so the cache's contents do not depend on the order the two groups are worked in)
+  SMJ_DEV float* mc_entry(int tag) const {
+    const unsigned slot = (((unsigned)tag >> 30) & 1u) << SMJ_MC_LOG2 | (((unsigned)tag * 2654435761u) >> (32 - SMJ_MC_LOG2));
+    return S.mcache + ((size_t)env * SMJ_MC_SLOTS + slot) * SMJ_MC_WORDS;
+  }
   SMJ_DEV void narrow_pair(const int* r, int s1, int s2, float* sepslot, int septag, bool sep_hit, const float* sd, float* pc, bool prof, bool lookup = true) {
     const int g1 = uni(r[SMJ_CP_G1]), g2 = uni(r[SMJ_CP_G2]);
     // the pair's stored manifold (DevState::mcache): valid while neither body has moved
@@ -2529,7 +2577,7 @@ struct StepKernel {
       }
     }
     narrow_pair_run(r, g1, g2, s1, s2, sepslot, septag, sep_hit, sd, pc, prof);
-    if (mc && ncon > ncon0 && ncon - ncon0 <= 5 && ncon < NCON) {   // keep what the narrowphase found, with the poses it was found at -- unless the contact list is full: the manifold may be cut short, and the worker that redoes the step (same poses) must not replay it
+    if (mc && ncon > ncon0 && ncon - ncon0 <= 5 && !(flags & SMJ_FLAG_CON_OVERFLOW)) {   // keep what the narrowphase found, with the poses it was found at -- unless the contact list has overflowed: the manifold may be cut short, and the worker that redoes the step (same poses) must not replay it
       const int b1 = uni(r[SMJ_CP_B1]), b2 = uni(r[SMJ_CP_B2]), n = ncon - ncon0;
       SYNC();
       LANES {
@@ -2538,8 +2586,8 @@ struct StepKernel {
           if (lane == 0) v = asf(septag);
           else if (lane < 15) { const int b = lane < 8 ? b1 : b2, k = lane < 8 ? lane - 1 : lane - 8; v = k < 3 ? s.xpos[b][k] : s.xquat[b][k - 3]; }
           else if (lane == 15) v = (float)n;
-          else if (lane < 19) v = s.cframe[ncon0][lane - 16];
-          else if (lane < 19 + 4 * n) { const int k = (lane - 19) >> 2, q = (lane - 19) & 3; v = q == 0 ? s.cdist[ncon0 + k] : s.cpos[ncon0 + k][q - 1]; }
+          else if (lane < 19) v = s.cframe[cslot(ncon0)][lane - 16];
+          else if (lane < 19 + 4 * n) { const int k = (lane - 19) >> 2, q = (lane - 19) & 3; v = q == 0 ? s.cdist[cslot(ncon0 + k)] : s.cpos[cslot(ncon0 + k)][q - 1]; }
           mc[lane] = v;
         }
       }
@@ -2651,9 +2699,85 @@ struct StepKernel {
     }
     SYNC();
     CTICK(SMJ_PROF_C_POSE)
+#if SMJ_SPLIT_COLLIDE
+    // The env's second wavefront works the moving-moving pairs (collide_helper -> collision_moving) while this one works the pairs with
+    // the static world: two barriers per step.  Its contacts come back in the slots NCON - 1, NCON - 2, ... and are appended here,
+    // behind the static ones: the one-wavefront build's list, contact for contact.
+    LANES {
+      if (lane == 0) { s.u.c.mbox[0] = W2_RUN; s.u.c.mbox[1] = env; s.u.c.contotal = ncon; }
+    }
+    WG_BARRIER();
+    split_on = true;
+    collision_static(pc, prof);
+    split_on = false;
+    CTICK(SMJ_PROF_C_NARROW)
+    WG_BARRIER();
+    {
+      const int nh = uni(s.u.c.mbox[2]);
+      flags |= uni(s.u.c.mbox[3]);
+      if (nh > 0 && ncon + nh <= NCON && !(flags & SMJ_FLAG_CON_OVERFLOW)) {
+        PL<float[31]> w;
+        LANES {
+          if (lane < nh) {
+            const int c = NCON - 1 - lane;
+            float* v = w[lane];
+            v[0] = s.cdist[c]; v[1] = s.cmargin[c];
+            for (int k = 0; k < 9; k++) v[2 + k] = s.cframe[c][k];
+            for (int k = 0; k < 3; k++) v[11 + k] = s.cpos[c][k];
+            for (int k = 0; k < 5; k++) { v[14 + k] = s.cfric[c][k]; v[19 + k] = s.csolimp[c][k]; }
+            v[24] = s.csolref[c][0]; v[25] = s.csolref[c][1];
+            v[26] = __builtin_bit_cast(float, (int)s.cdim[c]); v[27] = __builtin_bit_cast(float, (int)s.cgeom1[c]);
+            v[28] = __builtin_bit_cast(float, (int)s.cgeom2[c]); v[29] = __builtin_bit_cast(float, (int)s.cefc[c]);
+            v[30] = __builtin_bit_cast(float, (int)s.cpair[c]);
+          }
+        }
+        SYNC();
+        LANES {
+          if (lane < nh) {
+            const int c = ncon + lane;
+            const float* v = w[lane];
+            s.cdist[c] = v[0]; s.cmargin[c] = v[1];
+            for (int k = 0; k < 9; k++) s.cframe[c][k] = v[2 + k];
+            for (int k = 0; k < 3; k++) s.cpos[c][k] = v[11 + k];
+            for (int k = 0; k < 5; k++) { s.cfric[c][k] = v[14 + k]; s.csolimp[c][k] = v[19 + k]; }
+            s.csolref[c][0] = v[24]; s.csolref[c][1] = v[25];
+            s.cdim[c] = __builtin_bit_cast(int, v[26]); s.cgeom1[c] = (unsigned short)__builtin_bit_cast(int, v[27]);
+            s.cgeom2[c] = (unsigned short)__builtin_bit_cast(int, v[28]); s.cefc[c] = __builtin_bit_cast(int, v[29]);
+            s.cpair[c] = __builtin_bit_cast(int, v[30]);
+          }
+        }
+        ncon += nh;
+      } else if (nh > 0) flags |= SMJ_FLAG_CON_OVERFLOW | 0x4000;   // (a flagged step: the list stays this wavefront's own contacts, every slot of it written)
+    }
+    SYNC();
+    CTICK(SMJ_PROF_C_SPHERE)
+#undef CTICK
+  }
+  enum { W2_RUN = 1, W2_EXIT = 2 };
+  // The second wavefront of the env: waits for the first one to reach the collision stage of a step (first barrier), works the
+  // moving-moving pairs, hands its count and flags over (second barrier), and leaves when the first one is through with the launch.
+  // (Entered behind the first of those barriers -- the kernel reads the env from the mailbox there, smj_step_tu.h.)
+  SMJ_DEV void collide_helper() {
+    rev = true;
+    split_on = true;
+    for (;;) {
+      ncon = 0;
+      flags = 0;
+      collision_moving(nullptr, false);
+      LANES { if (lane == 0) { s.u.c.mbox[2] = ncon; s.u.c.mbox[3] = flags; } }
+      WG_BARRIER();   // the first wavefront takes the contacts over
+      WG_BARRIER();   // its next collision stage, or the end of the launch
+      if (uni(s.u.c.mbox[0]) != W2_RUN) return;
+    }
+  }
+  SMJ_DEV void collision_moving(float* pc, bool prof) {
+    long long tc = prof ? smj_clock() : 0;
+#define CTICK(slot) if (prof) { const long long t1 = smj_clock(); pc[slot] += (float)(t1 - tc); tc = t1; }
+#else
 #if NSAT > 0
     collision_static(pc, prof);   // moving geoms against the world body's geoms, through the uniform grid (before the moving-moving pairs: pair-table order)
     CTICK(SMJ_PROF_C_NARROW)
+#endif
 #endif
     // pass 1: bounding spheres of all pairs (lane = pair), survivors compacted in table order.  The pair words of eight
     // chunks are fetched up front so that their load latency is paid once per group, not once per chunk.

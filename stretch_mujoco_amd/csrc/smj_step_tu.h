@@ -103,9 +103,19 @@ __global__ __launch_bounds__(SMJ_WG_THREADS) SMJ_KERNEL_ATTR void SMJ_STEP_KERNE
   extern __shared__ __align__(16) unsigned char smj_lds[];
   Smem& smem = *reinterpret_cast<Smem*>(smj_lds);
 #ifdef SMJ_TWO_WAVES
-  if (threadIdx.x >= 64) {   // the env's second wavefront: the satellite islands' PGS sweeps (smj_sat_pgs.h pgs_helper), nothing else
+  if (threadIdx.x >= 64) {
+#if SMJ_SPLIT_COLLIDE
+    // the env's second wavefront under Newton: the moving-moving pairs of every collision stage (smj_step_impl.h collide_helper);
+    // the first wavefront names the env when it reaches its first collision stage -- or ends the launch
+    WG_BARRIER();
+    if (uni(smem.u.c.mbox[0]) != StepKernel::W2_RUN) return;
+    StepKernel h(M, S, smem, uni(smem.u.c.mbox[1]));
+    h.collide_helper();
+#else
+    // the env's second wavefront under PGS: the satellite islands' sweeps (smj_sat_pgs.h pgs_helper), nothing else
     StepKernel h(M, S, smem, 0);
     h.pgs_helper();
+#endif
     return;
   }
 #endif
@@ -122,7 +132,12 @@ __global__ __launch_bounds__(SMJ_WG_THREADS) SMJ_KERNEL_ATTR void SMJ_STEP_KERNE
   }
   if (S.sched && threadIdx.x == 0) atomicAdd(&S.sched[SMJ_SCHED_EXITED], 1);
 #ifdef SMJ_TWO_WAVES
-  if (threadIdx.x == 0) smem.sat.x[SX_MV][0][4] = __builtin_bit_cast(float, (int)StepKernel::PGS2_EXIT);   // release the second wavefront (every path of the first one ends here)
+  // release the second wavefront (every path of the first one ends here)
+#if SMJ_SPLIT_COLLIDE
+  if (threadIdx.x == 0) smem.u.c.mbox[0] = StepKernel::W2_EXIT;
+#else
+  if (threadIdx.x == 0) smem.sat.x[SX_MV][0][4] = __builtin_bit_cast(float, (int)StepKernel::PGS2_EXIT);
+#endif
   WG_BARRIER();
 #endif
 }

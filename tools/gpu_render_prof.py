@@ -1,4 +1,4 @@
-"""Workload for the rocprofv3 passes over the ray-casting kernels (tools/gpu_profile.sh): kitchen stand-in, B envs at random
+"""Workload for the rocprofv3 passes over the ray-casting kernels (tools/gpu_profile.sh): kitchen stand-in (or the scene named second), B envs at random
 arm / head poses, a few renders of both depth cameras and a few lidar readouts."""
 import sys
 
@@ -10,8 +10,8 @@ from stretch_mujoco_amd import StretchBatchSimulator, StretchSensors  # noqa: E4
 from stretch_mujoco_amd.enums import StretchCameras  # noqa: E402
 
 
-def main(B=4096, reps=3):
-    sim = StretchBatchSimulator(num_envs=B, device="cuda:0", scene="stretch_kitchen_standin", cameras_to_use=StretchCameras.depth(),
+def main(B=4096, reps=3, scene="stretch_kitchen_standin"):
+    sim = StretchBatchSimulator(num_envs=B, device="cuda:0", scene=scene, cameras_to_use=StretchCameras.depth(),
                                 sensors_to_use=StretchSensors.all())
     sim.start(home=False)
     g = torch.Generator(device=sim.device).manual_seed(1234)
@@ -29,4 +29,4 @@ def main(B=4096, reps=3):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 4096)
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 4096, scene=sys.argv[2] if len(sys.argv) > 2 else "stretch_kitchen_standin")
