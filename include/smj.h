@@ -98,8 +98,9 @@ int smj_base_controller_tick(smj_ctx* ctx, void* stream);
  * the previous sweep; 1: mju_QCQP's own iteration from 0, cap 20 -- the two differ where that cap is hit),
  * "pgs_two_waves" (PGS on the 16-satellite build, default 1: two wavefronts per env -- the second sweeps the satellites' constraint
  * islands beside the first one's sweeps of the dense system; 0: one wavefront), "newton_two_waves" (Newton on the 16-satellite build,
- * default 1: two wavefronts per env -- in the collision stage the second works the moving-moving pairs while the first works the pairs
- * with the static world; the same states bit for bit as 0: one wavefront), "balance_min" (default 1: launches of at least this many
+ * default 1: two wavefronts per env -- the second takes the moving-moving pairs of the collision stage and the satellites' lane-serial
+ * stages (forward pass, Newton blocks, integration) beside the first one's work; the same states bit for bit as 0: one wavefront),
+ * "balance_min" (default 1: launches of at least this many
  * steps are dispatched longest-env-first),
  * "pgs_island_stop" (PGS on the satellite builds, default 1: a satellite's constraint island whose own scaled improvement fell below
  * tolerance / 64 stops sweeping while the rest goes on; 0: every island sweeps until the whole system stops, as mj_solPGS without islands),

@@ -41,7 +41,7 @@ struct smj_ctx {
   int* order = nullptr;
   int balance = 1;
   int lidar_cull = 1;      // lidar: drop, per env, the geoms that cannot reach the scan plane (smj_render.h lidar_plane_*)
-  int newton_two_waves = 1;   // Newton on the 16-satellite build: 1 = the two-wavefront kernel (smj_kernels_sat2.hip: the collision stage on both), 0 = one wavefront per env
+  int newton_two_waves = 1;   // Newton on the 16-satellite build: 1 = the two-wavefront kernel (smj_kernels_sat2.hip: the second wavefront takes the moving-moving pairs and the satellites' lane-serial stages), 0 = one wavefront per env
   int pgs_two_waves = 1;   // PGS on the 16-satellite build: 1 = the two-wavefront kernel (smj_kernels_satp.hip), 0 = one wavefront per env
   int balance_min = 1;   // steps per launch from which the cost-ordered dispatch is used (round 4: 1 -- a one-step launch is as long as its slowest round of workgroups; was 4)
   int chunk = 0;               // steps per dispatch inside one smj_step (0: the whole launch at once; measured: no gain)
@@ -610,7 +610,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
     };
     if (!lrc)
       lrc = c->variant == 6   ? smj_launch_step_sat32(c->model, st, k, fl, sm)
-            : c->variant == 5 ? by_solver((c->newton_two_waves && !st.prof) ? smj_launch_step_sat2 : smj_launch_step_sat, c->pgs_two_waves ? smj_launch_step_satp : smj_launch_step_sat1)
+            : c->variant == 5 ? by_solver((c->newton_two_waves && (!st.prof || smj_sat2_profiling())) ? smj_launch_step_sat2 : smj_launch_step_sat, c->pgs_two_waves ? smj_launch_step_satp : smj_launch_step_sat1)
             : c->variant == 4 ? smj_launch_step_big(c->model, st, k, fl, sm)
             : c->variant == 3 ? by_solver(smj_launch_step_big50, smj_launch_step_big50p)
             : c->variant == 2 ? by_solver(smj_launch_step_big38, smj_launch_step_big38p)

@@ -33,7 +33,8 @@ int smj_launch_step_big(const DevModel& m, const DevState& s, int nsteps, unsign
 int smj_launch_step_big38(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);   // 38
 int smj_launch_step_big50(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);   // 50
 int smj_launch_step_satp(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);    // the same build with two wavefronts per env: PGS, satellite islands beside the dense system (smj_kernels_satp.hip)
-int smj_launch_step_sat2(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);    // 16 satellites, Newton only, two wavefronts per env: the collision stage on both (option newton_two_waves = 1)
+int smj_launch_step_sat2(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);    // 16 satellites, Newton only, two wavefronts per env (option newton_two_waves = 1)
+int smj_sat2_profiling();   // whether that build carries the per-stage cycle counters (DevState::prof)
 int smj_launch_step_sat1(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);    // 16 satellites, PGS only, one wavefront per env (option pgs_two_waves = 0)
 int smj_launch_step_sat(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);     // main tree + satellites (smj_sat.h)
 int smj_launch_step_sat32(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);   // up to 32 satellites, one env per CU

@@ -40,6 +40,16 @@ enum { CT_EQUALITY = 0, CT_FRICTION = 1, CT_LIMIT = 3, CT_CONTACT_FRICTIONLESS =
 #else
 #define SMJ_SPLIT_COLLIDE 0
 #endif
+// (the second wavefront's other jobs, helper(): switches for measurements)
+#ifndef SMJ_W2_FORWARD
+#define SMJ_W2_FORWARD SMJ_SPLIT_COLLIDE
+#endif
+#ifndef SMJ_W2_NEWTON
+#define SMJ_W2_NEWTON SMJ_SPLIT_COLLIDE
+#endif
+#ifndef SMJ_W2_INTEGRATE
+#define SMJ_W2_INTEGRATE SMJ_SPLIT_COLLIDE
+#endif
 struct TreeTmp {  // lives in the A region until A is built
   float cinert[NBP][10], crb[NBP][10], cvel[NBP][6], cfrc[NBP][6], buf[NVP][6], cdof[NVP][6], cdof_dot[NVP][6];
 };
@@ -94,10 +104,9 @@ struct Smem {
       float mc_r[NCG];             // bounding radii of the cached geoms
 #endif
 #if SMJ_SPLIT_COLLIDE
-      // two wavefronts in the collision stage (smj_kernels_sat2.hip, collide_helper()): the second one's multiccd scratch, the
-      // mailbox {command, env, its contact count, its flags}, the contact slots the two have claimed together
+      // two wavefronts in the collision stage (smj_kernels_sat2.hip, helper()): the second one's multiccd scratch, the contact
+      // slots the two have claimed together
       float mc2[5][3];
-      int mbox[4];
       int contotal;
 #endif
     } c;
@@ -130,6 +139,11 @@ struct Smem {
   } u;
 #if NSAT > 0
   SatMem sat;
+#endif
+#if SMJ_SPLIT_COLLIDE
+  // mailbox of the env's two wavefronts (helper()): [0] command; [1] the env (first command of a launch) / the cone mask's low word;
+  // [2] the second wavefront's contact count / the cone mask's high word; [3] its flags.  (The last 16 bytes of the 80 KB.)
+  int mbox[4];
 #endif
   SMJ_DEV float* A(int cap) { return &J[cap][0]; }   // PGS: A = Y D^-1 Y' + R as a packed lower triangle of cap (cap + 1) / 2 floats behind the rows a step may use (cap = NEFC_P: the union's start)
 };
@@ -667,8 +681,11 @@ struct StepKernel {
         }
         quat_normalize(quat);
       }
-      for (int k = 0; k < 3; k++) { pl[lane][k] = pos[k]; if (lane < NBP) s.xpos[lane][k] = pos[k]; }
-      for (int k = 0; k < 4; k++) { ql[lane][k] = quat[k]; if (lane < NBP) s.xquat[lane][k] = quat[k]; }
+      // (slots nb .. NBP-1 hold the satellites' bodies, written by sat_forward -- which runs beside this stage on the env's second
+      // wavefront in the two-wavefront build: no padding writes there)
+      const bool mine = lane < NBP && (!SMJ_W2_FORWARD || lane < nb);
+      for (int k = 0; k < 3; k++) { pl[lane][k] = pos[k]; if (mine) s.xpos[lane][k] = pos[k]; }
+      for (int k = 0; k < 4; k++) { ql[lane][k] = quat[k]; if (mine) s.xquat[lane][k] = quat[k]; }
     }
     SYNC();
 #pragma unroll
@@ -2704,7 +2721,7 @@ struct StepKernel {
     // the static world: two barriers per step.  Its contacts come back in the slots NCON - 1, NCON - 2, ... and are appended here,
     // behind the static ones: the one-wavefront build's list, contact for contact.
     LANES {
-      if (lane == 0) { s.u.c.mbox[0] = W2_RUN; s.u.c.mbox[1] = env; s.u.c.contotal = ncon; }
+      if (lane == 0) { s.mbox[0] = W2_COLLIDE; s.mbox[1] = env; s.u.c.contotal = ncon; }
     }
     WG_BARRIER();
     split_on = true;
@@ -2713,8 +2730,8 @@ struct StepKernel {
     CTICK(SMJ_PROF_C_NARROW)
     WG_BARRIER();
     {
-      const int nh = uni(s.u.c.mbox[2]);
-      flags |= uni(s.u.c.mbox[3]);
+      const int nh = uni(s.mbox[2]);
+      flags |= uni(s.mbox[3]);
       if (nh > 0 && ncon + nh <= NCON && !(flags & SMJ_FLAG_CON_OVERFLOW)) {
         PL<float[31]> w;
         LANES {
@@ -2753,22 +2770,50 @@ struct StepKernel {
     CTICK(SMJ_PROF_C_SPHERE)
 #undef CTICK
   }
-  enum { W2_RUN = 1, W2_EXIT = 2 };
-  // The second wavefront of the env: waits for the first one to reach the collision stage of a step (first barrier), works the
-  // moving-moving pairs, hands its count and flags over (second barrier), and leaves when the first one is through with the launch.
+  enum { W2_COLLIDE = 1, W2_EXIT = 2, W2_SAT_NEWTON = 3, W2_SAT_FORWARD = 4, W2_SAT_INTEGRATE = 5 };
+  // The second wavefront of the env (smj_kernels_sat2.hip).  It waits at a workgroup barrier until the first one has a job for it
+  // (the command in the mailbox), does it, meets the first one at a second barrier where the results change hands, and leaves when
+  // the first one is through with the launch.  Jobs -- all of them work the first wavefront does itself in the one-wavefront build,
+  // in the same arithmetic order, so the two builds agree bit for bit:
+  //   W2_SAT_FORWARD  sat_forward() (pose, mass block, smooth forces of every satellite) beside the main tree's kinematics;
+  //   W2_COLLIDE      the moving-moving pairs (collision_moving) beside the pairs with the static world;
+  //   W2_SAT_NEWTON   the satellites' Newton blocks and the search direction of the uncoupled ones (sat_hessian, sat_solve_own)
+  //                   beside the main block's H = M + J' W J on the matrix cores;
+  //   W2_SAT_INTEGRATE sat_integrate() (implicit velocity update and position integration of every satellite) beside the main
+  //                   tree's.
   // (Entered behind the first of those barriers -- the kernel reads the env from the mailbox there, smj_step_tu.h.)
-  SMJ_DEV void collide_helper() {
+  SMJ_DEV void helper() {
     rev = true;
     split_on = true;
-    for (;;) {
-      ncon = 0;
-      flags = 0;
-      collision_moving(nullptr, false);
-      LANES { if (lane == 0) { s.u.c.mbox[2] = ncon; s.u.c.mbox[3] = flags; } }
-      WG_BARRIER();   // the first wavefront takes the contacts over
-      WG_BARRIER();   // its next collision stage, or the end of the launch
-      if (uni(s.u.c.mbox[0]) != W2_RUN) return;
+    for (int cmd = uni(s.mbox[0]);;) {
+      if (cmd == W2_COLLIDE) {
+        ncon = 0;
+        flags = 0;
+        collision_moving(nullptr, false);
+        LANES { if (lane == 0) { s.mbox[2] = ncon; s.mbox[3] = flags; } }
+      } else if (cmd == W2_SAT_NEWTON) {
+        const uint64_t conemask = mk64(uni(s.mbox[1]), uni(s.mbox[2]));
+        sat_hessian(conemask);
+        SYNC();
+        sat_solve_own();
+      } else if (cmd == W2_SAT_FORWARD) {
+        sat_forward();
+      } else if (cmd == W2_SAT_INTEGRATE) {
+        PL<int> bad;
+        LANES { bad[lane] = 0; }
+        sat_integrate(bad);
+        const int anybad = wave_ballot(bad) != 0;
+        LANES { if (lane == 0) s.mbox[2] = anybad; }
+      }
+      WG_BARRIER();   // the first wavefront takes the results over
+      WG_BARRIER();   // its next job, or the end of the launch
+      cmd = uni(s.mbox[0]);
+      if (cmd == W2_EXIT) return;
     }
+  }
+  SMJ_DEV void fork2(int cmd, int w1 = 0, int w2 = 0) {
+    LANES { if (lane == 0) { s.mbox[0] = cmd; s.mbox[1] = w1; s.mbox[2] = w2; } }
+    WG_BARRIER();
   }
   SMJ_DEV void collision_moving(float* pc, bool prof) {
     long long tc = prof ? smj_clock() : 0;
@@ -4180,7 +4225,7 @@ struct StepKernel {
       // gradient = Ma - g - J'f   (lanes = dofs; force broadcast by readlane)
       matT_J(tmpv, nr0);
 #if NSAT > 0
-      sat_JTf();
+      sat_JTf();   // (handed to the second wavefront of the two-wavefront build as well, round 5: no gain -- the job is shorter than its two barriers)
 #endif
       PL<float> g2;
       PL<int> gsig;
@@ -4249,6 +4294,9 @@ struct StepKernel {
       }
       SYNC();
       TICK(SMJ_PROF_N_XA)
+#if SMJ_W2_NEWTON
+      fork2(W2_SAT_NEWTON, (int)(uint32_t)conemask, (int)(uint32_t)(conemask >> 32));   // the satellites' blocks: the second wavefront, beside the main block (helper())
+#endif
       // The lower 16x16 tiles over dofs (3 for 32 dofs, 10 for 64), K = constraint rows.  The operands of all tiles are fetched
       // first (J column blocks, shared between tiles) and the accumulation chains are interleaved, so that neither the LDS
       // latency nor the MFMA latency of one tile serialises the others.
@@ -4361,8 +4409,12 @@ struct StepKernel {
 #if NSAT > 0
       // the satellites' blocks; the coupled ones (contacts with the main tree / with each other) extend the dense system of this step
       const long long tsh = prof ? smj_clock() : 0;
+#if SMJ_W2_NEWTON
+      WG_BARRIER();   // Hb of every satellite and the search direction of the uncoupled ones are there
+#else
       sat_hessian(conemask);
       SYNC();
+#endif
       if (prof) pc[SMJ_PROF_SAT_H] += (float)(smj_clock() - tsh);
       if (next_sat > 0) {
         sat_extend_hessian(next_sat, conemask);
@@ -4374,7 +4426,9 @@ struct StepKernel {
           if (lane >= NVS && lane < NVS + 6 * next_sat) { const int e = (lane - NVS) / 6; s.sat.x[SX_SRCH][s.sat.xs[e]][lane - NVS - 6 * e] = -search[lane]; }
         }
       } else solve_H(search);
+#if !SMJ_W2_NEWTON
       sat_solve_own();
+#endif
       SYNC();
 #else
       solve_H(search);
@@ -4588,6 +4642,9 @@ struct StepKernel {
   SMJ_DEV void integrate() {
     const int nv = M.nv;
     const float h = M.timestep;
+#if SMJ_W2_INTEGRATE
+    fork2(W2_SAT_INTEGRATE);   // the satellites' own integration: the second wavefront, beside the main tree's (helper())
+#endif
     build_dense(true);
     PL<float> x;
     LANES { x[lane] = lane < nv ? s.tmp[lane] : 0.f; }
@@ -4622,7 +4679,10 @@ struct StepKernel {
       if (lane < nv) { const float v = s.qvel[lane]; b |= !(fabsf(v) < 1e10f); }
       bad[lane] = b;
     }
-#if NSAT > 0
+#if SMJ_W2_INTEGRATE
+    WG_BARRIER();
+    LANES { bad[lane] |= s.mbox[2]; }
+#elif NSAT > 0
     sat_integrate(bad);
 #endif
     if (wave_ballot(bad) != 0) {
@@ -4755,9 +4815,15 @@ struct StepKernel {
     TICK(SMJ_PROF_SETUP)
     for (int st = 0; st < nsteps; st++) {
       const bool last = st == nsteps - 1;
+#if SMJ_W2_FORWARD
+      fork2(W2_SAT_FORWARD, env);   // the satellites' forward pass: the second wavefront, beside the main tree's kinematics (helper())
+      kinematics();
+      WG_BARRIER();
+#else
       kinematics();
 #if NSAT > 0
       sat_forward();   // pose, mass block, smooth forces of every satellite (one lane each)
+#endif
 #endif
       if (last && (read_flags & 4)) dump_poses();
       TICK(SMJ_PROF_KIN)
@@ -4768,6 +4834,7 @@ struct StepKernel {
       TICK(SMJ_PROF_SMOOTH)
       if (!newton()) factor();   // the sparse L'DL of M is only needed by the PGS path (Y = J L^-1)
       TICK(SMJ_PROF_FACTOR)
+
       collision();
       collision_convex(pc, prof);
       if (last) dump_contacts();

@@ -105,12 +105,12 @@ __global__ __launch_bounds__(SMJ_WG_THREADS) SMJ_KERNEL_ATTR void SMJ_STEP_KERNE
 #ifdef SMJ_TWO_WAVES
   if (threadIdx.x >= 64) {
 #if SMJ_SPLIT_COLLIDE
-    // the env's second wavefront under Newton: the moving-moving pairs of every collision stage (smj_step_impl.h collide_helper);
-    // the first wavefront names the env when it reaches its first collision stage -- or ends the launch
+    // the env's second wavefront under Newton: jobs the first one hands it (smj_step_impl.h helper()); the first wavefront names the
+    // env with its first job -- or ends the launch
     WG_BARRIER();
-    if (uni(smem.u.c.mbox[0]) != StepKernel::W2_RUN) return;
-    StepKernel h(M, S, smem, uni(smem.u.c.mbox[1]));
-    h.collide_helper();
+    if (uni(smem.mbox[0]) == StepKernel::W2_EXIT) return;
+    StepKernel h(M, S, smem, uni(smem.mbox[1]));
+    h.helper();
 #else
     // the env's second wavefront under PGS: the satellite islands' sweeps (smj_sat_pgs.h pgs_helper), nothing else
     StepKernel h(M, S, smem, 0);
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(SMJ_WG_THREADS) SMJ_KERNEL_ATTR void SMJ_STEP_KERNE
 #ifdef SMJ_TWO_WAVES
   // release the second wavefront (every path of the first one ends here)
 #if SMJ_SPLIT_COLLIDE
-  if (threadIdx.x == 0) smem.u.c.mbox[0] = StepKernel::W2_EXIT;
+  if (threadIdx.x == 0) smem.mbox[0] = StepKernel::W2_EXIT;
 #else
   if (threadIdx.x == 0) smem.sat.x[SX_MV][0][4] = __builtin_bit_cast(float, (int)StepKernel::PGS2_EXIT);
 #endif

@@ -42,6 +42,8 @@ def profile(B, random_ctrl, steps=50, solver="pgs", scene=None):
     sim.start(home=False)
     import os
     if os.environ.get("SMJ_REP"): sim.set_option("pgs_fixed_iter", int(os.environ["SMJ_REP"]))
+    if os.environ.get("SMJ_NEWTON_TWO_WAVES"):   # 0: the one-wavefront kernel of the 16-satellite build; 1 (default): two wavefronts -- the table then shows the FIRST wavefront's cycles (sat_h: its wait for the second one's blocks)
+        sim.set_option("newton_two_waves", int(os.environ["SMJ_NEWTON_TWO_WAVES"]))
     dev = sim.device
     sim.ctrl[:] = torch.tensor(sim.model["key_ctrl"][0, :10], dtype=torch.float32, device=dev).unsqueeze(1)
     sim.step(500)
