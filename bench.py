@@ -212,7 +212,7 @@ def other_configs(B, dev, hold, solver):
         evs = []
         res[scene + "_physics"] = {"value": rollout(sim, 500, hold, events=evs), "unit": "env-steps/s", **flags_of(sim)}   # 10 launches: one with a hand-over to the larger variant costs +30 %
         res[scene + "_physics"]["roofline"] = roofline_of(sim, evs, scene[:-4] if scene.endswith("_sat") else scene,
-                                                          "smj_step_kernel_sat (+ _sat32 workers)" if "robocasa" in scene or scene.endswith("_sat") else "smj_step_kernel (variant by model size)")
+                                                          "smj_step_kernel_sat2 (two wavefronts per env; + _sat32 workers)" if "robocasa" in scene or scene.endswith("_sat") else "smj_step_kernel (variant by model size)")
         if scene == "stretch_kitchen_robocasa":
             res[scene + "_physics"].update(dofs=sim.nv, kernel_variant="sat (16 satellites, 208 rows, 2 envs per CU) -> sat32 (320 rows) for steps beyond it; under PGS the two-wavefront build satp (satellite islands swept beside the dense system)",
                                            note="overflow_flags bit 2 = more than 64 contacts in one env (a lane count); rows / dense rows / coupled satellites hand over and are not flagged")

@@ -56,9 +56,9 @@ def render_summary(out):
 
 
 def satellite_summary(out):
-    """Satellite builds (tools/gpu_r4_profile.sh): kernel stats of the Robocasa-scale kitchen, kitchen4 and scene.xml on smj_step_kernel_sat,
+    """Satellite builds (tools/gpu_r4_profile.sh): kernel stats of the Robocasa-scale kitchen, kitchen4 and scene.xml on smj_step_kernel_sat2 (Newton) / _satp (PGS),
     PMC means of the kitchen's launches."""
-    for sub, log, title in (("rctrace", "rc_trace.log", "kitchen at Robocasa scale (`tools/gpu_options_probe.py scene=stretch_kitchen_robocasa`: 44 fixture bodies, 307 collision geoms, 8 articulated fixture parts + 8 free objects = 16 satellites; 4096 envs; primary kernel `smj_step_kernel_sat`, two envs per CU; parked chunks go to `smj_step_kernel_sat32_worker`: pollers beside the launch + the sweep after it)"),
+    for sub, log, title in (("rctrace", "rc_trace.log", "kitchen at Robocasa scale (`tools/gpu_options_probe.py scene=stretch_kitchen_robocasa`: 44 fixture bodies, 307 collision geoms, 8 articulated fixture parts + 8 free objects = 16 satellites; 4096 envs; primary kernel `smj_step_kernel_sat2` (two wavefronts per env, round 5), two envs per CU; parked chunks go to `smj_step_kernel_sat32_worker`: pollers beside the launch + the sweep after it)"),
                             ("rcpgstrace", "rcpgs_trace.log", "the same kitchen under PGS (`tools/gpu_options_probe.py scene=stretch_kitchen_robocasa solver=0`; `smj_step_kernel_satp` = the 16-satellite build's PGS-only kernel, TWO wavefronts per env: the satellite islands swept beside the dense system; second start from the previous step's forces on)"),
                             ("trace_stretch_kitchen4_sat", "trace_stretch_kitchen4_sat.log", "kitchen with four free objects on the satellite build (`scene=stretch_kitchen4_sat`)"),
                             ("trace_stretch_scene_sat", "trace_stretch_scene_sat.log", "the reference's scene.xml on the satellite build (`scene=stretch_scene_sat`)")):
@@ -80,7 +80,7 @@ def satellite_summary(out):
         if os.path.exists(tp):
             with open(tp) as f:
                 allk = list(csv.DictReader(f))
-            kn = "smj_step_kernel_satp(" if sub == "rcpgstrace" else "smj_step_kernel_sat("
+            kn = "smj_step_kernel_satp(" if sub == "rcpgstrace" else "smj_step_kernel_sat2("
             tr = [r for r in allk if r["Kernel_Name"].startswith(kn)]
             if tr:
                 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in tr]
@@ -88,9 +88,9 @@ def satellite_summary(out):
                 out.append(f"\nPer-dispatch durations of `{kn[:-1]}` (ms; the first is the 300-step settle, then launches of 50 steps: "
                            f"6 settled + 14 under random actions): {[round(x, 1) for x in dur]}")
                 out.append(f"Resources: VGPR {r0['VGPR_Count']} (+AGPR {r0['Accum_VGPR_Count']}), SGPR {r0['SGPR_Count']}, scratch {r0['Scratch_Size']} B, "
-                           f"workgroup {r0['Workgroup_Size_X']}, grid {r0['Grid_Size_X']} (dynamic LDS 81 904 B per env: two envs per CU).")
+                           f"workgroup {r0['Workgroup_Size_X']}, grid {r0['Grid_Size_X']} (dynamic LDS per env: 81 904 B with one wavefront, 81 920 B -- the mailbox -- with two: two envs per CU).")
     scenes_traffic = {}
-    for pre, kn, what in (("rc", "smj_step_kernel_sat(", "Newton"), ("rcpgs", "smj_step_kernel_satp(", "PGS, two wavefronts per env")):
+    for pre, kn, what in (("rc", "smj_step_kernel_sat2(", "Newton, two wavefronts per env"), ("rcpgs", "smj_step_kernel_satp(", "PGS, two wavefronts per env")):
         kv = {}
         for d in sorted(glob.glob(os.path.join(SRC, pre + "pmc_*", "smj_counter_collection.csv"))):
             acc = collections.defaultdict(list)
@@ -115,7 +115,7 @@ def satellite_summary(out):
                 issued = kv.get("SQ_INSTS_VALU", 0) + kv.get("SQ_INSTS_SALU", 0) + kv.get("SQ_INSTS_LDS", 0)
                 nq, nv = 29 + 8 + 8 * 7, 28 + 8 + 8 * 6   # robot + 8 single-joint parts + 8 free objects
                 words = 2 * (nq + nv) + nv + 10 + nv   # qpos, qvel in and out; warm start; ctrl; act
-                out.append(f"\n{4 * wc / max(1, issued):.1f} shader cycles per issued instruction (one wave per SIMD, two of a CU's four SIMDs occupied); "
+                out.append(f"\n{4 * wc / max(1, issued):.1f} shader cycles per issued instruction (two wavefronts per env, two envs per CU: one wave on each of the CU's four SIMDs; an env's second wavefront sleeps at a workgroup barrier between its jobs, and its cycles count here); "
                            f"MFMA busy {kv.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / max(1, 4 * wc):.4f}; LDS bank-conflict ratio {kv.get('SQ_LDS_BANK_CONFLICT', 0) / max(1, kv.get('SQ_ACTIVE_INST_LDS', 1)):.3f}; "
                            f"VMEM reads per launch {kv.get('SQ_INSTS_VMEM_RD', 0):.3g} (static-geometry records and pair tables come from L2 / HBM, not LDS); "
                            f"HBM per launch: FETCH_SIZE {kv.get('FETCH_SIZE', 0) * 1024 / 1e6:.1f} MB + WRITE_SIZE {kv.get('WRITE_SIZE', 0) * 1024 / 1e6:.1f} MB "
