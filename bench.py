@@ -214,8 +214,14 @@ def other_configs(B, dev, hold, solver):
         res[scene + "_physics"]["roofline"] = roofline_of(sim, evs, scene[:-4] if scene.endswith("_sat") else scene,
                                                           "smj_step_kernel_sat2 (two wavefronts per env; + _sat32 workers)" if "robocasa" in scene or scene.endswith("_sat") else "smj_step_kernel (variant by model size)")
         if scene == "stretch_kitchen_robocasa":
-            res[scene + "_physics"].update(dofs=sim.nv, kernel_variant="sat (16 satellites, 208 rows, 2 envs per CU) -> sat32 (320 rows) for steps beyond it; under PGS the two-wavefront build satp (satellite islands swept beside the dense system)",
+            res[scene + "_physics"].update(dofs=sim.nv, kernel_variant="sat2 (16 satellites, 208 rows, 2 envs per CU, two wavefronts per env: the second takes the moving-moving pairs and the satellites' lane-serial stages) -> sat32 (320 rows) for steps beyond it; under PGS the two-wavefront build satp (satellite islands swept beside the dense system)",
                                            note="overflow_flags bit 2 = more than 64 contacts in one env (a lane count); rows / dense rows / coupled satellites hand over and are not flagged")
+            if solver == "newton":   # the same rollout on the one-wavefront kernel (smj_kernels_sat.hip; bit-identical states, tests/test_satellites.py): what the second wavefront buys
+                sim.stop()
+                sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver=solver, scene=scene)
+                sim.start(home=False)
+                sim.set_option("newton_two_waves", 0)
+                res[scene + "_physics"]["one_wavefront_per_env"] = {"value": rollout(sim, 500, hold), "unit": "env-steps/s", "kernel": "smj_step_kernel_sat (option newton_two_waves = 0)"}
         sim.stop()
     # north_star's target sentence (>= 1 M env-steps/s on 4096 kitchen envs at 8 GPUs): the per-rank share of 4096 kitchen envs in
     # total, on this one GPU -- 512 envs per rank at 8 GPUs, 1024 at 4
