@@ -610,7 +610,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
     };
     if (!lrc)
       lrc = c->variant == 6   ? smj_launch_step_sat32(c->model, st, k, fl, sm)
-            : c->variant == 5 ? by_solver((c->newton_two_waves && (!st.prof || smj_sat2_profiling())) ? smj_launch_step_sat2 : smj_launch_step_sat, c->pgs_two_waves ? smj_launch_step_satp : smj_launch_step_sat1)
+            : c->variant == 5 ? by_solver((c->model.solver == 2 && c->newton_two_waves && (!st.prof || smj_sat2_profiling())) ? smj_launch_step_sat2 : smj_launch_step_sat, c->pgs_two_waves ? smj_launch_step_satp : smj_launch_step_sat1)
             : c->variant == 4 ? smj_launch_step_big(c->model, st, k, fl, sm)
             : c->variant == 3 ? by_solver(smj_launch_step_big50, smj_launch_step_big50p)
             : c->variant == 2 ? by_solver(smj_launch_step_big38, smj_launch_step_big38p)
