@@ -235,7 +235,14 @@ def other_configs(B, dev, hold, solver):
             sim.start(home=False)
             kshare[scene][str(nb)] = {"value": rollout(sim, 200, hold), "unit": "env-steps/s", **flags_of(sim)}
             sim.stop()
-    res["kitchen_rank_share"] = {"envs_per_rank": kshare, "note": "one GPU, physics only, random actions: x8 (512 envs) / x4 (1024) = what 4096 kitchen envs in total can reach on a node"}
+            if solver == "newton" and scene == "stretch_kitchen_robocasa":   # north_star names PGS for this configuration: the same share under PGS
+                sim = StretchBatchSimulator(num_envs=nb, device=str(dev), solver="pgs", scene=scene)
+                sim.start(home=False)
+                kshare[scene][str(nb) + "_pgs"] = {"value": rollout(sim, 200, hold), "unit": "env-steps/s", **flags_of(sim)}
+                sim.stop()
+    res["kitchen_rank_share"] = {"envs_per_rank": kshare, "note": "one GPU, physics only, random actions: x8 (512 envs) / x4 (1024) = what 4096 kitchen envs in total can reach on a node.  "
+                                 "Under PGS a launch lasts as long as its slowest env -- one at the cap of 100 sweeps takes ~4 ms per step on the 16-satellite build, one handed to the 32-satellite build "
+                                 "(more than 96 rows on the robot's island) ~15 ms -- whatever the batch: the PGS share scales with the batch size (DESIGN.md section 7)"}
     # config 4 as north_star words it ("contact-rich PGS solve"): the same scenes under PGS.  The sweeps are serial over the rows
     # (100 sweeps x ~100 rows at one wavefront per env), so this is the slowest path of the library; Newton is the model's own solver.
     if solver != "pgs":
