@@ -113,7 +113,7 @@ int smj_base_controller_tick(smj_ctx* ctx, void* stream);
  * than the standard kernel variant holds is finished by the tall variant instead of being flagged), "balance" (default on:
  * workgroups are dispatched in the order of the envs' shader time in the previous dispatch, longest first), "chunk" (default 0 = one dispatch; k > 0:
  * smj_step sends its n steps out as dispatches of this many steps on the staged state, each with a fresh order; 0 = one dispatch),
- * "pipeline" (default 5; batches of more than 1024 envs: the n steps of a call are cut into chunks of this many steps and the
+ * "pipeline" (default 5; batches of more than "pipeline_min_envs" envs -- default 511 --: the n steps of a call are cut into chunks of this many steps and the
  * grid holds one workgroup per (chunk, env) that waits on the env's progress counter instead of a barrier between chunks --
  * scheduling only, results are bit-identical; 0 = one workgroup per env per call), "pollers" (default 2: workgroups of the
  * tall variant that run beside the standard kernel on a second stream, finish the current chunk of an env that ran out of

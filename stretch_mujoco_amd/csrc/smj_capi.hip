@@ -41,6 +41,12 @@ struct smj_ctx {
   int* order = nullptr;
   int balance = 1;
   int lidar_cull = 1;      // lidar: drop, per env, the geoms that cannot reach the scan plane (smj_render.h lidar_plane_*)
+  int balance_min_envs = 1024; // cost-ordered dispatch only above this many envs (option balance_min_envs)
+  // pipelined chunks (and with them the pollers) only above this many envs (option pipeline_min_envs).  Round 5: 511, was 1024 -- measured under
+  // random actions at 1024 envs: empty scene 5.16 -> 5.52 M, kitchen stand-in 3.97 -> 4.98 M, scene.xml 1.96 -> 2.37 M, the kitchen at Robocasa
+  // scale 0.73 -> 1.30 M (an env handed to the large build is finished beside the launch instead of after it); at 512 envs nothing but the
+  // last (0.56 -> 0.77 M); settled scenes pay 3-5 % for the chunks' state round trips at these sizes
+  int pipe_min_envs = 511;
   int newton_two_waves = 1;   // Newton on the 16-satellite build: 1 = the two-wavefront kernel (smj_kernels_sat2.hip: the second wavefront takes the moving-moving pairs and the satellites' lane-serial stages), 0 = one wavefront per env
   int pgs_two_waves = 1;   // PGS on the 16-satellite build: 1 = the two-wavefront kernel (smj_kernels_satp.hip), 0 = one wavefront per env
   int balance_min = 1;   // steps per launch from which the cost-ordered dispatch is used (round 4: 1 -- a one-step launch is as long as its slowest round of workgroups; was 4)
@@ -541,7 +547,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
   // measured: standard +19 % at chunks of 5, tall (2 envs per CU) +7 % at 10, big with 64 columns (1 env per CU, 16 rounds of workgroups) nothing
   // (three envs per CU: chunks of 8 measured 3 % ahead of 10)
   const int pipe_len = c->variant >= 2 ? 2 * c->pipeline : c->variant == 1 ? (3 * c->pipeline + 1) / 2 : c->pipeline;
-  const bool pipe = c->variant != 4 && c->variant != 6 && (c->variant < 2 || c->pipeline_big) && c->pipeline > 0 && chunk == nsteps && nsteps > pipe_len && !st.debug && !st.prof && c->num_envs > 1024;
+  const bool pipe = c->variant != 4 && c->variant != 6 && (c->variant < 2 || c->pipeline_big) && c->pipeline > 0 && chunk == nsteps && nsteps > pipe_len && !st.debug && !st.prof && c->num_envs > c->pipe_min_envs;
   st.progress = st.done_steps = st.sched = st.hot = nullptr;
   if (esc || pipe) {
     st.progress = c->progress;
@@ -574,7 +580,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
       // -1 = entry not published yet: only the pollers read entries while the list grows (the sweep runs after the kernel, the count is final)
       if (pipe && c->pollers > 0) HIPCHK(c, hipMemsetAsync(c->redo, 0xff, sizeof(int) * (size_t)st.pipe_total, sm));
     }
-    if (c->balance && k >= c->balance_min && c->num_envs > 1024) {
+    if (c->balance && k >= c->balance_min && c->num_envs > c->balance_min_envs) {
       smj_launch_order(c->cost, c->order, c->num_envs, sm);
       st.order = c->order;
     }
@@ -735,6 +741,8 @@ int smj_set_option(smj_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "chunk")) c->chunk = (int)v;
   else if (!strcmp(name, "pipeline")) c->pipeline = (int)v;
   else if (!strcmp(name, "pipeline_big")) c->pipeline_big = (int)v;
+  else if (!strcmp(name, "pipeline_min_envs")) c->pipe_min_envs = (int)v;
+  else if (!strcmp(name, "balance_min_envs")) c->balance_min_envs = (int)v;
   else if (!strcmp(name, "pollers")) {   // n > 0: n pollers when a recent launch escalated; -n: n pollers with every launch; 0: none
     c->pollers_always = v < 0;
     const int n = (int)(v < 0 ? -v : v);
