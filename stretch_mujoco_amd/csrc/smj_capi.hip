@@ -557,6 +557,9 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
   }
   st.pipe_len = 0;
   st.pollers = 0;
+  // the 32-satellite build exists twice: both solvers on one wavefront per env, and Newton only on two (smj_kernels_sat32n.hip)
+  typedef int (*Launch32)(const DevModel&, const DevState&, int, unsigned, hipStream_t);
+  auto sat32_of = [&](const DevModel& m) -> Launch32 { return (m.solver == 2 && c->newton_two_waves && !st.prof) ? smj_launch_step_sat32n : smj_launch_step_sat32; };
   int lrc = 0;
   for (int done = 0; done < nsteps && !lrc; done += chunk) {
     const int k = nsteps - done < chunk ? nsteps - done : chunk;
@@ -599,7 +602,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
       sp.order = nullptr;
       HIPCHK(c, hipEventRecord(c->ev_fork, sm));
       HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
-      lrc = c->variant == 5 ? smj_launch_step_sat32(c->model_esc, sp, k, fl, c->aux) : smj_launch_step_tall(c->model_esc, sp, k, fl, c->aux);
+      lrc = c->variant == 5 ? sat32_of(c->model_esc)(c->model_esc, sp, k, fl, c->aux) : smj_launch_step_tall(c->model_esc, sp, k, fl, c->aux);
       HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
     }
     // The primary builds exist once per solver (smj_step_impl.h newton()): the base name carries Newton, the twin PGS.  In a tools build
@@ -615,7 +618,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
       return twin(c->model, st, k, fl, sm);
     };
     if (!lrc)
-      lrc = c->variant == 6   ? smj_launch_step_sat32(c->model, st, k, fl, sm)
+      lrc = c->variant == 6   ? sat32_of(c->model)(c->model, st, k, fl, sm)
             : c->variant == 5 ? by_solver((c->model.solver == 2 && c->newton_two_waves && (!st.prof || smj_sat2_profiling())) ? smj_launch_step_sat2 : smj_launch_step_sat, c->pgs_two_waves ? smj_launch_step_satp : smj_launch_step_sat1)
             : c->variant == 4 ? smj_launch_step_big(c->model, st, k, fl, sm)
             : c->variant == 3 ? by_solver(smj_launch_step_big50, smj_launch_step_big50p)
@@ -629,7 +632,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
       // offending step) is finished by the tall variant (160 rows / 48 contacts); an empty list returns at once
       st.redo_worker = 1;
       st.pipe_len = 0;
-      lrc = c->variant <= 1 ? smj_launch_step_tall(c->model_esc, st, k, fl, sm) : c->variant == 5 ? smj_launch_step_sat32(c->model_esc, st, k, fl, sm) : smj_launch_step_big(c->model_esc, st, k, fl, sm);
+      lrc = c->variant <= 1 ? smj_launch_step_tall(c->model_esc, st, k, fl, sm) : c->variant == 5 ? sat32_of(c->model_esc)(c->model_esc, st, k, fl, sm) : smj_launch_step_big(c->model_esc, st, k, fl, sm);
     }
   }
   if (lrc) return fail(c, -2, "step kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));

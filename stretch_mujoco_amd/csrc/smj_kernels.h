@@ -37,6 +37,7 @@ int smj_launch_step_sat2(const DevModel& m, const DevState& s, int nsteps, unsig
 int smj_sat2_profiling();   // whether that build carries the per-stage cycle counters (DevState::prof)
 int smj_launch_step_sat1(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);    // 16 satellites, PGS only, one wavefront per env (option pgs_two_waves = 0)
 int smj_launch_step_sat(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);     // main tree + satellites (smj_sat.h)
+int smj_launch_step_sat32n(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);   // the same, Newton only, two wavefronts per env (option newton_two_waves = 1): primary kernel and escalation worker
 int smj_launch_step_sat32(const DevModel& m, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream);   // up to 32 satellites, one env per CU
 void smj_sat_caps(int* nvp, int* nbp, int* nent, int* nefc, int* ncon, int* debug_floats, int* nsat);
 void smj_sat32_caps(int* nvp, int* nbp, int* nent, int* nefc, int* ncon, int* debug_floats, int* nsat);

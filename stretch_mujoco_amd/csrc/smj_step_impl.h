@@ -353,7 +353,7 @@ struct StepKernel {
   const DevModel& M;
   const DevState& S;
   Smem& s;
-  const int env;
+  int env;   // (constant but in the second wavefront of a two-wavefront worker kernel, which follows the first one from env to env: helper())
 
   // Persistent lane-resident state is kept small on purpose (the kernel owns 512 registers per lane but also unrolls a
   // 32x32 elimination): model constants are (re)loaded at the top of the stage that needs them -- independent global loads
@@ -2797,6 +2797,7 @@ struct StepKernel {
         SYNC();
         sat_solve_own();
       } else if (cmd == W2_SAT_FORWARD) {
+        env = uni(s.mbox[1]);   // the first job of every step names the env (a worker kernel goes from env to env)
         sat_forward();
       } else if (cmd == W2_SAT_INTEGRATE) {
         PL<int> bad;

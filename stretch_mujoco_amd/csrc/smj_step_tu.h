@@ -11,8 +11,8 @@
 #if defined(SMJ_SAT)   // the satellite build (smj_sat.h)
 #define SMJ_STEP_KERNEL SMJ_CAT(smj_step_kernel_, SMJ_VARIANT_TAG)
 #define SMJ_LAUNCH_STEP SMJ_CAT(smj_launch_step_, SMJ_VARIANT_TAG)
-#if SMJ_SAT == 32   // the escalation target of the 16-satellite build
-#define SMJ_WORKER_KERNEL smj_step_kernel_sat32_worker
+#if SMJ_SAT == 32   // the escalation target of the 16-satellite build (smj_step_kernel_sat32_worker; the two-wavefront Newton build: _sat32n_worker)
+#define SMJ_WORKER_KERNEL SMJ_CAT(SMJ_CAT(smj_step_kernel_, SMJ_VARIANT_TAG), _worker)
 #endif
 #elif defined(SMJ_BIG)   // three builds: SMJ_VARIANT_TAG = big38 / big50 / big (column capacity SMJ_NVS, smj_model.h)
 #define SMJ_STEP_KERNEL SMJ_CAT(smj_step_kernel_, SMJ_VARIANT_TAG)
@@ -146,9 +146,7 @@ __global__ __launch_bounds__(SMJ_WG_THREADS) SMJ_KERNEL_ATTR void SMJ_STEP_KERNE
 // The escalation worker (the tall variant for the standard one, the 64-column big build for the 38- / 50-column ones): works the
 // list of envs the smaller variant parked (DevState::redo) -- as the sweep after its kernel (redo_worker 1) or as a poller beside
 // it (redo_worker 2, DevState::sched; standard variant only).  One call site of run().
-__global__ __launch_bounds__(64) void SMJ_WORKER_KERNEL(const DevModel M, const DevState S, int nsteps, unsigned read_flags) {
-  extern __shared__ __align__(16) unsigned char smj_lds[];
-  Smem& smem = *reinterpret_cast<Smem*>(smj_lds);
+static __device__ __forceinline__ void smj_worker_body(const DevModel& M, const DevState& S, Smem& smem, int nsteps, unsigned read_flags) {
   const int mode = S.redo_worker;
   long long t0 = mode == 2 ? wall_clock64() : 0;   // of the last sign of life of the standard kernel
   int exited_seen = -1;
@@ -203,12 +201,30 @@ __global__ __launch_bounds__(64) void SMJ_WORKER_KERNEL(const DevModel M, const 
     }
     StepKernel k(M, S, smem, env);
     k.run(steps, fl);
-    __syncthreads();
+    SYNC();
     if (mode == 2) {   // hand the env back to the standard kernel's next chunk (unless that one has given the env up)
       coh_release();
       if (threadIdx.x == 0) atomicCAS(&S.progress[env], -(chunk + 1), chunk + 1);
     }
   }
+}
+__global__ __launch_bounds__(SMJ_WG_THREADS) void SMJ_WORKER_KERNEL(const DevModel M, const DevState S, int nsteps, unsigned read_flags) {
+  extern __shared__ __align__(16) unsigned char smj_lds[];
+  Smem& smem = *reinterpret_cast<Smem*>(smj_lds);
+#if SMJ_SPLIT_COLLIDE
+  if (threadIdx.x >= 64) {   // the second wavefront: jobs of whichever env the first one is working (helper() takes the env from every forward-pass job)
+    WG_BARRIER();
+    if (uni(smem.mbox[0]) == StepKernel::W2_EXIT) return;
+    StepKernel h(M, S, smem, uni(smem.mbox[1]));
+    h.helper();
+    return;
+  }
+#endif
+  smj_worker_body(M, S, smem, nsteps, read_flags);
+#if SMJ_SPLIT_COLLIDE
+  if (threadIdx.x == 0) smem.mbox[0] = StepKernel::W2_EXIT;   // (every path of the first wavefront ends here)
+  WG_BARRIER();
+#endif
 }
 #endif
 
@@ -243,7 +259,7 @@ int SMJ_LAUNCH_STEP(const DevModel& m_in, const DevState& s, int nsteps, unsigne
 #if defined(SMJ_WORKER_KERNEL)
   if (s.redo_worker) {
     const unsigned wg = s.redo_worker == 2 ? (unsigned)(s.pollers < 0 ? -s.pollers : s.pollers) : (unsigned)(nsteps <= 2 ? (s.B < 64 ? s.B : 64) : s.B < 512 ? s.B : 512);   // sweep: two envs per CU fit (one under PGS); surplus workgroups find the list drained and leave (a one-step launch: 64 -- the empty sweep is pure launch cost there)
-    hipLaunchKernelGGL(SMJ_WORKER_KERNEL, dim3(wg), dim3(64), lds, stream, m, s, nsteps, read_flags);
+    hipLaunchKernelGGL(SMJ_WORKER_KERNEL, dim3(wg), dim3(SMJ_WG_THREADS), lds, stream, m, s, nsteps, read_flags);
     return 0;
   }
 #endif
