@@ -1002,12 +1002,6 @@ SMJ_DEV void collision_static(float* pc, bool prof) {
   // 260 k).  The uniform grid (k_grid_*) stays in the blob for scenes with thousands of static geoms.
   const float gm = M.grid_margin;
   const int ncg = M.ncgeom;
-  // bounding radii of the moving geoms, staged once (the `size` column of the staging slot NCG is free until a pair is staged)
-  for (int c0 = 0; c0 < ncg; c0 += 64) {
-    LANES { if (c0 + lane < ncg) s.u.c.mc_r[c0 + lane] = asf(M.k_cgrec[opaque(c0 + lane) * SMJ_CG_STRIDE + SMJ_CG_RBOUND]); }
-  }
-  SYNC();
-  if (prof) pc[SMJ_PROF_FACTOR] += (float)(smj_clock() - tb0);   // (profiling builds: PGS slots are free under Newton -- "factor": radii staged, "project": + phase 1)
   // phase 1 (only when a moving geom has travelled SMJ_SB_SLACK since the list was built, or at the start of a launch), lane =
   // static geom: its world AABB against every moving geom's bounding sphere inflated by the slack.  22 k tests: 116 k cycles when
   // it ran every step -- a launch-long LDS list of the ~200 near pairs makes it a once-in-ten-steps cost.
@@ -1022,6 +1016,11 @@ SMJ_DEV void collision_static(float* pc, bool prof) {
       mv[lane] = m;
     }
     if (!uni(s.sat.cand_ok) || wave_ballot(mv) != 0) {
+      // bounding radii of the moving geoms, staged for this rebuild only (round 5: they were staged every step -- two global-load
+      // round trips per step for a list that is rebuilt once in ten)
+      for (int c0 = 0; c0 < ncg; c0 += 64) {
+        LANES { if (c0 + lane < ncg) s.u.c.mc_r[c0 + lane] = asf(M.k_cgrec[opaque(c0 + lane) * SMJ_CG_STRIDE + SMJ_CG_RBOUND]); }
+      }
       LANES {
         if (lane == 0) { s.sat.ncand = 0; s.sat.cand_ok = 1; }
         for (int c = lane; c < ncg; c += 64)
@@ -1069,11 +1068,25 @@ SMJ_DEV void collision_static(float* pc, bool prof) {
   if (prof) pc[SMJ_PROF_PROJECT] += (float)(smj_clock() - tb0);
   const int ncand = uni(s.sat.ncand);
   // phase 2, lane = candidate: MuJoCo's pair filter (k_spair), then the six face axes of the two oriented boxes
-  for (int k0 = 0; k0 < ncand; k0 += 64) {
+  // (the filter look-ups of all rounds are issued first -- independent global loads, one round trip for the lot instead of one per round)
+  constexpr int NRND = (NCAND + 63) / 64;
+  PL<int> cw[NRND], csid[NRND];
+  LANES {
+#pragma unroll
+    for (int r = 0; r < NRND; r++) {
+      const int k = 64 * r + lane;
+      int w = 0, sid = -1;
+      if (k < ncand) { w = s.sat.cand[k]; sid = M.k_spair[(w >> 9) * nsg + (w & 511)]; }
+      cw[r][lane] = w; csid[r][lane] = sid;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NRND; r++) {
+    if (64 * r >= ncand) break;   // uniform
     LANES {
-      if (k0 + lane < ncand) {
-        const int w = s.sat.cand[k0 + lane], sg = w & 511, c = w >> 9;
-        const int sid = M.k_spair[c * nsg + sg];
+      {
+        const int w = cw[r][lane], sg = w & 511, c = w >> 9;
+        const int sid = csid[r][lane];
         if (sid >= 0) {
           const float* sw = M.k_sgw + 32 * sg;
           float Rb[9], hb[3], Ra[9], ha[3], Rm[3][3], ta[3], tb[3];
