@@ -98,7 +98,7 @@ int smj_base_controller_tick(smj_ctx* ctx, void* stream);
  * the previous sweep; 1: mju_QCQP's own iteration from 0, cap 20 -- the two differ where that cap is hit),
  * "pgs_two_waves" (PGS on the 16-satellite build, default 1: two wavefronts per env -- the second sweeps the satellites' constraint
  * islands beside the first one's sweeps of the dense system; 0: one wavefront), "newton_two_waves" (Newton on the 16-satellite build,
- * default 1: two wavefronts per env -- the second takes the moving-moving pairs of the collision stage and the satellites' lane-serial
+ * default 1 (= 3: both satellite builds; tools: 5 the 16-satellite build only, 2 the 32-satellite one only): two wavefronts per env -- the second takes the moving-moving pairs of the collision stage and the satellites' lane-serial
  * stages (forward pass, Newton blocks, integration) beside the first one's work; the same states bit for bit as 0: one wavefront),
  * "balance_min" (default 1: launches of at least this many
  * steps are dispatched longest-env-first),

@@ -47,7 +47,7 @@ struct smj_ctx {
   // scale 0.73 -> 1.30 M (an env handed to the large build is finished beside the launch instead of after it); at 512 envs nothing but the
   // last (0.56 -> 0.77 M); settled scenes pay 3-5 % for the chunks' state round trips at these sizes
   int pipe_min_envs = 511;
-  int newton_two_waves = 1;   // Newton on the 16-satellite build: 1 = the two-wavefront kernel (smj_kernels_sat2.hip: the second wavefront takes the moving-moving pairs and the satellites' lane-serial stages), 0 = one wavefront per env
+  int newton_two_waves = 3;   // Newton on the 16-satellite build: 1 = the two-wavefront kernel (smj_kernels_sat2.hip: the second wavefront takes the moving-moving pairs and the satellites' lane-serial stages), 0 = one wavefront per env
   int pgs_two_waves = 1;   // PGS on the 16-satellite build: 1 = the two-wavefront kernel (smj_kernels_satp.hip), 0 = one wavefront per env
   int balance_min = 1;   // steps per launch from which the cost-ordered dispatch is used (round 4: 1 -- a one-step launch is as long as its slowest round of workgroups; was 4)
   int chunk = 0;               // steps per dispatch inside one smj_step (0: the whole launch at once; measured: no gain)
@@ -559,7 +559,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
   st.pollers = 0;
   // the 32-satellite build exists twice: both solvers on one wavefront per env, and Newton only on two (smj_kernels_sat32n.hip)
   typedef int (*Launch32)(const DevModel&, const DevState&, int, unsigned, hipStream_t);
-  auto sat32_of = [&](const DevModel& m) -> Launch32 { return (m.solver == 2 && c->newton_two_waves && !st.prof) ? smj_launch_step_sat32n : smj_launch_step_sat32; };
+  auto sat32_of = [&](const DevModel& m) -> Launch32 { return (m.solver == 2 && (c->newton_two_waves & 2) && !st.prof) ? smj_launch_step_sat32n : smj_launch_step_sat32; };
   int lrc = 0;
   for (int done = 0; done < nsteps && !lrc; done += chunk) {
     const int k = nsteps - done < chunk ? nsteps - done : chunk;
@@ -619,7 +619,7 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
     };
     if (!lrc)
       lrc = c->variant == 6   ? sat32_of(c->model)(c->model, st, k, fl, sm)
-            : c->variant == 5 ? by_solver((c->model.solver == 2 && c->newton_two_waves && (!st.prof || smj_sat2_profiling())) ? smj_launch_step_sat2 : smj_launch_step_sat, c->pgs_two_waves ? smj_launch_step_satp : smj_launch_step_sat1)
+            : c->variant == 5 ? by_solver((c->model.solver == 2 && (c->newton_two_waves & 1) && (!st.prof || smj_sat2_profiling())) ? smj_launch_step_sat2 : smj_launch_step_sat, c->pgs_two_waves ? smj_launch_step_satp : smj_launch_step_sat1)
             : c->variant == 4 ? smj_launch_step_big(c->model, st, k, fl, sm)
             : c->variant == 3 ? by_solver(smj_launch_step_big50, smj_launch_step_big50p)
             : c->variant == 2 ? by_solver(smj_launch_step_big38, smj_launch_step_big38p)
@@ -740,7 +740,7 @@ int smj_set_option(smj_ctx* c, const char* name, double v) {
   else if (!strcmp(name, "balance")) c->balance = (int)v;
   else if (!strcmp(name, "balance_min")) c->balance_min = (int)v;
   else if (!strcmp(name, "pgs_two_waves")) c->pgs_two_waves = (int)v;
-  else if (!strcmp(name, "newton_two_waves")) c->newton_two_waves = (int)v;
+  else if (!strcmp(name, "newton_two_waves")) c->newton_two_waves = (int)v == 1 ? 3 : (int)v;   // 1 (or 3): both satellite builds; 0: neither; tools: 5 = the 16-satellite build only, 2 = the 32-satellite one only
   else if (!strcmp(name, "chunk")) c->chunk = (int)v;
   else if (!strcmp(name, "pipeline")) c->pipeline = (int)v;
   else if (!strcmp(name, "pipeline_big")) c->pipeline_big = (int)v;

@@ -10,9 +10,12 @@ sys.path.insert(0, ".")
 from stretch_mujoco_amd import StretchBatchSimulator  # noqa: E402
 
 
-def main(B=4096, steps=20000, scene="stretch_empty", solver="newton"):
+def main(B=4096, steps=20000, scene="stretch_empty", solver="newton", options=None):
     sim = StretchBatchSimulator(num_envs=B, device="cuda:0", solver=solver, scene=scene)
     sim.start(home=True)
+    for k_, v_ in (options or {}).items():
+        sim.set_option(k_, v_)
+    zmax_ever, zmax_at, zmax_who = -1.0, -1, ""
     dev = sim.device
     g = torch.Generator(device=dev).manual_seed(99)
     lo = torch.tensor(sim.model["actuator_ctrlrange"][:, 0], dtype=torch.float32, device=dev).unsqueeze(1)
@@ -30,6 +33,15 @@ def main(B=4096, steps=20000, scene="stretch_empty", solver="newton"):
         per_launch.append(float(((sim.info[3] & 1) != 0).float().mean()))
         ever |= sim.info[3]
         capped += int((sim.info[2] >= itmax).sum())
+        zk = float(sim.qpos[2].max())
+        if zk > 0.6:   # a 23 kg robot does not get there by itself: report the env while it happens
+            e_ = int(sim.qpos[2].argmax())
+            print(f"  launch {k}: env {e_} base z {zk:.3f}, |qvel| max {float(sim.qvel[:, e_].abs().max()):.1f}, flags of this launch {hex(int(sim.info[3, e_]))} (ever {hex(int(ever[e_]))}), "
+                  f"rows / contacts / iterations of its last step {int(sim.info[0, e_])} / {int(sim.info[1, e_])} / {int(sim.info[2, e_])}", flush=True)
+        if zk > zmax_ever:
+            zmax_ever, zmax_at = zk, k
+            e_ = int(sim.qpos[2].argmax())
+            zmax_who = f"env {e_}, its flag bits so far {hex(int(ever[e_]))}, rows / contacts of its last step {int(sim.info[0, e_])} / {int(sim.info[1, e_])}"
         if k % 40 == 39:
             q = sim.qpos
             assert torch.isfinite(q).all() and torch.isfinite(sim.qvel).all(), k
@@ -45,8 +57,9 @@ def main(B=4096, steps=20000, scene="stretch_empty", solver="newton"):
           f"bad-state resets {float(((fl & 4) != 0).float().mean()):.4f}; pipeline timeouts {int(((fl & 8) != 0).sum())}; "
           f"steps per env min {int(sim.nstep.min())} max {int(sim.nstep.max())}; |quat|-1 max {worst_q:.1e}; "
           f"base z in [{float(z.min()):.3f}, {float(z.max()):.3f}], upright (R22>0.9) {float((up > 0.9).float().mean()):.3f}, "
-          f"|x|,|y| max {float(sim.qpos[0:2].abs().max()):.1f} m; solver at its iteration cap on the last step of a launch: {capped} of {B * (steps // 50)} (env, launch) samples; union of all flag bits {hex(int(np.bitwise_or.reduce(fl.cpu().numpy())))} (satellite builds: include/smj.h names the capacity bits)")
+          f"|x|,|y| max {float(sim.qpos[0:2].abs().max()):.1f} m; highest base z of the run {zmax_ever:.3f} (launch {zmax_at}: {zmax_who}); {options or ''} solver at its iteration cap on the last step of a launch: {capped} of {B * (steps // 50)} (env, launch) samples; union of all flag bits {hex(int(np.bitwise_or.reduce(fl.cpu().numpy())))} (satellite builds: include/smj.h names the capacity bits)")
 
 
 if __name__ == "__main__":
-    main(steps=int(sys.argv[1]) if len(sys.argv) > 1 else 20000, scene=sys.argv[2] if len(sys.argv) > 2 else "stretch_empty", solver=sys.argv[3] if len(sys.argv) > 3 else "newton")
+    main(steps=int(sys.argv[1]) if len(sys.argv) > 1 else 20000, scene=sys.argv[2] if len(sys.argv) > 2 else "stretch_empty", solver=sys.argv[3] if len(sys.argv) > 3 else "newton",
+         options={a.split("=")[0]: float(a.split("=")[1]) for a in sys.argv[4:]})
