@@ -620,6 +620,38 @@ def test_pipelined_chunks_are_bit_identical_to_one_workgroup_per_env():
         sim.stop()
 
 
+@pytest.mark.parametrize("B", [512, 700])
+def test_pipelined_chunks_at_small_batches_are_bit_identical(B):
+    """Round 5: launches are pipelined from 512 envs on (option pipeline_min_envs, default 511; 1024 before).  At these sizes the
+    workgroups of an env's consecutive chunks can be resident at the same time (512 envs x 2 chunks fit the device's 1024 slots of
+    the standard variant): the later one waits on the env's progress counter.  Same check as above against the unpipelined launch
+    (pipeline_min_envs beyond the batch): every state and readout bit for bit."""
+    from stretch_mujoco_amd.enums import StretchSensors
+
+    final = None
+    for min_envs in (100000, 511):
+        sim = _sim(B, solver="newton", sensors_to_use=StretchSensors.all())
+        sim.set_option("pipeline_min_envs", min_envs)
+        sim.set_option("pollers", 0)
+        g = torch.Generator(device=sim.device).manual_seed(7)
+        lo = torch.tensor(sim.model["actuator_ctrlrange"][:, 0], dtype=torch.float32, device=sim.device).unsqueeze(1)
+        hi = torch.tensor(sim.model["actuator_ctrlrange"][:, 1], dtype=torch.float32, device=sim.device).unsqueeze(1)
+        _set_ctrl(sim, HOME_CTRL)
+        sim.step(200)
+        for _ in range(3):
+            sim.ctrl.copy_(lo + (hi - lo) * torch.rand(10, B, generator=g, device=sim.device))
+            sim.step(37)
+        torch.cuda.synchronize()
+        got = [t.clone() for t in (sim.qpos, sim.qvel, sim.qacc_warmstart, sim.actuator_length, sim.base_pose, sim.info, sim.nstep, sim.gyro, sim.accel, sim.lidar, sim.xpose)]
+        assert int(sim.info[3].max()) == 0 and int(sim.nstep.min()) == int(sim.nstep.max()) == 311
+        if final is None:
+            final = got
+        else:
+            for a, b in zip(final, got):
+                assert torch.equal(a, b)
+        sim.stop()
+
+
 def test_pollers_finish_the_parked_chunk_and_hand_the_env_back():
     """Escalation beside the standard kernel (DevState::sched): a few workgroups of the tall variant take parked envs off the
     list while the standard kernel runs, finish the env's chunk and publish it for the standard variant's next chunk.  The
