@@ -2732,7 +2732,9 @@ struct StepKernel {
     {
       const int nh = uni(s.mbox[2]);
       flags |= uni(s.mbox[3]);
-      if (nh > 0 && ncon + nh <= NCON && !(flags & SMJ_FLAG_CON_OVERFLOW)) {
+      // (also on a flagged step: every contact either wavefront wrote sits in a slot it had claimed, and the claims that succeeded add up
+      // to NCON at most -- the list keeps everything that fitted, as the one-wavefront kernel's does)
+      if (nh > 0 && ncon + nh <= NCON) {
         PL<float[31]> w;
         LANES {
           if (lane < nh) {
@@ -2764,7 +2766,7 @@ struct StepKernel {
           }
         }
         ncon += nh;
-      } else if (nh > 0) flags |= SMJ_FLAG_CON_OVERFLOW | 0x4000;   // (a flagged step: the list stays this wavefront's own contacts, every slot of it written)
+      } else if (nh > 0) flags |= SMJ_FLAG_CON_OVERFLOW | 0x4000;   // (cannot happen: see above; the list would stay this wavefront's own contacts)
     }
     SYNC();
     CTICK(SMJ_PROF_C_SPHERE)
