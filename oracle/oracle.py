@@ -54,6 +54,13 @@ def lib():
         L.smjo_flops.restype = ctypes.c_longlong
         L.smjo_set_contacts.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.smjo_set_contacts.restype = None
+        for f in ("smjo_free_data", "smjo_free_model"):
+            getattr(L, f).argtypes = [ctypes.c_void_p]
+            getattr(L, f).restype = None
+        L.smjo_mc_words.restype = ctypes.c_int
+        for f in ("smjo_mc_get", "smjo_mc_set"):
+            getattr(L, f).argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+            getattr(L, f).restype = None
         _LIB = L
     return _LIB
 
@@ -79,6 +86,14 @@ class Oracle:
         if not self.m:
             raise ValueError("bad model blob")
         self.d = self.L.smjo_make_data(self.m)
+
+    def close(self):
+        """Free the C side.  Explicit, not __del__: arr() hands out numpy VIEWS of the C arrays, and tests keep such views after the
+        Oracle object is gone.  The rollout harness, which makes thousands of short-lived oracles (one per perturbed evaluation), closes them."""
+        if getattr(self, "d", None):
+            self.L.smjo_free_data(self.d); self.d = None
+        if getattr(self, "m", None):
+            self.L.smjo_free_model(self.m); self.m = None
 
     def dim(self, name: str) -> int:
         return self.L.smjo_dim(self.m, name.encode())
@@ -137,6 +152,17 @@ class Oracle:
         collision stage (one-shot): dynamics on identical contacts."""
         con = np.ascontiguousarray(con, np.float64).reshape(-1, 9)
         self.L.smjo_set_contacts(self.d, len(con), con.ctypes.data_as(ctypes.c_void_p))
+
+    def mc_export(self) -> np.ndarray:
+        """The kept contact manifolds (option manifold_keep, the twin of the kernels' manifold cache) as one buffer."""
+        buf = np.zeros(self.L.smjo_mc_words(), np.float64)
+        self.L.smjo_mc_get(self.d, buf.ctypes.data_as(ctypes.c_void_p))
+        return buf
+
+    def mc_import(self, buf: np.ndarray):
+        buf = np.ascontiguousarray(buf, np.float64)
+        assert buf.size == self.L.smjo_mc_words()
+        self.L.smjo_mc_set(self.d, buf.ctypes.data_as(ctypes.c_void_p))
 
     def render_depth(self, cam: int, width: int, height: int, fovy_deg: float, max_depth: float = 0.0) -> np.ndarray:
         """Depth image [height, width] (fp32) of camera `cam` from the poses of the last forward()/step()."""

@@ -56,12 +56,20 @@ static int* blob_i32(const uint8_t* b, const char* name, int* count) {
 
 /* ------------------------------------------------------------------ model / data */
 struct smjo_model {
+  void** allocs; int nalloc, calloc_cap;   /* every array the model owns (smjo_free_model) */
   int nq, nv, nu, nbody, njnt, ngeom, nsite, ncam, neq, ntendon, nwrap, nkey, npair, nhullvert, nlidar;
   double timestep, gravity[3], impratio, tolerance, meaninertia, lidar_cutoff;
   int iterations, cone, warmstart, pgs_fixed_iter, max_con_pair, solver, ls_iterations;
   int qcqp_cap;      /* iterates of mju_QCQP (20 = MuJoCo); option "qcqp_cap" */
   int pgs_dual_warmstart; /* NOT MuJoCo (default 0): PGS may also start from the previous step's constraint forces, row by row (option "pgs_dual_warmstart"; the kernels' option of the same name) */
   int multiccd;      /* stretch.xml:8 <flag multiccd="enable"/>: multi-point contacts for convex pairs (default on) */
+  /* NOT MuJoCo (default 0; option "manifold_keep"): the TWIN of the kernels' contact-manifold cache (option manifold_cache there,
+   * smj_step_impl.h narrow_pair / smj_sat.h): a convex pair whose two bodies stand within manifold_keep_eps of the poses its
+   * manifold was built at keeps that manifold, carried to first order by the bodies' motion since -- same slots, same keep rule,
+   * same carry, in fp64.  Tests bound "kernel vs this twin" (the implementation) and "twin vs unmodified" (the rule) separately. */
+  int manifold_keep;
+  double manifold_keep_eps;
+  int* pair_tag;     /* per pair: the kernels' cache tag (index in k_convpair + 1, or 0x40000000 | index in k_statpair), 0 = none */
   double ls_tolerance;
   int *body_parentid, *body_weldid, *body_rootid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum;
   double *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_gravcomp, *body_invweight0,
@@ -100,6 +108,7 @@ typedef struct {
 } contact_t;
 
 struct smjo_data {
+  void** allocs; int nalloc, calloc_cap;   /* every array the data owns (smjo_free_data) */
   int nv, ncon, nefc, ne, nf, solver_niter, ncon_dropped;
   /* tests: contact list handed in from outside (smjo_set_contacts) replaces the collision stage of the next forward pass,
    * so that the DYNAMICS can be compared on identical contacts even where MPR's portal facet differs (curved rims, vertices) */
@@ -123,10 +132,20 @@ struct smjo_data {
   double* prev_force;
   double *gyro, *accel, *lidar;
   double* scratch;
+  /* option manifold_keep: MC_SLOTS entries of {tag, n, pose of body 1 (pos 3, quat 4), pose of body 2, normal 3, n x (dist, pos 3)} */
+  int mc_tag[64], mc_n[64], mc_hits;
+  double mc_pose[64][14], mc_nrm[64][3], mc_con[64][5][4];
 };
 
-#define LOADF(name) m->name = blob_f64(b, #name, NULL)
-#define LOADI(name) m->name = blob_i32(b, #name, NULL)
+static void* track_ptr(void*** list, int* n, int* cap, void* p) {
+  if (*n == *cap) { *cap = *cap ? 2 * *cap : 128; *list = (void**)realloc(*list, sizeof(void*) * (size_t)*cap); }
+  (*list)[(*n)++] = p;
+  return p;
+}
+#define MTRACK(m, p) track_ptr(&(m)->allocs, &(m)->nalloc, &(m)->calloc_cap, (p))
+#define DTRACK(d, p) track_ptr(&(d)->allocs, &(d)->nalloc, &(d)->calloc_cap, (p))
+#define LOADF(name) m->name = (double*)MTRACK(m, blob_f64(b, #name, NULL))
+#define LOADI(name) m->name = (int*)MTRACK(m, blob_i32(b, #name, NULL))
 
 smjo_model* smjo_load(const void* blob, size_t nbytes) {
   const uint8_t* b = (const uint8_t*)blob;
@@ -148,8 +167,8 @@ smjo_model* smjo_load(const void* blob, size_t nbytes) {
   ti = blob_i32(b, "opt_iterations", NULL); m->iterations = ti[0]; free(ti);
   ti = blob_i32(b, "opt_cone", NULL); m->cone = ti[0]; free(ti);
   ti = blob_i32(b, "sensor_imu_site", NULL); m->imu_site = ti[0]; free(ti);
-  m->lidar_site = blob_i32(b, "sensor_lidar_site", &m->nlidar);
-  m->lidar_static = blob_f64(b, "sensor_lidar_static", NULL);
+  m->lidar_site = (int*)MTRACK(m, blob_i32(b, "sensor_lidar_site", &m->nlidar));
+  m->lidar_static = (double*)MTRACK(m, blob_f64(b, "sensor_lidar_static", NULL));
   m->warmstart = 1; m->pgs_fixed_iter = 0; m->max_con_pair = 4; m->qcqp_cap = 20; m->solver = 0; m->ls_iterations = 50; m->ls_tolerance = 0.01; m->multiccd = 1;
   LOADI(body_parentid); LOADI(body_weldid); LOADI(body_rootid); LOADI(body_jntadr); LOADI(body_jntnum);
   LOADI(body_dofadr); LOADI(body_dofnum);
@@ -179,20 +198,35 @@ smjo_model* smjo_load(const void* blob, size_t nbytes) {
   LOADI(pair_geom1); LOADI(pair_geom2); LOADI(pair_condim);
   LOADF(pair_friction); LOADF(pair_solref); LOADF(pair_solimp); LOADF(pair_margin); LOADF(pair_gap);
   LOADI(geom_group);
+  m->manifold_keep = 0; m->manifold_keep_eps = 2e-5;   /* SMJ_MC_EPS, smj_model.h */
+  m->pair_tag = (int*)MTRACK(m, calloc(m->npair > 0 ? m->npair : 1, sizeof(int)));
+  for (int st = 0; st < 2; st++) {   /* the kernels' pair tables: moving-moving pairs (all convex pairs in the builds without satellites), pairs with the static world */
+    const char *tab = st ? "k_statpair" : "k_convpair", *cnt = st ? "k_nstatpair" : "k_nconvpair";
+    if (!blob_find(b, tab) || !blob_find(b, cnt)) continue;
+    int nt = 0, *tp = blob_i32(b, tab, &nt), *np_ = blob_i32(b, cnt, NULL);
+    for (int k = 0; k < np_[0] && k < nt; k++)
+      if (tp[k] >= 0 && tp[k] < m->npair) m->pair_tag[tp[k]] = st ? (0x40000000 | k) : k + 1;
+    free(tp); free(np_);
+  }
   if (blob_find(b, "geom_rmeshid") && blob_find(b, "rmesh_vert")) {
     LOADI(geom_rmeshid); LOADI(rmesh_vertadr); LOADI(rmesh_faceadr); LOADI(rmesh_face);
-    m->rmesh_facenum = blob_i32(b, "rmesh_facenum", &m->nrmesh);
+    m->rmesh_facenum = (int*)MTRACK(m, blob_i32(b, "rmesh_facenum", &m->nrmesh));
     const blob_entry* e = blob_find(b, "rmesh_vert");
     if (e->dtype != 3) { fprintf(stderr, "smj_oracle: rmesh_vert must be f32\n"); abort(); }
     size_t cnt = e->nbytes / 4;
-    m->rmesh_vert = (double*)malloc((cnt ? cnt : 1) * sizeof(double));
+    m->rmesh_vert = (double*)MTRACK(m, malloc((cnt ? cnt : 1) * sizeof(double)));
     for (size_t i = 0; i < cnt; i++) { float v; memcpy(&v, b + e->offset + 4 * i, 4); m->rmesh_vert[i] = v; }
     t = blob_f64(b, "vis_znear_zfar_extent", NULL); m->znear = t[0] * t[2]; m->zfar = t[1] * t[2]; free(t);
   }
   return m;
 }
 
-void smjo_free_model(smjo_model* m) { free(m); /* arrays leak by design: test process lifetime */ }
+void smjo_free_model(smjo_model* m) {
+  if (!m) return;
+  for (int i = 0; i < m->nalloc; i++) free(m->allocs[i]);
+  free(m->allocs);
+  free(m);
+}
 
 
 int smjo_set_option(smjo_model* m, const char* name, double v) {
@@ -206,6 +240,8 @@ int smjo_set_option(smjo_model* m, const char* name, double v) {
   else if (!strcmp(name, "solver")) m->solver = (int)v; /* 0 = PGS (north_star), 2 = Newton (the reference model's default) */
   else if (!strcmp(name, "convex_pairs")) m->convex_pairs = (int)v;
   else if (!strcmp(name, "multiccd")) m->multiccd = (int)v;
+  else if (!strcmp(name, "manifold_keep")) m->manifold_keep = (int)v;
+  else if (!strcmp(name, "manifold_keep_eps")) m->manifold_keep_eps = v;
   else if (!strcmp(name, "timestep")) m->timestep = v;
   else if (!strcmp(name, "gravity_z")) m->gravity[2] = v;
   else if (!strcmp(name, "impratio")) m->impratio = v;
@@ -233,34 +269,39 @@ smjo_data* smjo_make_data(const smjo_model* m) {
   smjo_data* d = (smjo_data*)calloc(1, sizeof(smjo_data));
   int nv = m->nv, nb = m->nbody;
   d->nv = nv;
-  d->qpos = dalloc(m->nq); d->qvel = dalloc(nv); d->ctrl = dalloc(m->nu); d->qacc_warmstart = dalloc(nv);
-  d->qacc = dalloc(nv); d->qacc_smooth = dalloc(nv); d->qfrc_bias = dalloc(nv); d->qfrc_passive = dalloc(nv);
-  d->qfrc_actuator = dalloc(nv); d->qfrc_smooth = dalloc(nv); d->qfrc_constraint = dalloc(nv);
-  d->qfrc_applied = dalloc(nv);
-  d->xpos = dalloc(3 * nb); d->xquat = dalloc(4 * nb); d->xmat = dalloc(9 * nb); d->xipos = dalloc(3 * nb);
-  d->ximat = dalloc(9 * nb); d->xanchor = dalloc(3 * m->njnt); d->xaxis = dalloc(3 * m->njnt);
-  d->geom_xpos = dalloc(3 * m->ngeom); d->geom_xmat = dalloc(9 * m->ngeom);
-  d->site_xpos = dalloc(3 * m->nsite); d->site_xmat = dalloc(9 * m->nsite);
-  d->cam_xpos = dalloc(3 * m->ncam); d->cam_xmat = dalloc(9 * m->ncam);
-  d->subtree_com = dalloc(3 * nb); d->cinert = dalloc(10 * nb); d->crb = dalloc(10 * nb); d->cdof = dalloc(6 * nv);
-  d->cdof_dot = dalloc(6 * nv); d->cvel = dalloc(6 * nb); d->cacc = dalloc(6 * nb); d->cfrc = dalloc(6 * nb);
-  d->qM = dalloc(nv * nv); d->qL = dalloc(nv * nv); d->qH = dalloc(nv * nv);
-  d->ten_length = dalloc(m->ntendon); d->ten_J = dalloc(m->ntendon * nv);
-  d->actuator_length = dalloc(m->nu); d->actuator_velocity = dalloc(m->nu); d->actuator_moment = dalloc(m->nu * nv);
-  d->actuator_force = dalloc(m->nu);
-  d->contact = (contact_t*)calloc(MAXCON, sizeof(contact_t));
+  d->qpos = (double*)DTRACK(d, dalloc(m->nq)); d->qvel = (double*)DTRACK(d, dalloc(nv)); d->ctrl = (double*)DTRACK(d, dalloc(m->nu)); d->qacc_warmstart = (double*)DTRACK(d, dalloc(nv));
+  d->qacc = (double*)DTRACK(d, dalloc(nv)); d->qacc_smooth = (double*)DTRACK(d, dalloc(nv)); d->qfrc_bias = (double*)DTRACK(d, dalloc(nv)); d->qfrc_passive = (double*)DTRACK(d, dalloc(nv));
+  d->qfrc_actuator = (double*)DTRACK(d, dalloc(nv)); d->qfrc_smooth = (double*)DTRACK(d, dalloc(nv)); d->qfrc_constraint = (double*)DTRACK(d, dalloc(nv));
+  d->qfrc_applied = (double*)DTRACK(d, dalloc(nv));
+  d->xpos = (double*)DTRACK(d, dalloc(3 * nb)); d->xquat = (double*)DTRACK(d, dalloc(4 * nb)); d->xmat = (double*)DTRACK(d, dalloc(9 * nb)); d->xipos = (double*)DTRACK(d, dalloc(3 * nb));
+  d->ximat = (double*)DTRACK(d, dalloc(9 * nb)); d->xanchor = (double*)DTRACK(d, dalloc(3 * m->njnt)); d->xaxis = (double*)DTRACK(d, dalloc(3 * m->njnt));
+  d->geom_xpos = (double*)DTRACK(d, dalloc(3 * m->ngeom)); d->geom_xmat = (double*)DTRACK(d, dalloc(9 * m->ngeom));
+  d->site_xpos = (double*)DTRACK(d, dalloc(3 * m->nsite)); d->site_xmat = (double*)DTRACK(d, dalloc(9 * m->nsite));
+  d->cam_xpos = (double*)DTRACK(d, dalloc(3 * m->ncam)); d->cam_xmat = (double*)DTRACK(d, dalloc(9 * m->ncam));
+  d->subtree_com = (double*)DTRACK(d, dalloc(3 * nb)); d->cinert = (double*)DTRACK(d, dalloc(10 * nb)); d->crb = (double*)DTRACK(d, dalloc(10 * nb)); d->cdof = (double*)DTRACK(d, dalloc(6 * nv));
+  d->cdof_dot = (double*)DTRACK(d, dalloc(6 * nv)); d->cvel = (double*)DTRACK(d, dalloc(6 * nb)); d->cacc = (double*)DTRACK(d, dalloc(6 * nb)); d->cfrc = (double*)DTRACK(d, dalloc(6 * nb));
+  d->qM = (double*)DTRACK(d, dalloc(nv * nv)); d->qL = (double*)DTRACK(d, dalloc(nv * nv)); d->qH = (double*)DTRACK(d, dalloc(nv * nv));
+  d->ten_length = (double*)DTRACK(d, dalloc(m->ntendon)); d->ten_J = (double*)DTRACK(d, dalloc(m->ntendon * nv));
+  d->actuator_length = (double*)DTRACK(d, dalloc(m->nu)); d->actuator_velocity = (double*)DTRACK(d, dalloc(m->nu)); d->actuator_moment = (double*)DTRACK(d, dalloc(m->nu * nv));
+  d->actuator_force = (double*)DTRACK(d, dalloc(m->nu));
+  d->contact = (contact_t*)DTRACK(d, calloc(MAXCON, sizeof(contact_t)));
   d->override_ncon = -1; d->override_con = NULL;
-  d->efc_J = dalloc((size_t)MAXEFC * nv); d->efc_pos = dalloc(MAXEFC); d->efc_margin = dalloc(MAXEFC);
-  d->efc_D = dalloc(MAXEFC); d->efc_R = dalloc(MAXEFC); d->efc_aref = dalloc(MAXEFC); d->efc_b = dalloc(MAXEFC);
-  d->efc_force = dalloc(MAXEFC); d->efc_vel = dalloc(MAXEFC); d->efc_KBIP = dalloc(4 * MAXEFC);
-  d->efc_diagApprox = dalloc(MAXEFC); d->efc_frictionloss = dalloc(MAXEFC); d->efc_AR = dalloc((size_t)MAXEFC * MAXEFC);
-  d->efc_type = (int*)calloc(MAXEFC, sizeof(int)); d->efc_id = (int*)calloc(MAXEFC, sizeof(int));
-  d->gyro = dalloc(3); d->accel = dalloc(3); d->lidar = dalloc(m->nlidar);
-  d->scratch = dalloc((size_t)MAXEFC * nv + 16 * nv);
+  d->efc_J = (double*)DTRACK(d, dalloc((size_t)MAXEFC * nv)); d->efc_pos = (double*)DTRACK(d, dalloc(MAXEFC)); d->efc_margin = (double*)DTRACK(d, dalloc(MAXEFC));
+  d->efc_D = (double*)DTRACK(d, dalloc(MAXEFC)); d->efc_R = (double*)DTRACK(d, dalloc(MAXEFC)); d->efc_aref = (double*)DTRACK(d, dalloc(MAXEFC)); d->efc_b = (double*)DTRACK(d, dalloc(MAXEFC));
+  d->efc_force = (double*)DTRACK(d, dalloc(MAXEFC)); d->efc_vel = (double*)DTRACK(d, dalloc(MAXEFC)); d->efc_KBIP = (double*)DTRACK(d, dalloc(4 * MAXEFC));
+  d->efc_diagApprox = (double*)DTRACK(d, dalloc(MAXEFC)); d->efc_frictionloss = (double*)DTRACK(d, dalloc(MAXEFC)); d->efc_AR = (double*)DTRACK(d, dalloc((size_t)MAXEFC * MAXEFC));
+  d->efc_type = (int*)DTRACK(d, calloc(MAXEFC, sizeof(int))); d->efc_id = (int*)DTRACK(d, calloc(MAXEFC, sizeof(int)));
+  d->gyro = (double*)DTRACK(d, dalloc(3)); d->accel = (double*)DTRACK(d, dalloc(3)); d->lidar = (double*)DTRACK(d, dalloc(m->nlidar));
+  d->scratch = (double*)DTRACK(d, dalloc((size_t)MAXEFC * nv + 16 * nv));
   smjo_reset(m, d);
   return d;
 }
-void smjo_free_data(smjo_data* d) { free(d); }
+void smjo_free_data(smjo_data* d) {
+  if (!d) return;
+  for (int i = 0; i < d->nalloc; i++) free(d->allocs[i]);
+  free(d->allocs); free(d->prev_key); free(d->prev_force); free(d->override_con);
+  free(d);
+}
 
 void smjo_reset(const smjo_model* m, smjo_data* d) {
   memcpy(d->qpos, m->qpos0, sizeof(double) * m->nq);
@@ -269,6 +310,7 @@ void smjo_reset(const smjo_model* m, smjo_data* d) {
   memset(d->qacc_warmstart, 0, sizeof(double) * m->nv);
   memset(d->qfrc_applied, 0, sizeof(double) * m->nv);
   d->time = 0;
+  memset(d->mc_tag, 0, sizeof(d->mc_tag)); d->mc_hits = 0;
 }
 
 #define GETD(nm, cnt) if (!strcmp(name, #nm)) { *n = (cnt); return d->nm; }
@@ -301,6 +343,7 @@ int* smjo_get_int(smjo_data* d, const char* name, int* n) {
   if (!strcmp(name, "nefc")) { *n = 1; return &d->nefc; }
   if (!strcmp(name, "solver_niter")) { *n = 1; return &d->solver_niter; }
   if (!strcmp(name, "ncon_dropped")) { *n = 1; return &d->ncon_dropped; }
+  if (!strcmp(name, "mc_hits")) { *n = 1; return &d->mc_hits; }
   return NULL;
 }
 
@@ -1369,8 +1412,59 @@ static void collision(const smjo_model* m, smjo_data* d) {
       else continue;
     } else {
       if (!m->convex_pairs) continue;
-      n = convex_pair(m, d, g1, g2, margin, rc);
-      if (n && dot3(rc[0].normal, rc[0].normal) < 0.5) continue; /* degenerate touching contact without a direction */
+      int slot = -1;
+      const int tag = m->pair_tag[p];
+      n = -1;
+      if (m->manifold_keep && tag && t1 != G_SPHERE && t2 != G_SPHERE && !(t1 == G_CAPSULE && t2 == G_CAPSULE)) {
+        /* the kernels' mc_entry(): pairs with the static world in the upper half of the slots; the look-up comes after the broadphase */
+        if (!obb_overlap(m, d, g1, g2, margin)) continue;
+        slot = (int)((((unsigned)tag >> 30) & 1u) << 5 | (((unsigned)tag * 2654435761u) >> 27));
+        const int b1 = m->geom_bodyid[g1], b2 = m->geom_bodyid[g2];
+        double cur[14];
+        memcpy(cur, d->xpos + 3 * b1, 24); memcpy(cur + 3, d->xquat + 4 * b1, 32);
+        memcpy(cur + 7, d->xpos + 3 * b2, 24); memcpy(cur + 10, d->xquat + 4 * b2, 32);
+        int ok = d->mc_tag[slot] == tag;
+        for (int k = 0; k < 14 && ok; k++) ok = fabs(cur[k] - d->mc_pose[slot][k]) <= m->manifold_keep_eps;
+        if (ok) {   /* smj_mc_motion / smj_mc_carry: u_b(p) = dx_b + dth_b x (p - x_b), dth = 2 vec(q1 conj(q0)) */
+          double dx[2][3], dt[2][3];
+          for (int k = 0; k < 2; k++) {
+            const double *q0 = d->mc_pose[slot] + 7 * k + 3, *q1 = cur + 7 * k + 3;
+            for (int i = 0; i < 3; i++) dx[k][i] = cur[7 * k + i] - d->mc_pose[slot][7 * k + i];
+            const double sw = q1[0] * q0[0] + q1[1] * q0[1] + q1[2] * q0[2] + q1[3] * q0[3], sg = sw < 0 ? -2.0 : 2.0;
+            dt[k][0] = sg * (q0[0] * q1[1] - q1[0] * q0[1] - (q1[2] * q0[3] - q1[3] * q0[2]));
+            dt[k][1] = sg * (q0[0] * q1[2] - q1[0] * q0[2] - (q1[3] * q0[1] - q1[1] * q0[3]));
+            dt[k][2] = sg * (q0[0] * q1[3] - q1[0] * q0[3] - (q1[1] * q0[2] - q1[2] * q0[1]));
+          }
+          n = d->mc_n[slot];
+          for (int i = 0; i < n; i++) {
+            const double* pp = d->mc_con[slot][i] + 1;
+            double u[2][3];
+            for (int k = 0; k < 2; k++) {
+              const double* x0 = d->mc_pose[slot] + 7 * k;
+              const double r[3] = {pp[0] - x0[0], pp[1] - x0[1], pp[2] - x0[2]};
+              u[k][0] = dx[k][0] + dt[k][1] * r[2] - dt[k][2] * r[1];
+              u[k][1] = dx[k][1] + dt[k][2] * r[0] - dt[k][0] * r[2];
+              u[k][2] = dx[k][2] + dt[k][0] * r[1] - dt[k][1] * r[0];
+            }
+            const double* nr = d->mc_nrm[slot];
+            rc[i].dist = d->mc_con[slot][i][0] + nr[0] * (u[1][0] - u[0][0]) + nr[1] * (u[1][1] - u[0][1]) + nr[2] * (u[1][2] - u[0][2]);
+            for (int k = 0; k < 3; k++) { rc[i].pos[k] = pp[k] + 0.5 * (u[0][k] + u[1][k]); rc[i].normal[k] = nr[k]; }
+          }
+          d->mc_hits++;
+        }
+      }
+      if (n < 0) {
+        n = convex_pair(m, d, g1, g2, margin, rc);
+        if (n && dot3(rc[0].normal, rc[0].normal) < 0.5) continue; /* degenerate touching contact without a direction */
+        if (slot >= 0 && n >= 1 && n <= 5 && d->ncon + n <= MAXCON) {   /* keep what the narrowphase found, with the poses it was found at */
+          const int b1 = m->geom_bodyid[g1], b2 = m->geom_bodyid[g2];
+          d->mc_tag[slot] = tag; d->mc_n[slot] = n;
+          memcpy(d->mc_pose[slot], d->xpos + 3 * b1, 24); memcpy(d->mc_pose[slot] + 3, d->xquat + 4 * b1, 32);
+          memcpy(d->mc_pose[slot] + 7, d->xpos + 3 * b2, 24); memcpy(d->mc_pose[slot] + 10, d->xquat + 4 * b2, 32);
+          memcpy(d->mc_nrm[slot], rc[0].normal, 24);
+          for (int i = 0; i < n; i++) { d->mc_con[slot][i][0] = rc[i].dist; memcpy(d->mc_con[slot][i] + 1, rc[i].pos, 24); }
+        }
+      }
     }
     for (int i = 0; i < n; i++) {
       if (d->ncon >= MAXCON) { d->ncon_dropped++; continue; }
@@ -2134,6 +2228,23 @@ static void fwd_constraint_newton(const smjo_model* m, smjo_data* d) {
 }
 
 /* ------------------------------------------------------------------ forward */
+/* option manifold_keep: the kept manifolds as one buffer of smjo_mc_words() doubles (tests: an oracle that evaluates one step of
+ * another one's trajectory takes that one's kept manifolds along) */
+int smjo_mc_words(void) { return 64 * 39; }
+void smjo_mc_get(const smjo_data* d, double* buf) {
+  for (int k = 0; k < 64; k++) {
+    double* w = buf + 39 * k;
+    w[0] = d->mc_tag[k]; w[1] = d->mc_n[k];
+    memcpy(w + 2, d->mc_pose[k], 14 * 8); memcpy(w + 16, d->mc_nrm[k], 24); memcpy(w + 19, d->mc_con[k], 20 * 8);
+  }
+}
+void smjo_mc_set(smjo_data* d, const double* buf) {
+  for (int k = 0; k < 64; k++) {
+    const double* w = buf + 39 * k;
+    d->mc_tag[k] = (int)w[0]; d->mc_n[k] = (int)w[1];
+    memcpy(d->mc_pose[k], w + 2, 14 * 8); memcpy(d->mc_nrm[k], w + 16, 24); memcpy(d->mc_con[k], w + 19, 20 * 8);
+  }
+}
 void smjo_set_contacts(smjo_data* d, int n, const double* con /* n x (dist, pos3, normal3, geom1, geom2) */) {
   free(d->override_con);
   d->override_con = (double*)malloc(sizeof(double) * 9 * (n > 0 ? n : 1));
@@ -2421,12 +2532,12 @@ static int rb_build(const smjo_model* m, int mesh, struct rbvh* t, int first, in
 }
 static void rb_ensure(smjo_model* m) {
   if (m->rbvh || !m->rmesh_vert) return;
-  m->rbvh = (struct rbvh*)calloc(m->nrmesh ? m->nrmesh : 1, sizeof(struct rbvh));
+  m->rbvh = (struct rbvh*)MTRACK(m, calloc(m->nrmesh ? m->nrmesh : 1, sizeof(struct rbvh)));
   for (int mesh = 0; mesh < m->nrmesh; mesh++) {
     int nf = m->rmesh_facenum[mesh];
     struct rbvh* t = &m->rbvh[mesh];
-    t->node = (rnode*)calloc(2 * (size_t)(nf ? nf : 1), sizeof(rnode));
-    t->tri = (int*)malloc((nf ? nf : 1) * sizeof(int));
+    t->node = (rnode*)MTRACK(m, calloc(2 * (size_t)(nf ? nf : 1), sizeof(rnode)));
+    t->tri = (int*)MTRACK(m, malloc((nf ? nf : 1) * sizeof(int)));
     double* cen3 = (double*)malloc(3 * (size_t)(nf ? nf : 1) * sizeof(double));
     const double* V = m->rmesh_vert + 3 * (size_t)m->rmesh_vertadr[mesh];
     const int* F = m->rmesh_face + 3 * (size_t)m->rmesh_faceadr[mesh];

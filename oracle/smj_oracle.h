@@ -38,6 +38,10 @@ void smjo_reset(const smjo_model* m, smjo_data* d);          /* qpos=qpos0, qvel
 void smjo_forward(const smjo_model* m, smjo_data* d);        /* mj_forward */
 /* tests: the next forward pass takes these contacts instead of running its collision stage (one-shot) */
 void smjo_set_contacts(smjo_data* d, int n, const double* con /* n x (dist, pos[3], normal[3], geom1, geom2) */);
+/* option "manifold_keep" (NOT MuJoCo; the twin of the kernels' manifold cache): the kept manifolds as smjo_mc_words() doubles */
+int smjo_mc_words(void);
+void smjo_mc_get(const smjo_data* d, double* buf);
+void smjo_mc_set(smjo_data* d, const double* buf);
 void smjo_step(const smjo_model* m, smjo_data* d);           /* mj_step (implicitfast + PGS) */
 void smjo_step_n(const smjo_model* m, smjo_data* d, int n);
 void smjo_sensors(const smjo_model* m, smjo_data* d, int with_lidar); /* gyro, accel, lidar into d */

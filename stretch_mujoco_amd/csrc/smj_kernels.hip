@@ -20,6 +20,13 @@ __global__ __launch_bounds__(256) void smj_reset_kernel(const DevModel M, const 
     for (int k = 0; k < SMJ_BC_ROWS; k++) S.bctl[k * S.ld + e] = 0.f;
   S.nstep[e] = 0;
   for (int k = 0; k < 4; k++) S.info[k * S.ld + e] = 0;
+  // what the library keeps between steps beside the state must not outlive the episode (mj_resetData leaves nothing behind): the PGS
+  // second start (row count 0 = none), the kept contact manifolds and separating directions (tag word 0 = empty entry)
+  if (S.pgsprev) S.pgsprev[(size_t)e * SMJ_PGSPREV_STRIDE] = 0.f;
+  if (S.mcache)
+    for (int k = 0; k < SMJ_MC_SLOTS; k++) S.mcache[((size_t)e * SMJ_MC_SLOTS + k) * SMJ_MC_WORDS] = 0.f;
+  if (S.sepcache)
+    for (int k = 0; k < SMJ_SEP_SLOTS; k++) S.sepcache[((size_t)e * SMJ_SEP_SLOTS + k) * 4 + 3] = 0.f;
 }
 
 // Staging transposes.  A block moves one tile: 64 envs x up to 128 rows of one batch-major array (blockIdx.y = tile).  Rows of

@@ -282,7 +282,7 @@ enum { SMJ_PGSPREV_ROWS = 320, SMJ_PGSPREV_STRIDE = 2 * SMJ_PGSPREV_ROWS + 4 };
 #ifndef SMJ_MC_LOG2
 #define SMJ_MC_LOG2 5
 #endif
-enum { SMJ_SEP_SLOTS = 64, SMJ_MC_SLOTS = 2 << SMJ_MC_LOG2, SMJ_MC_WORDS = 40 };   // (manifold slots: 1 << SMJ_MC_LOG2 for the moving-moving pairs, as many for the pairs with the static world)
+enum { SMJ_SEP_SLOTS = 128 /* 64 for the moving-moving pairs (slot = pair & 63), 64 for the pairs with the static world */, SMJ_MC_SLOTS = 2 << SMJ_MC_LOG2, SMJ_MC_WORDS = 40 };   // (manifold slots: 1 << SMJ_MC_LOG2 for the moving-moving pairs, as many for the pairs with the static world)
 #ifndef SMJ_MC_EPS
 #define SMJ_MC_EPS 2e-5f
 #endif

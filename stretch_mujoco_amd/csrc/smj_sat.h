@@ -1133,8 +1133,8 @@ SMJ_DEV void collision_static(float* pc, bool prof) {
   float* const sepbase = (S.sepcache && M.sep_cache) ? S.sepcache + (size_t)env * (SMJ_SEP_SLOTS * 4) : nullptr;
   const long long tn0 = prof ? smj_clock() : 0;
   for (int k0 = 0; k0 < n; k0 += 64) {
-    // the survivors' separating directions, fetched lane-parallel ahead of the serial loop (slots shared with the moving-moving
-    // pairs; the tag tells whose entry it is)
+    // the survivors' separating directions, fetched lane-parallel ahead of the serial loop (the upper half of the env's slots: the moving-moving
+    // pairs -- worked by the other wavefront in the two-wavefront builds -- keep to the lower half; the tag tells whose entry it is)
     PL<float> sdx, sdy, sdz;
     PL<int> stag, ssid;
     LANES {
@@ -1142,7 +1142,7 @@ SMJ_DEV void collision_static(float* pc, bool prof) {
       int sid = -1;
       if (k0 + lane < n) {
         sid = s.u.c.sl_sid[s.u.c.sl_ord[k0 + lane]];
-        if (sepbase) e = *reinterpret_cast<const Vec4*>(sepbase + 4 * ((sid * 7 + 29) & (SMJ_SEP_SLOTS - 1)));
+        if (sepbase) e = *reinterpret_cast<const Vec4*>(sepbase + 4 * (SMJ_SEP_SLOTS / 2 + ((sid * 7 + 29) & (SMJ_SEP_SLOTS / 2 - 1))));
       }
       sdx[lane] = e.x; sdy[lane] = e.y; sdz[lane] = e.z; stag[lane] = __builtin_bit_cast(int, e.w); ssid[lane] = sid;
     }
@@ -1230,7 +1230,7 @@ SMJ_DEV void collision_static(float* pc, bool prof) {
       stage_static(S1 < 0 ? -1 - S1 : -1 - S2);
       const float sd[3] = {wave_read(sdx, l), wave_read(sdy, l), wave_read(sdz, l)};
       const int tag = 0x40000000 | sid;
-      narrow_pair(r, S1 < 0 ? NCG : S1, S2 < 0 ? NCG : S2, sepbase ? sepbase + 4 * ((sid * 7 + 29) & (SMJ_SEP_SLOTS - 1)) : nullptr, tag,
+      narrow_pair(r, S1 < 0 ? NCG : S1, S2 < 0 ? NCG : S2, sepbase ? sepbase + 4 * (SMJ_SEP_SLOTS / 2 + ((sid * 7 + 29) & (SMJ_SEP_SLOTS / 2 - 1))) : nullptr, tag,
                   sepbase && wave_read(stag, l) == tag, sd, pc, prof, false);
       SYNC();
     }

@@ -543,7 +543,7 @@ SMJ_DEV void pgs_sat_core(PL<float>& u, bool dbg, float* pc, long long& t0, bool
   // from them that 100 sweeps never got there (fp64 oracle, Robocasa-scale kitchen: 100 sweeps on every step -> 19 settled / 71
   // under random actions; oracle option pgs_dual_warmstart).
   bool have_prev = false;
-  if (M.pgs_dual_ws && S.pgsprev) {
+  if (M.pgs_dual_ws && M.warmstart && S.pgsprev) {
     const int* const pk = reinterpret_cast<const int*>(S.pgsprev + (size_t)env * SMJ_PGSPREV_STRIDE);
     const float* const pf = S.pgsprev + (size_t)env * SMJ_PGSPREV_STRIDE + 1 + SMJ_PGSPREV_ROWS;
     int np = uni(pk[0]);
@@ -738,7 +738,7 @@ SMJ_DEV void pgs_sat_core(PL<float>& u, bool dbg, float* pc, long long& t0, bool
   // ---- forces back to their rows; qacc = M^-1 (qfrc_smooth + J' f)
   PSETS_ALL(p) LANES { const int i = lane + 64 * p; if (i < ndp) s.ef[drow_r[p][lane]] = f_r[p][lane]; }
   SYNC();
-  if (M.pgs_dual_ws && S.pgsprev) {   // the rows of this step and where their forces ended: the next step's second start
+  if (M.pgs_dual_ws && M.warmstart && S.pgsprev) {   // the rows of this step and where their forces ended: the next step's second start
     int* const pk = reinterpret_cast<int*>(S.pgsprev + (size_t)env * SMJ_PGSPREV_STRIDE);
     float* const pf = S.pgsprev + (size_t)env * SMJ_PGSPREV_STRIDE + 1 + SMJ_PGSPREV_ROWS;
     const int nst = ne < SMJ_PGSPREV_ROWS ? ne : SMJ_PGSPREV_ROWS;

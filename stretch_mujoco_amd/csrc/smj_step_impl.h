@@ -1733,8 +1733,13 @@ struct StepKernel {
     const float d = fminf(dv4 - dot3(P[1].v, dir), fminf(dv4 - dot3(P[2].v, dir), dv4 - dot3(P[3].v, dir)));
     return ccd_eq(d, tol) || d < tol;
   }
-  SMJ_DEV static float origin_tri_dist2(const float* a, const float* b, const float* c, float* w) {
+#ifndef SMJ_PORTAL_NORMAL
+#define SMJ_PORTAL_NORMAL 1   // (0: the witness' direction as it comes, the fp32 behaviour of rounds 1-5; A/B builds of tools / tests only)
+#endif
+  // interior (optional): set when the witness is the projection of the origin INTO the triangle (not onto an edge / a corner)
+  SMJ_DEV static float origin_tri_dist2(const float* a, const float* b, const float* c, float* w, bool* interior = nullptr) {
     float d1[3], d2[3];
+    if (interior) *interior = false;
     for (int i = 0; i < 3; i++) { d1[i] = b[i] - a[i]; d2[i] = c[i] - a[i]; }
     const float u = dot3(a, a), v = dot3(d1, d1), ww = dot3(d2, d2), p = dot3(a, d1), q = dot3(a, d2), r = dot3(d1, d2);
     const float den = ww * v - r * r;
@@ -1742,6 +1747,7 @@ struct StepKernel {
     if (!ccd_zero(den)) { sc = (q * r - ww * p) / den; t = (-sc * r - q) / ww; }
     if ((ccd_zero(sc) || sc > 0) && (ccd_eq(sc, 1) || sc < 1) && (ccd_zero(t) || t > 0) && (ccd_eq(t, 1) || t < 1) && (ccd_eq(t + sc, 1) || t + sc < 1)) {
       for (int i = 0; i < 3; i++) w[i] = a[i] + sc * d1[i] + t * d2[i];
+      if (interior) *interior = true;
       // |w|^2 from the witness point itself: libccd's expanded form (u + s^2 v + t^2 w + 2sp + 2tq + 2str) cancels to noise in
       // fp32 when the penetration (1e-5 m) is small against the portal's distance from the origin (1e-2 m)
       return dot3(w, w);
@@ -1840,9 +1846,24 @@ struct StepKernel {
       portal_dir(P, dir);
       mpr_support(A, Bs, dir, v4);
       if (reach_tolerance(P, v4, dir, tol) || it > maxit) {
-        depth = sqrtf(fmaxf(0.f, origin_tri_dist2(P[1].v, P[2].v, P[3].v, pdir)));
+        bool inside;
+        depth = sqrtf(fmaxf(0.f, origin_tri_dist2(P[1].v, P[2].v, P[3].v, pdir, &inside)));
         if (ccd_zero(pdir[0]) && ccd_zero(pdir[1]) && ccd_zero(pdir[2])) { pdir[0] = dir[0]; pdir[1] = dir[1]; pdir[2] = dir[2]; }
         normalize3(pdir);
+        // fp32: the witness is a vector of the penetration's length (1e-5 .. 1e-4 m for a resting body) put together from support
+        // points that carry the rounding of world coordinates (1e-7 at 1.5 m): its direction is good to 1e-3 .. 1e-2 rad -- a bottle
+        // standing on a counter got a contact normal 1.6e-3 rad off the counter's face, 5e-2 rad/s^2 on its tilt where the fp64
+        // oracle has 0.  Where the witness is the origin's projection INTO the portal it is parallel to the portal's normal in exact
+        // arithmetic (libccd's result, unchanged), and that normal comes from centimetre-long edges: good to 1e-5 rad.  Taken when it
+        // is the better conditioned of the two: the witness' direction is uncertain by (rounding) / depth, the normal's by (rounding) /
+        // (the portal's smallest height) -- a sliver portal's normal is no better than the witness.
+        if (SMJ_PORTAL_NORMAL && inside && dot3(pdir, dir) > 0.9995f) {
+          float ea[3], eb[3], ec[3], cr[3];
+          for (int i = 0; i < 3; i++) { ea[i] = P[2].v[i] - P[1].v[i]; eb[i] = P[3].v[i] - P[1].v[i]; ec[i] = P[3].v[i] - P[2].v[i]; }
+          cross3(cr, ea, eb);
+          const float emax2 = fmaxf(dot3(ea, ea), fmaxf(dot3(eb, eb), dot3(ec, ec)));
+          if (dot3(cr, cr) > 16.f * depth * depth * emax2) { pdir[0] = dir[0]; pdir[1] = dir[1]; pdir[2] = dir[2]; }   // height > 4 x depth
+        }
         float b[4], vec[3], sum;
         cross3(vec, P[1].v, P[2].v); b[0] = dot3(vec, P[3].v);
         cross3(vec, P[3].v, P[2].v); b[1] = dot3(vec, P[0].v);
@@ -2559,7 +2580,8 @@ struct StepKernel {
     const int ta0 = uni(s.u.c.meta[s1]) & 15, tb0 = uni(s.u.c.meta[s2]) & 15;
     float* mc = nullptr;
     const int ncon0 = ncon;
-    if (S.mcache && M.manifold_cache && ta0 != GT_SPHERE && tb0 != GT_SPHERE) {
+    // (not for capsule against capsule: a closed form, and its two contacts of the parallel case have normals of their own -- an entry keeps one)
+    if (S.mcache && M.manifold_cache && ta0 != GT_SPHERE && tb0 != GT_SPHERE && !(ta0 == GT_CAPSULE && tb0 == GT_CAPSULE)) {
       mc = mc_entry(septag);
       const int b1 = uni(r[SMJ_CP_B1]), b2 = uni(r[SMJ_CP_B2]);
       PL<float> w;
@@ -2916,7 +2938,7 @@ struct StepKernel {
       float* const sepbase = (S.sepcache && M.sep_cache) ? S.sepcache + (size_t)env * (SMJ_SEP_SLOTS * 4) : nullptr;
       LANES {
         Vec4 e = {0.f, 0.f, 0.f, 0.f};
-        if (sepbase && hit[lane]) e = *reinterpret_cast<const Vec4*>(sepbase + 4 * (tt[lane] & (SMJ_SEP_SLOTS - 1)));
+        if (sepbase && hit[lane]) e = *reinterpret_cast<const Vec4*>(sepbase + 4 * (tt[lane] & (SMJ_SEP_SLOTS / 2 - 1)));
         sdx[lane] = e.x; sdy[lane] = e.y; sdz[lane] = e.z; stag[lane] = __builtin_bit_cast(int, e.w);
       }
       CTICK(SMJ_PROF_C_OBB)
@@ -2927,7 +2949,7 @@ struct StepKernel {
         const int t = wave_read(tt, l);
         const int* r = static_cast<const int*>(__builtin_assume_aligned(M.k_cprec + t * SMJ_CP_STRIDE, 16));
         const float sd[3] = {wave_read(sdx, l), wave_read(sdy, l), wave_read(sdz, l)};
-        narrow_pair(r, uni(r[SMJ_CP_S1]), uni(r[SMJ_CP_S2]), sepbase ? sepbase + 4 * (t & (SMJ_SEP_SLOTS - 1)) : nullptr, t + 1,
+        narrow_pair(r, uni(r[SMJ_CP_S1]), uni(r[SMJ_CP_S2]), sepbase ? sepbase + 4 * (t & (SMJ_SEP_SLOTS / 2 - 1)) : nullptr, t + 1,
                     sepbase && wave_read(stag, l) == t + 1, sd, pc, prof);
       }
       CTICK(SMJ_PROF_C_NARROW)
@@ -3340,7 +3362,7 @@ struct StepKernel {
     // of MuJoCo's start.  Same fixed point (the dual is strictly convex, R > 0), fewer sweeps to it; smj_sat_pgs.h has the measurements.
     bool have_prev = false;
 #if NSAT == 0
-    if (M.pgs_dual_ws && S.pgsprev) {
+    if (M.pgs_dual_ws && M.warmstart && S.pgsprev) {
       const int* const pk = reinterpret_cast<const int*>(S.pgsprev + (size_t)env * SMJ_PGSPREV_STRIDE);
       const float* const pf = S.pgsprev + (size_t)env * SMJ_PGSPREV_STRIDE + 1 + SMJ_PGSPREV_ROWS;
       int np = uni(pk[0]);
@@ -3491,7 +3513,7 @@ struct StepKernel {
     PSETS_ALL(p) LANES { if (lane + 64 * p < NEFC) s.ef[lane + 64 * p] = lane + 64 * p < ne ? f_r[p][lane] : 0.f; }
     SYNC();
 #if NSAT == 0
-    if (M.pgs_dual_ws && S.pgsprev) {   // the rows of this step and where their forces ended: the next step's second start
+    if (M.pgs_dual_ws && M.warmstart && S.pgsprev) {   // the rows of this step and where their forces ended: the next step's second start
       int* const pk = reinterpret_cast<int*>(S.pgsprev + (size_t)env * SMJ_PGSPREV_STRIDE);
       float* const pf = S.pgsprev + (size_t)env * SMJ_PGSPREV_STRIDE + 1 + SMJ_PGSPREV_ROWS;
       const int nst = ne < SMJ_PGSPREV_ROWS ? ne : SMJ_PGSPREV_ROWS;

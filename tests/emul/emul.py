@@ -75,6 +75,11 @@ class Emul:
     def set_option(self, name, v):
         assert self.L.emul_set_option(self.c, name.encode(), float(v)) == 0
 
+    def clear_caches(self):
+        """What smj_reset drops beside the state: kept manifolds, separating directions, the PGS second start."""
+        self.L.emul_clear_caches.argtypes = [ctypes.c_void_p]
+        self.L.emul_clear_caches(self.c)
+
     def set_poison(self, byte):
         """Fill the emulated LDS with `byte` before every launch (-1: leave whatever the previous launch left)."""
         self.L.emul_set_poison(int(byte))

@@ -58,6 +58,13 @@ emul_ctx* emul_create(const void* blob, size_t nbytes, int num_envs) {
   c->keep.push_back(c->s.pgsprev);
   return c;
 }
+// what smj_reset drops of the library's own memory (smj_kernels.hip smj_reset_kernel): kept manifolds, separating directions, PGS second start
+void emul_clear_caches(emul_ctx* c) {
+  const size_t B = (size_t)c->s.B;
+  memset(c->s.sepcache, 0, B * SMJ_SEP_SLOTS * 4 * sizeof(float));
+  memset(c->s.mcache, 0, B * SMJ_MC_SLOTS * SMJ_MC_WORDS * sizeof(float));
+  memset(c->s.pgsprev, 0, B * SMJ_PGSPREV_STRIDE * sizeof(float));
+}
 void emul_destroy(emul_ctx* c) {
   for (void* p : c->keep) free(p);
   delete c;

@@ -35,15 +35,18 @@ OBJECT_SCENES = ("stretch_scene", "stretch_kitchen4", "stretch_kitchen_robocasa"
 # perturbed by <= 1e-5, or on the kernel's contact list), (ii) sensitivity (violent phases: the steps whose error matters for the band are each
 # within the oracle's own response to an input perturbed at fp32 resolution) or (iii) conditioning (no such step at all, and two fp64 oracles
 # started from the two in-band states end further apart than half the band).  The floors below only keep the test from passing vacuously.
-FLOOR_INSIDE = {"stretch_empty": 0.5, "stretch_kitchen_standin": 0.5, "stretch_scene": 0.0, "stretch_kitchen4": 0.25, "stretch_kitchen_robocasa": 0.125}   # (the kitchen at Robocasa scale: 3-4 of 16 measured -- which envs stay inside for 1000 steps moves with any change of the cache layout; the criterion is the explained departures and the first 250 steps)
-FLOOR_INSIDE_EARLY = 0.7     # scenes with free objects in reach: the first 250 steps
+FLOOR_INSIDE = {"stretch_empty": 0.5, "stretch_kitchen_standin": 0.5, "stretch_scene": 0.0, "stretch_kitchen4": 0.25, "stretch_kitchen_robocasa": 0.25}   # (fixed numbers, not "the last measurement minus one": round 6 measures 9-10 of 16 in the Robocasa-scale kitchen after the fp32 contact-normal fix)
+FLOOR_INSIDE_EARLY = 0.7     # scenes with free objects in reach: the first 250 steps, the robot's coordinates (the criterion of rounds 3-5, kept)
+FLOOR_INSIDE_EARLY_ALL = 0.5 # ... and every coordinate, the objects' included (round 6: the stronger verdict; objects the gripper is already pushing leave first)
+OBJ_BAND = 1e-4              # qpos of free objects / fixture parts: the same band as the robot's coordinates
 
 
 def _check_free_running(r, scene):
     B = len(r["base"])
     assert (r["flags"] == 0).all(), r["flags"]
-    ok = (r["base"] < 1e-4) & (r["arm"] < 1e-4)
-    print(f"   inside 1e-4 over the whole rollout: {int(ok.sum())} / {B}")
+    # the verdict is over EVERY coordinate: north_star says "per-env qpos ... match", and in the kitchens most of qpos is objects / fixture parts
+    ok = (r["base"] < 1e-4) & (r["arm"] < 1e-4) & (r["obj"] < OBJ_BAND)
+    print(f"   inside 1e-4 over the whole rollout (robot and objects): {int(ok.sum())} / {B}; robot alone: {int(((r['base'] < 1e-4) & (r['arm'] < 1e-4)).sum())} / {B}")
     dep = r["departures"]
     assert set(dep) == {b for b in range(B) if not ok[b]}
     for b in sorted(dep):
@@ -69,11 +72,13 @@ def _check_free_running(r, scene):
         # different rollouts (MPR's portal noise on cylinder rims seeds it, tools/parity_probe.py) -- as two MuJoCo builds would be.
         h = r["hist"][:5]
         early = np.max(np.stack([np.maximum(x[0], x[1]) for x in h]), 0)
-        print(f"   inside 1e-4 over the first 250 steps: {int((early < 1e-4).sum())} / {B}")
+        early_all = np.max(np.stack([np.maximum(np.maximum(x[0], x[1]), x[2]) for x in h]), 0)
+        print(f"   inside 1e-4 over the first 250 steps: robot {int((early < 1e-4).sum())} / {B}, robot and objects {int((early_all < 1e-4).sum())} / {B}")
         assert (early < 1e-4).mean() >= FLOOR_INSIDE_EARLY, early
-    assert ok.mean() >= FLOOR_INSIDE[scene], (ok.mean(), r["base"], r["arm"])
+        assert (early_all < 1e-4).mean() >= FLOOR_INSIDE_EARLY_ALL, early_all
+    assert ok.mean() >= FLOOR_INSIDE[scene], (ok.mean(), r["base"], r["arm"], r["obj"])
     if scene not in OBJECT_SCENES:
-        assert np.median(np.maximum(r["base"], r["arm"])) < 1e-4
+        assert np.median(np.maximum(np.maximum(r["base"], r["arm"]), r["obj"])) < 1e-4
 
 
 def _check_contacts():
@@ -90,17 +95,25 @@ def _check_contacts():
 
 
 def _check_events(rel, events):
-    print(f"\none-step relative qacc error over {len(rel)} env-steps: p50 {np.percentile(rel, 50):.1e} p99 {np.percentile(rel, 99):.1e} "
-          f"max {rel.max():.1e}; events {len(events)}")
-    for ev in events:
+    S = rc.state_synchronised
+    ro, ob, sr, so = S.rel_robot, S.rel_obj, S.same_robot, S.same_obj
+    pc = lambda a: f"p50 {np.percentile(a, 50):.1e} p99 {np.percentile(a, 99):.1e} max {a.max():.1e}"
+    print(f"\none-step relative qacc error over {len(rel)} env-steps, robot dofs / object dofs each on their own scale: robot {pc(ro)}; objects {pc(ob)}; "
+          f"with the kernel's contact list handed to the oracle: robot {pc(sr)}; objects {pc(so)}; events {len(events)}")
+    gross = [ev for ev in events if ev["eps"] != "contact-point scatter"]
+    for ev in gross:
         print("   ", ev)
-    clean = rc.state_synchronised.clean
-    print(f"   on the {len(clean)} env-steps whose contact lists agree (same pairs, normals within 0.5 deg): p99 {np.percentile(clean, 99):.1e} max {clean.max():.1e}")
-    assert len(clean) > 0.9 * len(rel) and np.percentile(clean, 99) < rc.TYPICAL_TOL
+    clean, cr = S.clean, S.clean_robot
+    print(f"   on the {len(clean)} env-steps whose contact lists agree (same pairs, normals within 0.5 deg): robot p99 {np.percentile(cr, 99):.1e} max {cr.max():.1e}")
+    assert len(clean) > 0.9 * len(rel) and np.percentile(cr, 99) < rc.TYPICAL_TOL
+    # objects: tight on identical contacts (the dynamics), every step; raw (each side's own narrowphase) reported and bounded loosely -- the
+    # contact points of a cylinder standing on its rim are MPR's to within millimetres (rollout_common.state_synchronised)
+    assert np.percentile(so, 99) < rc.OBJ_TOL and np.percentile(sr, 99) < rc.TYPICAL_TOL, (pc(so), pc(sr))
+    assert np.percentile(ob, 99) < rc.RAW_OBJ_TOL, pc(ob)
     assert all(ev["flags"] == 0 for ev in events)
     unexplained = [ev for ev in events if not ev["explained"]]
     assert not unexplained, unexplained
-    assert len(events) <= 0.005 * len(rel) + 2
+    assert len(gross) <= 0.005 * len(rel) + 2
 
 
 @pytest.mark.parametrize("scene", SCENES)
@@ -116,7 +129,7 @@ def test_emul_random_ctrl_free_running(scene):
 def test_emul_state_synchronised_steps(scene):
     blob, model = _blob(scene)
     be = rc.EmulBackend(blob, 4)
-    rel, events = rc.state_synchronised(be, blob, model, 4, 5, seed=5)
+    rel, events = rc.state_synchronised(be, blob, model, 4, 5, seed=5, twin=True)   # (the kernel keeps manifolds by default: against the oracle's twin of that rule)
     _check_events(rel, events)
     _check_contacts()
 
@@ -141,7 +154,7 @@ def test_gpu_state_synchronised_steps(scene):
     """8 envs x 400 steps with the oracle's state uploaded before every step: per-step errors and explained events."""
     blob, model = _blob(scene)
     be = rc.HipBackend(scene, 8)
-    rel, events = rc.state_synchronised(be, blob, model, 8, 8, seed=3)
+    rel, events = rc.state_synchronised(be, blob, model, 8, 8, seed=3, twin=True)
     be.close()
     _check_events(rel, events)
     _check_contacts()
