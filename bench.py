@@ -87,21 +87,32 @@ def cpu_baseline(hold: int, seconds: float, solver: str):
     scene = os.path.join(models, "stretch_scene.smjb")          # scene.xml equivalent: table + 2 free objects
     if not os.path.exists(scene):
         scene = os.path.join(models, "stretch_kitchen_standin.smjb")
+    kitchen = os.path.join(models, "stretch_kitchen_robocasa.smjb")   # config 4's scene (the generated kitchen at Robocasa scale, 82 dofs)
     ncpu = usable_cores()
     from oracle import oracle as _o
 
     _o.lib()                      # make sure the oracle library is built before the workers start
     ctx = mp.get_context("spawn")   # the parent holds a HIP context: no fork
     single = {}
-    with ctx.Pool(3) as pool:   # C1-C3 single-thread rates, measured side by side on three otherwise idle cores
-        r = pool.map_async(_cpu_worker, [(empty, 1, hold, seconds / 2, solver, False), (empty, 2, hold, seconds / 2, solver, True),
-                                         (scene, 3, hold, seconds / 2, solver, False)]).get(timeout=4 * seconds + 120)
-    for key, (n, dt) in zip(("C1_empty_sensors_off", "C2_empty_lidar_imu_every_step", "C3_" + os.path.basename(scene)[:-5]), r):
+    jobs = [(empty, 1, hold, seconds / 2, solver, False), (empty, 2, hold, seconds / 2, solver, True), (scene, 3, hold, seconds / 2, solver, False)]
+    keys = ["C1_empty_sensors_off", "C2_empty_lidar_imu_every_step", "C3_" + os.path.basename(scene)[:-5]]
+    if os.path.exists(kitchen):
+        jobs.append((kitchen, 4, hold, seconds / 2, solver, False)); keys.append("C3_kitchen_robocasa")
+    with ctx.Pool(min(len(jobs), ncpu)) as pool:   # single-thread rates, measured side by side on otherwise idle cores
+        r = pool.map_async(_cpu_worker, jobs).get(timeout=4 * seconds + 120)
+    for key, (n, dt) in zip(keys, r):
         single[key] = {"value": n / dt, "unit": "env-steps/s", "steps": n}
     with ctx.Pool(ncpu) as pool:
         r = pool.map_async(_cpu_worker, [(empty, 100 + i, hold, seconds, solver, False) for i in range(ncpu)]).get(timeout=4 * seconds + 120)
     total = sum(n / dt for n, dt in r)
-    return dict(value=total, unit="env-steps/s", cores=ncpu, kind="port",
+    kit = None
+    if os.path.exists(kitchen):   # C4 on config 4's scene: the comparator of the kitchen figures (BASELINE.md section 3 asks for one per reported config)
+        with ctx.Pool(ncpu) as pool:
+            rk = pool.map_async(_cpu_worker, [(kitchen, 200 + i, hold, seconds / 2, solver, False) for i in range(ncpu)]).get(timeout=4 * seconds + 120)
+        kit = {"value": sum(n / dt for n, dt in rk), "unit": "env-steps/s", "cores": ncpu, "kind": "port",
+               "sample": f"C4 on the kitchen at Robocasa scale: {ncpu} independent oracle processes x {seconds / 2:.0f} s (1 env each, 82 dofs, random ctrl every {hold} steps, {solver}); "
+                         f"{sum(n for n, _ in rk)} steps in total; single thread: single_thread.C3_kitchen_robocasa"}
+    return dict(value=total, unit="env-steps/s", cores=ncpu, kind="port", kitchen_robocasa=kit,
                 sample=f"C4 whole-host aggregate: {ncpu} independent oracle processes, one per usable core ({os.cpu_count()} visible, cgroup quota / affinity allow {ncpu}), {seconds:.0f} s each of the bench "
                        f"workload (1 env, empty scene, random ctrl every {hold} steps, {solver}); {sum(n for n, _ in r)} steps in total. "
                        f"Stand-in fp64 CPU restatement, NOT MuJoCo.",
@@ -322,13 +333,155 @@ def _free_port() -> int:
     return p
 
 
+def shard_sizes(envs, rank, world, scaling):
+    """(envs of this rank, envs in total): strong = `envs` in total in contiguous shards (parallel.shard_range), weak = `envs` per rank."""
+    from stretch_mujoco_amd import parallel
+
+    if scaling == "strong":
+        lo_e, hi_e = parallel.shard_range(envs, rank, world)
+        return hi_e - lo_e, envs
+    return envs, envs * world
+
+
+def measure_one(args, rank, world, hooks, scaling):
+    """One measurement of the contract on this rank: settle, pre-roll, W warm-up steps, then EXACTLY K timed steps between two
+    barrier + synchronize brackets, max over ranks.  Returns everything the JSON line is made of.  Device and torch.distributed come in
+    through `hooks` so that the control flow (shards, brackets, max over ranks, gather, ranks_seen) runs on the CPU under gloo as well."""
+    import torch
+
+    B, B_total = shard_sizes(args.envs, rank, world, scaling)
+    sim = hooks.make_sim(B)
+    dev = hooks.device
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    lo = torch.tensor(sim.model["actuator_ctrlrange"][:, 0], dtype=torch.float32, device=dev).unsqueeze(1)
+    hi = torch.tensor(sim.model["actuator_ctrlrange"][:, 1], dtype=torch.float32, device=dev).unsqueeze(1)
+
+    def random_action():
+        sim.ctrl.copy_(lo + (hi - lo) * torch.rand(sim.nu, B, generator=gen, device=dev))
+
+    hold = max(1, args.hold)
+    all_events = []   # every smj_step_kernel launch of this process (what `rocprofv3 --stats` averages over)
+    phase = [0]       # steps since the last action change
+
+    def timed_step(k, tag):
+        e0, e1 = hooks.event(), hooks.event()
+        e0.record()
+        sim.step(k)
+        e1.record()
+        all_events.append((e0, e1, k, tag))
+        return e0, e1
+
+    def rollout(nsteps, tag, on_launch=None):
+        """nsteps of the random-action schedule, continuing it: a new action whenever `hold` steps have passed."""
+        done = 0
+        while done < nsteps:
+            if phase[0] == 0:
+                random_action()
+            k = min(hold - phase[0], nsteps - done)
+            ev = timed_step(k, tag)
+            if on_launch:
+                on_launch(ev, k)
+            phase[0] = (phase[0] + k) % hold
+            done += k
+
+    # settle at the home keyframe (SURVEY.md 8(d)), then into the steady state of the random-action rollout
+    sim.ctrl[:] = torch.tensor(sim.model["key_ctrl"][0, : sim.nu], dtype=torch.float32, device=dev).unsqueeze(1)
+    for _ in range(500 // hold):
+        timed_step(hold, "settle")
+    rollout(max(200, 4 * hold), "preroll")
+    rollout(args.warmup, "warmup")
+    returns = torch.zeros(B, device=dev)
+
+    def barrier():
+        hooks.sync()
+        hooks.barrier()
+        hooks.sync()
+
+    # The timed region: EXACTLY K steps between two barrier + synchronize brackets, max over ranks.  A K below one action interval is a
+    # single launch of a few milliseconds -- one sample, which moved the figure by +-4 % from round to round -- so such a region is
+    # measured `reps` times (each repetition its own bracket of exactly K steps at the SAME phase of the action schedule: the untimed
+    # remainder of the action interval runs between two brackets, so the repetitions differ by their random actions only) and the MEDIAN
+    # repetition is reported -- its wall time AND its kernel time (one statistic for ms_per_step and kernel_ms_per_step); every
+    # repetition is listed in `timed_region_ms`.
+    reps = 3 if args.steps < hold else 1
+    samples, rep_events = [], []
+    for rep in range(reps):
+        if rep:
+            rollout((hold - args.steps) % hold, "between")
+        evs = []
+
+        def on_launch(ev, k, evs=evs):
+            evs.append((ev[0], ev[1], k))
+            returns.add_(sim.base_pose[0])   # synthetic per-env return: accumulated forward displacement
+
+        barrier()
+        t0 = time.perf_counter()
+        rollout(args.steps, "timed", on_launch)
+        barrier()
+        samples.append(hooks.max_over_ranks(time.perf_counter() - t0))
+        rep_events.append(evs)
+    pick = sorted(range(reps), key=lambda i: samples[i])[reps // 2]
+    dt, events = samples[pick], rep_events[pick]
+    all_returns, gather_path = hooks.gather(sim, returns)
+    f = sim.info[3]
+    flags = int(((f & 1).max() | (f & 2).max() | (f & 4).max() | (f & 8).max()).item())   # union of the sticky overflow / bad-state / time-out bits
+    flagged = float((f != 0).float().mean().item())
+    # bit 8 = a pipelined chunk gave up waiting: that env ran fewer steps than asked and the env-step count below would be wrong
+    if flags & 8 or int(sim.nstep.min().item()) != int(sim.nstep.max().item()):
+        raise SystemExit(f"bench.py: envs ran different step counts ({int(sim.nstep.min())}..{int(sim.nstep.max())}, flags {flags}): pipeline time-out, the measurement is void")
+    kern_ms = sum(a.elapsed_time(b) for a, b, _ in events)
+    kern_steps = sum(k for _, _, k in events)
+    return dict(sim=sim, B=B, B_total=B_total, hold=hold, dt=dt, samples=samples, reps=reps, value=float(B_total) * args.steps / dt, events=events, all_events=all_events,
+                kern_ms=kern_ms, kern_steps=kern_steps, flags=flags, flagged=flagged, all_returns=all_returns, gather_path=gather_path, returns=returns,
+                random_action=random_action, scaling=scaling)
+
+
+def measure_ranks(args, rank, world, hooks):
+    """The headline measurement (--scaling, default strong: BASELINE.json's 4096 envs IN TOTAL) and, at N > 1, the other scaling mode
+    beside it (key `other_scaling` of the result: weak = --envs per GPU), measured back to back by the same ranks."""
+    m = measure_one(args, rank, world, hooks, args.scaling)
+    m["other_scaling"] = None
+    if world > 1:
+        other = "weak" if args.scaling == "strong" else "strong"
+        o = measure_one(args, rank, world, hooks, other)
+        o["sim"].stop()
+        m["other_scaling"] = {"scaling": other, "value": o["value"], "unit": "env-steps/s", "ms_per_step": o["dt"] * 1e3 / args.steps, "envs_total": o["B_total"],
+                              "envs_per_gpu": o["B"], "ranks_seen": int(o["all_returns"].numel()) // max(1, int(o["returns"].numel())),
+                              "timed_region_ms": [round(x * 1e3, 3) for x in o["samples"]], "overflow_flags": o["flags"]}
+    return m
+
+
+def line_head(args, world, m):
+    """The contract's keys of the JSON line (everything but the roofline / baselines / other configs), from a measure_ranks result."""
+    B, B_total, hold = m["B"], m["B_total"], m["hold"]
+    all_returns, returns = m["all_returns"], m["returns"]
+    return {
+        "metric": "env-steps/sec (whole node), 4096 parallel Stretch envs" + (" per MI355X" if args.scaling == "weak" else " in total"),
+        "value": m["value"], "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": m["dt"] * 1e3 / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{B_total} parallel Stretch envs ({B} per GPU), stretch.xml + ground plane (empty scene), "
+                               f"physics-only, random ctrl in ctrlrange every {hold} steps (steady state: 500 settle + 200 "
+                               f"untimed random-action steps precede warm-up), {args.solver} solver "
+                               f"(iterations<=100, tol 1e-8), elliptic cones impratio 20, implicitfast, dt=0.002",
+                   "solver": args.solver, "envs_total": B_total,
+                   "envs_per_gpu": B, "steps_per_action": hold, "parallelism": f"env-sharded x{world}",
+                   "returns_gathered": int(all_returns.numel()), "ranks_seen": int(all_returns.numel()) // max(1, int(returns.numel())),
+                   "returns_gather_path": m["gather_path"], "timed_region_ms": [round(x * 1e3, 3) for x in m["samples"]],
+                   "timed_region_reported": "median (wall and kernel time of the same repetition)" if m["reps"] > 1 else "the one bracket",
+                   "overflow_flags": m["flags"], "envs_over_capacity_since_reset": m["flagged"]},
+        **({m["other_scaling"]["scaling"]: m["other_scaling"]} if m.get("other_scaling") else {}),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak: --envs per GPU; strong: --envs in total (BASELINE.json: 4096 envs at 1/2/4/8 GPUs)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="strong (default): --envs in total, split over the ranks -- BASELINE.json's metric is 4096 envs at 1 / 2 / 4 / 8 GPUs; at N > 1 the same "
+                         "line also carries the weak figure (--envs per GPU) under `weak`.  weak: --envs per GPU is `value`")
     ap.add_argument("--envs", "--envs-per-gpu", dest="envs", type=int, default=4096)
     ap.add_argument("--hold", type=int, default=50, help="physics steps per random action (and per launch)")
     ap.add_argument("--solver", choices=["newton", "pgs"], default="newton",
@@ -369,101 +522,47 @@ def main():
     from stretch_mujoco_amd import StretchBatchSimulator
     from stretch_mujoco_amd import parallel
 
-    if args.scaling == "strong":
-        lo_e, hi_e = parallel.shard_range(args.envs, rank, world)
-        B = hi_e - lo_e
-    else:
-        B = args.envs
-    B_total = args.envs if args.scaling == "strong" else args.envs * world
-    sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver=args.solver)
-    sim.start(home=False)
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    lo = torch.tensor(sim.model["actuator_ctrlrange"][:, 0], dtype=torch.float32, device=dev).unsqueeze(1)
-    hi = torch.tensor(sim.model["actuator_ctrlrange"][:, 1], dtype=torch.float32, device=dev).unsqueeze(1)
+    class Hooks:   # what the N-rank control flow needs from the device and from torch.distributed (tests/test_bench_ranks.py swaps in CPU stand-ins)
+        device = dev
 
-    def random_action():
-        sim.ctrl.copy_(lo + (hi - lo) * torch.rand(sim.nu, B, generator=gen, device=dev))
+        @staticmethod
+        def make_sim(B):
+            sim = StretchBatchSimulator(num_envs=B, device=str(dev), solver=args.solver)
+            sim.start(home=False)
+            return sim
 
-    hold = max(1, args.hold)
-    all_events = []   # every smj_step_kernel launch of this process (what `rocprofv3 --stats` averages over)
-    phase = [0]       # steps since the last action change
+        @staticmethod
+        def sync():
+            torch.cuda.synchronize(dev)
 
-    def timed_step(k, tag):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        sim.step(k)
-        e1.record()
-        all_events.append((e0, e1, k, tag))
-        return e0, e1
+        @staticmethod
+        def event():
+            return torch.cuda.Event(enable_timing=True)
 
-    def rollout(nsteps, tag, on_launch=None):
-        """nsteps of the random-action schedule, continuing it: a new action whenever `hold` steps have passed."""
-        done = 0
-        while done < nsteps:
-            if phase[0] == 0:
-                random_action()
-            k = min(hold - phase[0], nsteps - done)
-            ev = timed_step(k, tag)
-            if on_launch:
-                on_launch(ev, k)
-            phase[0] = (phase[0] + k) % hold
-            done += k
+        @staticmethod
+        def barrier():
+            if dist_on:
+                dist.barrier()
 
-    # settle at the home keyframe (SURVEY.md 8(d)), then into the steady state of the random-action rollout
-    sim.ctrl[:] = torch.tensor(sim.model["key_ctrl"][0, : sim.nu], dtype=torch.float32, device=dev).unsqueeze(1)
-    for _ in range(500 // hold):
-        timed_step(hold, "settle")
-    rollout(max(200, 4 * hold), "preroll")
-    rollout(args.warmup, "warmup")
-    returns = torch.zeros(B, device=dev)
-    events = []
+        @staticmethod
+        def max_over_ranks(x):
+            if not dist_on:
+                return x
+            t = torch.tensor([x], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if dist_on:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        @staticmethod
+        def gather(sim, returns):
+            try:   # RCCL all-gather of per-env returns inside libsmj.so (the only collective of the path); after the timed region
+                return parallel.gather_returns_native(sim, returns)
+            except Exception as e:   # never lose the measured line to the gather: fall back to torch.distributed's and say so
+                return parallel.gather_returns(returns), f"torch.distributed all_gather_into_tensor (the library's RCCL path failed: {type(e).__name__}: {e})"
 
-    def on_launch(ev, k):
-        events.append((ev[0], ev[1], k))
-        returns.add_(sim.base_pose[0])   # synthetic per-env return: accumulated forward displacement
-
-    # The timed region: EXACTLY K steps between two barrier + synchronize brackets, max over ranks.  A K below one action interval is a
-    # single launch of a few milliseconds -- one sample, which moved the figure by +-4 % from round to round -- so such a region is
-    # measured `reps` times (each repetition its own bracket of exactly K steps at the SAME phase of the action schedule: the untimed
-    # remainder of the action interval runs between two brackets, so the repetitions differ by their random actions only) and the MEDIAN
-    # repetition is reported; every repetition is listed in `timed_region_ms`.
-    reps = 3 if args.steps < hold else 1
-    samples = []
-    for rep in range(reps):
-        if rep:
-            rollout((hold - args.steps) % hold, "between")
-        barrier()
-        t0 = time.perf_counter()
-        rollout(args.steps, "timed", on_launch)
-        barrier()
-        dt = time.perf_counter() - t0
-        if dist_on:
-            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax.item())
-        samples.append(dt)
-    dt = sorted(samples)[len(samples) // 2]
-    try:   # RCCL all-gather of per-env returns inside libsmj.so (the only collective of the path); after the timed region
-        all_returns, gather_path = parallel.gather_returns_native(sim, returns)
-    except Exception as e:   # never lose the measured line to the gather: fall back to torch.distributed's and say so
-        all_returns = parallel.gather_returns(returns)
-        gather_path = f"torch.distributed all_gather_into_tensor (the library's RCCL path failed: {type(e).__name__}: {e})"
-    f = sim.info[3]
-    flags = int(((f & 1).max() | (f & 2).max() | (f & 4).max() | (f & 8).max()).item())   # union of the sticky overflow / bad-state / time-out bits
-    flagged = float((f != 0).float().mean().item())
-    # bit 8 = a pipelined chunk gave up waiting: that env ran fewer steps than asked and the env-step count below would be wrong
-    if flags & 8 or int(sim.nstep.min().item()) != int(sim.nstep.max().item()):
-        raise SystemExit(f"bench.py: envs ran different step counts ({int(sim.nstep.min())}..{int(sim.nstep.max())}, flags {flags}): pipeline time-out, the measurement is void")
-    kern_ms = sum(a.elapsed_time(b) for a, b, _ in events)
-    kern_steps = sum(k for _, _, k in events)
-    total_env_steps = float(B_total) * args.steps
-    value = total_env_steps / dt
+    m = measure_ranks(args, rank, world, Hooks)
+    sim, B, B_total, hold, dt, samples, reps, value = m["sim"], m["B"], m["B_total"], m["hold"], m["dt"], m["samples"], m["reps"], m["value"]
+    events, all_events, kern_ms, kern_steps, flags, flagged = m["events"], m["all_events"], m["kern_ms"], m["kern_steps"], m["flags"], m["flagged"]
+    all_returns, gather_path, returns = m["all_returns"], m["gather_path"], m["returns"]
     if rank == 0:
         # roofline of the dominant kernel: algorithmic bytes of the timed launches / their summed duration (HIP events on the
         # launch stream), i.e. 672 B x envs x steps-per-launch / average launch duration
@@ -481,19 +580,7 @@ def main():
                 flops = json.load(fh)
         launches = [{"tag": tag, "steps": k, "ms": round(a.elapsed_time(b), 3)} for a, b, k, tag in all_events]
         out = {
-            "metric": "env-steps/sec (whole node), 4096 parallel Stretch envs" + (" per MI355X" if args.scaling == "weak" else " in total"),
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{B_total} parallel Stretch envs ({B} per GPU), stretch.xml + ground plane (empty scene), "
-                                   f"physics-only, random ctrl in ctrlrange every {hold} steps (steady state: 500 settle + 200 "
-                                   f"untimed random-action steps precede warm-up), {args.solver} solver "
-                                   f"(iterations<=100, tol 1e-8), elliptic cones impratio 20, implicitfast, dt=0.002",
-                       "solver": args.solver, "envs_total": B_total,
-                       "envs_per_gpu": B, "steps_per_action": hold, "parallelism": f"env-sharded x{world}",
-                       "returns_gathered": int(all_returns.numel()), "ranks_seen": int(all_returns.numel()) // max(1, int(returns.numel())),
-                       "returns_gather_path": gather_path, "timed_region_ms": [round(x * 1e3, 3) for x in samples], "timed_region_reported": "median" if reps > 1 else "the one bracket",
-                       "overflow_flags": flags, "envs_over_capacity_since_reset": flagged},
+            **line_head(args, world, m),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on an earlier run "
@@ -514,6 +601,7 @@ def main():
             other = "pgs" if args.solver == "newton" else "newton"
             sim.set_option("solver", {"pgs": 0, "newton": 2}[other])
             n2 = 300   # six launches whatever --steps is: two made the figure swing by 5 %
+            random_action = m["random_action"]
             random_action(); sim.step(hold)
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
@@ -530,11 +618,28 @@ def main():
                                            "constraint rows / contacts since the reset (flags are sticky: the Newton phase before contributes none)"}
         import __graft_entry__ as _ge
         out["parity_oracle"] = _ge.mujoco_status()
+        oc = cb = None
         if not args.no_extra and world == 1:
             sim.stop()
-            out["other_configs"] = other_configs(B, dev, hold, args.solver)
+            oc = other_configs(B, dev, hold, args.solver)
         if not args.no_cpu_baseline and world == 1:   # the contract: rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(hold, args.cpu_seconds, args.solver)
+            cb = cpu_baseline(hold, args.cpu_seconds, args.solver)
+        if oc and oc.get("stretch_kitchen_robocasa_physics"):
+            # config 4 -- the configuration north_star's target sentence is quoted on -- as a top-level key ahead of the long blocks, so that a
+            # truncating reader keeps it: 4096 kitchens on this one GPU under the model's own solver and under PGS, their rooflines and flags,
+            # the per-rank shares of 4096 kitchens in total, and the CPU comparator on the same scene
+            kn, kp = oc["stretch_kitchen_robocasa_physics"], oc.get("stretch_kitchen_robocasa_physics_pgs")
+            out["config4"] = {"workload": f"{B} parallel Stretch envs in the generated kitchen at Robocasa scale (44 fixture bodies, 307 collision geoms, 8 articulated parts, 8 free objects: "
+                                          f"82 dofs), physics only, random ctrl every {hold} steps, 1 MI355X; Robocasa itself is unavailable here (stand-in, DESIGN.md section 1)",
+                              "newton": {k: kn.get(k) for k in ("value", "unit", "overflow_flags", "envs_flagged", "roofline", "kernel_variant")},
+                              "pgs": {k: kp.get(k) for k in ("value", "unit", "overflow_flags", "envs_flagged", "sweeps_last_step", "roofline")} if kp else None,
+                              "rank_share_of_4096_in_total": oc.get("kitchen_rank_share", {}).get("envs_per_rank", {}).get("stretch_kitchen_robocasa"),
+                              "cpu_baseline": {"aggregate": cb.get("kitchen_robocasa"), "single_thread": cb.get("single_thread", {}).get("C3_kitchen_robocasa")} if cb else None,
+                              "note": "delivered under Newton, the model's own solver (stretch.xml names none: MuJoCo's default); PGS, which north_star names, is the slower option (DESIGN.md section 7)"}
+        if oc:
+            out["other_configs"] = oc
+        if cb:
+            out["cpu_baseline"] = cb
         print(json.dumps(out))
     sim.stop()
     if dist_on:

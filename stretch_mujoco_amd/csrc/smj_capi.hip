@@ -54,6 +54,7 @@ struct smj_ctx {
   int pipeline_big = 1;        // pipelined dispatch for the two-envs-per-CU builds of the big variant too (option "pipeline_big")
   int pipeline = 5;            // chunk length of the pipelined dispatch (DevState::pipe_len; 0 = one workgroup per env for the whole launch)
   bool pollers_always = false; // option "pollers" < 0: send the pollers with every launch (tests)
+  bool prof_warned = false;    // the one-time warning of smj_step: profiling slot bound, PGS kernel without counters
   int pollers = 2;             // tall-variant workgroups that finish parked envs beside the standard kernel (0: the sweep does it all)
   int* progress = nullptr;     // [B] progress, [B] done_steps, [SMJ_SCHED_WORDS] sched (DevState)
   size_t redo_cap = 0;         // entries the escalation list holds
@@ -609,11 +610,13 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
     // (csrc/Makefile bigprof) the base name is the profiling copy with BOTH solvers: a PGS launch with the profiling slot bound tries it
     // first and falls back to the twin when the base build refuses the solver (its launcher returns before launching anything).
     typedef int (*Launch)(const DevModel&, const DevState&, int, unsigned, hipStream_t);
+    bool prof_dropped = false;
     auto by_solver = [&](Launch base, Launch twin) -> int {
       if (c->model.solver == 2) return base(c->model, st, k, fl, sm);
       if (st.prof) {
         const int r = base(c->model, st, k, fl, sm);
-        if (r != (int)hipErrorInvalidValue) return r;
+        if (r != SMJ_LAUNCH_REFUSED_SOLVER) return r;
+        prof_dropped = true;   // a product build: its base kernel carries Newton only, the PGS twin has no cycle counters compiled in
       }
       return twin(c->model, st, k, fl, sm);
     };
@@ -626,6 +629,11 @@ int smj_step(smj_ctx* c, int nsteps, unsigned read_flags, void* stream) {
             : c->variant == 1 ? by_solver(smj_launch_step_mid, smj_launch_step_midp)
             : st.prof         ? smj_launch_step_prof(c->model, st, k, fl, sm)
                               : by_solver(smj_launch_step, smj_launch_step_pgs);
+    if (lrc == SMJ_LAUNCH_REFUSED_SOLVER) return fail(c, -2, "no kernel of this build carries solver %d for variant %d", c->model.solver, c->variant);
+    if (prof_dropped && !c->prof_warned) {   // (once: the caller asked for stage cycles and gets zeros -- say so instead of returning them silently)
+      c->prof_warned = true;
+      fprintf(stderr, "libsmj: the profiling slot is bound but the PGS kernel of this build has no cycle counters (build `make bigprof` and load it through SMJ_LIB_PATH); the counters stay zero\n");
+    }
     if (poll) HIPCHK(c, hipStreamWaitEvent(sm, c->ev_join, 0));
     if (!lrc && esc) {
       // the sweep: whatever is left of the envs that ran out of constraint rows / contact slots (parked at the start of the

@@ -1,6 +1,9 @@
 // Launchers of the gfx950 kernels (smj_kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+// a launcher's answer when its build does not carry the solver asked for (nothing was launched): its own value, not a HIP error code --
+// a genuine hipErrorInvalidValue of a launch (a bad LDS size ...) must not be mistaken for it (smj_capi.hip by_solver)
+#define SMJ_LAUNCH_REFUSED_SOLVER (-7001)
 #include <stdint.h>
 
 #include "smj_model.h"

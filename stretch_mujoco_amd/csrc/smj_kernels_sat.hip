@@ -4,18 +4,20 @@
 // 79 KB of LDS per env, two envs per CU.  The kernel of kitchens: the reference's scene.xml (table + 2 free objects), the kitchen
 // stand-ins with free objects, exported Robocasa kitchens (robocasa_gen.py:129-239).  Larger models / steps: smj_kernels_sat32.hip.
 #define SMJ_SAT 16
+#ifndef SMJ_SAT_ROWS
 #define SMJ_SAT_ROWS 208
+#endif
 #define SMJ_SAT_CONTACTS 56
+#ifndef SMJ_SAT_DENSE
 #define SMJ_SAT_DENSE 96
+#endif
 #define SMJ_SAT_ITEMS 16
 #define SMJ_SAT_EXT 3
 #define SMJ_VARIANT_TAG sat
 #ifndef SMJ_PROFILING
 #define SMJ_PROFILING 0
 #endif
-#if !SMJ_PROFILING
-#define SMJ_ONLY_NEWTON 1   // the product build of this translation unit carries the Newton solver only (smj_step_impl.h newton()): PGS launches go to smj_kernels_satp.hip (two wavefronts per env) or smj_kernels_sat1.hip (one); the profiling build keeps both
-#endif
+#define SMJ_ONLY_NEWTON 1   // the product build of this translation unit carries the Newton solver only (smj_step_impl.h newton()): PGS launches go to smj_kernels_satp.hip (two wavefronts per env) or smj_kernels_sat1.hip (one); the profiling build (csrc/Makefile bigprof) likewise -- PGS stage cycles come from the profiling copy of smj_kernels_sat1.hip
 #include "smj_step_tu.h"
 
 void smj_sat_caps(int* nvp, int* nbp, int* nent, int* nefc, int* ncon, int* debug_floats, int* nsat) {

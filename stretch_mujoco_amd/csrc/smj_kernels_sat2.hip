@@ -14,9 +14,13 @@
 #define SMJ_TWO_WAVES 1
 #define SMJ_ONLY_NEWTON 1
 #define SMJ_SAT 16
+#ifndef SMJ_SAT_ROWS
 #define SMJ_SAT_ROWS 208
+#endif
 #define SMJ_SAT_CONTACTS 56
+#ifndef SMJ_SAT_DENSE
 #define SMJ_SAT_DENSE 96
+#endif
 #define SMJ_SAT_ITEMS 16
 #define SMJ_SAT_EXT 3
 #define SMJ_VARIANT_TAG sat2

@@ -110,7 +110,9 @@ struct Smem {
       int contotal;
 #endif
     } c;
-#if NSAT > 0
+#if NSAT > 0 && defined(SMJ_ONLY_NEWTON)
+    float pa[4];                            // (a Newton-only build keeps no A: the 18 KB of the triangle are what lets smj_kernels_sat.hip / _sat2.hip carry 112 dense rows in half a CU's LDS)
+#elif NSAT > 0
     float pa[NEFC_P * (NEFC_P + 1) / 2];   // PGS: A of the dense system, packed lower triangle
 #endif
     struct {                // plane narrowphase staging: contacts of the pair owned by each lane, emitted in pair order
@@ -371,6 +373,7 @@ struct StepKernel {
   // the shared counter Smem::u.c.contotal), `rev` in the second wavefront, whose contact k sits in slot NCON - 1 - k until the first
   // one appends them to its own
   bool split_on = false, rev = false;
+  bool serial_redo = false;   // run(): the collision stage's second go at a step whose contact list overflowed
 
   SMJ_DEV StepKernel(const DevModel& M_, const DevState& S_, Smem& s_, int env_) : M(M_), S(S_), s(s_), env(env_) {}
 
@@ -2742,6 +2745,12 @@ struct StepKernel {
     // The env's second wavefront works the moving-moving pairs (collide_helper -> collision_moving) while this one works the pairs with
     // the static world: two barriers per step.  Its contacts come back in the slots NCON - 1, NCON - 2, ... and are appended here,
     // behind the static ones: the one-wavefront build's list, contact for contact.
+    if (serial_redo) {   // the second go at a step whose contact list overflowed (run()): this wavefront alone, pairs in table order
+      collision_static(nullptr, false);
+      collision_moving(nullptr, false);
+      SYNC();
+      return;
+    }
     LANES {
       if (lane == 0) { s.mbox[0] = W2_COLLIDE; s.mbox[1] = env; s.u.c.contotal = ncon; }
     }
@@ -4861,7 +4870,28 @@ struct StepKernel {
       TICK(SMJ_PROF_FACTOR)
 
       collision();
-      collision_convex(pc, prof);
+      {
+        const int ncon_planes = ncon;
+        const unsigned flags_planes = flags;
+        collision_convex(pc, prof);
+        if (((flags & ~flags_planes) & SMJ_FLAG_CON_OVERFLOW) && (SMJ_SPLIT_COLLIDE || (S.mcache && M.manifold_cache))) {
+          // More contacts than slots.  With two wavefronts side by side WHICH claims failed depends on their timing (that the list
+          // overflowed does not: the total is what it is), and which manifolds were kept (mcache) up to the overflow depends on the
+          // same.  So the stage is run again by this wavefront alone, pairs in table order -- planes, static world, moving pairs: the
+          // truncated list is the same on every run and in the one- and two-wavefront builds -- after the env's kept manifolds have
+          // been dropped; the one-wavefront builds do the same, so that the two stay bit for bit equal through such a step (which
+          // the larger build may still finish unflagged: 57 .. 64 contacts).  Rare: <= 0.03 % of the kitchen's env-steps.
+          if (S.mcache) {
+            LANES { if (lane < SMJ_MC_SLOTS) S.mcache[((size_t)env * SMJ_MC_SLOTS + lane) * SMJ_MC_WORDS] = 0.f; }
+          }
+          SYNC();
+          ncon = ncon_planes;
+          flags = flags_planes;
+          serial_redo = true;
+          collision_convex(nullptr, false);
+          serial_redo = false;
+        }
+      }
       if (last) dump_contacts();
       TICK(SMJ_PROF_COLLISION)
 #if NSAT > 0

@@ -231,9 +231,9 @@ __global__ __launch_bounds__(SMJ_WG_THREADS) void SMJ_WORKER_KERNEL(const DevMod
 int SMJ_LAUNCH_STEP(const DevModel& m_in, const DevState& s, int nsteps, unsigned read_flags, hipStream_t stream) {
   // a build that carries one solver only (smj_step_impl.h newton()) refuses a launch for the other instead of running its own
 #if defined(SMJ_ONLY_NEWTON)
-  if (m_in.solver != 2) return (int)hipErrorInvalidValue;
+  if (m_in.solver != 2) return SMJ_LAUNCH_REFUSED_SOLVER;
 #elif defined(SMJ_ONLY_PGS)
-  if (m_in.solver == 2) return (int)hipErrorInvalidValue;
+  if (m_in.solver == 2) return SMJ_LAUNCH_REFUSED_SOLVER;
 #endif
   DevModel m = m_in;
   size_t lds = smj_lds_bytes(m.solver != 2);

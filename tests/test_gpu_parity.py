@@ -464,6 +464,99 @@ def test_full_batch_properties(B, solver):
     sim.stop(); sim2.stop()
 
 
+@pytest.mark.parametrize("scene,solver", [("stretch_empty", "pgs"), ("stretch_kitchen4_sat", "pgs"), ("stretch_kitchen_robocasa", "newton")])
+def test_reset_leaves_nothing_of_the_previous_episode(scene, solver):
+    """smj_reset is mj_resetData: what the library keeps between steps BESIDE the state -- the PGS second start (the previous step's
+    forces, option pgs_dual_warmstart, on by default), the kept contact manifolds and separating directions -- must not outlive the
+    episode.  The same 60 steps after a reset, once on a fresh simulator and once after 150 steps of random actions: bit for
+    bit the same states, row / contact / iteration counts, for all envs and for a masked subset."""
+    from stretch_mujoco_amd import StretchBatchSimulator
+
+    B = 64
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+
+    def episode(sim, ids=None):
+        sim.reset(ids)
+        sim.ctrl[:] = torch.tensor(np.asarray(sim.model["key_ctrl"])[0, : sim.nu], dtype=torch.float32, device=sim.device).unsqueeze(1)
+        sim.step(60)
+        torch.cuda.synchronize()
+        return sim.qpos.clone(), sim.qvel.clone(), sim.qacc_warmstart.clone(), sim.info[:3].clone()
+
+    fresh = StretchBatchSimulator(num_envs=B, device="cuda:0", scene=scene, solver=solver)
+    fresh.start(home=False)
+    ref = episode(fresh)
+    fresh.stop()
+    used = StretchBatchSimulator(num_envs=B, device="cuda:0", scene=scene, solver=solver)
+    used.start(home=False)
+    cr = torch.tensor(np.asarray(used.model["actuator_ctrlrange"]), dtype=torch.float32, device=used.device)
+    for _ in range(3):
+        used.ctrl[:] = cr[:, :1] + (cr[:, 1:] - cr[:, :1]) * torch.rand(used.nu, B, generator=g, device=used.device)
+        used.step(50)
+    again = episode(used)
+    for a, b in zip(ref, again):
+        assert torch.equal(a, b)
+    # a masked reset: the reset envs repeat the reference episode
+    for _ in range(2):
+        used.ctrl[:] = cr[:, :1] + (cr[:, 1:] - cr[:, :1]) * torch.rand(used.nu, B, generator=g, device=used.device)
+        used.step(50)
+    ids = [3, 17, 40, 63]
+    used.reset(ids)
+    used.ctrl[:, ids] = torch.tensor(np.asarray(used.model["key_ctrl"])[0, : used.nu], dtype=torch.float32, device=used.device).unsqueeze(1)
+    used.step(60)
+    torch.cuda.synchronize()
+    assert torch.equal(used.qpos[:, ids], ref[0][:, ids]) and torch.equal(used.qvel[:, ids], ref[1][:, ids])
+    used.stop()
+
+
+def test_config3_full_batch_4096_envs_with_lidar_and_imu():
+    """BASELINE.json config 3 at its full size: 4096 envs, joint readout + gyro / accelerometer + the 360-ray lidar evaluated on every
+    step of a 33-step stretch under heterogeneous random actions (15 Hz sim-time).  Properties that do not depend on the size: a
+    permutation of the envs permutes every readout bitwise; ranges are -1 (no return) or within the 10 m cutoff; the IMU of a robot
+    standing on its wheels reads gravity; and six envs picked across the batch agree with the oracle's sensors evaluated on the state
+    the device reached (lidar 1e-3 m with at most 2 silhouette rays, gyro / accelerometer to 1e-3 / 2e-2)."""
+    from stretch_mujoco_amd import StretchSensors
+
+    B = 4096
+    g = torch.Generator(device="cuda:0").manual_seed(21)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(4)).to("cuda:0")
+    outs = []
+    for p in (None, perm):
+        sim = _sim(B, sensors_to_use=StretchSensors.all(), solver="newton")
+        if p is None:
+            lo = torch.tensor(sim.model["actuator_ctrlrange"][:, 0], dtype=torch.float32, device=sim.device).unsqueeze(1)
+            hi = torch.tensor(sim.model["actuator_ctrlrange"][:, 1], dtype=torch.float32, device=sim.device).unsqueeze(1)
+            ctrl = lo + (hi - lo) * torch.rand(10, B, generator=g, device=sim.device)
+            ctrl[0:2] *= 0.3                      # (wheels: the robots stay on their wheels, the IMU check below means something)
+            yaw = 6.28 * torch.rand(B, generator=g, device=sim.device)
+        q0 = torch.tensor(home_qpos(sim.model["qpos0"]), dtype=torch.float32, device=sim.device).unsqueeze(1).repeat(1, B)
+        q0[3] = torch.cos(yaw / 2); q0[6] = torch.sin(yaw / 2)
+        sim.qpos[:] = q0 if p is None else q0[:, p]
+        sim.ctrl.copy_(ctrl if p is None else ctrl[:, p])
+        sim.step(200)
+        for _ in range(32):
+            sim.step(1)                           # sensors evaluated by every one of these launches
+        state = (sim.qpos.clone(), sim.qvel.clone(), sim.qacc_warmstart.clone())
+        sim.step(1)
+        torch.cuda.synchronize()
+        sd = sim.pull_sensor_data()
+        outs.append((sd.lidar.clone(), sd.base_gyro.clone(), sd.base_imu.clone(), sim.actuator_length.clone(), sim.info[3].clone(), state, sim._blob, ctrl))
+        sim.stop()
+    (L, gy, ac, al, fl, state, blob, ctrl), (L2, gy2, ac2, al2, _, _, _, _) = outs
+    assert int((fl != 0).sum()) == 0
+    assert torch.equal(L2, L[perm]) and torch.equal(gy2, gy[perm]) and torch.equal(ac2, ac[perm]) and torch.equal(al2, al[:, perm])
+    assert bool(torch.isfinite(L).all()) and bool(((L == -1) | ((L >= 0) & (L <= 10.0))).all())
+    assert float((ac.norm(dim=1) - 9.81).abs().median()) < 0.5
+    for e in (0, 1, 777, 2048, 3333, 4095):
+        o = Oracle(blob); o.set_option("solver", 2)
+        o.arr("qpos")[:] = state[0][:, e].cpu().numpy(); o.arr("qvel")[:] = state[1][:, e].cpu().numpy(); o.arr("qacc_warmstart")[:] = state[2][:, e].cpu().numpy()
+        o.arr("ctrl")[:] = ctrl[:, e].cpu().numpy()
+        o.forward(); o.sensors(True)          # (mj_step evaluates the sensors in its forward pass: on the state the step starts from)
+        ref = o.arr("lidar")
+        bad = np.abs(L[e].cpu().numpy() - ref) > 1e-3
+        assert bad.sum() <= 2, (e, int(bad.sum()))
+        assert np.abs(gy[e].cpu().numpy() - o.arr("gyro")).max() < 1e-3 and np.abs(ac[e].cpu().numpy() - o.arr("accel")).max() < 2e-2, e
+
+
 def test_lidar_floor_and_moving_meshes_vs_oracle():
     """Lidar kernel (launched by smj_step when SMJ_READ_LIDAR is set) against the oracle on poses where the scan meets the
     floor (base pitched) and the robot's own moving meshes (lift lowered into the scan plane).  Range tolerance 1e-3 m;

@@ -10,7 +10,10 @@ sys.path.insert(0, ".")
 from stretch_mujoco_amd import StretchBatchSimulator  # noqa: E402
 
 
-def main(B=4096, steps=20000, scene="stretch_empty", solver="newton", options=None):
+def main(B=4096, steps=20000, scene="stretch_empty", solver="newton", options=None, capture=None, capture_z=0.35, capture_max=12):
+    """capture: path of an .npz that receives, for the first `capture_max` envs whose base rises above capture_z, the env's state and
+    ctrl at the START of the launch in which it happens and of the launch before (so the CPU oracle / the lane emulator can run the same
+    100 steps: is the robot thrown by the physics or by the kernel?)."""
     sim = StretchBatchSimulator(num_envs=B, device="cuda:0", solver=solver, scene=scene)
     sim.start(home=True)
     for k_, v_ in (options or {}).items():
@@ -26,10 +29,22 @@ def main(B=4096, steps=20000, scene="stretch_empty", solver="newton", options=No
     ever = torch.zeros(B, dtype=torch.int32, device=dev)
     capped = 0   # launches x envs whose last step's solver ended at the iteration cap
     itmax = int(sim.model.get('opt_iterations', [100])[0]) if hasattr(sim.model, 'get') else 100
+    caps, seen, prev = [], set(), None
     for k in range(steps // 50):
         sim.ctrl.copy_(lo + (hi - lo) * torch.rand(sim.nu, B, generator=g, device=dev))
         sim.info[3].zero_()          # flags are sticky: clear them to count per launch
+        if capture:
+            cur = (sim.qpos.clone(), sim.qvel.clone(), sim.qacc_warmstart.clone(), sim.ctrl.clone())
         sim.step(50)
+        if capture:
+            high = torch.nonzero(sim.qpos[2] > capture_z).flatten().tolist()
+            for e_ in high:
+                if e_ not in seen and len(caps) < capture_max and prev is not None:
+                    seen.add(e_)
+                    caps.append(dict(env=e_, launch=k, flags=int(sim.info[3, e_]), z_after=float(sim.qpos[2, e_]),
+                                     **{f"{nm}{j}": t[:, e_].cpu().numpy() for j, st in enumerate((prev, cur)) for nm, t in zip(("qpos", "qvel", "warm", "ctrl"), st)}))
+                    print(f"  captured env {e_} at launch {k}: base z {float(sim.qpos[2, e_]):.3f}, flags {hex(int(sim.info[3, e_]))}, contacts {int(sim.info[1, e_])}", flush=True)
+            prev = cur
         per_launch.append(float(((sim.info[3] & 1) != 0).float().mean()))
         ever |= sim.info[3]
         capped += int((sim.info[2] >= itmax).sum())
@@ -48,6 +63,8 @@ def main(B=4096, steps=20000, scene="stretch_empty", solver="newton", options=No
             worst_q = max(worst_q, float((q[3:7].norm(dim=0) - 1).abs().max()))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if capture:
+        np.savez(capture, n=len(caps), **{f"c{i}_{k_}": np.asarray(v_) for i, c in enumerate(caps) for k_, v_ in c.items()})
     fl = ever
     z = sim.qpos[2]
     up = 1 - 2 * (sim.qpos[4] ** 2 + sim.qpos[5] ** 2)
@@ -62,4 +79,5 @@ def main(B=4096, steps=20000, scene="stretch_empty", solver="newton", options=No
 
 if __name__ == "__main__":
     main(steps=int(sys.argv[1]) if len(sys.argv) > 1 else 20000, scene=sys.argv[2] if len(sys.argv) > 2 else "stretch_empty", solver=sys.argv[3] if len(sys.argv) > 3 else "newton",
-         options={a.split("=")[0]: float(a.split("=")[1]) for a in sys.argv[4:]})
+         options={a.split("=")[0]: float(a.split("=")[1]) for a in sys.argv[4:] if not a.startswith("capture=")},
+         capture=next((a.split("=", 1)[1] for a in sys.argv[4:] if a.startswith("capture=")), None))
