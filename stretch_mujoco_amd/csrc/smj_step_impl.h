@@ -1736,6 +1736,9 @@ struct StepKernel {
     const float d = fminf(dv4 - dot3(P[1].v, dir), fminf(dv4 - dot3(P[2].v, dir), dv4 - dot3(P[3].v, dir)));
     return ccd_eq(d, tol) || d < tol;
   }
+#ifndef SMJ_MPR_LOCAL
+#define SMJ_MPR_LOCAL 1     // (0: MPR on world coordinates, rounds 1-5; A/B builds of tools / tests only)
+#endif
 #ifndef SMJ_PORTAL_NORMAL
 #define SMJ_PORTAL_NORMAL 1   // (0: the witness' direction as it comes, the fp32 behaviour of rounds 1-5; A/B builds of tools / tests only)
 #endif
@@ -2233,7 +2236,8 @@ struct StepKernel {
   // penetration query repeated; new points farther than 1e-3 x min(rbound) from the earlier ones join the manifold, which
   // shares the first normal.  A, Bs are modified in place (the pair is done afterwards).
   SMJ_DEV void convex_multi(const int* rec, Shape& A, Shape& Bs, int slotA, int slotB, const float* pos0, const float* dir0,
-                            float margin, float tol) {
+                            float margin, float tol, const float* org) {
+    const float p0l[3] = {pos0[0] - org[0], pos0[1] - org[1], pos0[2] - org[2]};   // (the first contact in the query's local frame, narrow_pair_run)
     float fr[9] = {dir0[0], dir0[1], dir0[2], 0, 0, 0, 0, 0, 0};
     make_frame(fr);
     LANES { if (lane == 0) for (int k = 0; k < 3; k++) mcs()[0][k] = pos0[k]; }
@@ -2248,14 +2252,15 @@ struct StepKernel {
       float Rp[9], Rn[9], ca[3], cb[3], mA[9], mB[9];
       axis_angle_mat(Rp, axv, neg); axis_angle_mat(Rn, axv, !neg);
       for (int k = 0; k < 3; k++) {
-        A.pos[k] = uni(s.u.c.pos[slotA][k]); Bs.pos[k] = uni(s.u.c.pos[slotB][k]); ca[k] = uni(s.u.c.ccen[slotA][k]); cb[k] = uni(s.u.c.ccen[slotB][k]);
+        A.pos[k] = uni(s.u.c.pos[slotA][k]) - org[k]; Bs.pos[k] = uni(s.u.c.pos[slotB][k]) - org[k]; ca[k] = uni(s.u.c.ccen[slotA][k]) - org[k]; cb[k] = uni(s.u.c.ccen[slotB][k]) - org[k];
       }
       for (int k = 0; k < 9; k++) { mA[k] = uni(s.u.c.mat[slotA][k]); mB[k] = uni(s.u.c.mat[slotB][k]); }
-      rotate_point(A.pos, pos0, Rp); rotate_point(Bs.pos, pos0, Rn); rotate_point(ca, pos0, Rp); rotate_point(cb, pos0, Rn);
+      rotate_point(A.pos, p0l, Rp); rotate_point(Bs.pos, p0l, Rn); rotate_point(ca, p0l, Rp); rotate_point(cb, p0l, Rn);
       mulmat3(A.mat, Rp, mA); mulmat3(Bs.mat, Rn, mB);
       float dp, dr[3], ps[3];
       if (!mpr_penetration(A, Bs, ca, cb, dp, dr, ps)) continue;
       if (-dp > margin || dot3(dr, dr) < 0.5f) continue;
+      for (int k = 0; k < 3; k++) ps[k] += org[k];
       bool dup = false;
 #pragma nounroll
       for (int k = 0; k < n; k++) {
@@ -2396,7 +2401,8 @@ struct StepKernel {
     }
   }
   SMJ_DEV int convex_multi4(const int* rec, const Shape& A, const Shape& Bs, int slotA, int slotB, const float* pos0, const float* dir0,
-                             float margin, float tol) {
+                             float margin, float tol, const float* org) {
+    const float p0l[3] = {pos0[0] - org[0], pos0[1] - org[1], pos0[2] - org[2]};   // (the first contact in the query's local frame, narrow_pair_run)
     float fr[9] = {dir0[0], dir0[1], dir0[2], 0, 0, 0, 0, 0, 0};
     make_frame(fr);
     const float tolm = 1e-6f;
@@ -2410,9 +2416,9 @@ struct StepKernel {
       const bool neg = (q & 1) != 0;
       float Rp[9], Rn[9], ca[3], cb[3], mA[9], mB[9];
       axis_angle_mat(Rp, axv, neg); axis_angle_mat(Rn, axv, !neg);
-      for (int k = 0; k < 3; k++) { m.apos[k] = s.u.c.pos[slotA][k]; m.bpos[k] = s.u.c.pos[slotB][k]; ca[k] = s.u.c.ccen[slotA][k]; cb[k] = s.u.c.ccen[slotB][k]; }
+      for (int k = 0; k < 3; k++) { m.apos[k] = s.u.c.pos[slotA][k] - org[k]; m.bpos[k] = s.u.c.pos[slotB][k] - org[k]; ca[k] = s.u.c.ccen[slotA][k] - org[k]; cb[k] = s.u.c.ccen[slotB][k] - org[k]; }
       for (int k = 0; k < 9; k++) { mA[k] = s.u.c.mat[slotA][k]; mB[k] = s.u.c.mat[slotB][k]; }
-      rotate_point(m.apos, pos0, Rp); rotate_point(m.bpos, pos0, Rn); rotate_point(ca, pos0, Rp); rotate_point(cb, pos0, Rn);
+      rotate_point(m.apos, p0l, Rp); rotate_point(m.bpos, p0l, Rn); rotate_point(ca, p0l, Rp); rotate_point(cb, p0l, Rn);
       mulmat3(m.amat, Rp, mA); mulmat3(m.bmat, Rn, mB);
       // mpr_penetration up to its first support query
       for (int i = 0; i < 3; i++) { m.P[0].a[i] = ca[i]; m.P[0].b[i] = cb[i]; m.P[0].v[i] = ca[i] - cb[i]; }
@@ -2533,7 +2539,7 @@ struct StepKernel {
       const int l = 16 * q;
       if (!wave_read(okp, l)) continue;
       const float dp = wave_read(dpp, l);
-      const float dr[3] = {wave_read(drx, l), wave_read(dry, l), wave_read(drz, l)}, ps[3] = {wave_read(psx, l), wave_read(psy, l), wave_read(psz, l)};
+      const float dr[3] = {wave_read(drx, l), wave_read(dry, l), wave_read(drz, l)}, ps[3] = {wave_read(psx, l) + org[0], wave_read(psy, l) + org[1], wave_read(psz, l) + org[2]};
       if (-dp > margin || dot3(dr, dr) < 0.5f) continue;
       bool dup = false;
 #pragma nounroll
@@ -2675,6 +2681,17 @@ struct StepKernel {
       return;
     }
     const long long tm = prof ? smj_clock() : 0;
+    // MPR in a LOCAL frame (round 6): the interior point of the smaller of the two geoms is the origin.  A support point of the Minkowski
+    // difference is a difference of two world points; at 1.5 m from the world origin each carries 1.2e-7 m of fp32 rounding -- the scale
+    // of MPR's own 1e-6 m tolerance and of a resting body's penetration (3e-5 m) -- while the same points a few centimetres from a local
+    // origin carry 4e-9.  (The poses themselves keep the rounding kinematics gave them: an offset common to all support points of a
+    // query, not noise between them.)  The contact position goes back to world coordinates at the end; directions do not change.
+    float org[3];
+    {
+      const float ha = uni(s.u.c.half[s1][0]) + uni(s.u.c.half[s1][1]) + uni(s.u.c.half[s1][2]), hb = uni(s.u.c.half[s2][0]) + uni(s.u.c.half[s2][1]) + uni(s.u.c.half[s2][2]);
+      for (int k = 0; k < 3; k++) org[k] = SMJ_MPR_LOCAL ? (ha <= hb ? c0[k] : c1[k]) : 0.f;
+      for (int k = 0; k < 3; k++) { A.pos[k] -= org[k]; Bs.pos[k] -= org[k]; c0[k] -= org[k]; c1[k] -= org[k]; }
+    }
     float sep[3];
     bool pen = false, skipped = false;
     if (sep_hit) {   // (tag = pair + 1: a zeroed cache holds no entry)
@@ -2696,15 +2713,16 @@ struct StepKernel {
     if (prof) pc[SMJ_PROF_C_TMPR1] += (float)(smj_clock() - tm);
     if (!pen) return;
     if (-depth > margin || dot3(dir, dir) < 0.5f) return;
+    for (int k = 0; k < 3; k++) pos[k] += org[k];
     add_contact(r, -depth, pos, dir);
     if (prof) pc[SMJ_PROF_C_NHIT] += 1.f;
     if (prof && M.multiccd && A.type != GT_SPHERE && Bs.type != GT_SPHERE) pc[SMJ_PROF_C_NMULTI] += 1.f;
     if (M.multiccd && A.type != GT_SPHERE && Bs.type != GT_SPHERE) {
 #ifdef SMJ_EMUL   // the serial formulation stays in the lane emulator as the comparator of the four-wide one (tests/test_emul_parity.py)
-      if (M.multi_serial) { convex_multi(r, A, Bs, s1, s2, pos, dir, margin, 1e-3f * asf(uni(r[SMJ_CP_RBMIN]))); return; }
+      if (M.multi_serial) { convex_multi(r, A, Bs, s1, s2, pos, dir, margin, 1e-3f * asf(uni(r[SMJ_CP_RBMIN])), org); return; }
 #endif
       const long long t4 = prof ? smj_clock() : 0;
-      const int rounds = convex_multi4(r, A, Bs, s1, s2, pos, dir, margin, 1e-3f * asf(uni(r[SMJ_CP_RBMIN])));
+      const int rounds = convex_multi4(r, A, Bs, s1, s2, pos, dir, margin, 1e-3f * asf(uni(r[SMJ_CP_RBMIN])), org);
       if (prof) { pc[SMJ_PROF_C_TMULTI] += (float)(smj_clock() - t4); pc[SMJ_PROF_C_ROUNDS] += (float)rounds; }
     }
   }
@@ -2745,20 +2763,22 @@ struct StepKernel {
     // The env's second wavefront works the moving-moving pairs (collide_helper -> collision_moving) while this one works the pairs with
     // the static world: two barriers per step.  Its contacts come back in the slots NCON - 1, NCON - 2, ... and are appended here,
     // behind the static ones: the one-wavefront build's list, contact for contact.
-    if (serial_redo) {   // the second go at a step whose contact list overflowed (run()): this wavefront alone, pairs in table order
-      collision_static(nullptr, false);
-      collision_moving(nullptr, false);
-      SYNC();
-      return;
+    // (serial_redo: the second go at a step whose contact list overflowed, run() -- this wavefront alone, pairs in table order)
+    if (!serial_redo) {
+      LANES {
+        if (lane == 0) { s.mbox[0] = W2_COLLIDE; s.mbox[1] = env; s.u.c.contotal = ncon; }
+      }
+      WG_BARRIER();
+      split_on = true;
     }
-    LANES {
-      if (lane == 0) { s.mbox[0] = W2_COLLIDE; s.mbox[1] = env; s.u.c.contotal = ncon; }
-    }
-    WG_BARRIER();
-    split_on = true;
     collision_static(pc, prof);
     split_on = false;
     CTICK(SMJ_PROF_C_NARROW)
+    if (serial_redo) {
+      collision_moving(pc, prof);
+      SYNC();
+      return;
+    }
     WG_BARRIER();
     {
       const int nh = uni(s.mbox[2]);
@@ -4871,16 +4891,19 @@ struct StepKernel {
 
       collision();
       {
+        // More contacts than slots?  With two wavefronts side by side WHICH claims failed depends on their timing (that the list
+        // overflowed does not: the total is what it is), and which manifolds were kept (mcache) up to the overflow depends on the same.
+        // So the stage is run again by this wavefront alone, pairs in table order -- planes, static world, moving pairs: the truncated
+        // list is the same on every run and in the one- and two-wavefront builds -- after the env's kept manifolds have been dropped;
+        // the one-wavefront builds do the same, so that the two stay bit for bit equal through such a step (which the larger build may
+        // still finish unflagged: 57 .. 64 contacts).  Rare: <= 0.03 % of the kitchen's env-steps.  (One call site in a loop: two would
+        // inline the stage twice.)
         const int ncon_planes = ncon;
         const unsigned flags_planes = flags;
-        collision_convex(pc, prof);
-        if (((flags & ~flags_planes) & SMJ_FLAG_CON_OVERFLOW) && (SMJ_SPLIT_COLLIDE || (S.mcache && M.manifold_cache))) {
-          // More contacts than slots.  With two wavefronts side by side WHICH claims failed depends on their timing (that the list
-          // overflowed does not: the total is what it is), and which manifolds were kept (mcache) up to the overflow depends on the
-          // same.  So the stage is run again by this wavefront alone, pairs in table order -- planes, static world, moving pairs: the
-          // truncated list is the same on every run and in the one- and two-wavefront builds -- after the env's kept manifolds have
-          // been dropped; the one-wavefront builds do the same, so that the two stay bit for bit equal through such a step (which
-          // the larger build may still finish unflagged: 57 .. 64 contacts).  Rare: <= 0.03 % of the kitchen's env-steps.
+#pragma nounroll
+        for (int pass = 0; pass < 2; pass++) {
+          collision_convex(pc, prof && pass == 0);
+          if (pass || !((flags & ~flags_planes) & SMJ_FLAG_CON_OVERFLOW) || !(SMJ_SPLIT_COLLIDE || (S.mcache && M.manifold_cache))) break;
           if (S.mcache) {
             LANES { if (lane < SMJ_MC_SLOTS) S.mcache[((size_t)env * SMJ_MC_SLOTS + lane) * SMJ_MC_WORDS] = 0.f; }
           }
@@ -4888,9 +4911,8 @@ struct StepKernel {
           ncon = ncon_planes;
           flags = flags_planes;
           serial_redo = true;
-          collision_convex(nullptr, false);
-          serial_redo = false;
         }
+        serial_redo = false;
       }
       if (last) dump_contacts();
       TICK(SMJ_PROF_COLLISION)

@@ -31,7 +31,8 @@ def ctrl_schedule(model, nu, B, windows, seed):
     return [(cr[:, 0][:, None] + (cr[:, 1] - cr[:, 0])[:, None] * rng.random((nu, B))).astype(np.float32) for _ in range(windows)]
 
 
-RAW_OBJ_TOL = 0.5     # ... the same dofs when each side runs its own narrowphase: a sanity bound (contact points on curved rims are MPR's to +-7 mm)
+RAW_OBJ_TOL = 5e-3    # ... the same dofs when each side runs its own narrowphase: the same bound (round 6, MPR in a local frame; on world coordinates the contact points
+                      # of a resting cylinder came out 0.25 mm apart in fp32 and fp64 -- 3e-2 .. 2e-1 rad/s^2 on its tilt -- which was rounding, not MPR's tolerance)
 TWIN = {"manifold_keep": 1}   # oracle option: the fp64 twin of the kernels' contact-manifold cache (NOT MuJoCo; oracle/smj_oracle.c)
 
 
@@ -231,7 +232,7 @@ def explain_departures(backend, blob, model, sched, snaps_k, snaps_o, left, solv
             nk = int(post["info"][1, b])
             if r > EVENT_TOL or nk != ob.ncon:
                 ok = False
-                if nk == ob.ncon:   # (cheap, and the usual cause of an object-dof event: contact points on curved rims, state_synchronised)
+                if nk == ob.ncon:   # (cheap: an event that is gone on the kernel's own contact list belongs to the narrowphase, not to the dynamics)
                     ok, err = _same_contacts_same_dynamics(blob, solver, st, ctrl[:, b], qk, post["contacts"][:, b], nk)
                     eps = "kernel contacts" if ok else None
                 if not ok:
@@ -341,10 +342,8 @@ def state_synchronised(backend, blob, model, B, windows, seed, solver=2, oracle_
     oracles = settled_oracles(blob, B, solver, options=oracle_options, late_options=TWIN if twin else None)
     xopt = dict(oracle_options or {}, **(TWIN if twin else {}))
     rel_robot, rel_obj = [], []
-    # the DYNAMICS on identical contacts, every env-step: a second oracle per env is handed the kernel's contact list at the shared state.
-    # (Contact POINTS on curved rims are determined by MPR only to within its 1e-6 m tolerance -- a 3 cm cylinder tilted by multiccd's
-    # 1e-3 rad: +-7 mm along the rim -- so the raw accelerations of a resting 0.1 kg object scatter by 1e-2 .. 1e-1 rad/s^2 between any
-    # two implementations; with the same contacts they must agree to fp32 rounding.)
+    # the DYNAMICS on identical contacts, every env-step: a second oracle per env is handed the kernel's contact list at the shared state --
+    # separates what the narrowphase contributes to a one-step error (contact points, depths, normals in fp32) from what the solver does
     shadow = [_fresh_oracle(blob, solver, oracle_options) for _ in range(B)]
     same_robot, same_obj = [], []
     nu, nv = oracles[0].dim("nu"), oracles[0].dim("nv")
@@ -382,7 +381,7 @@ def state_synchronised(backend, blob, model, B, windows, seed, solver=2, oracle_
                     clean.append((r, rr, ro))
                 if r > EVENT_TOL or int(out["info"][1, b]) != o.ncon:
                     if max(sr, so) < EVENT_TOL and int(out["info"][1, b]) == o.ncon and rr <= EVENT_TOL:
-                        # an object-dof event with the oracle's pair list, gone on the kernel's contact list: contact-point scatter (above)
+                        # an object-dof event with the oracle's pair list, gone on the kernel's contact list: the two narrowphases' contact points differ
                         ok, err, eps = True, max(sr, so), "contact-point scatter"
                     else:
                         ok, err, eps = _bifurcation_explains(blob, solver, (st[0][:, b], st[1][:, b], st[2][:, b]), sched[w][:, b], qk, options=xopt, mc=mc)
@@ -405,13 +404,14 @@ def state_synchronised(backend, blob, model, B, windows, seed, solver=2, oracle_
 
 
 def gross_events(events):
-    """Events other than contact-point scatter (an object-dof error that is gone on the kernel's contact list, pair lists equal)."""
+    """Events other than contact-point scatter (an object-dof error that is gone on the kernel's contact list, pair lists equal: rare since the
+    narrowphase runs in a local frame)."""
     return [ev for ev in events if ev["eps"] != "contact-point scatter"]
 
 
 def assert_object_dofs(tag=""):
-    """The object-dof part of the last state_synchronised run, printed and bounded: tight on identical contacts (OBJ_TOL, every step),
-    loose on each side's own narrowphase (RAW_OBJ_TOL)."""
+    """The object-dof part of the last state_synchronised run, printed and bounded on their own scale, every step: on identical contacts
+    (OBJ_TOL) and on each side's own narrowphase (RAW_OBJ_TOL, the same value)."""
     S = state_synchronised
     pc = lambda a: f"p50 {np.percentile(a, 50):.1e} p99 {np.percentile(a, 99):.1e} max {a.max():.1e}"
     print(f"   {tag}object / fixture dofs on their own scale: own narrowphase {pc(S.rel_obj)}; on the kernel's contact list {pc(S.same_obj)} (robot dofs there: {pc(S.same_robot)})")

@@ -106,8 +106,7 @@ def _check_events(rel, events):
     clean, cr = S.clean, S.clean_robot
     print(f"   on the {len(clean)} env-steps whose contact lists agree (same pairs, normals within 0.5 deg): robot p99 {np.percentile(cr, 99):.1e} max {cr.max():.1e}")
     assert len(clean) > 0.9 * len(rel) and np.percentile(cr, 99) < rc.TYPICAL_TOL
-    # objects: tight on identical contacts (the dynamics), every step; raw (each side's own narrowphase) reported and bounded loosely -- the
-    # contact points of a cylinder standing on its rim are MPR's to within millimetres (rollout_common.state_synchronised)
+    # objects, on their own scale, every step: on identical contacts (the dynamics) and on each side's own narrowphase
     assert np.percentile(so, 99) < rc.OBJ_TOL and np.percentile(sr, 99) < rc.TYPICAL_TOL, (pc(so), pc(sr))
     assert np.percentile(ob, 99) < rc.RAW_OBJ_TOL, pc(ob)
     assert all(ev["flags"] == 0 for ev in events)
