@@ -10,7 +10,7 @@ sys.path.insert(0, ".")
 from stretch_mujoco_amd import StretchBatchSimulator  # noqa: E402
 
 
-def main(B=4096, steps=20000, scene="stretch_empty", solver="newton", options=None, capture=None, capture_z=0.35, capture_max=12):
+def main(B=4096, steps=20000, scene="stretch_empty", solver="newton", options=None, capture=None, capture_z=0.35, capture_max=12, seed=99):
     """capture: path of an .npz that receives, for the first `capture_max` envs whose base rises above capture_z, the env's state and
     ctrl at the START of the launch in which it happens and of the launch before (so the CPU oracle / the lane emulator can run the same
     100 steps: is the robot thrown by the physics or by the kernel?)."""
@@ -20,7 +20,7 @@ def main(B=4096, steps=20000, scene="stretch_empty", solver="newton", options=No
         sim.set_option(k_, v_)
     zmax_ever, zmax_at, zmax_who = -1.0, -1, ""
     dev = sim.device
-    g = torch.Generator(device=dev).manual_seed(99)
+    g = torch.Generator(device=dev).manual_seed(seed)
     lo = torch.tensor(sim.model["actuator_ctrlrange"][:, 0], dtype=torch.float32, device=dev).unsqueeze(1)
     hi = torch.tensor(sim.model["actuator_ctrlrange"][:, 1], dtype=torch.float32, device=dev).unsqueeze(1)
     t0 = time.perf_counter()
@@ -79,5 +79,6 @@ def main(B=4096, steps=20000, scene="stretch_empty", solver="newton", options=No
 
 if __name__ == "__main__":
     main(steps=int(sys.argv[1]) if len(sys.argv) > 1 else 20000, scene=sys.argv[2] if len(sys.argv) > 2 else "stretch_empty", solver=sys.argv[3] if len(sys.argv) > 3 else "newton",
-         options={a.split("=")[0]: float(a.split("=")[1]) for a in sys.argv[4:] if not a.startswith("capture=")},
+         options={a.split("=")[0]: float(a.split("=")[1]) for a in sys.argv[4:] if not a.startswith(("capture=", "seed="))},
+         seed=int(next((a.split("=", 1)[1] for a in sys.argv[4:] if a.startswith("seed=")), 99)),
          capture=next((a.split("=", 1)[1] for a in sys.argv[4:] if a.startswith("capture=")), None))

@@ -18,7 +18,7 @@ def render_summary(out):
     path = os.path.join(SRC, "rtrace", "smj_kernel_stats.csv")
     if not os.path.exists(path):
         return
-    out.append("\n## Depth / lidar kernels: `rocprofv3 --kernel-trace --stats -- python tools/gpu_render_prof.py` (kitchen stand-in, 4096 envs, both depth cameras + lidar)\n")
+    out.append("\n## Depth / lidar kernels: `rocprofv3 --kernel-trace --stats -- python tools/gpu_render_prof.py` 4096 stretch_kitchen_robocasa` (the kitchen at Robocasa scale, 4096 envs, both depth cameras + lidar; rounds 3-5: the kitchen stand-in)\n")
     out.append("A depth render of one camera = `smj_depth_prepass` (per-env staging) + `smj_fill_kernel` (z-buffer) + `smj_meshlet_kernel` (meshes and boxes rasterised, "
                "atomicMin) + `smj_depth_kernel<false, true>` (per-pixel: remaining primitives, handed-over triangles, limits); calls 1 and 3 of each are the one-off camera-static layers.\n")
     out.append("| kernel | calls | total ms | avg ms | % | min ms | max ms |\n|---|---|---|---|---|---|---|")
