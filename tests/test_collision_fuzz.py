@@ -257,3 +257,50 @@ def test_gpu_piles_of_primitives_state_synchronised(nbodies, solver):
     print(f"\npiles of {nbodies} [{solver}]: {agree} of {total} steps with equal contact / row counts; rel dqvel p50 {np.percentile(errs, 50):.1e} p90 {np.percentile(errs, 90):.1e} max {max(errs):.1e}")
     # (PGS observed: 1199 of 1200, p90 4e-6, max 1.3e-3)
     assert agree >= 0.99 * total and np.percentile(errs, 90) < 1e-4
+
+
+@pytest.mark.parametrize("shape,kind", [("cylinder", "slide"), ("box", "slide"), ("cylinder", "spin")])
+def test_kept_manifolds_on_a_slowly_sliding_or_turning_body(shape, kind):
+    """the manifold cache keeps a resting pair's manifold while both bodies stay within 2e-5 of the poses it was
+    built at and carries it to first order with their motion.  A body that creeps -- sliding down a 4 degree ramp with little
+    friction, or turning slowly about the vertical on a flat top -- is the case that exercises the carry: the kernel source (lane
+    emulator, cache on) against (i) the oracle's twin of the rule, state by state, and (ii) the UNMODIFIED oracle free-running, 300
+    steps.  The cache must actually be used, the twin must be followed to fp32 rounding, and the rule must not move the body by more
+    than 1e-5 against MuJoCo's rebuild-every-step."""
+    from emul.emul import Emul, lib
+
+    t, sz, h = SHAPES[shape]
+    tilt = 0.07 if kind == "slide" else 0.0
+    fr = "1 0.005 0.0001"      # (sticking contact: what moves the body down the ramp is the creep of the soft friction constraint, ~1e-6 m per step)
+    scene = ('<mujoco><compiler angle="radian"/>' + OPT + '<option timestep="0.002"/><worldbody>'
+             f'<geom type="box" size=".6 .5 .1" pos="0 0 0.1" euler="0 {tilt} 0" friction="{fr}"/>'
+             f'<body pos="0 0 {0.2 + h + 0.0005}" euler="0 {tilt} 0"><freejoint/><geom type="{t}" size="{sz}" mass="0.4" friction="{fr}"/></body>'
+             '</worldbody></mujoco>')
+    blob = B.dumps(F.prepare_for_kernels(C.compile_string(scene)))
+    plain, twin = Oracle(blob), Oracle(blob)
+    for o in (plain, twin):
+        o.set_option("solver", 2)
+    nq, nv = plain.dim("nq"), plain.dim("nv")
+    if kind == "spin":
+        for o in (plain, twin):
+            o.arr("qvel")[5] = 0.02          # 0.02 rad/s about z: 4e-5 rad per step -- every second step leaves the keep tolerance
+    for o in (plain, twin):
+        o.step(150)                           # come to rest on the top first (both without the rule: the same state)
+    twin.set_option("manifold_keep", 1)
+    e = Emul(blob, dict(nq=nq, nv=nv, nu=0, nlidar=0), num_envs=1, variant="standard", debug=True)
+    e.set_option("solver", 2)
+    e.set_option("manifold_cache", 1)         # (off by default for models of <= 32 dofs: a robot alone has no resting convex pair)
+    e.qpos[:, 0] = plain.arr("qpos"); e.qvel[:, 0] = plain.arr("qvel"); e.warm[:, 0] = plain.arr("qacc_warmstart")
+    hits0 = lib("standard").emul_mc_hits()
+    worst_twin = 0.0
+    for k in range(300):
+        twin.step(1); plain.step(1); e.step(1)
+        worst_twin = max(worst_twin, float(np.abs(e.qpos[:, 0] - twin.arr("qpos")).max()))
+    hits = lib("standard").emul_mc_hits() - hits0
+    d_plain = float(np.abs(e.qpos[:, 0] - plain.arr("qpos")).max())
+    d_rule = float(np.abs(twin.arr("qpos") - plain.arr("qpos")).max())
+    print(f"\n[{shape}, {kind}] kept manifolds used on {hits} of 300 steps (twin: {int(twin.iarr('mc_hits')[0])}); kernel vs twin {worst_twin:.1e}; "
+          f"kernel vs unmodified oracle {d_plain:.1e}; twin vs unmodified {d_rule:.1e}; body at {plain.arr('qpos')[:3]}")
+    assert int(e.info[3, 0]) == 0
+    assert hits > 20 and int(twin.iarr("mc_hits")[0]) > 20
+    assert worst_twin < 2e-5 and d_rule < 1e-5 and d_plain < 3e-5
