@@ -17,7 +17,8 @@
  * tools/gen_notebook_images_golden.py / gen_lidar_golden.py).  They cover the quasi-static chain (kinematics, gravity compensation,
  * actuators, equality constraints, friction loss, limits, wheel contacts, implicitfast), the camera and rangefinder models and the
  * scene geometry; fast contact dynamics, multiccd and box-box manifolds stay unpinned.  Options that are NOT MuJoCo's (default off
- * here): qcqp_cap, pgs_dual_warmstart.
+ * here): qcqp_cap, pgs_dual_warmstart, manifold_keep (round 6: the twin of the kernels' contact-manifold cache -- tests bound the kernels
+ * against it and it against the unmodified restatement, separately).
  */
 #ifndef SMJ_ORACLE_H
 #define SMJ_ORACLE_H
