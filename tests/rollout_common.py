@@ -111,8 +111,8 @@ def free_running(backend, blob, model, B, windows, seed, solver=2, band=1e-4, ke
     flags = backend.download()["info"][3].copy()
     robot = np.stack([np.maximum(np.maximum(h[0], h[1]), h[2]) for h in hist])          # [windows, B], every coordinate
     left = {b: int(np.argmax(robot[:, b] >= band)) for b in range(B) if (robot[:, b] >= band).any()}
-    departures = explain_departures(backend, blob, model, sched, snaps_k, snaps_o, left, solver, band,
-                                    oracle_options=TWIN if kernel_keeps_manifolds else None)
+    keeps = kernel_keeps_manifolds and int(np.asarray(model["dims"]).ravel()[1]) > 32   # (the kernels' default: off for a robot alone, smj_model_load.h)
+    departures = explain_departures(backend, blob, model, sched, snaps_k, snaps_o, left, solver, band, oracle_options=TWIN if keeps else None)
     return dict(base=mx(0), arm=mx(1), obj=mx(2), hist=hist, flags=flags, oracles=oracles, departures=departures)
 
 
