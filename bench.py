@@ -343,7 +343,7 @@ def shard_sizes(envs, rank, world, scaling):
     return envs, envs * world
 
 
-def measure_one(args, rank, world, hooks, scaling):
+def measure_one(args, rank, world, hooks, scaling, gather=None):
     """One measurement of the contract on this rank: settle, pre-roll, W warm-up steps, then EXACTLY K timed steps between two
     barrier + synchronize brackets, max over ranks.  Returns everything the JSON line is made of.  Device and torch.distributed come in
     through `hooks` so that the control flow (shards, brackets, max over ranks, gather, ranks_seen) runs on the CPU under gloo as well."""
@@ -422,7 +422,7 @@ def measure_one(args, rank, world, hooks, scaling):
         rep_events.append(evs)
     pick = sorted(range(reps), key=lambda i: samples[i])[reps // 2]
     dt, events = samples[pick], rep_events[pick]
-    all_returns, gather_path = hooks.gather(sim, returns)
+    all_returns, gather_path = (gather or hooks.gather)(sim, returns)
     f = sim.info[3]
     flags = int(((f & 1).max() | (f & 2).max() | (f & 4).max() | (f & 8).max()).item())   # union of the sticky overflow / bad-state / time-out bits
     flagged = float((f != 0).float().mean().item())
@@ -443,7 +443,10 @@ def measure_ranks(args, rank, world, hooks):
     m["other_scaling"] = None
     if world > 1:
         other = "weak" if args.scaling == "strong" else "strong"
-        o = measure_one(args, rank, world, hooks, other)
+        from stretch_mujoco_amd import parallel
+
+        # (the second measurement gathers through torch.distributed: the library's own RCCL communicator is brought up once per process, by the headline)
+        o = measure_one(args, rank, world, hooks, other, gather=lambda sim, r: (parallel.gather_returns(r), "torch.distributed all_gather_into_tensor"))
         o["sim"].stop()
         m["other_scaling"] = {"scaling": other, "value": o["value"], "unit": "env-steps/s", "ms_per_step": o["dt"] * 1e3 / args.steps, "envs_total": o["B_total"],
                               "envs_per_gpu": o["B"], "ranks_seen": int(o["all_returns"].numel()) // max(1, int(o["returns"].numel())),
