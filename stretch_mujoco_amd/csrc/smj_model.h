@@ -279,6 +279,9 @@ struct DevState {
   float* pgsprev;
 };
 enum { SMJ_PGSPREV_ROWS = 320, SMJ_PGSPREV_STRIDE = 2 * SMJ_PGSPREV_ROWS + 4 };
+#ifndef SMJ_PGS_GUARD
+#define SMJ_PGS_GUARD 1e-10f   // [MJ] mj_solPGS: an update whose cost change comes out above this is undone (A/B builds of tools only)
+#endif
 #ifndef SMJ_MC_LOG2
 #define SMJ_MC_LOG2 5
 #endif

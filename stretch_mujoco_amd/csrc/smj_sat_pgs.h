@@ -91,10 +91,15 @@ SMJ_DEV float pgs_block_lane(int r0, int c, float* z) {
 #pragma unroll
     for (int j = 1; j < DIM; j++) f[j] = 0;
   } else if (denom >= SMJ_MINVAL) {   // ray update
-    float x = -num * fast_rcp(denom);
-    if (f[0] + x * old[0] < 0) x = -f[0] * fast_rcp(old[0]);
+    const float x = -num * fast_rcp(denom);
+    // [MJ] a step that would take the normal force below zero ends AT the cone's apex: x = -f0 / old0 = -1 (f == old here), every
+    // component exactly 0.  Computed as f + x old with an fp32 reciprocal it left 2^-31 .. 1e-9 of the old force behind -- above
+    // mjMINVAL, so the next sweeps took neither the normal update (f0 >= MINVAL) nor the ray update (old' A old < MINVAL): the contact
+    // stayed switched off for the rest of the solve and a resting mug tilted at 4 rad/s^2 under PGS (round 6, found on the objects'
+    // own scale; the fp64 oracle's residue is 1e-19, below MINVAL).
+    const bool apex = f[0] + x * old[0] < 0;
 #pragma unroll
-    for (int r = 0; r < DIM; r++) f[r] += x * old[r];
+    for (int r = 0; r < DIM; r++) f[r] = apex ? 0.f : f[r] + x * old[r];
   }
   float bc[NF], v[NF];
 #pragma unroll
@@ -127,7 +132,7 @@ SMJ_DEV float pgs_block_lane(int r0, int c, float* z) {
     for (int q = 0; q < DIM; q++) a += At[p * DIM + q] * delta[q];
     change += delta[p] * (0.5f * a + res[p]);
   }
-  if (change > 1e-10f) return 0.f;
+  if (change > SMJ_PGS_GUARD) return 0.f;
 #pragma unroll
   for (int p = 0; p < DIM; p++) {
     const float* yp = s.sat.Js[r0 + p];
@@ -182,7 +187,7 @@ SMJ_DEV float sat_lanes_sweep(PL<float[6]>& zs, PL<int>& frozen, int iter, float
           const float fn = fminf(hi, fmaxf(lo, old - res * fast_rcp(aii)));
           float delta = fn - old;
           float change = delta * (0.5f * aii * delta + res);
-          if (change > 1e-10f) { delta = 0; change = 0; }
+          if (change > SMJ_PGS_GUARD) { delta = 0; change = 0; }
           im -= change;
           s.ef[r0] = old + delta;
           for (int k = 0; k < 6; k++) z[k] += y[k] * delta;
@@ -701,7 +706,7 @@ SMJ_DEV void pgs_sat_core(PL<float>& u, bool dbg, float* pc, long long& t0, bool
           const float fn = fminf(hi, fmaxf(lo, old - res * ainv));
           float delta = fn - old;
           float change = delta * (0.5f * aii * delta + res);
-          if (change > 1e-10f) { delta = 0; change = 0; }
+          if (change > SMJ_PGS_GUARD) { delta = 0; change = 0; }
           improvement -= change;
           PSETS(p, nD) LANES {
             r_r[p][lane] += arow[p][lane] * delta;

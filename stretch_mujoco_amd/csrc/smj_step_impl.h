@@ -3660,10 +3660,15 @@ struct StepKernel {
 #pragma unroll
       for (int j = 1; j < DIM; j++) f[j] = 0;
     } else if (denom >= SMJ_MINVAL) {  // ray update
-      float x = -num * fast_rcp(denom);
-      if (f[0] + x * old[0] < 0) x = -f[0] * fast_rcp(old[0]);
+      const float x = -num * fast_rcp(denom);
+      // [MJ] a step that would take the normal force below zero ends AT the cone's apex: x = -f0 / old0 = -1 (f == old here), every
+      // component exactly 0.  Computed as f + x old with an fp32 reciprocal it left 2^-31 .. 1e-9 of the old force behind -- above
+      // mjMINVAL, so the next sweeps took neither the normal update (f0 >= MINVAL) nor the ray update (old' A old < MINVAL): the contact
+      // stayed switched off for the rest of the solve and a resting mug tilted at 4 rad/s^2 under PGS (round 6, found on the objects'
+      // own scale; the fp64 oracle's residue is 1e-19, below MINVAL).
+      const bool apex = f[0] + x * old[0] < 0;
 #pragma unroll
-      for (int r = 0; r < DIM; r++) f[r] += x * old[r];
+      for (int r = 0; r < DIM; r++) f[r] = apex ? 0.f : f[r] + x * old[r];
     }
     // friction update with the normal fixed
     float bc[NF], v[NF];

@@ -310,7 +310,9 @@ def test_emul_pgs_satellite_build_state_synchronised(scene, variant, dual):
     _, events = rc.state_synchronised(be, blob, model, 2, 2, seed=5, solver=0, oracle_options={"pgs_dual_warmstart": dual}, twin=True)
     rel, ob, so = rc.state_synchronised.rel_robot, rc.state_synchronised.rel_obj, rc.state_synchronised.same_obj   # (the bounds below: the robot's dofs; the satellites' dofs on their own scale are printed and bounded separately)
     print(f"   satellite dofs on their own scale: own narrowphase p50 {np.percentile(ob, 50):.1e} p99 {np.percentile(ob, 99):.1e} max {ob.max():.1e}; on the kernel's contact list p50 {np.percentile(so, 50):.1e} p99 {np.percentile(so, 99):.1e} max {so.max():.1e}")
-    assert np.percentile(so, 50) < 1e-2   # (the median only, on the kernel's contact list: an object's island that PGS has not converged on either side -- 100 sweeps -- ends O(1) apart)
+    # (round 6: p99 was 4.1 / 0.3 on the objects' own scale until the ray update of the block solvers ended exactly at the cone's apex -- an fp32
+    # residue of 2^-31 of the old force left a contact switched off for the rest of the solve, smj_sat_pgs.h pgs_block_lane; observed now <= 1e-2)
+    assert np.percentile(so, 50) < 5e-3 and np.percentile(ob, 99) < 3e-2 and np.percentile(so, 99) < 3e-2
     c = rc.state_synchronised.contacts
     print(f"\n[{scene}, PGS, dual warm start {dual}] {len(rel)} env-steps: rel qacc p50 {np.percentile(rel, 50):.1e} p90 {np.percentile(rel, 90):.1e} p99 {np.percentile(rel, 99):.1e} "
           f"max {rel.max():.1e}; sweeps per step {np.mean(sweeps):.1f}; events {len(events)}; contacts {c['n']}, steps with differing pair lists {c['mismatched_steps']}")
@@ -431,7 +433,7 @@ def test_gpu_pgs_satellite_build_state_synchronised(scene):
         _, events = rc.state_synchronised(be, blob, model, 4, 4, seed=3, solver=0, oracle_options={"pgs_dual_warmstart": dual}, twin=True)
         rel, ob, so = rc.state_synchronised.rel_robot, rc.state_synchronised.rel_obj, rc.state_synchronised.same_obj   # (the bounds below: the robot's dofs)
         print(f"   satellite dofs on their own scale: own narrowphase p50 {np.percentile(ob, 50):.1e} p99 {np.percentile(ob, 99):.1e} max {ob.max():.1e}; on the kernel's contact list p50 {np.percentile(so, 50):.1e} p99 {np.percentile(so, 99):.1e} max {so.max():.1e}")
-        assert np.percentile(so, 50) < 1e-2   # (the median, on the kernel's contact list)
+        assert np.percentile(so, 50) < 5e-3 and np.percentile(ob, 99) < 3e-2 and np.percentile(so, 99) < 3e-2   # (as in the emulator's test above)
         flags = int(be.sim.info[3].max())
         be.close()
         c = rc.state_synchronised.contacts
