@@ -586,6 +586,18 @@ def test_gpu_newton_two_wavefronts_at_scale_with_contact_overflow(escalate):
     # (escalate = 1: a parked step is redone from the same state by the same large build in both sims -- those envs are not flagged and
     # are among the compared ones)
     assert bool(same[clean].all()), int((~same & clean).sum())
+    # Round 6: a step whose contact list overflows is redone by one wavefront in table order in BOTH builds (run(), smj_step_impl.h), so the
+    # flagged envs stay equal too -- the truncated list no longer depends on the two wavefronts' timing.  With escalate = 0
+    # nothing is handed over and every env must agree; with escalate = 1 the envs flagged for contacts (more than 64: nobody to hand to).
+    nfl = int(flagged.sum())
+    print(f"   flagged envs with identical states in the two builds: {int((same & flagged).sum())} of {nfl}")
+    for e in torch.nonzero(flagged & ~same).flatten().tolist()[:8]:
+        print(f"      env {e}: flags two / one wavefront {hex(int(a.info[3, e]))} / {hex(int(b.info[3, e]))}, max |dqpos| {float((a.qpos[:, e] - b.qpos[:, e]).abs().max()):.1e}, contacts {int(a.info[1, e])} / {int(b.info[1, e])}")
+    # (an env that ran out of ROWS / dense rows under escalate = 0 goes on with a truncated constraint set, which the two builds do not
+    # truncate bit for bit alike -- never claimed; the claim is about the contact list)
+    only_contacts = flagged & ((a.info[3] | b.info[3]) & ~(0x4000 | 2)).eq(0)
+    print(f"   of them flagged for contacts only: {int(only_contacts.sum())}, identical: {int((same & only_contacts).sum())}")
+    assert bool(same[only_contacts].all()), int((~same & only_contacts).sum())
     for sim in sims:
         sim.stop()
 
